@@ -1,0 +1,266 @@
+/* C-ABI of libspb_hip.so -- the MI355X (gfx950) kernels behind the KRN / DANN / SPN / styleaug hot path of
+ * tpark94/speedplusbaseline.
+ *
+ * The reference has no FFI for this path: its hot loop is ordinary torch.nn modules dispatched to cuDNN/cuBLAS
+ * (SURVEY.md F1, 8(b)).  Each entry below therefore names the torch call site it replaces (reference file:line).
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller (torch allocates; this library never allocates or frees
+ *     user-visible memory; network plans take a caller-provided workspace);
+ *   - `dtype` selects the activation storage/compute type: SPB_F32 (exact f32 MFMA, parity mode) or SPB_BF16
+ *     (bf16 storage, f32 accumulation).  Parameters, gradients, BN statistics and losses are always f32;
+ *   - activations are NHWC ([B,H,W,C], C fastest); a 1x1 convolution is the row-major GEMM [M=B*H*W, C];
+ *   - every call only ENQUEUES work on `stream` (asynchronous, graph-capturable) and returns 0 or a negative
+ *     SPB_E_* / positive hipError_t code.  Nothing throws across the boundary.
+ */
+#ifndef SPB_HIP_H
+#define SPB_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* spb_stream_t; /* hipStream_t */
+
+enum { SPB_F32 = 0, SPB_BF16 = 1 };
+enum { SPB_ACT_NONE = 0, SPB_ACT_RELU = 1, SPB_ACT_RELU6 = 2, SPB_ACT_LEAKY = 3 };
+enum { SPB_E_ARG = -1, SPB_E_SHAPE = -2, SPB_E_STATE = -3, SPB_E_UNSUPPORTED = -4 };
+
+/* A BatchNorm2d (training or eval) between a producer convolution and its consumers.  The producer's epilogue
+ * accumulates per-channel batch sums; consumers derive the affine from them in their load prologue.
+ * Replaces nn.BatchNorm2d + ReLU6/ReLU/LeakyReLU at park2019.py:48-53,65-66 and torchvision MobileNetV2 blocks. */
+typedef struct spb_bnref {
+  const float* sums;  /* training: [R][2][C] = sum(z), sum(z^2) replicas;  eval (moments=1): [2][C] = mean, var */
+  const float* gamma; /* [C]; NULL => identity (tensor already normalised/activated) */
+  const float* beta;  /* [C] */
+  const float* bsums; /* backward only: [R][2][C] = sum(g), sum(g*xhat) */
+  float inv_n;        /* 1 / (B*H*W) */
+  float eps;
+  float slope;        /* LeakyReLU negative slope */
+  int C;
+  int R;              /* number of replicas of sums/bsums (spreads atomic contention) */
+  int act;            /* SPB_ACT_* applied after the affine */
+  int moments;        /* 1: sums holds mean/var directly */
+} spb_bnref_t;
+
+/* ---- pointwise (1x1) convolution = GEMM ------------------------------------------------------------------
+ * nn.Conv2d(k=1) forward / input-gradient / weight-gradient: park2019.py:51,64; revgrad.py:76; torchvision
+ * MobileNetV2 expand/project convs (park2019.py:107-108).                                                      */
+typedef struct spb_gemm_args {
+  const void* A;     /* [M,K] input rows (fwd: raw z of the producer or a materialised tensor; bwd: g) */
+  const void* A2;    /* bwd prologue only: z with the shape of A (for xhat); NULL otherwise */
+  const void* Bw;    /* [N,K] weights, K contiguous (dgrad passes the transposed copy) */
+  void* Y;           /* [M,N] */
+  const void* res;   /* optional [M,N] tensor added before the output-side mask (residual gradient) */
+  const void* Zout;  /* epi_mode 2: raw z [M,N] of the tensor whose gradient Y is */
+  const float* bias; /* epi_mode 0: optional [N] */
+  float* osums;      /* epi_mode 1: [oR][2][N] sum(y), sum(y^2);  epi_mode 2: sum(g), sum(g*xhat) */
+  spb_bnref_t pro;   /* BN/activation applied to A while loading (pro_mode 1) or BN-backward (pro_mode 2) */
+  spb_bnref_t epi;   /* epi_mode 2: BN/activation of the output-side tensor */
+  int M, K, N;
+  int pro_mode;      /* 1: a = act(bn(A));  2: a = bn_backward(g=A, z=A2) */
+  int epi_mode;      /* 0: y = out_act(acc*out_scale + bias);  1: y = acc, accumulate batch sums;  2: g = (acc+res)*act'(bn(Zout)) */
+  int out_act;       /* epi_mode 0 */
+  int oR;
+  float out_scale;   /* epi_mode 0: y = out_act(acc*out_scale + bias); callers pass 1 for a plain product */
+} spb_gemm_args_t;
+int spb_pwconv_gemm(int dtype, const spb_gemm_args_t* args, spb_stream_t stream);
+
+/* dW[N,K] += sum_m dz[m,n] * a[m,k];  dz = bn_backward(G, Zn) (pro_dz), a = act(bn(X)) (pro_a).  dW is f32. */
+typedef struct spb_wgrad_args {
+  const void* G;  /* [M,N] */
+  const void* Zn; /* [M,N] or NULL */
+  const void* X;  /* [M,K] */
+  float* dW;      /* [N,K] f32, accumulated with atomics */
+  spb_bnref_t pro_dz;
+  spb_bnref_t pro_a;
+  int M, K, N;
+} spb_wgrad_args_t;
+int spb_pwconv_wgrad(int dtype, const spb_wgrad_args_t* args, spb_stream_t stream);
+
+/* ---- depthwise 3x3 convolution, pad 1, stride 1|2 ----------------------------------------------------------
+ * nn.Conv2d(C,C,3,groups=C): park2019.py:47 and torchvision MobileNetV2 blocks.                               */
+typedef struct spb_dw_args {
+  const void* X;     /* fwd: [B,H,W,C] input;  dgrad/wgrad: G [B,OH,OW,C] */
+  const void* X2;    /* dgrad/wgrad: z [B,OH,OW,C] of the conv output (BN backward prologue) */
+  const void* Xin;   /* wgrad: raw input [B,H,W,C] */
+  const float* Wd;   /* [C][3][3] f32 (the OIHW parameter itself) */
+  void* Y;           /* fwd: [B,OH,OW,C];  dgrad: [B,H,W,C] */
+  float* dW;         /* wgrad: [C][3][3] f32 accumulated */
+  const void* res;   /* dgrad epi 2 */
+  const void* Zout;  /* dgrad epi 2: raw z [B,H,W,C] of the input-side tensor */
+  float* osums;
+  spb_bnref_t pro;   /* fwd: BN/act of the input;  dgrad/wgrad: BN-backward of the output */
+  spb_bnref_t pro_in;/* wgrad: BN/act of the input */
+  spb_bnref_t epi;   /* dgrad epi 2 */
+  int B, H, W, C, stride;
+  int epi_mode;      /* fwd: 1;  dgrad: 0 or 2 */
+  int oR;
+} spb_dw_args_t;
+int spb_dwconv_fwd(int dtype, const spb_dw_args_t* args, spb_stream_t stream);
+int spb_dwconv_dgrad(int dtype, const spb_dw_args_t* args, spb_stream_t stream);
+int spb_dwconv_wgrad(int dtype, const spb_dw_args_t* args, spb_stream_t stream);
+
+/* ---- stem: Conv2d(3,32,3,stride 2,pad 1,bias=False) on the NCHW f32 image (torchvision features[0]) -------- */
+int spb_stem_fwd(int dtype, const float* x_nchw, const float* w /*[32][3][3][3]*/, void* y_nhwc, float* osums, int oR,
+                 int B, int H, int W, spb_stream_t stream);
+int spb_stem_wgrad(int dtype, const float* x_nchw, const void* G, const void* Z, const spb_bnref_t* pro_dz,
+                   float* dW, int B, int H, int W, spb_stream_t stream);
+
+/* ---- elementwise BN passes ---------------------------------------------------------------------------------
+ * y = act(bn(z)) + act2(bn2(res)), optionally scattered into a wider channel-concatenated tensor and/or through
+ * the RouterV2 space-to-depth "reorg" (park2019.py:74-80).                                                     */
+typedef struct spb_bnapply_args {
+  const void* Z;     /* [B,H,W,C] */
+  const void* res;   /* optional [B,H,W,C] */
+  void* Y;           /* [B,OH,OW,ldc] */
+  spb_bnref_t bn;
+  spb_bnref_t bn_res;
+  int B, H, W, C;
+  int ldc;           /* channels of the destination tensor */
+  int coff;          /* first destination channel */
+  int reorg;         /* 0: same H,W;  s>0: space-to-depth by s (out[b,h,w,coff+(i*s+j)*C+c] = in[b,h*s+i,w*s+j,c]) */
+} spb_bnapply_args_t;
+int spb_bn_apply(int dtype, const spb_bnapply_args_t* args, spb_stream_t stream);
+/* g = dY(gathered with the same mapping) * act'(bn(z)); accumulates sum(g), sum(g*xhat) into osums. */
+typedef struct spb_bnbwd_args {
+  const void* dY;    /* [B,OH,OW,ldc] */
+  const void* Z;     /* [B,H,W,C] */
+  void* G;           /* [B,H,W,C] */
+  float* osums;      /* [oR][2][C] */
+  spb_bnref_t bn;
+  int B, H, W, C, ldc, coff, reorg, oR;
+} spb_bnbwd_args_t;
+int spb_bn_bwd_prep(int dtype, const spb_bnbwd_args_t* args, spb_stream_t stream);
+
+/* ---- KRN head: Conv2d(1024,2K,7) on the 7x7 map == FC over (h,w,c) + interleaved (x,y) MSE loss -----------
+ * park2019.py:121,139-162.                                                                                     */
+typedef struct spb_head_args {
+  const void* Z;       /* [B, HW*C] raw z of the last ConvDw pointwise conv (NHWC flattened) */
+  const void* Wp;      /* [Jp, HW*C] weights permuted to (h,w,c) order in the compute dtype; rows >= J are zero */
+  const float* bias;   /* [J] */
+  const float* target; /* [B,2,J/2] or NULL */
+  float* partial;      /* [S][B][Jp] split-K partials (workspace) */
+  float* pred;         /* [B][J] */
+  float* dout;         /* [B][J] = d loss / d pred (unit upstream gradient) */
+  float* scalars;      /* [3] = loss, loss_x, loss_y */
+  spb_bnref_t pro;     /* BN+ReLU of Z; channel = k % C */
+  int B, J, Jp, HW, C, S;
+} spb_head_args_t;
+int spb_head_fwd(int dtype, const spb_head_args_t* a, spb_stream_t stream);
+typedef struct spb_head_bwd_args {
+  const void* Z;       /* as above */
+  const void* Wp;      /* as above */
+  const float* dout;   /* [B][J] */
+  void* G;             /* [B, HW*C]: g = dA * relu'(bn(z)) */
+  float* osums;        /* [oR][2][C] */
+  float* dW;           /* [J][C][HW] f32 (OIHW), accumulated */
+  float* dbias;        /* [J] accumulated */
+  spb_bnref_t pro;
+  float gscale;        /* upstream d(loss) */
+  int B, J, Jp, HW, C, oR;
+} spb_head_bwd_args_t;
+int spb_head_bwd(int dtype, const spb_head_bwd_args_t* a, spb_stream_t stream);
+
+/* ---- parameter / statistics maintenance (one launch for the whole network, table driven) ------------------ */
+typedef struct spb_bnupd_entry {
+  long long sums_off;  /* into the stats arena (floats) */
+  long long bsums_off; /* into the stats arena (floats), -1 if none */
+  long long rm_off;    /* running_mean offset in the buffer arena; running_var = rm_off + C */
+  long long gamma_off; /* parameter offsets (gamma grad / beta grad written at the same offsets of the grad arena) */
+  long long beta_off;
+  int C, R, bn_index;
+  float inv_n, unbias; /* unbias = n/(n-1) */
+} spb_bnupd_entry_t;
+/* running_mean/var momentum update + num_batches_tracked++ (nn.BatchNorm2d training side effects) */
+int spb_bn_running_update(const spb_bnupd_entry_t* table_dev, int n_bn, const float* stats, float* buffers,
+                          long long* nbt, float momentum, spb_stream_t stream);
+/* dgamma += sum(g*xhat), dbeta += sum(g) */
+int spb_bn_param_grads(const spb_bnupd_entry_t* table_dev, int n_bn, const float* stats, float* grads,
+                       spb_stream_t stream);
+/* eval mode: fill the stats arena slots with running mean/var so consumers see (mean,var) moments */
+int spb_bn_load_running(const spb_bnupd_entry_t* table_dev, int n_bn, float* stats, const float* buffers,
+                        spb_stream_t stream);
+
+typedef struct spb_prep_entry {
+  long long src_off; /* f32 parameter arena offset */
+  long long dst_off; /* element offset into the compute-dtype weight arena */
+  int rows, cols;    /* source viewed as [rows][cols] */
+  int mode;          /* 0: copy;  1: transpose -> [cols][rows];  2: head permute [J][C][HW] -> [Jp][HW][C] */
+  int aux;           /* mode 2: HW */
+  int aux2;          /* mode 2: Jp */
+  int tile0;         /* first tile index of this entry in the launch grid */
+} spb_prep_entry_t;
+int spb_weight_prep(int dtype, const spb_prep_entry_t* table_dev, int n_entries, int n_tiles, const float* params,
+                    void* wcompute, spb_stream_t stream);
+
+/* ---- optimiser: global-norm clip (trainer.py:90,97; dann.py:99) fused with the update (build.py:60-78) ----- */
+int spb_grad_sqnorm(const float* grads, long long n, float* sqnorm_out /*[1], zeroed by this call*/, spb_stream_t stream);
+typedef struct spb_optim_args {
+  float* params; float* grads; float* m; float* v; /* flat f32 arenas; m/v may be NULL for sgd w/o momentum */
+  const float* sqnorm;  /* optional device scalar: clip coefficient = min(1, max_norm/(sqrt(sqnorm)+1e-6)) */
+  const float* gmul;    /* optional device scalar multiplied into every gradient (1/world_size, 1/loss_scale) */
+  const unsigned char* mask; /* optional [n]: 1 = this element is a decayed/updated parameter (all, today) */
+  long long n;
+  int kind;             /* 0 sgd, 1 rmsprop, 2 adam, 3 adamw */
+  float lr, beta1, beta2, eps, weight_decay, max_norm, clip_value; /* max_norm<=0: no norm clip; clip_value<=0: none */
+  float bias_c1, bias_c2; /* 1-beta1^t, 1-beta2^t */
+  int first_step;       /* sgd momentum buffer initialisation */
+} spb_optim_args_t;
+int spb_optim_step(const spb_optim_args_t* a, spb_stream_t stream);
+
+/* ---- whole-network plans (C++ runtime: layer graph, workspace layout, launch sequencing) -------------------- */
+typedef struct spb_krn spb_krn_t;
+typedef struct spb_tensor_info {
+  char name[96];      /* state-dict key, e.g. "base.3.conv.1.0.weight" */
+  long long offset;   /* element offset in the f32 parameter (or buffer) arena */
+  long long numel;
+  int ndim;
+  int shape[4];
+} spb_tensor_info_t;
+
+/* KeypointRegressionNet (park2019.py:101-165).  dann=1 adds RevGrad's domain classifier (revgrad.py:58-96);
+ * parameter names then carry the "net." / "domain_classifier." prefixes of RevGrad.state_dict().               */
+int spb_krn_create(int num_keypoints, int dann, spb_krn_t** out);
+void spb_krn_destroy(spb_krn_t* m);
+int spb_krn_num_params(const spb_krn_t* m);
+int spb_krn_param_info(const spb_krn_t* m, int i, spb_tensor_info_t* out);
+int spb_krn_num_buffers(const spb_krn_t* m); /* running_mean / running_var (f32 arena) */
+int spb_krn_buffer_info(const spb_krn_t* m, int i, spb_tensor_info_t* out);
+int spb_krn_num_bn(const spb_krn_t* m);      /* num_batches_tracked entries (int64 arena, one per BN) */
+int spb_krn_bn_name(const spb_krn_t* m, int i, char* out96);
+long long spb_krn_param_numel(const spb_krn_t* m);
+long long spb_krn_buffer_numel(const spb_krn_t* m);
+long long spb_krn_wcompute_bytes(const spb_krn_t* m, int dtype);
+long long spb_krn_tables_bytes(const spb_krn_t* m);
+/* binds the arenas; tables_dev is a device scratch of spb_krn_tables_bytes() the call fills (synchronously). */
+int spb_krn_bind(spb_krn_t* m, float* params, float* grads, float* buffers, long long* nbt, void* wcompute,
+                 void* tables_dev, int dtype);
+
+typedef struct spb_krn_ctx spb_krn_ctx_t; /* activations of ONE forward pass at a fixed batch size */
+long long spb_krn_ctx_bytes(const spb_krn_t* m, int batch, int dtype);
+int spb_krn_ctx_create(spb_krn_t* m, int batch, void* workspace, spb_krn_ctx_t** out);
+void spb_krn_ctx_destroy(spb_krn_ctx_t* c);
+
+/* refresh compute-dtype weight copies (W, W^T, permuted head) from the f32 parameters */
+int spb_krn_prepare_weights(spb_krn_t* m, spb_stream_t stream);
+/* forward.  training=1: batch statistics + running-stat update.  target NULL => prediction only.
+ * pred [B][2K] f32 (interleaved x,y as the head emits them), scalars [3] = loss, loss_x, loss_y.
+ * alpha_valid=1 with a dann plan also runs the domain classifier: domain_logits [B].                           */
+int spb_krn_forward(spb_krn_ctx_t* c, const float* x_nchw, const float* target, int training, float* pred,
+                    float* scalars, float* domain_logits, spb_stream_t stream);
+/* backward of loss*gscale (+ sum_b domain_logit_grad[b]*logit[b] through the gradient-reversal layer with alpha).
+ * Accumulates into the bound grad arena (caller zeroes it, as optimizer.zero_grad does).                       */
+int spb_krn_backward(spb_krn_ctx_t* c, float gscale, int with_pose, const float* domain_logit_grad, float alpha,
+                     spb_stream_t stream);
+
+/* debug / test helpers */
+int spb_debug_trread(const unsigned short* in4096, unsigned short* out256, spb_stream_t stream);
+const char* spb_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

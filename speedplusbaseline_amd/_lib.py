@@ -1,0 +1,154 @@
+"""ctypes binding of libspb_hip.so (the C-ABI declared in include/spb_hip.h).
+
+There is deliberately no fallback: if the HIP library is missing or a symbol is absent, importing/using the ops raises.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libspb_hip.so")
+
+F32, BF16 = 0, 1
+ACT_NONE, ACT_RELU, ACT_RELU6, ACT_LEAKY = 0, 1, 2, 3
+
+vp = C.c_void_p
+fp = C.c_void_p  # float* passed as raw device address
+i32 = C.c_int
+i64 = C.c_longlong
+f32 = C.c_float
+
+
+class BNRef(C.Structure):
+    _fields_ = [("sums", vp), ("gamma", vp), ("beta", vp), ("bsums", vp), ("inv_n", f32), ("eps", f32),
+                ("slope", f32), ("C", i32), ("R", i32), ("act", i32), ("moments", i32)]
+
+
+class GemmArgs(C.Structure):
+    _fields_ = [("A", vp), ("A2", vp), ("Bw", vp), ("Y", vp), ("res", vp), ("Zout", vp), ("bias", vp), ("osums", vp),
+                ("pro", BNRef), ("epi", BNRef), ("M", i32), ("K", i32), ("N", i32), ("pro_mode", i32),
+                ("epi_mode", i32), ("out_act", i32), ("oR", i32), ("out_scale", f32)]
+
+
+class WgradArgs(C.Structure):
+    _fields_ = [("G", vp), ("Zn", vp), ("X", vp), ("dW", vp), ("pro_dz", BNRef), ("pro_a", BNRef), ("M", i32),
+                ("K", i32), ("N", i32)]
+
+
+class DwArgs(C.Structure):
+    _fields_ = [("X", vp), ("X2", vp), ("Xin", vp), ("Wd", vp), ("Y", vp), ("dW", vp), ("res", vp), ("Zout", vp),
+                ("osums", vp), ("pro", BNRef), ("pro_in", BNRef), ("epi", BNRef), ("B", i32), ("H", i32), ("W", i32),
+                ("C", i32), ("stride", i32), ("epi_mode", i32), ("oR", i32)]
+
+
+class BnApplyArgs(C.Structure):
+    _fields_ = [("Z", vp), ("res", vp), ("Y", vp), ("bn", BNRef), ("bn_res", BNRef), ("B", i32), ("H", i32),
+                ("W", i32), ("C", i32), ("ldc", i32), ("coff", i32), ("reorg", i32)]
+
+
+class BnBwdArgs(C.Structure):
+    _fields_ = [("dY", vp), ("Z", vp), ("G", vp), ("osums", vp), ("bn", BNRef), ("B", i32), ("H", i32), ("W", i32),
+                ("C", i32), ("ldc", i32), ("coff", i32), ("reorg", i32), ("oR", i32)]
+
+
+class HeadArgs(C.Structure):
+    _fields_ = [("Z", vp), ("Wp", vp), ("bias", vp), ("target", vp), ("partial", vp), ("pred", vp), ("dout", vp),
+                ("scalars", vp), ("pro", BNRef), ("B", i32), ("J", i32), ("Jp", i32), ("HW", i32), ("C", i32),
+                ("S", i32)]
+
+
+class HeadBwdArgs(C.Structure):
+    _fields_ = [("Z", vp), ("Wp", vp), ("dout", vp), ("G", vp), ("osums", vp), ("dW", vp), ("dbias", vp),
+                ("pro", BNRef), ("gscale", f32), ("B", i32), ("J", i32), ("Jp", i32), ("HW", i32), ("C", i32),
+                ("oR", i32)]
+
+
+class BnUpdEntry(C.Structure):
+    _fields_ = [("sums_off", i64), ("bsums_off", i64), ("rm_off", i64), ("gamma_off", i64), ("beta_off", i64),
+                ("C", i32), ("R", i32), ("bn_index", i32), ("inv_n", f32), ("unbias", f32)]
+
+
+class PrepEntry(C.Structure):
+    _fields_ = [("src_off", i64), ("dst_off", i64), ("rows", i32), ("cols", i32), ("mode", i32), ("aux", i32),
+                ("aux2", i32), ("tile0", i32)]
+
+
+class OptimArgs(C.Structure):
+    _fields_ = [("params", vp), ("grads", vp), ("m", vp), ("v", vp), ("sqnorm", vp), ("gmul", vp), ("mask", vp),
+                ("n", i64), ("kind", i32), ("lr", f32), ("beta1", f32), ("beta2", f32), ("eps", f32),
+                ("weight_decay", f32), ("max_norm", f32), ("clip_value", f32), ("bias_c1", f32), ("bias_c2", f32),
+                ("first_step", i32)]
+
+
+class TensorInfo(C.Structure):
+    _fields_ = [("name", C.c_char * 96), ("offset", i64), ("numel", i64), ("ndim", i32), ("shape", i32 * 4)]
+
+
+# every symbol include/spb_hip.h declares: name -> (restype, argtypes)
+SYMBOLS = {
+    "spb_pwconv_gemm": (i32, [i32, C.POINTER(GemmArgs), vp]),
+    "spb_pwconv_wgrad": (i32, [i32, C.POINTER(WgradArgs), vp]),
+    "spb_dwconv_fwd": (i32, [i32, C.POINTER(DwArgs), vp]),
+    "spb_dwconv_dgrad": (i32, [i32, C.POINTER(DwArgs), vp]),
+    "spb_dwconv_wgrad": (i32, [i32, C.POINTER(DwArgs), vp]),
+    "spb_stem_fwd": (i32, [i32, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
+    "spb_stem_wgrad": (i32, [i32, vp, vp, vp, C.POINTER(BNRef), vp, i32, i32, i32, vp]),
+    "spb_bn_apply": (i32, [i32, C.POINTER(BnApplyArgs), vp]),
+    "spb_bn_bwd_prep": (i32, [i32, C.POINTER(BnBwdArgs), vp]),
+    "spb_head_fwd": (i32, [i32, C.POINTER(HeadArgs), vp]),
+    "spb_head_bwd": (i32, [i32, C.POINTER(HeadBwdArgs), vp]),
+    "spb_bn_running_update": (i32, [vp, i32, vp, vp, vp, f32, vp]),
+    "spb_bn_param_grads": (i32, [vp, i32, vp, vp, vp]),
+    "spb_bn_load_running": (i32, [vp, i32, vp, vp, vp]),
+    "spb_weight_prep": (i32, [i32, vp, i32, i32, vp, vp, vp]),
+    "spb_grad_sqnorm": (i32, [vp, i64, vp, vp]),
+    "spb_optim_step": (i32, [C.POINTER(OptimArgs), vp]),
+    "spb_krn_create": (i32, [i32, i32, C.POINTER(vp)]),
+    "spb_krn_destroy": (None, [vp]),
+    "spb_krn_num_params": (i32, [vp]),
+    "spb_krn_param_info": (i32, [vp, i32, C.POINTER(TensorInfo)]),
+    "spb_krn_num_buffers": (i32, [vp]),
+    "spb_krn_buffer_info": (i32, [vp, i32, C.POINTER(TensorInfo)]),
+    "spb_krn_num_bn": (i32, [vp]),
+    "spb_krn_bn_name": (i32, [vp, i32, C.c_char_p]),
+    "spb_krn_param_numel": (i64, [vp]),
+    "spb_krn_buffer_numel": (i64, [vp]),
+    "spb_krn_wcompute_bytes": (i64, [vp, i32]),
+    "spb_krn_tables_bytes": (i64, [vp]),
+    "spb_krn_bind": (i32, [vp, vp, vp, vp, vp, vp, vp, i32]),
+    "spb_krn_ctx_bytes": (i64, [vp, i32, i32]),
+    "spb_krn_ctx_create": (i32, [vp, i32, vp, C.POINTER(vp)]),
+    "spb_krn_ctx_destroy": (None, [vp]),
+    "spb_krn_prepare_weights": (i32, [vp, vp]),
+    "spb_krn_forward": (i32, [vp, vp, vp, i32, vp, vp, vp, vp]),
+    "spb_krn_backward": (i32, [vp, f32, i32, vp, f32, vp]),
+    "spb_debug_trread": (i32, [vp, vp, vp]),
+    "spb_version": (C.c_char_p, []),
+}
+
+_lib = None
+
+
+def lib():
+    """Load the HIP library (built in-tree by speedplusbaseline_amd/build.py). No fallback exists."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "libspb_hip.so is missing (%s). Build it with `python -m speedplusbaseline_amd.build`; this package "
+                "has no CPU or PyTorch fallback for the hot path." % LIB_PATH)
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(l, name)  # AttributeError if the symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+class SpbError(RuntimeError):
+    pass
+
+
+def check(code, what):
+    if code != 0:
+        raise SpbError("%s failed with code %d" % (what, code))

@@ -1,0 +1,75 @@
+"""In-tree build of libspb_hip.so (hipcc, gfx950 only).
+
+The shared object is git-ignored but travels with the repo snapshot to the GPU box; nothing is JIT-compiled at
+run time and there is no non-HIP code path behind it.
+"""
+import hashlib
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+ROOT = os.path.dirname(HERE)
+LIB = os.path.join(HERE, "libspb_hip.so")
+OBJDIR = os.path.join(HERE, "csrc", "_obj")
+SOURCES = ["gemm_pw.hip", "dwconv.hip", "stem_head.hip", "elemwise.hip", "krn_plan.hip"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result", "-Wno-unused-value"]
+
+
+def _hipcc():
+    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
+            return c
+    raise RuntimeError("hipcc not found")
+
+
+def _digest(paths):
+    h = hashlib.sha256()
+    for p in paths:
+        with open(p, "rb") as f:
+            h.update(f.read())
+    h.update(" ".join(FLAGS).encode())
+    return h.hexdigest()
+
+
+def build(force=False, verbose=True):
+    os.makedirs(OBJDIR, exist_ok=True)
+    headers = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(".h")]
+    headers.append(os.path.join(ROOT, "include", "spb_hip.h"))
+    srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+    stamp = os.path.join(OBJDIR, "stamp.txt")
+    want = _digest(srcs + headers)
+    if not force and os.path.exists(LIB) and os.path.exists(stamp) and open(stamp).read().strip() == want:
+        return LIB
+    hipcc = _hipcc()
+
+    def compile_one(src):
+        obj = os.path.join(OBJDIR, os.path.basename(src) + ".o")
+        dig = os.path.join(OBJDIR, os.path.basename(src) + ".sha")
+        d = _digest([src] + headers)
+        if not force and os.path.exists(obj) and os.path.exists(dig) and open(dig).read().strip() == d:
+            return obj
+        cmd = [hipcc] + FLAGS + ["-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+        with open(dig, "w") as f:
+            f.write(d)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        objs = list(ex.map(compile_one, srcs))
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    with open(stamp, "w") as f:
+        f.write(want)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)
+    print(LIB)

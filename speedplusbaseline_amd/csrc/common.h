@@ -1,0 +1,148 @@
+// Shared device helpers for the gfx950 (MI355X / CDNA4) kernels of the KRN/SPN/DANN hot path.
+// Everything here is written for wave64 + MFMA; there is no other target.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/spb_hip.h"
+
+typedef unsigned short bf16_t;  // raw bfloat16 bits; activations in HBM are bf16 (or float in parity mode)
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+
+#define SPB_WAVE 64
+
+#define SPB_CHECK_LAUNCH()                                  \
+  do {                                                      \
+    hipError_t e__ = hipGetLastError();                     \
+    if (e__ != hipSuccess) return (int)e__;                 \
+  } while (0)
+
+// ---------------------------------------------------------------------------------------------
+// scalar conversions
+__device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f) {  // round-to-nearest-even, NaN preserved
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (bf16_t)(u >> 16);
+}
+template <typename T> __device__ __forceinline__ float to_f(T v);
+template <> __device__ __forceinline__ float to_f<float>(float v) { return v; }
+template <> __device__ __forceinline__ float to_f<bf16_t>(bf16_t v) { return bf2f(v); }
+template <typename T> __device__ __forceinline__ T from_f(float v);
+template <> __device__ __forceinline__ float from_f<float>(float v) { return v; }
+template <> __device__ __forceinline__ bf16_t from_f<bf16_t>(float v) { return f2bf(v); }
+// value after a round trip through the storage type (what a consumer will read back)
+template <typename T> __device__ __forceinline__ float rnd(float v) { return to_f<T>(from_f<T>(v)); }
+
+// ---------------------------------------------------------------------------------------------
+// 8-element vector access (16 B for bf16, 2x16 B for float).  p must be 16-byte aligned.
+template <typename T> __device__ __forceinline__ void ld8(const T* p, float v[8]);
+template <> __device__ __forceinline__ void ld8<float>(const float* p, float v[8]) {
+  const float4 a = *reinterpret_cast<const float4*>(p);
+  const float4 b = *reinterpret_cast<const float4*>(p + 4);
+  v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+template <> __device__ __forceinline__ void ld8<bf16_t>(const bf16_t* p, float v[8]) {
+  const uint4 u = *reinterpret_cast<const uint4*>(p);
+  v[0] = __uint_as_float(u.x << 16); v[1] = __uint_as_float(u.x & 0xffff0000u);
+  v[2] = __uint_as_float(u.y << 16); v[3] = __uint_as_float(u.y & 0xffff0000u);
+  v[4] = __uint_as_float(u.z << 16); v[5] = __uint_as_float(u.z & 0xffff0000u);
+  v[6] = __uint_as_float(u.w << 16); v[7] = __uint_as_float(u.w & 0xffff0000u);
+}
+template <typename T> __device__ __forceinline__ void st8(T* p, const float v[8]);
+template <> __device__ __forceinline__ void st8<float>(float* p, const float v[8]) {
+  *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+  *reinterpret_cast<float4*>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
+}
+template <> __device__ __forceinline__ void st8<bf16_t>(bf16_t* p, const float v[8]) {
+  uint4 u;
+  u.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
+  u.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+  u.z = (uint32_t)f2bf(v[4]) | ((uint32_t)f2bf(v[5]) << 16);
+  u.w = (uint32_t)f2bf(v[6]) | ((uint32_t)f2bf(v[7]) << 16);
+  *reinterpret_cast<uint4*>(p) = u;
+}
+template <typename T> __device__ __forceinline__ void rnd8(float v[8]) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) v[i] = rnd<T>(v[i]);
+}
+
+// ---------------------------------------------------------------------------------------------
+// activations (codes are SPB_ACT_* in the public header)
+__device__ __forceinline__ float act_fwd(float u, int act, float slope) {
+  if (act == SPB_ACT_RELU) return fmaxf(u, 0.f);
+  if (act == SPB_ACT_RELU6) return fminf(fmaxf(u, 0.f), 6.f);
+  if (act == SPB_ACT_LEAKY) return u > 0.f ? u : u * slope;
+  return u;
+}
+__device__ __forceinline__ float act_grad(float u, int act, float slope) {
+  if (act == SPB_ACT_RELU) return u > 0.f ? 1.f : 0.f;
+  if (act == SPB_ACT_RELU6) return (u > 0.f && u < 6.f) ? 1.f : 0.f;
+  if (act == SPB_ACT_LEAKY) return u > 0.f ? 1.f : slope;
+  return 1.f;
+}
+
+// ---------------------------------------------------------------------------------------------
+// BatchNorm reference (spb_bnref_t in the public header).  A consumer derives the per-channel affine
+// itself from the raw batch sums the producer's epilogue accumulated, so no "finalize" launch sits
+// between a convolution and the next one.
+typedef spb_bnref_t BNRef;
+
+// mean / inverse std of channel c
+__device__ __forceinline__ void bn_moments(const BNRef& r, int c, float& mean, float& invstd) {
+  if (r.moments) {  // eval: sums holds [mean | var]
+    mean = r.sums[c];
+    invstd = rsqrtf(r.sums[r.C + c] + r.eps);
+    return;
+  }
+  float s = 0.f, q = 0.f;
+  for (int i = 0; i < r.R; ++i) {
+    s += r.sums[(size_t)i * 2 * r.C + c];
+    q += r.sums[(size_t)i * 2 * r.C + r.C + c];
+  }
+  mean = s * r.inv_n;
+  float var = fmaxf(q * r.inv_n - mean * mean, 0.f);
+  invstd = rsqrtf(var + r.eps);
+}
+// forward affine: a = act(z*scale + shift)
+__device__ __forceinline__ void bn_fwd_coef(const BNRef& r, int c, float& scale, float& shift) {
+  if (r.gamma == nullptr) { scale = 1.f; shift = 0.f; return; }
+  float mean, is;
+  bn_moments(r, c, mean, is);
+  scale = r.gamma[c] * is;
+  shift = r.beta[c] - mean * scale;
+}
+// backward: dz = g*p0 + z*p1 + p2   (training-mode BN input gradient; g = dL/d(BN output))
+__device__ __forceinline__ void bn_bwd_coef(const BNRef& r, int c, float& p0, float& p1, float& p2) {
+  if (r.gamma == nullptr) { p0 = 1.f; p1 = 0.f; p2 = 0.f; return; }
+  float mean, is;
+  bn_moments(r, c, mean, is);
+  float s1 = 0.f, s2 = 0.f;
+  for (int i = 0; i < r.R; ++i) {
+    s1 += r.bsums[(size_t)i * 2 * r.C + c];
+    s2 += r.bsums[(size_t)i * 2 * r.C + r.C + c];
+  }
+  s1 *= r.inv_n; s2 *= r.inv_n;
+  p0 = r.gamma[c] * is;
+  p1 = -p0 * is * s2;
+  p2 = p0 * (mean * is * s2 - s1);
+}
+
+// ---------------------------------------------------------------------------------------------
+// wave64 reductions via DPP-lowered shuffles
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// XCD-aware remap of a linear workgroup id: the dispatcher places block b on XCD b%8, so give
+// each XCD a contiguous chunk of the logical id space (neighbouring tiles then share one L2).
+__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
+  if (nblk & 7) return bid;
+  return (bid & 7) * (nblk >> 3) + (bid >> 3);
+}
+
+static inline int spb_ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }

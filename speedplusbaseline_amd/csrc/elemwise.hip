@@ -1,0 +1,353 @@
+// Streaming (HBM-bound) passes around the convolutions:
+//   * bn_apply / bn_bwd_prep : materialise act(bn(z)) (+ residual, concat, RouterV2 reorg) and its backward
+//       (MobileNetV2 residual adds; reference park2019.py:74-80 reorg + cat)
+//   * table-driven whole-network maintenance: BN running statistics, BN parameter gradients, compute-dtype weight
+//       copies (bf16 W, W^T, permuted head weight)
+//   * global-norm clip + optimiser update fused over the flat parameter arena
+//       (reference trainer.py:90,97  clip_grad_norm_; build.py:60-78 sgd/rmsprop/adam/adamw)
+#include "common.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------ bn_apply
+template <typename T>
+__global__ __launch_bounds__(256) void bn_apply_kernel(const spb_bnapply_args_t a) {
+  extern __shared__ float cf[];  // [4][C]: scale, shift, res scale, res shift
+  const int C = a.C, CG = C >> 3;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    bn_fwd_coef(a.bn, c, cf[c], cf[C + c]);
+    if (a.res) bn_fwd_coef(a.bn_res, c, cf[2 * C + c], cf[3 * C + c]);
+  }
+  __syncthreads();
+  const T* Z = reinterpret_cast<const T*>(a.Z);
+  const T* R = reinterpret_cast<const T*>(a.res);
+  T* Y = reinterpret_cast<T*>(a.Y);
+  const long long items = (long long)a.B * a.H * a.W * CG;
+  const int s = a.reorg;
+  for (long long it = (long long)blockIdx.x * 256 + threadIdx.x; it < items; it += (long long)gridDim.x * 256) {
+    const int cg = (int)(it % CG);
+    const long long p = it / CG;
+    const int c0 = cg * 8;
+    float v[8];
+    ld8<T>(Z + (size_t)p * C + c0, v);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = act_fwd(v[j] * cf[c0 + j] + cf[C + c0 + j], a.bn.act, a.bn.slope);
+    if (R) {
+      float r[8];
+      ld8<T>(R + (size_t)p * C + c0, r);
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        v[j] += act_fwd(r[j] * cf[2 * C + c0 + j] + cf[3 * C + c0 + j], a.bn_res.act, a.bn_res.slope);
+    }
+    size_t o;
+    if (s > 0) {
+      const int w = (int)(p % a.W), h = (int)((p / a.W) % a.H), b = (int)(p / ((long long)a.W * a.H));
+      const int OH = a.H / s, OW = a.W / s;
+      o = ((size_t)(b * OH + h / s) * OW + w / s) * a.ldc + a.coff + ((h % s) * s + (w % s)) * C + c0;
+    } else {
+      o = (size_t)p * a.ldc + a.coff + c0;
+    }
+    st8<T>(Y + o, v);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ bn_bwd_prep
+// thread keeps a fixed channel group (grid size is a multiple of CG/gcd(CG,256)) so sums stay in registers
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_prep_kernel(const spb_bnbwd_args_t a) {
+  extern __shared__ float cf[];  // [4][C] scale, shift, mean, invstd ; then [2][C] reduction
+  const int C = a.C, CG = C >> 3;
+  float* red = cf + 4 * C;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float mu = 0.f, is = 0.f, sc = 1.f, sh = 0.f;
+    if (a.bn.gamma) {
+      bn_moments(a.bn, c, mu, is);
+      sc = a.bn.gamma[c] * is;
+      sh = a.bn.beta[c] - mu * sc;
+    }
+    cf[c] = sc; cf[C + c] = sh; cf[2 * C + c] = mu; cf[3 * C + c] = is;
+    red[c] = 0.f; red[C + c] = 0.f;
+  }
+  __syncthreads();
+  const T* dY = reinterpret_cast<const T*>(a.dY);
+  const T* Z = reinterpret_cast<const T*>(a.Z);
+  T* G = reinterpret_cast<T*>(a.G);
+  const long long items = (long long)a.B * a.H * a.W * CG;
+  const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+  const int cg = (int)(gid % CG), c0 = cg * 8;
+  const int s = a.reorg;
+  float s1[8], s2[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
+  for (long long it = gid; it < items; it += (long long)gridDim.x * 256) {
+    const long long p = it / CG;
+    size_t o;
+    if (s > 0) {
+      const int w = (int)(p % a.W), h = (int)((p / a.W) % a.H), b = (int)(p / ((long long)a.W * a.H));
+      const int OH = a.H / s, OW = a.W / s;
+      o = ((size_t)(b * OH + h / s) * OW + w / s) * a.ldc + a.coff + ((h % s) * s + (w % s)) * C + c0;
+    } else {
+      o = (size_t)p * a.ldc + a.coff + c0;
+    }
+    float d[8], z[8];
+    ld8<T>(dY + o, d);
+    ld8<T>(Z + (size_t)p * C + c0, z);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float u = z[j] * cf[c0 + j] + cf[C + c0 + j];
+      d[j] = rnd<T>(d[j] * act_grad(u, a.bn.act, a.bn.slope));
+      s1[j] += d[j];
+      s2[j] += d[j] * ((z[j] - cf[2 * C + c0 + j]) * cf[3 * C + c0 + j]);
+    }
+    st8<T>(G + (size_t)p * C + c0, d);
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    atomicAdd(&red[c0 + j], s1[j]);
+    atomicAdd(&red[C + c0 + j], s2[j]);
+  }
+  __syncthreads();
+  const int rep = blockIdx.x % a.oR;
+  for (int i = threadIdx.x; i < 2 * C; i += 256) atomicAdd(a.osums + (size_t)rep * 2 * C + i, red[i]);
+}
+
+// ------------------------------------------------------------------------------------------------ BN tables
+__global__ __launch_bounds__(256) void bn_running_update_kernel(const spb_bnupd_entry_t* tab, const float* stats,
+                                                                float* buffers, long long* nbt, float momentum) {
+  const spb_bnupd_entry_t e = tab[blockIdx.x];
+  for (int c = threadIdx.x; c < e.C; c += 256) {
+    float s = 0.f, q = 0.f;
+    for (int r = 0; r < e.R; ++r) {
+      s += stats[e.sums_off + (size_t)r * 2 * e.C + c];
+      q += stats[e.sums_off + (size_t)r * 2 * e.C + e.C + c];
+    }
+    const float mean = s * e.inv_n;
+    const float var = fmaxf(q * e.inv_n - mean * mean, 0.f);
+    float* rm = buffers + e.rm_off;
+    rm[c] = (1.f - momentum) * rm[c] + momentum * mean;
+    rm[e.C + c] = (1.f - momentum) * rm[e.C + c] + momentum * var * e.unbias;
+  }
+  if (threadIdx.x == 0 && nbt) nbt[e.bn_index] += 1;
+}
+
+__global__ __launch_bounds__(256) void bn_param_grads_kernel(const spb_bnupd_entry_t* tab, const float* stats,
+                                                             float* grads) {
+  const spb_bnupd_entry_t e = tab[blockIdx.x];
+  if (e.bsums_off < 0) return;
+  for (int c = threadIdx.x; c < e.C; c += 256) {
+    float s1 = 0.f, s2 = 0.f;
+    for (int r = 0; r < e.R; ++r) {
+      s1 += stats[e.bsums_off + (size_t)r * 2 * e.C + c];
+      s2 += stats[e.bsums_off + (size_t)r * 2 * e.C + e.C + c];
+    }
+    grads[e.gamma_off + c] += s2;
+    grads[e.beta_off + c] += s1;
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_load_running_kernel(const spb_bnupd_entry_t* tab, float* stats,
+                                                              const float* buffers) {
+  const spb_bnupd_entry_t e = tab[blockIdx.x];
+  for (int c = threadIdx.x; c < 2 * e.C; c += 256) stats[e.sums_off + c] = buffers[e.rm_off + c];
+}
+
+// ------------------------------------------------------------------------------------------------ weight prep
+template <typename T>
+__global__ __launch_bounds__(256) void weight_prep_kernel(const spb_prep_entry_t* tab, int n_entries,
+                                                          const float* params, T* wc) {
+  __shared__ float tile[32][33];
+  int ei = 0;
+  for (int i = 1; i < n_entries; ++i)
+    if ((int)blockIdx.x >= tab[i].tile0) ei = i;
+  const spb_prep_entry_t e = tab[ei];
+  int tl = blockIdx.x - e.tile0;
+  int rows = e.rows, cols = e.cols;
+  const float* src = params + e.src_off;
+  T* dst = wc + e.dst_off;
+  size_t dbase = 0;
+  if (e.mode == 2) {  // per-j [C][HW] -> [HW][C]
+    const int tx_n = (cols + 31) / 32, ty_n = (rows + 31) / 32;
+    const int j = tl / (tx_n * ty_n);
+    tl -= j * tx_n * ty_n;
+    src += (size_t)j * rows * cols;
+    dbase = (size_t)j * rows * cols;
+  }
+  const int tx_n = (cols + 31) / 32;
+  const int r0 = (tl / tx_n) * 32, c0 = (tl % tx_n) * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = r0 + ty + 8 * i, c = c0 + tx;
+    tile[ty + 8 * i][tx] = (r < rows && c < cols) ? src[(size_t)r * cols + c] : 0.f;
+  }
+  __syncthreads();
+  if (e.mode == 0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = r0 + ty + 8 * i, c = c0 + tx;
+      if (r < rows && c < cols) dst[(size_t)r * cols + c] = from_f<T>(tile[ty + 8 * i][tx]);
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c = c0 + ty + 8 * i, r = r0 + tx;  // destination row = source column
+      if (r < rows && c < cols) dst[dbase + (size_t)c * rows + r] = from_f<T>(tile[tx][ty + 8 * i]);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ optimiser
+__global__ __launch_bounds__(256) void grad_sqnorm_kernel(const float* __restrict__ g, long long n, float* out) {
+  __shared__ float red[4];
+  float s = 0.f;
+  const long long n4 = n >> 2;
+  const float4* g4 = reinterpret_cast<const float4*>(g);
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+    const float4 v = g4[i];
+    s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) { const float v = g[(n4 << 2) + threadIdx.x]; s += v * v; }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(256) void optim_step_kernel(const spb_optim_args_t a) {
+  float gm = a.gmul ? *a.gmul : 1.f;
+  float coef = 1.f;
+  if (a.max_norm > 0.f && a.sqnorm) {
+    const float tn = sqrtf(*a.sqnorm) * fabsf(gm);
+    coef = fminf(a.max_norm / (tn + 1e-6f), 1.f);
+  }
+  const float gs = gm * coef;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < a.n; i += (long long)gridDim.x * 256) {
+    float p = a.params[i];
+    float g = a.grads[i] * gs;
+    if (a.clip_value > 0.f) g = fminf(fmaxf(g, -a.clip_value), a.clip_value);
+    if (a.kind == 3) {  // adamw (decoupled decay)
+      p *= 1.f - a.lr * a.weight_decay;
+      const float m = a.beta1 * a.m[i] + (1.f - a.beta1) * g;
+      const float v = a.beta2 * a.v[i] + (1.f - a.beta2) * g * g;
+      a.m[i] = m; a.v[i] = v;
+      const float denom = sqrtf(v) / sqrtf(a.bias_c2) + a.eps;
+      p -= (a.lr / a.bias_c1) * (m / denom);
+    } else if (a.kind == 2) {  // adam (L2 folded into the gradient)
+      g += a.weight_decay * p;
+      const float m = a.beta1 * a.m[i] + (1.f - a.beta1) * g;
+      const float v = a.beta2 * a.v[i] + (1.f - a.beta2) * g * g;
+      a.m[i] = m; a.v[i] = v;
+      const float denom = sqrtf(v) / sqrtf(a.bias_c2) + a.eps;
+      p -= (a.lr / a.bias_c1) * (m / denom);
+    } else if (a.kind == 1) {  // rmsprop (alpha = beta2 slot), no momentum, not centred
+      g += a.weight_decay * p;
+      const float v = a.beta2 * a.v[i] + (1.f - a.beta2) * g * g;
+      a.v[i] = v;
+      p -= a.lr * g / (sqrtf(v) + a.eps);
+    } else {  // sgd with momentum (beta1), dampening 0
+      g += a.weight_decay * p;
+      if (a.beta1 != 0.f && a.m) {
+        const float b = a.first_step ? g : a.beta1 * a.m[i] + g;
+        a.m[i] = b;
+        g = b;
+      }
+      p -= a.lr * g;
+    }
+    a.params[i] = p;
+  }
+}
+
+int elem_grid(long long items) {
+  long long g = (items + 255) / 256;
+  if (g > 2048) g = 2048;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+int gcd_i(int a, int b) { while (b) { int t = a % b; a = b; b = t; } return a; }
+
+}  // namespace
+
+extern "C" int spb_bn_apply(int dtype, const spb_bnapply_args_t* a, spb_stream_t stream) {
+  if (!a || !a->Z || !a->Y) return SPB_E_ARG;
+  if (a->C <= 0 || (a->C & 7) || (a->ldc & 7) || (a->coff & 7)) return SPB_E_SHAPE;
+  if (a->reorg > 0 && ((a->H % a->reorg) || (a->W % a->reorg))) return SPB_E_SHAPE;
+  const long long items = (long long)a->B * a->H * a->W * (a->C >> 3);
+  const size_t lds = (size_t)4 * a->C * sizeof(float);
+  if (dtype == SPB_BF16) hipLaunchKernelGGL(bn_apply_kernel<bf16_t>, dim3(elem_grid(items)), dim3(256), lds, (hipStream_t)stream, *a);
+  else if (dtype == SPB_F32) hipLaunchKernelGGL(bn_apply_kernel<float>, dim3(elem_grid(items)), dim3(256), lds, (hipStream_t)stream, *a);
+  else return SPB_E_ARG;
+  SPB_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int spb_bn_bwd_prep(int dtype, const spb_bnbwd_args_t* a, spb_stream_t stream) {
+  if (!a || !a->dY || !a->Z || !a->G || !a->osums || a->oR < 1) return SPB_E_ARG;
+  if (a->C <= 0 || (a->C & 7) || (a->ldc & 7) || (a->coff & 7)) return SPB_E_SHAPE;
+  if (a->reorg > 0 && ((a->H % a->reorg) || (a->W % a->reorg))) return SPB_E_SHAPE;
+  const int CG = a->C >> 3;
+  const long long items = (long long)a->B * a->H * a->W * CG;
+  const int unit = CG / gcd_i(CG, 256);
+  long long want = (items + 256 * 8 - 1) / (256 * 8);
+  if (want > 256) want = 256;
+  int grid = (int)((want + unit - 1) / unit) * unit;
+  if (grid < unit) grid = unit;
+  const size_t lds = (size_t)6 * a->C * sizeof(float);
+  if (dtype == SPB_BF16) hipLaunchKernelGGL(bn_bwd_prep_kernel<bf16_t>, dim3(grid), dim3(256), lds, (hipStream_t)stream, *a);
+  else if (dtype == SPB_F32) hipLaunchKernelGGL(bn_bwd_prep_kernel<float>, dim3(grid), dim3(256), lds, (hipStream_t)stream, *a);
+  else return SPB_E_ARG;
+  SPB_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int spb_bn_running_update(const spb_bnupd_entry_t* tab, int n_bn, const float* stats, float* buffers,
+                                     long long* nbt, float momentum, spb_stream_t stream) {
+  if (!tab || !stats || !buffers || n_bn <= 0) return SPB_E_ARG;
+  hipLaunchKernelGGL(bn_running_update_kernel, dim3(n_bn), dim3(256), 0, (hipStream_t)stream, tab, stats, buffers, nbt, momentum);
+  SPB_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int spb_bn_param_grads(const spb_bnupd_entry_t* tab, int n_bn, const float* stats, float* grads,
+                                  spb_stream_t stream) {
+  if (!tab || !stats || !grads || n_bn <= 0) return SPB_E_ARG;
+  hipLaunchKernelGGL(bn_param_grads_kernel, dim3(n_bn), dim3(256), 0, (hipStream_t)stream, tab, stats, grads);
+  SPB_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int spb_bn_load_running(const spb_bnupd_entry_t* tab, int n_bn, float* stats, const float* buffers,
+                                   spb_stream_t stream) {
+  if (!tab || !stats || !buffers || n_bn <= 0) return SPB_E_ARG;
+  hipLaunchKernelGGL(bn_load_running_kernel, dim3(n_bn), dim3(256), 0, (hipStream_t)stream, tab, stats, buffers);
+  SPB_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int spb_weight_prep(int dtype, const spb_prep_entry_t* tab, int n_entries, int n_tiles, const float* params,
+                               void* wc, spb_stream_t stream) {
+  if (!tab || !params || !wc || n_entries <= 0 || n_tiles <= 0) return SPB_E_ARG;
+  if (dtype == SPB_BF16) hipLaunchKernelGGL(weight_prep_kernel<bf16_t>, dim3(n_tiles), dim3(256), 0, (hipStream_t)stream, tab, n_entries, params, (bf16_t*)wc);
+  else if (dtype == SPB_F32) hipLaunchKernelGGL(weight_prep_kernel<float>, dim3(n_tiles), dim3(256), 0, (hipStream_t)stream, tab, n_entries, params, (float*)wc);
+  else return SPB_E_ARG;
+  SPB_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int spb_grad_sqnorm(const float* grads, long long n, float* out, spb_stream_t stream) {
+  if (!grads || !out || n <= 0) return SPB_E_ARG;
+  hipError_t e = hipMemsetAsync(out, 0, sizeof(float), (hipStream_t)stream);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(grad_sqnorm_kernel, dim3(elem_grid((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, grads, n, out);
+  SPB_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int spb_optim_step(const spb_optim_args_t* a, spb_stream_t stream) {
+  if (!a || !a->params || !a->grads || a->n <= 0) return SPB_E_ARG;
+  if (a->kind < 0 || a->kind > 3) return SPB_E_ARG;
+  if (a->kind >= 2 && (!a->m || !a->v)) return SPB_E_ARG;
+  if (a->kind == 1 && !a->v) return SPB_E_ARG;
+  hipLaunchKernelGGL(optim_step_kernel, dim3(elem_grid(a->n)), dim3(256), 0, (hipStream_t)stream, *a);
+  SPB_CHECK_LAUNCH();
+  return 0;
+}

@@ -1,0 +1,512 @@
+// Pointwise (1x1) convolution as NHWC row-major GEMMs on the gfx950 matrix cores.
+//
+//   forward   Y[M,N]  = act(bn(A))[M,K] * W[N,K]^T        + per-channel sum(y), sum(y^2) for the next BN
+//   dgrad     dA[M,K] = bn_bwd(G,Z)[M,N] * Wt[K,N]^T      + output-side activation mask and sum(g), sum(g*xhat)
+//   wgrad     dW[N,K] = bn_bwd(G,Z)[M,N]^T * act(bn(X))[M,K]
+//
+// Replaces nn.Conv2d(k=1) + nn.BatchNorm2d + ReLU6/ReLU/LeakyReLU at reference park2019.py:51-53,64-66,
+// revgrad.py:76 and the torchvision MobileNetV2 expand/project convolutions (park2019.py:107-108).
+//
+// Design notes (MI355X):
+//   * 92 % of KRN FLOPs but only ~30 FLOP/B: these GEMMs are HBM-bound except at the 7x7 maps, so the BN affine and
+//     the activation are applied while the A tile is staged (registers -> LDS), and the BN batch sums of the output are
+//     reduced in the epilogue -- each activation tensor is written once and read once per pass.
+//   * 256 threads = 4 waves; workgroup tile 128 x BN; MFMA 16x16x32 bf16 (or the exact 16x16x4 f32 form in parity mode).
+//   * the output tile is staged through LDS so global stores are full 16-byte vectors along the channel axis.
+//   * workgroups are persistent over M tiles (fixed N tile) so the per-channel sums stay in registers; one set of
+//     atomics per workgroup at the end, spread over `oR` replicas of the accumulator.
+//   * logical workgroup ids are remapped so the N tiles that share an A tile run on one XCD (one L2).
+#include "common.h"
+
+namespace {
+
+constexpr int GBM = 128;
+constexpr int GBK = 32;
+
+template <typename T> struct LdsPad { static constexpr int LDK = GBK + 8; };
+template <> struct LdsPad<float> { static constexpr int LDK = GBK + 4; };
+
+template <typename T, int BN>
+constexpr size_t gemm_region_bytes() {
+  size_t a = (size_t)(GBM + BN) * LdsPad<T>::LDK * sizeof(T);
+  size_t b = (size_t)GBM * (BN + 8) * sizeof(T);
+  size_t c = (size_t)2 * 256 * 8 * sizeof(float);  // stats reduction scratch
+  size_t m = a > b ? a : b;
+  return m > c ? m : c;
+}
+
+template <typename T, int BN, int PRO, int EPI>
+__global__ __launch_bounds__(256) void pw_gemm_kernel(const spb_gemm_args_t g) {
+  constexpr int LDK = LdsPad<T>::LDK;
+  constexpr int LDO = BN + 8;
+  constexpr int NF = BN / 16;           // 16-wide column fragments per wave
+  constexpr int NV = BN / 8;            // 8-wide column vectors per tile row
+  constexpr int VR = 256 / NV;          // rows covered per epilogue sweep
+  constexpr int NBV = (BN * 4 + 255) / 256;  // B-tile vec8 loads per thread
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int M = g.M, K = g.K, N = g.N;
+  const int Kp = (K + GBK - 1) / GBK * GBK;
+  float* coef = reinterpret_cast<float*>(smem);  // [3][Kp]
+  T* As = reinterpret_cast<T*>(smem + (size_t)3 * Kp * sizeof(float));
+  T* Bs = As + GBM * LDK;
+  T* Os = As;
+
+  const int t = threadIdx.x;
+  const int l = t & 63, w = t >> 6;
+  const int li = l & 15, lq = l >> 4;
+
+  // ---- prologue coefficients for every reduction channel (derived from the producer's raw batch sums)
+  for (int c = t; c < Kp; c += 256) {
+    float c0 = 0.f, c1 = 0.f, c2 = 0.f;
+    if (c < K) {
+      if (PRO == 1) bn_fwd_coef(g.pro, c, c0, c1);
+      else bn_bwd_coef(g.pro, c, c0, c1, c2);
+    }
+    coef[c] = c0; coef[Kp + c] = c1; coef[2 * Kp + c] = c2;
+  }
+
+  const int NT = (N + BN - 1) / BN;
+  const int MT = (M + GBM - 1) / GBM;
+  const int lid = xcd_remap(blockIdx.x, gridDim.x);
+  const int nt = lid % NT;
+  const int GM = gridDim.x / NT;
+  const int n0 = nt * BN;
+
+  // epilogue ownership: 8 consecutive output channels, a strided set of rows
+  const int vcol = t % NV, vrow0 = t / NV;
+  const int nE = n0 + vcol * 8;
+  const bool colok = nE < N;
+  float s1[8], s2[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
+  float e_sc[8], e_sh[8], e_mu[8], e_is[8], e_bias[8];
+  if (EPI == 2) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      e_sc[j] = 1.f; e_sh[j] = 0.f; e_mu[j] = 0.f; e_is[j] = 0.f;
+      if (colok && g.epi.gamma != nullptr) {
+        bn_moments(g.epi, nE + j, e_mu[j], e_is[j]);
+        e_sc[j] = g.epi.gamma[nE + j] * e_is[j];
+        e_sh[j] = g.epi.beta[nE + j] - e_mu[j] * e_sc[j];
+      }
+    }
+  }
+  if (EPI == 0) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) e_bias[j] = (colok && g.bias) ? g.bias[nE + j] : 0.f;
+  }
+  __syncthreads();
+
+  const T* Ag = reinterpret_cast<const T*>(g.A);
+  const T* A2g = reinterpret_cast<const T*>(g.A2);
+  const T* Bg = reinterpret_cast<const T*>(g.Bw);
+  T* Yg = reinterpret_cast<T*>(g.Y);
+  const T* Rg = reinterpret_cast<const T*>(g.res);
+  const T* Zg = reinterpret_cast<const T*>(g.Zout);
+
+  const int kvA = t & 3, rowA = t >> 2;  // A tile: rows rowA, rowA+64
+  const int KT = Kp / GBK;
+
+  for (int mt = lid / NT; mt < MT; mt += GM) {
+    const int m0 = mt * GBM;
+    f32x4_t acc[2][NF];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < NF; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    float ra[2][8], ra2[2][8], rb[NBV][8];
+    // ---- global loads for reduction tile kt into registers
+#define LOAD_TILE(kt)                                                                         \
+    {                                                                                         \
+      const int k = (kt) * GBK + kvA * 8;                                                     \
+      _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                         \
+        const int m = m0 + rowA + 64 * i;                                                     \
+        if (m < M && k < K) {                                                                 \
+          ld8<T>(Ag + (size_t)m * K + k, ra[i]);                                              \
+          if (PRO == 2) {                                                                     \
+            if (A2g) ld8<T>(A2g + (size_t)m * K + k, ra2[i]);                                 \
+            else { _Pragma("unroll") for (int j = 0; j < 8; ++j) ra2[i][j] = 0.f; }           \
+          }                                                                                   \
+        } else {                                                                              \
+          _Pragma("unroll") for (int j = 0; j < 8; ++j) { ra[i][j] = 0.f; ra2[i][j] = 0.f; }  \
+        }                                                                                     \
+      }                                                                                       \
+      _Pragma("unroll") for (int i = 0; i < NBV; ++i) {                                       \
+        const int e = t + 256 * i;                                                            \
+        const int rb_ = e >> 2, kb = (kt) * GBK + (e & 3) * 8;                                \
+        const int n = n0 + rb_;                                                               \
+        if (rb_ < BN && n < N && kb < K) ld8<T>(Bg + (size_t)n * K + kb, rb[i]);              \
+        else { _Pragma("unroll") for (int j = 0; j < 8; ++j) rb[i][j] = 0.f; }                \
+      }                                                                                       \
+    }
+    // ---- transform + write the staged tile to LDS
+#define STORE_TILE(kt)                                                                        \
+    {                                                                                         \
+      const int k = (kt) * GBK + kvA * 8;                                                     \
+      _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                         \
+        const int m = m0 + rowA + 64 * i;                                                     \
+        float v[8];                                                                           \
+        const bool ok = (m < M && k < K);                                                     \
+        _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                       \
+          float x;                                                                            \
+          if (PRO == 1) x = act_fwd(ra[i][j] * coef[k + j] + coef[Kp + k + j], g.pro.act, g.pro.slope); \
+          else x = ra[i][j] * coef[k + j] + ra2[i][j] * coef[Kp + k + j] + coef[2 * Kp + k + j]; \
+          v[j] = ok ? x : 0.f;                                                                \
+        }                                                                                     \
+        st8<T>(As + (rowA + 64 * i) * LDK + kvA * 8, v);                                      \
+      }                                                                                       \
+      _Pragma("unroll") for (int i = 0; i < NBV; ++i) {                                       \
+        const int e = t + 256 * i;                                                            \
+        const int rb_ = e >> 2;                                                               \
+        if (rb_ < BN) st8<T>(Bs + rb_ * LDK + (e & 3) * 8, rb[i]);                            \
+      }                                                                                       \
+    }
+
+    LOAD_TILE(0);
+    for (int kt = 0; kt < KT; ++kt) {
+      STORE_TILE(kt);
+      __syncthreads();
+      if (kt + 1 < KT) LOAD_TILE(kt + 1);
+      if constexpr (sizeof(T) == 2) {
+        bf16x8_t af[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+          af[i] = *reinterpret_cast<const bf16x8_t*>(As + (w * 32 + i * 16 + li) * LDK + lq * 8);
+#pragma unroll
+        for (int j = 0; j < NF; ++j) {
+          const bf16x8_t bfv = *reinterpret_cast<const bf16x8_t*>(Bs + (j * 16 + li) * LDK + lq * 8);
+#pragma unroll
+          for (int i = 0; i < 2; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfv, acc[i][j], 0, 0, 0);
+        }
+      } else {
+#pragma unroll
+        for (int kk = 0; kk < GBK / 4; ++kk) {
+          float af[2];
+#pragma unroll
+          for (int i = 0; i < 2; ++i) af[i] = As[(w * 32 + i * 16 + li) * LDK + kk * 4 + lq];
+#pragma unroll
+          for (int j = 0; j < NF; ++j) {
+            const float bfv = Bs[(j * 16 + li) * LDK + kk * 4 + lq];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bfv, acc[i][j], 0, 0, 0);
+          }
+        }
+      }
+      __syncthreads();
+    }
+#undef LOAD_TILE
+#undef STORE_TILE
+
+    // ---- accumulators -> LDS (C layout: col = lane&15, row = (lane>>4)*4 + r)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < NF; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          Os[(w * 32 + i * 16 + lq * 4 + r) * LDO + j * 16 + li] = from_f<T>(acc[i][j][r]);
+    __syncthreads();
+
+    // ---- coalesced epilogue: 16-byte vectors along the channel axis
+    if (colok) {
+#pragma unroll
+      for (int s = 0; s < GBM / VR; ++s) {
+        const int r = vrow0 + s * VR;
+        const int m = m0 + r;
+        if (m < M) {
+          float v[8];
+          ld8<T>(Os + r * LDO + vcol * 8, v);
+          const size_t o = (size_t)m * N + nE;
+          if (EPI == 0) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = act_fwd(v[j] * g.out_scale + e_bias[j], g.out_act, 0.f);
+            st8<T>(Yg + o, v);
+          } else if (EPI == 1) {
+            st8<T>(Yg + o, v);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { s1[j] += v[j]; s2[j] += v[j] * v[j]; }
+          } else {
+            float z[8], rr[8];
+            ld8<T>(Zg + o, z);
+            if (Rg) {
+              ld8<T>(Rg + o, rr);
+#pragma unroll
+              for (int j = 0; j < 8; ++j) v[j] += rr[j];
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              const float u = z[j] * e_sc[j] + e_sh[j];
+              v[j] = rnd<T>(v[j] * act_grad(u, g.epi.act, g.epi.slope));
+              const float xh = (z[j] - e_mu[j]) * e_is[j];
+              s1[j] += v[j];
+              s2[j] += v[j] * xh;
+            }
+            st8<T>(Yg + o, v);
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- per-channel batch sums: reduce over the workgroup, one atomic per channel per workgroup
+  if (EPI != 0) {
+    float* Rs = reinterpret_cast<float*>(As);  // [2][VR][BN]
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      Rs[vrow0 * BN + vcol * 8 + j] = s1[j];
+      Rs[VR * BN + vrow0 * BN + vcol * 8 + j] = s2[j];
+    }
+    __syncthreads();
+    if (t < 2 * BN) {
+      const int which = t / BN, c = t % BN;
+      float s = 0.f;
+      for (int r = 0; r < VR; ++r) s += Rs[which * VR * BN + r * BN + c];
+      if (n0 + c < N) {
+        const int rep = blockIdx.x % g.oR;
+        atomicAdd(g.osums + (size_t)rep * 2 * N + (size_t)which * N + n0 + c, s);
+      }
+    }
+  }
+}
+
+template <typename T, int BN, int PRO, int EPI>
+int launch_gemm(const spb_gemm_args_t& g, hipStream_t stream) {
+  const int NT = (g.N + BN - 1) / BN;
+  const int MT = (g.M + GBM - 1) / GBM;
+  int GM = MT;
+  const int cap = 2048 / NT > 8 ? 2048 / NT : 8;
+  if (GM > cap) GM = cap;
+  if (GM >= 8) GM = GM / 8 * 8;
+  const int Kp = (g.K + GBK - 1) / GBK * GBK;
+  const size_t lds = (size_t)3 * Kp * sizeof(float) + gemm_region_bytes<T, BN>();
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&pw_gemm_kernel<T, BN, PRO, EPI>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_done = true;
+  }
+  if (lds > 160 * 1024) return SPB_E_SHAPE;
+  hipLaunchKernelGGL((pw_gemm_kernel<T, BN, PRO, EPI>), dim3(NT * GM), dim3(256), lds, stream, g);
+  SPB_CHECK_LAUNCH();
+  return 0;
+}
+
+template <typename T, int PRO, int EPI>
+int dispatch_bn(const spb_gemm_args_t& g, hipStream_t stream) {
+  const int N = g.N;
+  int bn;
+  if (N <= 32) bn = 32;
+  else if (N <= 64) bn = 64;
+  else {
+    const int p64 = (N + 63) / 64 * 64, p128 = (N + 127) / 128 * 128;
+    bn = (p128 <= p64) ? 128 : 64;
+  }
+  if (sizeof(T) == 4 && bn == 128) bn = 64;  // parity mode: keep the LDS footprint small
+  if (bn == 32) return launch_gemm<T, 32, PRO, EPI>(g, stream);
+  if (bn == 64) return launch_gemm<T, 64, PRO, EPI>(g, stream);
+  return launch_gemm<T, 128, PRO, EPI>(g, stream);
+}
+
+template <typename T>
+int dispatch_modes(const spb_gemm_args_t& g, hipStream_t stream) {
+  if (g.pro_mode == 1 && g.epi_mode == 1) return dispatch_bn<T, 1, 1>(g, stream);
+  if (g.pro_mode == 1 && g.epi_mode == 0) return dispatch_bn<T, 1, 0>(g, stream);
+  if (g.pro_mode == 2 && g.epi_mode == 0) return dispatch_bn<T, 2, 0>(g, stream);
+  if (g.pro_mode == 2 && g.epi_mode == 2) return dispatch_bn<T, 2, 2>(g, stream);
+  return SPB_E_UNSUPPORTED;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// weight gradient: dW[n,k] += sum_m dz[m,n] * a[m,k].  The reduction axis (m) is the slow axis of both operands,
+// so the staged row-major LDS tiles are read with the gfx950 transpose load (ds_read_b64_tr_b16): lane (i,q) of a
+// 16-lane group gets 4 consecutive m for one column, exactly the MFMA operand layout.
+constexpr int WT = 64;   // output tile (n and k)
+constexpr int WM = 64;   // m rows per LDS stage
+
+template <typename T>
+__global__ __launch_bounds__(256) void pw_wgrad_kernel(const spb_wgrad_args_t g, int rows_per_split) {
+  constexpr int LD = WT + 8;
+  __shared__ __attribute__((aligned(16))) T Ds[WM * LD];
+  __shared__ __attribute__((aligned(16))) T Xs[WM * LD];
+  __shared__ float cz[3][WT];
+  __shared__ float ca[2][WT];
+
+  const int M = g.M, K = g.K, N = g.N;
+  const int NT = (N + WT - 1) / WT, KT = (K + WT - 1) / WT;
+  const int tile = blockIdx.x % (NT * KT), split = blockIdx.x / (NT * KT);
+  const int n0 = (tile / KT) * WT, k0 = (tile % KT) * WT;
+  const int mbeg = split * rows_per_split;
+  const int mend = min(M, mbeg + rows_per_split);
+
+  const int t = threadIdx.x, l = t & 63, w = t >> 6;
+  const int li = l & 15, lq = l >> 4;
+  const int wn = w >> 1, wk = w & 1;
+
+  if (t < WT) {
+    float p0 = 0.f, p1 = 0.f, p2 = 0.f;
+    if (n0 + t < N) bn_bwd_coef(g.pro_dz, n0 + t, p0, p1, p2);
+    cz[0][t] = p0; cz[1][t] = p1; cz[2][t] = p2;
+  } else if (t < 2 * WT) {
+    const int c = t - WT;
+    float sc = 0.f, sh = 0.f;
+    if (k0 + c < K) bn_fwd_coef(g.pro_a, k0 + c, sc, sh);
+    ca[0][c] = sc; ca[1][c] = sh;
+  }
+  __syncthreads();
+
+  const T* Gg = reinterpret_cast<const T*>(g.G);
+  const T* Zg = reinterpret_cast<const T*>(g.Zn);
+  const T* Xg = reinterpret_cast<const T*>(g.X);
+
+  f32x4_t acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) acc[a][b] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+  const int cv = t & 7, rw = t >> 3;  // rows rw, rw+32; columns cv*8..cv*8+7
+  for (int mb = mbeg; mb < mend; mb += WM) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int r = rw + 32 * i, m = mb + r;
+      float v[8];
+      {  // dz tile
+        const int n = n0 + cv * 8;
+        const bool ok = (m < mend) && (n < N);
+        float gg[8], zz[8];
+        if (ok) {
+          ld8<T>(Gg + (size_t)m * N + n, gg);
+          if (Zg) ld8<T>(Zg + (size_t)m * N + n, zz);
+          else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) zz[j] = 0.f;
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          v[j] = ok ? (gg[j] * cz[0][cv * 8 + j] + zz[j] * cz[1][cv * 8 + j] + cz[2][cv * 8 + j]) : 0.f;
+        st8<T>(Ds + r * LD + cv * 8, v);
+      }
+      {  // a tile
+        const int k = k0 + cv * 8;
+        const bool ok = (m < mend) && (k < K);
+        float xx[8];
+        if (ok) ld8<T>(Xg + (size_t)m * K + k, xx);
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          v[j] = ok ? act_fwd(xx[j] * ca[0][cv * 8 + j] + ca[1][cv * 8 + j], g.pro_a.act, g.pro_a.slope) : 0.f;
+        st8<T>(Xs + r * LD + cv * 8, v);
+      }
+    }
+    __syncthreads();
+    if constexpr (sizeof(T) == 2) {
+#pragma unroll
+      for (int mc = 0; mc < WM / 32; ++mc) {
+        bf16x8_t pf[2], qf[2];
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+          const int row = mc * 32 + lq * 8 + (li >> 2);
+          const bf16_t* pa = Ds + row * LD + (wn * 2 + f) * 16 + (li & 3) * 4;
+          const bf16_t* qa = Xs + row * LD + (wk * 2 + f) * 16 + (li & 3) * 4;
+          typedef s16x4_t __attribute__((address_space(3))) * lds_v4;
+          const s16x4_t plo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(pa));
+          const s16x4_t phi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(pa + 4 * LD));
+          const s16x4_t qlo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(qa));
+          const s16x4_t qhi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(qa + 4 * LD));
+          union { struct { s16x4_t lo, hi; } s; bf16x8_t v; } up, uq;
+          up.s.lo = plo; up.s.hi = phi; uq.s.lo = qlo; uq.s.hi = qhi;
+          pf[f] = up.v; qf[f] = uq.v;
+        }
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int b = 0; b < 2; ++b)
+            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf[a], qf[b], acc[a][b], 0, 0, 0);
+      }
+    } else {
+#pragma unroll 4
+      for (int mm = 0; mm < WM / 4; ++mm) {
+        float pf[2], qf[2];
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+          pf[f] = Ds[(mm * 4 + lq) * LD + (wn * 2 + f) * 16 + li];
+          qf[f] = Xs[(mm * 4 + lq) * LD + (wk * 2 + f) * 16 + li];
+        }
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int b = 0; b < 2; ++b)
+            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(pf[a], qf[b], acc[a][b], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = n0 + (wn * 2 + a) * 16 + lq * 4 + r;
+        const int k = k0 + (wk * 2 + b) * 16 + li;
+        if (n < N && k < K) atomicAdd(g.dW + (size_t)n * K + k, acc[a][b][r]);
+      }
+}
+
+template <typename T>
+int launch_wgrad(const spb_wgrad_args_t& g, hipStream_t stream) {
+  const int NT = (g.N + WT - 1) / WT, KT = (g.K + WT - 1) / WT;
+  int S = spb_ceil_div(1024, NT * KT);
+  const int maxS = spb_ceil_div(g.M, 2 * WM);
+  if (S > maxS) S = maxS;
+  if (S < 1) S = 1;
+  int rps = spb_ceil_div(spb_ceil_div(g.M, S), WM) * WM;
+  S = spb_ceil_div(g.M, rps);
+  hipLaunchKernelGGL((pw_wgrad_kernel<T>), dim3(NT * KT * S), dim3(256), 0, stream, g, rps);
+  SPB_CHECK_LAUNCH();
+  return 0;
+}
+
+// lane l of a wave reads 8 bytes at in + l*4 elements through the transpose load; used by the unit test that pins
+// the instruction's semantics on the box.
+__global__ void trread_probe(const unsigned short* in, unsigned short* out) {
+  __shared__ __attribute__((aligned(16))) unsigned short lds[4096];
+  for (int i = threadIdx.x; i < 4096; i += 64) lds[i] = in[i];
+  __syncthreads();
+  typedef s16x4_t __attribute__((address_space(3))) * lds_v4;
+  const int l = threadIdx.x;
+  const s16x4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(lds + l * 4));
+  for (int j = 0; j < 4; ++j) out[l * 4 + j] = (unsigned short)v[j];
+}
+
+}  // namespace
+
+extern "C" int spb_pwconv_gemm(int dtype, const spb_gemm_args_t* a, spb_stream_t stream) {
+  if (!a || !a->A || !a->Bw || !a->Y) return SPB_E_ARG;
+  if (a->M <= 0 || a->K <= 0 || a->N <= 0 || (a->K & 7) || (a->N & 7)) return SPB_E_SHAPE;
+  if (a->epi_mode != 0 && (!a->osums || a->oR < 1)) return SPB_E_ARG;
+  if (a->epi_mode == 2 && !a->Zout) return SPB_E_ARG;
+  if (dtype == SPB_BF16) return dispatch_modes<bf16_t>(*a, (hipStream_t)stream);
+  if (dtype == SPB_F32) return dispatch_modes<float>(*a, (hipStream_t)stream);
+  return SPB_E_ARG;
+}
+
+extern "C" int spb_pwconv_wgrad(int dtype, const spb_wgrad_args_t* a, spb_stream_t stream) {
+  if (!a || !a->G || !a->X || !a->dW) return SPB_E_ARG;
+  if (a->M <= 0 || a->K <= 0 || a->N <= 0 || (a->K & 7) || (a->N & 7)) return SPB_E_SHAPE;
+  if (dtype == SPB_BF16) return launch_wgrad<bf16_t>(*a, (hipStream_t)stream);
+  if (dtype == SPB_F32) return launch_wgrad<float>(*a, (hipStream_t)stream);
+  return SPB_E_ARG;
+}
+
+extern "C" int spb_debug_trread(const unsigned short* in4096, unsigned short* out256, spb_stream_t stream) {
+  hipLaunchKernelGGL(trread_probe, dim3(1), dim3(64), 0, (hipStream_t)stream, in4096, out256);
+  SPB_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" const char* spb_version(void) { return "speedplusbaseline_amd gfx950 r1"; }

@@ -1,0 +1,646 @@
+// Network-level runtime for KeypointRegressionNet (+ RevGrad's domain classifier): layer graph, parameter/arena
+// layout with the reference's state-dict names, activation workspace layout and the launch sequence of one
+// forward and one backward pass.  Reference: park2019.py:101-165 (KRN), torchvision mobilenet_v2.features[:-1]
+// (park2019.py:107-108), revgrad.py:58-96 (RevGrad), dann.py:68-100 (which passes call backward).
+//
+// Dataflow (training): every BatchNorm'd tensor lives in HBM only as the raw convolution output z plus
+// per-channel batch sums; consumers normalise/activate on load.  Inverted-residual outputs with a skip connection,
+// the tap after block 13 and the RouterV2 concat are the only materialised normalised tensors.  In backward every
+// such tensor has g = dL/d(bn output) (activation mask applied) plus sum(g), sum(g*xhat); producers rebuild dz on load.
+#include <string>
+#include <vector>
+#include <cstring>
+#include <cstdio>
+#include "common.h"
+
+namespace {
+
+struct PInfo { std::string name; int ndim; int shape[4]; long long off; long long numel; };
+struct BNDef { int C; long long g_off, b_off, rm_off; int index; };
+struct PWDef { int K, N; long long w_off, bias_off, wc_off, wct_off; };
+struct DWDef { int C, stride; long long w_off; };
+struct ActDef { int H, W, C, bn, act; float slope; };
+struct MatDef { int H, W, C; };
+struct Block { int t, cin, cout, stride, hid, Hin, Hout; bool res; PWDef E, P; DWDef D; int aE, aD, aP, matY; };
+
+constexpr float kEps = 1e-5f;
+constexpr float kMomentum = 0.1f;
+constexpr int kIn = 224;
+
+size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+}  // namespace
+
+struct spb_krn {
+  int nK = 0, J = 0, Jp = 0; bool dann = false;
+  std::vector<PInfo> params, buffers;
+  std::vector<std::string> bn_names;
+  std::vector<BNDef> bns;
+  std::vector<ActDef> acts;
+  std::vector<MatDef> mats;
+  Block blk[18];
+  int aStem = -1; long long stem_w_off = 0;
+  DWDef eD[4]; PWDef eP[4]; int aED[4], aEP[4];  // extras 0,1,3 are ConvDw; index 2 unused
+  PWDef router; int aR = -1; int matCat = -1;
+  long long head_w_off = 0, head_b_off = 0, head_wc_off = 0;
+  PWDef dc0; long long dc3_w_off = 0, dc3_b_off = 0;
+  long long n_params = 0, n_buffers = 0, wc_elems = 0;
+  // bound state
+  float* P = nullptr; float* G = nullptr; float* Bf = nullptr; long long* nbt = nullptr;
+  char* wc = nullptr; spb_prep_entry_t* prep_d = nullptr; int n_prep = 0, n_prep_tiles = 0;
+  std::vector<spb_prep_entry_t> prep;
+  int dtype = -1;
+  std::string prefix;
+
+  long long add_param(const std::string& name, std::vector<int> shape) {
+    PInfo p; p.name = prefix + name; p.ndim = (int)shape.size(); p.numel = 1;
+    for (int i = 0; i < 4; ++i) p.shape[i] = i < p.ndim ? shape[i] : 1;
+    for (int d : shape) p.numel *= d;
+    n_params = (long long)align_up((size_t)n_params, 4);  // keep every tensor 16-byte aligned in the arena
+    p.off = n_params; n_params += p.numel;
+    params.push_back(p);
+    return p.off;
+  }
+  int add_bn(const std::string& name, int C) {
+    BNDef b; b.C = C; b.index = (int)bns.size();
+    b.g_off = add_param(name + ".weight", {C});
+    b.b_off = add_param(name + ".bias", {C});
+    PInfo rm; rm.name = prefix + name + ".running_mean"; rm.ndim = 1; rm.shape[0] = C; rm.shape[1] = rm.shape[2] = rm.shape[3] = 1;
+    rm.numel = C; rm.off = n_buffers; n_buffers += C;
+    PInfo rv = rm; rv.name = prefix + name + ".running_var"; rv.off = n_buffers; n_buffers += C;
+    b.rm_off = rm.off;
+    buffers.push_back(rm); buffers.push_back(rv);
+    bn_names.push_back(prefix + name + ".num_batches_tracked");
+    bns.push_back(b);
+    return b.index;
+  }
+  int add_act(int H, int W, int C, int bn, int act, float slope = 0.f) {
+    acts.push_back(ActDef{H, W, C, bn, act, slope});
+    return (int)acts.size() - 1;
+  }
+  PWDef add_pw(const std::string& name, int K, int N, bool bias = false) {
+    PWDef d; d.K = K; d.N = N; d.w_off = add_param(name + ".weight", {N, K, 1, 1});
+    d.bias_off = bias ? add_param(name + ".bias", {N}) : -1;
+    d.wc_off = (long long)align_up((size_t)wc_elems, 8); wc_elems = d.wc_off + (long long)N * K;
+    d.wct_off = (long long)align_up((size_t)wc_elems, 8); wc_elems = d.wct_off + (long long)N * K;
+    return d;
+  }
+  DWDef add_dw(const std::string& name, int C, int stride) {
+    DWDef d; d.C = C; d.stride = stride; d.w_off = add_param(name + ".weight", {C, 1, 3, 3});
+    return d;
+  }
+};
+
+struct spb_krn_ctx {
+  spb_krn* m = nullptr; int B = 0; char* ws = nullptr; size_t es = 2;
+  std::vector<size_t> z_off, g_off, y_off;          // byte offsets in ws
+  std::vector<size_t> sums_off, bsums_off;          // float offsets in the stats arena
+  std::vector<int> R;
+  size_t stats_off = 0, stats_floats = 0;
+  size_t dcat_off = 0, dtap_off = 0, ddom_off = 0, dom1_off = 0, gdom_off = 0;
+  size_t partial_off = 0, dout_off = 0, table_off = 0, dompool_off = 0;
+  int S = 0;
+  int last_training = 0;
+  const float* x = nullptr;  // image of the last forward (needed by the stem weight gradient)
+};
+
+namespace {
+
+void build_model(spb_krn* m, int nK, bool dann) {
+  m->nK = nK; m->J = 2 * nK; m->Jp = (m->J + 15) / 16 * 16; m->dann = dann;
+  m->prefix = dann ? "net." : "";
+  // ---- torchvision mobilenet_v2.features[:-1]
+  m->stem_w_off = m->add_param("base.0.0.weight", {32, 3, 3, 3});
+  m->aStem = m->add_act(112, 112, 32, m->add_bn("base.0.1", 32), SPB_ACT_RELU6);
+  const int cfg[7][4] = {{1, 16, 1, 1}, {6, 24, 2, 2}, {6, 32, 3, 2}, {6, 64, 4, 2}, {6, 96, 3, 1}, {6, 160, 3, 2}, {6, 320, 1, 1}};
+  int cin = 32, H = 112, k = 1;
+  for (int s = 0; s < 7; ++s)
+    for (int i = 0; i < cfg[s][2]; ++i, ++k) {
+      Block& b = m->blk[k];
+      b.t = cfg[s][0]; b.cin = cin; b.cout = cfg[s][1]; b.stride = i == 0 ? cfg[s][3] : 1;
+      b.hid = cin * b.t; b.Hin = H; b.Hout = (H - 1) / b.stride + 1;
+      b.res = (b.stride == 1 && b.cin == b.cout);
+      const std::string pre = "base." + std::to_string(k) + ".conv.";
+      int idx = 0;
+      b.aE = -1;
+      if (b.t != 1) {
+        b.E = m->add_pw(pre + "0.0", cin, b.hid);
+        b.aE = m->add_act(H, H, b.hid, m->add_bn(pre + "0.1", b.hid), SPB_ACT_RELU6);
+        idx = 1;
+      }
+      b.D = m->add_dw(pre + std::to_string(idx) + ".0", b.hid, b.stride);
+      b.aD = m->add_act(b.Hout, b.Hout, b.hid, m->add_bn(pre + std::to_string(idx) + ".1", b.hid), SPB_ACT_RELU6);
+      b.P = m->add_pw(pre + std::to_string(idx + 1), b.hid, b.cout);
+      b.aP = m->add_act(b.Hout, b.Hout, b.cout, m->add_bn(pre + std::to_string(idx + 2), b.cout), SPB_ACT_NONE);
+      b.matY = -1;
+      if (b.res) { m->mats.push_back(MatDef{b.Hout, b.Hout, b.cout}); b.matY = (int)m->mats.size() - 1; }
+      cin = b.cout; H = b.Hout;
+    }
+  // ---- extras (park2019.py:113-118): ConvDw(320,1024), ConvDw(1024,1024), RouterV2(96,64), ConvDw(1280,1024)
+  const int ein[4] = {320, 1024, 0, 1280};
+  for (int e = 0; e < 4; ++e) {
+    const std::string pre = "extras." + std::to_string(e) + ".conv.";
+    if (e == 2) {
+      m->router = m->add_pw(pre + "0", 96, 64);
+      m->aR = m->add_act(14, 14, 64, m->add_bn(pre + "1", 64), SPB_ACT_LEAKY, 0.2f);
+      continue;
+    }
+    m->eD[e] = m->add_dw(pre + "0", ein[e], 1);
+    m->aED[e] = m->add_act(7, 7, ein[e], m->add_bn(pre + "1", ein[e]), SPB_ACT_RELU);
+    m->eP[e] = m->add_pw(pre + "3", ein[e], 1024);
+    m->aEP[e] = m->add_act(7, 7, 1024, m->add_bn(pre + "4", 1024), SPB_ACT_RELU);
+  }
+  m->mats.push_back(MatDef{7, 7, 1280}); m->matCat = (int)m->mats.size() - 1;
+  // ---- head (park2019.py:121)
+  m->head_w_off = m->add_param("head.0.weight", {m->J, 1024, 7, 7});
+  m->head_b_off = m->add_param("head.0.bias", {m->J});
+  m->head_wc_off = (long long)align_up((size_t)m->wc_elems, 8);
+  m->wc_elems = m->head_wc_off + (long long)m->Jp * 49 * 1024;
+  // ---- RevGrad domain classifier (revgrad.py:75-80)
+  if (dann) {
+    m->prefix = "";
+    m->dc0 = m->add_pw("domain_classifier.0", 320, 1280, true);
+    m->dc3_w_off = m->add_param("domain_classifier.3.weight", {1, 1280, 1, 1});
+    m->dc3_b_off = m->add_param("domain_classifier.3.bias", {1});
+  }
+  m->n_params = (long long)align_up((size_t)m->n_params, 4);
+  // ---- weight-prep table: W copy, W^T copy per pointwise conv; permuted head weight
+  int tile = 0;
+  auto add_prep = [&](long long src, long long dst, int rows, int cols, int mode, int batch) {
+    spb_prep_entry_t e; e.src_off = src; e.dst_off = dst; e.rows = rows; e.cols = cols; e.mode = mode;
+    e.aux = 0; e.aux2 = 0; e.tile0 = tile;
+    tile += batch * ((rows + 31) / 32) * ((cols + 31) / 32);
+    m->prep.push_back(e);
+  };
+  auto add_pw_prep = [&](const PWDef& d) {
+    add_prep(d.w_off, d.wc_off, d.N, d.K, 0, 1);
+    add_prep(d.w_off, d.wct_off, d.N, d.K, 1, 1);
+  };
+  for (int kk = 1; kk <= 17; ++kk) { if (m->blk[kk].t != 1) add_pw_prep(m->blk[kk].E); add_pw_prep(m->blk[kk].P); }
+  add_pw_prep(m->eP[0]); add_pw_prep(m->eP[1]); add_pw_prep(m->router); add_pw_prep(m->eP[3]);
+  add_prep(m->head_w_off, m->head_wc_off, 1024, 49, 2, m->J);
+  if (dann) add_pw_prep(m->dc0);
+  m->n_prep = (int)m->prep.size(); m->n_prep_tiles = tile;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+struct Src { const void* ptr; spb_bnref_t ref; };
+
+struct Runner {
+  spb_krn_ctx* c; spb_krn* m; hipStream_t st; int dt; int err = 0;
+  Runner(spb_krn_ctx* c_, hipStream_t s) : c(c_), m(c_->m), st(s), dt(c_->m->dtype) {}
+  void ok(int e) { if (e != 0 && err == 0) err = e; }
+
+  float* stats() const { return reinterpret_cast<float*>(c->ws + c->stats_off); }
+  void* z(int a) const { return c->ws + c->z_off[a]; }
+  void* g(int a) const { return c->ws + c->g_off[a]; }
+  void* y(int mt) const { return c->ws + c->y_off[mt]; }
+  float* sums(int a) const { return stats() + c->sums_off[a]; }
+  float* bsums(int a) const { return stats() + c->bsums_off[a]; }
+  int M(int a) const { return c->B * m->acts[a].H * m->acts[a].W; }
+  const void* wc(long long off) const { return m->wc + (size_t)off * c->es; }
+
+  spb_bnref_t ref(int a, bool training) const {
+    const ActDef& d = m->acts[a]; const BNDef& b = m->bns[d.bn];
+    spb_bnref_t r; r.sums = sums(a); r.gamma = m->P + b.g_off; r.beta = m->P + b.b_off; r.bsums = bsums(a);
+    r.inv_n = 1.f / (float)M(a); r.eps = kEps; r.slope = d.slope; r.C = d.C;
+    r.R = training ? c->R[a] : 1; r.act = d.act; r.moments = training ? 0 : 1;
+    return r;
+  }
+  static spb_bnref_t ident(int C) {
+    spb_bnref_t r; std::memset(&r, 0, sizeof(r)); r.C = C; r.R = 1; r.inv_n = 1.f; r.eps = kEps; return r;
+  }
+  Src src_act(int a, bool tr) const { return Src{z(a), ref(a, tr)}; }
+  Src src_mat(int mt) const { return Src{y(mt), ident(m->mats[mt].C)}; }
+  Src block_out(int k, bool tr) const {  // output of inverted-residual block k as a consumer sees it
+    const Block& b = m->blk[k];
+    return b.res ? src_mat(b.matY) : src_act(b.aP, tr);
+  }
+
+  // ---- forward pieces
+  void pw_fwd(const PWDef& L, const Src& in, int aout, bool tr) {
+    spb_gemm_args_t g; std::memset(&g, 0, sizeof(g));
+    g.A = in.ptr; g.Bw = wc(L.wc_off); g.Y = z(aout); g.pro = in.ref; g.M = M(aout); g.K = L.K; g.N = L.N;
+    g.pro_mode = 1; g.out_scale = 1.f;
+    if (tr) { g.epi_mode = 1; g.osums = sums(aout); g.oR = c->R[aout]; } else { g.epi_mode = 0; g.oR = 1; }
+    ok(spb_pwconv_gemm(dt, &g, st));
+  }
+  void dw_fwd(const DWDef& L, const Src& in, int Hin, int aout, bool tr) {
+    spb_dw_args_t d; std::memset(&d, 0, sizeof(d));
+    d.X = in.ptr; d.Wd = m->P + L.w_off; d.Y = z(aout); d.pro = in.ref; d.B = c->B; d.H = Hin; d.W = Hin; d.C = L.C;
+    d.stride = L.stride; d.epi_mode = tr ? 1 : 0; d.osums = sums(aout); d.oR = c->R[aout];
+    ok(spb_dwconv_fwd(dt, &d, st));
+  }
+  // ---- backward pieces.  `atgt` is the Act whose g / bsums the input gradient lands in (-1: plain output to `plain`)
+  void pw_bwd(const PWDef& L, const Src& in, int aout, int atgt, void* plain, const void* res, float plain_scale = 1.f) {
+    spb_gemm_args_t g; std::memset(&g, 0, sizeof(g));
+    g.A = this->g(aout); g.A2 = z(aout); g.Bw = wc(L.wct_off); g.pro = ref(aout, true);
+    g.M = M(aout); g.K = L.N; g.N = L.K; g.pro_mode = 2; g.out_scale = plain_scale;
+    if (atgt >= 0) {
+      g.Y = this->g(atgt); g.Zout = z(atgt); g.epi = ref(atgt, true); g.osums = bsums(atgt); g.oR = c->R[atgt];
+      g.res = res; g.epi_mode = 2;
+    } else { g.Y = plain; g.epi_mode = 0; g.oR = 1; }
+    ok(spb_pwconv_gemm(dt, &g, st));
+    spb_wgrad_args_t w; std::memset(&w, 0, sizeof(w));
+    w.G = this->g(aout); w.Zn = z(aout); w.X = in.ptr; w.dW = m->G + L.w_off; w.pro_dz = ref(aout, true);
+    w.pro_a = in.ref; w.M = M(aout); w.K = L.K; w.N = L.N;
+    ok(spb_pwconv_wgrad(dt, &w, st));
+  }
+  void dw_bwd(const DWDef& L, const Src& in, int Hin, int aout, int atgt, void* plain, const void* res) {
+    spb_dw_args_t d; std::memset(&d, 0, sizeof(d));
+    d.X = this->g(aout); d.X2 = z(aout); d.Xin = in.ptr; d.Wd = m->P + L.w_off; d.dW = m->G + L.w_off;
+    d.pro = ref(aout, true); d.pro_in = in.ref; d.B = c->B; d.H = Hin; d.W = Hin; d.C = L.C; d.stride = L.stride;
+    if (atgt >= 0) {
+      d.Y = this->g(atgt); d.Zout = z(atgt); d.epi = ref(atgt, true); d.osums = bsums(atgt); d.oR = c->R[atgt];
+      d.res = res; d.epi_mode = 2;
+    } else { d.Y = plain; d.epi_mode = 0; d.oR = 1; }
+    ok(spb_dwconv_dgrad(dt, &d, st));
+    ok(spb_dwconv_wgrad(dt, &d, st));
+  }
+};
+
+__global__ void domain_tail_fwd_kernel(const void* D1, int dtype, const float* w3, const float* b3, float* pooled,
+                                       float* logits, int HW, int C) {
+  // logits[b] = b3 + sum_c w3[c] * mean_hw D1[b,hw,c]      (AvgPool2d(7) + Conv2d(1280,1,1), revgrad.py:78-79)
+  __shared__ float red[4];
+  const int b = blockIdx.x;
+  float s = 0.f;
+  for (int cidx = threadIdx.x; cidx < C; cidx += 256) {
+    float a = 0.f;
+    for (int p = 0; p < HW; ++p) {
+      const size_t o = ((size_t)b * HW + p) * C + cidx;
+      a += dtype == SPB_BF16 ? bf2f(reinterpret_cast<const bf16_t*>(D1)[o]) : reinterpret_cast<const float*>(D1)[o];
+    }
+    a /= (float)HW;
+    pooled[(size_t)b * C + cidx] = a;
+    s += a * w3[cidx];
+  }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) logits[b] = red[0] + red[1] + red[2] + red[3] + b3[0];
+}
+
+__global__ void domain_tail_bwd_kernel(const void* D1, void* Gd, int dtype, const float* w3, const float* pooled,
+                                       const float* dlogit, float* dw3, float* db3, float* dbias0, int B, int HW, int C) {
+  // one block per channel slab of 256: dD1[b,hw,c] = dlogit[b]*w3[c]/HW * (D1>0);  dw3[c] += sum_b dlogit[b]*pooled[b,c]
+  const int cidx = blockIdx.x * 256 + threadIdx.x;
+  if (cidx < C) {
+    float gw = 0.f, gb0 = 0.f;
+    const float w = w3[cidx];
+    for (int b = 0; b < B; ++b) {
+      const float dl = dlogit[b];
+      gw += dl * pooled[(size_t)b * C + cidx];
+      const float up = dl * w / (float)HW;
+      for (int p = 0; p < HW; ++p) {
+        const size_t o = ((size_t)b * HW + p) * C + cidx;
+        if (dtype == SPB_BF16) {
+          const float d1 = bf2f(reinterpret_cast<const bf16_t*>(D1)[o]);
+          const float gv = bf2f(f2bf(d1 > 0.f ? up : 0.f));
+          reinterpret_cast<bf16_t*>(Gd)[o] = f2bf(gv);
+          gb0 += gv;
+        } else {
+          const float d1 = reinterpret_cast<const float*>(D1)[o];
+          const float gv = d1 > 0.f ? up : 0.f;
+          reinterpret_cast<float*>(Gd)[o] = gv;
+          gb0 += gv;
+        }
+      }
+    }
+    dw3[cidx] += gw;
+    dbias0[cidx] += gb0;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    float s = 0.f;
+    for (int b = 0; b < B; ++b) s += dlogit[b];
+    db3[0] += s;
+  }
+}
+
+__global__ void bce_logits_kernel(const float* logits, float label, int B, float* loss, float* dlogit, float gscale) {
+  // binary_cross_entropy_with_logits(reduction='mean') against a constant label (dann.py:85-92)
+  __shared__ float red[256];
+  float s = 0.f;
+  for (int b = threadIdx.x; b < B; b += 256) {
+    const float x = logits[b];
+    s += fmaxf(x, 0.f) - x * label + log1pf(expf(-fabsf(x)));
+    const float sig = 1.f / (1.f + expf(-x));
+    if (dlogit) dlogit[b] = gscale * (sig - label) / (float)B;
+  }
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+  if (threadIdx.x == 0 && loss) loss[0] = red[0] / (float)B;
+}
+
+}  // namespace
+
+// =================================================================================================================
+extern "C" int spb_krn_create(int num_keypoints, int dann, spb_krn_t** out) {
+  if (!out || num_keypoints <= 0 || num_keypoints > 16) return SPB_E_ARG;
+  spb_krn* m = new spb_krn();
+  build_model(m, num_keypoints, dann != 0);
+  *out = m;
+  return 0;
+}
+extern "C" void spb_krn_destroy(spb_krn_t* m) { delete m; }
+extern "C" int spb_krn_num_params(const spb_krn_t* m) { return (int)m->params.size(); }
+extern "C" int spb_krn_num_buffers(const spb_krn_t* m) { return (int)m->buffers.size(); }
+extern "C" int spb_krn_num_bn(const spb_krn_t* m) { return (int)m->bns.size(); }
+static int fill_info(const PInfo& p, spb_tensor_info_t* o) {
+  std::memset(o, 0, sizeof(*o));
+  std::snprintf(o->name, sizeof(o->name), "%s", p.name.c_str());
+  o->offset = p.off; o->numel = p.numel; o->ndim = p.ndim;
+  for (int i = 0; i < 4; ++i) o->shape[i] = p.shape[i];
+  return 0;
+}
+extern "C" int spb_krn_param_info(const spb_krn_t* m, int i, spb_tensor_info_t* o) {
+  if (!m || !o || i < 0 || i >= (int)m->params.size()) return SPB_E_ARG;
+  return fill_info(m->params[i], o);
+}
+extern "C" int spb_krn_buffer_info(const spb_krn_t* m, int i, spb_tensor_info_t* o) {
+  if (!m || !o || i < 0 || i >= (int)m->buffers.size()) return SPB_E_ARG;
+  return fill_info(m->buffers[i], o);
+}
+extern "C" int spb_krn_bn_name(const spb_krn_t* m, int i, char* out96) {
+  if (!m || !out96 || i < 0 || i >= (int)m->bn_names.size()) return SPB_E_ARG;
+  std::snprintf(out96, 96, "%s", m->bn_names[i].c_str());
+  return 0;
+}
+extern "C" long long spb_krn_param_numel(const spb_krn_t* m) { return m->n_params; }
+extern "C" long long spb_krn_buffer_numel(const spb_krn_t* m) { return m->n_buffers; }
+extern "C" long long spb_krn_wcompute_bytes(const spb_krn_t* m, int dtype) {
+  return (long long)align_up((size_t)m->wc_elems * (dtype == SPB_BF16 ? 2 : 4), 256);
+}
+extern "C" long long spb_krn_tables_bytes(const spb_krn_t* m) {
+  return (long long)align_up(m->prep.size() * sizeof(spb_prep_entry_t), 256);
+}
+
+extern "C" int spb_krn_bind(spb_krn_t* m, float* params, float* grads, float* buffers, long long* nbt, void* wcompute,
+                            void* tables_dev, int dtype) {
+  if (!m || !params || !buffers || !wcompute || !tables_dev) return SPB_E_ARG;
+  if (dtype != SPB_F32 && dtype != SPB_BF16) return SPB_E_ARG;
+  m->P = params; m->G = grads; m->Bf = buffers; m->nbt = nbt; m->wc = (char*)wcompute; m->dtype = dtype;
+  m->prep_d = (spb_prep_entry_t*)tables_dev;
+  hipError_t e = hipMemcpy(m->prep_d, m->prep.data(), m->prep.size() * sizeof(spb_prep_entry_t), hipMemcpyHostToDevice);
+  if (e != hipSuccess) return (int)e;
+  e = hipMemset(wcompute, 0, (size_t)spb_krn_wcompute_bytes(m, dtype));  // padded head rows stay zero
+  if (e != hipSuccess) return (int)e;
+  return 0;
+}
+
+extern "C" int spb_krn_prepare_weights(spb_krn_t* m, spb_stream_t stream) {
+  if (!m || m->dtype < 0) return SPB_E_STATE;
+  return spb_weight_prep(m->dtype, m->prep_d, m->n_prep, m->n_prep_tiles, m->P, m->wc, stream);
+}
+
+// ---- context layout -------------------------------------------------------------------------------------------
+static void layout_ctx(const spb_krn* m, int B, int dtype, spb_krn_ctx* c, size_t* total) {
+  const size_t es = dtype == SPB_BF16 ? 2 : 4;
+  size_t off = 0;
+  auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
+  const int nA = (int)m->acts.size();
+  if (c) { c->es = es; c->z_off.resize(nA); c->g_off.resize(nA); c->sums_off.resize(nA); c->bsums_off.resize(nA); c->R.resize(nA); c->y_off.resize(m->mats.size()); }
+  size_t table = take(m->bns.size() * sizeof(spb_bnupd_entry_t));
+  size_t sf = 0;
+  std::vector<size_t> so(nA), bo(nA); std::vector<int> Rv(nA);
+  for (int a = 0; a < nA; ++a) {
+    const ActDef& d = m->acts[a];
+    const long long Mrows = (long long)B * d.H * d.W;
+    Rv[a] = Mrows >= 32768 ? 8 : 1;
+    so[a] = sf; sf += (size_t)Rv[a] * 2 * d.C;
+    bo[a] = sf; sf += (size_t)Rv[a] * 2 * d.C;
+  }
+  size_t stats = take(sf * sizeof(float));
+  for (int a = 0; a < nA; ++a) {
+    const ActDef& d = m->acts[a];
+    const size_t bytes = (size_t)B * d.H * d.W * d.C * es;
+    size_t zo = take(bytes), go = take(bytes);
+    if (c) { c->z_off[a] = zo; c->g_off[a] = go; c->sums_off[a] = so[a]; c->bsums_off[a] = bo[a]; c->R[a] = Rv[a]; }
+  }
+  for (size_t i = 0; i < m->mats.size(); ++i) {
+    size_t yo = take((size_t)B * m->mats[i].H * m->mats[i].W * m->mats[i].C * es);
+    if (c) c->y_off[i] = yo;
+  }
+  const int S = 256;  // split-K waves of the head GEMM
+  size_t dcat = take((size_t)B * 49 * 1280 * es);
+  size_t dtap = take((size_t)B * 14 * 14 * 96 * es);
+  size_t ddom = take((size_t)B * 49 * 320 * es);
+  size_t dom1 = take((size_t)B * 49 * 1280 * es);
+  size_t gdom = take((size_t)B * 49 * 1280 * es);
+  size_t dompool = take((size_t)B * 1280 * sizeof(float));
+  size_t partial = take((size_t)S * B * m->Jp * sizeof(float));
+  size_t dout = take((size_t)B * m->J * sizeof(float));
+  if (c) {
+    c->table_off = table; c->stats_off = stats; c->stats_floats = sf; c->dcat_off = dcat; c->dtap_off = dtap;
+    c->ddom_off = ddom; c->dom1_off = dom1; c->gdom_off = gdom; c->dompool_off = dompool; c->partial_off = partial;
+    c->dout_off = dout; c->S = S;
+  }
+  *total = off;
+}
+
+extern "C" long long spb_krn_ctx_bytes(const spb_krn_t* m, int batch, int dtype) {
+  if (!m || batch <= 0) return SPB_E_ARG;
+  size_t total = 0;
+  layout_ctx(m, batch, dtype, nullptr, &total);
+  return (long long)total;
+}
+
+extern "C" int spb_krn_ctx_create(spb_krn_t* m, int batch, void* workspace, spb_krn_ctx_t** out) {
+  if (!m || !workspace || !out || batch <= 0) return SPB_E_ARG;
+  if (m->dtype < 0) return SPB_E_STATE;
+  spb_krn_ctx* c = new spb_krn_ctx();
+  c->m = m; c->B = batch; c->ws = (char*)workspace;
+  size_t total = 0;
+  layout_ctx(m, batch, m->dtype, c, &total);
+  // BN maintenance table (stats offsets are per context)
+  std::vector<spb_bnupd_entry_t> tab(m->bns.size());
+  for (size_t a = 0; a < m->acts.size(); ++a) {
+    const ActDef& d = m->acts[a];
+    const BNDef& b = m->bns[d.bn];
+    spb_bnupd_entry_t& e = tab[b.index];
+    const double n = (double)batch * d.H * d.W;
+    e.sums_off = (long long)c->sums_off[a]; e.bsums_off = (long long)c->bsums_off[a]; e.rm_off = b.rm_off;
+    e.gamma_off = b.g_off; e.beta_off = b.b_off; e.C = d.C; e.R = c->R[a]; e.bn_index = b.index;
+    e.inv_n = (float)(1.0 / n); e.unbias = n > 1 ? (float)(n / (n - 1.0)) : 1.f;
+  }
+  hipError_t e = hipMemcpy(c->ws + c->table_off, tab.data(), tab.size() * sizeof(spb_bnupd_entry_t), hipMemcpyHostToDevice);
+  if (e != hipSuccess) { delete c; return (int)e; }
+  *out = c;
+  return 0;
+}
+extern "C" void spb_krn_ctx_destroy(spb_krn_ctx_t* c) { delete c; }
+
+// ---- forward ---------------------------------------------------------------------------------------------------
+extern "C" int spb_krn_forward(spb_krn_ctx_t* c, const float* x, const float* target, int training, float* pred,
+                               float* scalars, float* domain_logits, spb_stream_t stream) {
+  if (!c || !x || !pred) return SPB_E_ARG;
+  if (target && !scalars) return SPB_E_ARG;
+  spb_krn* m = c->m;
+  hipStream_t st = (hipStream_t)stream;
+  Runner r(c, st);
+  const bool tr = training != 0;
+  const spb_bnupd_entry_t* tab = reinterpret_cast<const spb_bnupd_entry_t*>(c->ws + c->table_off);
+  if (tr) {
+    hipError_t e = hipMemsetAsync(r.stats(), 0, c->stats_floats * sizeof(float), st);
+    if (e != hipSuccess) return (int)e;
+  } else {
+    r.ok(spb_bn_load_running(tab, (int)m->bns.size(), r.stats(), m->Bf, stream));
+  }
+  c->last_training = training;
+  c->x = x;
+  // stem
+  r.ok(spb_stem_fwd(m->dtype, x, m->P + m->stem_w_off, r.z(m->aStem), tr ? r.sums(m->aStem) : nullptr, c->R[m->aStem],
+                    c->B, kIn, kIn, stream));
+  // inverted residual blocks
+  Src cur = r.src_act(m->aStem, tr);
+  for (int k = 1; k <= 17; ++k) {
+    const Block& b = m->blk[k];
+    if (b.t != 1) {
+      r.pw_fwd(b.E, cur, b.aE, tr);
+      r.dw_fwd(b.D, r.src_act(b.aE, tr), b.Hin, b.aD, tr);
+    } else {
+      r.dw_fwd(b.D, cur, b.Hin, b.aD, tr);
+    }
+    r.pw_fwd(b.P, r.src_act(b.aD, tr), b.aP, tr);
+    if (b.res) {
+      spb_bnapply_args_t a; std::memset(&a, 0, sizeof(a));
+      a.Z = r.z(b.aP); a.res = cur.ptr; a.Y = r.y(b.matY); a.bn = r.ref(b.aP, tr); a.bn_res = cur.ref;
+      a.B = c->B; a.H = b.Hout; a.W = b.Hout; a.C = b.cout; a.ldc = b.cout; a.coff = 0; a.reorg = 0;
+      r.ok(spb_bn_apply(m->dtype, &a, stream));
+    }
+    cur = r.block_out(k, tr);
+  }
+  const Src feat = cur;  // base[-1] output (RevGrad's hooked feature, revgrad.py:66-71)
+  // extras
+  r.dw_fwd(m->eD[0], feat, 7, m->aED[0], tr);
+  r.pw_fwd(m->eP[0], r.src_act(m->aED[0], tr), m->aEP[0], tr);
+  r.dw_fwd(m->eD[1], r.src_act(m->aEP[0], tr), 7, m->aED[1], tr);
+  r.pw_fwd(m->eP[1], r.src_act(m->aED[1], tr), m->aEP[1], tr);
+  r.pw_fwd(m->router, r.block_out(13, tr), m->aR, tr);
+  {  // cat((reorg(router), x1), dim=1)  (park2019.py:74-80)
+    spb_bnapply_args_t a; std::memset(&a, 0, sizeof(a));
+    a.Z = r.z(m->aR); a.Y = r.y(m->matCat); a.bn = r.ref(m->aR, tr); a.bn_res = Runner::ident(64);
+    a.B = c->B; a.H = 14; a.W = 14; a.C = 64; a.ldc = 1280; a.coff = 0; a.reorg = 2;
+    r.ok(spb_bn_apply(m->dtype, &a, stream));
+    a.Z = r.z(m->aEP[1]); a.bn = r.ref(m->aEP[1], tr); a.bn_res = Runner::ident(1024);
+    a.H = 7; a.W = 7; a.C = 1024; a.coff = 256; a.reorg = 0;
+    r.ok(spb_bn_apply(m->dtype, &a, stream));
+  }
+  r.dw_fwd(m->eD[3], r.src_mat(m->matCat), 7, m->aED[3], tr);
+  r.pw_fwd(m->eP[3], r.src_act(m->aED[3], tr), m->aEP[3], tr);
+  {  // head + loss
+    spb_head_args_t h; std::memset(&h, 0, sizeof(h));
+    h.Z = r.z(m->aEP[3]); h.Wp = r.wc(m->head_wc_off); h.bias = m->P + m->head_b_off; h.target = target;
+    h.partial = reinterpret_cast<float*>(c->ws + c->partial_off); h.pred = pred;
+    h.dout = reinterpret_cast<float*>(c->ws + c->dout_off); h.scalars = scalars; h.pro = r.ref(m->aEP[3], tr);
+    h.B = c->B; h.J = m->J; h.Jp = m->Jp; h.HW = 49; h.C = 1024; h.S = c->S;
+    r.ok(spb_head_fwd(m->dtype, &h, stream));
+  }
+  if (m->dann && domain_logits) {  // domain classifier on the (gradient-reversed) feature
+    spb_gemm_args_t g; std::memset(&g, 0, sizeof(g));
+    g.A = feat.ptr; g.Bw = r.wc(m->dc0.wc_off); g.Y = c->ws + c->dom1_off; g.bias = m->P + m->dc0.bias_off;
+    g.pro = feat.ref; g.M = c->B * 49; g.K = 320; g.N = 1280; g.pro_mode = 1; g.epi_mode = 0; g.out_act = SPB_ACT_RELU;
+    g.oR = 1; g.out_scale = 1.f;
+    r.ok(spb_pwconv_gemm(m->dtype, &g, stream));
+    hipLaunchKernelGGL(domain_tail_fwd_kernel, dim3(c->B), dim3(256), 0, st, (const void*)(c->ws + c->dom1_off), m->dtype,
+                       (const float*)(m->P + m->dc3_w_off), (const float*)(m->P + m->dc3_b_off),
+                       reinterpret_cast<float*>(c->ws + c->dompool_off), domain_logits, 49, 1280);
+  }
+  if (tr) r.ok(spb_bn_running_update(tab, (int)m->bns.size(), r.stats(), m->Bf, m->nbt, kMomentum, stream));
+  hipError_t le = hipGetLastError();
+  if (le != hipSuccess && r.err == 0) r.err = (int)le;
+  return r.err;
+}
+
+// ---- backward --------------------------------------------------------------------------------------------------
+extern "C" int spb_krn_backward(spb_krn_ctx_t* c, float gscale, int with_pose, const float* dlogit, float alpha,
+                                spb_stream_t stream) {
+  if (!c) return SPB_E_ARG;
+  spb_krn* m = c->m;
+  if (!m->G || !c->last_training) return SPB_E_STATE;
+  if (!with_pose && !dlogit) return SPB_E_ARG;
+  if (dlogit && !m->dann) return SPB_E_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  Runner r(c, st);
+  const int dt = m->dtype;
+  const int aF = m->blk[17].aP;  // feature = bn(z) of block 17's projection (no residual there)
+  void* ddom = nullptr;
+  if (dlogit) {  // domain classifier backward, then the gradient-reversal layer (-alpha) into the feature
+    hipLaunchKernelGGL(domain_tail_bwd_kernel, dim3((1280 + 255) / 256), dim3(256), 0, st,
+                       (const void*)(c->ws + c->dom1_off), (void*)(c->ws + c->gdom_off), dt,
+                       (const float*)(m->P + m->dc3_w_off), (const float*)(c->ws + c->dompool_off), dlogit,
+                       m->G + m->dc3_w_off, m->G + m->dc3_b_off, m->G + m->dc0.bias_off, c->B, 49, 1280);
+    spb_gemm_args_t g; std::memset(&g, 0, sizeof(g));
+    g.A = c->ws + c->gdom_off; g.Bw = r.wc(m->dc0.wct_off); g.Y = c->ws + c->ddom_off; g.pro = Runner::ident(1280);
+    g.M = c->B * 49; g.K = 1280; g.N = 320; g.pro_mode = 2; g.epi_mode = 0; g.oR = 1; g.out_scale = -alpha;
+    r.ok(spb_pwconv_gemm(dt, &g, stream));
+    spb_wgrad_args_t w; std::memset(&w, 0, sizeof(w));
+    w.G = c->ws + c->gdom_off; w.X = r.z(aF); w.dW = m->G + m->dc0.w_off; w.pro_dz = Runner::ident(1280);
+    w.pro_a = r.ref(aF, true); w.M = c->B * 49; w.K = 320; w.N = 1280;
+    r.ok(spb_pwconv_wgrad(dt, &w, stream));
+    ddom = c->ws + c->ddom_off;
+  }
+  if (with_pose) {
+    {  // head
+      spb_head_bwd_args_t h; std::memset(&h, 0, sizeof(h));
+      h.Z = r.z(m->aEP[3]); h.Wp = r.wc(m->head_wc_off); h.dout = reinterpret_cast<float*>(c->ws + c->dout_off);
+      h.G = r.g(m->aEP[3]); h.osums = r.bsums(m->aEP[3]); h.dW = m->G + m->head_w_off; h.dbias = m->G + m->head_b_off;
+      h.pro = r.ref(m->aEP[3], true); h.gscale = gscale; h.B = c->B; h.J = m->J; h.Jp = m->Jp; h.HW = 49; h.C = 1024;
+      h.oR = c->R[m->aEP[3]];
+      r.ok(spb_head_bwd(dt, &h, stream));
+    }
+    // extras[3] = ConvDw(1280,1024) on the concat
+    r.pw_bwd(m->eP[3], r.src_act(m->aED[3], true), m->aEP[3], m->aED[3], nullptr, nullptr);
+    r.dw_bwd(m->eD[3], r.src_mat(m->matCat), 7, m->aED[3], -1, c->ws + c->dcat_off, nullptr);
+    {  // split the concat gradient: channels [256,1280) -> extras[1] output, [0,256) -> un-reorg -> router output
+      spb_bnbwd_args_t a; std::memset(&a, 0, sizeof(a));
+      a.dY = c->ws + c->dcat_off; a.Z = r.z(m->aEP[1]); a.G = r.g(m->aEP[1]); a.osums = r.bsums(m->aEP[1]);
+      a.bn = r.ref(m->aEP[1], true); a.B = c->B; a.H = 7; a.W = 7; a.C = 1024; a.ldc = 1280; a.coff = 256; a.reorg = 0;
+      a.oR = c->R[m->aEP[1]];
+      r.ok(spb_bn_bwd_prep(dt, &a, stream));
+      a.Z = r.z(m->aR); a.G = r.g(m->aR); a.osums = r.bsums(m->aR); a.bn = r.ref(m->aR, true);
+      a.H = 14; a.W = 14; a.C = 64; a.coff = 0; a.reorg = 2; a.oR = c->R[m->aR];
+      r.ok(spb_bn_bwd_prep(dt, &a, stream));
+    }
+    r.pw_bwd(m->router, r.block_out(13, true), m->aR, -1, c->ws + c->dtap_off, nullptr);
+    r.pw_bwd(m->eP[1], r.src_act(m->aED[1], true), m->aEP[1], m->aED[1], nullptr, nullptr);
+    r.dw_bwd(m->eD[1], r.src_act(m->aEP[0], true), 7, m->aED[1], m->aEP[0], nullptr, nullptr);
+    r.pw_bwd(m->eP[0], r.src_act(m->aED[0], true), m->aEP[0], m->aED[0], nullptr, nullptr);
+    r.dw_bwd(m->eD[0], r.block_out(17, true), 7, m->aED[0], aF, nullptr, ddom);
+  } else {
+    // target-domain pass of DANN: only the domain loss reaches the backbone (dann.py:89-92)
+    spb_bnbwd_args_t a; std::memset(&a, 0, sizeof(a));
+    a.dY = ddom; a.Z = r.z(aF); a.G = r.g(aF); a.osums = r.bsums(aF); a.bn = r.ref(aF, true);
+    a.B = c->B; a.H = 7; a.W = 7; a.C = 320; a.ldc = 320; a.coff = 0; a.reorg = 0; a.oR = c->R[aF];
+    r.ok(spb_bn_bwd_prep(dt, &a, stream));
+  }
+  // inverted residual blocks, last to first
+  for (int k = 17; k >= 1; --k) {
+    const Block& b = m->blk[k];
+    const Src in = k == 1 ? r.src_act(m->aStem, true) : r.block_out(k - 1, true);
+    const int atgt = k == 1 ? m->aStem : m->blk[k - 1].aP;
+    // gradient joining the block input besides this block's own path
+    const void* res = nullptr;
+    if (b.res) res = r.g(b.aP);                                  // skip connection: d y_{k-1} += d y_k
+    else if (k == 14 && with_pose) res = c->ws + c->dtap_off;    // RouterV2 branch taps block 13's output
+    r.pw_bwd(b.P, r.src_act(b.aD, true), b.aP, b.aD, nullptr, nullptr);
+    if (b.t != 1) {
+      r.dw_bwd(b.D, r.src_act(b.aE, true), b.Hin, b.aD, b.aE, nullptr, nullptr);
+      r.pw_bwd(b.E, in, b.aE, atgt, nullptr, res);
+    } else {
+      r.dw_bwd(b.D, in, b.Hin, b.aD, atgt, nullptr, res);
+    }
+  }
+  // stem weight gradient (the image needs no gradient)
+  {
+    spb_bnref_t pro = r.ref(m->aStem, true);
+    r.ok(spb_stem_wgrad(dt, c->x, r.g(m->aStem), r.z(m->aStem), &pro, m->G + m->stem_w_off, c->B, kIn, kIn, stream));
+  }
+  // BatchNorm affine gradients: dgamma += sum(g*xhat), dbeta += sum(g)
+  r.ok(spb_bn_param_grads(reinterpret_cast<const spb_bnupd_entry_t*>(c->ws + c->table_off), (int)m->bns.size(), r.stats(),
+                          m->G, stream));
+  hipError_t le = hipGetLastError();
+  if (le != hipSuccess && r.err == 0) r.err = (int)le;
+  return r.err;
+}

@@ -1,0 +1,443 @@
+// The two dense convolutions of KRN that are not 1x1/depthwise:
+//   stem  Conv2d(3,32,3,stride 2,pad 1,bias=False) on the NCHW f32 image  (torchvision mobilenet_v2.features[0],
+//         reached through reference park2019.py:107-108)
+//   head  Conv2d(1024,2K,kernel 7) on the 7x7 map, i.e. one fully-connected layer over (h,w,c), followed by the
+//         (x,y) de-interleave and the summed per-keypoint MSE (park2019.py:121,139-162).
+#include "common.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------ stem forward
+// thread = (output pixel, group of 8 output channels); weights live in LDS as [tap][co] so the 4 channel groups
+// of a pixel read 4 distinct 32-byte rows.  Output is written as NHWC 16-byte vectors (64 B contiguous per pixel).
+template <typename T>
+__global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                       T* __restrict__ y, float* osums, int oR, int B, int H, int W) {
+  __shared__ __attribute__((aligned(16))) float wl[27 * 32];
+  __shared__ float red[64];
+  const int t = threadIdx.x;
+  for (int i = t; i < 27 * 32; i += 256) {
+    const int tap = i >> 5, co = i & 31;
+    wl[i] = w[co * 27 + tap];
+  }
+  if (t < 64) red[t] = 0.f;
+  __syncthreads();
+  const int OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1;
+  const long long P = (long long)B * OH * OW;
+  const int cg = t & 3, pl = t >> 2;
+  float s1[8], s2[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
+  for (long long p = (long long)blockIdx.x * 64 + pl; p < P; p += (long long)gridDim.x * 64) {
+    const int ow = (int)(p % OW), oh = (int)((p / OW) % OH), b = (int)(p / ((long long)OW * OH));
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+#pragma unroll
+    for (int ci = 0; ci < 3; ++ci)
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) {
+        const int ih = oh * 2 - 1 + ky;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          const int iw = ow * 2 - 1 + kx;
+          float xv = 0.f;
+          if (ih >= 0 && ih < H && iw >= 0 && iw < W) xv = x[((size_t)(b * 3 + ci) * H + ih) * W + iw];
+          const float* wr = wl + (ci * 9 + ky * 3 + kx) * 32 + cg * 8;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) acc[j] += xv * wr[j];
+        }
+      }
+    rnd8<T>(acc);
+    st8<T>(y + (size_t)p * 32 + cg * 8, acc);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { s1[j] += acc[j]; s2[j] += acc[j] * acc[j]; }
+  }
+  if (osums) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      atomicAdd(&red[cg * 8 + j], s1[j]);
+      atomicAdd(&red[32 + cg * 8 + j], s2[j]);
+    }
+    __syncthreads();
+    if (t < 64) atomicAdd(osums + (size_t)(blockIdx.x % oR) * 64 + t, red[t]);
+  }
+}
+
+// dW[co,ci,ky,kx] += sum_pixels dz[pixel,co] * x[pixel -> (ci,ky,kx)];  thread = (pixel, 8 co, ci) -> 72 partials
+template <typename T>
+__global__ __launch_bounds__(192) void stem_wgrad_kernel(const float* __restrict__ x, const T* __restrict__ G,
+                                                         const T* __restrict__ Z, const spb_bnref_t pro, float* dW,
+                                                         int B, int H, int W) {
+  __shared__ float red[32 * 27];
+  const int t = threadIdx.x;
+  for (int i = t; i < 32 * 27; i += 192) red[i] = 0.f;
+  __syncthreads();
+  const int OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1;
+  const long long P = (long long)B * OH * OW;
+  const int sub = t % 12, pl = t / 12;
+  const int cg = sub & 3, ci = sub >> 2;
+  float p0[8], p1[8], p2[8], aw[9][8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    bn_bwd_coef(pro, cg * 8 + j, p0[j], p1[j], p2[j]);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) aw[k][j] = 0.f;
+  }
+  for (long long p = (long long)blockIdx.x * 16 + pl; p < P; p += (long long)gridDim.x * 16) {
+    const int ow = (int)(p % OW), oh = (int)((p / OW) % OH), b = (int)(p / ((long long)OW * OH));
+    float g[8], z[8], dz[8];
+    ld8<T>(G + (size_t)p * 32 + cg * 8, g);
+    ld8<T>(Z + (size_t)p * 32 + cg * 8, z);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) dz[j] = g[j] * p0[j] + z[j] * p1[j] + p2[j];
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      const int ih = oh * 2 - 1 + ky;
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int iw = ow * 2 - 1 + kx;
+        float xv = 0.f;
+        if (ih >= 0 && ih < H && iw >= 0 && iw < W) xv = x[((size_t)(b * 3 + ci) * H + ih) * W + iw];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) aw[ky * 3 + kx][j] += xv * dz[j];
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 9; ++k)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) atomicAdd(&red[(cg * 8 + j) * 27 + ci * 9 + k], aw[k][j]);
+  __syncthreads();
+  for (int i = t; i < 32 * 27; i += 192) atomicAdd(dW + i, red[i]);
+}
+
+// ------------------------------------------------------------------------------------------------ head forward
+// out[b,j] = sum_k relu(bn(z))[b,k] * Wp[j,k],  K = HW*C = 50 176.  Skinny GEMM (M = batch, N = 2K keypoints):
+// split K over all waves of the grid, fragments straight from HBM (each operand element is used by one wave),
+// partial [wave][B][Jp] tiles reduced by the loss kernel.
+template <typename T>
+__global__ __launch_bounds__(256) void head_fwd_kernel(const spb_head_args_t a, int kchunk) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* sc = reinterpret_cast<float*>(smem);  // [C]
+  float* sh = sc + a.C;
+  const int t = threadIdx.x, l = t & 63, w = t >> 6, li = l & 15, lq = l >> 4;
+  for (int c = t; c < a.C; c += 256) bn_fwd_coef(a.pro, c, sc[c], sh[c]);
+  __syncthreads();
+  const int KH = a.HW * a.C;
+  const int wave = blockIdx.x * 4 + w;
+  const int kbeg = wave * kchunk, kend = min(KH, kbeg + kchunk);
+  const T* Z = reinterpret_cast<const T*>(a.Z);
+  const T* Wp = reinterpret_cast<const T*>(a.Wp);
+  const int NJ = a.Jp / 16;  // <= 2
+  for (int bb = 0; bb < a.B; bb += 64) {
+    f32x4_t acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    if constexpr (sizeof(T) == 2) {
+      for (int k = kbeg; k < kend; k += 32) {
+        const int kk = k + lq * 8;
+        const int c0 = kk % a.C;
+        bf16x8_t bf[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          uint4 u = make_uint4(0, 0, 0, 0);
+          if (j < NJ) u = *reinterpret_cast<const uint4*>(Wp + (size_t)(j * 16 + li) * KH + kk);
+          bf[j] = __builtin_bit_cast(bf16x8_t, u);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int b = bb + i * 16 + li;
+          float v[8];
+          if (b < a.B) {
+            ld8<T>(Z + (size_t)b * KH + kk, v);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = act_fwd(v[e] * sc[c0 + e] + sh[c0 + e], a.pro.act, a.pro.slope);
+          } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = 0.f;
+          }
+          uint4 u;
+          u.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
+          u.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+          u.z = (uint32_t)f2bf(v[4]) | ((uint32_t)f2bf(v[5]) << 16);
+          u.w = (uint32_t)f2bf(v[6]) | ((uint32_t)f2bf(v[7]) << 16);
+          const bf16x8_t af = __builtin_bit_cast(bf16x8_t, u);
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bf[j], acc[i][j], 0, 0, 0);
+        }
+      }
+    } else {
+      // f32: each lane owns 4 consecutive k; MFMA step s pairs element s of every lane (same k set on both sides)
+      for (int k = kbeg; k < kend; k += 16) {
+        const int kk = k + lq * 4;
+        const int c0 = kk % a.C;
+        float bw[2][4];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          float4 u = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (j < NJ) u = *reinterpret_cast<const float4*>(Wp + (size_t)(j * 16 + li) * KH + kk);
+          bw[j][0] = u.x; bw[j][1] = u.y; bw[j][2] = u.z; bw[j][3] = u.w;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int b = bb + i * 16 + li;
+          float av[4] = {0.f, 0.f, 0.f, 0.f};
+          if (b < a.B) {
+            const float4 u = *reinterpret_cast<const float4*>(Z + (size_t)b * KH + kk);
+            av[0] = u.x; av[1] = u.y; av[2] = u.z; av[3] = u.w;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) av[e] = act_fwd(av[e] * sc[c0 + e] + sh[c0 + e], a.pro.act, a.pro.slope);
+          }
+#pragma unroll
+          for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bw[j][s], acc[i][j], 0, 0, 0);
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int b = bb + i * 16 + lq * 4 + r, col = j * 16 + li;
+          if (b < a.B && col < a.Jp) a.partial[((size_t)wave * a.B + b) * a.Jp + col] = acc[i][j][r];
+        }
+  }
+}
+
+// pred = sum of split-K partials + bias; loss = sum_k mean_b (x-tx)^2 + (y-ty)^2 (park2019.py:142-156)
+__global__ __launch_bounds__(256) void head_loss_kernel(const spb_head_args_t a) {
+  __shared__ float rx[256], ry[256];
+  const int t = threadIdx.x;
+  const int nK = a.J / 2;
+  float lx = 0.f, ly = 0.f;
+  for (int idx = t; idx < a.B * a.J; idx += 256) {
+    const int b = idx / a.J, j = idx % a.J;
+    float s = a.bias ? a.bias[j] : 0.f;
+    for (int w = 0; w < a.S; ++w) s += a.partial[((size_t)w * a.B + b) * a.Jp + j];
+    a.pred[idx] = s;
+    if (a.target) {
+      const float tg = a.target[(size_t)b * a.J + (j & 1) * nK + (j >> 1)];
+      const float d = s - tg;
+      if (j & 1) ly += d * d; else lx += d * d;
+      a.dout[idx] = 2.f * d / (float)a.B;
+    }
+  }
+  rx[t] = lx; ry[t] = ly;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (t < o) { rx[t] += rx[t + o]; ry[t] += ry[t + o]; }
+    __syncthreads();
+  }
+  if (t == 0 && a.target && a.scalars) {
+    const float fx = rx[0] / (float)a.B, fy = ry[0] / (float)a.B;
+    a.scalars[0] = fx + fy; a.scalars[1] = fx; a.scalars[2] = fy;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ head backward
+// blockIdx.y == 0: dA = dout * Wp, masked by relu'(bn(z)), plus sum(g), sum(g*xhat) for the BN below
+// blockIdx.y == 1: dW[j,c,hw] += sum_b dout[b,j] * relu(bn(z))[b,hw,c];  block 0 also adds dbias
+template <typename T>
+__global__ __launch_bounds__(256) void head_bwd_kernel(const spb_head_bwd_args_t a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* ds = reinterpret_cast<float*>(smem);     // [B][J] upstream gradient * gscale
+  float* wl = ds + ((a.B * a.J + 3) & ~3);        // role 0: [J][512] weight slab;  role 1 unused
+  float* red = wl + (size_t)a.J * 512;            // [2][512]
+  const int t = threadIdx.x;
+  const int KH = a.HW * a.C;
+  const int kbase = blockIdx.x * 512;
+  const T* Z = reinterpret_cast<const T*>(a.Z);
+  const T* Wp = reinterpret_cast<const T*>(a.Wp);
+  for (int i = t; i < a.B * a.J; i += 256) ds[i] = a.dout[i] * a.gscale;
+  const int k8 = t & 63, sub = t >> 6;
+  const int k = kbase + k8 * 8;
+  const bool kok = k < KH;
+  const int c0 = k % a.C;
+  float sc[8], sh[8], mu[8], is[8];
+  if (kok) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      bn_moments(a.pro, c0 + j, mu[j], is[j]);
+      sc[j] = a.pro.gamma[c0 + j] * is[j];
+      sh[j] = a.pro.beta[c0 + j] - mu[j] * sc[j];
+    }
+  }
+  if (blockIdx.y == 0) {
+    for (int i = t; i < a.J * 64; i += 256) {
+      const int j = i >> 6, v8 = i & 63;
+      float v[8];
+      if (kbase + v8 * 8 < KH) ld8<T>(Wp + (size_t)j * KH + kbase + v8 * 8, v);
+      else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = 0.f;
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) wl[j * 512 + v8 * 8 + e] = v[e];
+    }
+    for (int i = t; i < 1024; i += 256) red[i] = 0.f;
+    __syncthreads();
+    T* G = reinterpret_cast<T*>(a.G);
+    float s1[8], s2[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
+    if (kok) {
+      for (int b = sub; b < a.B; b += 4) {
+        float da[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) da[e] = 0.f;
+        for (int j = 0; j < a.J; ++j) {
+          const float d = ds[b * a.J + j];
+          const float4 w0 = *reinterpret_cast<const float4*>(wl + j * 512 + k8 * 8);
+          const float4 w1 = *reinterpret_cast<const float4*>(wl + j * 512 + k8 * 8 + 4);
+          da[0] += d * w0.x; da[1] += d * w0.y; da[2] += d * w0.z; da[3] += d * w0.w;
+          da[4] += d * w1.x; da[5] += d * w1.y; da[6] += d * w1.z; da[7] += d * w1.w;
+        }
+        float z[8];
+        ld8<T>(Z + (size_t)b * KH + k, z);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float u = z[e] * sc[e] + sh[e];
+          da[e] = rnd<T>(da[e] * act_grad(u, a.pro.act, a.pro.slope));
+          s1[e] += da[e];
+          s2[e] += da[e] * ((z[e] - mu[e]) * is[e]);
+        }
+        st8<T>(G + (size_t)b * KH + k, da);
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        atomicAdd(&red[k8 * 8 + e], s1[e]);
+        atomicAdd(&red[512 + k8 * 8 + e], s2[e]);
+      }
+    }
+    __syncthreads();
+    for (int i = t; i < 1024; i += 256) {
+      const int which = i >> 9, kk = kbase + (i & 511);
+      if (kk < KH) {
+        const int rep = blockIdx.x % a.oR;
+        atomicAdd(a.osums + (size_t)rep * 2 * a.C + (size_t)which * a.C + (kk % a.C), red[i]);
+      }
+    }
+  } else {
+    __syncthreads();
+    if (blockIdx.x == 0 && t < a.J) {
+      float s = 0.f;
+      for (int b = 0; b < a.B; ++b) s += ds[b * a.J + t];
+      a.dbias[t] += s;
+    }
+    if (kok) {
+      // this thread owns j = sub, sub+4, ... (at most 8 of them for J <= 32)
+      float aw[8][8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) aw[q][e] = 0.f;
+      for (int b = 0; b < a.B; ++b) {
+        float z[8];
+        ld8<T>(Z + (size_t)b * KH + k, z);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) z[e] = act_fwd(z[e] * sc[e] + sh[e], a.pro.act, a.pro.slope);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const int j = sub + 4 * q;
+          if (j < a.J) {
+            const float d = ds[b * a.J + j];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) aw[q][e] += d * z[e];
+          }
+        }
+      }
+      const int hw = k / a.C;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int j = sub + 4 * q;
+        if (j < a.J) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) a.dW[((size_t)j * a.C + c0 + e) * a.HW + hw] += aw[q][e];
+        }
+      }
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int spb_stem_fwd(int dtype, const float* x, const float* w, void* y, float* osums, int oR, int B, int H,
+                            int W, spb_stream_t stream) {
+  if (!x || !w || !y || B <= 0 || H <= 0 || W <= 0) return SPB_E_ARG;
+  const int OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1;
+  long long P = (long long)B * OH * OW;
+  int grid = (int)((P + 64 * 8 - 1) / (64 * 8));
+  if (grid > 2048) grid = 2048;
+  if (dtype == SPB_BF16)
+    hipLaunchKernelGGL(stem_fwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, w, (bf16_t*)y, osums, oR, B, H, W);
+  else if (dtype == SPB_F32)
+    hipLaunchKernelGGL(stem_fwd_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, w, (float*)y, osums, oR, B, H, W);
+  else return SPB_E_ARG;
+  SPB_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int spb_stem_wgrad(int dtype, const float* x, const void* G, const void* Z, const spb_bnref_t* pro,
+                              float* dW, int B, int H, int W, spb_stream_t stream) {
+  if (!x || !G || !Z || !pro || !dW) return SPB_E_ARG;
+  const int OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1;
+  long long P = (long long)B * OH * OW;
+  int grid = (int)((P + 16 * 32 - 1) / (16 * 32));
+  if (grid > 1024) grid = 1024;
+  if (grid < 1) grid = 1;
+  if (dtype == SPB_BF16)
+    hipLaunchKernelGGL(stem_wgrad_kernel<bf16_t>, dim3(grid), dim3(192), 0, (hipStream_t)stream, x, (const bf16_t*)G, (const bf16_t*)Z, *pro, dW, B, H, W);
+  else if (dtype == SPB_F32)
+    hipLaunchKernelGGL(stem_wgrad_kernel<float>, dim3(grid), dim3(192), 0, (hipStream_t)stream, x, (const float*)G, (const float*)Z, *pro, dW, B, H, W);
+  else return SPB_E_ARG;
+  SPB_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int spb_head_fwd(int dtype, const spb_head_args_t* a, spb_stream_t stream) {
+  if (!a || !a->Z || !a->Wp || !a->partial || !a->pred) return SPB_E_ARG;
+  if (a->B <= 0 || a->J <= 0 || a->J > 32 || (a->J & 1) || a->Jp < a->J || (a->Jp & 15) || a->Jp > 32) return SPB_E_SHAPE;
+  if ((a->C & 7) || a->S <= 0 || (a->S & 3)) return SPB_E_SHAPE;
+  if (a->target && (!a->dout || !a->scalars)) return SPB_E_ARG;
+  const int KH = a->HW * a->C;
+  const int kchunk = spb_ceil_div(spb_ceil_div(KH, a->S), 32) * 32;
+  const size_t lds = (size_t)2 * a->C * sizeof(float);
+  if (dtype == SPB_BF16)
+    hipLaunchKernelGGL(head_fwd_kernel<bf16_t>, dim3(a->S / 4), dim3(256), lds, (hipStream_t)stream, *a, kchunk);
+  else if (dtype == SPB_F32)
+    hipLaunchKernelGGL(head_fwd_kernel<float>, dim3(a->S / 4), dim3(256), lds, (hipStream_t)stream, *a, kchunk);
+  else return SPB_E_ARG;
+  SPB_CHECK_LAUNCH();
+  hipLaunchKernelGGL(head_loss_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, *a);
+  SPB_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int spb_head_bwd(int dtype, const spb_head_bwd_args_t* a, spb_stream_t stream) {
+  if (!a || !a->Z || !a->Wp || !a->dout || !a->G || !a->osums || !a->dW || !a->dbias || !a->pro.gamma) return SPB_E_ARG;
+  if (a->B <= 0 || a->J <= 0 || a->J > 32 || (a->C & 7) || a->oR < 1) return SPB_E_SHAPE;
+  const int KH = a->HW * a->C;
+  const int gx = spb_ceil_div(KH, 512);
+  const size_t lds = ((size_t)((a->B * a->J + 3) & ~3) + (size_t)a->J * 512 + 1024) * sizeof(float);
+  if (lds > 160 * 1024) return SPB_E_SHAPE;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&head_bwd_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&head_bwd_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_done = true;
+  }
+  if (dtype == SPB_BF16)
+    hipLaunchKernelGGL(head_bwd_kernel<bf16_t>, dim3(gx, 2), dim3(256), lds, (hipStream_t)stream, *a);
+  else if (dtype == SPB_F32)
+    hipLaunchKernelGGL(head_bwd_kernel<float>, dim3(gx, 2), dim3(256), lds, (hipStream_t)stream, *a);
+  else return SPB_E_ARG;
+  SPB_CHECK_LAUNCH();
+  return 0;
+}

@@ -1,0 +1,193 @@
+"""Thin torch-tensor front end of the per-kernel C-ABI entry points (used by the parity tests and by callers that
+want a single fused op).  Tensors are device memory only; all arithmetic happens in libspb_hip.so.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+
+_DT = {torch.float32: L.F32, torch.bfloat16: L.BF16}
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _need_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("speedplusbaseline_amd ops run on the GPU only (got a %s tensor)" % t.device)
+        if t is not None and not t.is_contiguous():
+            raise RuntimeError("speedplusbaseline_amd ops need contiguous tensors")
+
+
+def dtype_code(t):
+    try:
+        return _DT[t.dtype]
+    except KeyError:
+        raise RuntimeError("activation dtype must be float32 or bfloat16, got %s" % t.dtype)
+
+
+def bnref(C_, sums=None, gamma=None, beta=None, bsums=None, n=1, R=1, act=L.ACT_NONE, slope=0.0, eps=1e-5, moments=0):
+    """spb_bnref_t from f32 tensors. gamma=None means identity (already normalised tensor)."""
+    _need_cuda(sums, gamma, beta, bsums)
+    r = L.BNRef()
+    r.sums = _ptr(sums); r.gamma = _ptr(gamma); r.beta = _ptr(beta); r.bsums = _ptr(bsums)
+    r.inv_n = 1.0 / float(n); r.eps = eps; r.slope = slope; r.C = C_; r.R = R; r.act = act; r.moments = moments
+    r._keep = (sums, gamma, beta, bsums)
+    return r
+
+
+def pwconv_gemm(A, Bw, Y, pro, pro_mode, epi_mode, A2=None, res=None, Zout=None, bias=None, osums=None, epi=None,
+                out_act=L.ACT_NONE, oR=1, out_scale=1.0):
+    _need_cuda(A, Bw, Y, A2, res, Zout, bias, osums)
+    g = L.GemmArgs()
+    g.A = _ptr(A); g.A2 = _ptr(A2); g.Bw = _ptr(Bw); g.Y = _ptr(Y); g.res = _ptr(res); g.Zout = _ptr(Zout)
+    g.bias = _ptr(bias); g.osums = _ptr(osums); g.pro = pro
+    g.epi = epi if epi is not None else bnref(Y.shape[-1])
+    g.M, g.K = A.shape[0], A.shape[1]; g.N = Bw.shape[0]
+    g.pro_mode = pro_mode; g.epi_mode = epi_mode; g.out_act = out_act; g.oR = oR; g.out_scale = out_scale
+    L.check(L.lib().spb_pwconv_gemm(dtype_code(A), C.byref(g), _stream()), "spb_pwconv_gemm")
+
+
+def pwconv_wgrad(G, X, dW, pro_dz, pro_a, Zn=None):
+    _need_cuda(G, X, dW, Zn)
+    w = L.WgradArgs()
+    w.G = _ptr(G); w.Zn = _ptr(Zn); w.X = _ptr(X); w.dW = _ptr(dW); w.pro_dz = pro_dz; w.pro_a = pro_a
+    w.M = G.shape[0]; w.N = G.shape[1]; w.K = X.shape[1]
+    L.check(L.lib().spb_pwconv_wgrad(dtype_code(G), C.byref(w), _stream()), "spb_pwconv_wgrad")
+
+
+def _dwargs(X, Wd, B, H, W_, C_, stride, **kw):
+    d = L.DwArgs()
+    d.X = _ptr(X); d.Wd = _ptr(Wd); d.B = B; d.H = H; d.W = W_; d.C = C_; d.stride = stride
+    for k, v in kw.items():
+        if isinstance(v, torch.Tensor) or v is None:
+            setattr(d, k, _ptr(v))
+        else:
+            setattr(d, k, v)
+    ident = bnref(C_)
+    for k in ("pro", "pro_in", "epi"):
+        if k not in kw:
+            setattr(d, k, ident)
+    if "oR" not in kw:
+        d.oR = 1
+    return d
+
+
+def dwconv_fwd(X, Wd, Y, pro, stride, osums=None, oR=1):
+    B, H, W_, C_ = X.shape
+    _need_cuda(X, Wd, Y, osums)
+    d = _dwargs(X, Wd, B, H, W_, C_, stride, Y=Y, pro=pro, osums=osums, oR=oR, epi_mode=1 if osums is not None else 0)
+    L.check(L.lib().spb_dwconv_fwd(dtype_code(X), C.byref(d), _stream()), "spb_dwconv_fwd")
+
+
+def dwconv_dgrad(G, Z, Wd, Y, pro, stride, in_hw, epi=None, Zout=None, res=None, osums=None, oR=1):
+    B, C_ = G.shape[0], G.shape[3]
+    _need_cuda(G, Z, Wd, Y, Zout, res, osums)
+    kw = dict(X2=Z, Y=Y, pro=pro, epi_mode=2 if epi is not None else 0, oR=oR)
+    if epi is not None:
+        kw.update(epi=epi, Zout=Zout, res=res, osums=osums)
+    d = _dwargs(G, Wd, B, in_hw[0], in_hw[1], C_, stride, **kw)
+    L.check(L.lib().spb_dwconv_dgrad(dtype_code(G), C.byref(d), _stream()), "spb_dwconv_dgrad")
+
+
+def dwconv_wgrad(G, Z, Xin, Wd, dW, pro, pro_in, stride):
+    B, H, W_, C_ = Xin.shape
+    _need_cuda(G, Z, Xin, Wd, dW)
+    d = _dwargs(G, Wd, B, H, W_, C_, stride, X2=Z, Xin=Xin, dW=dW, pro=pro, pro_in=pro_in)
+    L.check(L.lib().spb_dwconv_wgrad(dtype_code(G), C.byref(d), _stream()), "spb_dwconv_wgrad")
+
+
+def stem_fwd(x_nchw, w, y_nhwc, osums=None, oR=1):
+    _need_cuda(x_nchw, w, y_nhwc, osums)
+    B, _, H, W_ = x_nchw.shape
+    L.check(L.lib().spb_stem_fwd(dtype_code(y_nhwc), _ptr(x_nchw), _ptr(w), _ptr(y_nhwc), _ptr(osums), oR, B, H, W_,
+                                 _stream()), "spb_stem_fwd")
+
+
+def stem_wgrad(x_nchw, G, Z, pro_dz, dW):
+    _need_cuda(x_nchw, G, Z, dW)
+    B, _, H, W_ = x_nchw.shape
+    L.check(L.lib().spb_stem_wgrad(dtype_code(G), _ptr(x_nchw), _ptr(G), _ptr(Z), C.byref(pro_dz), _ptr(dW), B, H, W_,
+                                   _stream()), "spb_stem_wgrad")
+
+
+def bn_apply(Z, Y, bn, res=None, bn_res=None, ldc=None, coff=0, reorg=0):
+    _need_cuda(Z, Y, res)
+    B, H, W_, C_ = Z.shape
+    a = L.BnApplyArgs()
+    a.Z = _ptr(Z); a.res = _ptr(res); a.Y = _ptr(Y); a.bn = bn
+    a.bn_res = bn_res if bn_res is not None else bnref(C_)
+    a.B, a.H, a.W, a.C = B, H, W_, C_
+    a.ldc = ldc if ldc is not None else C_
+    a.coff = coff; a.reorg = reorg
+    L.check(L.lib().spb_bn_apply(dtype_code(Z), C.byref(a), _stream()), "spb_bn_apply")
+
+
+def bn_bwd_prep(dY, Z, G, osums, bn, ldc=None, coff=0, reorg=0, oR=1):
+    _need_cuda(dY, Z, G, osums)
+    B, H, W_, C_ = Z.shape
+    a = L.BnBwdArgs()
+    a.dY = _ptr(dY); a.Z = _ptr(Z); a.G = _ptr(G); a.osums = _ptr(osums); a.bn = bn
+    a.B, a.H, a.W, a.C = B, H, W_, C_
+    a.ldc = ldc if ldc is not None else C_
+    a.coff = coff; a.reorg = reorg; a.oR = oR
+    L.check(L.lib().spb_bn_bwd_prep(dtype_code(Z), C.byref(a), _stream()), "spb_bn_bwd_prep")
+
+
+def head_fwd(Z, Wp, bias, pro, J, HW, C_, target=None, S=256):
+    """Z [B, HW*C]; Wp [Jp, HW*C] (compute dtype). Returns pred [B,J], scalars [3], dout [B,J]."""
+    _need_cuda(Z, Wp, bias, target)
+    B = Z.shape[0]
+    Jp = Wp.shape[0]
+    dev = Z.device
+    partial = torch.empty(S * B * Jp, dtype=torch.float32, device=dev)
+    pred = torch.empty(B, J, dtype=torch.float32, device=dev)
+    dout = torch.zeros(B, J, dtype=torch.float32, device=dev)
+    scalars = torch.zeros(3, dtype=torch.float32, device=dev)
+    h = L.HeadArgs()
+    h.Z = _ptr(Z); h.Wp = _ptr(Wp); h.bias = _ptr(bias); h.target = _ptr(target); h.partial = _ptr(partial)
+    h.pred = _ptr(pred); h.dout = _ptr(dout); h.scalars = _ptr(scalars); h.pro = pro
+    h.B, h.J, h.Jp, h.HW, h.C, h.S = B, J, Jp, HW, C_, S
+    L.check(L.lib().spb_head_fwd(dtype_code(Z), C.byref(h), _stream()), "spb_head_fwd")
+    return pred, scalars, dout
+
+
+def head_bwd(Z, Wp, dout, G, osums, dW, dbias, pro, J, HW, C_, gscale=1.0, oR=1):
+    _need_cuda(Z, Wp, dout, G, osums, dW, dbias)
+    h = L.HeadBwdArgs()
+    h.Z = _ptr(Z); h.Wp = _ptr(Wp); h.dout = _ptr(dout); h.G = _ptr(G); h.osums = _ptr(osums); h.dW = _ptr(dW)
+    h.dbias = _ptr(dbias); h.pro = pro; h.gscale = gscale
+    h.B, h.J, h.Jp, h.HW, h.C, h.oR = Z.shape[0], J, Wp.shape[0], HW, C_, oR
+    L.check(L.lib().spb_head_bwd(dtype_code(Z), C.byref(h), _stream()), "spb_head_bwd")
+
+
+def grad_sqnorm(grads, out):
+    _need_cuda(grads, out)
+    L.check(L.lib().spb_grad_sqnorm(_ptr(grads), grads.numel(), _ptr(out), _stream()), "spb_grad_sqnorm")
+
+
+OPT_KIND = {"sgd": 0, "rmsprop": 1, "adam": 2, "adamw": 3}
+
+
+def optim_step(kind, params, grads, m=None, v=None, sqnorm=None, gmul=None, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8,
+               weight_decay=0.0, max_norm=0.0, clip_value=0.0, step=1, first_step=False):
+    _need_cuda(params, grads, m, v, sqnorm, gmul)
+    a = L.OptimArgs()
+    a.params = _ptr(params); a.grads = _ptr(grads); a.m = _ptr(m); a.v = _ptr(v); a.sqnorm = _ptr(sqnorm)
+    a.gmul = _ptr(gmul); a.mask = None; a.n = params.numel(); a.kind = OPT_KIND[kind]
+    a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.weight_decay = weight_decay
+    a.max_norm = max_norm; a.clip_value = clip_value
+    a.bias_c1 = 1.0 - beta1 ** step; a.bias_c2 = 1.0 - beta2 ** step; a.first_step = 1 if first_step else 0
+    L.check(L.lib().spb_optim_step(C.byref(a), _stream()), "spb_optim_step")
+
+
+def debug_trread(inp, out):
+    _need_cuda(inp, out)
+    L.check(L.lib().spb_debug_trread(_ptr(inp), _ptr(out), _stream()), "spb_debug_trread")

@@ -1,0 +1,399 @@
+"""Per-kernel parity: each HIP entry point of libspb_hip.so against a float64 PyTorch (CPU) reference of the same op.
+
+Backward kernels are checked against torch.autograd through the composite
+    z_in -> act1(bn1(z_in)) -> conv -> bn2 -> act2 -> loss
+so the (g, sum g, sum g*xhat) contract between kernels is pinned to autograd's definition of BatchNorm backward.
+Tolerances: f32 mode 2e-5 relative (exact f32 MFMA, different summation order); bf16 mode 2e-2 relative (operands
+are rounded to bf16 before the matrix cores, accumulation is f32).
+"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from speedplusbaseline_amd import _lib as L  # noqa: E402
+from speedplusbaseline_amd import ops  # noqa: E402
+
+DTYPES = [torch.float32, torch.bfloat16]
+TOL = {torch.float32: 2e-5, torch.bfloat16: 2e-2}
+EPS = 1e-5
+
+
+def relerr(a, b):
+    a = a.detach().double().cpu(); b = b.detach().double().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def rt(x, dt):
+    """round-trip through the storage dtype (what the kernels read)"""
+    return x.to(dt).double()
+
+
+def act_fn(u, act, slope=0.2):
+    if act == L.ACT_RELU: return F.relu(u)
+    if act == L.ACT_RELU6: return F.relu6(u)
+    if act == L.ACT_LEAKY: return F.leaky_relu(u, slope)
+    return u
+
+
+def bn_train(z2d, gamma, beta):
+    mean = z2d.mean(0); var = z2d.var(0, unbiased=False)
+    xhat = (z2d - mean) / torch.sqrt(var + EPS)
+    return xhat * gamma + beta, xhat
+
+
+def sums_of(z2d, R, dev):
+    """[R][2][C] replicas that add up to (sum z, sum z^2)"""
+    C = z2d.shape[1]
+    s = torch.stack([z2d.sum(0), (z2d * z2d).sum(0)])  # [2][C]
+    w = torch.rand(R, 1, 1, dtype=torch.float64) + 0.1
+    w = w / w.sum()
+    return (w * s.unsqueeze(0)).float().contiguous().to(dev)
+
+
+def test_trread_semantics(device):
+    """pins ds_read_b64_tr_b16: lane i of a 16-lane group gets column i of the 4x16 block whose row r is supplied
+    by lanes 4r..4r+3 (4 consecutive elements each)."""
+    inp = torch.arange(4096, dtype=torch.int16, device=device)
+    out = torch.zeros(256, dtype=torch.int16, device=device)
+    ops.debug_trread(inp, out)
+    torch.cuda.synchronize()
+    out = out.cpu().view(64, 4).long()
+    exp = torch.zeros(64, 4, dtype=torch.long)
+    for l in range(64):
+        q, i = l // 16, l % 16
+        for j in range(4):
+            # block row j is held by lanes 4j..4j+3 of the group; column i lives in lane 4j + i//4, element i%4
+            src_lane = q * 16 + 4 * j + i // 4
+            exp[l, j] = src_lane * 4 + i % 4
+    assert torch.equal(out, exp), (out[:20], exp[:20])
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("M,K,N,act,R", [(300, 24, 144, L.ACT_RELU6, 1), (1000, 144, 32, L.ACT_RELU6, 3),
+                                          (257, 320, 1024, L.ACT_NONE, 1), (2352, 96, 64, L.ACT_RELU, 2),
+                                          (129, 16, 96, L.ACT_NONE, 8)])
+def test_pw_gemm_fwd(device, dt, M, K, N, act, R):
+    torch.manual_seed(M + K + N)
+    zin = rt(torch.randn(M, K, dtype=torch.float64) * 1.5 + 0.3, dt)
+    gamma = torch.rand(K, dtype=torch.float64) + 0.5; beta = torch.randn(K, dtype=torch.float64) * 0.3
+    W = rt(torch.randn(N, K, dtype=torch.float64) / math.sqrt(K), dt)
+    u, _ = bn_train(zin, gamma, beta)
+    a = act_fn(u, act)
+    y = a @ W.t()
+    pro = ops.bnref(K, sums=sums_of(zin, R, device), gamma=gamma.float().to(device), beta=beta.float().to(device), n=M,
+                    R=R, act=act, slope=0.2)
+    Y = torch.empty(M, N, dtype=dt, device=device)
+    oR = 4
+    osums = torch.zeros(oR, 2, N, dtype=torch.float32, device=device)
+    ops.pwconv_gemm(zin.to(dt).to(device), W.to(dt).to(device), Y, pro, 1, 1, osums=osums, oR=oR)
+    torch.cuda.synchronize()
+    assert relerr(Y, y) < TOL[dt]
+    ys = Y.double().cpu()
+    s = osums.double().cpu().sum(0)
+    assert relerr(s[0], ys.sum(0)) < 1e-4 and relerr(s[1], (ys * ys).sum(0)) < 1e-4
+    # plain epilogue with bias + relu
+    bias = torch.randn(N, dtype=torch.float32, device=device)
+    Y2 = torch.empty(M, N, dtype=dt, device=device)
+    ops.pwconv_gemm(zin.to(dt).to(device), W.to(dt).to(device), Y2, pro, 1, 0, bias=bias, out_act=L.ACT_RELU, out_scale=1.0)
+    torch.cuda.synchronize()
+    assert relerr(Y2, F.relu(y + bias.double().cpu())) < TOL[dt]
+
+
+def _composite(M, K, N, act1, act2, dt, seed):
+    """z_in -> a=act1(bn1) -> z=a W^T -> o=act2(bn2(z)); returns tensors + autograd grads (float64, CPU)"""
+    torch.manual_seed(seed)
+    zin = rt(torch.randn(M, K, dtype=torch.float64) + 0.2, dt).requires_grad_(True)
+    g1 = (torch.rand(K, dtype=torch.float64) + 0.5); b1 = torch.randn(K, dtype=torch.float64) * 0.3
+    g2 = (torch.rand(N, dtype=torch.float64) + 0.5).requires_grad_(True); b2 = (torch.randn(N, dtype=torch.float64) * 0.3).requires_grad_(True)
+    W = rt(torch.randn(N, K, dtype=torch.float64) / math.sqrt(K), dt).requires_grad_(True)
+    u1, xh1 = bn_train(zin, g1, b1); u1.retain_grad()
+    a = act_fn(u1, act1)
+    z = a @ W.t()
+    zq = rt(z.detach(), dt)  # the stored z the kernels see
+    z = z + (zq - z).detach()
+    u2, xh2 = bn_train(z, g2, b2); u2.retain_grad()
+    o = act_fn(u2, act2)
+    Rm = torch.randn(M, N, dtype=torch.float64)
+    (o * Rm).sum().backward()
+    return dict(zin=zin, g1=g1, b1=b1, g2=g2, b2=b2, W=W, u1=u1, xh1=xh1, z=zq, u2=u2, xh2=xh2, a=a.detach())
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("M,K,N,act1,act2", [(300, 24, 144, L.ACT_RELU6, L.ACT_RELU6), (513, 144, 32, L.ACT_RELU6, L.ACT_NONE),
+                                             (260, 96, 64, L.ACT_NONE, L.ACT_LEAKY), (200, 1024, 1024, L.ACT_RELU, L.ACT_RELU)])
+def test_pw_gemm_bwd(device, dt, M, K, N, act1, act2):
+    c = _composite(M, K, N, act1, act2, dt, seed=M * 7 + N)
+    dev = device
+    g2 = rt(c["u2"].grad, dt)  # g = dL/d(bn2 output) with act2' applied by autograd
+    # NB: bsums must be computed from the *stored* g for the chain to be self-consistent
+    bs = torch.stack([g2.sum(0), (g2 * c["xh2"].detach()).sum(0)]).float().unsqueeze(0).contiguous().to(dev)
+    pro = ops.bnref(N, sums=sums_of(c["z"], 1, dev), gamma=c["g2"].detach().float().to(dev), beta=c["b2"].detach().float().to(dev),
+                    bsums=bs, n=M, act=act2, slope=0.2)
+    epi = ops.bnref(K, sums=sums_of(c["zin"].detach(), 2, dev), gamma=c["g1"].float().to(dev), beta=c["b1"].float().to(dev),
+                    n=M, R=2, act=act1, slope=0.2)
+    Wt = c["W"].detach().t().contiguous().to(dt).to(dev)
+    G1 = torch.empty(M, K, dtype=dt, device=dev)
+    osums = torch.zeros(2, 2, K, dtype=torch.float32, device=dev)
+    res = rt(torch.randn(M, K, dtype=torch.float64) * 0.1, dt)
+    ops.pwconv_gemm(g2.to(dt).to(dev), Wt, G1, pro, 2, 2, A2=c["z"].to(dt).to(dev), Zout=c["zin"].detach().to(dt).to(dev),
+                    res=res.to(dt).to(dev), osums=osums, epi=epi, oR=2)
+    torch.cuda.synchronize()
+    # expected: autograd's dL/du1 plus the injected residual gradient routed through act1'
+    u1 = c["u1"].detach()
+    if act1 == L.ACT_RELU6: m1 = ((u1 > 0) & (u1 < 6)).double()
+    elif act1 == L.ACT_RELU: m1 = (u1 > 0).double()
+    elif act1 == L.ACT_LEAKY: m1 = torch.where(u1 > 0, 1.0, 0.2).double()
+    else: m1 = torch.ones_like(u1)
+    exp = c["u1"].grad + res * m1
+    tol = TOL[dt] * (3 if dt == torch.bfloat16 else 1)
+    assert relerr(G1, exp) < tol
+    gs = G1.double().cpu()
+    s = osums.double().cpu().sum(0)
+    assert relerr(s[0], gs.sum(0)) < 1e-3 and relerr(s[1], (gs * c["xh1"].detach()).sum(0)) < 1e-3
+    # weight gradient
+    dW = torch.zeros(N, K, dtype=torch.float32, device=dev)
+    ops.pwconv_wgrad(g2.to(dt).to(dev), c["zin"].detach().to(dt).to(dev), dW, pro, epi, Zn=c["z"].to(dt).to(dev))
+    torch.cuda.synchronize()
+    assert relerr(dW, c["W"].grad) < tol
+    # plain dgrad (no output-side BN): dA = dz W, scaled
+    P = torch.empty(M, K, dtype=dt, device=dev)
+    ops.pwconv_gemm(g2.to(dt).to(dev), Wt, P, pro, 2, 0, A2=c["z"].to(dt).to(dev), out_scale=-0.5)
+    torch.cuda.synchronize()
+    # reconstruct dz in float64 from the same definition
+    xh2 = c["xh2"].detach(); n = float(M)
+    var2 = c["z"].var(0, unbiased=False)
+    dz = c["g2"].detach() / torch.sqrt(var2 + EPS) * (g2 - g2.sum(0) / n - xh2 * (g2 * xh2).sum(0) / n)
+    assert relerr(P, -0.5 * (dz @ c["W"].detach())) < tol
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("B,H,C,stride,act", [(2, 14, 96, 1, L.ACT_RELU6), (3, 15, 32, 2, L.ACT_RELU6), (2, 7, 1280, 1, L.ACT_NONE),
+                                              (2, 28, 144, 2, L.ACT_RELU)])
+def test_dwconv(device, dt, B, H, C, stride, act):
+    torch.manual_seed(B * H + C)
+    dev = device
+    zin = rt(torch.randn(B, C, H, H, dtype=torch.float64) + 0.1, dt).requires_grad_(True)
+    g1 = torch.rand(C, dtype=torch.float64) + 0.5; b1 = torch.randn(C, dtype=torch.float64) * 0.2
+    g2 = torch.rand(C, dtype=torch.float64) + 0.5; b2 = torch.randn(C, dtype=torch.float64) * 0.2
+    Wd = (torch.randn(C, 1, 3, 3, dtype=torch.float64) * 0.3).float().double().requires_grad_(True)
+
+    def bn4(z, g, b):
+        mean = z.mean((0, 2, 3), keepdim=True); var = z.var((0, 2, 3), unbiased=False, keepdim=True)
+        xh = (z - mean) / torch.sqrt(var + EPS)
+        return xh * g.view(1, -1, 1, 1) + b.view(1, -1, 1, 1), xh
+
+    u1, xh1 = bn4(zin, g1, b1); u1.retain_grad()
+    a = act_fn(u1, act)
+    z = F.conv2d(a, Wd, stride=stride, padding=1, groups=C)
+    zq = rt(z.detach(), dt); z = z + (zq - z).detach()
+    u2, xh2 = bn4(z, g2, b2); u2.retain_grad()
+    o = F.relu6(u2)
+    (o * torch.randn_like(o)).sum().backward()
+    OH = z.shape[2]
+    nhwc = lambda t: t.detach().permute(0, 2, 3, 1).contiguous()
+    n_in, n_out = B * H * H, B * OH * OH
+    zin2d = nhwc(zin).view(-1, C); z2d = nhwc(zq).view(-1, C)
+    pro_in = ops.bnref(C, sums=sums_of(zin2d, 2, dev), gamma=g1.float().to(dev), beta=b1.float().to(dev), n=n_in, R=2, act=act)
+    X = nhwc(zin).to(dt).to(dev)
+    Y = torch.empty(B, OH, OH, C, dtype=dt, device=dev)
+    osums = torch.zeros(3, 2, C, dtype=torch.float32, device=dev)
+    Wdev = Wd.detach().float().to(dev).contiguous()
+    ops.dwconv_fwd(X, Wdev, Y, pro_in, stride, osums=osums, oR=3)
+    torch.cuda.synchronize()
+    assert relerr(Y, nhwc(z)) < TOL[dt]
+    ys = Y.double().cpu().view(-1, C); s = osums.double().cpu().sum(0)
+    assert relerr(s[0], ys.sum(0)) < 1e-4 and relerr(s[1], (ys * ys).sum(0)) < 1e-4
+    # backward
+    g2s = rt(nhwc(u2.grad), dt)
+    xh2n = nhwc(xh2).view(-1, C)
+    bs = torch.stack([g2s.view(-1, C).sum(0), (g2s.view(-1, C) * xh2n).sum(0)]).float().unsqueeze(0).contiguous().to(dev)
+    pro = ops.bnref(C, sums=sums_of(z2d, 1, dev), gamma=g2.float().to(dev), beta=b2.float().to(dev), bsums=bs, n=n_out,
+                    act=L.ACT_RELU6)
+    G1 = torch.empty(B, H, H, C, dtype=dt, device=dev)
+    os2 = torch.zeros(2, 2, C, dtype=torch.float32, device=dev)
+    ops.dwconv_dgrad(g2s.to(dt).to(dev), nhwc(zq).to(dt).to(dev), Wdev, G1, pro, stride, (H, H), epi=pro_in, Zout=X,
+                     osums=os2, oR=2)
+    torch.cuda.synchronize()
+    tol = TOL[dt] * (3 if dt == torch.bfloat16 else 1)
+    assert relerr(G1, nhwc(u1.grad)) < tol
+    gs = G1.double().cpu().view(-1, C); s = os2.double().cpu().sum(0)
+    assert relerr(s[0], gs.sum(0)) < 1e-3 and relerr(s[1], (gs * nhwc(xh1).view(-1, C)).sum(0)) < 1e-3
+    dW = torch.zeros(C, 1, 3, 3, dtype=torch.float32, device=dev)
+    ops.dwconv_wgrad(g2s.to(dt).to(dev), nhwc(zq).to(dt).to(dev), X, Wdev, dW, pro, pro_in, stride)
+    torch.cuda.synchronize()
+    assert relerr(dW, Wd.grad) < tol
+    # plain dgrad
+    P = torch.empty(B, H, H, C, dtype=dt, device=dev)
+    ops.dwconv_dgrad(g2s.to(dt).to(dev), nhwc(zq).to(dt).to(dev), Wdev, P, pro, stride, (H, H))
+    torch.cuda.synchronize()
+    assert relerr(P, nhwc(_dw_da(a, Wd, z, g2, g2s, xh2, C, stride))) < tol
+
+
+def _dw_da(a, Wd, z, g2, g2s_nhwc, xh2, C, stride):
+    """d loss / d a for the depthwise conv, rebuilt in float64 from the BN-backward definition"""
+    g = g2s_nhwc.permute(0, 3, 1, 2)
+    n = g.numel() / C
+    xh = xh2.detach()
+    var = z.detach().var((0, 2, 3), unbiased=False, keepdim=True)
+    dz = g2.view(1, -1, 1, 1) / torch.sqrt(var + EPS) * (g - g.sum((0, 2, 3), keepdim=True) / n -
+                                                            xh * (g * xh).sum((0, 2, 3), keepdim=True) / n)
+    ad = a.detach().requires_grad_(True)
+    out = F.conv2d(ad, Wd.detach(), stride=stride, padding=1, groups=C)
+    out.backward(dz)
+    return ad.grad
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_stem(device, dt):
+    torch.manual_seed(5)
+    dev = device
+    B, H = 3, 32
+    x = torch.rand(B, 3, H, H, dtype=torch.float32).double()
+    W = (torch.randn(32, 3, 3, 3) * 0.2).double().requires_grad_(True)
+    g2 = torch.rand(32, dtype=torch.float64) + 0.5; b2 = torch.randn(32, dtype=torch.float64) * 0.2
+    z = F.conv2d(x, W, stride=2, padding=1)
+    zq = rt(z.detach(), dt); z = z + (zq - z).detach()
+    mean = z.mean((0, 2, 3), keepdim=True); var = z.var((0, 2, 3), unbiased=False, keepdim=True)
+    xh = (z - mean) / torch.sqrt(var + EPS)
+    u = xh * g2.view(1, -1, 1, 1) + b2.view(1, -1, 1, 1); u.retain_grad()
+    (F.relu6(u) * torch.randn_like(u)).sum().backward()
+    Y = torch.empty(B, 16, 16, 32, dtype=dt, device=dev)
+    osums = torch.zeros(2, 2, 32, dtype=torch.float32, device=dev)
+    ops.stem_fwd(x.float().to(dev), W.detach().float().to(dev), Y, osums=osums, oR=2)
+    torch.cuda.synchronize()
+    nhwc = lambda t: t.detach().permute(0, 2, 3, 1).contiguous()
+    assert relerr(Y, nhwc(z)) < TOL[dt]
+    ys = Y.double().cpu().view(-1, 32)
+    assert relerr(osums.double().cpu().sum(0)[0], ys.sum(0)) < 1e-4
+    gs = rt(nhwc(u.grad), dt).view(-1, 32)
+    bs = torch.stack([gs.sum(0), (gs * nhwc(xh).view(-1, 32)).sum(0)]).float().unsqueeze(0).contiguous().to(dev)
+    pro = ops.bnref(32, sums=sums_of(nhwc(zq).view(-1, 32), 1, dev), gamma=g2.float().to(dev), beta=b2.float().to(dev), bsums=bs,
+                    n=B * 256, act=L.ACT_RELU6)
+    dW = torch.zeros(32, 3, 3, 3, dtype=torch.float32, device=dev)
+    ops.stem_wgrad(x.float().to(dev), gs.view(B, 16, 16, 32).to(dt).to(dev), nhwc(zq).to(dt).to(dev), pro, dW)
+    torch.cuda.synchronize()
+    assert relerr(dW, W.grad) < TOL[dt] * 3
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("B", [5, 48])
+def test_head(device, dt, B):
+    torch.manual_seed(B)
+    dev = device
+    J, HW, C = 22, 49, 64  # narrower C than KRN's 1024 keeps the CPU reference cheap; the kernel is generic in C
+    z = rt(torch.randn(B, C, 7, 7, dtype=torch.float64), dt).requires_grad_(True)
+    g1 = torch.rand(C, dtype=torch.float64) + 0.5; b1 = torch.randn(C, dtype=torch.float64) * 0.2
+    W = rt(torch.randn(J, C, 7, 7, dtype=torch.float64) * 0.05, dt).requires_grad_(True)
+    bias = torch.randn(J, dtype=torch.float64).float().double().requires_grad_(True)
+    tgt = torch.rand(B, 2, J // 2, dtype=torch.float64).float().double()
+    mean = z.mean((0, 2, 3), keepdim=True); var = z.var((0, 2, 3), unbiased=False, keepdim=True)
+    xh = (z - mean) / torch.sqrt(var + EPS)
+    u = xh * g1.view(1, -1, 1, 1) + b1.view(1, -1, 1, 1); u.retain_grad()
+    out = F.conv2d(F.relu(u), W, bias).view(B, J)
+    xc, yc = out[:, 0::2], out[:, 1::2]
+    lx = sum(F.mse_loss(xc[:, i], tgt[:, 0, i]) for i in range(J // 2))
+    ly = sum(F.mse_loss(yc[:, i], tgt[:, 1, i]) for i in range(J // 2))
+    (lx + ly).backward()
+    nhwc = lambda t: t.detach().permute(0, 2, 3, 1).contiguous()
+    Z = nhwc(z).view(B, HW * C).to(dt).to(dev)
+    Wp = torch.zeros(32, HW * C, dtype=dt, device=dev)
+    Wp[:J] = W.detach().permute(0, 2, 3, 1).reshape(J, HW * C).to(dt).to(dev)
+    pro = ops.bnref(C, sums=sums_of(nhwc(z).view(-1, C), 1, dev), gamma=g1.float().to(dev), beta=b1.float().to(dev), n=B * HW,
+                    act=L.ACT_RELU)
+    pred, scal, dout = ops.head_fwd(Z, Wp, bias.detach().float().to(dev), pro, J, HW, C, target=tgt.float().to(dev))
+    torch.cuda.synchronize()
+    assert relerr(pred, out) < TOL[dt]
+    assert abs(float(scal[1]) - float(lx)) < TOL[dt] * max(1.0, float(lx)) * 3
+    assert abs(float(scal[0]) - float(lx + ly)) < TOL[dt] * max(1.0, float(lx + ly)) * 3
+    G = torch.empty(B, HW * C, dtype=dt, device=dev)
+    osums = torch.zeros(1, 2, C, dtype=torch.float32, device=dev)
+    dW = torch.zeros(J, C, 7, 7, dtype=torch.float32, device=dev)
+    db = torch.zeros(J, dtype=torch.float32, device=dev)
+    ops.head_bwd(Z, Wp, dout, G, osums, dW, db, pro, J, HW, C)
+    torch.cuda.synchronize()
+    tol = TOL[dt] * 3
+    assert relerr(G.view(B, 7, 7, C), nhwc(u.grad)) < tol
+    assert relerr(dW, W.grad) < tol
+    assert relerr(db, bias.grad) < tol
+    gs = G.double().cpu().view(-1, C)
+    s = osums.double().cpu()[0]
+    assert relerr(s[0], gs.sum(0)) < 1e-3 and relerr(s[1], (gs * nhwc(xh).view(-1, C)).sum(0)) < 1e-3
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_bn_apply_and_bwd_prep(device, dt):
+    torch.manual_seed(11)
+    dev = device
+    B, H, C = 2, 14, 64
+    z = rt(torch.randn(B, H, H, C, dtype=torch.float64), dt)
+    r = rt(torch.randn(B, H, H, C, dtype=torch.float64), dt)
+    g1 = torch.rand(C, dtype=torch.float64) + 0.5; b1 = torch.randn(C, dtype=torch.float64) * 0.2
+    u, xh = bn_train(z.view(-1, C), g1, b1)
+    bn = ops.bnref(C, sums=sums_of(z.view(-1, C), 2, dev), gamma=g1.float().to(dev), beta=b1.float().to(dev), n=B * H * H, R=2,
+                   act=L.ACT_LEAKY, slope=0.2)
+    # residual add
+    Y = torch.empty(B, H, H, C, dtype=dt, device=dev)
+    ops.bn_apply(z.to(dt).to(dev), Y, bn, res=r.to(dt).to(dev))
+    torch.cuda.synchronize()
+    exp = F.leaky_relu(u, 0.2).view(B, H, H, C) + r
+    assert relerr(Y, exp) < TOL[dt]
+    # reorg (RouterV2, park2019.py:74-80) into a wider concat buffer: router channels first
+    cat = torch.zeros(B, H // 2, H // 2, 4 * C + 32, dtype=dt, device=dev)
+    ops.bn_apply(z.to(dt).to(dev), cat, bn, ldc=4 * C + 32, coff=0, reorg=2)
+    torch.cuda.synchronize()
+    x2 = F.leaky_relu(u, 0.2).view(B, H, H, C).permute(0, 3, 1, 2)  # NCHW
+    s = 2
+    t = x2.reshape(B, C, H // s, s, H // s, s).transpose(3, 4).contiguous()
+    t = t.view(B, C, H // s * H // s, s * s).transpose(2, 3).contiguous()
+    t = t.view(B, C, s * s, H // s, H // s).transpose(1, 2).contiguous()
+    t = t.view(B, s * s * C, H // s, H // s)
+    assert relerr(cat[..., : 4 * C], t.permute(0, 2, 3, 1)) < TOL[dt]
+    assert float(cat[..., 4 * C:].abs().max()) == 0.0
+    # backward of the same mapping
+    dcat = rt(torch.randn(B, H // 2, H // 2, 4 * C + 32, dtype=torch.float64), dt)
+    G = torch.empty(B, H, H, C, dtype=dt, device=dev)
+    osums = torch.zeros(2, 2, C, dtype=torch.float32, device=dev)
+    ops.bn_bwd_prep(dcat.to(dt).to(dev), z.to(dt).to(dev), G, osums, bn, ldc=4 * C + 32, coff=0, reorg=2, oR=2)
+    torch.cuda.synchronize()
+    d_nchw = dcat[..., : 4 * C].permute(0, 3, 1, 2)  # [B, 4C, h, w]
+    dx = torch.zeros(B, C, H, H, dtype=torch.float64)
+    for i in range(2):
+        for j in range(2):
+            dx[:, :, i::2, j::2] = d_nchw[:, (i * 2 + j) * C:(i * 2 + j + 1) * C]
+    mask = torch.where(u > 0, 1.0, 0.2).view(B, H, H, C)
+    expg = dx.permute(0, 2, 3, 1) * mask
+    assert relerr(G, expg) < TOL[dt]
+    gs = G.double().cpu().view(-1, C); sm = osums.double().cpu().sum(0)
+    assert relerr(sm[0], gs.sum(0)) < 1e-3 and relerr(sm[1], (gs * xh).sum(0)) < 1e-3
+
+
+@pytest.mark.parametrize("kind", ["adamw", "adam", "rmsprop", "sgd"])
+def test_optim_step_matches_torch(device, kind):
+    """fused clip + update vs clip_grad_norm_ + torch.optim (reference build.py:60-78, trainer.py:97-98)"""
+    torch.manual_seed(3)
+    n = 10007
+    p0 = torch.randn(n); steps = 3
+    grads = [torch.randn(n) * (0.05 if i else 3.0) for i in range(steps)]
+    p_ref = torch.nn.Parameter(p0.clone())
+    mk = dict(adamw=lambda: torch.optim.AdamW([p_ref], lr=1e-2, betas=(0.9, 0.999), weight_decay=0.01),
+              adam=lambda: torch.optim.Adam([p_ref], lr=1e-2, betas=(0.9, 0.999), weight_decay=5e-5),
+              rmsprop=lambda: torch.optim.RMSprop([p_ref], lr=1e-2, alpha=0.9, weight_decay=5e-5),
+              sgd=lambda: torch.optim.SGD([p_ref], lr=1e-2, momentum=0.9, weight_decay=5e-5))[kind]
+    opt = mk()
+    wd = 0.01 if kind == "adamw" else 5e-5
+    p = p0.clone().to(device); m = torch.zeros(n, device=device); v = torch.zeros(n, device=device)
+    sq = torch.zeros(1, device=device)
+    for i, g in enumerate(grads):
+        p_ref.grad = g.clone()
+        torch.nn.utils.clip_grad_norm_([p_ref], 1.0)
+        opt.step()
+        gd = g.clone().to(device)
+        ops.grad_sqnorm(gd, sq)
+        ops.optim_step(kind, p, gd, m=m, v=v, sqnorm=sq, lr=1e-2, beta1=0.9, beta2=0.9 if kind == "rmsprop" else 0.999,
+                       weight_decay=wd, max_norm=1.0, step=i + 1, first_step=(i == 0))
+    torch.cuda.synchronize()
+    assert relerr(p, p_ref.detach()) < 1e-5
