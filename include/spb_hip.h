@@ -252,9 +252,13 @@ int spb_krn_prepare_weights(spb_krn_t* m, spb_stream_t stream);
 int spb_krn_forward(spb_krn_ctx_t* c, const float* x_nchw, const float* target, int training, float* pred,
                     float* scalars, float* domain_logits, spb_stream_t stream);
 /* backward of loss*gscale (+ sum_b domain_logit_grad[b]*logit[b] through the gradient-reversal layer with alpha).
- * Accumulates into the bound grad arena (caller zeroes it, as optimizer.zero_grad does).                       */
-int spb_krn_backward(spb_krn_ctx_t* c, float gscale, int with_pose, const float* domain_logit_grad, float alpha,
-                     spb_stream_t stream);
+ * ACCUMULATES into `grads` (f32 arena with the parameter layout; NULL = the arena given to spb_krn_bind); the caller
+ * zeroes it, as optimizer.zero_grad does.                                                                       */
+int spb_krn_backward(spb_krn_ctx_t* c, float* grads, float gscale, int with_pose, const float* domain_logit_grad,
+                     float alpha, spb_stream_t stream);
+/* binary_cross_entropy_with_logits(logits, full(label), reduction='mean') and its gradient * gscale (dann.py:85-92) */
+int spb_bce_logits(const float* logits, float label, int B, float* loss_out, float* dlogit_out, float gscale,
+                   spb_stream_t stream);
 
 /* debug / test helpers */
 int spb_debug_trread(const unsigned short* in4096, unsigned short* out256, spb_stream_t stream);

@@ -120,7 +120,8 @@ SYMBOLS = {
     "spb_krn_ctx_destroy": (None, [vp]),
     "spb_krn_prepare_weights": (i32, [vp, vp]),
     "spb_krn_forward": (i32, [vp, vp, vp, i32, vp, vp, vp, vp]),
-    "spb_krn_backward": (i32, [vp, f32, i32, vp, f32, vp]),
+    "spb_krn_backward": (i32, [vp, vp, f32, i32, vp, f32, vp]),
+    "spb_bce_logits": (i32, [vp, f32, i32, vp, vp, f32, vp]),
     "spb_debug_trread": (i32, [vp, vp, vp]),
     "spb_version": (C.c_char_p, []),
 }

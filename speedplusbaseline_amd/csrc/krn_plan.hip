@@ -554,10 +554,21 @@ extern "C" int spb_krn_forward(spb_krn_ctx_t* c, const float* x, const float* ta
 }
 
 // ---- backward --------------------------------------------------------------------------------------------------
-extern "C" int spb_krn_backward(spb_krn_ctx_t* c, float gscale, int with_pose, const float* dlogit, float alpha,
-                                spb_stream_t stream) {
+extern "C" int spb_bce_logits(const float* logits, float label, int B, float* loss_out, float* dlogit_out, float gscale,
+                              spb_stream_t stream) {
+  if (!logits || B <= 0) return SPB_E_ARG;
+  hipLaunchKernelGGL(bce_logits_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, logits, label, B, loss_out, dlogit_out, gscale);
+  SPB_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int spb_krn_backward(spb_krn_ctx_t* c, float* grads, float gscale, int with_pose, const float* dlogit,
+                                float alpha, spb_stream_t stream) {
   if (!c) return SPB_E_ARG;
   spb_krn* m = c->m;
+  float* const bound_G = m->G;
+  if (grads) m->G = grads;
+  struct Restore { spb_krn* m; float* g; ~Restore() { m->G = g; } } restore{m, bound_G};
   if (!m->G || !c->last_training) return SPB_E_STATE;
   if (!with_pose && !dlogit) return SPB_E_ARG;
   if (dlogit && !m->dann) return SPB_E_ARG;

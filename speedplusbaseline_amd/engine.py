@@ -1,0 +1,149 @@
+"""Python side of the C++ network plan (csrc/krn_plan.hip): owns the flat f32 parameter / gradient / BN-buffer arenas
+on the GPU and the per-batch-size activation workspaces, and exposes forward / backward as single asynchronous calls.
+
+PyTorch is used for device memory and streams only.  There is no CPU or eager-PyTorch fallback: every entry raises if
+the HIP library is missing or the tensors are not on the GPU.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+
+PRECISIONS = {"fp32": L.F32, "f32": L.F32, "float32": L.F32, "bf16": L.BF16, "bfloat16": L.BF16}
+
+
+def _p(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class KrnEngine:
+    """One KeypointRegressionNet (optionally with RevGrad's domain classifier) bound to device arenas."""
+
+    def __init__(self, num_keypoints, dann=False):
+        self.lib = L.lib()
+        self.h = C.c_void_p()
+        L.check(self.lib.spb_krn_create(int(num_keypoints), 1 if dann else 0, C.byref(self.h)), "spb_krn_create")
+        self.num_keypoints = int(num_keypoints)
+        self.dann = bool(dann)
+        ti = L.TensorInfo()
+        self.param_infos, self.buffer_infos, self.bn_names = [], [], []
+        for i in range(self.lib.spb_krn_num_params(self.h)):
+            L.check(self.lib.spb_krn_param_info(self.h, i, C.byref(ti)), "param_info")
+            self.param_infos.append((ti.name.decode(), tuple(ti.shape[: ti.ndim]), int(ti.offset), int(ti.numel)))
+        for i in range(self.lib.spb_krn_num_buffers(self.h)):
+            L.check(self.lib.spb_krn_buffer_info(self.h, i, C.byref(ti)), "buffer_info")
+            self.buffer_infos.append((ti.name.decode(), tuple(ti.shape[: ti.ndim]), int(ti.offset), int(ti.numel)))
+        buf = C.create_string_buffer(96)
+        for i in range(self.lib.spb_krn_num_bn(self.h)):
+            L.check(self.lib.spb_krn_bn_name(self.h, i, buf), "bn_name")
+            self.bn_names.append(buf.value.decode())
+        self.n_params = int(self.lib.spb_krn_param_numel(self.h))
+        self.n_buffers = int(self.lib.spb_krn_buffer_numel(self.h))
+        self.device = None
+        self.dtype_code = None
+        self._ctx = {}
+
+    def __del__(self):
+        try:
+            for h, _ws in self._ctx.values():
+                self.lib.spb_krn_ctx_destroy(h)
+            if self.h:
+                self.lib.spb_krn_destroy(self.h)
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------------------------------------ arenas
+    def attach(self, device, precision):
+        device = torch.device(device)
+        if device.type != "cuda":
+            raise RuntimeError("the KRN engine runs on the MI355X only; there is no CPU path (got device %s)" % device)
+        code = PRECISIONS[precision] if isinstance(precision, str) else int(precision)
+        for h, _ws in self._ctx.values():
+            self.lib.spb_krn_ctx_destroy(h)
+        self._ctx = {}
+        self.device, self.dtype_code = device, code
+        with torch.cuda.device(device):
+            self.params = torch.zeros(self.n_params, dtype=torch.float32, device=device)
+            self.grads = torch.zeros(self.n_params, dtype=torch.float32, device=device)
+            self.buffers = torch.zeros(self.n_buffers, dtype=torch.float32, device=device)
+            self.nbt = torch.zeros(len(self.bn_names), dtype=torch.int64, device=device)
+            self.wc = torch.empty(int(self.lib.spb_krn_wcompute_bytes(self.h, code)), dtype=torch.uint8, device=device)
+            self.tables = torch.empty(int(self.lib.spb_krn_tables_bytes(self.h)), dtype=torch.uint8, device=device)
+            torch.cuda.synchronize(device)
+            L.check(self.lib.spb_krn_bind(self.h, _p(self.params), _p(self.grads), _p(self.buffers), _p(self.nbt),
+                                          _p(self.wc), _p(self.tables), code), "spb_krn_bind")
+        return self
+
+    def param_view(self, info, arena=None):
+        _name, shape, off, numel = info
+        a = self.params if arena is None else arena
+        return a[off: off + numel].view(shape)
+
+    def context(self, batch, slot=0):
+        key = (int(batch), int(slot))
+        if key not in self._ctx:
+            nbytes = int(self.lib.spb_krn_ctx_bytes(self.h, key[0], self.dtype_code))
+            if nbytes <= 0:
+                raise L.SpbError("spb_krn_ctx_bytes failed: %d" % nbytes)
+            with torch.cuda.device(self.device):
+                ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+                h = C.c_void_p()
+                torch.cuda.synchronize(self.device)
+                L.check(self.lib.spb_krn_ctx_create(self.h, key[0], _p(ws), C.byref(h)), "spb_krn_ctx_create")
+            self._ctx[key] = (h, ws)
+        return self._ctx[key][0]
+
+    # ------------------------------------------------------------------------------------------------ passes
+    def _check_input(self, x):
+        if self.device is None:
+            raise RuntimeError("model is not on the GPU: call model.to('cuda') first (no CPU path exists)")
+        if not x.is_cuda:
+            raise RuntimeError("input images must be on the GPU (got %s)" % x.device)
+        if x.dim() != 4 or x.shape[1] != 3 or x.shape[2] != 224 or x.shape[3] != 224:
+            raise RuntimeError("KRN needs [B,3,224,224] images so the 7x7 head reduces to 1x1 (park2019.py:139-142); got %s"
+                               % (tuple(x.shape),))
+        return x.detach().to(torch.float32).contiguous()
+
+    def forward(self, x, target=None, training=True, slot=0, domain=False):
+        """Enqueue one forward.  Returns (pred [B,2K], scalars [3] or None, domain_logits [B] or None); x is kept
+        alive by the caller/ctx until backward."""
+        x = self._check_input(x)
+        B = x.shape[0]
+        ctx = self.context(B, slot)
+        with torch.cuda.device(self.device):
+            st = _stream()
+            L.check(self.lib.spb_krn_prepare_weights(self.h, st), "spb_krn_prepare_weights")
+            pred = torch.empty(B, 2 * self.num_keypoints, dtype=torch.float32, device=self.device)
+            scalars = None
+            if target is not None:
+                target = target.detach().to(device=self.device, dtype=torch.float32).contiguous()
+                if tuple(target.shape) != (B, 2, self.num_keypoints):
+                    raise RuntimeError("target must be [B,2,%d], got %s" % (self.num_keypoints, tuple(target.shape)))
+                scalars = torch.empty(3, dtype=torch.float32, device=self.device)
+            dom = torch.empty(B, dtype=torch.float32, device=self.device) if (domain and self.dann) else None
+            L.check(self.lib.spb_krn_forward(ctx, _p(x), _p(target), 1 if training else 0, _p(pred), _p(scalars), _p(dom),
+                                             st), "spb_krn_forward")
+        self._last_x = getattr(self, "_last_x", {})
+        self._last_x[(B, slot)] = (x, target)
+        return pred, scalars, dom
+
+    def backward(self, batch, slot=0, grads=None, gscale=1.0, with_pose=True, dlogit=None, alpha=0.0):
+        ctx = self.context(batch, slot)
+        with torch.cuda.device(self.device):
+            L.check(self.lib.spb_krn_backward(ctx, _p(grads), float(gscale), 1 if with_pose else 0, _p(dlogit), float(alpha),
+                                              _stream()), "spb_krn_backward")
+
+    def bce_logits(self, logits, label, gscale=1.0):
+        """mean BCE-with-logits against a constant label; returns (loss [1], dlogit [B])"""
+        B = logits.shape[0]
+        loss = torch.empty(1, dtype=torch.float32, device=self.device)
+        dl = torch.empty(B, dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            L.check(self.lib.spb_bce_logits(_p(logits), float(label), B, _p(loss), _p(dl), float(gscale), _stream()),
+                    "spb_bce_logits")
+        return loss, dl
