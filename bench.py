@@ -1,0 +1,188 @@
+#!/usr/bin/env python
+"""Throughput of the KRN training step on MI355X (BASELINE.json metric: images/sec, KRN 224x224, bs=48/GPU).
+
+  python bench.py --gpus 1 --steps 50 --warmup 10
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+One step = forward + zero_grad + backward + [gradient all-reduce over RCCL] + global-norm clip + AdamW on one batch of
+synthetic images already resident in HBM (README recipe: bs 48, AdamW lr 1e-3 wd 0.01; trainer.py:72-98 order).  Prints
+ONE JSON line on rank 0.  Besides the contract fields it carries
+  roofline      the dominant kernel family's algorithmic bytes / its launch time, timed live with HIP events on the launch
+                stream in an instrumented pass of the same step (speedplusbaseline_amd engine profiler)
+  kernels       the same for every kernel family of the step
+  cpu_baseline  the CPU oracle (oracle/krn_oracle.py, the reference's --no_cuda fp32 path restated) on this box's cores
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
+MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=48, help="images per GPU (README recipe: 48)")
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-graph", action="store_true", help="launch kernels eagerly instead of replaying a hipGraph")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=3)
+    args = ap.parse_args()
+
+    from speedplusbaseline_amd.engine import KrnEngine
+    from speedplusbaseline_amd.step import FusedTrainStep
+    from oracle import krn_oracle as O  # checker / cpu_baseline leg only
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs one process per GPU: launch with python -m torch.distributed.run "
+                             "--nproc-per-node %d ..." % (args.gpus, args.gpus))
+        raise SystemExit("--gpus (%d) != WORLD_SIZE (%d)" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X; there is no CPU path for the product")
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+    group = None
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.distributed.init_process_group("nccl", device_id=dev)
+        group = torch.distributed.group.WORLD
+
+    B = args.batch
+    eng = KrnEngine(11).attach(dev, args.precision)
+    sd = O.init_state(11)  # random-init weights of the KRN architecture (no checkpoints offline)
+    for info in eng.param_infos:
+        eng.param_view(info).copy_(sd[info[0]].to(dev))
+    for name, shape, off, numel in eng.buffer_infos:
+        eng.buffers[off: off + numel].copy_(sd[name].flatten().to(dev))
+    if world > 1:  # identical replicas: rank 0's parameters everywhere
+        torch.distributed.broadcast(eng.params, 0); torch.distributed.broadcast(eng.buffers, 0)
+    gen = torch.Generator(device="cpu"); gen.manual_seed(2021 + rank)  # seed 2021 (config.py:13) + rank offset
+    x = torch.rand(B, 3, 224, 224, generator=gen).to(dev)   # U[0,1) like transforms.py:192-196
+    y = torch.rand(B, 2, 11, generator=gen).to(dev)
+    step = FusedTrainStep(eng, B, kind="adamw", lr=1e-3, momentum=0.9, weight_decay=0.01, max_norm=1.0,
+                          dist_group=group, world_size=world, use_graph=not args.no_graph)
+
+    def sync_all():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step(x, y)
+    if step.static_inputs() is not None:  # replay straight from the graph's input buffers
+        x, y = step.static_inputs()
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        scal = step(x, y)
+    sync_all()
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+    dt = float(t.item())
+    loss_last = [float(v) for v in scal.cpu()]
+    ms_per_step = dt / args.steps * 1e3
+    value = world * B * args.steps / dt
+
+    # ---- instrumented pass: per-kernel-family time (HIP events on the launch stream) and algorithmic bytes
+    kernels = {}
+    roofline = None
+    if rank == 0:
+        es = 2 if args.precision == "bf16" else 4
+        n_prof = 5
+        eng.prof_enable(B, 0, True)
+        import ctypes as C
+        from speedplusbaseline_amd import _lib as L
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(6)]
+        t_prep = t_zero = t_opt = 0.0
+        agg = {}
+        for _ in range(n_prof):
+            step.t += 1; step._refresh_hyper()
+            _, _, _ = eng.forward(x, y, training=True, slot=0)
+            ev[0].record(); eng.grads.zero_(); ev[1].record()
+            eng.backward(B, slot=0)
+            ev[2].record(); step._update(); ev[3].record()
+            ev[4].record()
+            L.check(eng.lib.spb_krn_prepare_weights(eng.h, C.c_void_p(torch.cuda.current_stream().cuda_stream)), "prepare_weights")
+            ev[5].record()
+            torch.cuda.synchronize()
+            t_zero += ev[0].elapsed_time(ev[1]); t_opt += ev[2].elapsed_time(ev[3]); t_prep += ev[4].elapsed_time(ev[5])
+            for k, v in eng.prof_read(B, 0).items():
+                a = agg.setdefault(k, dict(launches=0, ms=0.0, bytes=0.0, flops=0.0))
+                for f in a:
+                    a[f] += v[f]
+        eng.prof_enable(B, 0, False)
+        agg["weight_prep"] = dict(launches=n_prof, ms=t_prep, bytes=float(eng.weight_prep_bytes()) * n_prof, flops=0.0)
+        agg["grad_zero"] = dict(launches=n_prof, ms=t_zero, bytes=4.0 * eng.n_params * n_prof, flops=0.0)
+        agg["clip_adamw"] = dict(launches=2 * n_prof, ms=t_opt, bytes=(4.0 + 28.0) * eng.n_params * n_prof, flops=0.0)
+        tot_ms = sum(v["ms"] for v in agg.values())
+        for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["ms"]):
+            ms = v["ms"] / n_prof
+            kernels[k] = dict(launches_per_step=v["launches"] // n_prof, ms_per_step=round(ms, 4),
+                              share=round(v["ms"] / tot_ms, 4),
+                              GBps=round(v["bytes"] / n_prof / (ms * 1e-3) / 1e9, 1) if ms > 0 else None,
+                              TFLOPs=round(v["flops"] / n_prof / (ms * 1e-3) / 1e12, 2) if ms > 0 else None,
+                              alg_MB_per_step=round(v["bytes"] / n_prof / 1e6, 2))
+        dom = max(agg.items(), key=lambda kv: kv[1]["ms"])
+        dk, dv = dom
+        achieved = dv["bytes"] / (dv["ms"] * 1e-3) / 1e9
+        roofline = dict(bound="hbm", kernel=dk, achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+                        frac=round(achieved / HBM_PEAK_GBS, 4), traffic=None,
+                        launches_per_step=dv["launches"] // n_prof,
+                        avg_launch_us=round(dv["ms"] / dv["launches"] * 1e3, 2),
+                        alg_bytes_per_launch=round(dv["bytes"] / dv["launches"]),
+                        step_sum_of_kernels_ms=round(tot_ms / n_prof, 3),
+                        step_alg_GBps=round(sum(v["bytes"] for v in agg.values()) / n_prof / (ms_per_step * 1e-3) / 1e9, 1),
+                        step_alg_TFLOPs=round(sum(v["flops"] for v in agg.values()) / n_prof / (ms_per_step * 1e-3) / 1e12, 2),
+                        mfma_peak_TFLOPs=MFMA_PEAK_TFLOPS[args.precision])
+
+    # ---- CPU baseline: the oracle's train step (reference --no_cuda fp32 path) on this box's host cores, rank 0 only
+    cpu = None
+    if rank == 0 and not args.no_cpu_baseline:
+        ncores = os.cpu_count() or 1
+        torch.set_num_threads(ncores)
+        tr = O.KrnTrainer(O.init_state(11), "adamw", lr=1e-3, momentum=0.9, weight_decay=0.01)
+        xc, yc = x.cpu(), y.cpu()
+        tr.step(xc, yc)  # warm-up
+        t1 = time.perf_counter()
+        for _ in range(args.cpu_steps):
+            tr.step(xc, yc)
+        cdt = time.perf_counter() - t1
+        cpu = dict(value=round(B * args.cpu_steps / cdt, 2), unit="images/sec", cores=torch.get_num_threads(), kind="port",
+                   sample="%d train steps of the same bs=%d 224x224 batch, fp32, PyTorch CPU oracle (%.1f s)" % (args.cpu_steps, B, cdt))
+
+    if rank == 0:
+        out = {
+            "metric": "images/sec KRN 224x224 bs=48/GPU train step",
+            "value": round(value, 1), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": args.precision, "data": "synthetic",
+            "config": {"workload": "KRN (MobileNetV2 features + ConvDw extras + 7x7 keypoint head) train step, 224x224, "
+                                   "bs=%d/GPU, AdamW lr 1e-3 wd 0.01 + clip_grad_norm 1.0" % B,
+                       "per_gpu_batch": B, "global_batch": B * world, "parallelism": "dp%d" % world,
+                       "launch": "eager" if args.no_graph else "hipGraph replay (fwd+bwd | all-reduce | clip+AdamW)",
+                       "weights": "random init (no checkpoints offline)", "loss_last_step": loss_last},
+            "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels,
+        }
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

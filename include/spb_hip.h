@@ -202,7 +202,8 @@ typedef struct spb_optim_args {
   float* params; float* grads; float* m; float* v; /* flat f32 arenas; m/v may be NULL for sgd w/o momentum */
   const float* sqnorm;  /* optional device scalar: clip coefficient = min(1, max_norm/(sqrt(sqnorm)+1e-6)) */
   const float* gmul;    /* optional device scalar multiplied into every gradient (1/world_size, 1/loss_scale) */
-  const unsigned char* mask; /* optional [n]: 1 = this element is a decayed/updated parameter (all, today) */
+  const float* hyper;   /* optional device [3] = lr, 1-beta1^t, 1-beta2^t: overrides the by-value fields so a captured
+                           graph can be replayed with per-step values (the host refreshes this buffer before each replay) */
   long long n;
   int kind;             /* 0 sgd, 1 rmsprop, 2 adam, 3 adamw */
   float lr, beta1, beta2, eps, weight_decay, max_norm, clip_value; /* max_norm<=0: no norm clip; clip_value<=0: none */
@@ -259,6 +260,15 @@ int spb_krn_backward(spb_krn_ctx_t* c, float* grads, float gscale, int with_pose
 /* binary_cross_entropy_with_logits(logits, full(label), reduction='mean') and its gradient * gscale (dann.py:85-92) */
 int spb_bce_logits(const float* logits, float label, int B, float* loss_out, float* dlogit_out, float gscale,
                    spb_stream_t stream);
+
+/* live per-launch timing of the plan's kernels: HIP events recorded on the launch stream around every launch, grouped
+ * by kernel family, with the ALGORITHMIC bytes/flops of each launch (every operand read once, every result written
+ * once).  bench.py derives roofline.achieved from these.                                                          */
+int spb_krn_prof_enable(spb_krn_ctx_t* c, int on);
+int spb_krn_prof_num_categories(void);
+const char* spb_krn_prof_category_name(int i);
+int spb_krn_prof_read(spb_krn_ctx_t* c, int* launches, float* ms, double* bytes, double* flops);
+long long spb_krn_weight_prep_bytes(const spb_krn_t* m);
 
 /* debug / test helpers */
 int spb_debug_trread(const unsigned short* in4096, unsigned short* out256, spb_stream_t stream);

@@ -119,18 +119,37 @@ def param_names(sd):
 
 # ------------------------------------------------------------------------------------------------- functional net
 class _Net:
+    momentum = BN_MOM  # class-level knob: tests set 1.0 to make running stats equal the batch statistics
+    # class-level knob: emulate the bf16 storage/operand rounding points of the HIP path (straight-through in backward):
+    #   every convolution output is stored as bf16; matrix-core operands (input and weight of 1x1 convs, head, domain
+    #   conv) are rounded to bf16; depthwise/stem arithmetic stays f32; materialised tensors (skip outputs, concat) bf16.
+    quant = False
+
     def __init__(self, sd, training, prefix=""):
         self.sd, self.training, self.p = sd, training, prefix
 
+    @classmethod
+    def q(cls, t):
+        if not cls.quant:
+            return t
+        return t + (t.detach().to(torch.bfloat16).to(t.dtype) - t.detach())
+
     def conv(self, x, name, stride=1, padding=0, groups=1):
-        return F.conv2d(x, self.sd[self.p + name + ".weight"], self.sd.get(self.p + name + ".bias"), stride, padding, 1, groups)
+        w = self.sd[self.p + name + ".weight"]
+        b = self.sd.get(self.p + name + ".bias")
+        if groups == 1 and w.shape[1] > 3:  # matrix-core layers: operands rounded
+            x, w = self.q(x), self.q(w)
+        z = F.conv2d(x, w, None, stride, padding, 1, groups)
+        if b is not None:  # head / domain conv: f32 bias after the (rounded, for the domain conv) product
+            return z + b.view(1, -1, 1, 1)
+        return self.q(z)
 
     def bn(self, x, name):
         sd, n = self.sd, self.p + name
         if self.training:
             sd[n + ".num_batches_tracked"] += 1
         return F.batch_norm(x, sd[n + ".running_mean"], sd[n + ".running_var"], sd[n + ".weight"], sd[n + ".bias"],
-                            self.training, BN_MOM, BN_EPS)
+                            self.training, self.momentum, BN_EPS)
 
 
 def krn_features(sd, x, training, prefix=""):
@@ -146,7 +165,7 @@ def krn_features(sd, x, training, prefix=""):
             y = F.relu6(net.bn(net.conv(y, p + "0.0"), p + "0.1")); i = 1
         y = F.relu6(net.bn(net.conv(y, p + "%d.0" % i, s, 1, hid), p + "%d.1" % i))
         y = net.bn(net.conv(y, p + "%d" % (i + 1)), p + "%d" % (i + 2))
-        x = x + y if (s == 1 and cin == cout) else y
+        x = net.q(x + y) if (s == 1 and cin == cout) else y
         if k == 13:
             tap = x
     return x, tap
@@ -172,7 +191,7 @@ def krn_predict(sd, x, training, prefix=""):
     h = _conv_dw(net, feat, 0)
     h = _conv_dw(net, h, 1)
     r = F.leaky_relu(net.bn(net.conv(tap, "extras.2.conv.0"), "extras.2.conv.1"), 0.2)
-    h = torch.cat((reorg(r, 2), h), dim=1)
+    h = net.q(torch.cat((reorg(r, 2), h), dim=1))
     h = _conv_dw(net, h, 3)
     out = net.conv(h, "head.0")
     return out.reshape(x.shape[0], -1), feat
@@ -211,7 +230,9 @@ def revgrad_forward(sd, x, y=None, alpha=None, training=True):
     if alpha is None:
         return pose
     d = _GRL.apply(feat, alpha)
-    d = F.relu(F.conv2d(d, sd["domain_classifier.0.weight"], sd["domain_classifier.0.bias"]))
+    q = _Net.q
+    d = q(F.conv2d(q(d), q(sd["domain_classifier.0.weight"])))
+    d = q(F.relu(d + sd["domain_classifier.0.bias"].view(1, -1, 1, 1)))
     d = F.avg_pool2d(d, 7)
     d = F.conv2d(d, sd["domain_classifier.3.weight"], sd["domain_classifier.3.bias"])
     return pose, d.reshape(-1)

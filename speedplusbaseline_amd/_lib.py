@@ -73,7 +73,7 @@ class PrepEntry(C.Structure):
 
 
 class OptimArgs(C.Structure):
-    _fields_ = [("params", vp), ("grads", vp), ("m", vp), ("v", vp), ("sqnorm", vp), ("gmul", vp), ("mask", vp),
+    _fields_ = [("params", vp), ("grads", vp), ("m", vp), ("v", vp), ("sqnorm", vp), ("gmul", vp), ("hyper", vp),
                 ("n", i64), ("kind", i32), ("lr", f32), ("beta1", f32), ("beta2", f32), ("eps", f32),
                 ("weight_decay", f32), ("max_norm", f32), ("clip_value", f32), ("bias_c1", f32), ("bias_c2", f32),
                 ("first_step", i32)]
@@ -122,6 +122,11 @@ SYMBOLS = {
     "spb_krn_forward": (i32, [vp, vp, vp, i32, vp, vp, vp, vp]),
     "spb_krn_backward": (i32, [vp, vp, f32, i32, vp, f32, vp]),
     "spb_bce_logits": (i32, [vp, f32, i32, vp, vp, f32, vp]),
+    "spb_krn_prof_enable": (i32, [vp, i32]),
+    "spb_krn_prof_num_categories": (i32, []),
+    "spb_krn_prof_category_name": (C.c_char_p, [i32]),
+    "spb_krn_prof_read": (i32, [vp, vp, vp, vp, vp]),
+    "spb_krn_weight_prep_bytes": (i64, [vp]),
     "spb_debug_trread": (i32, [vp, vp, vp]),
     "spb_version": (C.c_char_p, []),
 }

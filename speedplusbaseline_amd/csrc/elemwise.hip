@@ -221,29 +221,32 @@ __global__ __launch_bounds__(256) void optim_step_kernel(const spb_optim_args_t 
     coef = fminf(a.max_norm / (tn + 1e-6f), 1.f);
   }
   const float gs = gm * coef;
+  const float lr = a.hyper ? a.hyper[0] : a.lr;
+  const float bias_c1 = a.hyper ? a.hyper[1] : a.bias_c1;
+  const float bias_c2 = a.hyper ? a.hyper[2] : a.bias_c2;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < a.n; i += (long long)gridDim.x * 256) {
     float p = a.params[i];
     float g = a.grads[i] * gs;
     if (a.clip_value > 0.f) g = fminf(fmaxf(g, -a.clip_value), a.clip_value);
     if (a.kind == 3) {  // adamw (decoupled decay)
-      p *= 1.f - a.lr * a.weight_decay;
+      p *= 1.f - lr * a.weight_decay;
       const float m = a.beta1 * a.m[i] + (1.f - a.beta1) * g;
       const float v = a.beta2 * a.v[i] + (1.f - a.beta2) * g * g;
       a.m[i] = m; a.v[i] = v;
-      const float denom = sqrtf(v) / sqrtf(a.bias_c2) + a.eps;
-      p -= (a.lr / a.bias_c1) * (m / denom);
+      const float denom = sqrtf(v) / sqrtf(bias_c2) + a.eps;
+      p -= (lr / bias_c1) * (m / denom);
     } else if (a.kind == 2) {  // adam (L2 folded into the gradient)
       g += a.weight_decay * p;
       const float m = a.beta1 * a.m[i] + (1.f - a.beta1) * g;
       const float v = a.beta2 * a.v[i] + (1.f - a.beta2) * g * g;
       a.m[i] = m; a.v[i] = v;
-      const float denom = sqrtf(v) / sqrtf(a.bias_c2) + a.eps;
-      p -= (a.lr / a.bias_c1) * (m / denom);
+      const float denom = sqrtf(v) / sqrtf(bias_c2) + a.eps;
+      p -= (lr / bias_c1) * (m / denom);
     } else if (a.kind == 1) {  // rmsprop (alpha = beta2 slot), no momentum, not centred
       g += a.weight_decay * p;
       const float v = a.beta2 * a.v[i] + (1.f - a.beta2) * g * g;
       a.v[i] = v;
-      p -= a.lr * g / (sqrtf(v) + a.eps);
+      p -= lr * g / (sqrtf(v) + a.eps);
     } else {  // sgd with momentum (beta1), dampening 0
       g += a.weight_decay * p;
       if (a.beta1 != 0.f && a.m) {
@@ -251,7 +254,7 @@ __global__ __launch_bounds__(256) void optim_step_kernel(const spb_optim_args_t 
         a.m[i] = b;
         g = b;
       }
-      p -= a.lr * g;
+      p -= lr * g;
     }
     a.params[i] = p;
   }

@@ -102,7 +102,20 @@ struct spb_krn_ctx {
   int S = 0;
   int last_training = 0;
   const float* x = nullptr;  // image of the last forward (needed by the stem weight gradient)
+  // live per-launch timing (HIP events on the launch stream) with the algorithmic bytes of each launch
+  bool prof_on = false;
+  std::vector<hipEvent_t> prof_ev;   // pairs
+  std::vector<int> prof_cat;
+  std::vector<double> prof_bytes, prof_flops;
+  int prof_n = 0;
 };
+
+enum ProfCat { PC_STEM_FWD = 0, PC_PW_FWD, PC_DW_FWD, PC_BN_APPLY, PC_HEAD_FWD, PC_BN_UPDATE, PC_HEAD_BWD, PC_PW_DGRAD,
+               PC_PW_WGRAD, PC_DW_DGRAD, PC_DW_WGRAD, PC_BN_BWD_PREP, PC_STEM_WGRAD, PC_BN_PARAM_GRADS, PC_DOMAIN,
+               PC_WEIGHT_PREP, PC_COUNT };
+static const char* kProfNames[PC_COUNT] = {"stem_fwd", "pw_gemm_fwd", "dw_fwd", "bn_apply", "head_fwd", "bn_running_update",
+                                           "head_bwd", "pw_gemm_dgrad", "pw_wgrad", "dw_dgrad", "dw_wgrad", "bn_bwd_prep",
+                                           "stem_wgrad", "bn_param_grads", "domain_head", "weight_prep"};
 
 namespace {
 
@@ -190,6 +203,24 @@ struct Runner {
   spb_krn_ctx* c; spb_krn* m; hipStream_t st; int dt; int err = 0;
   Runner(spb_krn_ctx* c_, hipStream_t s) : c(c_), m(c_->m), st(s), dt(c_->m->dtype) {}
   void ok(int e) { if (e != 0 && err == 0) err = e; }
+  // ---- live timing: tic(category, algorithmic bytes, flops) ... toc() around one launch
+  void tic(int cat, double bytes, double flops = 0.0) {
+    if (!c->prof_on) return;
+    if ((size_t)(2 * c->prof_n + 2) > c->prof_ev.size()) {
+      hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+      c->prof_ev.push_back(a); c->prof_ev.push_back(b);
+      c->prof_cat.push_back(0); c->prof_bytes.push_back(0); c->prof_flops.push_back(0);
+    }
+    c->prof_cat[c->prof_n] = cat; c->prof_bytes[c->prof_n] = bytes; c->prof_flops[c->prof_n] = flops;
+    hipEventRecord(c->prof_ev[2 * c->prof_n], st);
+  }
+  void toc() {
+    if (!c->prof_on) return;
+    hipEventRecord(c->prof_ev[2 * c->prof_n + 1], st);
+    c->prof_n++;
+  }
+  double es() const { return (double)c->es; }
+  double elems(int a) const { return (double)M(a) * m->acts[a].C; }
 
   float* stats() const { return reinterpret_cast<float*>(c->ws + c->stats_off); }
   void* z(int a) const { return c->ws + c->z_off[a]; }
@@ -223,13 +254,17 @@ struct Runner {
     g.A = in.ptr; g.Bw = wc(L.wc_off); g.Y = z(aout); g.pro = in.ref; g.M = M(aout); g.K = L.K; g.N = L.N;
     g.pro_mode = 1; g.out_scale = 1.f;
     if (tr) { g.epi_mode = 1; g.osums = sums(aout); g.oR = c->R[aout]; } else { g.epi_mode = 0; g.oR = 1; }
+    tic(PC_PW_FWD, ((double)g.M * (L.K + L.N) + (double)L.K * L.N) * es(), 2.0 * g.M * L.K * L.N);
     ok(spb_pwconv_gemm(dt, &g, st));
+    toc();
   }
   void dw_fwd(const DWDef& L, const Src& in, int Hin, int aout, bool tr) {
     spb_dw_args_t d; std::memset(&d, 0, sizeof(d));
     d.X = in.ptr; d.Wd = m->P + L.w_off; d.Y = z(aout); d.pro = in.ref; d.B = c->B; d.H = Hin; d.W = Hin; d.C = L.C;
     d.stride = L.stride; d.epi_mode = tr ? 1 : 0; d.osums = sums(aout); d.oR = c->R[aout];
+    tic(PC_DW_FWD, ((double)c->B * Hin * Hin * L.C + elems(aout)) * es(), 18.0 * elems(aout));
     ok(spb_dwconv_fwd(dt, &d, st));
+    toc();
   }
   // ---- backward pieces.  `atgt` is the Act whose g / bsums the input gradient lands in (-1: plain output to `plain`)
   void pw_bwd(const PWDef& L, const Src& in, int aout, int atgt, void* plain, const void* res, float plain_scale = 1.f) {
@@ -240,11 +275,18 @@ struct Runner {
       g.Y = this->g(atgt); g.Zout = z(atgt); g.epi = ref(atgt, true); g.osums = bsums(atgt); g.oR = c->R[atgt];
       g.res = res; g.epi_mode = 2;
     } else { g.Y = plain; g.epi_mode = 0; g.oR = 1; }
+    {
+      const double mn = (double)g.M * L.N, mk = (double)g.M * L.K;
+      tic(PC_PW_DGRAD, (2 * mn + (atgt >= 0 ? 2 : 1) * mk + (res ? mk : 0) + (double)L.K * L.N) * es(), 2.0 * g.M * L.K * L.N);
+    }
     ok(spb_pwconv_gemm(dt, &g, st));
+    toc();
     spb_wgrad_args_t w; std::memset(&w, 0, sizeof(w));
     w.G = this->g(aout); w.Zn = z(aout); w.X = in.ptr; w.dW = m->G + L.w_off; w.pro_dz = ref(aout, true);
     w.pro_a = in.ref; w.M = M(aout); w.K = L.K; w.N = L.N;
+    tic(PC_PW_WGRAD, ((double)w.M * (2 * L.N + L.K)) * es() + 4.0 * L.K * L.N, 2.0 * w.M * L.K * L.N);
     ok(spb_pwconv_wgrad(dt, &w, st));
+    toc();
   }
   void dw_bwd(const DWDef& L, const Src& in, int Hin, int aout, int atgt, void* plain, const void* res) {
     spb_dw_args_t d; std::memset(&d, 0, sizeof(d));
@@ -254,8 +296,13 @@ struct Runner {
       d.Y = this->g(atgt); d.Zout = z(atgt); d.epi = ref(atgt, true); d.osums = bsums(atgt); d.oR = c->R[atgt];
       d.res = res; d.epi_mode = 2;
     } else { d.Y = plain; d.epi_mode = 0; d.oR = 1; }
+    const double nin = (double)c->B * Hin * Hin * L.C, nout = elems(aout);
+    tic(PC_DW_DGRAD, (2 * nout + (atgt >= 0 ? 2 : 1) * nin + (res ? nin : 0)) * es(), 18.0 * nout);
     ok(spb_dwconv_dgrad(dt, &d, st));
+    toc();
+    tic(PC_DW_WGRAD, (2 * nout + nin) * es(), 18.0 * nout);
     ok(spb_dwconv_wgrad(dt, &d, st));
+    toc();
   }
 };
 
@@ -389,6 +436,11 @@ extern "C" int spb_krn_bind(spb_krn_t* m, float* params, float* grads, float* bu
   return 0;
 }
 
+extern "C" long long spb_krn_weight_prep_bytes(const spb_krn_t* m) {  // algorithmic bytes of one prepare_weights call
+  long long b = 0;
+  for (const auto& e : m->prep) b += (long long)e.rows * e.cols * (e.mode == 2 ? m->J : 1) * (4 + (m->dtype == SPB_BF16 ? 2 : 4));
+  return b;
+}
 extern "C" int spb_krn_prepare_weights(spb_krn_t* m, spb_stream_t stream) {
   if (!m || m->dtype < 0) return SPB_E_STATE;
   return spb_weight_prep(m->dtype, m->prep_d, m->n_prep, m->n_prep_tiles, m->P, m->wc, stream);
@@ -490,8 +542,10 @@ extern "C" int spb_krn_forward(spb_krn_ctx_t* c, const float* x, const float* ta
   c->last_training = training;
   c->x = x;
   // stem
+  r.tic(PC_STEM_FWD, (double)c->B * 3 * kIn * kIn * 4 + r.elems(m->aStem) * r.es(), 54.0 * r.elems(m->aStem));
   r.ok(spb_stem_fwd(m->dtype, x, m->P + m->stem_w_off, r.z(m->aStem), tr ? r.sums(m->aStem) : nullptr, c->R[m->aStem],
                     c->B, kIn, kIn, stream));
+  r.toc();
   // inverted residual blocks
   Src cur = r.src_act(m->aStem, tr);
   for (int k = 1; k <= 17; ++k) {
@@ -507,7 +561,9 @@ extern "C" int spb_krn_forward(spb_krn_ctx_t* c, const float* x, const float* ta
       spb_bnapply_args_t a; std::memset(&a, 0, sizeof(a));
       a.Z = r.z(b.aP); a.res = cur.ptr; a.Y = r.y(b.matY); a.bn = r.ref(b.aP, tr); a.bn_res = cur.ref;
       a.B = c->B; a.H = b.Hout; a.W = b.Hout; a.C = b.cout; a.ldc = b.cout; a.coff = 0; a.reorg = 0;
+      r.tic(PC_BN_APPLY, 3.0 * r.elems(b.aP) * r.es());
       r.ok(spb_bn_apply(m->dtype, &a, stream));
+      r.toc();
     }
     cur = r.block_out(k, tr);
   }
@@ -522,10 +578,14 @@ extern "C" int spb_krn_forward(spb_krn_ctx_t* c, const float* x, const float* ta
     spb_bnapply_args_t a; std::memset(&a, 0, sizeof(a));
     a.Z = r.z(m->aR); a.Y = r.y(m->matCat); a.bn = r.ref(m->aR, tr); a.bn_res = Runner::ident(64);
     a.B = c->B; a.H = 14; a.W = 14; a.C = 64; a.ldc = 1280; a.coff = 0; a.reorg = 2;
+    r.tic(PC_BN_APPLY, 2.0 * r.elems(m->aR) * r.es());
     r.ok(spb_bn_apply(m->dtype, &a, stream));
+    r.toc();
     a.Z = r.z(m->aEP[1]); a.bn = r.ref(m->aEP[1], tr); a.bn_res = Runner::ident(1024);
     a.H = 7; a.W = 7; a.C = 1024; a.coff = 256; a.reorg = 0;
+    r.tic(PC_BN_APPLY, 2.0 * r.elems(m->aEP[1]) * r.es());
     r.ok(spb_bn_apply(m->dtype, &a, stream));
+    r.toc();
   }
   r.dw_fwd(m->eD[3], r.src_mat(m->matCat), 7, m->aED[3], tr);
   r.pw_fwd(m->eP[3], r.src_act(m->aED[3], tr), m->aEP[3], tr);
@@ -535,9 +595,12 @@ extern "C" int spb_krn_forward(spb_krn_ctx_t* c, const float* x, const float* ta
     h.partial = reinterpret_cast<float*>(c->ws + c->partial_off); h.pred = pred;
     h.dout = reinterpret_cast<float*>(c->ws + c->dout_off); h.scalars = scalars; h.pro = r.ref(m->aEP[3], tr);
     h.B = c->B; h.J = m->J; h.Jp = m->Jp; h.HW = 49; h.C = 1024; h.S = c->S;
+    r.tic(PC_HEAD_FWD, (r.elems(m->aEP[3]) + (double)m->Jp * 49 * 1024) * r.es(), 2.0 * c->B * m->J * 49 * 1024);
     r.ok(spb_head_fwd(m->dtype, &h, stream));
+    r.toc();
   }
   if (m->dann && domain_logits) {  // domain classifier on the (gradient-reversed) feature
+    r.tic(PC_DOMAIN, ((double)c->B * 49 * (320 + 1280) + 320.0 * 1280) * r.es(), 2.0 * c->B * 49 * 320 * 1280);
     spb_gemm_args_t g; std::memset(&g, 0, sizeof(g));
     g.A = feat.ptr; g.Bw = r.wc(m->dc0.wc_off); g.Y = c->ws + c->dom1_off; g.bias = m->P + m->dc0.bias_off;
     g.pro = feat.ref; g.M = c->B * 49; g.K = 320; g.N = 1280; g.pro_mode = 1; g.epi_mode = 0; g.out_act = SPB_ACT_RELU;
@@ -546,8 +609,13 @@ extern "C" int spb_krn_forward(spb_krn_ctx_t* c, const float* x, const float* ta
     hipLaunchKernelGGL(domain_tail_fwd_kernel, dim3(c->B), dim3(256), 0, st, (const void*)(c->ws + c->dom1_off), m->dtype,
                        (const float*)(m->P + m->dc3_w_off), (const float*)(m->P + m->dc3_b_off),
                        reinterpret_cast<float*>(c->ws + c->dompool_off), domain_logits, 49, 1280);
+    r.toc();
   }
-  if (tr) r.ok(spb_bn_running_update(tab, (int)m->bns.size(), r.stats(), m->Bf, m->nbt, kMomentum, stream));
+  if (tr) {
+    r.tic(PC_BN_UPDATE, (double)c->stats_floats * 2 + (double)m->n_buffers * 8);
+    r.ok(spb_bn_running_update(tab, (int)m->bns.size(), r.stats(), m->Bf, m->nbt, kMomentum, stream));
+    r.toc();
+  }
   hipError_t le = hipGetLastError();
   if (le != hipSuccess && r.err == 0) r.err = (int)le;
   return r.err;
@@ -578,6 +646,7 @@ extern "C" int spb_krn_backward(spb_krn_ctx_t* c, float* grads, float gscale, in
   const int aF = m->blk[17].aP;  // feature = bn(z) of block 17's projection (no residual there)
   void* ddom = nullptr;
   if (dlogit) {  // domain classifier backward, then the gradient-reversal layer (-alpha) into the feature
+    r.tic(PC_DOMAIN, ((double)c->B * 49 * (3 * 1280 + 2 * 320) + 2 * 320.0 * 1280) * r.es(), 4.0 * c->B * 49 * 320 * 1280);
     hipLaunchKernelGGL(domain_tail_bwd_kernel, dim3((1280 + 255) / 256), dim3(256), 0, st,
                        (const void*)(c->ws + c->dom1_off), (void*)(c->ws + c->gdom_off), dt,
                        (const float*)(m->P + m->dc3_w_off), (const float*)(c->ws + c->dompool_off), dlogit,
@@ -590,6 +659,7 @@ extern "C" int spb_krn_backward(spb_krn_ctx_t* c, float* grads, float gscale, in
     w.G = c->ws + c->gdom_off; w.X = r.z(aF); w.dW = m->G + m->dc0.w_off; w.pro_dz = Runner::ident(1280);
     w.pro_a = r.ref(aF, true); w.M = c->B * 49; w.K = 320; w.N = 1280;
     r.ok(spb_pwconv_wgrad(dt, &w, stream));
+    r.toc();
     ddom = c->ws + c->ddom_off;
   }
   if (with_pose) {
@@ -599,7 +669,10 @@ extern "C" int spb_krn_backward(spb_krn_ctx_t* c, float* grads, float gscale, in
       h.G = r.g(m->aEP[3]); h.osums = r.bsums(m->aEP[3]); h.dW = m->G + m->head_w_off; h.dbias = m->G + m->head_b_off;
       h.pro = r.ref(m->aEP[3], true); h.gscale = gscale; h.B = c->B; h.J = m->J; h.Jp = m->Jp; h.HW = 49; h.C = 1024;
       h.oR = c->R[m->aEP[3]];
+      r.tic(PC_HEAD_BWD, (3.0 * r.elems(m->aEP[3]) + (double)m->Jp * 49 * 1024) * r.es() + 4.0 * m->J * 49 * 1024,
+            4.0 * c->B * m->J * 49 * 1024);
       r.ok(spb_head_bwd(dt, &h, stream));
+      r.toc();
     }
     // extras[3] = ConvDw(1280,1024) on the concat
     r.pw_bwd(m->eP[3], r.src_act(m->aED[3], true), m->aEP[3], m->aED[3], nullptr, nullptr);
@@ -609,10 +682,14 @@ extern "C" int spb_krn_backward(spb_krn_ctx_t* c, float* grads, float gscale, in
       a.dY = c->ws + c->dcat_off; a.Z = r.z(m->aEP[1]); a.G = r.g(m->aEP[1]); a.osums = r.bsums(m->aEP[1]);
       a.bn = r.ref(m->aEP[1], true); a.B = c->B; a.H = 7; a.W = 7; a.C = 1024; a.ldc = 1280; a.coff = 256; a.reorg = 0;
       a.oR = c->R[m->aEP[1]];
+      r.tic(PC_BN_BWD_PREP, 3.0 * r.elems(m->aEP[1]) * r.es());
       r.ok(spb_bn_bwd_prep(dt, &a, stream));
+      r.toc();
       a.Z = r.z(m->aR); a.G = r.g(m->aR); a.osums = r.bsums(m->aR); a.bn = r.ref(m->aR, true);
       a.H = 14; a.W = 14; a.C = 64; a.coff = 0; a.reorg = 2; a.oR = c->R[m->aR];
+      r.tic(PC_BN_BWD_PREP, 3.0 * r.elems(m->aR) * r.es());
       r.ok(spb_bn_bwd_prep(dt, &a, stream));
+      r.toc();
     }
     r.pw_bwd(m->router, r.block_out(13, true), m->aR, -1, c->ws + c->dtap_off, nullptr);
     r.pw_bwd(m->eP[1], r.src_act(m->aED[1], true), m->aEP[1], m->aED[1], nullptr, nullptr);
@@ -624,7 +701,9 @@ extern "C" int spb_krn_backward(spb_krn_ctx_t* c, float* grads, float gscale, in
     spb_bnbwd_args_t a; std::memset(&a, 0, sizeof(a));
     a.dY = ddom; a.Z = r.z(aF); a.G = r.g(aF); a.osums = r.bsums(aF); a.bn = r.ref(aF, true);
     a.B = c->B; a.H = 7; a.W = 7; a.C = 320; a.ldc = 320; a.coff = 0; a.reorg = 0; a.oR = c->R[aF];
+    r.tic(PC_BN_BWD_PREP, 3.0 * r.elems(aF) * r.es());
     r.ok(spb_bn_bwd_prep(dt, &a, stream));
+    r.toc();
   }
   // inverted residual blocks, last to first
   for (int k = 17; k >= 1; --k) {
@@ -646,12 +725,41 @@ extern "C" int spb_krn_backward(spb_krn_ctx_t* c, float* grads, float gscale, in
   // stem weight gradient (the image needs no gradient)
   {
     spb_bnref_t pro = r.ref(m->aStem, true);
+    r.tic(PC_STEM_WGRAD, (double)c->B * 3 * kIn * kIn * 4 + 2.0 * r.elems(m->aStem) * r.es(), 54.0 * r.elems(m->aStem));
     r.ok(spb_stem_wgrad(dt, c->x, r.g(m->aStem), r.z(m->aStem), &pro, m->G + m->stem_w_off, c->B, kIn, kIn, stream));
+    r.toc();
   }
+  r.tic(PC_BN_PARAM_GRADS, (double)c->stats_floats * 2);
   // BatchNorm affine gradients: dgamma += sum(g*xhat), dbeta += sum(g)
   r.ok(spb_bn_param_grads(reinterpret_cast<const spb_bnupd_entry_t*>(c->ws + c->table_off), (int)m->bns.size(), r.stats(),
                           m->G, stream));
+  r.toc();
   hipError_t le = hipGetLastError();
   if (le != hipSuccess && r.err == 0) r.err = (int)le;
   return r.err;
+}
+
+// ---- live per-launch timing ------------------------------------------------------------------------------------
+extern "C" int spb_krn_prof_enable(spb_krn_ctx_t* c, int on) {
+  if (!c) return SPB_E_ARG;
+  c->prof_on = on != 0; c->prof_n = 0;
+  return 0;
+}
+extern "C" int spb_krn_prof_num_categories(void) { return PC_COUNT; }
+extern "C" const char* spb_krn_prof_category_name(int i) { return (i >= 0 && i < PC_COUNT) ? kProfNames[i] : ""; }
+// Sums the launches recorded since the last call per category (synchronises on the recorded events) and resets.
+extern "C" int spb_krn_prof_read(spb_krn_ctx_t* c, int* launches, float* ms, double* bytes, double* flops) {
+  if (!c || !launches || !ms || !bytes || !flops) return SPB_E_ARG;
+  for (int i = 0; i < PC_COUNT; ++i) { launches[i] = 0; ms[i] = 0.f; bytes[i] = 0.0; flops[i] = 0.0; }
+  for (int i = 0; i < c->prof_n; ++i) {
+    hipError_t e = hipEventSynchronize(c->prof_ev[2 * i + 1]);
+    if (e != hipSuccess) return (int)e;
+    float t = 0.f;
+    e = hipEventElapsedTime(&t, c->prof_ev[2 * i], c->prof_ev[2 * i + 1]);
+    if (e != hipSuccess) return (int)e;
+    const int k = c->prof_cat[i];
+    launches[k] += 1; ms[k] += t; bytes[k] += c->prof_bytes[i]; flops[k] += c->prof_flops[i];
+  }
+  c->prof_n = 0;
+  return 0;
 }

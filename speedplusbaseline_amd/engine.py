@@ -138,6 +138,25 @@ class KrnEngine:
             L.check(self.lib.spb_krn_backward(ctx, _p(grads), float(gscale), 1 if with_pose else 0, _p(dlogit), float(alpha),
                                               _stream()), "spb_krn_backward")
 
+    # ------------------------------------------------------------------------------------------------ live timing
+    def prof_enable(self, batch, slot=0, on=True):
+        L.check(self.lib.spb_krn_prof_enable(self.context(batch, slot), 1 if on else 0), "spb_krn_prof_enable")
+
+    def prof_read(self, batch, slot=0):
+        """{kernel family: dict(launches, ms, bytes, flops)} summed over the launches since the last read"""
+        n = self.lib.spb_krn_prof_num_categories()
+        la = (C.c_int * n)(); ms = (C.c_float * n)(); by = (C.c_double * n)(); fl = (C.c_double * n)()
+        L.check(self.lib.spb_krn_prof_read(self.context(batch, slot), la, ms, by, fl), "spb_krn_prof_read")
+        out = {}
+        for i in range(n):
+            if la[i]:
+                out[self.lib.spb_krn_prof_category_name(i).decode()] = dict(launches=int(la[i]), ms=float(ms[i]),
+                                                                            bytes=float(by[i]), flops=float(fl[i]))
+        return out
+
+    def weight_prep_bytes(self):
+        return int(self.lib.spb_krn_weight_prep_bytes(self.h))
+
     def bce_logits(self, logits, label, gscale=1.0):
         """mean BCE-with-logits against a constant label; returns (loss [1], dlogit [B])"""
         B = logits.shape[0]

@@ -177,11 +177,11 @@ OPT_KIND = {"sgd": 0, "rmsprop": 1, "adam": 2, "adamw": 3}
 
 
 def optim_step(kind, params, grads, m=None, v=None, sqnorm=None, gmul=None, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8,
-               weight_decay=0.0, max_norm=0.0, clip_value=0.0, step=1, first_step=False):
-    _need_cuda(params, grads, m, v, sqnorm, gmul)
+               weight_decay=0.0, max_norm=0.0, clip_value=0.0, step=1, first_step=False, hyper=None):
+    _need_cuda(params, grads, m, v, sqnorm, gmul, hyper)
     a = L.OptimArgs()
     a.params = _ptr(params); a.grads = _ptr(grads); a.m = _ptr(m); a.v = _ptr(v); a.sqnorm = _ptr(sqnorm)
-    a.gmul = _ptr(gmul); a.mask = None; a.n = params.numel(); a.kind = OPT_KIND[kind]
+    a.gmul = _ptr(gmul); a.hyper = _ptr(hyper); a.n = params.numel(); a.kind = OPT_KIND[kind]
     a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.weight_decay = weight_decay
     a.max_norm = max_norm; a.clip_value = clip_value
     a.bias_c1 = 1.0 - beta1 ** step; a.bias_c2 = 1.0 - beta2 ** step; a.first_step = 1 if first_step else 0

@@ -1,0 +1,135 @@
+"""One fused KRN / DANN training step on the MI355X: forward -> zero_grad -> backward -> [gradient all-reduce] ->
+global-norm clip -> optimizer update, in the reference's order (trainer.py:72-98; dann.py:68-100), enqueued as HIP
+kernels with no host synchronisation and optionally replayed from a captured hipGraph.
+
+The per-step scalars that change between replays (lr, Adam bias corrections) live in a 3-float device buffer that is
+refreshed by an async H2D copy before each step, so the captured launch arguments stay valid.
+"""
+import torch
+
+from . import ops
+
+_KIND_DEFAULT_EPS = 1e-8
+
+
+class FusedTrainStep:
+    def __init__(self, engine, batch, kind="adamw", lr=1e-3, momentum=0.9, weight_decay=0.01, max_norm=1.0,
+                 clip_value=0.0, dist_group=None, world_size=1, use_graph=True, dann=False):
+        self.e = engine
+        self.B = int(batch)
+        self.kind = kind
+        self.lr = float(lr)
+        self.momentum = float(momentum)
+        self.weight_decay = float(weight_decay)
+        self.max_norm = float(max_norm)
+        self.clip_value = float(clip_value)
+        self.world = int(world_size)
+        self.group = dist_group
+        self.use_graph = bool(use_graph)
+        self.dann = bool(dann)
+        dev = engine.device
+        n = engine.n_params
+        self.m = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.v = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.sq = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.gmul = torch.full((1,), 1.0 / self.world, dtype=torch.float32, device=dev) if self.world > 1 else None
+        self.hyper = torch.zeros(3, dtype=torch.float32, device=dev)
+        self.hyper_host = torch.zeros(3, dtype=torch.float32).pin_memory()
+        self.t = 0
+        self._graphs = None
+        self._static = None
+        self.last_scalars = None
+
+    # optimizer hyper-parameters of step t (build.py:60-78: cfg.momentum doubles as RMSprop alpha / Adam beta1)
+    def _betas(self):
+        if self.kind == "rmsprop":
+            return 0.0, self.momentum
+        if self.kind in ("adam", "adamw"):
+            return self.momentum, 0.999
+        return self.momentum, 0.0
+
+    def _refresh_hyper(self):
+        b1, b2 = self._betas()
+        self.hyper_host[0] = self.lr
+        self.hyper_host[1] = 1.0 - b1 ** self.t if b1 > 0 else 1.0
+        self.hyper_host[2] = 1.0 - b2 ** self.t if b2 > 0 else 1.0
+        self.hyper.copy_(self.hyper_host, non_blocking=True)
+
+    # ---- the three phases (phase 2, the collective, is never captured)
+    def _fwd_bwd(self, x, y, xt=None, alpha=0.0):
+        e = self.e
+        if not self.dann:
+            _, scal, _ = e.forward(x, y, training=True, slot=0)
+            e.grads.zero_()
+            e.backward(self.B, slot=0)
+            return scal
+        # DANN: zero_grad, source pass (pose + domain=1), target pass (domain=0), one backward of the sum
+        e.grads.zero_()
+        _, scal, dom_s = e.forward(x, y, training=True, slot=0, domain=True)
+        loss_s, dl_s = e.bce_logits(dom_s, 1.0)
+        _, _, dom_t = e.forward(xt, None, training=True, slot=1, domain=True)
+        loss_t, dl_t = e.bce_logits(dom_t, 0.0)
+        e.backward(self.B, slot=0, with_pose=True, dlogit=dl_s, alpha=alpha)
+        e.backward(self.B, slot=1, with_pose=False, dlogit=dl_t, alpha=alpha)
+        return torch.cat([scal, loss_s, loss_t])
+
+    def _allreduce(self):
+        if self.world > 1:
+            torch.distributed.all_reduce(self.e.grads, group=self.group)  # RCCL sum; the mean is folded into gmul
+
+    def _update(self):
+        e = self.e
+        b1, b2 = self._betas()
+        if self.max_norm > 0:
+            ops.grad_sqnorm(e.grads, self.sq)
+        ops.optim_step(self.kind, e.params, e.grads, m=self.m, v=self.v, sqnorm=self.sq if self.max_norm > 0 else None,
+                       gmul=self.gmul, lr=self.lr, beta1=b1, beta2=b2, eps=_KIND_DEFAULT_EPS,
+                       weight_decay=self.weight_decay, max_norm=self.max_norm, clip_value=self.clip_value, step=max(self.t, 1),
+                       first_step=False, hyper=self.hyper)
+
+    def static_inputs(self):
+        """the graph's input buffers (write a batch into them to skip the per-step device copy)"""
+        return None if self._static is None else (self._static["x"], self._static["y"])
+
+    def _capture(self, x, y, xt, alpha):
+        self._static = dict(x=x.clone(), y=y.clone(), xt=None if xt is None else xt.clone())
+        s = self._static
+        side = torch.cuda.Stream(device=self.e.device)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):  # warm-up outside capture: lazy kernel attributes, context creation
+            self._fwd_bwd(s["x"], s["y"], s["xt"], alpha)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        g1 = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g1):
+            scal = self._fwd_bwd(s["x"], s["y"], s["xt"], alpha)
+        g2 = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g2):
+            self._update()
+        self._graphs = (g1, g2, scal)
+
+    def __call__(self, x, y, xt=None, alpha=0.0):
+        """x [B,3,224,224], y [B,2,K] on the GPU (xt: target-domain images for DANN).  Returns a device tensor
+        (loss, loss_x, loss_y[, loss_domain_source, loss_domain_target]); nothing is synchronised."""
+        self.t += 1
+        if self.kind == "sgd" and self.t == 1 and self.momentum != 0:
+            self.m.zero_()  # buf_1 = g_1 == momentum*0 + g_1
+        self._refresh_hyper()
+        if self.use_graph and not self.dann:
+            if self._graphs is None:
+                self._capture(x, y, xt, alpha)
+            s = self._static
+            if x.data_ptr() != s["x"].data_ptr():
+                s["x"].copy_(x, non_blocking=True)
+            if y.data_ptr() != s["y"].data_ptr():
+                s["y"].copy_(y, non_blocking=True)
+            g1, g2, scal = self._graphs
+            g1.replay()
+            self._allreduce()
+            g2.replay()
+        else:
+            scal = self._fwd_bwd(x, y, xt, alpha)
+            self._allreduce()
+            self._update()
+        self.last_scalars = scal
+        return scal

@@ -71,6 +71,10 @@ def _install_stubs():
     sys.modules["src.utils.visualize"] = vis
 
 
+G7S_TENSORS = ("base.0.1.weight", "base.0.1.bias", "base.9.conv.1.1.weight", "extras.2.conv.1.bias",
+               "extras.3.conv.4.weight", "head.0.bias", "base.17.conv.3.weight")
+
+
 def _cfg(**kw):
     c = types.SimpleNamespace(model_name="krn", num_keypoints=11, num_classes=5000, dann=False, optimizer="adamw", lr=1e-4,
                               momentum=0.9, weight_decay=0.01, max_epochs=75, texture_ratio=0.5, use_cuda=False)
@@ -177,6 +181,24 @@ def main():
     out["g7_losses"] = np.array(losses)
     cs = O.checksum(model.state_dict())
     out["g7_keys"] = np.array(list(cs.keys())); out["g7_checksums"] = np.stack(list(cs.values()))
+
+    # ---- G7s same loop with SGD(momentum): the update is proportional to the gradient, so the post-step state is a
+    # well-conditioned function of it (step 1 of Adam is lr*sign(g), which turns fp32 noise on near-zero gradients
+    # into +-lr flips and is only reproducible between two runs of the very same kernels)
+    model = get_model(_cfg())
+    model.load_state_dict(O.init_state(11), strict=True)
+    cfg_s = _cfg(optimizer="sgd", lr=0.05, momentum=0.9, weight_decay=5e-5)
+    opt = get_optimizer(cfg_s, model)
+    losses = []
+    orig_fwd = model.forward
+    model.forward = spy
+    train_single_epoch_krn(1, cfg_s, model, batches, opt, None, dev)
+    print()
+    out["g7s_losses"] = np.array(losses)
+    cs = O.checksum(model.state_dict())
+    out["g7s_keys"] = np.array(list(cs.keys())); out["g7s_checksums"] = np.stack(list(cs.values()))
+    for k in G7S_TENSORS:
+        out["g7s_final/" + k] = model.state_dict()[k].numpy().copy()
 
     # ---- G6 RevGrad forward + 2 DANN iterations (dann.py)
     cfgd = _cfg(dann=True, max_epochs=5)
