@@ -142,6 +142,9 @@ def lib():
             raise RuntimeError(
                 "libspb_hip.so is missing (%s). Build it with `python -m speedplusbaseline_amd.build`; this package "
                 "has no CPU or PyTorch fallback for the hot path." % LIB_PATH)
+        # torch must load ITS HIP runtime first: the kernels work on torch-allocated device memory and torch's streams,
+        # so libspb_hip.so has to bind to the same libamdhip64 instance (a second runtime sees no device: error 100)
+        import torch  # noqa: F401
         l = C.CDLL(LIB_PATH)
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(l, name)  # AttributeError if the symbol is not exported

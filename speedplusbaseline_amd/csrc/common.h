@@ -64,6 +64,29 @@ template <> __device__ __forceinline__ void st8<bf16_t>(bf16_t* p, const float v
   u.w = (uint32_t)f2bf(v[6]) | ((uint32_t)f2bf(v[7]) << 16);
   *reinterpret_cast<uint4*>(p) = u;
 }
+// Raw (unconverted) 8-element vectors: kernels issue all their global loads back to back into these, with clamped
+// addresses instead of branches, and convert/mask afterwards -- a load inside a conditional block is waited for
+// inside that block, which serialises HBM round trips (measured: 10x on the depthwise kernels).
+template <typename T> struct Raw8;
+template <> struct Raw8<bf16_t> { uint4 u; };
+template <> struct Raw8<float> { float4 a, b; };
+template <typename T> __device__ __forceinline__ Raw8<T> ldraw(const T* p);
+template <> __device__ __forceinline__ Raw8<bf16_t> ldraw<bf16_t>(const bf16_t* p) {
+  Raw8<bf16_t> r; r.u = *reinterpret_cast<const uint4*>(p); return r;
+}
+template <> __device__ __forceinline__ Raw8<float> ldraw<float>(const float* p) {
+  Raw8<float> r; r.a = *reinterpret_cast<const float4*>(p); r.b = *reinterpret_cast<const float4*>(p + 4); return r;
+}
+__device__ __forceinline__ void cvt8(const Raw8<bf16_t>& r, float v[8]) {
+  v[0] = __uint_as_float(r.u.x << 16); v[1] = __uint_as_float(r.u.x & 0xffff0000u);
+  v[2] = __uint_as_float(r.u.y << 16); v[3] = __uint_as_float(r.u.y & 0xffff0000u);
+  v[4] = __uint_as_float(r.u.z << 16); v[5] = __uint_as_float(r.u.z & 0xffff0000u);
+  v[6] = __uint_as_float(r.u.w << 16); v[7] = __uint_as_float(r.u.w & 0xffff0000u);
+}
+__device__ __forceinline__ void cvt8(const Raw8<float>& r, float v[8]) {
+  v[0] = r.a.x; v[1] = r.a.y; v[2] = r.a.z; v[3] = r.a.w; v[4] = r.b.x; v[5] = r.b.y; v[6] = r.b.z; v[7] = r.b.w;
+}
+
 template <typename T> __device__ __forceinline__ void rnd8(float v[8]) {
 #pragma unroll
   for (int i = 0; i < 8; ++i) v[i] = rnd<T>(v[i]);
@@ -71,17 +94,19 @@ template <typename T> __device__ __forceinline__ void rnd8(float v[8]) {
 
 // ---------------------------------------------------------------------------------------------
 // activations (codes are SPB_ACT_* in the public header)
+// All four activations are one branch-free form:  act(u) = min(max(u,0),hi) + ns*min(u,0)
+//   none: hi=inf ns=1   relu: hi=inf ns=0   relu6: hi=6 ns=0   leaky: hi=inf ns=slope
+// (hi, ns) depend on kernel arguments only, so the compiler keeps them in SGPRs; a per-element switch on `act` cost
+// 272 branches and 216 VGPRs in the depthwise kernel.
+__device__ __forceinline__ float act_hi(int act) { return act == SPB_ACT_RELU6 ? 6.f : __builtin_inff(); }
+__device__ __forceinline__ float act_ns(int act, float slope) {
+  return act == SPB_ACT_NONE ? 1.f : (act == SPB_ACT_LEAKY ? slope : 0.f);
+}
 __device__ __forceinline__ float act_fwd(float u, int act, float slope) {
-  if (act == SPB_ACT_RELU) return fmaxf(u, 0.f);
-  if (act == SPB_ACT_RELU6) return fminf(fmaxf(u, 0.f), 6.f);
-  if (act == SPB_ACT_LEAKY) return u > 0.f ? u : u * slope;
-  return u;
+  return fminf(fmaxf(u, 0.f), act_hi(act)) + act_ns(act, slope) * fminf(u, 0.f);
 }
 __device__ __forceinline__ float act_grad(float u, int act, float slope) {
-  if (act == SPB_ACT_RELU) return u > 0.f ? 1.f : 0.f;
-  if (act == SPB_ACT_RELU6) return (u > 0.f && u < 6.f) ? 1.f : 0.f;
-  if (act == SPB_ACT_LEAKY) return u > 0.f ? 1.f : slope;
-  return 1.f;
+  return u > 0.f ? (u < act_hi(act) ? 1.f : 0.f) : act_ns(act, slope);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -108,6 +108,60 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(const spb_gemm_args_t g) {
   const int kvA = t & 3, rowA = t >> 2;  // A tile: rows rowA, rowA+64
   const int KT = Kp / GBK;
 
+    // ---- LOAD_TILE: global loads of one reduction chunk into registers (clamped addresses, no branches)
+#define LOAD_TILE(m0_, kt)                                                                    \
+    {                                                                                         \
+      const int k = (kt) * GBK + kvA * 8;                                                     \
+      const int kc = k < K ? k : K - 8;                                                       \
+      _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                         \
+        const int m = (m0_) + rowA + 64 * i;                                                  \
+        const size_t o = (size_t)(m < M ? m : M - 1) * K + kc;                                \
+        ra[i] = ldraw<T>(Ag + o);                                                             \
+        if (PRO == 2) { if (A2g) ra2[i] = ldraw<T>(A2g + o); }                                \
+      }                                                                                       \
+      _Pragma("unroll") for (int i = 0; i < NBV; ++i) {                                       \
+        const int e = t + 256 * i;                                                            \
+        const int rb_ = e >> 2, kb = (kt) * GBK + (e & 3) * 8;                                \
+        const int n = n0 + (rb_ < BN ? rb_ : BN - 1);                                         \
+        rb[i] = ldraw<T>(Bg + (size_t)(n < N ? n : N - 1) * K + (kb < K ? kb : K - 8));       \
+      }                                                                                       \
+    }
+    // ---- transform + write the staged tile to LDS
+#define STORE_TILE(m0_, kt)                                                                   \
+    {                                                                                         \
+      const int k = (kt) * GBK + kvA * 8;                                                     \
+      _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                         \
+        const int m = (m0_) + rowA + 64 * i;                                                  \
+        float v[8], a1[8], a2[8];                                                             \
+        const bool ok = (m < M && k < K);                                                     \
+        cvt8(ra[i], a1);                                                                      \
+        if (PRO == 2) {                                                                       \
+          if (A2g) cvt8(ra2[i], a2);                                                          \
+          else { _Pragma("unroll") for (int j = 0; j < 8; ++j) a2[j] = 0.f; }                 \
+        }                                                                                     \
+        _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                       \
+          float x;                                                                            \
+          if (PRO == 1) x = act_fwd(a1[j] * coef[k + j] + coef[Kp + k + j], g.pro.act, g.pro.slope); \
+          else x = a1[j] * coef[k + j] + a2[j] * coef[Kp + k + j] + coef[2 * Kp + k + j];     \
+          v[j] = ok ? x : 0.f;                                                                \
+        }                                                                                     \
+        st8<T>(As + (rowA + 64 * i) * LDK + kvA * 8, v);                                      \
+      }                                                                                       \
+      _Pragma("unroll") for (int i = 0; i < NBV; ++i) {                                       \
+        const int e = t + 256 * i;                                                            \
+        const int rb_ = e >> 2, kb = (kt) * GBK + (e & 3) * 8;                                \
+        if (rb_ < BN) {                                                                       \
+          float v[8];                                                                         \
+          cvt8(rb[i], v);                                                                     \
+          const bool ok = (n0 + rb_ < N) && (kb < K);                                         \
+          _Pragma("unroll") for (int j = 0; j < 8; ++j) v[j] = ok ? v[j] : 0.f;               \
+          st8<T>(Bs + rb_ * LDK + (e & 3) * 8, v);                                            \
+        }                                                                                     \
+      }                                                                                       \
+    }
+
+  Raw8<T> ra[2], ra2[2], rb[NBV];
+  if (lid / NT < MT) LOAD_TILE((lid / NT) * GBM, 0);
   for (int mt = lid / NT; mt < MT; mt += GM) {
     const int m0 = mt * GBM;
     f32x4_t acc[2][NF];
@@ -116,59 +170,10 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(const spb_gemm_args_t g) {
 #pragma unroll
       for (int j = 0; j < NF; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
-    float ra[2][8], ra2[2][8], rb[NBV][8];
-    // ---- global loads for reduction tile kt into registers
-#define LOAD_TILE(kt)                                                                         \
-    {                                                                                         \
-      const int k = (kt) * GBK + kvA * 8;                                                     \
-      _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                         \
-        const int m = m0 + rowA + 64 * i;                                                     \
-        if (m < M && k < K) {                                                                 \
-          ld8<T>(Ag + (size_t)m * K + k, ra[i]);                                              \
-          if (PRO == 2) {                                                                     \
-            if (A2g) ld8<T>(A2g + (size_t)m * K + k, ra2[i]);                                 \
-            else { _Pragma("unroll") for (int j = 0; j < 8; ++j) ra2[i][j] = 0.f; }           \
-          }                                                                                   \
-        } else {                                                                              \
-          _Pragma("unroll") for (int j = 0; j < 8; ++j) { ra[i][j] = 0.f; ra2[i][j] = 0.f; }  \
-        }                                                                                     \
-      }                                                                                       \
-      _Pragma("unroll") for (int i = 0; i < NBV; ++i) {                                       \
-        const int e = t + 256 * i;                                                            \
-        const int rb_ = e >> 2, kb = (kt) * GBK + (e & 3) * 8;                                \
-        const int n = n0 + rb_;                                                               \
-        if (rb_ < BN && n < N && kb < K) ld8<T>(Bg + (size_t)n * K + kb, rb[i]);              \
-        else { _Pragma("unroll") for (int j = 0; j < 8; ++j) rb[i][j] = 0.f; }                \
-      }                                                                                       \
-    }
-    // ---- transform + write the staged tile to LDS
-#define STORE_TILE(kt)                                                                        \
-    {                                                                                         \
-      const int k = (kt) * GBK + kvA * 8;                                                     \
-      _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                         \
-        const int m = m0 + rowA + 64 * i;                                                     \
-        float v[8];                                                                           \
-        const bool ok = (m < M && k < K);                                                     \
-        _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                       \
-          float x;                                                                            \
-          if (PRO == 1) x = act_fwd(ra[i][j] * coef[k + j] + coef[Kp + k + j], g.pro.act, g.pro.slope); \
-          else x = ra[i][j] * coef[k + j] + ra2[i][j] * coef[Kp + k + j] + coef[2 * Kp + k + j]; \
-          v[j] = ok ? x : 0.f;                                                                \
-        }                                                                                     \
-        st8<T>(As + (rowA + 64 * i) * LDK + kvA * 8, v);                                      \
-      }                                                                                       \
-      _Pragma("unroll") for (int i = 0; i < NBV; ++i) {                                       \
-        const int e = t + 256 * i;                                                            \
-        const int rb_ = e >> 2;                                                               \
-        if (rb_ < BN) st8<T>(Bs + rb_ * LDK + (e & 3) * 8, rb[i]);                            \
-      }                                                                                       \
-    }
-
-    LOAD_TILE(0);
     for (int kt = 0; kt < KT; ++kt) {
-      STORE_TILE(kt);
+      STORE_TILE(m0, kt);
       __syncthreads();
-      if (kt + 1 < KT) LOAD_TILE(kt + 1);
+      if (kt + 1 < KT) LOAD_TILE(m0, kt + 1);
       if constexpr (sizeof(T) == 2) {
         bf16x8_t af[2];
 #pragma unroll
@@ -196,8 +201,19 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(const spb_gemm_args_t g) {
       }
       __syncthreads();
     }
-#undef LOAD_TILE
-#undef STORE_TILE
+    // next M tile's first chunk and this tile's output-side operands: in flight during the epilogue
+    if (mt + GM < MT) LOAD_TILE((mt + GM) * GBM, 0);
+    constexpr int VRI = GBM / VR;
+    Raw8<T> zr[EPI == 2 ? VRI : 1], rr[EPI == 2 ? VRI : 1];
+    if (EPI == 2) {
+#pragma unroll
+      for (int s = 0; s < VRI; ++s) {
+        const int m = m0 + vrow0 + s * VR;
+        const size_t o = (size_t)(m < M ? m : M - 1) * N + (colok ? nE : 0);
+        zr[EPI == 2 ? s : 0] = ldraw<T>(Zg + o);
+        if (Rg) rr[EPI == 2 ? s : 0] = ldraw<T>(Rg + o);
+      }
+    }
 
     // ---- accumulators -> LDS (C layout: col = lane&15, row = (lane>>4)*4 + r)
 #pragma unroll
@@ -228,12 +244,12 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(const spb_gemm_args_t g) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) { s1[j] += v[j]; s2[j] += v[j] * v[j]; }
           } else {
-            float z[8], rr[8];
-            ld8<T>(Zg + o, z);
+            float z[8], rv[8];
+            cvt8(zr[EPI == 2 ? s : 0], z);
             if (Rg) {
-              ld8<T>(Rg + o, rr);
+              cvt8(rr[EPI == 2 ? s : 0], rv);
 #pragma unroll
-              for (int j = 0; j < 8; ++j) v[j] += rr[j];
+              for (int j = 0; j < 8; ++j) v[j] += rv[j];
             }
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
@@ -250,6 +266,8 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(const spb_gemm_args_t g) {
     }
     __syncthreads();
   }
+#undef LOAD_TILE
+#undef STORE_TILE
 
   // ---- per-channel batch sums: reduce over the workgroup, one atomic per channel per workgroup
   if (EPI != 0) {
@@ -305,6 +323,7 @@ int dispatch_bn(const spb_gemm_args_t& g, hipStream_t stream) {
     bn = (p128 <= p64) ? 128 : 64;
   }
   if (sizeof(T) == 4 && bn == 128) bn = 64;  // parity mode: keep the LDS footprint small
+  if (EPI == 2 && bn == 128) bn = 64;        // backward epilogue hoists 2 operand vectors per output row sweep
   if (bn == 32) return launch_gemm<T, 32, PRO, EPI>(g, stream);
   if (bn == 64) return launch_gemm<T, 64, PRO, EPI>(g, stream);
   return launch_gemm<T, 128, PRO, EPI>(g, stream);
@@ -368,40 +387,44 @@ __global__ __launch_bounds__(256) void pw_wgrad_kernel(const spb_wgrad_args_t g,
     for (int b = 0; b < 2; ++b) acc[a][b] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
   const int cv = t & 7, rw = t >> 3;  // rows rw, rw+32; columns cv*8..cv*8+7
+  const int nl = n0 + cv * 8, kl = k0 + cv * 8;
+  const int nlc = nl < N ? nl : N - 8, klc = kl < K ? kl : K - 8;
+  Raw8<T> gr[2], zr[2], xr[2];
+  // all global loads of a stage are issued together with clamped addresses; the next stage's loads are in flight
+  // while the matrix cores work on the current one
+#define WG_LOAD(mb_)                                                          \
+  _Pragma("unroll") for (int i = 0; i < 2; ++i) {                             \
+    const int m = (mb_) + rw + 32 * i;                                        \
+    const size_t mc_ = (size_t)(m < mend ? m : mend - 1);                     \
+    gr[i] = ldraw<T>(Gg + mc_ * N + nlc);                                     \
+    if (Zg) zr[i] = ldraw<T>(Zg + mc_ * N + nlc);                             \
+    xr[i] = ldraw<T>(Xg + mc_ * K + klc);                                     \
+  }
+  if (mbeg < mend) WG_LOAD(mbeg);
   for (int mb = mbeg; mb < mend; mb += WM) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int r = rw + 32 * i, m = mb + r;
-      float v[8];
-      {  // dz tile
-        const int n = n0 + cv * 8;
-        const bool ok = (m < mend) && (n < N);
-        float gg[8], zz[8];
-        if (ok) {
-          ld8<T>(Gg + (size_t)m * N + n, gg);
-          if (Zg) ld8<T>(Zg + (size_t)m * N + n, zz);
-          else {
+      float v[8], gg[8], zz[8], xx[8];
+      cvt8(gr[i], gg);
+      if (Zg) cvt8(zr[i], zz);
+      else {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) zz[j] = 0.f;
-          }
-        }
-#pragma unroll
-        for (int j = 0; j < 8; ++j)
-          v[j] = ok ? (gg[j] * cz[0][cv * 8 + j] + zz[j] * cz[1][cv * 8 + j] + cz[2][cv * 8 + j]) : 0.f;
-        st8<T>(Ds + r * LD + cv * 8, v);
+        for (int j = 0; j < 8; ++j) zz[j] = 0.f;
       }
-      {  // a tile
-        const int k = k0 + cv * 8;
-        const bool ok = (m < mend) && (k < K);
-        float xx[8];
-        if (ok) ld8<T>(Xg + (size_t)m * K + k, xx);
+      cvt8(xr[i], xx);
+      const bool okn = (m < mend) && (nl < N), okk = (m < mend) && (kl < K);
 #pragma unroll
-        for (int j = 0; j < 8; ++j)
-          v[j] = ok ? act_fwd(xx[j] * ca[0][cv * 8 + j] + ca[1][cv * 8 + j], g.pro_a.act, g.pro_a.slope) : 0.f;
-        st8<T>(Xs + r * LD + cv * 8, v);
-      }
+      for (int j = 0; j < 8; ++j)
+        v[j] = okn ? (gg[j] * cz[0][cv * 8 + j] + zz[j] * cz[1][cv * 8 + j] + cz[2][cv * 8 + j]) : 0.f;
+      st8<T>(Ds + r * LD + cv * 8, v);
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        v[j] = okk ? act_fwd(xx[j] * ca[0][cv * 8 + j] + ca[1][cv * 8 + j], g.pro_a.act, g.pro_a.slope) : 0.f;
+      st8<T>(Xs + r * LD + cv * 8, v);
     }
     __syncthreads();
+    if (mb + WM < mend) WG_LOAD(mb + WM);
     if constexpr (sizeof(T) == 2) {
 #pragma unroll
       for (int mc = 0; mc < WM / 32; ++mc) {
@@ -444,6 +467,7 @@ __global__ __launch_bounds__(256) void pw_wgrad_kernel(const spb_wgrad_args_t g,
     }
     __syncthreads();
   }
+#undef WG_LOAD
 
 #pragma unroll
   for (int a = 0; a < 2; ++a)

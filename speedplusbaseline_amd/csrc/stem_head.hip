@@ -41,8 +41,9 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx) {
           const int iw = ow * 2 - 1 + kx;
-          float xv = 0.f;
-          if (ih >= 0 && ih < H && iw >= 0 && iw < W) xv = x[((size_t)(b * 3 + ci) * H + ih) * W + iw];
+          const int ihc = ih < 0 ? 0 : (ih >= H ? H - 1 : ih), iwc = iw < 0 ? 0 : (iw >= W ? W - 1 : iw);
+          float xv = x[((size_t)(b * 3 + ci) * H + ihc) * W + iwc];  // clamped address: no branch around the load
+          xv = (ih == ihc && iw == iwc) ? xv : 0.f;
           const float* wr = wl + (ci * 9 + ky * 3 + kx) * 32 + cg * 8;
 #pragma unroll
           for (int j = 0; j < 8; ++j) acc[j] += xv * wr[j];
@@ -97,8 +98,9 @@ __global__ __launch_bounds__(192) void stem_wgrad_kernel(const float* __restrict
 #pragma unroll
       for (int kx = 0; kx < 3; ++kx) {
         const int iw = ow * 2 - 1 + kx;
-        float xv = 0.f;
-        if (ih >= 0 && ih < H && iw >= 0 && iw < W) xv = x[((size_t)(b * 3 + ci) * H + ih) * W + iw];
+        const int ihc = ih < 0 ? 0 : (ih >= H ? H - 1 : ih), iwc = iw < 0 ? 0 : (iw >= W ? W - 1 : iw);
+        float xv = x[((size_t)(b * 3 + ci) * H + ihc) * W + iwc];
+        xv = (ih == ihc && iw == iwc) ? xv : 0.f;
 #pragma unroll
         for (int j = 0; j < 8; ++j) aw[ky * 3 + kx][j] += xv * dz[j];
       }
@@ -211,34 +213,46 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const spb_head_args_t a, 
   }
 }
 
-// pred = sum of split-K partials + bias; loss = sum_k mean_b (x-tx)^2 + (y-ty)^2 (park2019.py:142-156)
-__global__ __launch_bounds__(256) void head_loss_kernel(const spb_head_args_t a) {
-  __shared__ float rx[256], ry[256];
-  const int t = threadIdx.x;
-  const int nK = a.J / 2;
-  float lx = 0.f, ly = 0.f;
-  for (int idx = t; idx < a.B * a.J; idx += 256) {
-    const int b = idx / a.J, j = idx % a.J;
-    float s = a.bias ? a.bias[j] : 0.f;
-    for (int w = 0; w < a.S; ++w) s += a.partial[((size_t)w * a.B + b) * a.Jp + j];
-    a.pred[idx] = s;
-    if (a.target) {
-      const float tg = a.target[(size_t)b * a.J + (j & 1) * nK + (j >> 1)];
-      const float d = s - tg;
-      if (j & 1) ly += d * d; else lx += d * d;
-      a.dout[idx] = 2.f * d / (float)a.B;
+// pred = sum of split-K partials + bias; loss = sum_k mean_b (x-tx)^2 + (y-ty)^2 (park2019.py:142-156).
+// 64 outputs per workgroup, 4 lane groups each summing a quarter of the partials with independent (pipelined) loads.
+__global__ __launch_bounds__(256) void head_reduce_kernel(const spb_head_args_t a) {
+  __shared__ float red[4][64];
+  __shared__ float rl[2][64];
+  const int t = threadIdx.x, i = t & 63, q = t >> 6;
+  const int idx = blockIdx.x * 64 + i;
+  const bool ok = idx < a.B * a.J;
+  const int b = ok ? idx / a.J : 0, j = ok ? idx % a.J : 0;
+  const int per = a.S / 4;
+  const size_t stride = (size_t)a.B * a.Jp;
+  const float* p = a.partial + ((size_t)q * per * a.B + b) * a.Jp + j;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int w = 0;
+  for (; w + 4 <= per; w += 4) {
+    s0 += p[(size_t)w * stride]; s1 += p[(size_t)(w + 1) * stride];
+    s2 += p[(size_t)(w + 2) * stride]; s3 += p[(size_t)(w + 3) * stride];
+  }
+  for (; w < per; ++w) s0 += p[(size_t)w * stride];
+  red[q][i] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (q == 0) {
+    float lx = 0.f, ly = 0.f;
+    if (ok) {
+      const float s = red[0][i] + red[1][i] + red[2][i] + red[3][i] + (a.bias ? a.bias[j] : 0.f);
+      a.pred[idx] = s;
+      if (a.target) {
+        const int nK = a.J / 2;
+        const float d = s - a.target[(size_t)b * a.J + (j & 1) * nK + (j >> 1)];
+        if (j & 1) ly = d * d; else lx = d * d;
+        a.dout[idx] = 2.f * d / (float)a.B;
+      }
+    }
+    lx = wave_sum(lx); ly = wave_sum(ly);
+    if (i == 0 && a.target && a.scalars) {
+      lx /= (float)a.B; ly /= (float)a.B;
+      atomicAdd(a.scalars + 0, lx + ly); atomicAdd(a.scalars + 1, lx); atomicAdd(a.scalars + 2, ly);
     }
   }
-  rx[t] = lx; ry[t] = ly;
-  __syncthreads();
-  for (int o = 128; o > 0; o >>= 1) {
-    if (t < o) { rx[t] += rx[t + o]; ry[t] += ry[t + o]; }
-    __syncthreads();
-  }
-  if (t == 0 && a.target && a.scalars) {
-    const float fx = rx[0] / (float)a.B, fy = ry[0] / (float)a.B;
-    a.scalars[0] = fx + fy; a.scalars[1] = fx; a.scalars[2] = fy;
-  }
+  (void)rl;
 }
 
 // ------------------------------------------------------------------------------------------------ head backward
@@ -415,7 +429,11 @@ extern "C" int spb_head_fwd(int dtype, const spb_head_args_t* a, spb_stream_t st
     hipLaunchKernelGGL(head_fwd_kernel<float>, dim3(a->S / 4), dim3(256), lds, (hipStream_t)stream, *a, kchunk);
   else return SPB_E_ARG;
   SPB_CHECK_LAUNCH();
-  hipLaunchKernelGGL(head_loss_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, *a);
+  if (a->target) {
+    hipError_t me = hipMemsetAsync(a->scalars, 0, 3 * sizeof(float), (hipStream_t)stream);
+    if (me != hipSuccess) return (int)me;
+  }
+  hipLaunchKernelGGL(head_reduce_kernel, dim3(spb_ceil_div(a->B * a->J, 64)), dim3(256), 0, (hipStream_t)stream, *a);
   SPB_CHECK_LAUNCH();
   return 0;
 }
