@@ -1,0 +1,47 @@
+"""python adapt.py --perform_dann ...  -- same command line as the reference's adapt.py:47-148, MI355X backend."""
+import logging
+import os
+import os.path as osp
+
+import torch
+
+from config import cfg
+from speedplusbaseline_amd.core.dann import train_dann_single_epoch_krn
+from speedplusbaseline_amd.data import SyntheticKeypointLoader
+from speedplusbaseline_amd.nets import get_model, get_optimizer
+from speedplusbaseline_amd.utils import load_checkpoint, save_checkpoint, set_all_seeds, setup_logger
+
+logger = logging.getLogger(__name__)
+
+
+def main():
+    assert cfg.dann and cfg.model_name == 'krn', 'DANN (--perform_dann) is only for KRN'
+    if not (torch.cuda.is_available() and cfg.use_cuda):
+        raise SystemExit("This build runs on an AMD MI355X only (HIP kernels).")
+    device = torch.device('cuda:0')
+    setup_logger('adapt')
+    set_all_seeds(2021, cfg, True)  # the reference pins 2021 here (adapt.py:55)
+    os.makedirs(cfg.savedir, exist_ok=True)
+    model = get_model(cfg)
+    optimizer = get_optimizer(cfg, model)
+    checkpoint_file = osp.join(cfg.savedir, 'checkpoint.pth.tar')
+    begin_epoch = 0
+    if cfg.auto_resume and osp.exists(checkpoint_file):
+        begin_epoch, _ = load_checkpoint(checkpoint_file, model, optimizer, device)
+    elif cfg.pretrained and osp.exists(cfg.pretrained):
+        model.net.load_state_dict(torch.load(cfg.pretrained, map_location='cpu'), strict=True)
+    model = model.to(device)
+    lr_scheduler = torch.optim.lr_scheduler.StepLR(optimizer, step_size=cfg.lr_decay_step, gamma=cfg.lr_decay_alpha)
+    if cfg.synthetic_batches <= 0:
+        raise SystemExit("The SPEED+ dataset pipeline is not part of this build; pass --synthetic_batches N.")
+    src = SyntheticKeypointLoader(cfg.batch_size, cfg.synthetic_batches, cfg.num_keypoints, cfg.input_shape, seed=cfg.seed)
+    tgt = SyntheticKeypointLoader(cfg.batch_size, cfg.synthetic_batches, cfg.num_keypoints, cfg.input_shape, labels=False, seed=cfg.seed + 1)
+    for epoch in range(begin_epoch, cfg.max_epochs):
+        train_dann_single_epoch_krn(epoch, cfg, model, src, tgt, optimizer, None, device)
+        lr_scheduler.step()
+        save_checkpoint({'epoch': epoch + 1, 'model': cfg.model_name, 'state_dict': model.state_dict(),
+                         'best_score': epoch + 1, 'optimizer': optimizer.state_dict()}, True, cfg.savedir)
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,59 @@
+"""Epoch drivers -- mirror of reference src/core/trainer.py:41-199 (same names and positional signatures; train.py
+looks them up by name).  The per-batch sequence is the reference's: to(device), optional style augmentation, forward,
+zero_grad, backward, clip_grad_norm_(1.0), optimizer step, meters.  With the FusedOptimizer returned by get_optimizer the
+whole sequence is one train_step() of HIP launches; any other torch optimizer goes through the generic autograd path."""
+import logging
+import random
+import time
+
+from torch.nn.utils import clip_grad_norm_
+
+from ..optim import FusedOptimizer
+from ..utils import AverageMeter, report_progress
+
+logger = logging.getLogger("Training")
+
+
+def train_single_epoch_krn(epoch, cfg, model, data_loader, optimizer, writer, device, styleAugmentor=None, scaler=None):
+    training_time_meter = AverageMeter('ms')
+    loss_x_meter = AverageMeter('-')
+    loss_y_meter = AverageMeter('-')
+    model.train()
+    lr = optimizer.param_groups[-1]['lr']
+    fused = isinstance(optimizer, FusedOptimizer) and scaler is None
+    n_iter = len(data_loader)
+    for idx, (images, target) in enumerate(data_loader):
+        start = time.time()
+        B = images.shape[0]
+        images = images.to(device, non_blocking=True)
+        target = target.to(device, non_blocking=True)
+        if styleAugmentor is not None and random.random() < cfg.texture_ratio:
+            images = styleAugmentor(images)
+        if fused:
+            lx, ly = optimizer.train_step(images, target)[1:3].tolist()  # host floats per step, as the reference reports
+        else:
+            loss, summary = model(images, target)
+            optimizer.zero_grad(set_to_none=True)
+            if scaler is not None:
+                scaler.scale(loss).backward()
+                scaler.unscale_(optimizer)
+                clip_grad_norm_(model.parameters(), 1.0)
+                scaler.step(optimizer)
+                scaler.update()
+            else:
+                loss.backward()
+                clip_grad_norm_(model.parameters(), 1.0)
+                optimizer.step()
+            lx, ly = summary['loss_x'], summary['loss_y']
+        training_time_meter.update((time.time() - start) * 1000, B)
+        loss_x_meter.update(lx, B)
+        loss_y_meter.update(ly, B)
+        report_progress(epoch=epoch, lr=lr, epoch_iter=idx + 1, epoch_size=n_iter, time=training_time_meter, is_train=True,
+                        loss_x=loss_x_meter, loss_y=loss_y_meter)
+    if writer is not None:
+        writer.add_scalar('train/loss_x', loss_x_meter.avg, epoch)
+        writer.add_scalar('train/loss_y', loss_y_meter.avg, epoch)
+
+
+def train_single_epoch_spn(epoch, cfg, model, data_loader, optimizer, writer, device, styleAugmentor=None, scaler=None):
+    raise NotImplementedError("the SPN training step has no HIP path yet (DESIGN.md: scope / next rows)")

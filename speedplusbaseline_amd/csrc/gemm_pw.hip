@@ -20,28 +20,31 @@
 
 namespace {
 
-constexpr int GBM = 128;
-constexpr int GBK = 32;
+constexpr int GBK = 32;   // reduction chunk per LDS stage
 
 template <typename T> struct LdsPad { static constexpr int LDK = GBK + 8; };
 template <> struct LdsPad<float> { static constexpr int LDK = GBK + 4; };
 
-template <typename T, int BN>
+template <typename T, int RF, int BN>
 constexpr size_t gemm_region_bytes() {
-  size_t a = (size_t)(GBM + BN) * LdsPad<T>::LDK * sizeof(T);
-  size_t b = (size_t)GBM * (BN + 8) * sizeof(T);
+  constexpr int BM = 64 * RF;
+  size_t a = (size_t)(BM + BN) * LdsPad<T>::LDK * sizeof(T);
+  size_t b = (size_t)BM * (BN + 8) * sizeof(T);
   size_t c = (size_t)2 * 256 * 8 * sizeof(float);  // stats reduction scratch
   size_t m = a > b ? a : b;
   return m > c ? m : c;
 }
 
-template <typename T, int BN, int PRO, int EPI>
+// RF = 16-row fragments per wave (workgroup tile = 64*RF rows x BN columns)
+template <typename T, int RF, int BN, int PRO, int EPI>
 __global__ __launch_bounds__(256) void pw_gemm_kernel(const spb_gemm_args_t g) {
+  constexpr int BM = 64 * RF;
   constexpr int LDK = LdsPad<T>::LDK;
   constexpr int LDO = BN + 8;
   constexpr int NF = BN / 16;           // 16-wide column fragments per wave
   constexpr int NV = BN / 8;            // 8-wide column vectors per tile row
   constexpr int VR = 256 / NV;          // rows covered per epilogue sweep
+  constexpr int VRI = (BM + VR - 1) / VR;
   constexpr int NBV = (BN * 4 + 255) / 256;  // B-tile vec8 loads per thread
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -49,7 +52,7 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(const spb_gemm_args_t g) {
   const int Kp = (K + GBK - 1) / GBK * GBK;
   float* coef = reinterpret_cast<float*>(smem);  // [3][Kp]
   T* As = reinterpret_cast<T*>(smem + (size_t)3 * Kp * sizeof(float));
-  T* Bs = As + GBM * LDK;
+  T* Bs = As + BM * LDK;
   T* Os = As;
 
   const int t = threadIdx.x;
@@ -67,7 +70,7 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(const spb_gemm_args_t g) {
   }
 
   const int NT = (N + BN - 1) / BN;
-  const int MT = (M + GBM - 1) / GBM;
+  const int MT = (M + BM - 1) / BM;
   const int lid = xcd_remap(blockIdx.x, gridDim.x);
   const int nt = lid % NT;
   const int GM = gridDim.x / NT;
@@ -96,7 +99,6 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(const spb_gemm_args_t g) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) e_bias[j] = (colok && g.bias) ? g.bias[nE + j] : 0.f;
   }
-  __syncthreads();
 
   const T* Ag = reinterpret_cast<const T*>(g.A);
   const T* A2g = reinterpret_cast<const T*>(g.A2);
@@ -105,38 +107,40 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(const spb_gemm_args_t g) {
   const T* Rg = reinterpret_cast<const T*>(g.res);
   const T* Zg = reinterpret_cast<const T*>(g.Zout);
 
-  const int kvA = t & 3, rowA = t >> 2;  // A tile: rows rowA, rowA+64
+  const int kvA = t & 3, rowA = t >> 2;  // A tile: rows rowA + 64*i
   const int KT = Kp / GBK;
 
-    // ---- LOAD_TILE: global loads of one reduction chunk into registers (clamped addresses, no branches)
-#define LOAD_TILE(m0_, kt)                                                                    \
+  // Two register sets: the loads of reduction chunks kt+1 and kt+2 are in flight while chunk kt is on the matrix cores
+  // (one set left the K loop of a 48-workgroup layer latency-bound at 2.3 us per chunk).  Clamped addresses, no
+  // branches around loads.
+  Raw8<T> ra[2][RF], ra2[2][RF], rb[2][NBV];
+#define LOAD_TILE(S, m0_, kt)                                                                 \
     {                                                                                         \
       const int k = (kt) * GBK + kvA * 8;                                                     \
       const int kc = k < K ? k : K - 8;                                                       \
-      _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                         \
+      _Pragma("unroll") for (int i = 0; i < RF; ++i) {                                        \
         const int m = (m0_) + rowA + 64 * i;                                                  \
         const size_t o = (size_t)(m < M ? m : M - 1) * K + kc;                                \
-        ra[i] = ldraw<T>(Ag + o);                                                             \
-        if (PRO == 2) { if (A2g) ra2[i] = ldraw<T>(A2g + o); }                                \
+        ra[S][i] = ldraw<T>(Ag + o);                                                          \
+        if (PRO == 2) { if (A2g) ra2[S][i] = ldraw<T>(A2g + o); }                             \
       }                                                                                       \
       _Pragma("unroll") for (int i = 0; i < NBV; ++i) {                                       \
         const int e = t + 256 * i;                                                            \
         const int rb_ = e >> 2, kb = (kt) * GBK + (e & 3) * 8;                                \
         const int n = n0 + (rb_ < BN ? rb_ : BN - 1);                                         \
-        rb[i] = ldraw<T>(Bg + (size_t)(n < N ? n : N - 1) * K + (kb < K ? kb : K - 8));       \
+        rb[S][i] = ldraw<T>(Bg + (size_t)(n < N ? n : N - 1) * K + (kb < K ? kb : K - 8));    \
       }                                                                                       \
     }
-    // ---- transform + write the staged tile to LDS
-#define STORE_TILE(m0_, kt)                                                                   \
+#define STORE_TILE(S, m0_, kt)                                                                \
     {                                                                                         \
       const int k = (kt) * GBK + kvA * 8;                                                     \
-      _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                         \
+      _Pragma("unroll") for (int i = 0; i < RF; ++i) {                                        \
         const int m = (m0_) + rowA + 64 * i;                                                  \
         float v[8], a1[8], a2[8];                                                             \
         const bool ok = (m < M && k < K);                                                     \
-        cvt8(ra[i], a1);                                                                      \
+        cvt8(ra[S][i], a1);                                                                   \
         if (PRO == 2) {                                                                       \
-          if (A2g) cvt8(ra2[i], a2);                                                          \
+          if (A2g) cvt8(ra2[S][i], a2);                                                       \
           else { _Pragma("unroll") for (int j = 0; j < 8; ++j) a2[j] = 0.f; }                 \
         }                                                                                     \
         _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                       \
@@ -152,58 +156,69 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(const spb_gemm_args_t g) {
         const int rb_ = e >> 2, kb = (kt) * GBK + (e & 3) * 8;                                \
         if (rb_ < BN) {                                                                       \
           float v[8];                                                                         \
-          cvt8(rb[i], v);                                                                     \
+          cvt8(rb[S][i], v);                                                                  \
           const bool ok = (n0 + rb_ < N) && (kb < K);                                         \
           _Pragma("unroll") for (int j = 0; j < 8; ++j) v[j] = ok ? v[j] : 0.f;               \
           st8<T>(Bs + rb_ * LDK + (e & 3) * 8, v);                                            \
         }                                                                                     \
       }                                                                                       \
     }
+#define MMA_TILE()                                                                                            \
+    if constexpr (sizeof(T) == 2) {                                                                            \
+      bf16x8_t af[RF];                                                                                         \
+      _Pragma("unroll") for (int i = 0; i < RF; ++i)                                                           \
+        af[i] = *reinterpret_cast<const bf16x8_t*>(As + (w * 16 * RF + i * 16 + li) * LDK + lq * 8);           \
+      _Pragma("unroll") for (int j = 0; j < NF; ++j) {                                                         \
+        const bf16x8_t bfv = *reinterpret_cast<const bf16x8_t*>(Bs + (j * 16 + li) * LDK + lq * 8);            \
+        _Pragma("unroll") for (int i = 0; i < RF; ++i)                                                         \
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfv, acc[i][j], 0, 0, 0);                 \
+      }                                                                                                        \
+    } else {                                                                                                   \
+      _Pragma("unroll") for (int kk = 0; kk < GBK / 4; ++kk) {                                                 \
+        float af[RF];                                                                                          \
+        _Pragma("unroll") for (int i = 0; i < RF; ++i) af[i] = As[(w * 16 * RF + i * 16 + li) * LDK + kk * 4 + lq]; \
+        _Pragma("unroll") for (int j = 0; j < NF; ++j) {                                                       \
+          const float bfv = Bs[(j * 16 + li) * LDK + kk * 4 + lq];                                             \
+          _Pragma("unroll") for (int i = 0; i < RF; ++i)                                                       \
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bfv, acc[i][j], 0, 0, 0);                  \
+        }                                                                                                      \
+      }                                                                                                        \
+    }
 
-  Raw8<T> ra[2], ra2[2], rb[NBV];
-  if (lid / NT < MT) LOAD_TILE((lid / NT) * GBM, 0);
+  if (lid / NT < MT) {
+    LOAD_TILE(0, (lid / NT) * BM, 0);
+    if (KT > 1) LOAD_TILE(1, (lid / NT) * BM, 1);
+  }
+  __syncthreads();  // coefficients visible
+
   for (int mt = lid / NT; mt < MT; mt += GM) {
-    const int m0 = mt * GBM;
-    f32x4_t acc[2][NF];
+    const int m0 = mt * BM;
+    f32x4_t acc[RF][NF];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < RF; ++i)
 #pragma unroll
       for (int j = 0; j < NF; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
-    for (int kt = 0; kt < KT; ++kt) {
-      STORE_TILE(m0, kt);
+    for (int kt = 0; kt < KT; kt += 2) {
+      STORE_TILE(0, m0, kt);
       __syncthreads();
-      if (kt + 1 < KT) LOAD_TILE(m0, kt + 1);
-      if constexpr (sizeof(T) == 2) {
-        bf16x8_t af[2];
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-          af[i] = *reinterpret_cast<const bf16x8_t*>(As + (w * 32 + i * 16 + li) * LDK + lq * 8);
-#pragma unroll
-        for (int j = 0; j < NF; ++j) {
-          const bf16x8_t bfv = *reinterpret_cast<const bf16x8_t*>(Bs + (j * 16 + li) * LDK + lq * 8);
-#pragma unroll
-          for (int i = 0; i < 2; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfv, acc[i][j], 0, 0, 0);
-        }
-      } else {
-#pragma unroll
-        for (int kk = 0; kk < GBK / 4; ++kk) {
-          float af[2];
-#pragma unroll
-          for (int i = 0; i < 2; ++i) af[i] = As[(w * 32 + i * 16 + li) * LDK + kk * 4 + lq];
-#pragma unroll
-          for (int j = 0; j < NF; ++j) {
-            const float bfv = Bs[(j * 16 + li) * LDK + kk * 4 + lq];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bfv, acc[i][j], 0, 0, 0);
-          }
-        }
+      if (kt + 2 < KT) LOAD_TILE(0, m0, kt + 2);
+      MMA_TILE();
+      __syncthreads();
+      if (kt + 1 < KT) {
+        STORE_TILE(1, m0, kt + 1);
+        __syncthreads();
+        if (kt + 3 < KT) LOAD_TILE(1, m0, kt + 3);
+        MMA_TILE();
+        __syncthreads();
       }
-      __syncthreads();
     }
-    // next M tile's first chunk and this tile's output-side operands: in flight during the epilogue
-    if (mt + GM < MT) LOAD_TILE((mt + GM) * GBM, 0);
-    constexpr int VRI = GBM / VR;
+
+    // next M tile's first chunks and this tile's output-side operands: in flight during the epilogue
+    if (mt + GM < MT) {
+      LOAD_TILE(0, (mt + GM) * BM, 0);
+      if (KT > 1) LOAD_TILE(1, (mt + GM) * BM, 1);
+    }
     Raw8<T> zr[EPI == 2 ? VRI : 1], rr[EPI == 2 ? VRI : 1];
     if (EPI == 2) {
 #pragma unroll
@@ -217,21 +232,21 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(const spb_gemm_args_t g) {
 
     // ---- accumulators -> LDS (C layout: col = lane&15, row = (lane>>4)*4 + r)
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < RF; ++i)
 #pragma unroll
       for (int j = 0; j < NF; ++j)
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-          Os[(w * 32 + i * 16 + lq * 4 + r) * LDO + j * 16 + li] = from_f<T>(acc[i][j][r]);
+          Os[(w * 16 * RF + i * 16 + lq * 4 + r) * LDO + j * 16 + li] = from_f<T>(acc[i][j][r]);
     __syncthreads();
 
     // ---- coalesced epilogue: 16-byte vectors along the channel axis
     if (colok) {
 #pragma unroll
-      for (int s = 0; s < GBM / VR; ++s) {
+      for (int s = 0; s < VRI; ++s) {
         const int r = vrow0 + s * VR;
         const int m = m0 + r;
-        if (m < M) {
+        if (r < BM && m < M) {
           float v[8];
           ld8<T>(Os + r * LDO + vcol * 8, v);
           const size_t o = (size_t)m * N + nE;
@@ -268,6 +283,7 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(const spb_gemm_args_t g) {
   }
 #undef LOAD_TILE
 #undef STORE_TILE
+#undef MMA_TILE
 
   // ---- per-channel batch sums: reduce over the workgroup, one atomic per channel per workgroup
   if (EPI != 0) {
@@ -290,24 +306,30 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(const spb_gemm_args_t g) {
   }
 }
 
-template <typename T, int BN, int PRO, int EPI>
+template <typename T, int RF, int BN, int PRO, int EPI>
 int launch_gemm(const spb_gemm_args_t& g, hipStream_t stream) {
+  constexpr int BM = 64 * RF;
   const int NT = (g.N + BN - 1) / BN;
-  const int MT = (g.M + GBM - 1) / GBM;
-  int GM = MT;
+  const int MT = (g.M + BM - 1) / BM;
+  // persistent over M tiles: at most ~2048 workgroups, and an even split of the tiles (19 tiles on 16 workgroup rows
+  // made the slowest row take two tiles: 2x the layer time)
   const int cap = 2048 / NT > 8 ? 2048 / NT : 8;
-  if (GM > cap) GM = cap;
-  if (GM >= 8) GM = GM / 8 * 8;
+  int GM = MT;
+  if (GM > cap) {
+    const int rounds = (MT + cap - 1) / cap;
+    GM = (MT + rounds - 1) / rounds;
+    if (GM >= 8 && (GM & 7)) GM = (GM + 7) / 8 * 8;  // multiple of 8 keeps the XCD remap bijective
+  }
   const int Kp = (g.K + GBK - 1) / GBK * GBK;
-  const size_t lds = (size_t)3 * Kp * sizeof(float) + gemm_region_bytes<T, BN>();
+  const size_t lds = (size_t)3 * Kp * sizeof(float) + gemm_region_bytes<T, RF, BN>();
   static bool attr_done = false;
   if (!attr_done) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&pw_gemm_kernel<T, BN, PRO, EPI>),
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&pw_gemm_kernel<T, RF, BN, PRO, EPI>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done = true;
   }
   if (lds > 160 * 1024) return SPB_E_SHAPE;
-  hipLaunchKernelGGL((pw_gemm_kernel<T, BN, PRO, EPI>), dim3(NT * GM), dim3(256), lds, stream, g);
+  hipLaunchKernelGGL((pw_gemm_kernel<T, RF, BN, PRO, EPI>), dim3(NT * GM), dim3(256), lds, stream, g);
   SPB_CHECK_LAUNCH();
   return 0;
 }
@@ -324,9 +346,16 @@ int dispatch_bn(const spb_gemm_args_t& g, hipStream_t stream) {
   }
   if (sizeof(T) == 4 && bn == 128) bn = 64;  // parity mode: keep the LDS footprint small
   if (EPI == 2 && bn == 128) bn = 64;        // backward epilogue hoists 2 operand vectors per output row sweep
-  if (bn == 32) return launch_gemm<T, 32, PRO, EPI>(g, stream);
-  if (bn == 64) return launch_gemm<T, 64, PRO, EPI>(g, stream);
-  return launch_gemm<T, 128, PRO, EPI>(g, stream);
+  // small M (the 14x14 and 7x7 maps): 64-row tiles and 64-column tiles so the launch has enough workgroups
+  const bool small_m = g.M <= 16384;
+  if (small_m && bn == 128) bn = 64;
+  if (small_m) {
+    if (bn == 32) return launch_gemm<T, 1, 32, PRO, EPI>(g, stream);
+    return launch_gemm<T, 1, 64, PRO, EPI>(g, stream);
+  }
+  if (bn == 32) return launch_gemm<T, 2, 32, PRO, EPI>(g, stream);
+  if (bn == 64) return launch_gemm<T, 2, 64, PRO, EPI>(g, stream);
+  return launch_gemm<T, 2, 128, PRO, EPI>(g, stream);
 }
 
 template <typename T>

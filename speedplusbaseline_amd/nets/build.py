@@ -1,0 +1,46 @@
+"""Model / optimizer factory -- mirror of reference src/nets/build.py:39-78 (same names, same cfg fields)."""
+import logging
+
+from .park2019 import KeypointRegressionNet
+from .revgrad import RevGrad
+from .spn import SpacecraftPoseNet
+from ..optim import FusedOptimizer
+
+logger = logging.getLogger(__name__)
+
+
+def _precision(cfg):
+    p = getattr(cfg, "precision", None)
+    if p:
+        return p
+    return "bf16" if getattr(cfg, "fp16", False) else None  # --use_fp16 selects the reduced-precision (bf16) kernels
+
+
+def get_model(cfg):
+    assert cfg.model_name == 'krn' or cfg.model_name == 'spn', 'Model name must be either krn or spn'
+    if not cfg.dann:
+        if cfg.model_name == 'krn':
+            model = KeypointRegressionNet(cfg.num_keypoints, precision=_precision(cfg))
+            logger.info('KRN created')
+        else:
+            model = SpacecraftPoseNet(cfg.num_classes, pretrain=True)
+            logger.info('SPN created')
+    else:
+        model = RevGrad(cfg.num_keypoints, precision=_precision(cfg))
+        logger.info('RevGrad created with {}'.format(cfg.model_name))
+    logger.info('   - Number of total parameters:     {:,}'.format(sum(p.numel() for p in model.parameters())))
+    logger.info('   - Number of trainable parameters: {:,}'.format(sum(p.numel() for p in model.parameters() if p.requires_grad)))
+    return model
+
+
+def get_optimizer(cfg, model):
+    """sgd / rmsprop / adam / adamw with cfg.momentum doubling as RMSprop alpha and Adam beta1 (build.py:60-78).
+    Returns a torch.optim.Optimizer subclass whose update (and the trainers' clip_grad_norm_) is one fused HIP pass
+    over the model's flat parameter arena."""
+    if cfg.optimizer not in ('sgd', 'rmsprop', 'adam', 'adamw'):
+        raise ValueError('unknown optimizer %r' % cfg.optimizer)
+    params = [p for p in model.parameters() if p.requires_grad]
+    optimizer = FusedOptimizer(params, kind=cfg.optimizer, lr=cfg.lr, momentum=cfg.momentum,
+                               weight_decay=cfg.weight_decay, model=model)
+    logger.info('Optimizer created: {}'.format(cfg.optimizer))
+    return optimizer

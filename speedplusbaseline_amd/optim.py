@@ -1,0 +1,133 @@
+"""Optimizer front end: a torch.optim.Optimizer (so StepLR, checkpoints and the reference's loops keep working) whose
+update -- together with the trainers' clip_grad_norm_(1.0) -- is one fused HIP pass over the model's flat f32 parameter
+arena (reference build.py:60-78 for the four kinds; trainer.py:90,97 / dann.py:99 for the clip).
+
+Two ways in:
+  * train_step(images, target)   fast path used by speedplusbaseline_amd.core.{trainer,dann}: forward, zero_grad, backward,
+                                 clip, update as HIP launches (optionally a replayed hipGraph), no autograd;
+  * step()                       generic path after loss.backward() / clip_grad_norm_: gathers p.grad into the arena if
+                                 autograd did not already leave them there, then runs the same update kernel.
+"""
+import torch
+
+from .step import FusedTrainStep
+
+
+class FusedOptimizer(torch.optim.Optimizer):
+    def __init__(self, params, kind="adamw", lr=1e-3, momentum=0.9, weight_decay=0.0, model=None, max_norm=1.0,
+                 use_graph=True):
+        defaults = dict(lr=lr, momentum=momentum, weight_decay=weight_decay, kind=kind)
+        super().__init__(params, defaults)
+        if len(self.param_groups) != 1:
+            raise ValueError("FusedOptimizer works on the model's single parameter group (as the reference builds it)")
+        self._model = model
+        self._max_norm = max_norm
+        self._use_graph = use_graph
+        self._ts = None
+        self._pending_state = None
+
+    # ------------------------------------------------------------------------------------------------ binding
+    def _bind(self, batch, dann=False, world_size=1, group=None):
+        m = self._model
+        if m is None:
+            raise RuntimeError("FusedOptimizer needs the HIP-backed model it was built for (get_optimizer(cfg, model))")
+        eng = m.engine()
+        g = self.param_groups[0]
+        ts = self._ts
+        if ts is None or ts.e is not eng or ts.B != batch or ts.dann != dann:
+            old = ts
+            ts = FusedTrainStep(eng, batch, kind=g["kind"], lr=g["lr"], momentum=g["momentum"], weight_decay=g["weight_decay"],
+                                max_norm=self._max_norm, dist_group=group, world_size=world_size,
+                                use_graph=self._use_graph, dann=dann)
+            if old is not None and old.e is eng:  # keep the moments when only the batch size changed
+                ts.m.copy_(old.m); ts.v.copy_(old.v); ts.t = old.t
+            self._ts = ts
+            if self._pending_state is not None:
+                self._load_into(ts, self._pending_state)
+                self._pending_state = None
+        ts.lr = float(g["lr"])  # StepLR edits param_groups between epochs
+        return ts
+
+    # ------------------------------------------------------------------------------------------------ fast path
+    def train_step(self, images, target, target_images=None, alpha=0.0, world_size=1, group=None):
+        """one whole training step on the GPU; returns the device tensor (loss, loss_x, loss_y[, bce_src, bce_tgt])"""
+        ts = self._bind(images.shape[0], dann=target_images is not None, world_size=world_size, group=group)
+        return ts(images, target, target_images, alpha)
+
+    # ------------------------------------------------------------------------------------------------ generic path
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        eng = self._model.engine()
+        names = {id(p): n for n, p in self._model.named_parameters()}
+        infos = {i[0]: i for i in eng.param_infos}
+        ts = self._ts
+        if ts is None or ts.e is not eng:
+            ts = self._bind(1)
+        ts.lr = float(self.param_groups[0]["lr"])
+        # the clip (if any) already happened in the caller (clip_grad_norm_): plain update here
+        eng.grads.zero_()
+        for p in self.param_groups[0]["params"]:
+            if p.grad is not None:
+                eng.param_view(infos[names[id(p)]], eng.grads).copy_(p.grad)
+        ts.t += 1
+        ts._refresh_hyper()
+        keep = ts.max_norm
+        ts.max_norm = 0.0
+        try:
+            ts._update()
+        finally:
+            ts.max_norm = keep
+        return loss
+
+    # ------------------------------------------------------------------------------------------------ checkpoints
+    def state_dict(self):
+        """torch.optim-compatible layout: per-parameter step / exp_avg / exp_avg_sq (or momentum_buffer / square_avg)"""
+        g = self.param_groups[0]
+        kind = g["kind"]
+        state = {}
+        ts = self._ts
+        if ts is not None and ts.t > 0:
+            eng = ts.e
+            names = {id(p): n for n, p in self._model.named_parameters()}
+            infos = {i[0]: i for i in eng.param_infos}
+            for idx, p in enumerate(g["params"]):
+                info = infos[names[id(p)]]
+                st = {"step": torch.tensor(float(ts.t))}
+                if kind in ("adam", "adamw"):
+                    st["exp_avg"] = eng.param_view(info, ts.m).clone(); st["exp_avg_sq"] = eng.param_view(info, ts.v).clone()
+                elif kind == "rmsprop":
+                    st["square_avg"] = eng.param_view(info, ts.v).clone()
+                elif g["momentum"] != 0:
+                    st["momentum_buffer"] = eng.param_view(info, ts.m).clone()
+                state[idx] = st
+        pg = {k: v for k, v in g.items() if k != "params"}
+        pg["params"] = list(range(len(g["params"])))
+        return {"state": state, "param_groups": [pg]}
+
+    def load_state_dict(self, sd):
+        g = self.param_groups[0]
+        for k, v in sd["param_groups"][0].items():
+            if k != "params":
+                g[k] = v
+        if self._ts is not None:
+            self._load_into(self._ts, sd["state"])
+        else:
+            self._pending_state = sd["state"]
+
+    def _load_into(self, ts, state):
+        eng = ts.e
+        names = {id(p): n for n, p in self._model.named_parameters()}
+        infos = {i[0]: i for i in eng.param_infos}
+        for idx, p in enumerate(self.param_groups[0]["params"]):
+            st = state.get(idx, state.get(str(idx)))
+            if not st:
+                continue
+            info = infos[names[id(p)]]
+            ts.t = int(float(st.get("step", ts.t)))
+            for key, arena in (("exp_avg", ts.m), ("exp_avg_sq", ts.v), ("square_avg", ts.v), ("momentum_buffer", ts.m)):
+                if key in st and st[key] is not None:
+                    eng.param_view(info, arena).copy_(st[key].to(arena.device))

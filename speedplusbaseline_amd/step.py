@@ -8,6 +8,7 @@ refreshed by an async H2D copy before each step, so the captured launch argument
 import torch
 
 from . import ops
+from .parallel import allreduce_sum_, mean_scale
 
 _KIND_DEFAULT_EPS = 1e-8
 
@@ -32,7 +33,7 @@ class FusedTrainStep:
         self.m = torch.zeros(n, dtype=torch.float32, device=dev)
         self.v = torch.zeros(n, dtype=torch.float32, device=dev)
         self.sq = torch.zeros(1, dtype=torch.float32, device=dev)
-        self.gmul = torch.full((1,), 1.0 / self.world, dtype=torch.float32, device=dev) if self.world > 1 else None
+        self.gmul = torch.full((1,), mean_scale(self.world), dtype=torch.float32, device=dev) if self.world > 1 else None
         self.hyper = torch.zeros(3, dtype=torch.float32, device=dev)
         self.hyper_host = torch.zeros(3, dtype=torch.float32).pin_memory()
         self.t = 0
@@ -75,7 +76,7 @@ class FusedTrainStep:
 
     def _allreduce(self):
         if self.world > 1:
-            torch.distributed.all_reduce(self.e.grads, group=self.group)  # RCCL sum; the mean is folded into gmul
+            allreduce_sum_(self.e.grads, self.group)  # RCCL sum; the 1/world mean is folded into gmul
 
     def _update(self):
         e = self.e

