@@ -142,8 +142,16 @@ def main():
         dom = max(agg.items(), key=lambda kv: kv[1]["ms"])
         dk, dv = dom
         achieved = dv["bytes"] / (dv["ms"] * 1e-3) / 1e9
+        # HBM bytes per launch of that family from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE, separate
+        # runs, corrected as MI355X_MICROARCH.md prescribes; scratch/pmc_summary.py) -- rocprofv3 cannot run inside bench.py
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")) as f:
+                traffic = json.load(f)["families"][dk]["hbm_bytes_per_launch"]
+        except Exception:
+            traffic = None
         roofline = dict(bound="hbm", kernel=dk, achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
-                        frac=round(achieved / HBM_PEAK_GBS, 4), traffic=None,
+                        frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic,
                         launches_per_step=dv["launches"] // n_prof,
                         avg_launch_us=round(dv["ms"] / dv["launches"] * 1e3, 2),
                         alg_bytes_per_launch=round(dv["bytes"] / dv["launches"]),

@@ -1,0 +1,43 @@
+"""Summarise rocprofv3 passes into profiles/: per-kernel-family time (kernel trace) and HBM traffic (PMC FETCH_SIZE /
+WRITE_SIZE, separate passes).  Corrections per /opt/skills/guides/MI355X_MICROARCH.md (HBM section): counters are in KB;
+on gfx950 FETCH_SIZE reports exactly 1/2 of the bytes of a wide coalesced stream (16 B/lane), so reads are doubled;
+WRITE_SIZE is used as reported (uncalibrated)."""
+import csv, json, re, sys, collections
+
+def family(name):
+    m = re.search(r"pw_gemm_kernel<[^,]+, *(\d+), *(\d+), *(\d+), *(\d+)>", name)
+    if m:
+        pro, epi = int(m.group(3)), int(m.group(4))
+        return "pw_gemm_dgrad" if pro == 2 else ("pw_gemm_fwd" if epi == 1 else "pw_gemm_plain")
+    for k in ("pw_wgrad", "dw_fwd", "dw_dgrad", "dw_wgrad", "stem_fwd", "stem_wgrad", "head_fwd", "head_reduce", "head_bwd",
+              "bn_apply", "bn_bwd_prep", "bn_running_update", "bn_param_grads", "bn_load_running", "weight_prep", "grad_sqnorm",
+              "optim_step", "domain_tail", "bce_logits"):
+        if k in name:
+            return k
+    return "other:" + name[:40]
+
+def counters(path, counter):
+    agg = collections.defaultdict(lambda: [0, 0.0])
+    with open(path) as f:
+        for r in csv.DictReader(f):
+            if r["Counter_Name"] != counter:
+                continue
+            a = agg[family(r["Kernel_Name"])]
+            a[0] += 1; a[1] += float(r["Counter_Value"])
+    return agg
+
+def main(stats_csv, fetch_csv, write_csv, out_json, steps_in_pmc):
+    fetch, write = counters(fetch_csv, "FETCH_SIZE"), counters(write_csv, "WRITE_SIZE")
+    out = {"_note": "bytes per launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 averaged over the launches of the family; see scratch/pmc_summary.py",
+           "families": {}}
+    for fam in sorted(set(fetch) | set(write)):
+        nf, kbf = fetch.get(fam, [0, 0.0]); nw, kbw = write.get(fam, [0, 0.0])
+        n = max(nf, nw, 1)
+        out["families"][fam] = {"launches": n, "fetch_KB_raw_per_launch": round(kbf / max(nf, 1), 2), "write_KB_per_launch": round(kbw / max(nw, 1), 2),
+                                "hbm_bytes_per_launch": round((2 * kbf / max(nf, 1) + kbw / max(nw, 1)) * 1024)}
+    with open(out_json, "w") as f:
+        json.dump(out, f, indent=1)
+    print(json.dumps(out["families"], indent=1)[:3000])
+
+if __name__ == "__main__":
+    main(*sys.argv[1:5], int(sys.argv[5]) if len(sys.argv) > 5 else 3)

@@ -97,9 +97,13 @@ class FusedTrainStep:
         s = self._static
         side = torch.cuda.Stream(device=self.e.device)
         side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):  # warm-up outside capture: lazy kernel attributes, context creation
+        # warm-up outside capture (lazy kernel attributes, context creation).  It is a real forward: undo its only
+        # lasting side effect, the BatchNorm running statistics / num_batches_tracked update.
+        keep_buf, keep_nbt = self.e.buffers.clone(), self.e.nbt.clone()
+        with torch.cuda.stream(side):
             self._fwd_bwd(s["x"], s["y"], s["xt"], alpha)
         torch.cuda.current_stream().wait_stream(side)
+        self.e.buffers.copy_(keep_buf); self.e.nbt.copy_(keep_nbt)
         torch.cuda.synchronize()
         g1 = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g1):
