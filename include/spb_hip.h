@@ -100,6 +100,9 @@ typedef struct spb_dw_args {
   int oR;
 } spb_dw_args_t;
 int spb_dwconv_fwd(int dtype, const spb_dw_args_t* args, spb_stream_t stream);
+/* dgrad with args->dW != NULL also accumulates the weight gradient in the same pass (one read of g, z and the input
+ * instead of two kernels); Zout / epi must then name the convolution's input tensor and its BN+activation, also when
+ * epi_mode == 0.  This is the form the KRN plan uses. */
 int spb_dwconv_dgrad(int dtype, const spb_dw_args_t* args, spb_stream_t stream);
 int spb_dwconv_wgrad(int dtype, const spb_dw_args_t* args, spb_stream_t stream);
 
@@ -272,6 +275,7 @@ long long spb_krn_weight_prep_bytes(const spb_krn_t* m);
 
 /* debug / test helpers */
 int spb_debug_trread(const unsigned short* in4096, unsigned short* out256, spb_stream_t stream);
+int spb_debug_set_gemm_dma(int on); /* 0: route every pointwise GEMM through the register-prefetch kernel (A/B tests) */
 const char* spb_version(void);
 
 #ifdef __cplusplus

@@ -1,0 +1,36 @@
+// phase ablation of the fused depthwise backward kernel on KRN layer shapes (not part of the product)
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I include -DSPB_ABL=<bits> scratch/ubench_dwbwd.hip -o scratch/ubench_dwbwd_<bits>
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstring>
+#include "../speedplusbaseline_amd/csrc/dwconv.hip"
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("err %s line %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
+int main() {
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  struct Sh { int B, H, C, st; } shapes[] = {{48, 112, 32, 1}, {48, 112, 96, 2}, {48, 56, 144, 1}, {48, 56, 144, 2}, {48, 28, 192, 1}, {48, 14, 384, 1}, {48, 14, 576, 1}, {48, 7, 960, 1}};
+  printf("SPB_ABL=%d\n", SPB_ABL);
+  for (auto sh : shapes) {
+    const int OH = (sh.H - 1) / sh.st + 1;
+    size_t nin = (size_t)sh.B * sh.H * sh.H * sh.C, nout = (size_t)sh.B * OH * OH * sh.C;
+    void *g, *z, *zo, *rr, *y; float *w, *dw, *sums, *gam, *bet, *osums, *bsums;
+    CK(hipMalloc(&g, nout * 2)); CK(hipMalloc(&z, nout * 2)); CK(hipMalloc(&zo, nin * 2)); CK(hipMalloc(&rr, nin * 2)); CK(hipMalloc(&y, nin * 2));
+    CK(hipMalloc(&w, sh.C * 36)); CK(hipMalloc(&dw, sh.C * 36)); CK(hipMalloc(&sums, 64 * sh.C)); CK(hipMalloc(&bsums, 64 * sh.C));
+    CK(hipMalloc(&gam, sh.C * 4)); CK(hipMalloc(&bet, sh.C * 4)); CK(hipMalloc(&osums, 64 * sh.C));
+    CK(hipMemset(g, 0, nout * 2)); CK(hipMemset(z, 0, nout * 2)); CK(hipMemset(zo, 0, nin * 2)); CK(hipMemset(rr, 0, nin * 2));
+    CK(hipMemset(w, 0, sh.C * 36)); CK(hipMemset(dw, 0, sh.C * 36)); CK(hipMemset(sums, 0, 64 * sh.C)); CK(hipMemset(bsums, 0, 64 * sh.C));
+    CK(hipMemset(gam, 0, sh.C * 4)); CK(hipMemset(bet, 0, sh.C * 4)); CK(hipMemset(osums, 0, 64 * sh.C));
+    spb_dw_args_t a; std::memset(&a, 0, sizeof(a));
+    a.X = g; a.X2 = z; a.Wd = w; a.Y = y; a.dW = dw; a.Zout = zo; a.res = sh.st == 1 ? rr : nullptr; a.osums = osums; a.oR = 8; a.epi_mode = 2;
+    a.B = sh.B; a.H = sh.H; a.W = sh.H; a.C = sh.C; a.stride = sh.st;
+    spb_bnref_t r; std::memset(&r, 0, sizeof(r));
+    r.sums = sums; r.gamma = gam; r.beta = bet; r.bsums = bsums; r.inv_n = 1.f; r.eps = 1e-5f; r.C = sh.C; r.R = 8; r.act = SPB_ACT_RELU6;
+    a.pro = r; a.epi = r; a.pro_in = r;
+    for (int k = 0; k < 3; ++k) spb_dwconv_dgrad(SPB_BF16, &a, 0);
+    CK(hipEventRecord(e0)); for (int k = 0; k < 10; ++k) spb_dwconv_dgrad(SPB_BF16, &a, 0);
+    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    const double bytes = (2.0 * nout + (a.res ? 3.0 : 2.0) * nin) * 2.0;
+    printf("dw_bwd B%d H%3d C%3d s%d: %8.2f us  %7.1f GB/s\n", sh.B, sh.H, sh.C, sh.st, ms * 100, bytes / (ms / 10 * 1e-3) / 1e9);
+    hipFree(g); hipFree(z); hipFree(zo); hipFree(rr); hipFree(y);
+  }
+  return 0;
+}

@@ -171,3 +171,19 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
 }
 
 static inline int spb_ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+// ---------------------------------------------------------------------------------------------
+// LDS-DMA (global_load_lds_dwordx4): lane i's 16 bytes land at lds_base + 16*i with no VGPR in between.
+// Inline asm on purpose: with the builtin hipcc knows the instruction writes LDS and drains vmcnt(0) before the next
+// ds_read, which serialises every ring built on it; hidden in asm, a counted s_waitcnt (wait_vmcnt) is the only
+// ordering (and it is required: nothing else orders a ds_read behind a pending DMA).  M0 is compiler-reserved: saved
+// and restored.  lds_base must be wave-uniform.
+__device__ __forceinline__ void dma16(const void* gsrc, unsigned lds_base) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_base) : "memory");
+}
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
+  return (unsigned)(size_t)(const __attribute__((address_space(3))) char*)p;
+}
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }

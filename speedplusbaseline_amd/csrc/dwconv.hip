@@ -18,6 +18,11 @@
 #ifndef SPB_TS
 #define SPB_TS(i)
 #endif
+// ablation switches for scratch/ubench_dwbwd.hip (0 in the product build): 1 no taps, 2 no transform, 4 no DMA after
+// the first tile, 8 no output store, 16 no input-side loads
+#ifndef SPB_ABL
+#define SPB_ABL 0
+#endif
 
 namespace {
 
@@ -69,11 +74,11 @@ __device__ __forceinline__ TileMap make_map(int th, int tw, const DwThread& d, i
 }
 
 // issue the raw loads of one window (origin y0,x0 of image b; clamped addresses, no branches)
-template <typename T, int MODE>
-__device__ __forceinline__ void tile_issue(Raw8<T> r1[NIT], Raw8<T> r2[NIT], const TileMap& m, const T* X, const T* X2, int b,
+template <typename T, int MODE, int N = NIT>
+__device__ __forceinline__ void tile_issue(Raw8<T>* r1, Raw8<T>* r2, const TileMap& m, const T* X, const T* X2, int b,
                                            int y0, int x0, int H, int W, int C) {
 #pragma unroll
-  for (int it = 0; it < NIT; ++it) {
+  for (int it = 0; it < N; ++it) {
     const int y = clampi(y0 + m.dy[it], 0, H - 1), x = clampi(x0 + m.dx[it], 0, W - 1);
     const size_t o = ((size_t)(b * H + y) * W + x) * C + m.coff;
     r1[it] = ldraw<T>(X + o);
@@ -83,14 +88,14 @@ __device__ __forceinline__ void tile_issue(Raw8<T> r1[NIT], Raw8<T> r2[NIT], con
 
 // transform the raw window and park it in LDS as f32.  MODE 0: act(x*c0 + c1);  MODE 1: g*c0 + z*c1 + c2.  Pixels
 // outside the image and channel groups beyond C become zeros (zero padding applies to the TRANSFORMED tensor).
-template <typename T, int MODE>
-__device__ __forceinline__ void tile_store(float* tile, const Raw8<T> r1[NIT], const Raw8<T> r2[NIT], const TileMap& m, bool has2,
+template <typename T, int MODE, int N = NIT>
+__device__ __forceinline__ void tile_store(float* tile, const Raw8<T>* r1, const Raw8<T>* r2, const TileMap& m, bool has2,
                                            int y0, int x0, int H, int W, const float* cf, int cl8, int act, float slope) {
   const float* c0 = cf + cl8;
   const float* c1 = cf + 64 + cl8;
   const float* c2 = cf + 128 + cl8;
 #pragma unroll
-  for (int it = 0; it < NIT; ++it) {
+  for (int it = 0; it < N; ++it) {
     __builtin_amdgcn_sched_barrier(0);  // one slot at a time: keeps the live set at ~24 VGPRs instead of 5x that
     if (m.lds[it] >= 0) {
       const int yy = y0 + m.dy[it], xx = x0 + m.dx[it];
@@ -117,6 +122,9 @@ __device__ __forceinline__ void tile_store(float* tile, const Raw8<T> r1[NIT], c
     }
   }
 }
+
+template <typename R>
+__device__ __forceinline__ R sel8(int r, const R& a, const R& b) { return r == 0 ? a : b; }
 
 __device__ __forceinline__ void ld_lds8(const float* p, float v[8]) {
   const float4 a = *reinterpret_cast<const float4*>(p);
@@ -260,25 +268,53 @@ __global__ __launch_bounds__(256, 3) void dw_fwd_kernel(const spb_dw_args_t a) {
 // ------------------------------------------------------------------------------------------------ input gradient
 // dA[b,ih,iw,c] = sum_{ky,kx} dz[b,oh,ow,c] * w[c,ky,kx]  with  oh*stride - 1 + ky = ih.  Tiles are 8x8 INPUT pixels;
 // the dz window they need is 10x10 (stride 1) or 5x5 (stride 2).
-template <typename T>
+// WG = true fuses the weight gradient: the (output pixel, tap) pairs of dW[c,ky,kx] = sum dz[q]*a[q*s-1+k] are in
+// one-to-one correspondence with (input pixel p, tap) pairs, and the thread that owns input pixel p already holds a[p]
+// (it loads the input-side z for the activation mask) and gathers exactly the dz taps the sum needs -- 8 more FMAs per
+// tap instead of a second kernel that re-reads g, z and the input (measured: 0.94 ms of the 6.8 ms step).
+//
+// Staging.  The raw g / z windows of tile t+1 are fetched by LDS-DMA (global_load_lds_dwordx4, no VGPR in flight) into
+// the second of two LDS buffers while tile t is computed; a buffer is then transformed IN PLACE (raw bf16 g,z -> f32 dz,
+// the same number of bytes) and the taps read the f32 tile.  A register prefetch of the window plus the 72 weight-
+// gradient accumulators does not fit 256 VGPRs (167..312 spilled dwords in every variant tried, and a spilled load
+// destination turns the prefetch into a blocking load).
+struct DgLayout { int DTH, DTW, npix, pixB, RB, NI, BUFB; };
+__host__ __device__ inline DgLayout dg_layout(int st, int slab, int esize) {
+  DgLayout L;
+  L.DTH = st == 2 ? 5 : 10; L.DTW = L.DTH;          // dz window of an 8x8 input tile
+  L.npix = L.DTH * L.DTW;
+  L.pixB = slab * esize;                            // bytes of one pixel's channel slab
+  L.RB = (L.npix * L.pixB + 1023) & ~1023;          // one raw window = whole 64-lane x 16-byte DMA instructions
+  L.NI = L.RB >> 10;
+  const int tileB = L.npix * PADC * 4;
+  L.BUFB = ((2 * L.RB > tileB ? 2 * L.RB : tileB) + 15) & ~15;
+  return L;
+}
+
+template <typename T, bool WG, bool EPI>
 __global__ __launch_bounds__(256, 2) void dw_dgrad_kernel(const spb_dw_args_t a) {
+  constexpr int ND = 4;                                   // 10x10 window x 8 channel groups / 256 threads
+  constexpr int MAXI = sizeof(T) == 2 ? 4 : 7;            // DMA instructions per wave per raw window
+  constexpr int EPG = 16 / sizeof(T);                     // elements per 16-byte DMA granule
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* wl = smem;             // [9][64]
   float* cf = wl + 9 * 64;      // [3][64] p0,p1,p2
-  float* ce = cf + 3 * 64;      // [4][64] epi scale, shift, mean, invstd
-  float* red = ce + 4 * 64;     // [4][2][64]
-  float* tile = red + 512;
+  float* ce = cf + 3 * 64;      // [4][64] input-side scale, shift, mean, invstd
+  float* red = ce + 4 * 64;     // [4][2][64]  (WG: [4][64*9])
+  char* bufs = reinterpret_cast<char*>(red + (WG ? 4 * 64 * 9 : 512));
   const DwThread d = dw_thread(a.C);
   const int C = a.C, H = a.H, W = a.W, st = a.stride;
   const int OH = (H - 1) / st + 1, OW = (W - 1) / st + 1;
   const int slab = d.cgl_n * 8;
+  constexpr bool epi = EPI;
+  const DgLayout L = dg_layout(st, slab, (int)sizeof(T));
   fill_weights(wl, a.Wd, C, slab);
   if (threadIdx.x < 64) {
     const int c = blockIdx.y * slab + threadIdx.x;
     float p0 = 0.f, p1 = 0.f, p2 = 0.f, sc = 1.f, sh = 0.f, mu = 0.f, is = 0.f;
     if (threadIdx.x < slab && c < C) {
       bn_bwd_coef(a.pro, c, p0, p1, p2);
-      if (a.epi_mode == 2 && a.epi.gamma != nullptr) {
+      if ((epi || WG) && a.epi.gamma != nullptr) {
         bn_moments(a.epi, c, mu, is);
         sc = a.epi.gamma[c] * is;
         sh = a.epi.beta[c] - mu * sc;
@@ -288,104 +324,217 @@ __global__ __launch_bounds__(256, 2) void dw_dgrad_kernel(const spb_dw_args_t a)
     ce[threadIdx.x] = sc; ce[64 + threadIdx.x] = sh; ce[128 + threadIdx.x] = mu; ce[192 + threadIdx.x] = is;
   }
   const Tiles tl = make_tiles(a.B, H, W, 1);  // 8x8 tiles over the INPUT image
-  const int DTH = st == 2 ? tl.TH / 2 + 1 : tl.TH + 2, DTW = st == 2 ? tl.TW / 2 + 1 : tl.TW + 2;
-  const TileMap m = make_map(DTH, DTW, d, C);
+  const int DTH = L.DTH, DTW = L.DTW;
+  const TileMap m = make_map(DTH, DTW, d, C);   // transform slots: (pixel, channel group) -> f32 tile offset
+  int rawoff[ND];                               // byte offset of the slot's 8 channels in a raw window
+#pragma unroll
+  for (int k = 0; k < ND; ++k)
+    rawoff[k] = m.lds[k] >= 0 ? (m.lds[k] / PADC) * L.pixB + (threadIdx.x % d.cgl_n) * 8 * (int)sizeof(T) : 0;
+  // DMA map: instruction i = wave + 4k covers granules i*64 + lane; granule -> (window pixel, 16-byte part of its slab)
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+  const int gpp = L.pixB >> 4;
+  short qy[MAXI], qx[MAXI];
+#pragma unroll
+  for (int k = 0; k < MAXI; ++k) {
+    int pix = ((wv + 4 * k) * 64 + lane) / gpp;
+    pix = pix < L.npix ? pix : L.npix - 1;
+    qy[k] = (short)(pix / DTW); qx[k] = (short)(pix % DTW);
+  }
+  int qch = blockIdx.y * slab + (lane % gpp) * EPG;
+  qch = qch + EPG <= C ? qch : C - EPG;
+  const unsigned buf_lds = lds_addr(bufs);
   const int c0 = d.cg * 8, l0 = d.cgl * 8, cl8 = (threadIdx.x % d.cgl_n) * 8;
   const T* G = reinterpret_cast<const T*>(a.X);
   const T* Z = reinterpret_cast<const T*>(a.X2);
   const T* Rg = reinterpret_cast<const T*>(a.res);
   const T* Zo = reinterpret_cast<const T*>(a.Zout);
   T* Y = reinterpret_cast<T*>(a.Y);
-  const bool epi = a.epi_mode == 2;
+  constexpr bool need_in = EPI || WG;
   float s1[8], s2[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
-  Raw8<T> r1[NIT], r2[NIT], zo[2], rr[2];
+  float aw[WG ? 9 : 1][8];
+#pragma unroll
+  for (int k = 0; k < (WG ? 9 : 1); ++k)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) aw[k][j] = 0.f;
+  Raw8<T> zo[2], rr[2];
   // dz window origin (output coordinates) of the tile at input origin (y0,x0)
 #define DW_DY0(y0_) (st == 2 ? (y0_) / 2 : (y0_) - 1)
-#define DW_ISSUE(pp)                                                                                       \
+#define DW_ISSUE(pp, bi)                                                                                   \
   {                                                                                                        \
-    tile_issue<T, 1>(r1, r2, m, G, Z, (pp).b, DW_DY0((pp).y0), DW_DY0((pp).x0), OH, OW, C);                 \
-    if (epi) {                                                                                             \
-      _Pragma("unroll") for (int r = 0; r < 2; ++r) {                                                      \
-        const int o = d.pl + r * d.npl;                                                                    \
-        const int ih = clampi((pp).y0 + o / tl.TW, 0, H - 1), iw = clampi((pp).x0 + o % tl.TW, 0, W - 1);   \
-        const size_t off = ((size_t)((pp).b * H + ih) * W + iw) * C + (d.valid ? c0 : 0);                  \
-        zo[r] = ldraw<T>(Zo + off);                                                                        \
-        if (Rg) rr[r] = ldraw<T>(Rg + off);                                                                \
+    const int oy0 = DW_DY0((pp).y0), ox0 = DW_DY0((pp).x0);                                                \
+    const unsigned lb = buf_lds + (unsigned)((bi) * L.BUFB);                                               \
+    _Pragma("unroll") for (int k = 0; k < MAXI; ++k) {                                                     \
+      const int i = wv + 4 * k;                                                                            \
+      if (i < L.NI) {                                                                                      \
+        const int y = clampi(oy0 + qy[k], 0, OH - 1), x = clampi(ox0 + qx[k], 0, OW - 1);                   \
+        const size_t o = ((size_t)((pp).b * OH + y) * OW + x) * C + qch;                                   \
+        dma16(G + o, lb + (unsigned)(i << 10));                                                            \
+        dma16(Z + o, lb + (unsigned)(L.RB + (i << 10)));                                                    \
       }                                                                                                    \
+    }                                                                                                      \
+  }
+  // the owned pixels' input-side z (activation mask, a[p]) and residual gradient: ordinary loads, issued AFTER the taps
+  // of the previous tile so that they are not live across them; the counted wait at the loop top lets them fly on
+#define DW_ISSUE_IN(pp)                                                                                    \
+  if (need_in) {                                                                                           \
+    _Pragma("unroll") for (int r = 0; r < 2; ++r) {                                                        \
+      const int o = d.pl + r * d.npl;                                                                      \
+      const int ih = clampi((pp).y0 + o / tl.TW, 0, H - 1), iw = clampi((pp).x0 + o % tl.TW, 0, W - 1);     \
+      const size_t off = ((size_t)((pp).b * H + ih) * W + iw) * C + (d.valid ? c0 : 0);                    \
+      zo[r] = ldraw<T>(Zo + off);                                                                          \
+      if (epi) { if (Rg) rr[r] = ldraw<T>(Rg + off); }                                                     \
+    }                                                                                                      \
+  }
+  // one row of taps (fixed ky): gather dz from the LDS window; accumulate the input gradient and, fused, dz * a[p]
+#define DW_TAPS(ky)                                                                                        \
+  {                                                                                                        \
+    const int ty = ih + 1 - (ky);                                                                          \
+    const bool oky = !(st == 2 && (ty & 1));                                                               \
+    const int ly = clampi((st == 2 ? ty / 2 : ty) - dy0, 0, DTH - 1);                                      \
+    _Pragma("unroll") for (int kx = 0; kx < 3; ++kx) {                                                     \
+      const int tx = iw + 1 - kx;                                                                          \
+      const bool ok = oky && !(st == 2 && (tx & 1));                                                       \
+      const int lx = clampi((st == 2 ? tx / 2 : tx) - dx0, 0, DTW - 1);                                    \
+      float x[8], w[8];                                                                                    \
+      ld_lds8(tile + (ly * DTW + lx) * PADC + l0, x);                                                      \
+      ld_lds8(wl + ((ky) * 3 + kx) * 64 + l0, w);                                                          \
+      const float msk = ok ? 1.f : 0.f;                                                                    \
+      _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                      \
+        const float xm = msk * x[j];                                                                       \
+        acc[j] += xm * w[j];                                                                               \
+        if (WG) aw[WG ? (ky) * 3 + kx : 0][j] += xm * ap[j];                                               \
+      }                                                                                                    \
+    }                                                                                                      \
+  }
+#define DW_TAP_LD(k, X_, W_, M_)                                                                           \
+  {                                                                                                        \
+    const int ty = ih + 1 - (k) / 3, tx = iw + 1 - (k) % 3;                                                \
+    const bool ok = !(st == 2 && ((ty | tx) & 1));                                                         \
+    const int ly = clampi((st == 2 ? ty / 2 : ty) - dy0, 0, DTH - 1);                                      \
+    const int lx = clampi((st == 2 ? tx / 2 : tx) - dx0, 0, DTW - 1);                                      \
+    ld_lds8(tile + (ly * DTW + lx) * PADC + l0, X_);                                                       \
+    ld_lds8(wl + (k) * 64 + l0, W_);                                                                       \
+    M_ = ok ? 1.f : 0.f;                                                                                   \
+    asm volatile("" ::: "memory");                                                                         \
+  }
+#define DW_TAP_FMA(k, X_, W_, M_)                                                                          \
+  {                                                                                                        \
+    _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                        \
+      const float xm = M_ * X_[j];                                                                         \
+      acc[j] += xm * W_[j];                                                                                \
+      aw[WG ? (k) : 0][j] += xm * ap[j];                                                                   \
     }                                                                                                      \
   }
   long long ti = blockIdx.x;
   TilePos p = tile_pos(tl, ti < tl.total ? ti : 0);
-  if (ti < tl.total) DW_ISSUE(p);
-  __syncthreads();
-  for (; ti < tl.total; ti += gridDim.x) {
+  if (ti < tl.total) { DW_ISSUE(p, 0); DW_ISSUE_IN(p); }
+  int cb = 0;
+  constexpr int LPT = sizeof(T) == 2 ? 1 : 2;   // global_load_dwordx4 per Raw8
+#pragma clang loop unroll(disable)
+  for (; ti < tl.total; ti += gridDim.x, cb ^= 1) {
     const TilePos cur = p;
     const int dy0 = DW_DY0(cur.y0), dx0 = DW_DY0(cur.x0);
-    tile_store<T, 1>(tile, r1, r2, m, Z != nullptr, dy0, dx0, OH, OW, cf, cl8, 0, 0.f);
-    float zf[2][8], rf[2][8];
-    if (epi) {
+    char* buf = bufs + cb * L.BUFB;
+    float* tile = reinterpret_cast<float*>(buf);
+    // this wave's share of the window has landed (vm ops return in order; only the zo/rr loads are younger) ...
+    if (!need_in) wait_vmcnt<0>();
+    else if (epi && Rg) wait_vmcnt<4 * LPT>();
+    else wait_vmcnt<2 * LPT>();
+    __syncthreads();     // ... and so has everybody else's (first pass: also orders the coefficient tables)
+    Raw8<T> r1[ND], r2[ND];
 #pragma unroll
-      for (int r = 0; r < 2; ++r) {
-        cvt8(zo[r], zf[r]);
-        if (Rg) cvt8(rr[r], rf[r]);
-      }
+    for (int k = 0; k < ND; ++k) {
+      r1[k] = *reinterpret_cast<const Raw8<T>*>(buf + rawoff[k]);
+      r2[k] = *reinterpret_cast<const Raw8<T>*>(buf + L.RB + rawoff[k]);
     }
+    __syncthreads();     // every raw read done: the f32 tile may overwrite the window
+    if (!(SPB_ABL & 2)) tile_store<T, 1, ND>(tile, r1, r2, m, true, dy0, dx0, OH, OW, cf, cl8, 0, 0.f);
     __syncthreads();
-    if (ti + gridDim.x < tl.total) {
+    if (ti + gridDim.x < tl.total) {  // the other buffer was last read before the barriers above
       p = tile_pos(tl, ti + gridDim.x);
-      DW_ISSUE(p);
+      if (!(SPB_ABL & 4)) DW_ISSUE(p, cb ^ 1);
     }
-#pragma unroll
+#pragma unroll 1
     for (int r = 0; r < 2; ++r) {
       const int o = d.pl + r * d.npl;
       const int iy = o / tl.TW, ix = o % tl.TW;
       const int ih = cur.y0 + iy, iw = cur.x0 + ix;
       if (o < tl.TH * tl.TW && d.valid && ih < H && iw < W) {
-        float acc[8];
+        float acc[8], ap[8], zf[8];
+        if (need_in) cvt8(sel8(r, zo[0], zo[1]), zf);
+        asm volatile("" ::: "memory");  // keep the coefficient reads here (hoisted out of the r loop they cost 32 VGPRs)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+        for (int j = 0; j < 8; ++j) {
+          acc[j] = 0.f;
+          ap[j] = WG ? act_fwd(zf[j] * ce[l0 + j] + ce[64 + l0 + j], a.epi.act, a.epi.slope) : 0.f;
+        }
+        if (SPB_ABL & 1) {
+        } else if constexpr (WG) {
+          // all 9 taps unrolled (aw needs static indices) but software-pipelined two deep by hand: left alone the
+          // scheduler hoists all 18 LDS reads to the top (144 VGPRs) and spills
+          float xa[8], wa[8], xb[8], wb[8], ma, mb;
+          DW_TAP_LD(0, xa, wa, ma)
+          DW_TAP_LD(1, xb, wb, mb) DW_TAP_FMA(0, xa, wa, ma)
+          DW_TAP_LD(2, xa, wa, ma) DW_TAP_FMA(1, xb, wb, mb)
+          DW_TAP_LD(3, xb, wb, mb) DW_TAP_FMA(2, xa, wa, ma)
+          DW_TAP_LD(4, xa, wa, ma) DW_TAP_FMA(3, xb, wb, mb)
+          DW_TAP_LD(5, xb, wb, mb) DW_TAP_FMA(4, xa, wa, ma)
+          DW_TAP_LD(6, xa, wa, ma) DW_TAP_FMA(5, xb, wb, mb)
+          DW_TAP_LD(7, xb, wb, mb) DW_TAP_FMA(6, xa, wa, ma)
+          DW_TAP_LD(8, xa, wa, ma) DW_TAP_FMA(7, xb, wb, mb)
+          DW_TAP_FMA(8, xa, wa, ma)
+        } else {
 #pragma unroll 1
-        for (int ky = 0; ky < 3; ++ky) {
-          const int ty = ih + 1 - ky;            // = oh*stride
-          const bool oky = !(st == 2 && (ty & 1));
-          const int ly = clampi((st == 2 ? ty / 2 : ty) - dy0, 0, DTH - 1);
-#pragma unroll
-          for (int kx = 0; kx < 3; ++kx) {
-            const int tx = iw + 1 - kx;
-            const bool ok = oky && !(st == 2 && (tx & 1));
-            const int lx = clampi((st == 2 ? tx / 2 : tx) - dx0, 0, DTW - 1);
-            float x[8], w[8];
-            ld_lds8(tile + (ly * DTW + lx) * PADC + l0, x);
-            ld_lds8(wl + (ky * 3 + kx) * 64 + l0, w);
-            const float msk = ok ? 1.f : 0.f;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) acc[j] += msk * x[j] * w[j];
-          }
+          for (int ky = 0; ky < 3; ++ky) DW_TAPS(ky)
         }
         if (epi) {
+          asm volatile("" ::: "memory");
           if (Rg) {
+            float rf[8];
+            cvt8(sel8(r, rr[0], rr[1]), rf);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) acc[j] += rf[r][j];
+            for (int j = 0; j < 8; ++j) acc[j] += rf[j];
           }
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
-            const float z = zf[r][j];
+            const float z = zf[j];
             const float u = z * ce[l0 + j] + ce[64 + l0 + j];
             acc[j] = rnd<T>(acc[j] * act_grad(u, a.epi.act, a.epi.slope));
             s1[j] += acc[j];
             s2[j] += acc[j] * ((z - ce[128 + l0 + j]) * ce[192 + l0 + j]);
           }
         }
-        st8<T>(Y + ((size_t)(cur.b * H + ih) * W + iw) * C + c0, acc);
+        if (!(SPB_ABL & 8) || acc[0] == 123.f) st8<T>(Y + ((size_t)(cur.b * H + ih) * W + iw) * C + c0, acc);
       }
     }
-    __syncthreads();
+    if (!(SPB_ABL & 16) && ti + gridDim.x < tl.total) DW_ISSUE_IN(p);
   }
 #undef DW_ISSUE
+#undef DW_ISSUE_IN
 #undef DW_DY0
+#undef DW_TAPS
+#undef DW_TAP_LD
+#undef DW_TAP_FMA
+  __syncthreads();
   if (epi) dw_push_sums(red, s1, s2, d, C, a.osums, a.oR);
+  if constexpr (WG) {
+    const int t = threadIdx.x, w = t >> 6;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 9; ++k)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float v = cg_sum(d.valid ? aw[k][j] : 0.f, d.cgl_n);
+        if (lane < d.cgl_n) red[w * 576 + (lane * 8 + j) * 9 + k] = v;
+      }
+    __syncthreads();
+    for (int i = t; i < slab * 9; i += 256) {
+      const int c = blockIdx.y * slab + i / 9;
+      if (c < C) atomicAdd(a.dW + (size_t)c * 9 + (i % 9), red[i] + red[576 + i] + red[1152 + i] + red[1728 + i]);
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------ weight gradient
@@ -536,21 +685,40 @@ extern "C" int spb_dwconv_fwd(int dtype, const spb_dw_args_t* a, spb_stream_t st
   return 0;
 }
 
+// dW != NULL fuses the weight gradient into the same pass: then Zout must be the input tensor of the convolution and
+// `epi` its BN/activation (what spb_dwconv_wgrad takes as Xin / pro_in), also when epi_mode == 0.
 extern "C" int spb_dwconv_dgrad(int dtype, const spb_dw_args_t* a, spb_stream_t stream) {
   int e = dw_check(a);
   if (e) return e;
   if (!a->Y) return SPB_E_ARG;
   if (a->epi_mode == 2 && (!a->osums || a->oR < 1 || !a->Zout)) return SPB_E_ARG;
-  const int st = a->stride;
+  const bool wg = a->dW != nullptr;
+  if (wg && !a->Zout) return SPB_E_ARG;
   const Tiles tl = make_tiles(a->B, a->H, a->W, 1);
-  const int DTH = st == 2 ? tl.TH / 2 + 1 : tl.TH + 2, DTW = st == 2 ? tl.TW / 2 + 1 : tl.TW + 2;
-  const size_t lds = (size_t)(9 * 64 + 3 * 64 + 4 * 64 + 512 + DTH * DTW * PADC) * sizeof(float);
+  const int slab = (a->C >> 3) < 8 ? 32 : 64;
+  const DgLayout L = dg_layout(a->stride, slab, dtype == SPB_BF16 ? 2 : 4);
+  const size_t lds = (size_t)(9 * 64 + 3 * 64 + 4 * 64 + (wg ? 4 * 64 * 9 : 512)) * sizeof(float) + 2 * (size_t)L.BUFB;
   const dim3 grid = dw_grid(*a, tl, 2);
-  static bool once = false;
-  if (!once) { dw_set_lds(dw_dgrad_kernel<bf16_t>); dw_set_lds(dw_dgrad_kernel<float>); once = true; }
-  if (dtype == SPB_BF16) hipLaunchKernelGGL(dw_dgrad_kernel<bf16_t>, grid, dim3(256), lds, (hipStream_t)stream, *a);
-  else if (dtype == SPB_F32) hipLaunchKernelGGL(dw_dgrad_kernel<float>, grid, dim3(256), lds, (hipStream_t)stream, *a);
+  spb_dw_args_t k = *a;
+  if (!k.X2) k.X2 = k.X;  // no BN behind the convolution: p1 == 0, the kernel still reads a (finite) second operand
+  const bool epi = k.epi_mode == 2;
+  hipStream_t s = (hipStream_t)stream;
+#define DG_LAUNCH(T_, WG_, EPI_)                                                       \
+  {                                                                                    \
+    static bool once = false;                                                          \
+    if (!once) { dw_set_lds(dw_dgrad_kernel<T_, WG_, EPI_>); once = true; }            \
+    hipLaunchKernelGGL((dw_dgrad_kernel<T_, WG_, EPI_>), grid, dim3(256), lds, s, k);  \
+  }
+#define DG_PICK(T_)                                                                    \
+  {                                                                                    \
+    if (wg) { if (epi) DG_LAUNCH(T_, true, true) else DG_LAUNCH(T_, true, false) }     \
+    else { if (epi) DG_LAUNCH(T_, false, true) else DG_LAUNCH(T_, false, false) }      \
+  }
+  if (dtype == SPB_BF16) DG_PICK(bf16_t)
+  else if (dtype == SPB_F32) DG_PICK(float)
   else return SPB_E_ARG;
+#undef DG_PICK
+#undef DG_LAUNCH
   SPB_CHECK_LAUNCH();
   return 0;
 }

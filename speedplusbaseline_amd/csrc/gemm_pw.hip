@@ -18,17 +18,23 @@
 //   * logical workgroup ids are remapped so the N tiles that share an A tile run on one XCD (one L2).
 #include "common.h"
 
+// phase timestamps for scratch/ubench_gemm.hip (compiled out in the product build)
+#ifndef SPB_TS
+#define SPB_TS(i)
+#endif
+
 namespace {
 
-constexpr int GBK = 32;   // reduction chunk per LDS stage
+// BK = reduction chunk per LDS stage: 32 for the streaming (large M, small K) layers, 64 for the 14x14 / 7x7 maps where a
+// launch has few workgroups and the K loop is latency bound (fewer, fatter stages).  BK=128 was measured slower: its two
+// prefetch register sets push the dgrad variant to 256 VGPRs (1 wave per SIMD).
+template <typename T, int BK> struct LdsPad { static constexpr int LDK = BK + 8; };
+template <int BK> struct LdsPad<float, BK> { static constexpr int LDK = BK + 4; };
 
-template <typename T> struct LdsPad { static constexpr int LDK = GBK + 8; };
-template <> struct LdsPad<float> { static constexpr int LDK = GBK + 4; };
-
-template <typename T, int RF, int BN>
+template <typename T, int RF, int BN, int BK>
 constexpr size_t gemm_region_bytes() {
   constexpr int BM = 64 * RF;
-  size_t a = (size_t)(BM + BN) * LdsPad<T>::LDK * sizeof(T);
+  size_t a = (size_t)(BM + BN) * LdsPad<T, BK>::LDK * sizeof(T);
   size_t b = (size_t)BM * (BN + 8) * sizeof(T);
   size_t c = (size_t)2 * 256 * 8 * sizeof(float);  // stats reduction scratch
   size_t m = a > b ? a : b;
@@ -36,18 +42,23 @@ constexpr size_t gemm_region_bytes() {
 }
 
 // RF = 16-row fragments per wave (workgroup tile = 64*RF rows x BN columns)
-template <typename T, int RF, int BN, int PRO, int EPI>
+template <typename T, int RF, int BN, int BK, int PRO, int EPI>
 __global__ __launch_bounds__(256) void pw_gemm_kernel(const spb_gemm_args_t g) {
   constexpr int BM = 64 * RF;
-  constexpr int LDK = LdsPad<T>::LDK;
+  constexpr int GBK = BK;
+  constexpr int LDK = LdsPad<T, BK>::LDK;
+  constexpr int BKV = BK / 8;            // vec8 per tile row
+  constexpr int AROWS = 256 / BKV;       // tile rows covered by one pass of the 256 threads
+  constexpr int NA = BM / AROWS;         // A vectors per thread per stage
   constexpr int LDO = BN + 8;
   constexpr int NF = BN / 16;           // 16-wide column fragments per wave
   constexpr int NV = BN / 8;            // 8-wide column vectors per tile row
   constexpr int VR = 256 / NV;          // rows covered per epilogue sweep
   constexpr int VRI = (BM + VR - 1) / VR;
-  constexpr int NBV = (BN * 4 + 255) / 256;  // B-tile vec8 loads per thread
+  constexpr int NBV = (BN * BKV + 255) / 256;  // B-tile vec8 loads per thread
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  SPB_TS(0);
   const int M = g.M, K = g.K, N = g.N;
   const int Kp = (K + GBK - 1) / GBK * GBK;
   float* coef = reinterpret_cast<float*>(smem);  // [3][Kp]
@@ -107,26 +118,26 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(const spb_gemm_args_t g) {
   const T* Rg = reinterpret_cast<const T*>(g.res);
   const T* Zg = reinterpret_cast<const T*>(g.Zout);
 
-  const int kvA = t & 3, rowA = t >> 2;  // A tile: rows rowA + 64*i
+  const int kvA = t % BKV, rowA = t / BKV;  // A tile: rows rowA + AROWS*i
   const int KT = Kp / GBK;
 
   // Two register sets: the loads of reduction chunks kt+1 and kt+2 are in flight while chunk kt is on the matrix cores
   // (one set left the K loop of a 48-workgroup layer latency-bound at 2.3 us per chunk).  Clamped addresses, no
   // branches around loads.
-  Raw8<T> ra[2][RF], ra2[2][RF], rb[2][NBV];
+  Raw8<T> ra[2][NA], ra2[2][NA], rb[2][NBV];
 #define LOAD_TILE(S, m0_, kt)                                                                 \
     {                                                                                         \
       const int k = (kt) * GBK + kvA * 8;                                                     \
       const int kc = k < K ? k : K - 8;                                                       \
-      _Pragma("unroll") for (int i = 0; i < RF; ++i) {                                        \
-        const int m = (m0_) + rowA + 64 * i;                                                  \
+      _Pragma("unroll") for (int i = 0; i < NA; ++i) {                                        \
+        const int m = (m0_) + rowA + AROWS * i;                                               \
         const size_t o = (size_t)(m < M ? m : M - 1) * K + kc;                                \
         ra[S][i] = ldraw<T>(Ag + o);                                                          \
         if (PRO == 2) { if (A2g) ra2[S][i] = ldraw<T>(A2g + o); }                             \
       }                                                                                       \
       _Pragma("unroll") for (int i = 0; i < NBV; ++i) {                                       \
         const int e = t + 256 * i;                                                            \
-        const int rb_ = e >> 2, kb = (kt) * GBK + (e & 3) * 8;                                \
+        const int rb_ = e / BKV, kb = (kt) * GBK + (e % BKV) * 8;                             \
         const int n = n0 + (rb_ < BN ? rb_ : BN - 1);                                         \
         rb[S][i] = ldraw<T>(Bg + (size_t)(n < N ? n : N - 1) * K + (kb < K ? kb : K - 8));    \
       }                                                                                       \
@@ -134,8 +145,8 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(const spb_gemm_args_t g) {
 #define STORE_TILE(S, m0_, kt)                                                                \
     {                                                                                         \
       const int k = (kt) * GBK + kvA * 8;                                                     \
-      _Pragma("unroll") for (int i = 0; i < RF; ++i) {                                        \
-        const int m = (m0_) + rowA + 64 * i;                                                  \
+      _Pragma("unroll") for (int i = 0; i < NA; ++i) {                                        \
+        const int m = (m0_) + rowA + AROWS * i;                                               \
         float v[8], a1[8], a2[8];                                                             \
         const bool ok = (m < M && k < K);                                                     \
         cvt8(ra[S][i], a1);                                                                   \
@@ -149,29 +160,31 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(const spb_gemm_args_t g) {
           else x = a1[j] * coef[k + j] + a2[j] * coef[Kp + k + j] + coef[2 * Kp + k + j];     \
           v[j] = ok ? x : 0.f;                                                                \
         }                                                                                     \
-        st8<T>(As + (rowA + 64 * i) * LDK + kvA * 8, v);                                      \
+        st8<T>(As + (rowA + AROWS * i) * LDK + kvA * 8, v);                                   \
       }                                                                                       \
       _Pragma("unroll") for (int i = 0; i < NBV; ++i) {                                       \
         const int e = t + 256 * i;                                                            \
-        const int rb_ = e >> 2, kb = (kt) * GBK + (e & 3) * 8;                                \
+        const int rb_ = e / BKV, kb = (kt) * GBK + (e % BKV) * 8;                             \
         if (rb_ < BN) {                                                                       \
           float v[8];                                                                         \
           cvt8(rb[S][i], v);                                                                  \
           const bool ok = (n0 + rb_ < N) && (kb < K);                                         \
           _Pragma("unroll") for (int j = 0; j < 8; ++j) v[j] = ok ? v[j] : 0.f;               \
-          st8<T>(Bs + rb_ * LDK + (e & 3) * 8, v);                                            \
+          st8<T>(Bs + rb_ * LDK + (e % BKV) * 8, v);                                          \
         }                                                                                     \
       }                                                                                       \
     }
 #define MMA_TILE()                                                                                            \
     if constexpr (sizeof(T) == 2) {                                                                            \
-      bf16x8_t af[RF];                                                                                         \
-      _Pragma("unroll") for (int i = 0; i < RF; ++i)                                                           \
-        af[i] = *reinterpret_cast<const bf16x8_t*>(As + (w * 16 * RF + i * 16 + li) * LDK + lq * 8);           \
-      _Pragma("unroll") for (int j = 0; j < NF; ++j) {                                                         \
-        const bf16x8_t bfv = *reinterpret_cast<const bf16x8_t*>(Bs + (j * 16 + li) * LDK + lq * 8);            \
+      _Pragma("unroll") for (int ks = 0; ks < GBK / 32; ++ks) {                                                \
+        bf16x8_t af[RF];                                                                                       \
         _Pragma("unroll") for (int i = 0; i < RF; ++i)                                                         \
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfv, acc[i][j], 0, 0, 0);                 \
+          af[i] = *reinterpret_cast<const bf16x8_t*>(As + (w * 16 * RF + i * 16 + li) * LDK + ks * 32 + lq * 8); \
+        _Pragma("unroll") for (int j = 0; j < NF; ++j) {                                                       \
+          const bf16x8_t bfv = *reinterpret_cast<const bf16x8_t*>(Bs + (j * 16 + li) * LDK + ks * 32 + lq * 8); \
+          _Pragma("unroll") for (int i = 0; i < RF; ++i)                                                       \
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfv, acc[i][j], 0, 0, 0);               \
+        }                                                                                                      \
       }                                                                                                        \
     } else {                                                                                                   \
       _Pragma("unroll") for (int kk = 0; kk < GBK / 4; ++kk) {                                                 \
@@ -190,6 +203,7 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(const spb_gemm_args_t g) {
     if (KT > 1) LOAD_TILE(1, (lid / NT) * BM, 1);
   }
   __syncthreads();  // coefficients visible
+  SPB_TS(1);
 
   for (int mt = lid / NT; mt < MT; mt += GM) {
     const int m0 = mt * BM;
@@ -214,6 +228,7 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(const spb_gemm_args_t g) {
       }
     }
 
+    SPB_TS(2);
     // next M tile's first chunks and this tile's output-side operands: in flight during the epilogue
     if (mt + GM < MT) {
       LOAD_TILE(0, (mt + GM) * BM, 0);
@@ -280,6 +295,7 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(const spb_gemm_args_t g) {
       }
     }
     __syncthreads();
+    SPB_TS(3);
   }
 #undef LOAD_TILE
 #undef STORE_TILE
@@ -304,11 +320,13 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(const spb_gemm_args_t g) {
       }
     }
   }
+  SPB_TS(4);
 }
 
-template <typename T, int RF, int BN, int PRO, int EPI>
+template <typename T, int RF, int BN, int BK, int PRO, int EPI>
 int launch_gemm(const spb_gemm_args_t& g, hipStream_t stream) {
   constexpr int BM = 64 * RF;
+  constexpr int GBK = BK;
   const int NT = (g.N + BN - 1) / BN;
   const int MT = (g.M + BM - 1) / BM;
   // persistent over M tiles: at most ~2048 workgroups, and an even split of the tiles (19 tiles on 16 workgroup rows
@@ -321,18 +339,265 @@ int launch_gemm(const spb_gemm_args_t& g, hipStream_t stream) {
     if (GM >= 8 && (GM & 7)) GM = (GM + 7) / 8 * 8;  // multiple of 8 keeps the XCD remap bijective
   }
   const int Kp = (g.K + GBK - 1) / GBK * GBK;
-  const size_t lds = (size_t)3 * Kp * sizeof(float) + gemm_region_bytes<T, RF, BN>();
+  const size_t lds = (size_t)3 * Kp * sizeof(float) + gemm_region_bytes<T, RF, BN, BK>();
   static bool attr_done = false;
   if (!attr_done) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&pw_gemm_kernel<T, RF, BN, PRO, EPI>),
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&pw_gemm_kernel<T, RF, BN, BK, PRO, EPI>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done = true;
   }
   if (lds > 160 * 1024) return SPB_E_SHAPE;
-  hipLaunchKernelGGL((pw_gemm_kernel<T, RF, BN, PRO, EPI>), dim3(NT * GM), dim3(256), lds, stream, g);
+  hipLaunchKernelGGL((pw_gemm_kernel<T, RF, BN, BK, PRO, EPI>), dim3(NT * GM), dim3(256), lds, stream, g);
   SPB_CHECK_LAUNCH();
   return 0;
 }
+
+// ------------------------------------------------------------------------------------------------------------
+// LDS-DMA variant for the 14x14 / 7x7 maps (M <= 16K rows, bf16).  There a launch has only 100-900 workgroups and
+// the register-prefetch kernel above is latency bound: 1.6 us per 64-deep reduction stage, measured, because only
+// two stages (8-16 KB per workgroup) are in flight against a ~3 us loaded memory latency.  Here the raw operand tiles go
+// global -> LDS with `global_load_lds_dwordx4` (no VGPRs), DS stages deep, counted `s_waitcnt vmcnt(N)` + one raw
+// `s_barrier` per stage; the BN / BN-backward transform moves to the fragment read (8 values per lane per MFMA step).
+// The LDS image is lane-linear (DMA constraint), so the 16-byte slot of a row is XOR-swizzled with (row & 7) on the
+// SOURCE address and on the fragment read (conflict-free ds_read_b128 instead of 8-way).
+constexpr int DBM = 64, DBN = 64, DBK = 64, DS = 4;
+
+// One LDS-DMA instruction: lane l's 16 bytes at gsrc land at LDS byte address lds_base + 16*l (lds_base wave-uniform).
+template <int PRO, int EPI>
+__global__ __launch_bounds__(256) void pw_gemm_dma_kernel(const spb_gemm_args_t g) {
+  typedef bf16_t T;
+  constexpr int IPS = PRO == 2 ? 6 : 4;                        // DMA instructions per stage per wave
+  constexpr int STAGE = (PRO == 2 ? 3 : 2) * DBM * DBK * 2;    // bytes: A [, A2], B tiles of 64 x 64 bf16
+  constexpr int LDO = DBN + 8, NV = DBN / 8, VR = 256 / NV, VRI = DBM / VR;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int M = g.M, K = g.K, N = g.N;
+  const int Kp = (K + DBK - 1) / DBK * DBK, KT = Kp / DBK;
+  float* coef = reinterpret_cast<float*>(smem);                // [3][Kp]
+  char* stages = smem + (size_t)3 * Kp * sizeof(float);
+  T* Os = reinterpret_cast<T*>(stages);                        // aliases the stage ring after the K loop
+
+  const int t = threadIdx.x, l = t & 63, w = t >> 6, li = l & 15, lq = l >> 4;
+  const int NT = (N + DBN - 1) / DBN;
+  const int lid = xcd_remap(blockIdx.x, gridDim.x);
+  const int n0 = (lid % NT) * DBN, m0 = (lid / NT) * DBM;
+
+  const T* Ag = reinterpret_cast<const T*>(g.A);
+  const T* A2g = (PRO == 2 && g.A2) ? reinterpret_cast<const T*>(g.A2) : Ag;  // identity prologue: p1 == 0, any finite data
+  const T* Bg = reinterpret_cast<const T*>(g.Bw);
+  T* Yg = reinterpret_cast<T*>(g.Y);
+  const T* Rg = reinterpret_cast<const T*>(g.res);
+  const T* Zg = reinterpret_cast<const T*>(g.Zout);
+
+  // per-lane DMA sources: row (within the tile) = w*16 + i*8 + (l>>3); 16-byte slot l&7 holds k-vector slot^(row&7)
+  const int drow = w * 16 + (l >> 3);
+  const int dkv = (l & 7) ^ (drow & 7);                        // (row+8)&7 == row&7: same for i = 0, 1
+  size_t arow[2], brow[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int m = m0 + drow + 8 * i, n = n0 + drow + 8 * i;
+    arow[i] = (size_t)(m < M ? m : M - 1) * K;
+    brow[i] = (size_t)(n < N ? n : N - 1) * K;
+  }
+  const unsigned stages_lds = lds_addr(stages);
+  const unsigned wave_ro = __builtin_amdgcn_readfirstlane((unsigned)(w * 16 * DBK * 2));  // provably wave-uniform for "s"
+#define DMA_STAGE(kt_)                                                                          \
+  {                                                                                             \
+    const unsigned sb = stages_lds + (unsigned)(((kt_) % DS) * STAGE) + wave_ro;                \
+    const int k = (kt_) * DBK + dkv * 8;                                                        \
+    const int kc = k < K ? k : K - 8;                                                           \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                             \
+      const unsigned ro = (unsigned)(i * 8 * DBK * 2);                                          \
+      dma16(Ag + arow[i] + kc, sb + ro);                                                        \
+      if (PRO == 2) dma16(A2g + arow[i] + kc, sb + DBM * DBK * 2 + ro);                         \
+      dma16(Bg + brow[i] + kc, sb + (PRO == 2 ? 2 : 1) * DBM * DBK * 2 + ro);                   \
+    }                                                                                           \
+  }
+  for (int s = 0; s < DS - 1 && s < KT; ++s) DMA_STAGE(s);
+
+  // ---- prologue coefficients (ordinary loads; they complete before the first counted wait)
+  for (int c = t; c < Kp; c += 256) {
+    float c0 = 0.f, c1 = 0.f, c2 = 0.f;
+    if (c < K) {
+      if (PRO == 1) bn_fwd_coef(g.pro, c, c0, c1);
+      else bn_bwd_coef(g.pro, c, c0, c1, c2);
+    }
+    coef[c] = c0; coef[Kp + c] = c1; coef[2 * Kp + c] = c2;
+  }
+  const int vcol = t % NV, vrow0 = t / NV;
+  const int nE = n0 + vcol * 8;
+  const bool colok = nE < N;
+  float e_sc[8], e_sh[8], e_mu[8], e_is[8], e_bias[8];
+  if (EPI == 2) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      e_sc[j] = 1.f; e_sh[j] = 0.f; e_mu[j] = 0.f; e_is[j] = 0.f;
+      if (colok && g.epi.gamma != nullptr) {
+        bn_moments(g.epi, nE + j, e_mu[j], e_is[j]);
+        e_sc[j] = g.epi.gamma[nE + j] * e_is[j];
+        e_sh[j] = g.epi.beta[nE + j] - e_mu[j] * e_sc[j];
+      }
+    }
+  }
+  if (EPI == 0) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) e_bias[j] = (colok && g.bias) ? g.bias[nE + j] : 0.f;
+  }
+  // output-side operands of the epilogue: issued now, consumed after the K loop
+  Raw8<T> zr[EPI == 2 ? VRI : 1], rr[EPI == 2 ? VRI : 1];
+  if (EPI == 2) {
+#pragma unroll
+    for (int s = 0; s < VRI; ++s) {
+      const int m = m0 + vrow0 + s * VR;
+      const size_t o = (size_t)(m < M ? m : M - 1) * N + (colok ? nE : 0);
+      zr[EPI == 2 ? s : 0] = ldraw<T>(Zg + o);
+      if (Rg) rr[EPI == 2 ? s : 0] = ldraw<T>(Rg + o);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // simplest correct start: everything issued so far has landed
+  __syncthreads();
+
+  f32x4_t acc[DBN / 16];
+#pragma unroll
+  for (int j = 0; j < DBN / 16; ++j) acc[j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  const float act_h = act_hi(g.pro.act), act_n = act_ns(g.pro.act, g.pro.slope);
+  const int frow = w * 16 + li;
+
+  for (int kt = 0; kt < KT; ++kt) {
+    // stage kt has landed once at most min(DS-2, KT-1-kt) younger stages are still in flight
+    if (kt > 0) {
+      const int rem = KT - 1 - kt;
+      if (rem >= DS - 2) wait_vmcnt<(DS - 2) * IPS>();
+      else if (rem == 1) wait_vmcnt<IPS>();
+      else wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();   // every wave's share of stage kt is visible; everyone is done reading stage kt-1
+    }
+    if (kt + DS - 1 < KT) DMA_STAGE(kt + DS - 1);  // into the buffer stage kt-1 just vacated
+    const char* sb = stages + (size_t)(kt % DS) * STAGE;
+#pragma unroll
+    for (int ks = 0; ks < DBK / 32; ++ks) {
+      const int v = ks * 4 + lq;                   // k-vector of this lane
+      const int kb = kt * DBK + v * 8;
+      const int so = frow * (DBK * 2) + ((v ^ (frow & 7)) << 4);
+      Raw8<T> ar, a2r;
+      ar.u = *reinterpret_cast<const uint4*>(sb + so);
+      if (PRO == 2) a2r.u = *reinterpret_cast<const uint4*>(sb + DBM * DBK * 2 + so);
+      float a[8], a2[8], x[8];
+      cvt8(ar, a);
+      if (PRO == 2) cvt8(a2r, a2);
+      const float4 c0a = *reinterpret_cast<const float4*>(coef + kb), c0b = *reinterpret_cast<const float4*>(coef + kb + 4);
+      const float4 c1a = *reinterpret_cast<const float4*>(coef + Kp + kb), c1b = *reinterpret_cast<const float4*>(coef + Kp + kb + 4);
+      const float c0[8] = {c0a.x, c0a.y, c0a.z, c0a.w, c0b.x, c0b.y, c0b.z, c0b.w};
+      const float c1[8] = {c1a.x, c1a.y, c1a.z, c1a.w, c1b.x, c1b.y, c1b.z, c1b.w};
+      if (PRO == 1) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float u = a[j] * c0[j] + c1[j];
+          x[j] = fminf(fmaxf(u, 0.f), act_h) + act_n * fminf(u, 0.f);
+        }
+      } else {
+        const float4 c2a = *reinterpret_cast<const float4*>(coef + 2 * Kp + kb), c2b = *reinterpret_cast<const float4*>(coef + 2 * Kp + kb + 4);
+        const float c2[8] = {c2a.x, c2a.y, c2a.z, c2a.w, c2b.x, c2b.y, c2b.z, c2b.w};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[j] = a[j] * c0[j] + a2[j] * c1[j] + c2[j];
+      }
+      uint4 pa;
+      pa.x = (uint32_t)f2bf(x[0]) | ((uint32_t)f2bf(x[1]) << 16); pa.y = (uint32_t)f2bf(x[2]) | ((uint32_t)f2bf(x[3]) << 16);
+      pa.z = (uint32_t)f2bf(x[4]) | ((uint32_t)f2bf(x[5]) << 16); pa.w = (uint32_t)f2bf(x[6]) | ((uint32_t)f2bf(x[7]) << 16);
+      if (kb >= K) pa = make_uint4(0, 0, 0, 0);    // reduction padding: clamped (finite) data times an explicit zero
+      const bf16x8_t af = __builtin_bit_cast(bf16x8_t, pa);
+#pragma unroll
+      for (int j = 0; j < DBN / 16; ++j) {
+        const int brow_ = j * 16 + li;
+        uint4 pb = *reinterpret_cast<const uint4*>(sb + (PRO == 2 ? 2 : 1) * DBM * DBK * 2 + brow_ * (DBK * 2) + ((v ^ (brow_ & 7)) << 4));
+        if (kb >= K || n0 + brow_ >= N) pb = make_uint4(0, 0, 0, 0);
+        acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, __builtin_bit_cast(bf16x8_t, pb), acc[j], 0, 0, 0);
+      }
+    }
+  }
+#undef DMA_STAGE
+  __syncthreads();  // all DMA consumed (the last stages were waited with vmcnt(0)); the ring can be reused
+
+  // ---- accumulators -> LDS (C layout: col = lane&15, row = (lane>>4)*4 + r), then coalesced 16-byte epilogue
+#pragma unroll
+  for (int j = 0; j < DBN / 16; ++j)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Os[(w * 16 + lq * 4 + r) * LDO + j * 16 + li] = f2bf(acc[j][r]);
+  __syncthreads();
+  float s1[8], s2[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
+  if (colok) {
+#pragma unroll
+    for (int s = 0; s < VRI; ++s) {
+      const int r = vrow0 + s * VR;
+      const int m = m0 + r;
+      if (m < M) {
+        float v[8];
+        ld8<T>(Os + r * LDO + vcol * 8, v);
+        const size_t o = (size_t)m * N + nE;
+        if (EPI == 0) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] = act_fwd(v[j] * g.out_scale + e_bias[j], g.out_act, 0.f);
+          st8<T>(Yg + o, v);
+        } else if (EPI == 1) {
+          st8<T>(Yg + o, v);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) { s1[j] += v[j]; s2[j] += v[j] * v[j]; }
+        } else {
+          float z[8], rv[8];
+          cvt8(zr[EPI == 2 ? s : 0], z);
+          if (Rg) {
+            cvt8(rr[EPI == 2 ? s : 0], rv);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] += rv[j];
+          }
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const float u = z[j] * e_sc[j] + e_sh[j];
+            v[j] = rnd<T>(v[j] * act_grad(u, g.epi.act, g.epi.slope));
+            s1[j] += v[j];
+            s2[j] += v[j] * ((z[j] - e_mu[j]) * e_is[j]);
+          }
+          st8<T>(Yg + o, v);
+        }
+      }
+    }
+  }
+  if (EPI != 0) {
+    __syncthreads();
+    float* Rs = reinterpret_cast<float*>(stages);  // [2][VR][DBN]
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      Rs[vrow0 * DBN + vcol * 8 + j] = s1[j];
+      Rs[VR * DBN + vrow0 * DBN + vcol * 8 + j] = s2[j];
+    }
+    __syncthreads();
+    if (t < 2 * DBN) {
+      const int which = t / DBN, c = t % DBN;
+      float s = 0.f;
+      for (int r = 0; r < VR; ++r) s += Rs[which * VR * DBN + r * DBN + c];
+      if (n0 + c < N) atomicAdd(g.osums + (size_t)(blockIdx.x % g.oR) * 2 * N + (size_t)which * N + n0 + c, s);
+    }
+  }
+}
+
+template <int PRO, int EPI>
+int launch_gemm_dma(const spb_gemm_args_t& g, hipStream_t stream) {
+  const int NT = (g.N + DBN - 1) / DBN, MT = (g.M + DBM - 1) / DBM;
+  const int Kp = (g.K + DBK - 1) / DBK * DBK;
+  const size_t lds = (size_t)3 * Kp * sizeof(float) + (size_t)DS * (PRO == 2 ? 3 : 2) * DBM * DBK * 2;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&pw_gemm_dma_kernel<PRO, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_done = true;
+  }
+  if (lds > 160 * 1024) return SPB_E_SHAPE;
+  hipLaunchKernelGGL((pw_gemm_dma_kernel<PRO, EPI>), dim3(NT * MT), dim3(256), lds, stream, g);
+  SPB_CHECK_LAUNCH();
+  return 0;
+}
+
+bool g_disable_dma = false;  // test hook: spb_debug_set_gemm_dma(0) forces the register-prefetch kernel everywhere
 
 template <typename T, int PRO, int EPI>
 int dispatch_bn(const spb_gemm_args_t& g, hipStream_t stream) {
@@ -350,12 +615,13 @@ int dispatch_bn(const spb_gemm_args_t& g, hipStream_t stream) {
   const bool small_m = g.M <= 16384;
   if (small_m && bn == 128) bn = 64;
   if (small_m) {
-    if (bn == 32) return launch_gemm<T, 1, 32, PRO, EPI>(g, stream);
-    return launch_gemm<T, 1, 64, PRO, EPI>(g, stream);
+    if (bn == 32) return launch_gemm<T, 1, 32, 32, PRO, EPI>(g, stream);
+    if (g.K >= 64 && sizeof(T) == 2 && !g_disable_dma) return launch_gemm_dma<PRO, EPI>(g, stream);
+    return launch_gemm<T, 1, 64, 32, PRO, EPI>(g, stream);
   }
-  if (bn == 32) return launch_gemm<T, 2, 32, PRO, EPI>(g, stream);
-  if (bn == 64) return launch_gemm<T, 2, 64, PRO, EPI>(g, stream);
-  return launch_gemm<T, 2, 128, PRO, EPI>(g, stream);
+  if (bn == 32) return launch_gemm<T, 2, 32, 32, PRO, EPI>(g, stream);
+  if (bn == 64) return launch_gemm<T, 2, 64, 32, PRO, EPI>(g, stream);
+  return launch_gemm<T, 2, 128, 32, PRO, EPI>(g, stream);
 }
 
 template <typename T>
@@ -561,5 +827,7 @@ extern "C" int spb_debug_trread(const unsigned short* in4096, unsigned short* ou
   SPB_CHECK_LAUNCH();
   return 0;
 }
+
+extern "C" int spb_debug_set_gemm_dma(int on) { g_disable_dma = (on == 0); return 0; }
 
 extern "C" const char* spb_version(void) { return "speedplusbaseline_amd gfx950 r1"; }

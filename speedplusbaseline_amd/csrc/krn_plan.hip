@@ -289,19 +289,17 @@ struct Runner {
     toc();
   }
   void dw_bwd(const DWDef& L, const Src& in, int Hin, int aout, int atgt, void* plain, const void* res) {
+    // one fused pass: input gradient (+ activation mask / BN sums of the input-side tensor) and weight gradient
     spb_dw_args_t d; std::memset(&d, 0, sizeof(d));
     d.X = this->g(aout); d.X2 = z(aout); d.Xin = in.ptr; d.Wd = m->P + L.w_off; d.dW = m->G + L.w_off;
     d.pro = ref(aout, true); d.pro_in = in.ref; d.B = c->B; d.H = Hin; d.W = Hin; d.C = L.C; d.stride = L.stride;
+    d.Zout = in.ptr; d.epi = in.ref;  // the convolution's input and its BN/activation (== ref(atgt) when atgt >= 0)
     if (atgt >= 0) {
-      d.Y = this->g(atgt); d.Zout = z(atgt); d.epi = ref(atgt, true); d.osums = bsums(atgt); d.oR = c->R[atgt];
-      d.res = res; d.epi_mode = 2;
+      d.Y = this->g(atgt); d.osums = bsums(atgt); d.oR = c->R[atgt]; d.res = res; d.epi_mode = 2;
     } else { d.Y = plain; d.epi_mode = 0; d.oR = 1; }
     const double nin = (double)c->B * Hin * Hin * L.C, nout = elems(aout);
-    tic(PC_DW_DGRAD, (2 * nout + (atgt >= 0 ? 2 : 1) * nin + (res ? nin : 0)) * es(), 18.0 * nout);
+    tic(PC_DW_DGRAD, (2 * nout + 2 * nin + (res ? nin : 0)) * es(), 36.0 * nout);
     ok(spb_dwconv_dgrad(dt, &d, st));
-    toc();
-    tic(PC_DW_WGRAD, (2 * nout + nin) * es(), 18.0 * nout);
-    ok(spb_dwconv_wgrad(dt, &d, st));
     toc();
   }
 };

@@ -29,12 +29,15 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__
 #pragma unroll
   for (int j = 0; j < 8; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
   for (long long p = (long long)blockIdx.x * 64 + pl; p < P; p += (long long)gridDim.x * 64) {
+    // the 27x8 weights this thread uses are loop invariant; without this barrier the compiler keeps all 216 of them in
+    // VGPRs (282 registers, 1 wave per SIMD, 280 GB/s).  Re-reading them from LDS per pixel costs 54 ds_read_b128.
+    asm volatile("" ::: "memory");
     const int ow = (int)(p % OW), oh = (int)((p / OW) % OH), b = (int)(p / ((long long)OW * OH));
     float acc[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[j] = 0.f;
-#pragma unroll
-    for (int ci = 0; ci < 3; ++ci)
+#pragma unroll 1
+    for (int ci = 0; ci < 3; ++ci)  // not unrolled: 9 taps (72 weights) live at a time instead of 27 (216)
 #pragma unroll
       for (int ky = 0; ky < 3; ++ky) {
         const int ih = oh * 2 - 1 + ky;

@@ -87,12 +87,19 @@ def dwconv_fwd(X, Wd, Y, pro, stride, osums=None, oR=1):
     L.check(L.lib().spb_dwconv_fwd(dtype_code(X), C.byref(d), _stream()), "spb_dwconv_fwd")
 
 
-def dwconv_dgrad(G, Z, Wd, Y, pro, stride, in_hw, epi=None, Zout=None, res=None, osums=None, oR=1):
+def dwconv_dgrad(G, Z, Wd, Y, pro, stride, in_hw, epi=None, Zout=None, res=None, osums=None, oR=1, dW=None, Xin=None,
+                 pro_in=None):
+    """Input gradient of the depthwise conv.  With `dW` the weight gradient is accumulated in the same pass; `Xin` and
+    `pro_in` (the conv's input tensor and its BN/activation) are then required unless `epi`/`Zout` already name them."""
     B, C_ = G.shape[0], G.shape[3]
-    _need_cuda(G, Z, Wd, Y, Zout, res, osums)
+    _need_cuda(G, Z, Wd, Y, Zout, res, osums, dW, Xin)
     kw = dict(X2=Z, Y=Y, pro=pro, epi_mode=2 if epi is not None else 0, oR=oR)
     if epi is not None:
         kw.update(epi=epi, Zout=Zout, res=res, osums=osums)
+    if dW is not None:
+        kw.update(dW=dW)
+        if epi is None:
+            kw.update(epi=pro_in, Zout=Xin)
     d = _dwargs(G, Wd, B, in_hw[0], in_hw[1], C_, stride, **kw)
     L.check(L.lib().spb_dwconv_dgrad(dtype_code(G), C.byref(d), _stream()), "spb_dwconv_dgrad")
 

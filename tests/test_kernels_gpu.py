@@ -230,7 +230,24 @@ def test_dwconv(device, dt, B, H, C, stride, act):
     P = torch.empty(B, H, H, C, dtype=dt, device=dev)
     ops.dwconv_dgrad(g2s.to(dt).to(dev), nhwc(zq).to(dt).to(dev), Wdev, P, pro, stride, (H, H))
     torch.cuda.synchronize()
-    assert relerr(P, nhwc(_dw_da(a, Wd, z, g2, g2s, xh2, C, stride))) < tol
+    da = nhwc(_dw_da(a, Wd, z, g2, g2s, xh2, C, stride))
+    assert relerr(P, da) < tol
+    # fused: input gradient and weight gradient in one pass, with and without the activation/BN-sum epilogue
+    for with_epi in (True, False):
+        Gf = torch.empty(B, H, H, C, dtype=dt, device=dev)
+        dWf = torch.zeros(C, 1, 3, 3, dtype=torch.float32, device=dev)
+        osf = torch.zeros(2, 2, C, dtype=torch.float32, device=dev)
+        if with_epi:
+            ops.dwconv_dgrad(g2s.to(dt).to(dev), nhwc(zq).to(dt).to(dev), Wdev, Gf, pro, stride, (H, H), epi=pro_in, Zout=X,
+                             osums=osf, oR=2, dW=dWf)
+        else:
+            ops.dwconv_dgrad(g2s.to(dt).to(dev), nhwc(zq).to(dt).to(dev), Wdev, Gf, pro, stride, (H, H), dW=dWf, Xin=X,
+                             pro_in=pro_in)
+        torch.cuda.synchronize()
+        assert relerr(dWf, Wd.grad) < tol
+        assert relerr(Gf, nhwc(u1.grad) if with_epi else da) < tol
+        if with_epi:
+            assert relerr(Gf, G1) < 1e-5 and relerr(osf.sum(0), os2.sum(0)) < 1e-5
 
 
 def _dw_da(a, Wd, z, g2, g2s_nhwc, xh2, C, stride):
