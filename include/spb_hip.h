@@ -276,6 +276,8 @@ long long spb_krn_weight_prep_bytes(const spb_krn_t* m);
 /* debug / test helpers */
 int spb_debug_trread(const unsigned short* in4096, unsigned short* out256, spb_stream_t stream);
 int spb_debug_set_gemm_dma(int on); /* 0: route every pointwise GEMM through the register-prefetch kernel (A/B tests) */
+int spb_debug_set_dw_mode(int mode); /* depthwise fwd/dgrad: 1 row-unit kernels (default), 0 LDS-tiled kernels */
+int spb_debug_set_dw_rows(int rows); /* rows per row unit (0: automatic) */
 const char* spb_version(void);
 
 #ifdef __cplusplus

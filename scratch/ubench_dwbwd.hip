@@ -3,12 +3,16 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include "../speedplusbaseline_amd/csrc/dwconv.hip"
+extern "C" int spb_debug_set_dw_rows(int);
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("err %s line %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
 int main() {
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   struct Sh { int B, H, C, st; } shapes[] = {{48, 112, 32, 1}, {48, 112, 96, 2}, {48, 56, 144, 1}, {48, 56, 144, 2}, {48, 28, 192, 1}, {48, 14, 384, 1}, {48, 14, 576, 1}, {48, 7, 960, 1}};
-  printf("SPB_ABL=%d\n", SPB_ABL);
+  if (getenv("DW_MODE")) spb_debug_set_dw_mode(atoi(getenv("DW_MODE")));
+  if (getenv("DW_ROWS")) spb_debug_set_dw_rows(atoi(getenv("DW_ROWS")));
+  printf("SPB_ABL=%d DW_MODE=%s DW_ROWS=%s\n", SPB_ABL, getenv("DW_MODE") ? getenv("DW_MODE") : "-", getenv("DW_ROWS") ? getenv("DW_ROWS") : "-");
   for (auto sh : shapes) {
     const int OH = (sh.H - 1) / sh.st + 1;
     size_t nin = (size_t)sh.B * sh.H * sh.H * sh.C, nout = (size_t)sh.B * OH * OH * sh.C;
@@ -29,7 +33,16 @@ int main() {
     CK(hipEventRecord(e0)); for (int k = 0; k < 10; ++k) spb_dwconv_dgrad(SPB_BF16, &a, 0);
     CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); float ms; CK(hipEventElapsedTime(&ms, e0, e1));
     const double bytes = (2.0 * nout + (a.res ? 3.0 : 2.0) * nin) * 2.0;
-    printf("dw_bwd B%d H%3d C%3d s%d: %8.2f us  %7.1f GB/s\n", sh.B, sh.H, sh.C, sh.st, ms * 100, bytes / (ms / 10 * 1e-3) / 1e9);
+    printf("dw_bwd B%d H%3d C%3d s%d: %8.2f us  %7.1f GB/s", sh.B, sh.H, sh.C, sh.st, ms * 100, bytes / (ms / 10 * 1e-3) / 1e9);
+    {  // forward of the same layer: x = zo -> y = g
+      spb_dw_args_t f; std::memset(&f, 0, sizeof(f));
+      f.X = zo; f.Wd = w; f.Y = g; f.osums = osums; f.oR = 8; f.epi_mode = 1; f.B = sh.B; f.H = sh.H; f.W = sh.H; f.C = sh.C; f.stride = sh.st;
+      f.pro = r;
+      for (int k = 0; k < 3; ++k) spb_dwconv_fwd(SPB_BF16, &f, 0);
+      CK(hipEventRecord(e0)); for (int k = 0; k < 10; ++k) spb_dwconv_fwd(SPB_BF16, &f, 0);
+      CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1));
+      printf("   | fwd %8.2f us  %7.1f GB/s\n", ms * 100, (nin + nout) * 2.0 / (ms / 10 * 1e-3) / 1e9);
+    }
     hipFree(g); hipFree(z); hipFree(zo); hipFree(rr); hipFree(y);
   }
   return 0;

@@ -129,6 +129,8 @@ SYMBOLS = {
     "spb_krn_weight_prep_bytes": (i64, [vp]),
     "spb_debug_trread": (i32, [vp, vp, vp]),
     "spb_debug_set_gemm_dma": (i32, [i32]),
+    "spb_debug_set_dw_mode": (i32, [i32]),
+    "spb_debug_set_dw_rows": (i32, [i32]),
     "spb_version": (C.c_char_p, []),
 }
 

@@ -666,10 +666,23 @@ void dw_set_lds(K kernel) {
 
 }  // namespace
 
+// row-unit kernels (dwconv_rows.hip); g_dw_mode 1 (default) routes forward and input gradient through them, 0 keeps
+// the LDS-tiled kernels of this file (A/B measurements, spb_debug_set_dw_mode)
+int spb_dwr_fwd(int dtype, const spb_dw_args_t* a, hipStream_t s);
+int spb_dwr_bwd(int dtype, const spb_dw_args_t* a, hipStream_t s);
+static int g_dw_mode = 1;
+extern "C" int spb_debug_set_dw_mode(int mode) { g_dw_mode = mode; return 0; }
+
 extern "C" int spb_dwconv_fwd(int dtype, const spb_dw_args_t* a, spb_stream_t stream) {
   int e = dw_check(a);
   if (e) return e;
   if (!a->Y || (a->epi_mode == 1 && (!a->osums || a->oR < 1))) return SPB_E_ARG;
+  if (dtype != SPB_BF16 && dtype != SPB_F32) return SPB_E_ARG;
+  if (g_dw_mode == 1) {
+    spb_dwr_fwd(dtype, a, (hipStream_t)stream);
+    SPB_CHECK_LAUNCH();
+    return 0;
+  }
   const int st = a->stride;
   const int OH = (a->H - 1) / st + 1, OW = (a->W - 1) / st + 1;
   const Tiles tl = make_tiles(a->B, OH, OW, st);
@@ -703,6 +716,12 @@ extern "C" int spb_dwconv_dgrad(int dtype, const spb_dw_args_t* a, spb_stream_t 
   if (!k.X2) k.X2 = k.X;  // no BN behind the convolution: p1 == 0, the kernel still reads a (finite) second operand
   const bool epi = k.epi_mode == 2;
   hipStream_t s = (hipStream_t)stream;
+  if (dtype != SPB_BF16 && dtype != SPB_F32) return SPB_E_ARG;
+  if (g_dw_mode == 1) {
+    spb_dwr_bwd(dtype, &k, s);
+    SPB_CHECK_LAUNCH();
+    return 0;
+  }
 #define DG_LAUNCH(T_, WG_, EPI_)                                                       \
   {                                                                                    \
     static bool once = false;                                                          \

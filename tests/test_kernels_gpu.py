@@ -247,7 +247,7 @@ def test_dwconv(device, dt, B, H, C, stride, act):
         assert relerr(dWf, Wd.grad) < tol
         assert relerr(Gf, nhwc(u1.grad) if with_epi else da) < tol
         if with_epi:
-            assert relerr(Gf, G1) < 1e-5 and relerr(osf.sum(0), os2.sum(0)) < 1e-5
+            assert relerr(Gf, G1) < tol and relerr(osf.sum(0), os2.sum(0)) < 1e-3
 
 
 def _dw_da(a, Wd, z, g2, g2s_nhwc, xh2, C, stride):
