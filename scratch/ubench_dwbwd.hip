@@ -12,6 +12,7 @@ int main() {
   struct Sh { int B, H, C, st; } shapes[] = {{48, 112, 32, 1}, {48, 112, 96, 2}, {48, 56, 144, 1}, {48, 56, 144, 2}, {48, 28, 192, 1}, {48, 14, 384, 1}, {48, 14, 576, 1}, {48, 7, 960, 1}};
   if (getenv("DW_MODE")) spb_debug_set_dw_mode(atoi(getenv("DW_MODE")));
   if (getenv("DW_ROWS")) spb_debug_set_dw_rows(atoi(getenv("DW_ROWS")));
+  if (getenv("DW_BLOCKS")) spb_debug_set_dw_rows(-atoi(getenv("DW_BLOCKS")));
   printf("SPB_ABL=%d DW_MODE=%s DW_ROWS=%s\n", SPB_ABL, getenv("DW_MODE") ? getenv("DW_MODE") : "-", getenv("DW_ROWS") ? getenv("DW_ROWS") : "-");
   for (auto sh : shapes) {
     const int OH = (sh.H - 1) / sh.st + 1;
@@ -24,7 +25,7 @@ int main() {
     CK(hipMemset(w, 0, sh.C * 36)); CK(hipMemset(dw, 0, sh.C * 36)); CK(hipMemset(sums, 0, 64 * sh.C)); CK(hipMemset(bsums, 0, 64 * sh.C));
     CK(hipMemset(gam, 0, sh.C * 4)); CK(hipMemset(bet, 0, sh.C * 4)); CK(hipMemset(osums, 0, 64 * sh.C));
     spb_dw_args_t a; std::memset(&a, 0, sizeof(a));
-    a.X = g; a.X2 = z; a.Wd = w; a.Y = y; a.dW = dw; a.Zout = zo; a.res = sh.st == 1 ? rr : nullptr; a.osums = osums; a.oR = 8; a.epi_mode = 2;
+    a.X = g; a.X2 = z; a.Wd = w; a.Y = y; a.dW = dw; a.Zout = zo; a.res = getenv("DW_RES") && sh.st == 1 ? rr : nullptr; a.osums = osums; a.oR = 8; a.epi_mode = 2;
     a.B = sh.B; a.H = sh.H; a.W = sh.H; a.C = sh.C; a.stride = sh.st;
     spb_bnref_t r; std::memset(&r, 0, sizeof(r));
     r.sums = sums; r.gamma = gam; r.beta = bet; r.bsums = bsums; r.inv_n = 1.f; r.eps = 1e-5f; r.C = sh.C; r.R = 8; r.act = SPB_ACT_RELU6;

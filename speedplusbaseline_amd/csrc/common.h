@@ -21,12 +21,15 @@ typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 // ---------------------------------------------------------------------------------------------
 // scalar conversions
 __device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
-__device__ __forceinline__ bf16_t f2bf(float f) {  // round-to-nearest-even, NaN preserved
-  uint32_t u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (bf16_t)(u >> 16);
+// float -> bf16, round-to-nearest-even: one v_cvt_pk_bf16_f32 per pair on gfx950 (the integer emulation cost 7 VALU
+// ops per value and was ~20 % of the instruction stream of the streaming kernels)
+typedef __bf16 spb_bf16x2_hw __attribute__((ext_vector_type(2)));
+typedef float spb_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+  const spb_f32x2 v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, spb_bf16x2_hw));
 }
+__device__ __forceinline__ bf16_t f2bf(float f) { return (bf16_t)(pack_bf16x2(f, 0.f) & 0xffffu); }
 template <typename T> __device__ __forceinline__ float to_f(T v);
 template <> __device__ __forceinline__ float to_f<float>(float v) { return v; }
 template <> __device__ __forceinline__ float to_f<bf16_t>(bf16_t v) { return bf2f(v); }
@@ -58,10 +61,10 @@ template <> __device__ __forceinline__ void st8<float>(float* p, const float v[8
 }
 template <> __device__ __forceinline__ void st8<bf16_t>(bf16_t* p, const float v[8]) {
   uint4 u;
-  u.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
-  u.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
-  u.z = (uint32_t)f2bf(v[4]) | ((uint32_t)f2bf(v[5]) << 16);
-  u.w = (uint32_t)f2bf(v[6]) | ((uint32_t)f2bf(v[7]) << 16);
+  u.x = pack_bf16x2(v[0], v[1]);
+  u.y = pack_bf16x2(v[2], v[3]);
+  u.z = pack_bf16x2(v[4], v[5]);
+  u.w = pack_bf16x2(v[6], v[7]);
   *reinterpret_cast<uint4*>(p) = u;
 }
 // Raw (unconverted) 8-element vectors: kernels issue all their global loads back to back into these, with clamped
@@ -87,9 +90,14 @@ __device__ __forceinline__ void cvt8(const Raw8<float>& r, float v[8]) {
   v[0] = r.a.x; v[1] = r.a.y; v[2] = r.a.z; v[3] = r.a.w; v[4] = r.b.x; v[5] = r.b.y; v[6] = r.b.z; v[7] = r.b.w;
 }
 
-template <typename T> __device__ __forceinline__ void rnd8(float v[8]) {
+template <typename T> __device__ __forceinline__ void rnd8(float v[8]);
+template <> __device__ __forceinline__ void rnd8<float>(float v[8]) {}
+template <> __device__ __forceinline__ void rnd8<bf16_t>(float v[8]) {
 #pragma unroll
-  for (int i = 0; i < 8; ++i) v[i] = rnd<T>(v[i]);
+  for (int i = 0; i < 8; i += 2) {
+    const uint32_t p = pack_bf16x2(v[i], v[i + 1]);
+    v[i] = __uint_as_float(p << 16); v[i + 1] = __uint_as_float(p & 0xffff0000u);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -103,7 +111,7 @@ __device__ __forceinline__ float act_ns(int act, float slope) {
   return act == SPB_ACT_NONE ? 1.f : (act == SPB_ACT_LEAKY ? slope : 0.f);
 }
 __device__ __forceinline__ float act_fwd(float u, int act, float slope) {
-  return fminf(fmaxf(u, 0.f), act_hi(act)) + act_ns(act, slope) * fminf(u, 0.f);
+  return __builtin_amdgcn_fmed3f(u, 0.f, act_hi(act)) + act_ns(act, slope) * fminf(u, 0.f);
 }
 __device__ __forceinline__ float act_grad(float u, int act, float slope) {
   return u > 0.f ? (u < act_hi(act) ? 1.f : 0.f) : act_ns(act, slope);
