@@ -34,7 +34,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=48, help="images per GPU (README recipe: 48)")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
-    ap.add_argument("--no-graph", action="store_true", help="launch kernels eagerly instead of replaying a hipGraph")
+    ap.add_argument("--graph", action="store_true", help="replay a captured hipGraph instead of enqueuing the launches "
+                    "eagerly (eager + side-stream weight gradients is the faster, default mode)")
+    ap.add_argument("--no-graph", action="store_true", help=argparse.SUPPRESS)  # old spelling of the default
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=3)
     ap.add_argument("--cpu-threads", type=int, default=32)
@@ -62,6 +64,13 @@ def main():
         torch.distributed.init_process_group("nccl", device_id=dev)
         group = torch.distributed.group.WORLD
 
+    # A/B switches for experiments (defaults are the product configuration)
+    from speedplusbaseline_amd import _lib as _L
+    for env, fn in (("SPB_SIDE_WGRAD", "spb_debug_set_side_wgrad"), ("SPB_DW_MODE", "spb_debug_set_dw_mode"),
+                    ("SPB_GEMM_DMA", "spb_debug_set_gemm_dma")):
+        if os.environ.get(env) is not None:
+            getattr(_L.lib(), fn)(int(os.environ[env]))
+
     B = args.batch
     eng = KrnEngine(11).attach(dev, args.precision)
     sd = O.init_state(11)  # random-init weights of the KRN architecture (no checkpoints offline)
@@ -75,7 +84,7 @@ def main():
     x = torch.rand(B, 3, 224, 224, generator=gen).to(dev)   # U[0,1) like transforms.py:192-196
     y = torch.rand(B, 2, 11, generator=gen).to(dev)
     step = FusedTrainStep(eng, B, kind="adamw", lr=1e-3, momentum=0.9, weight_decay=0.01, max_norm=1.0,
-                          dist_group=group, world_size=world, use_graph=not args.no_graph)
+                          dist_group=group, world_size=world, use_graph=args.graph)
 
     def sync_all():
         if world > 1:
@@ -190,7 +199,8 @@ def main():
             "config": {"workload": "KRN (MobileNetV2 features + ConvDw extras + 7x7 keypoint head) train step, 224x224, "
                                    "bs=%d/GPU, AdamW lr 1e-3 wd 0.01 + clip_grad_norm 1.0" % B,
                        "per_gpu_batch": B, "global_batch": B * world, "parallelism": "dp%d" % world,
-                       "launch": "eager" if args.no_graph else "hipGraph replay (fwd+bwd | all-reduce | clip+AdamW)",
+                       "launch": "hipGraph replay (fwd+bwd | all-reduce | clip+AdamW)" if args.graph else
+                                 "eager enqueue, weight-gradient GEMMs on a side stream",
                        "weights": "random init (no checkpoints offline)", "loss_last_step": loss_last},
             "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels,
         }

@@ -247,6 +247,10 @@ typedef struct spb_krn_ctx spb_krn_ctx_t; /* activations of ONE forward pass at 
 long long spb_krn_ctx_bytes(const spb_krn_t* m, int batch, int dtype);
 int spb_krn_ctx_create(spb_krn_t* m, int batch, void* workspace, spb_krn_ctx_t** out);
 void spb_krn_ctx_destroy(spb_krn_ctx_t* c);
+/* The pointwise weight-gradient GEMMs of spb_krn_backward only feed the optimizer; by default they are enqueued on a
+ * context-owned side stream (forked from / joined to `stream` with events) so that they overlap the input-gradient
+ * chain.  on = 0 keeps every launch on `stream` (use this when capturing into a hipGraph: measured slower there). */
+int spb_krn_ctx_set_side_stream(spb_krn_ctx_t* c, int on);
 
 /* refresh compute-dtype weight copies (W, W^T, permuted head) from the f32 parameters */
 int spb_krn_prepare_weights(spb_krn_t* m, spb_stream_t stream);
@@ -275,8 +279,9 @@ long long spb_krn_weight_prep_bytes(const spb_krn_t* m);
 
 /* debug / test helpers */
 int spb_debug_trread(const unsigned short* in4096, unsigned short* out256, spb_stream_t stream);
-int spb_debug_set_gemm_dma(int on); /* 0: route every pointwise GEMM through the register-prefetch kernel (A/B tests) */
+int spb_debug_set_gemm_dma(int on); /* 1: small-M bf16 pointwise GEMMs use the LDS-DMA ring kernel (default 0) */
 int spb_debug_set_dw_mode(int mode); /* depthwise fwd/dgrad: 1 row-unit kernels (default), 0 LDS-tiled kernels */
+int spb_debug_set_side_wgrad(int on); /* 0: pointwise weight gradients stay on the launch stream */
 int spb_debug_set_dw_rows(int rows); /* rows per row unit (0: automatic) */
 const char* spb_version(void);
 

@@ -118,6 +118,7 @@ SYMBOLS = {
     "spb_krn_ctx_bytes": (i64, [vp, i32, i32]),
     "spb_krn_ctx_create": (i32, [vp, i32, vp, C.POINTER(vp)]),
     "spb_krn_ctx_destroy": (None, [vp]),
+    "spb_krn_ctx_set_side_stream": (i32, [vp, i32]),
     "spb_krn_prepare_weights": (i32, [vp, vp]),
     "spb_krn_forward": (i32, [vp, vp, vp, i32, vp, vp, vp, vp]),
     "spb_krn_backward": (i32, [vp, vp, f32, i32, vp, f32, vp]),
@@ -130,6 +131,7 @@ SYMBOLS = {
     "spb_debug_trread": (i32, [vp, vp, vp]),
     "spb_debug_set_gemm_dma": (i32, [i32]),
     "spb_debug_set_dw_mode": (i32, [i32]),
+    "spb_debug_set_side_wgrad": (i32, [i32]),
     "spb_debug_set_dw_rows": (i32, [i32]),
     "spb_version": (C.c_char_p, []),
 }

@@ -597,7 +597,9 @@ int launch_gemm_dma(const spb_gemm_args_t& g, hipStream_t stream) {
   return 0;
 }
 
-bool g_disable_dma = false;  // test hook: spb_debug_set_gemm_dma(0) forces the register-prefetch kernel everywhere
+// The LDS-DMA ring variant is kept for experiments (spb_debug_set_gemm_dma(1)); measured in the full KRN step it is
+// slower than the register-prefetch kernel on the small-M layers it was written for (dgrad 1.52 vs 1.38 ms / step).
+bool g_disable_dma = true;
 
 template <typename T, int PRO, int EPI>
 int dispatch_bn(const spb_gemm_args_t& g, hipStream_t stream) {

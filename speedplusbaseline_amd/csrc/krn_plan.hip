@@ -108,6 +108,19 @@ struct spb_krn_ctx {
   std::vector<int> prof_cat;
   std::vector<double> prof_bytes, prof_flops;
   int prof_n = 0;
+  // weight-gradient GEMMs run on a side stream: they only feed the optimizer, so they overlap the dgrad / depthwise
+  // chain of the earlier layers (fork/join with events, capturable into a hipGraph)
+  hipStream_t side = nullptr;
+  bool side_on = true;
+  std::vector<hipEvent_t> fork_ev;
+  hipEvent_t join_ev = nullptr;
+  int n_fork = 0;
+  ~spb_krn_ctx() {
+    for (hipEvent_t e : fork_ev) hipEventDestroy(e);
+    for (hipEvent_t e : prof_ev) hipEventDestroy(e);
+    if (join_ev) hipEventDestroy(join_ev);
+    if (side) hipStreamDestroy(side);
+  }
 };
 
 enum ProfCat { PC_STEM_FWD = 0, PC_PW_FWD, PC_DW_FWD, PC_BN_APPLY, PC_HEAD_FWD, PC_BN_UPDATE, PC_HEAD_BWD, PC_PW_DGRAD,
@@ -199,6 +212,7 @@ void build_model(spb_krn* m, int nK, bool dann) {
 // ---------------------------------------------------------------------------------------------------------------
 struct Src { const void* ptr; spb_bnref_t ref; };
 
+static int g_side_wgrad = 1;
 struct Runner {
   spb_krn_ctx* c; spb_krn* m; hipStream_t st; int dt; int err = 0;
   Runner(spb_krn_ctx* c_, hipStream_t s) : c(c_), m(c_->m), st(s), dt(c_->m->dtype) {}
@@ -268,6 +282,13 @@ struct Runner {
   }
   // ---- backward pieces.  `atgt` is the Act whose g / bsums the input gradient lands in (-1: plain output to `plain`)
   void pw_bwd(const PWDef& L, const Src& in, int aout, int atgt, void* plain, const void* res, float plain_scale = 1.f) {
+    // weight gradient first: on the side stream it then runs beside this layer's input-gradient GEMM
+    spb_wgrad_args_t w; std::memset(&w, 0, sizeof(w));
+    w.G = this->g(aout); w.Zn = z(aout); w.X = in.ptr; w.dW = m->G + L.w_off; w.pro_dz = ref(aout, true);
+    w.pro_a = in.ref; w.M = M(aout); w.K = L.K; w.N = L.N;
+    tic(PC_PW_WGRAD, ((double)w.M * (2 * L.N + L.K)) * es() + 4.0 * L.K * L.N, 2.0 * w.M * L.K * L.N);
+    ok(spb_pwconv_wgrad(dt, &w, side_stream()));
+    toc();
     spb_gemm_args_t g; std::memset(&g, 0, sizeof(g));
     g.A = this->g(aout); g.A2 = z(aout); g.Bw = wc(L.wct_off); g.pro = ref(aout, true);
     g.M = M(aout); g.K = L.N; g.N = L.K; g.pro_mode = 2; g.out_scale = plain_scale;
@@ -281,13 +302,29 @@ struct Runner {
     }
     ok(spb_pwconv_gemm(dt, &g, st));
     toc();
-    spb_wgrad_args_t w; std::memset(&w, 0, sizeof(w));
-    w.G = this->g(aout); w.Zn = z(aout); w.X = in.ptr; w.dW = m->G + L.w_off; w.pro_dz = ref(aout, true);
-    w.pro_a = in.ref; w.M = M(aout); w.K = L.K; w.N = L.N;
-    tic(PC_PW_WGRAD, ((double)w.M * (2 * L.N + L.K)) * es() + 4.0 * L.K * L.N, 2.0 * w.M * L.K * L.N);
-    ok(spb_pwconv_wgrad(dt, &w, st));
-    toc();
   }
+  // Stream for work that only the optimizer consumes.  Forked from the launch stream at the current point (everything
+  // the weight gradient reads -- g, z, bsums of the output, the forward activations -- is final before pw_bwd starts);
+  // joined at the end of spb_krn_backward.  With the profiler on everything stays on the launch stream.
+  hipStream_t side_stream() {
+    if (c->prof_on || !c->side || !c->side_on || !g_side_wgrad) return st;
+    if ((size_t)c->n_fork >= c->fork_ev.size()) {
+      hipEvent_t e; hipEventCreateWithFlags(&e, hipEventDisableTiming);
+      c->fork_ev.push_back(e);
+    }
+    hipEvent_t e = c->fork_ev[c->n_fork++];
+    hipEventRecord(e, st);
+    hipStreamWaitEvent(c->side, e, 0);
+    forked = true;
+    return c->side;
+  }
+  void join_side() {
+    if (!forked) return;
+    hipEventRecord(c->join_ev, c->side);
+    hipStreamWaitEvent(st, c->join_ev, 0);
+    forked = false;
+  }
+  bool forked = false;
   void dw_bwd(const DWDef& L, const Src& in, int Hin, int aout, int atgt, void* plain, const void* res) {
     // one fused pass: input gradient (+ activation mask / BN sums of the input-side tensor) and weight gradient
     spb_dw_args_t d; std::memset(&d, 0, sizeof(d));
@@ -516,10 +553,24 @@ extern "C" int spb_krn_ctx_create(spb_krn_t* m, int batch, void* workspace, spb_
   }
   hipError_t e = hipMemcpy(c->ws + c->table_off, tab.data(), tab.size() * sizeof(spb_bnupd_entry_t), hipMemcpyHostToDevice);
   if (e != hipSuccess) { delete c; return (int)e; }
+  // side stream + events are created here, outside any stream capture
+  if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess) c->side = nullptr;
+  if (hipEventCreateWithFlags(&c->join_ev, hipEventDisableTiming) != hipSuccess) { delete c; return SPB_E_STATE; }
+  for (int i = 0; i < 64; ++i) {
+    hipEvent_t ev;
+    if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) break;
+    c->fork_ev.push_back(ev);
+  }
   *out = c;
   return 0;
 }
 extern "C" void spb_krn_ctx_destroy(spb_krn_ctx_t* c) { delete c; }
+extern "C" int spb_debug_set_side_wgrad(int on) { g_side_wgrad = on; return 0; }
+extern "C" int spb_krn_ctx_set_side_stream(spb_krn_ctx_t* c, int on) {
+  if (!c) return SPB_E_ARG;
+  c->side_on = on != 0;
+  return 0;
+}
 
 // ---- forward ---------------------------------------------------------------------------------------------------
 extern "C" int spb_krn_forward(spb_krn_ctx_t* c, const float* x, const float* target, int training, float* pred,
@@ -640,6 +691,7 @@ extern "C" int spb_krn_backward(spb_krn_ctx_t* c, float* grads, float gscale, in
   if (dlogit && !m->dann) return SPB_E_ARG;
   hipStream_t st = (hipStream_t)stream;
   Runner r(c, st);
+  c->n_fork = 0;
   const int dt = m->dtype;
   const int aF = m->blk[17].aP;  // feature = bn(z) of block 17's projection (no residual there)
   void* ddom = nullptr;
@@ -727,6 +779,7 @@ extern "C" int spb_krn_backward(spb_krn_ctx_t* c, float* grads, float gscale, in
     r.ok(spb_stem_wgrad(dt, c->x, r.g(m->aStem), r.z(m->aStem), &pro, m->G + m->stem_w_off, c->B, kIn, kIn, stream));
     r.toc();
   }
+  r.join_side();
   r.tic(PC_BN_PARAM_GRADS, (double)c->stats_floats * 2);
   // BatchNorm affine gradients: dgamma += sum(g*xhat), dbeta += sum(g)
   r.ok(spb_bn_param_grads(reinterpret_cast<const spb_bnupd_entry_t*>(c->ws + c->table_off), (int)m->bns.size(), r.stats(),

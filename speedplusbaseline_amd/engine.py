@@ -139,6 +139,10 @@ class KrnEngine:
                                               _stream()), "spb_krn_backward")
 
     # ------------------------------------------------------------------------------------------------ live timing
+    def set_side_stream(self, batch, slot=0, on=True):
+        """weight-gradient GEMMs on the context's side stream (default) or on the launch stream (hipGraph capture)"""
+        L.check(self.lib.spb_krn_ctx_set_side_stream(self.context(batch, slot), 1 if on else 0), "spb_krn_ctx_set_side_stream")
+
     def prof_enable(self, batch, slot=0, on=True):
         L.check(self.lib.spb_krn_prof_enable(self.context(batch, slot), 1 if on else 0), "spb_krn_prof_enable")
 

@@ -15,7 +15,7 @@ from .step import FusedTrainStep
 
 class FusedOptimizer(torch.optim.Optimizer):
     def __init__(self, params, kind="adamw", lr=1e-3, momentum=0.9, weight_decay=0.0, model=None, max_norm=1.0,
-                 use_graph=True):
+                 use_graph=False):
         defaults = dict(lr=lr, momentum=momentum, weight_decay=weight_decay, kind=kind)
         super().__init__(params, defaults)
         if len(self.param_groups) != 1:

@@ -72,11 +72,27 @@ def test_trread_semantics(device):
     assert torch.equal(out, exp), (out[:20], exp[:20])
 
 
+@pytest.fixture(params=["prefetch", "lds_dma"])
+def gemm_variant(request):
+    """both pointwise-GEMM kernels: the default register-prefetch one and the LDS-DMA ring (small M, bf16, K >= 64)"""
+    L.lib().spb_debug_set_gemm_dma(1 if request.param == "lds_dma" else 0)
+    yield request.param
+    L.lib().spb_debug_set_gemm_dma(0)
+
+
+@pytest.fixture(params=["rows", "tiles"])
+def dw_variant(request):
+    """both depthwise kernel families: the default row-unit kernels and the LDS-tiled ones"""
+    L.lib().spb_debug_set_dw_mode(1 if request.param == "rows" else 0)
+    yield request.param
+    L.lib().spb_debug_set_dw_mode(1)
+
+
 @pytest.mark.parametrize("dt", DTYPES)
 @pytest.mark.parametrize("M,K,N,act,R", [(300, 24, 144, L.ACT_RELU6, 1), (1000, 144, 32, L.ACT_RELU6, 3),
                                           (257, 320, 1024, L.ACT_NONE, 1), (2352, 96, 64, L.ACT_RELU, 2),
                                           (129, 16, 96, L.ACT_NONE, 8)])
-def test_pw_gemm_fwd(device, dt, M, K, N, act, R):
+def test_pw_gemm_fwd(device, gemm_variant, dt, M, K, N, act, R):
     torch.manual_seed(M + K + N)
     zin = rt(torch.randn(M, K, dtype=torch.float64) * 1.5 + 0.3, dt)
     gamma = torch.rand(K, dtype=torch.float64) + 0.5; beta = torch.randn(K, dtype=torch.float64) * 0.3
@@ -125,7 +141,7 @@ def _composite(M, K, N, act1, act2, dt, seed):
 @pytest.mark.parametrize("dt", DTYPES)
 @pytest.mark.parametrize("M,K,N,act1,act2", [(300, 24, 144, L.ACT_RELU6, L.ACT_RELU6), (513, 144, 32, L.ACT_RELU6, L.ACT_NONE),
                                              (260, 96, 64, L.ACT_NONE, L.ACT_LEAKY), (200, 1024, 1024, L.ACT_RELU, L.ACT_RELU)])
-def test_pw_gemm_bwd(device, dt, M, K, N, act1, act2):
+def test_pw_gemm_bwd(device, gemm_variant, dt, M, K, N, act1, act2):
     c = _composite(M, K, N, act1, act2, dt, seed=M * 7 + N)
     dev = device
     g2 = rt(c["u2"].grad, dt)  # g = dL/d(bn2 output) with act2' applied by autograd
@@ -173,7 +189,7 @@ def test_pw_gemm_bwd(device, dt, M, K, N, act1, act2):
 @pytest.mark.parametrize("dt", DTYPES)
 @pytest.mark.parametrize("B,H,C,stride,act", [(2, 14, 96, 1, L.ACT_RELU6), (3, 15, 32, 2, L.ACT_RELU6), (2, 7, 1280, 1, L.ACT_NONE),
                                               (2, 28, 144, 2, L.ACT_RELU)])
-def test_dwconv(device, dt, B, H, C, stride, act):
+def test_dwconv(device, dw_variant, dt, B, H, C, stride, act):
     torch.manual_seed(B * H + C)
     dev = device
     zin = rt(torch.randn(B, C, H, H, dtype=torch.float64) + 0.1, dt).requires_grad_(True)
