@@ -80,6 +80,28 @@ typedef struct spb_wgrad_args {
 } spb_wgrad_args_t;
 int spb_pwconv_wgrad(int dtype, const spb_wgrad_args_t* args, spb_stream_t stream);
 
+/* Fused backward of a pointwise convolution (input gradient + weight gradient in one pass over g and z) for the
+ * wide, shallow layers (M = B*H*W >= ~32k rows, N*K small).  Same math as spb_pwconv_gemm(pro_mode 2, epi_mode 2)
+ * followed by spb_pwconv_wgrad.  Returns SPB_E_UNSUPPORTED when no fused instance exists for (dtype, N, K): the caller
+ * then runs the two kernels.  Replaces the autograd backward of nn.Conv2d(k=1)+BatchNorm2d(+ReLU6) in torchvision's
+ * InvertedResidual (call site park2019.py:107-108). */
+typedef struct {
+  const void* G;      /* [M,N] g of the conv output (dL/d(bn out) * act') */
+  const void* Zn;     /* [M,N] raw conv output z */
+  const void* Wt;     /* [K,N] transposed weights in the compute dtype */
+  const void* X;      /* [M,K] conv input as stored: raw z of its producer, or a materialised tensor */
+  const void* Zout;   /* [M,K] raw z of the input-side BN'd tensor (== X when the input is not materialised) */
+  const void* res;    /* [M,K] gradient joining the input-side tensor from elsewhere, or NULL */
+  void* Y;            /* [M,K] out: g of the input-side tensor */
+  float* dW;          /* [N,K] f32, accumulated */
+  float* osums;       /* [oR][2][K] f32, accumulated: sum g, sum g*xhat */
+  spb_bnref_t pro_dz; /* BN backward of the conv output */
+  spb_bnref_t pro_a;  /* BN + activation turning X into the conv input */
+  spb_bnref_t epi;    /* BN + activation of the input-side tensor (mask and xhat) */
+  int M, K, N, oR;
+} spb_pwbwd_args_t;
+int spb_pwconv_bwd_fused(int dtype, const spb_pwbwd_args_t* args, spb_stream_t stream);
+
 /* ---- depthwise 3x3 convolution, pad 1, stride 1|2 ----------------------------------------------------------
  * nn.Conv2d(C,C,3,groups=C): park2019.py:47 and torchvision MobileNetV2 blocks.                               */
 typedef struct spb_dw_args {
@@ -281,6 +303,7 @@ long long spb_krn_weight_prep_bytes(const spb_krn_t* m);
 int spb_debug_trread(const unsigned short* in4096, unsigned short* out256, spb_stream_t stream);
 int spb_debug_set_gemm_dma(int on); /* 1: small-M bf16 pointwise GEMMs use the LDS-DMA ring kernel (default 0) */
 int spb_debug_set_dw_mode(int mode); /* depthwise fwd/dgrad: 1 row-unit kernels (default), 0 LDS-tiled kernels */
+int spb_debug_set_fused_pw_bwd(int on); /* 0: the KRN plan never uses spb_pwconv_bwd_fused */
 int spb_debug_set_side_wgrad(int on); /* 0: pointwise weight gradients stay on the launch stream */
 int spb_debug_set_dw_rows(int rows); /* rows per row unit (0: automatic) */
 const char* spb_version(void);

@@ -34,6 +34,12 @@ class WgradArgs(C.Structure):
                 ("K", i32), ("N", i32)]
 
 
+class PwBwdArgs(C.Structure):
+    _fields_ = [("G", vp), ("Zn", vp), ("Wt", vp), ("X", vp), ("Zout", vp), ("res", vp), ("Y", vp), ("dW", vp),
+                ("osums", vp), ("pro_dz", BNRef), ("pro_a", BNRef), ("epi", BNRef), ("M", i32), ("K", i32), ("N", i32),
+                ("oR", i32)]
+
+
 class DwArgs(C.Structure):
     _fields_ = [("X", vp), ("X2", vp), ("Xin", vp), ("Wd", vp), ("Y", vp), ("dW", vp), ("res", vp), ("Zout", vp),
                 ("osums", vp), ("pro", BNRef), ("pro_in", BNRef), ("epi", BNRef), ("B", i32), ("H", i32), ("W", i32),
@@ -87,6 +93,7 @@ class TensorInfo(C.Structure):
 SYMBOLS = {
     "spb_pwconv_gemm": (i32, [i32, C.POINTER(GemmArgs), vp]),
     "spb_pwconv_wgrad": (i32, [i32, C.POINTER(WgradArgs), vp]),
+    "spb_pwconv_bwd_fused": (i32, [i32, C.POINTER(PwBwdArgs), vp]),
     "spb_dwconv_fwd": (i32, [i32, C.POINTER(DwArgs), vp]),
     "spb_dwconv_dgrad": (i32, [i32, C.POINTER(DwArgs), vp]),
     "spb_dwconv_wgrad": (i32, [i32, C.POINTER(DwArgs), vp]),
@@ -132,6 +139,7 @@ SYMBOLS = {
     "spb_debug_set_gemm_dma": (i32, [i32]),
     "spb_debug_set_dw_mode": (i32, [i32]),
     "spb_debug_set_side_wgrad": (i32, [i32]),
+    "spb_debug_set_fused_pw_bwd": (i32, [i32]),
     "spb_debug_set_dw_rows": (i32, [i32]),
     "spb_version": (C.c_char_p, []),
 }

@@ -30,8 +30,12 @@
 namespace {
 
 constexpr int CFN = 128;  // floats of per-channel-group coefficients: w[9][8] | p0,p1,p2 (bwd) or sc,sh (fwd) | sc,sh,mu,is
-// ring depth: stream elements in flight per wave (the f32 parity mode needs twice the bytes per element)
-template <typename T> struct RingDepth { static constexpr int v = sizeof(T) == 2 ? 4 : 2; };
+// ring depth: stream elements in flight per wave, sized so that a block's rings stay under ~48 KB (3 blocks per CU by
+// LDS; with 96 KB rings the stride-2 backward ran one block per CU)
+template <typename T, int NS> struct RingDepth {
+  static constexpr int bytes = NS * (sizeof(T) == 2 ? 1 : 2) * 4096;   // one element of all 4 waves
+  static constexpr int v = 49152 / bytes >= 4 ? 4 : (49152 / bytes >= 2 ? 49152 / bytes : 2);
+};
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
@@ -131,8 +135,8 @@ template <typename T, int ST>
 __global__ __launch_bounds__(256, 2) void dwr_fwd_kernel(const spb_dw_args_t a, const Geo g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NP = ST == 1 ? 14 : 15;
-  constexpr int RD = RingDepth<T>::v;
   constexpr int NS = ST == 1 ? 1 : 4;                     // vectors per stream element
+  constexpr int RD = RingDepth<T, NS>::v;
   constexpr int SLOT = NS * (sizeof(T) == 2 ? 1 : 2) * 1024;
   float* cfs = reinterpret_cast<float*>(smem);            // [4][CFN]
   char* rings = smem + 4 * CFN * sizeof(float);           // [4 waves][RD][SLOT]
@@ -286,10 +290,10 @@ template <typename T, int ST, bool WG, bool EPI>
 __global__ __launch_bounds__(256, 2) void dwr_bwd_kernel(const spb_dw_args_t a, const Geo g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NP = ST == 1 ? 14 : 15;
-  constexpr int RD = RingDepth<T>::v;
   constexpr int LH = ST == 1 ? 1 : 0;                    // stride 2 only needs the right neighbour
   constexpr bool IN = WG || EPI;                         // the conv-input tensor is read
   constexpr int NS = 2 + (IN ? (ST == 1 ? 1 : 4) : 0);
+  constexpr int RD = RingDepth<T, NS>::v;
   constexpr int SLOT = NS * (sizeof(T) == 2 ? 1 : 2) * 1024;
   float* cfs = reinterpret_cast<float*>(smem);
   char* rings = smem + 4 * CFN * sizeof(float);
@@ -549,6 +553,11 @@ Geo make_geo(int B, int C, int lane_rows, int lane_cols, int NP, int halo, int t
   return g;
 }
 
+int ring_depth_host(int ns, int es) {   // == RingDepth<T, NS>::v
+  const int bytes = ns * es * 4096;
+  return 49152 / bytes >= 4 ? 4 : (49152 / bytes >= 2 ? 49152 / bytes : 2);
+}
+
 template <typename K>
 void allow_lds(K kernel, size_t bytes) {
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
@@ -566,7 +575,7 @@ int spb_dwr_fwd(int dtype, const spb_dw_args_t* a, hipStream_t s) {
   const int nquads = ((a->C >> 3) + 3) / 4;
   const dim3 grid((unsigned)(nquads * g.nb));
   const int es = dtype == SPB_BF16 ? 1 : 2;
-  const int rd = dtype == SPB_BF16 ? RingDepth<bf16_t>::v : RingDepth<float>::v;
+  const int rd = ring_depth_host(st == 1 ? 1 : 4, es);
   size_t lds = 4 * CFN * sizeof(float) + (size_t)4 * rd * (st == 1 ? 1 : 4) * es * 1024;
   const size_t red = (size_t)16 * 16 * sizeof(float) + 4 * CFN * sizeof(float);
   if (lds < red) lds = red;
@@ -591,7 +600,7 @@ int spb_dwr_bwd(int dtype, const spb_dw_args_t* a, hipStream_t s) {
   const bool wg = a->dW != nullptr, epi = a->epi_mode == 2;
   const int es = dtype == SPB_BF16 ? 1 : 2;
   const int ns = 2 + ((wg || epi) ? (st == 1 ? 1 : 4) : 0);
-  const int rd = dtype == SPB_BF16 ? RingDepth<bf16_t>::v : RingDepth<float>::v;
+  const int rd = ring_depth_host(ns, es);
   size_t lds = 4 * CFN * sizeof(float) + (size_t)4 * rd * ns * es * 1024;
   const size_t red = (size_t)16 * 72 * sizeof(float) + 4 * CFN * sizeof(float);   // reduction scratch reuses the rings
   if (lds < red) lds = red;

@@ -125,10 +125,10 @@ struct spb_krn_ctx {
 
 enum ProfCat { PC_STEM_FWD = 0, PC_PW_FWD, PC_DW_FWD, PC_BN_APPLY, PC_HEAD_FWD, PC_BN_UPDATE, PC_HEAD_BWD, PC_PW_DGRAD,
                PC_PW_WGRAD, PC_DW_DGRAD, PC_DW_WGRAD, PC_BN_BWD_PREP, PC_STEM_WGRAD, PC_BN_PARAM_GRADS, PC_DOMAIN,
-               PC_WEIGHT_PREP, PC_COUNT };
+               PC_WEIGHT_PREP, PC_PW_BWD_FUSED, PC_COUNT };
 static const char* kProfNames[PC_COUNT] = {"stem_fwd", "pw_gemm_fwd", "dw_fwd", "bn_apply", "head_fwd", "bn_running_update",
                                            "head_bwd", "pw_gemm_dgrad", "pw_wgrad", "dw_dgrad", "dw_wgrad", "bn_bwd_prep",
-                                           "stem_wgrad", "bn_param_grads", "domain_head", "weight_prep"};
+                                           "stem_wgrad", "bn_param_grads", "domain_head", "weight_prep", "pw_bwd_fused"};
 
 namespace {
 
@@ -213,6 +213,7 @@ void build_model(spb_krn* m, int nK, bool dann) {
 struct Src { const void* ptr; spb_bnref_t ref; };
 
 static int g_side_wgrad = 1;
+static int g_fused_pw_bwd = 1;
 struct Runner {
   spb_krn_ctx* c; spb_krn* m; hipStream_t st; int dt; int err = 0;
   Runner(spb_krn_ctx* c_, hipStream_t s) : c(c_), m(c_->m), st(s), dt(c_->m->dtype) {}
@@ -282,6 +283,21 @@ struct Runner {
   }
   // ---- backward pieces.  `atgt` is the Act whose g / bsums the input gradient lands in (-1: plain output to `plain`)
   void pw_bwd(const PWDef& L, const Src& in, int aout, int atgt, void* plain, const void* res, float plain_scale = 1.f) {
+    // wide, shallow layers (the 112x112 / 56x56 maps): one fused pass over g and z for both gradients
+    if (g_fused_pw_bwd && dt == SPB_BF16 && atgt >= 0 && M(aout) >= 32768) {
+      spb_pwbwd_args_t f; std::memset(&f, 0, sizeof(f));
+      f.G = this->g(aout); f.Zn = z(aout); f.Wt = wc(L.wct_off); f.X = in.ptr; f.Zout = z(atgt); f.res = res;
+      f.Y = this->g(atgt); f.dW = m->G + L.w_off; f.osums = bsums(atgt); f.pro_dz = ref(aout, true); f.pro_a = in.ref;
+      f.epi = ref(atgt, true); f.M = M(aout); f.K = L.K; f.N = L.N; f.oR = c->R[atgt];
+      const double mn = (double)f.M * L.N, mk = (double)f.M * L.K;
+      tic(PC_PW_BWD_FUSED, (2 * mn + (2 + (f.X != f.Zout ? 1 : 0) + (res ? 1 : 0)) * mk + (double)L.K * L.N) * es() + 4.0 * L.K * L.N,
+          4.0 * f.M * L.K * L.N);
+      const int e = spb_pwconv_bwd_fused(dt, &f, st);
+      toc();
+      if (e == 0) return;
+      if (e != SPB_E_UNSUPPORTED) { ok(e); return; }
+      if (c->prof_on) c->prof_n--;   // no fused instance for this shape: drop the empty timing record
+    }
     // weight gradient first: on the side stream it then runs beside this layer's input-gradient GEMM
     spb_wgrad_args_t w; std::memset(&w, 0, sizeof(w));
     w.G = this->g(aout); w.Zn = z(aout); w.X = in.ptr; w.dW = m->G + L.w_off; w.pro_dz = ref(aout, true);
@@ -566,6 +582,7 @@ extern "C" int spb_krn_ctx_create(spb_krn_t* m, int batch, void* workspace, spb_
 }
 extern "C" void spb_krn_ctx_destroy(spb_krn_ctx_t* c) { delete c; }
 extern "C" int spb_debug_set_side_wgrad(int on) { g_side_wgrad = on; return 0; }
+extern "C" int spb_debug_set_fused_pw_bwd(int on) { g_fused_pw_bwd = on; return 0; }
 extern "C" int spb_krn_ctx_set_side_stream(spb_krn_ctx_t* c, int on) {
   if (!c) return SPB_E_ARG;
   c->side_on = on != 0;

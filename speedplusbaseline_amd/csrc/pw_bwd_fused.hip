@@ -1,0 +1,359 @@
+// Fused backward of a pointwise (1x1) convolution for the wide-and-shallow layers at the top of MobileNetV2
+// (112x112 and 56x56 maps: M = B*H*W is 150k..600k rows, N*K is a few thousand weights).
+// Replaces, for those layers, the pair spb_pwconv_gemm(pro 2, epi 2) + spb_pwconv_wgrad -- i.e. the autograd backward
+// of nn.Conv2d(k=1) + BatchNorm2d + ReLU6 in torchvision's InvertedResidual (reference call site park2019.py:107-108).
+//
+//   dz[m,n]  = g[m,n]*p0[n] + z[m,n]*p1[n] + p2[n]                 (BN backward of the conv output, rebuilt on the fly)
+//   gin[m,k] = round((sum_n dz[m,n] W[n,k] + res[m,k]) * act'(u_in[m,k]))    + its BN-backward sums over m
+//   dW[n,k] += sum_m dz[m,n] * a[m,k]                               (a = the conv input, act(bn(x)) or materialised)
+//
+// The two GEMMs share their big operand: g and z ([M,N], the dominant bytes) are read from HBM once instead of twice,
+// and everything else a row needs travels with it.  One wave owns 32-row chunks end to end, nothing is exchanged
+// between waves until the final reduction:
+//   * an LDS-DMA double buffer (global_load_lds_dwordx4) holds the raw rows of the next chunk: g, z, the input-side z,
+//     the conv input and the residual gradient; no VGPRs are spent on loads in flight;
+//   * W^T fragments stay in registers for the whole kernel;
+//   * input gradient as (gin)^T = W^T * dz^T: the MFMA B operand is then a plain 16-byte row read of dz, and the result
+//     leaves the matrix core as 4 consecutive k per lane -- row-major, no transpose through LDS;
+//   * weight gradient needs both operands with the reduction axis (m) fastest: dz and a are parked row-major in
+//     wave-private LDS tiles and read back with the gfx950 transpose load (ds_read_b64_tr_b16);
+//   * wide K (144) is split over blockIdx.y so that accumulators fit; g,z are then read once per split.
+// bf16 only (the f32 parity mode keeps the two-kernel path).
+#include "common.h"
+
+namespace {
+
+constexpr int CH = 32;  // rows per chunk
+
+// dz tile: when N is a multiple of 16 the transformed dz overwrites the raw g rows it came from (same lane, same
+// 16 bytes; leading dimension N); otherwise (N = 24) the 16-column blocks overrun a row and a padded tile is used.
+struct PwbLay { int gB, kB, stage, oZ, oZo, oX, oR, oDzt, oAt, ldz, wave_bytes; };
+__host__ __device__ inline PwbLay pwb_lay(int N, int KW, int NPAD, int KPAD, bool hasx, bool hasr) {
+  PwbLay L;
+  const bool inplace = (N & 15) == 0;
+  L.gB = (CH * N * 2 + 1023) & ~1023;     // raw g (and z) rows of a chunk, whole 1 KB DMA instructions
+  L.kB = (CH * KW * 2 + 1023) & ~1023;    // one K-side tile
+  L.oZ = L.gB; L.oZo = 2 * L.gB; L.oX = L.oZo + L.kB; L.oR = L.oX + (hasx ? L.kB : 0);
+  L.stage = L.oR + (hasr ? L.kB : 0);
+  L.oDzt = inplace ? -1 : 2 * L.stage;
+  L.ldz = inplace ? N : NPAD;
+  L.oAt = 2 * L.stage + (inplace ? 0 : CH * NPAD * 2);
+  L.wave_bytes = (L.oAt + CH * KPAD * 2 + 1023) & ~1023;
+  return L;
+}
+
+__device__ __forceinline__ void unpack4(uint2 r, float v[4]) {
+  v[0] = __uint_as_float(r.x << 16); v[1] = __uint_as_float(r.x & 0xffff0000u);
+  v[2] = __uint_as_float(r.y << 16); v[3] = __uint_as_float(r.y & 0xffff0000u);
+}
+
+// transpose-load fragment: 32 rows x 16 columns (c0..c0+15) of a row-major bf16 LDS tile with leading dimension LD
+// -> lane (li, lq) gets column c0+li, rows lq*8 .. lq*8+7  (same addressing as pw_wgrad_kernel in gemm_pw.hip)
+__device__ __forceinline__ bf16x8_t tr_frag(const bf16_t* tile, int LD, int c0, int li, int lq) {
+  typedef s16x4_t __attribute__((address_space(3))) * lds_v4;
+  const bf16_t* p = tile + (lq * 8 + (li >> 2)) * LD + c0 + (li & 3) * 4;
+  union { struct { s16x4_t lo, hi; } s; bf16x8_t v; } u;
+  u.s.lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(p));
+  u.s.hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(p + 4 * LD));
+  return u.v;
+}
+
+template <int NB, int KB>
+__global__ __launch_bounds__(256, 1) void pwb_kernel(const spb_pwbwd_args_t g, long long nchunks) {
+  constexpr int NS = (NB + 1) / 2;               // 32-wide reduction steps of the input-gradient GEMM
+  constexpr int NP = NS * 32, NPAD = NP + 8;
+  constexpr int KW = KB * 16, KPAD = KW + 8;
+  constexpr int GPR = KW / 8;                    // 16-byte granules per K-side tile row
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int M = g.M, N = g.N, K = g.K;
+  const int lane = threadIdx.x & 63, li = lane & 15, lq = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int nw = (int)(blockDim.x >> 6), nthr = (int)blockDim.x;   // 2..4 waves per block, whatever fits the LDS
+  const int k0 = blockIdx.y * KW;                // first input channel of this split
+  const bool hasx = g.X != g.Zout, hasr = g.res != nullptr;
+  const PwbLay L = pwb_lay(N, KW, NPAD, KPAD, hasx, hasr);
+  float* pdz = reinterpret_cast<float*>(smem);   // [3][NP]  p0, p1, p2 of the conv output's BN backward
+  float* pep = pdz + 3 * NP;                     // [4][KW]  scale, shift, mean, invstd of the input-side BN
+  float* pa = pep + 4 * KW;                      // [2][KW]  scale, shift that turn X into the conv input
+  char* wreg = reinterpret_cast<char*>(pa + 2 * KW) + (size_t)wave * L.wave_bytes;
+  for (int i = threadIdx.x; i < NP; i += nthr) {
+    float p0 = 0.f, p1 = 0.f, p2 = 0.f;
+    if (i < N) bn_bwd_coef(g.pro_dz, i, p0, p1, p2);
+    pdz[i] = p0; pdz[NP + i] = p1; pdz[2 * NP + i] = p2;
+  }
+  for (int i = threadIdx.x; i < KW; i += nthr) {
+    const int k = k0 + i;
+    float sc = 1.f, sh = 0.f, mu = 0.f, is = 0.f, asc = 0.f, ash = 0.f;
+    if (k < K) {
+      if (g.epi.gamma != nullptr) {
+        bn_moments(g.epi, k, mu, is);
+        sc = g.epi.gamma[k] * is; sh = g.epi.beta[k] - mu * sc;
+      }
+      bn_fwd_coef(g.pro_a, k, asc, ash);
+    }
+    pep[i] = sc; pep[KW + i] = sh; pep[2 * KW + i] = mu; pep[3 * KW + i] = is;
+    pa[i] = asc; pa[KW + i] = ash;
+  }
+  // W^T fragments (A operand of the input-gradient MFMA): lane (li, lq) = row k0+kb*16+li, columns ns*32+lq*8..+7
+  const bf16_t* Wt = reinterpret_cast<const bf16_t*>(g.Wt);
+  bf16x8_t Wf[KB][NS];
+#pragma unroll
+  for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+    for (int ns = 0; ns < NS; ++ns) {
+      const int k = k0 + kb * 16 + li, n = ns * 32 + lq * 8;
+      uint4 u = make_uint4(0, 0, 0, 0);
+      if (k < K && n < N) u = *reinterpret_cast<const uint4*>(Wt + (size_t)k * N + n);
+      Wf[kb][ns] = __builtin_bit_cast(bf16x8_t, u);
+    }
+  __syncthreads();
+
+  const char* Gp = reinterpret_cast<const char*>(g.G);
+  const char* Zp = reinterpret_cast<const char*>(g.Zn);
+  const char* Zop = reinterpret_cast<const char*>(g.Zout);
+  const char* Xp = reinterpret_cast<const char*>(g.X);
+  const char* Rp = reinterpret_cast<const char*>(g.res);
+  bf16_t* Y = reinterpret_cast<bf16_t*>(g.Y);
+  const unsigned wlds = lds_addr(wreg);
+  const long long gtot = (long long)M * N * 2;
+  const int eact = g.epi.act, aact = g.pro_a.act;
+  const float eslope = g.epi.slope, aslope = g.pro_a.slope;
+
+  auto issue = [&](long long c, int s) {
+    const unsigned sb = wlds + (unsigned)(s * L.stage);
+    const long long m0 = c * CH;
+    for (int i = 0; i < (L.gB >> 10); ++i) {
+      long long off = m0 * N * 2 + (long long)(i * 64 + lane) * 16;
+      off = off > gtot - 16 ? gtot - 16 : off;       // past the tensor: any valid address, the rows are masked
+      dma16(Gp + off, sb + (unsigned)(i << 10));
+      dma16(Zp + off, sb + (unsigned)(L.oZ + (i << 10)));
+    }
+    for (int i = 0; i < (L.kB >> 10); ++i) {
+      const int q = i * 64 + lane;
+      long long m = m0 + q / GPR;
+      m = m > M - 1 ? M - 1 : m;
+      int k = k0 + (q % GPR) * 8;
+      k = k > K - 8 ? K - 8 : k;
+      const long long off = (m * K + k) * 2;
+      dma16(Zop + off, sb + (unsigned)(L.oZo + (i << 10)));
+      if (hasx) dma16(Xp + off, sb + (unsigned)(L.oX + (i << 10)));
+      if (hasr) dma16(Rp + off, sb + (unsigned)(L.oR + (i << 10)));
+    }
+  };
+
+  f32x4_t dw[NB][KB];
+#pragma unroll
+  for (int a = 0; a < NB; ++a)
+#pragma unroll
+    for (int b = 0; b < KB; ++b) dw[a][b] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  float s1[KB][4], s2[KB][4];
+#pragma unroll
+  for (int b = 0; b < KB; ++b)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { s1[b][i] = 0.f; s2[b][i] = 0.f; }
+
+  bf16_t* at = reinterpret_cast<bf16_t*>(wreg + L.oAt);
+  const int LDZ = L.ldz;
+  const long long cstride = (long long)gridDim.x * nw;
+  long long c = (long long)blockIdx.x * nw + wave;
+  if (c < nchunks) issue(c, 0);
+  int s = 0;
+  for (; c < nchunks; c += cstride, s ^= 1) {
+    wait_vmcnt<0>();                                   // stage s has landed; nothing else of this wave is in flight
+    if (c + cstride < nchunks) issue(c + cstride, s ^ 1);  // the other stage was consumed in the previous pass
+    char* st = wreg + s * L.stage;
+    bf16_t* dzt = reinterpret_cast<bf16_t*>(L.oDzt < 0 ? st : wreg + L.oDzt);
+    const long long m0 = c * CH;
+    // ---- dz: MFMA B fragments (row m = h*16+li, 8 consecutive n) and the row-major copy for the transpose loads
+    bf16x8_t bz[2][NS];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int ns = 0; ns < NS; ++ns) {
+        const int row = h * 16 + li, n = ns * 32 + lq * 8;
+        const bool ok = n < N && m0 + row < M;
+        const int nc = n < N ? n : N - 8;
+        float gf[8], zf[8], p0[8], p1[8], p2[8], v[8];
+        Raw8<bf16_t> gr, zr;
+        gr.u = *reinterpret_cast<const uint4*>(st + (row * N + nc) * 2);
+        zr.u = *reinterpret_cast<const uint4*>(st + L.oZ + (row * N + nc) * 2);
+        cvt8(gr, gf); cvt8(zr, zf);
+#pragma unroll
+        for (int j = 0; j < 8; j += 4) {
+          *reinterpret_cast<float4*>(p0 + j) = *reinterpret_cast<const float4*>(pdz + n + j);
+          *reinterpret_cast<float4*>(p1 + j) = *reinterpret_cast<const float4*>(pdz + NP + n + j);
+          *reinterpret_cast<float4*>(p2 + j) = *reinterpret_cast<const float4*>(pdz + 2 * NP + n + j);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = ok ? gf[j] * p0[j] + zf[j] * p1[j] + p2[j] : 0.f;
+        uint4 u;
+        u.x = pack_bf16x2(v[0], v[1]); u.y = pack_bf16x2(v[2], v[3]);
+        u.z = pack_bf16x2(v[4], v[5]); u.w = pack_bf16x2(v[6], v[7]);
+        bz[h][ns] = __builtin_bit_cast(bf16x8_t, u);
+        if (L.oDzt >= 0 || n < N) *reinterpret_cast<uint4*>(dzt + row * LDZ + n) = u;
+      }
+    // ---- input gradient, one 16-row half at a time
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      f32x4_t acc[KB];
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb) {
+        acc[kb] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ns = 0; ns < NS; ++ns) acc[kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Wf[kb][ns], bz[h][ns], acc[kb], 0, 0, 0);
+      }
+      const int row = h * 16 + li;
+      const long long m = m0 + row;
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb) {
+        const int kl = kb * 16 + lq * 4, k = k0 + kl;
+        const bool ok = m < M && k < K;
+        float zf[4], xf[4], sc[4], sh[4], asc[4], ash[4], v[4], a[4];
+        const uint2 zraw = *reinterpret_cast<const uint2*>(st + L.oZo + (row * KW + kl) * 2);
+        unpack4(zraw, zf);
+        if (hasx) unpack4(*reinterpret_cast<const uint2*>(st + L.oX + (row * KW + kl) * 2), xf);
+        else {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) xf[i] = zf[i];
+        }
+        *reinterpret_cast<float4*>(sc) = *reinterpret_cast<const float4*>(pep + kl);
+        *reinterpret_cast<float4*>(sh) = *reinterpret_cast<const float4*>(pep + KW + kl);
+        *reinterpret_cast<float4*>(asc) = *reinterpret_cast<const float4*>(pa + kl);
+        *reinterpret_cast<float4*>(ash) = *reinterpret_cast<const float4*>(pa + KW + kl);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          a[i] = ok ? act_fwd(xf[i] * asc[i] + ash[i], aact, aslope) : 0.f;
+          v[i] = acc[kb][i];
+        }
+        uint2 ap;
+        ap.x = pack_bf16x2(a[0], a[1]); ap.y = pack_bf16x2(a[2], a[3]);
+        *reinterpret_cast<uint2*>(at + row * KPAD + kl) = ap;
+        if (hasr) {
+          float rf[4];
+          unpack4(*reinterpret_cast<const uint2*>(st + L.oR + (row * KW + kl) * 2), rf);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) v[i] += rf[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] *= act_grad(zf[i] * sc[i] + sh[i], eact, eslope);
+        uint2 o;
+        o.x = pack_bf16x2(v[0], v[1]); o.y = pack_bf16x2(v[2], v[3]);
+        unpack4(o, v);                                     // the rounded values are what the sums must see
+        if (ok) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) { s1[kb][i] += v[i]; s2[kb][i] += v[i] * zf[i]; }
+          *reinterpret_cast<uint2*>(Y + (size_t)m * K + k) = o;
+        }
+      }
+    }
+    // ---- weight gradient: dW[n,k] += sum over the 32 rows
+    bf16x8_t bf[KB];
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) bf[kb] = tr_frag(at, KPAD, kb * 16, li, lq);
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+      const bf16x8_t af = tr_frag(dzt, LDZ, nb * 16, li, lq);
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb) dw[nb][kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bf[kb], dw[nb][kb], 0, 0, 0);
+    }
+  }
+  wait_vmcnt<0>();
+
+  // ---- reductions over the block: weight gradient (C layout: column k = li, rows n = lq*4+i) and the BN sums
+  __syncthreads();
+  float* red = reinterpret_cast<float*>(pa + 2 * KW);          // the wave regions are idle now
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) red[((wave * NB + nb) * KB + kb) * 256 + (lq * 4 + i) * 16 + li] = dw[nb][kb][i];
+  __syncthreads();
+  for (int e = threadIdx.x; e < NB * KB * 256; e += nthr) {
+    const int blk = e >> 8, r = (e >> 4) & 15, cidx = e & 15;
+    const int nb = blk / KB, kb = blk % KB;
+    const int n = nb * 16 + r, k = k0 + kb * 16 + cidx;
+    if (n < N && k < K) {
+      float v = 0.f;
+      for (int w = 0; w < nw; ++w) v += red[w * NB * KB * 256 + e];
+      atomicAdd(g.dW + (size_t)n * K + k, v);
+    }
+  }
+  __syncthreads();
+  // BN-backward sums of gin: lanes of a 16-lane row hold different m for the same 4 k -> butterfly, then waves in LDS
+#pragma unroll
+  for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float a = s1[kb][i], b = s2[kb][i];
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) { a += __shfl_xor(a, o, 16); b += __shfl_xor(b, o, 16); }
+      if (li == 0) {
+        red[(wave * 2 + 0) * KW + kb * 16 + lq * 4 + i] = a;
+        red[(wave * 2 + 1) * KW + kb * 16 + lq * 4 + i] = b;
+      }
+    }
+  __syncthreads();
+  for (int e = threadIdx.x; e < KW; e += nthr) {
+    const int k = k0 + e;
+    if (k < K) {
+      float a = 0.f, b = 0.f;
+      for (int w = 0; w < nw; ++w) { a += red[(w * 2 + 0) * KW + e]; b += red[(w * 2 + 1) * KW + e]; }
+      const float mu = pep[2 * KW + e], is = pep[3 * KW + e];
+      float* dst = g.osums + (size_t)(blockIdx.x % g.oR) * 2 * K;
+      atomicAdd(dst + k, a);
+      atomicAdd(dst + K + k, is * (b - mu * a));   // sum g*xhat from sum g*z (see dwconv_rows.hip)
+    }
+  }
+}
+
+template <int NB, int KB>
+int pwb_launch(const spb_pwbwd_args_t& g, hipStream_t stream) {
+  constexpr int NS = (NB + 1) / 2, NP = NS * 32, NPAD = NP + 8, KW = KB * 16, KPAD = KW + 8;
+  const bool hasx = g.X != g.Zout, hasr = g.res != nullptr;
+  const PwbLay L = pwb_lay(g.N, KW, NPAD, KPAD, hasx, hasr);
+  const size_t tables = (size_t)(3 * NP + 6 * KW) * sizeof(float);
+  int nw = 4;
+  size_t lds = 0;
+  for (; nw >= 2; --nw) {
+    lds = tables + (size_t)nw * L.wave_bytes;
+    const size_t red = tables + (size_t)nw * NB * KB * 256 * sizeof(float);
+    if (red > lds) lds = red;
+    if (lds <= 160 * 1024) break;
+  }
+  if (nw < 2) return SPB_E_UNSUPPORTED;
+  static bool once = false;
+  if (!once) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pwb_kernel<NB, KB>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    once = true;
+  }
+  const long long nchunks = ((long long)g.M + CH - 1) / CH;
+  const int per_cu = (int)((160 * 1024) / lds) < 1 ? 1 : (int)((160 * 1024) / lds);
+  long long blocks = (nchunks + nw - 1) / nw;
+  const long long cap = 256LL * (per_cu > 2 ? 2 : per_cu);
+  if (blocks > cap) blocks = cap;
+  const int nsplit = (g.K + KW - 1) / KW;
+  hipLaunchKernelGGL((pwb_kernel<NB, KB>), dim3((unsigned)blocks, (unsigned)nsplit), dim3(64 * nw), lds, stream, g, nchunks);
+  return 0;
+}
+
+}  // namespace
+
+// 0 on launch, SPB_E_UNSUPPORTED when this shape / dtype has no fused instance (the caller then uses
+// spb_pwconv_gemm + spb_pwconv_wgrad)
+extern "C" int spb_pwconv_bwd_fused(int dtype, const spb_pwbwd_args_t* a, spb_stream_t stream) {
+  if (!a || !a->G || !a->Zn || !a->Wt || !a->X || !a->Zout || !a->Y || !a->dW || !a->osums) return SPB_E_ARG;
+  if (a->M <= 0 || a->K <= 0 || a->N <= 0 || (a->K & 7) || (a->N & 7) || a->oR < 1) return SPB_E_SHAPE;
+  if (dtype != SPB_BF16) return SPB_E_UNSUPPORTED;
+  const int NB = (a->N + 15) / 16, KBt = (a->K + 15) / 16;
+  hipStream_t s = (hipStream_t)stream;
+  int e = SPB_E_UNSUPPORTED;
+  if (NB == 1 && KBt <= 2) e = pwb_launch<1, 2>(*a, s);           // 32 -> 16 @112
+  else if (NB <= 6 && NB > 2 && KBt == 1) e = pwb_launch<6, 1>(*a, s);  // 16 -> 96 @112
+  else if (NB <= 2 && KBt <= 6 && KBt > 2) e = pwb_launch<2, 6>(*a, s); // 96 -> 24 @56
+  else if (NB <= 9 && NB > 6 && KBt <= 2) e = pwb_launch<9, 2>(*a, s);  // 24 -> 144 @56
+  else if (NB <= 2 && KBt <= 10 && KBt > 6) e = pwb_launch<2, 5>(*a, s); // 144 -> 24 @56, 144 -> 32 @28 (two K splits)
+  if (e != 0) return e;
+  SPB_CHECK_LAUNCH();
+  return 0;
+}

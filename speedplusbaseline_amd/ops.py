@@ -63,6 +63,21 @@ def pwconv_wgrad(G, X, dW, pro_dz, pro_a, Zn=None):
     L.check(L.lib().spb_pwconv_wgrad(dtype_code(G), C.byref(w), _stream()), "spb_pwconv_wgrad")
 
 
+def pwconv_bwd_fused(G, Zn, Wt, X, Zout, Y, dW, osums, pro_dz, pro_a, epi, res=None, oR=1):
+    """Fused input-gradient + weight-gradient of a pointwise conv.  Returns False when the library has no fused instance
+    for this (dtype, N, K) -- the caller then uses pwconv_gemm + pwconv_wgrad."""
+    _need_cuda(G, Zn, Wt, X, Zout, Y, dW, osums, res)
+    a = L.PwBwdArgs()
+    a.G = _ptr(G); a.Zn = _ptr(Zn); a.Wt = _ptr(Wt); a.X = _ptr(X); a.Zout = _ptr(Zout); a.res = _ptr(res); a.Y = _ptr(Y)
+    a.dW = _ptr(dW); a.osums = _ptr(osums); a.pro_dz = pro_dz; a.pro_a = pro_a; a.epi = epi
+    a.M = G.shape[0]; a.N = G.shape[1]; a.K = X.shape[1]; a.oR = oR
+    code = L.lib().spb_pwconv_bwd_fused(dtype_code(G), C.byref(a), _stream())
+    if code == -4:  # SPB_E_UNSUPPORTED
+        return False
+    L.check(code, "spb_pwconv_bwd_fused")
+    return True
+
+
 def _dwargs(X, Wd, B, H, W_, C_, stride, **kw):
     d = L.DwArgs()
     d.X = _ptr(X); d.Wd = _ptr(Wd); d.B = B; d.H = H; d.W = W_; d.C = C_; d.stride = stride

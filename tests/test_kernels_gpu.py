@@ -186,6 +186,50 @@ def test_pw_gemm_bwd(device, gemm_variant, dt, M, K, N, act1, act2):
     assert relerr(P, -0.5 * (dz @ c["W"].detach())) < tol
 
 
+@pytest.mark.parametrize("M,K,N,act1,act2,with_res,mat", [
+    (1000, 32, 16, L.ACT_RELU6, L.ACT_NONE, False, False),   # 32 -> 16 project @112
+    (777, 16, 96, L.ACT_NONE, L.ACT_RELU6, True, True),      # 16 -> 96 expand, materialised input, skip gradient
+    (500, 96, 24, L.ACT_RELU6, L.ACT_NONE, False, False),    # 96 -> 24
+    (1234, 24, 144, L.ACT_NONE, L.ACT_RELU6, True, False),   # 24 -> 144
+    (901, 144, 24, L.ACT_RELU6, L.ACT_NONE, False, False),   # 144 -> 24: two K splits
+    (4133, 144, 32, L.ACT_RELU6, L.ACT_NONE, False, False)])
+def test_pw_bwd_fused(device, M, K, N, act1, act2, with_res, mat):
+    """fused dgrad+wgrad (bf16 only) against the same float64 composite as the two-kernel path"""
+    dt = torch.bfloat16
+    c = _composite(M, K, N, act1, act2, dt, seed=M + K + N)
+    dev = device
+    g2 = rt(c["u2"].grad, dt)
+    bs = torch.stack([g2.sum(0), (g2 * c["xh2"].detach()).sum(0)]).float().unsqueeze(0).contiguous().to(dev)
+    pro = ops.bnref(N, sums=sums_of(c["z"], 1, dev), gamma=c["g2"].detach().float().to(dev), beta=c["b2"].detach().float().to(dev),
+                    bsums=bs, n=M, act=act2, slope=0.2)
+    epi = ops.bnref(K, sums=sums_of(c["zin"].detach(), 2, dev), gamma=c["g1"].float().to(dev), beta=c["b1"].float().to(dev),
+                    n=M, R=2, act=act1, slope=0.2)
+    Wt = c["W"].detach().t().contiguous().to(dt).to(dev)
+    zin = c["zin"].detach().to(dt).to(dev)
+    if mat:   # the conv input is a materialised tensor (bn + act already applied, as after a residual block)
+        X = rt(c["a"].detach(), dt).to(dt).to(dev); pro_a = ops.bnref(K)
+    else:
+        X = zin; pro_a = epi
+    res = rt(torch.randn(M, K, dtype=torch.float64) * 0.1, dt) if with_res else None
+    G1 = torch.empty(M, K, dtype=dt, device=dev)
+    dW = torch.zeros(N, K, dtype=torch.float32, device=dev)
+    osums = torch.zeros(2, 2, K, dtype=torch.float32, device=dev)
+    ran = ops.pwconv_bwd_fused(g2.to(dt).to(dev), c["z"].to(dt).to(dev), Wt, X, zin, G1, dW, osums, pro, pro_a, epi,
+                               res=None if res is None else res.to(dt).to(dev), oR=2)
+    assert ran, "no fused instance for this shape"
+    torch.cuda.synchronize()
+    u1 = c["u1"].detach()
+    if act1 == L.ACT_RELU6: m1 = ((u1 > 0) & (u1 < 6)).double()
+    else: m1 = torch.ones_like(u1)
+    exp = c["u1"].grad + (res * m1 if with_res else 0)
+    tol = TOL[dt] * 3
+    assert relerr(G1, exp) < tol
+    gs = G1.double().cpu()
+    s = osums.double().cpu().sum(0)
+    assert relerr(s[0], gs.sum(0)) < 1e-3 and relerr(s[1], (gs * c["xh1"].detach()).sum(0)) < 2e-3
+    assert relerr(dW, c["W"].grad) < tol * (4 if mat else 1)   # materialised a is itself rounded to bf16
+
+
 @pytest.mark.parametrize("dt", DTYPES)
 @pytest.mark.parametrize("B,H,C,stride,act", [(2, 14, 96, 1, L.ACT_RELU6), (3, 15, 32, 2, L.ACT_RELU6), (2, 7, 1280, 1, L.ACT_NONE),
                                               (2, 28, 144, 2, L.ACT_RELU)])
