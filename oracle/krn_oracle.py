@@ -121,8 +121,9 @@ def param_names(sd):
 class _Net:
     momentum = BN_MOM  # class-level knob: tests set 1.0 to make running stats equal the batch statistics
     # class-level knob: emulate the bf16 storage/operand rounding points of the HIP path (straight-through in backward):
-    #   every convolution output is stored as bf16; matrix-core operands (input and weight of 1x1 convs, head, domain
-    #   conv) are rounded to bf16; depthwise/stem arithmetic stays f32; materialised tensors (skip outputs, concat) bf16.
+    #   every convolution output is stored as bf16; matrix-core operands (input and weight of the stem, the 1x1 convs,
+    #   the head and the domain conv) are rounded to bf16; depthwise arithmetic stays f32; materialised tensors (skip
+    #   outputs, concat) bf16.
     quant = False
 
     def __init__(self, sd, training, prefix=""):
@@ -137,7 +138,7 @@ class _Net:
     def conv(self, x, name, stride=1, padding=0, groups=1):
         w = self.sd[self.p + name + ".weight"]
         b = self.sd.get(self.p + name + ".bias")
-        if groups == 1 and w.shape[1] > 3:  # matrix-core layers: operands rounded
+        if groups == 1:  # matrix-core layers (stem, pointwise, head, domain conv): operands rounded
             x, w = self.q(x), self.q(w)
         z = F.conv2d(x, w, None, stride, padding, 1, groups)
         if b is not None:  # head / domain conv: f32 bias after the (rounded, for the domain conv) product

@@ -247,6 +247,7 @@ __global__ __launch_bounds__(256, 1) void pwb_kernel(const spb_pwbwd_args_t g, l
       }
     }
     // ---- weight gradient: dW[n,k] += sum over the 32 rows
+    asm volatile("" ::: "memory");   // the dz / a tile stores above stay ahead of the transpose loads
     bf16x8_t bf[KB];
 #pragma unroll
     for (int kb = 0; kb < KB; ++kb) bf[kb] = tr_frag(at, KPAD, kb * 16, li, lq);

@@ -385,6 +385,12 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const spb_head_bwd_args_t
 
 }  // namespace
 
+int spb_stem_fwd_mfma(const float* x, const float* w, void* y, float* osums, int oR, int B, int H, int W, hipStream_t s);
+int spb_stem_wgrad_mfma(const float* x, const void* G, const void* Z, const spb_bnref_t* pro, float* dW, int B, int H, int W,
+                        hipStream_t s);
+static int g_stem_mfma = 1;
+extern "C" int spb_debug_set_stem_mfma(int on) { g_stem_mfma = on; return 0; }
+
 extern "C" int spb_stem_fwd(int dtype, const float* x, const float* w, void* y, float* osums, int oR, int B, int H,
                             int W, spb_stream_t stream) {
   if (!x || !w || !y || B <= 0 || H <= 0 || W <= 0) return SPB_E_ARG;
@@ -392,6 +398,11 @@ extern "C" int spb_stem_fwd(int dtype, const float* x, const float* w, void* y, 
   long long P = (long long)B * OH * OW;
   int grid = (int)((P + 64 * 8 - 1) / (64 * 8));
   if (grid > 2048) grid = 2048;
+  if (dtype == SPB_BF16 && g_stem_mfma) {   // implicit GEMM on the matrix cores (stem_mfma.hip)
+    spb_stem_fwd_mfma(x, w, y, osums, oR, B, H, W, (hipStream_t)stream);
+    SPB_CHECK_LAUNCH();
+    return 0;
+  }
   if (dtype == SPB_BF16)
     hipLaunchKernelGGL(stem_fwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, w, (bf16_t*)y, osums, oR, B, H, W);
   else if (dtype == SPB_F32)
@@ -409,6 +420,11 @@ extern "C" int spb_stem_wgrad(int dtype, const float* x, const void* G, const vo
   int grid = (int)((P + 16 * 32 - 1) / (16 * 32));
   if (grid > 1024) grid = 1024;
   if (grid < 1) grid = 1;
+  if (dtype == SPB_BF16 && g_stem_mfma && (OW & 7) == 0) {
+    spb_stem_wgrad_mfma(x, G, Z, pro, dW, B, H, W, (hipStream_t)stream);
+    SPB_CHECK_LAUNCH();
+    return 0;
+  }
   if (dtype == SPB_BF16)
     hipLaunchKernelGGL(stem_wgrad_kernel<bf16_t>, dim3(grid), dim3(192), 0, (hipStream_t)stream, x, (const bf16_t*)G, (const bf16_t*)Z, *pro, dW, B, H, W);
   else if (dtype == SPB_F32)

@@ -1,0 +1,258 @@
+// MobileNetV2 stem (Conv2d(3,32,3,stride 2,pad 1), features[0][0]; reference call site park2019.py:107-108) as an
+// implicit GEMM on the matrix cores, bf16 mode.  The scalar kernels in stem_head.hip spend 50 VALU instructions per
+// output value (216 FMAs + 54 LDS weight reads per pixel and 8 channels) and had become the largest single launches of
+// the step (stem_wgrad 276 us, stem_fwd 121 us at B=48); as a [pixels x 27] x [27 x 32] product the stem is 2 MFMAs per
+// 16 pixels and the kernels stream at HBM speed.
+//   forward        y^T[co, p]   = W[co, tap] * patch^T[tap, p]          (K = 27 taps padded to 32)
+//                  -> each lane ends up with 4 consecutive channels of one pixel: an 8-byte NHWC store, no transpose
+//   weight grad    dW[co, tap] += dz^T[co, p] * patch[p, tap]           (K = 32 pixels per step)
+//                  dz^T comes from a wave-private LDS tile via the transpose load, the patches are gathered from x
+// x is the fp32 NCHW image; it is rounded to bf16 on the fly (the reference's autocast does the same in fp16).
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+__device__ __forceinline__ bf16x8_t pack8(const float v[8]) {
+  uint4 u;
+  u.x = pack_bf16x2(v[0], v[1]); u.y = pack_bf16x2(v[2], v[3]);
+  u.z = pack_bf16x2(v[4], v[5]); u.w = pack_bf16x2(v[6], v[7]);
+  return __builtin_bit_cast(bf16x8_t, u);
+}
+
+__device__ __forceinline__ bf16x8_t tr_frag(const bf16_t* tile, int LD, int c0, int li, int lq) {
+  typedef s16x4_t __attribute__((address_space(3))) * lds_v4;
+  const bf16_t* p = tile + (lq * 8 + (li >> 2)) * LD + c0 + (li & 3) * 4;
+  union { struct { s16x4_t lo, hi; } s; bf16x8_t v; } u;
+  u.s.lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(p));
+  u.s.hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(p + 4 * LD));
+  return u.v;
+}
+
+// ------------------------------------------------------------------------------------------------------ forward
+__global__ __launch_bounds__(256) void stem_fwd_mfma_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                            bf16_t* __restrict__ y, float* osums, int oR, int B, int H, int W) {
+  __shared__ float red[4][2][32];
+  const int lane = threadIdx.x & 63, li = lane & 15, lq = lane >> 4, wave = threadIdx.x >> 6;
+  const int OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1;
+  const long long P = (long long)B * OH * OW;
+  const long long groups = (P + 15) / 16;
+  // A operand: W[co = cb*16+li][tap = lq*8+e], taps >= 27 are zero
+  bf16x8_t Wa[2];
+#pragma unroll
+  for (int cb = 0; cb < 2; ++cb) {
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int t = lq * 8 + e;
+      v[e] = t < 27 ? w[(cb * 16 + li) * 27 + t] : 0.f;
+    }
+    Wa[cb] = pack8(v);
+  }
+  // the 8 taps this lane gathers for its pixel: (ci, ky, kx) of tap lq*8+e
+  int tci[8], tky[8], tkx[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int t = lq * 8 + e, tt = t < 27 ? t : 26;
+    tci[e] = t < 27 ? tt / 9 : -1; tky[e] = (tt % 9) / 3; tkx[e] = tt % 3;
+  }
+  float s1[2][4], s2[2][4];
+#pragma unroll
+  for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { s1[cb][e] = 0.f; s2[cb][e] = 0.f; }
+
+  auto gather = [&](long long gi, float v[8]) {
+    long long p = gi * 16 + li;
+    p = p < P ? p : P - 1;
+    const int ow = (int)(p % OW), oh = (int)((p / OW) % OH), b = (int)(p / ((long long)OW * OH));
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int ih = 2 * oh - 1 + tky[e], iw = 2 * ow - 1 + tkx[e];
+      const bool ok = tci[e] >= 0 && ih >= 0 && ih < H && iw >= 0 && iw < W;
+      const float xv = x[((size_t)(b * 3 + (tci[e] < 0 ? 0 : tci[e])) * H + clampi(ih, 0, H - 1)) * W + clampi(iw, 0, W - 1)];
+      v[e] = ok ? xv : 0.f;
+    }
+  };
+
+  const long long gstride = (long long)gridDim.x * 4;
+  long long gi = (long long)blockIdx.x * 4 + wave;
+  float nxt[8];
+  if (gi < groups) gather(gi, nxt);
+  for (; gi < groups; gi += gstride) {
+    const bf16x8_t bf = pack8(nxt);
+    if (gi + gstride < groups) gather(gi + gstride, nxt);   // next group's loads fly during the MFMAs / stores
+    const long long p = gi * 16 + li;
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+      f32x4_t acc = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Wa[cb], bf, acc, 0, 0, 0);
+      // lane (li, lq): pixel p, channels cb*16 + lq*4 .. +3
+      uint2 o;
+      o.x = pack_bf16x2(acc[0], acc[1]); o.y = pack_bf16x2(acc[2], acc[3]);
+      if (p < P) {
+        *reinterpret_cast<uint2*>(y + (size_t)p * 32 + cb * 16 + lq * 4) = o;
+        const float r0 = __uint_as_float(o.x << 16), r1 = __uint_as_float(o.x & 0xffff0000u);
+        const float r2 = __uint_as_float(o.y << 16), r3 = __uint_as_float(o.y & 0xffff0000u);
+        s1[cb][0] += r0; s1[cb][1] += r1; s1[cb][2] += r2; s1[cb][3] += r3;
+        s2[cb][0] += r0 * r0; s2[cb][1] += r1 * r1; s2[cb][2] += r2 * r2; s2[cb][3] += r3 * r3;
+      }
+    }
+  }
+  if (osums) {
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float a = s1[cb][e], b2 = s2[cb][e];
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) { a += __shfl_xor(a, o, 16); b2 += __shfl_xor(b2, o, 16); }
+        if (li == 0) { red[wave][0][cb * 16 + lq * 4 + e] = a; red[wave][1][cb * 16 + lq * 4 + e] = b2; }
+      }
+    __syncthreads();
+    if (threadIdx.x < 64) {
+      const int which = threadIdx.x >> 5, c = threadIdx.x & 31;
+      const float v = red[0][which][c] + red[1][which][c] + red[2][which][c] + red[3][which][c];
+      atomicAdd(osums + (size_t)(blockIdx.x % oR) * 64 + which * 32 + c, v);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ weight gradient
+// requires OW % 8 == 0 (8 consecutive pixels of a lane lie in one output row)
+__global__ __launch_bounds__(256) void stem_wgrad_mfma_kernel(const float* __restrict__ x, const bf16_t* __restrict__ G,
+                                                              const bf16_t* __restrict__ Z, const spb_bnref_t pro, float* dW,
+                                                              int B, int H, int W) {
+  constexpr int LD = 40;
+  __shared__ __attribute__((aligned(16))) bf16_t dzt_all[4][32 * LD];
+  __shared__ __attribute__((aligned(16))) float cf[3][32];
+  __shared__ float red[4][32 * 32];
+  const int lane = threadIdx.x & 63, li = lane & 15, lq = lane >> 4, wave = threadIdx.x >> 6;
+  if (threadIdx.x < 32) {
+    float p0, p1, p2;
+    bn_bwd_coef(pro, threadIdx.x, p0, p1, p2);
+    cf[0][threadIdx.x] = p0; cf[1][threadIdx.x] = p1; cf[2][threadIdx.x] = p2;
+  }
+  __syncthreads();
+  bf16_t* dzt = dzt_all[wave];
+  const int OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1;
+  const long long P = (long long)B * OH * OW;
+  const long long groups = (P + 31) / 32;
+  // patch operand: lane column = tap tb*16+li, rows = pixels lq*8 .. lq*8+7
+  int tci[2], tky[2], tkx[2];
+#pragma unroll
+  for (int tb = 0; tb < 2; ++tb) {
+    const int t = tb * 16 + li, tt = t < 27 ? t : 26;
+    tci[tb] = t < 27 ? tt / 9 : -1; tky[tb] = (tt % 9) / 3; tkx[tb] = tt % 3;
+  }
+  const int px = lane >> 2, part = lane & 3;   // dz tile load: pixels px and px+16, channels part*8..+7
+  float c0[8], c1[8], c2[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { c0[j] = cf[0][part * 8 + j]; c1[j] = cf[1][part * 8 + j]; c2[j] = cf[2][part * 8 + j]; }
+
+  f32x4_t acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) acc[a][b] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+  Raw8<bf16_t> gr[2], zr[2];
+  float xr[2][8];
+  auto load = [&](long long gi) {
+    const long long p0 = gi * 32;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      long long p = p0 + px + 16 * i;
+      p = p < P ? p : P - 1;
+      gr[i] = ldraw<bf16_t>(G + (size_t)p * 32 + part * 8);
+      zr[i] = ldraw<bf16_t>(Z + (size_t)p * 32 + part * 8);
+    }
+    long long pg = p0 + lq * 8;                 // first of this lane's 8 pixels (same output row: OW % 8 == 0)
+    pg = pg < P ? pg : P - 8;
+    const int ow0 = (int)(pg % OW), oh = (int)((pg / OW) % OH), b = (int)(pg / ((long long)OW * OH));
+#pragma unroll
+    for (int tb = 0; tb < 2; ++tb) {
+      const int ih = 2 * oh - 1 + tky[tb];
+      const bool rowok = tci[tb] >= 0 && ih >= 0 && ih < H;
+      const float* row = x + ((size_t)(b * 3 + (tci[tb] < 0 ? 0 : tci[tb])) * H + clampi(ih, 0, H - 1)) * W;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int iw = 2 * (ow0 + e) - 1 + tkx[tb];
+        const float v = row[clampi(iw, 0, W - 1)];
+        xr[tb][e] = (rowok && iw >= 0 && iw < W) ? v : 0.f;
+      }
+    }
+  };
+
+  const long long gstride = (long long)gridDim.x * 4;
+  long long gi = (long long)blockIdx.x * 4 + wave;
+  if (gi < groups) load(gi);
+  for (; gi < groups; gi += gstride) {
+    const long long p0 = gi * 32;
+    // dz tile (bf16, row-major [pixel][co]) for the transpose load
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      float gf[8], zf[8], v[8];
+      cvt8(gr[i], gf); cvt8(zr[i], zf);
+      const bool ok = p0 + px + 16 * i < P;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = ok ? gf[j] * c0[j] + zf[j] * c1[j] + c2[j] : 0.f;
+      *reinterpret_cast<bf16x8_t*>(dzt + (px + 16 * i) * LD + part * 8) = pack8(v);
+    }
+    bf16x8_t pf[2];
+    {
+      const bool gok = p0 + lq * 8 < P;   // whole 8-pixel runs are valid or not (P % 8 == 0 when OW % 8 == 0)
+#pragma unroll
+      for (int tb = 0; tb < 2; ++tb) {
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = gok ? xr[tb][e] : 0.f;
+        pf[tb] = pack8(v);
+      }
+    }
+    if (gi + gstride < groups) load(gi + gstride);
+    asm volatile("" ::: "memory");   // the tile stores above must stay ahead of the transpose loads
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+      const bf16x8_t af = tr_frag(dzt, LD, cb * 16, li, lq);
+#pragma unroll
+      for (int tb = 0; tb < 2; ++tb) acc[cb][tb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, pf[tb], acc[cb][tb], 0, 0, 0);
+    }
+    asm volatile("" ::: "memory");
+  }
+  // C layout: column = tap tb*16+li, rows = co cb*16 + lq*4 + e
+#pragma unroll
+  for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+    for (int tb = 0; tb < 2; ++tb)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) red[wave][(cb * 16 + lq * 4 + e) * 32 + tb * 16 + li] = acc[cb][tb][e];
+  __syncthreads();
+  for (int i = threadIdx.x; i < 32 * 32; i += 256) {
+    const int co = i >> 5, t = i & 31;
+    if (t < 27) atomicAdd(dW + co * 27 + t, red[0][i] + red[1][i] + red[2][i] + red[3][i]);
+  }
+}
+
+}  // namespace
+
+int spb_stem_fwd_mfma(const float* x, const float* w, void* y, float* osums, int oR, int B, int H, int W, hipStream_t s) {
+  const int OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1;
+  const long long groups = ((long long)B * OH * OW + 15) / 16;
+  long long grid = (groups + 3) / 4;
+  if (grid > 512) grid = 512;
+  hipLaunchKernelGGL(stem_fwd_mfma_kernel, dim3((unsigned)grid), dim3(256), 0, s, x, w, (bf16_t*)y, osums, oR, B, H, W);
+  return 0;
+}
+
+int spb_stem_wgrad_mfma(const float* x, const void* G, const void* Z, const spb_bnref_t* pro, float* dW, int B, int H, int W,
+                        hipStream_t s) {
+  const int OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1;
+  const long long groups = ((long long)B * OH * OW + 31) / 32;
+  long long grid = (groups + 3) / 4;
+  if (grid > 512) grid = 512;
+  hipLaunchKernelGGL(stem_wgrad_mfma_kernel, dim3((unsigned)grid), dim3(256), 0, s, x, (const bf16_t*)G, (const bf16_t*)Z, *pro,
+                     dW, B, H, W);
+  return 0;
+}

@@ -324,8 +324,16 @@ def _dw_da(a, Wd, z, g2, g2s_nhwc, xh2, C, stride):
     return ad.grad
 
 
+@pytest.fixture(params=["mfma", "scalar"])
+def stem_variant(request):
+    """bf16 stem: implicit GEMM on the matrix cores (default) and the scalar kernels (the f32 mode always uses those)"""
+    L.lib().spb_debug_set_stem_mfma(1 if request.param == "mfma" else 0)
+    yield request.param
+    L.lib().spb_debug_set_stem_mfma(1)
+
+
 @pytest.mark.parametrize("dt", DTYPES)
-def test_stem(device, dt):
+def test_stem(device, stem_variant, dt):
     torch.manual_seed(5)
     dev = device
     B, H = 3, 32
