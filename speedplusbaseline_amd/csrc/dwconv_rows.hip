@@ -533,7 +533,7 @@ Geo make_geo(int B, int C, int lane_rows, int lane_cols, int NP, int halo, int t
   const int ncg = C >> 3, nquads = (ncg + 3) / 4;
   g.nstrip = (lane_cols + NP - 1) / NP;
   if (g_blocks_override > 0) target_blocks = g_blocks_override;
-  g.nb = (target_blocks + nquads - 1) / nquads;
+  g.nb = target_blocks / nquads;   // never more blocks than are resident at once: a partial second round doubles small layers
   const long long per_seg = (long long)B * g.nstrip;
   if ((long long)g.nb * 4 > per_seg * lane_rows) g.nb = (int)((per_seg * lane_rows + 3) / 4);
   if (g.nb < 1) g.nb = 1;
