@@ -43,7 +43,7 @@ constexpr size_t gemm_region_bytes() {
 
 // RF = 16-row fragments per wave (workgroup tile = 64*RF rows x BN columns)
 template <typename T, int RF, int BN, int BK, int PRO, int EPI>
-__global__ __launch_bounds__(256) void pw_gemm_kernel(const spb_gemm_args_t g) {
+__global__ __launch_bounds__(256, (RF == 1 && sizeof(T) == 2) ? 4 : 1) void pw_gemm_kernel(const spb_gemm_args_t g) {
   constexpr int BM = 64 * RF;
   constexpr int GBK = BK;
   constexpr int LDK = LdsPad<T, BK>::LDK;
@@ -62,7 +62,8 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(const spb_gemm_args_t g) {
   const int M = g.M, K = g.K, N = g.N;
   const int Kp = (K + GBK - 1) / GBK * GBK;
   float* coef = reinterpret_cast<float*>(smem);  // [3][Kp]
-  T* As = reinterpret_cast<T*>(smem + (size_t)3 * Kp * sizeof(float));
+  float* ecoef = coef + 3 * Kp;                   // [2][BN] (EPI 2): scale, shift of the input-side BN
+  T* As = reinterpret_cast<T*>(smem + (size_t)(3 * Kp + (EPI == 2 ? 2 * BN : 0)) * sizeof(float));
   T* Bs = As + BM * LDK;
   T* Os = As;
 
@@ -94,16 +95,21 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(const spb_gemm_args_t g) {
   float s1[8], s2[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
-  float e_sc[8], e_sh[8], e_mu[8], e_is[8], e_bias[8];
+  // backward epilogue: scale/shift of the input-side BN are read from LDS where they are used, and the second BN sum
+  // is accumulated as sum g*z and turned into sum g*xhat = invstd*(sum g*z - mean*sum g) in the final reduction.
+  // (With mean/invstd/scale/shift in registers this variant sat at 164 VGPRs = 2 workgroups per CU, and the
+  // 882-workgroup layers ran in two rounds.)
+  float e_bias[8];
   if (EPI == 2) {
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      e_sc[j] = 1.f; e_sh[j] = 0.f; e_mu[j] = 0.f; e_is[j] = 0.f;
-      if (colok && g.epi.gamma != nullptr) {
-        bn_moments(g.epi, nE + j, e_mu[j], e_is[j]);
-        e_sc[j] = g.epi.gamma[nE + j] * e_is[j];
-        e_sh[j] = g.epi.beta[nE + j] - e_mu[j] * e_sc[j];
+    for (int c = t; c < BN; c += 256) {
+      float sc = 1.f, sh = 0.f;
+      if (n0 + c < N && g.epi.gamma != nullptr) {
+        float mu, is;
+        bn_moments(g.epi, n0 + c, mu, is);
+        sc = g.epi.gamma[n0 + c] * is;
+        sh = g.epi.beta[n0 + c] - mu * sc;
       }
+      ecoef[c] = sc; ecoef[BN + c] = sh;
     }
   }
   if (EPI == 0) {
@@ -274,8 +280,13 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(const spb_gemm_args_t g) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) { s1[j] += v[j]; s2[j] += v[j] * v[j]; }
           } else {
-            float z[8], rv[8];
+            float z[8], rv[8], e_sc[8], e_sh[8];
             cvt8(zr[EPI == 2 ? s : 0], z);
+#pragma unroll
+            for (int j = 0; j < 8; j += 4) {
+              *reinterpret_cast<float4*>(e_sc + j) = *reinterpret_cast<const float4*>(ecoef + vcol * 8 + j);
+              *reinterpret_cast<float4*>(e_sh + j) = *reinterpret_cast<const float4*>(ecoef + BN + vcol * 8 + j);
+            }
             if (Rg) {
               cvt8(rr[EPI == 2 ? s : 0], rv);
 #pragma unroll
@@ -285,9 +296,8 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(const spb_gemm_args_t g) {
             for (int j = 0; j < 8; ++j) {
               const float u = z[j] * e_sc[j] + e_sh[j];
               v[j] = rnd<T>(v[j] * act_grad(u, g.epi.act, g.epi.slope));
-              const float xh = (z[j] - e_mu[j]) * e_is[j];
               s1[j] += v[j];
-              s2[j] += v[j] * xh;
+              s2[j] += v[j] * z[j];
             }
             st8<T>(Yg + o, v);
           }
@@ -315,6 +325,12 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(const spb_gemm_args_t g) {
       float s = 0.f;
       for (int r = 0; r < VR; ++r) s += Rs[which * VR * BN + r * BN + c];
       if (n0 + c < N) {
+        if (EPI == 2 && which == 1) {   // sum g*z -> sum g*xhat
+          float sg = 0.f, mu = 0.f, is = 0.f;
+          for (int r = 0; r < VR; ++r) sg += Rs[r * BN + c];
+          if (g.epi.gamma != nullptr) bn_moments(g.epi, n0 + c, mu, is);
+          s = is * (s - mu * sg);
+        }
         const int rep = blockIdx.x % g.oR;
         atomicAdd(g.osums + (size_t)rep * 2 * N + (size_t)which * N + n0 + c, s);
       }
@@ -339,7 +355,7 @@ int launch_gemm(const spb_gemm_args_t& g, hipStream_t stream) {
     if (GM >= 8 && (GM & 7)) GM = (GM + 7) / 8 * 8;  // multiple of 8 keeps the XCD remap bijective
   }
   const int Kp = (g.K + GBK - 1) / GBK * GBK;
-  const size_t lds = (size_t)3 * Kp * sizeof(float) + gemm_region_bytes<T, RF, BN, BK>();
+  const size_t lds = (size_t)(3 * Kp + (EPI == 2 ? 2 * BN : 0)) * sizeof(float) + gemm_region_bytes<T, RF, BN, BK>();
   static bool attr_done = false;
   if (!attr_done) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(&pw_gemm_kernel<T, RF, BN, BK, PRO, EPI>),
@@ -614,7 +630,7 @@ int dispatch_bn(const spb_gemm_args_t& g, hipStream_t stream) {
   if (sizeof(T) == 4 && bn == 128) bn = 64;  // parity mode: keep the LDS footprint small
   if (EPI == 2 && bn == 128) bn = 64;        // backward epilogue hoists 2 operand vectors per output row sweep
   // small M (the 14x14 and 7x7 maps): 64-row tiles and 64-column tiles so the launch has enough workgroups
-  const bool small_m = g.M <= 16384;
+  const bool small_m = g.M <= 40000;   // 28x28 and below: 64-row tiles at 4 waves/SIMD beat 128-row tiles at 2
   if (small_m && bn == 128) bn = 64;
   if (small_m) {
     if (bn == 32) return launch_gemm<T, 1, 32, 32, PRO, EPI>(g, stream);
