@@ -5,10 +5,14 @@ WRITE_SIZE is used as reported (uncalibrated)."""
 import csv, json, re, sys, collections
 
 def family(name):
-    m = re.search(r"pw_gemm_kernel<[^,]+, *(\d+), *(\d+), *(\d+), *(\d+)>", name)
+    m = re.search(r"pw_gemm_kernel<[^>]*?, *(\d+), *(\d+)>", name)   # last two template ints: PRO, EPI
     if m:
-        pro, epi = int(m.group(3)), int(m.group(4))
+        pro, epi = int(m.group(1)), int(m.group(2))
         return "pw_gemm_dgrad" if pro == 2 else ("pw_gemm_fwd" if epi == 1 else "pw_gemm_plain")
+    for pat, fam in (("pwb_kernel", "pw_bwd_fused"), ("dwr_fwd_kernel", "dw_fwd"), ("dwr_bwd_kernel", "dw_dgrad"),
+                     ("stem_fwd_mfma", "stem_fwd"), ("stem_wgrad_mfma", "stem_wgrad"), ("pw_gemm_dma_kernel", "pw_gemm_dma")):
+        if pat in name:
+            return fam
     for k in ("pw_wgrad", "dw_fwd", "dw_dgrad", "dw_wgrad", "stem_fwd", "stem_wgrad", "head_fwd", "head_reduce", "head_bwd",
               "bn_apply", "bn_bwd_prep", "bn_running_update", "bn_param_grads", "bn_load_running", "weight_prep", "grad_sqnorm",
               "optim_step", "domain_tail", "bce_logits"):
