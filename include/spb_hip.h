@@ -299,6 +299,35 @@ const char* spb_krn_prof_category_name(int i);
 int spb_krn_prof_read(spb_krn_ctx_t* c, int* launches, float* ms, double* bytes, double* flops);
 long long spb_krn_weight_prep_bytes(const spb_krn_t* m);
 
+/* ---- style-transfer decoder (Ghiasi), inference only: src/styleaug/ghiasi.py:6-135, called from
+ * StyleAugmentor.forward (styleAugmentor.py:48-68).  An instance-normalised tensor is its RAW conv output (NHWC bf16)
+ * plus per-(image, channel) sums; consumers apply a = act(x*scale[b,c] + shift[b,c]) while loading. */
+typedef struct {
+  const void* X;      /* [B,Hin,Win,Cin] NHWC bf16 */
+  const void* W;      /* [Cout][KH*KH][Cin] bf16 (PyTorch weight permuted (0,2,3,1)) */
+  const float* bias;  /* [Cout] or NULL */
+  const float* coef;  /* [B][Cin][2] scale, shift applied to X on load, or NULL */
+  void* Y;            /* [B,Hout,Wout,ldc] NHWC bf16, raw conv output (+bias) */
+  float* stats;       /* [B][Cout][2] f32 accumulated: sum and sum of squares of the stored output, or NULL */
+  int B, Hin, Win, Cin, Cout, KH, stride, upsample, relu, ldc;
+} spb_gconv_args_t;
+/* KxK conv (K = 3 | 9), nn.ReflectionPad2d(K/2), stride 1|2, optional nearest x2 upsampling of the input
+ * (torch.nn.Upsample(scale_factor=2)); Hout = Hin*upsample/stride must be a multiple of 8.  bf16 only. */
+int spb_gconv(int dtype, const spb_gconv_args_t* args, spb_stream_t stream);
+/* first layer: Conv2d(3,32,9) with reflection padding on the fp32 NCHW image -> NHWC bf16 [B,H,W,32] + stats; W % 16 == 0 */
+int spb_conv9_rgb(const float* x, const float* w_oihw, const float* bias, void* y, float* stats, int B, int H, int W,
+                  spb_stream_t stream);
+/* coef[b][c] = (gamma*invstd, beta - mean*gamma*invstd); gamma/beta [B][ld] rows (NULL: 1 / 0); eps as InstanceNorm2d */
+int spb_in_coef(const float* stats, const float* gamma, const float* beta, int ld, float* coef, int B, int C, long long hw,
+                float eps, spb_stream_t stream);
+/* out[b][j] = bias[j] + sum_i style[b][i]*W[j][i]: every nn.Linear(100, C) of the decoder stacked into one [N,100] matrix */
+int spb_style_fc(const float* style, const float* W, const float* bias, float* out, int B, int N, spb_stream_t stream);
+/* Y = [res +] act(X*scale + shift), NHWC bf16 (the residual stream of ResidualBlock, ghiasi.py:92-104) */
+int spb_in_apply(const void* X, const float* coef, const void* res, void* Y, int B, long long hw, int C, int relu,
+                 spb_stream_t stream);
+/* out (fp32 NCHW, 3 channels) = sigmoid(Z*scale + shift), Z NHWC bf16 with channel stride ldc (ghiasi.py:135) */
+int spb_final_sigmoid(const void* Z, const float* coef, float* out, int B, long long hw, int ldc, spb_stream_t stream);
+
 /* debug / test helpers */
 int spb_debug_trread(const unsigned short* in4096, unsigned short* out256, spb_stream_t stream);
 int spb_debug_set_gemm_dma(int on); /* 1: small-M bf16 pointwise GEMMs use the LDS-DMA ring kernel (default 0) */

@@ -1,0 +1,24 @@
+"""time the HIP style decoder at the training shape (B=48, 224x224)"""
+import sys, time, torch
+sys.path.insert(0, ".")
+from oracle import ghiasi_oracle as G
+from speedplusbaseline_amd.styleaug import Ghiasi
+dev = torch.device("cuda:0")
+net = Ghiasi(); net.load_state_dict(G.init_state()); net.to(dev)
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 48
+x = torch.rand(B, 3, 224, 224, device=dev); s = torch.randn(B, 100, device=dev)
+for _ in range(3): net(x, s)
+torch.cuda.synchronize(); t0 = time.perf_counter()
+n = 10
+for _ in range(n): net(x, s)
+torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / n
+print("Ghiasi forward B=%d: %.3f ms  (%.1f TFLOP/s at 15.43 GFLOP/img)" % (B, dt * 1e3, 15.43e9 * B / dt / 1e12))
+
+net.profile = []
+net(x, s); torch.cuda.synchronize()
+marks = net.profile; net.profile = None
+agg = {}
+for (l0, e0), (l1, e1) in zip(marks[:-1], marks[1:]):
+    agg.setdefault(l1, [0, 0.0]); agg[l1][0] += 1; agg[l1][1] += e0.elapsed_time(e1)
+for k, (n_, ms) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+    print("%-34s x%2d  %8.3f ms" % (k, n_, ms))

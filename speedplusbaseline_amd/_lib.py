@@ -40,6 +40,12 @@ class PwBwdArgs(C.Structure):
                 ("oR", i32)]
 
 
+class GconvArgs(C.Structure):
+    _fields_ = [("X", vp), ("W", vp), ("bias", vp), ("coef", vp), ("Y", vp), ("stats", vp), ("B", i32), ("Hin", i32),
+                ("Win", i32), ("Cin", i32), ("Cout", i32), ("KH", i32), ("stride", i32), ("upsample", i32), ("relu", i32),
+                ("ldc", i32)]
+
+
 class DwArgs(C.Structure):
     _fields_ = [("X", vp), ("X2", vp), ("Xin", vp), ("Wd", vp), ("Y", vp), ("dW", vp), ("res", vp), ("Zout", vp),
                 ("osums", vp), ("pro", BNRef), ("pro_in", BNRef), ("epi", BNRef), ("B", i32), ("H", i32), ("W", i32),
@@ -135,6 +141,12 @@ SYMBOLS = {
     "spb_krn_prof_category_name": (C.c_char_p, [i32]),
     "spb_krn_prof_read": (i32, [vp, vp, vp, vp, vp]),
     "spb_krn_weight_prep_bytes": (i64, [vp]),
+    "spb_gconv": (i32, [i32, C.POINTER(GconvArgs), vp]),
+    "spb_conv9_rgb": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, vp]),
+    "spb_in_coef": (i32, [vp, vp, vp, i32, vp, i32, i32, i64, f32, vp]),
+    "spb_style_fc": (i32, [vp, vp, vp, vp, i32, i32, vp]),
+    "spb_in_apply": (i32, [vp, vp, vp, vp, i32, i64, i32, i32, vp]),
+    "spb_final_sigmoid": (i32, [vp, vp, vp, i32, i64, i32, vp]),
     "spb_debug_trread": (i32, [vp, vp, vp]),
     "spb_debug_set_gemm_dma": (i32, [i32]),
     "spb_debug_set_dw_mode": (i32, [i32]),

@@ -1,0 +1,464 @@
+// Style-transfer decoder of the reference's style augmentation (Ghiasi et al.), inference only.
+// Reference: src/styleaug/ghiasi.py (ConvInRelu :6-23, UpsampleConvInRelu :26-59, ResidualBlock :62-104, Ghiasi :107-135),
+// called from StyleAugmentor.forward (styleAugmentor.py:48-68) on half of the training batches (trainer.py:68-69).
+//
+// 15.4 GFLOP per 224x224 image, almost all of it in 3x3 convolutions with 32..128 channels: MFMA-bound implicit GEMMs.
+// Data design (the same idea as the KRN BatchNorm layers): an instance-normalised tensor exists only as the RAW
+// convolution output (NHWC bf16) plus per-(image, channel) sums; its consumer applies
+//     a = act(x * scale[b,c] + shift[b,c]),   scale = gamma[b,c] * invstd[b,c],  shift = beta[b,c] - mean[b,c] * scale
+// while it stages its input tile, with gamma/beta coming from the style embedding (or 1/0 for the first three layers).
+//
+//   gconv_kernel<NB>     KxK convolution, reflection padding, stride 1|2, optional nearest x2 upsampling of the input:
+//                        an 8x8 output tile per workgroup; the (upsampled, reflected, normalised, activated) input halo is
+//                        staged ONCE in LDS, then every tap is an MFMA step whose B operand is a plain 16-byte LDS read of
+//                        32 input channels of the tap's pixel.  y^T = W * patch^T, so results leave the matrix core as
+//                        consecutive output channels per lane (rows of W permuted at load: 4*NB consecutive channels per
+//                        lane).  Weights [Cout][K*K][Cin] stream from L2 (double-buffered in registers).  The per-(image,
+//                        channel) sums of the stored output are reduced with DPP butterflies and one atomic per channel.
+//   conv9_rgb_kernel     first layer, 3 -> 32, 9x9 on the fp32 NCHW image: K = 243 taps gathered per pixel.
+//   in_coef / style_fc / in_apply / final_sigmoid: the small per-(image, channel) and elementwise pieces.
+// bf16 storage and MFMA operands, f32 accumulation.
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ int reflecti(int i, int n) { i = i < 0 ? -i : i; return i >= n ? 2 * n - 2 - i : i; }
+
+// ---------------------------------------------------------------------------------------------- implicit-GEMM conv
+// WLDS: the whole weight tensor sits in LDS (<= 64 KB: the 32/64-channel layers); otherwise weights stream from L2 with a
+// PD-step register prefetch.  A workgroup is persistent over `tpw` consecutive 8x8 tiles of ONE image: weights are staged
+// once, and the per-(image, channel) sums stay in registers until the end (first version: one tile per workgroup, one
+// prefetch step, per-wave atomics -- 9.6 M atomics and an exposed L2 round trip per tap: 5.5 ms for the 64->32 layer).
+// PXG = 8x8 tiles a workgroup computes side by side (the streaming variant uses 2: every weight fragment fetched from
+// L2 then feeds two MFMAs -- with one, the 128->128 layers were bound by 2.8 GB of weight re-reads per launch).
+template <int NB, bool WLDS, int PXG>
+__global__ __launch_bounds__(256) void gconv_kernel(const spb_gconv_args_t g, int tpw) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int PD = NB >= 8 ? 2 : 3;                          // weight prefetch depth (steps) when streaming
+  const int Cin = g.Cin, Cout = g.Cout, KH = g.KH, st = g.stride, up = g.upsample;
+  const int Hu = g.Hin * up, Wu = g.Win * up;                 // input size after upsampling
+  const int Hout = Hu / st, Wout = Wu / st;
+  const int pad = KH / 2;
+  const int HT = 7 * st + KH;                                 // halo tile edge (upsampled coordinates)
+  const int LDP = Cin + 8;                                    // bf16 per halo pixel (+16 B skew)
+  const int KK = KH * KH;
+  const int LDW = KK * Cin + 8;                               // bf16 per weight row in LDS (+16 B skew)
+  float* cf = reinterpret_cast<float*>(smem);                 // [Cin][2]
+  float* red = cf + Cin * 2;                                  // [4 waves][NB*16][2]
+  bf16_t* halo = reinterpret_cast<bf16_t*>(red + 4 * NB * 16 * 2);
+  bf16_t* wl = halo + PXG * HT * HT * LDP;                    // [Cout][LDW] (WLDS)
+  const int t = threadIdx.x, lane = t & 63, li = lane & 15, lq = lane >> 4, wave = t >> 6;
+  const int tiles_x = Wout >> 3, tiles_y = Hout >> 3;
+  const int tpi = tiles_x * tiles_y;
+  const int gpi = (tpi + PXG - 1) / PXG;                      // tile groups per image
+  const int wpi = gpi / tpw;                                  // workgroups per image
+  const int b = blockIdx.x / wpi;
+  const int grp0 = (blockIdx.x % wpi) * tpw;
+  const bf16_t* Wg = reinterpret_cast<const bf16_t*>(g.W);
+
+  for (int c = t; c < Cin; c += 256) {
+    float sc = 1.f, sh = 0.f;
+    if (g.coef) { sc = g.coef[((size_t)b * Cin + c) * 2]; sh = g.coef[((size_t)b * Cin + c) * 2 + 1]; }
+    cf[c * 2] = sc; cf[c * 2 + 1] = sh;
+  }
+  if (WLDS) {   // Cout rows; lanes whose (permuted) row is >= Cout use a zero fragment
+    const int RV = (KK * Cin) >> 3;
+    for (int i = t; i < Cout * RV; i += 256) {
+      const int r = i / RV, v = i % RV;
+      *reinterpret_cast<uint4*>(wl + r * LDW + v * 8) = *reinterpret_cast<const uint4*>(Wg + (size_t)r * KK * Cin + v * 8);
+    }
+  }
+  const bf16_t* X = reinterpret_cast<const bf16_t*>(g.X);
+  bf16_t* Y = reinterpret_cast<bf16_t*>(g.Y);
+  const int CV = Cin >> 3;
+  const int prow = wave * 2 + (li >> 3), pcol = li & 7;
+  const bf16_t* hbase = halo + ((prow * st) * HT + pcol * st) * LDP + lq * 8;
+  const int nch = Cin >> 5;
+  const int nsteps = KK * nch;
+  int wco[NB];
+  bool wok[NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) {
+    const int co = (li >> 2) * 4 * NB + nb * 4 + (li & 3);     // row permutation: see header
+    wok[nb] = co < Cout;
+    wco[nb] = wok[nb] ? co : 0;
+  }
+  const int co0 = lq * 4 * NB;
+  for (int i = t; i < 4 * NB * 16 * 2; i += 256) red[i] = 0.f;   // per-wave (image, channel) sums, kept in LDS
+
+  for (int ti = 0; ti < tpw; ++ti) {
+    int oy0[PXG], ox0[PXG];
+    bool tvalid[PXG];
+#pragma unroll
+    for (int p = 0; p < PXG; ++p) {
+      int tr = (grp0 + ti) * PXG + p;
+      tvalid[p] = tr < tpi;                                    // odd tile counts: the last group repeats its first tile
+      tr = tvalid[p] ? tr : tpi - 1;
+      oy0[p] = (tr / tiles_x) * 8; ox0[p] = (tr % tiles_x) * 8;
+    }
+    __syncthreads();   // previous tile's taps are done with the halo (first pass: coefficient / weight tables written)
+    // ---- stage the input halo(s): upsample (nearest), reflect, normalise + activate, bf16
+    for (int i = t; i < PXG * HT * HT * CV; i += 256) {
+      const int p = i / (HT * HT * CV), ii = i % (HT * HT * CV);
+      const int hp = ii / CV, cv = ii % CV;
+      const int hy = hp / HT, hx = hp % HT;
+      const int sy = reflecti(oy0[PXG > 1 ? p : 0] * st - pad + hy, Hu) / up, sx = reflecti(ox0[PXG > 1 ? p : 0] * st - pad + hx, Wu) / up;
+      float v[8];
+      ld8<bf16_t>(X + ((size_t)(b * g.Hin + sy) * g.Win + sx) * Cin + cv * 8, v);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float u = v[j] * cf[(cv * 8 + j) * 2] + cf[(cv * 8 + j) * 2 + 1];
+        v[j] = g.relu ? fmaxf(u, 0.f) : u;
+      }
+      st8<bf16_t>(halo + (p * HT * HT + hp) * LDP + cv * 8, v);
+    }
+    __syncthreads();
+    // ---- K loop: taps x 32-channel chunks.  lane (li, lq): pixel li of this wave's 2x8 strip, channels lq*8..+7
+    f32x4_t acc[PXG][NB];
+#pragma unroll
+    for (int p = 0; p < PXG; ++p)
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) acc[p][nb] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    if constexpr (WLDS) {
+      int ky = 0, kx = 0, cc = 0;
+      for (int s = 0; s < nsteps; ++s) {
+        bf16x8_t bf[PXG];
+#pragma unroll
+        for (int p = 0; p < PXG; ++p)
+          bf[p] = *reinterpret_cast<const bf16x8_t*>(hbase + (p * HT * HT + ky * HT + kx) * LDP + cc * 32);
+        const int ko = (ky * KH + kx) * Cin + cc * 32 + lq * 8;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+          uint4 au = *reinterpret_cast<const uint4*>(wl + wco[nb] * LDW + ko);
+          if (!wok[nb]) au = make_uint4(0, 0, 0, 0);
+#pragma unroll
+          for (int p = 0; p < PXG; ++p)
+            acc[p][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, au), bf[p], acc[p][nb], 0, 0, 0);
+        }
+        if (++cc == nch) { cc = 0; if (++kx == KH) { kx = 0; ++ky; } }
+      }
+    } else {
+      uint4 an[PD][NB];
+#pragma unroll
+      for (int d = 0; d < PD; ++d)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+          an[d][nb] = *reinterpret_cast<const uint4*>(Wg + (size_t)wco[nb] * KK * Cin + lq * 8 + (size_t)(d < nsteps ? d : 0) * 32);
+      int ky = 0, kx = 0, cc = 0;
+      for (int s0 = 0; s0 < nsteps; s0 += PD) {
+#pragma unroll
+        for (int d = 0; d < PD; ++d) {
+          const int s = s0 + d;
+          if (s < nsteps) {
+            uint4 a[NB];   // streaming path: Cout == 16*NB (checked by the launcher), every row is real
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) a[nb] = an[d][nb];
+            bf16x8_t bf[PXG];
+#pragma unroll
+            for (int p = 0; p < PXG; ++p)
+              bf[p] = *reinterpret_cast<const bf16x8_t*>(hbase + (p * HT * HT + ky * HT + kx) * LDP + cc * 32);
+            const int sn = s + PD;   // weights are [co][tap][ci]: step index * 32 is the offset inside a row
+            if (sn < nsteps) {
+#pragma unroll
+              for (int nb = 0; nb < NB; ++nb)
+                an[d][nb] = *reinterpret_cast<const uint4*>(Wg + (size_t)wco[nb] * KK * Cin + lq * 8 + (size_t)sn * 32);
+            }
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+              for (int p = 0; p < PXG; ++p)
+                acc[p][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a[nb]), bf[p], acc[p][nb], 0, 0, 0);
+            if (++cc == nch) { cc = 0; if (++kx == KH) { kx = 0; ++ky; } }
+          }
+        }
+      }
+    }
+    // ---- epilogue: lane (li = pixel, lq): channels lq*4*NB + nb*4 + e
+#pragma unroll
+    for (int p = 0; p < PXG; ++p) {
+      if (!tvalid[p]) continue;
+      const int oy = oy0[p] + prow, ox = ox0[p] + pcol;
+      bf16_t* dst = Y + ((size_t)(b * Hout + oy) * Wout + ox) * g.ldc + co0;
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int co = co0 + nb * 4 + e;
+          v[e] = acc[p][nb][e] + ((g.bias && co < Cout) ? g.bias[co] : 0.f);
+        }
+        uint2 o;
+        o.x = pack_bf16x2(v[0], v[1]); o.y = pack_bf16x2(v[2], v[3]);
+        if (co0 + nb * 4 < g.ldc) *reinterpret_cast<uint2*>(dst + nb * 4) = o;
+        if (g.stats) {   // sums of the stored values: 16-lane butterfly, then the owning lane adds into its wave's LDS slot
+          const float r[4] = {__uint_as_float(o.x << 16), __uint_as_float(o.x & 0xffff0000u), __uint_as_float(o.y << 16),
+                              __uint_as_float(o.y & 0xffff0000u)};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float a1 = r[e], a2 = r[e] * r[e];
+#pragma unroll
+            for (int o2 = 1; o2 < 16; o2 <<= 1) { a1 += __shfl_xor(a1, o2, 16); a2 += __shfl_xor(a2, o2, 16); }
+            if (li == 0) {
+              red[(wave * NB * 16 + co0 + nb * 4 + e) * 2] += a1;
+              red[(wave * NB * 16 + co0 + nb * 4 + e) * 2 + 1] += a2;
+            }
+          }
+        }
+      }
+    }
+  }
+  if (g.stats) {   // 4 waves -> one atomic per (image, channel, moment) and workgroup
+    __syncthreads();
+    for (int i = t; i < NB * 16 * 2; i += 256) {
+      const int co = i >> 1;
+      if (co < Cout)
+        atomicAdd(g.stats + ((size_t)b * Cout + co) * 2 + (i & 1),
+                  red[i] + red[NB * 32 + i] + red[2 * NB * 32 + i] + red[3 * NB * 32 + i]);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------- first layer: 3 -> 32, 9x9
+// x fp32 NCHW [B,3,H,W]; w fp32 [32][3][9][9] (PyTorch layout); y bf16 NHWC [B,H,W,32] raw conv (+bias); stats [B][32][2].
+// 16 consecutive pixels of a row per wave step; K = 243 (k = (ky*9+kx)*3 + ci) padded to 256.  blockIdx.y = image, so the
+// per-(image, channel) sums stay in registers for the whole kernel; the weight fragments sit in LDS (in registers, with the
+// 64 gathers of a pixel group in flight, the kernel needed 256 VGPRs + spills and ran one wave per SIMD).
+__global__ __launch_bounds__(256) void conv9_rgb_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                        const float* __restrict__ bias, bf16_t* __restrict__ y, float* stats,
+                                                        int B, int H, int W) {
+  __shared__ int ktab[256];   // k -> (ky << 16) | (kx << 8) | ci, -1 past 243
+  __shared__ __attribute__((aligned(16))) uint4 wfrag[8][2][64];   // [ks][cb][lane]: A operand fragments
+  __shared__ float red[4][64];
+  const int lane = threadIdx.x & 63, li = lane & 15, lq = lane >> 4, wave = threadIdx.x >> 6;
+  for (int k = threadIdx.x; k < 256; k += 256) {
+    const int tp = k / 3;
+    ktab[k] = k < 243 ? ((tp / 9) << 16) | ((tp % 9) << 8) | (k % 3) : -1;
+  }
+  // A operand: W[co = cb*16+li][k = ks*32 + lq*8 + e]
+  for (int f = wave; f < 16; f += 4) {
+    const int ks = f >> 1, cb = f & 1;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int k = ks * 32 + lq * 8 + e;
+      float wv = 0.f;
+      if (k < 243) { const int tp = k / 3, ci = k % 3; wv = w[((cb * 16 + li) * 3 + ci) * 81 + tp]; }
+      v[e] = wv;
+    }
+    uint4 u;
+    u.x = pack_bf16x2(v[0], v[1]); u.y = pack_bf16x2(v[2], v[3]); u.z = pack_bf16x2(v[4], v[5]); u.w = pack_bf16x2(v[6], v[7]);
+    wfrag[ks][cb][lane] = u;
+  }
+  __syncthreads();
+  const int b = blockIdx.y;
+  const int gpr = W >> 4;
+  const int groups = H * gpr;
+  float s1[2][4], s2[2][4];
+#pragma unroll
+  for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { s1[cb][e] = 0.f; s2[cb][e] = 0.f; }
+  for (int gi = blockIdx.x * 4 + wave; gi < groups; gi += gridDim.x * 4) {
+    const int oy = gi / gpr, ox = (gi % gpr) * 16 + li;
+    f32x4_t acc[2] = {(f32x4_t){0.f, 0.f, 0.f, 0.f}, (f32x4_t){0.f, 0.f, 0.f, 0.f}};
+#pragma unroll 2
+    for (int ks = 0; ks < 8; ++ks) {
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int kt = ktab[ks * 32 + lq * 8 + e];
+        const int ky = (kt >> 16) & 0xff, kx = (kt >> 8) & 0xff, ci = kt & 0xff;
+        const float xv = x[((size_t)(b * 3 + (kt < 0 ? 0 : ci)) * H + reflecti(oy - 4 + (kt < 0 ? 4 : ky), H)) * W +
+                           reflecti(ox - 4 + (kt < 0 ? 4 : kx), W)];
+        v[e] = kt < 0 ? 0.f : xv;
+      }
+      uint4 u;
+      u.x = pack_bf16x2(v[0], v[1]); u.y = pack_bf16x2(v[2], v[3]); u.z = pack_bf16x2(v[4], v[5]); u.w = pack_bf16x2(v[6], v[7]);
+      const bf16x8_t bf = __builtin_bit_cast(bf16x8_t, u);
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb)
+        acc[cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wfrag[ks][cb][lane]), bf, acc[cb], 0, 0, 0);
+    }
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+      float v[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = acc[cb][e] + (bias ? bias[cb * 16 + lq * 4 + e] : 0.f);
+      uint2 o;
+      o.x = pack_bf16x2(v[0], v[1]); o.y = pack_bf16x2(v[2], v[3]);
+      *reinterpret_cast<uint2*>(y + ((size_t)(b * H + oy) * W + ox) * 32 + cb * 16 + lq * 4) = o;
+      const float r[4] = {__uint_as_float(o.x << 16), __uint_as_float(o.x & 0xffff0000u), __uint_as_float(o.y << 16),
+                          __uint_as_float(o.y & 0xffff0000u)};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { s1[cb][e] += r[e]; s2[cb][e] += r[e] * r[e]; }
+    }
+  }
+  if (stats) {
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float a1 = s1[cb][e], a2 = s2[cb][e];
+#pragma unroll
+        for (int o2 = 1; o2 < 16; o2 <<= 1) { a1 += __shfl_xor(a1, o2, 16); a2 += __shfl_xor(a2, o2, 16); }
+        if (li == 0) { red[wave][(cb * 16 + lq * 4 + e) * 2] = a1; red[wave][(cb * 16 + lq * 4 + e) * 2 + 1] = a2; }
+      }
+    __syncthreads();
+    if (threadIdx.x < 64)
+      atomicAdd(stats + (size_t)b * 64 + threadIdx.x,
+                red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------- small pieces
+// coef[b][c] = (gamma*invstd, beta - mean*gamma*invstd) from the raw sums of an instance-normalised tensor
+__global__ void in_coef_kernel(const float* stats, const float* gamma, const float* beta, int ld, float* coef, int B, int C,
+                               float inv_n, float eps) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * C) return;
+  const int b = i / C, c = i % C;
+  const float mean = stats[i * 2] * inv_n;
+  const float var = fmaxf(stats[i * 2 + 1] * inv_n - mean * mean, 0.f);
+  const float is = rsqrtf(var + eps);
+  const float ga = gamma ? gamma[(size_t)b * ld + c] : 1.f, be = beta ? beta[(size_t)b * ld + c] : 0.f;
+  coef[i * 2] = ga * is;
+  coef[i * 2 + 1] = be - mean * ga * is;
+}
+
+// out[b][j] = bias[j] + sum_i style[b][i] * W[j][i]   (all 26 nn.Linear(100, C) of the decoder as one [N,100] matrix)
+__global__ void style_fc_kernel(const float* style, const float* W, const float* bias, float* out, int B, int N) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * N) return;
+  const int b = i / N, j = i % N;
+  float s = bias[j];
+  for (int k = 0; k < 100; ++k) s += style[b * 100 + k] * W[(size_t)j * 100 + k];
+  out[i] = s;
+}
+
+// y = [res +] act(x*scale + shift), NHWC bf16 (materialises the residual stream)
+__global__ void in_apply_kernel(const bf16_t* X, const float* coef, const bf16_t* res, bf16_t* Y, long long hw, int C, int relu,
+                                long long n8) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n8) return;
+  const int CV = C >> 3;
+  const int cv = (int)(i % CV);
+  const long long b = i / (CV * hw);
+  float v[8], r[8];
+  ld8<bf16_t>(X + i * 8, v);
+  if (res) ld8<bf16_t>(res + i * 8, r);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float* cf = coef + ((size_t)b * C + cv * 8 + j) * 2;
+    float u = v[j] * cf[0] + cf[1];
+    u = relu ? fmaxf(u, 0.f) : u;
+    v[j] = res ? u + r[j] : u;
+  }
+  st8<bf16_t>(Y + i * 8, v);
+}
+
+// out[b][c][y][x] = sigmoid(z[b][y][x][c] * scale + shift), z NHWC bf16 with channel stride ldc, out fp32 NCHW (3 channels)
+__global__ void final_sigmoid_kernel(const bf16_t* Z, const float* coef, float* out, int B, long long hw, int ldc) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)B * hw) return;
+  const long long b = i / hw, p = i % hw;
+  for (int c = 0; c < 3; ++c) {
+    const float z = bf2f(Z[i * ldc + c]);
+    const float u = z * coef[((size_t)b * 3 + c) * 2] + coef[((size_t)b * 3 + c) * 2 + 1];
+    out[((size_t)b * 3 + c) * hw + p] = 1.f / (1.f + __expf(-u));
+  }
+}
+
+}  // namespace
+
+extern "C" int spb_gconv(int dtype, const spb_gconv_args_t* a, spb_stream_t stream) {
+  if (!a || !a->X || !a->W || !a->Y) return SPB_E_ARG;
+  if (dtype != SPB_BF16) return SPB_E_UNSUPPORTED;
+  if (a->B <= 0 || (a->Cin & 31) || a->Cout <= 0 || a->Cout > 128 || (a->KH != 3 && a->KH != 9)) return SPB_E_SHAPE;
+  if ((a->stride != 1 && a->stride != 2) || (a->upsample != 1 && a->upsample != 2)) return SPB_E_SHAPE;
+  const int Hu = a->Hin * a->upsample, Wu = a->Win * a->upsample;
+  if (Hu % a->stride || Wu % a->stride) return SPB_E_SHAPE;
+  const int Hout = Hu / a->stride, Wout = Wu / a->stride;
+  if ((Hout & 7) || (Wout & 7) || a->ldc < a->Cout || (a->ldc & 3)) return SPB_E_SHAPE;
+  if (a->KH / 2 >= Hu || a->KH / 2 >= Wu) return SPB_E_SHAPE;   // reflection padding needs pad < size
+  const int HT = 7 * a->stride + a->KH, KK = a->KH * a->KH;
+  const int NB = a->Cout <= 16 ? 1 : (a->Cout <= 32 ? 2 : (a->Cout <= 64 ? 4 : 8));
+  const size_t wbytes = (size_t)a->Cout * (KK * a->Cin + 8) * 2;
+  const bool wlds = wbytes <= 64 * 1024;
+  if (!wlds && a->Cout != NB * 16) return SPB_E_SHAPE;   // the streaming variant has no zero rows
+  const int pxg = wlds ? 1 : 2;
+  const size_t lds = (size_t)a->Cin * 2 * sizeof(float) + (size_t)4 * NB * 16 * 2 * sizeof(float) +
+                     (size_t)pxg * HT * HT * (a->Cin + 8) * 2 + (wlds ? wbytes : 0);
+  // tile groups per workgroup: the largest divisor of the groups of one image that still leaves >= 1024 workgroups
+  const int tpi = (Hout >> 3) * (Wout >> 3);
+  const int gpi = (tpi + pxg - 1) / pxg;
+  int tpw = 1;
+  for (int d = 1; d <= gpi; ++d)
+    if (gpi % d == 0 && (long long)a->B * (gpi / d) >= 1024) tpw = d;
+  const dim3 grid((unsigned)(a->B * (gpi / tpw)));
+  hipStream_t s = (hipStream_t)stream;
+#define G_(NB_, WL_, PX_)                                                                                            \
+  {                                                                                                                  \
+    static bool once = false;                                                                                        \
+    if (!once) {                                                                                                     \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gconv_kernel<NB_, WL_, PX_>),                         \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                             \
+      once = true;                                                                                                   \
+    }                                                                                                                \
+    hipLaunchKernelGGL((gconv_kernel<NB_, WL_, PX_>), grid, dim3(256), lds, s, *a, tpw);                             \
+  }
+  if (NB == 1) { if (wlds) G_(1, true, 1) else return SPB_E_SHAPE; }
+  else if (NB == 2) { if (wlds) G_(2, true, 1) else G_(2, false, 2) }
+  else if (NB == 4) { if (wlds) G_(4, true, 1) else G_(4, false, 2) }
+  else G_(8, false, 2)
+#undef G_
+  SPB_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int spb_conv9_rgb(const float* x, const float* w, const float* bias, void* y, float* stats, int B, int H, int W,
+                             spb_stream_t stream) {
+  if (!x || !w || !y || B <= 0 || H < 5 || W < 16 || (W & 15)) return SPB_E_ARG;
+  const int groups = H * (W >> 4);
+  int gx = (groups + 3) / 4;
+  const int cap = (2048 + B - 1) / B;
+  if (gx > cap) gx = cap;
+  hipLaunchKernelGGL(conv9_rgb_kernel, dim3((unsigned)gx, (unsigned)B), dim3(256), 0, (hipStream_t)stream, x, w, bias, (bf16_t*)y,
+                     stats, B, H, W);
+  SPB_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int spb_in_coef(const float* stats, const float* gamma, const float* beta, int ld, float* coef, int B, int C,
+                           long long hw, float eps, spb_stream_t stream) {
+  if (!stats || !coef || B <= 0 || C <= 0 || hw <= 0) return SPB_E_ARG;
+  hipLaunchKernelGGL(in_coef_kernel, dim3((B * C + 255) / 256), dim3(256), 0, (hipStream_t)stream, stats, gamma, beta, ld, coef, B,
+                     C, 1.f / (float)hw, eps);
+  SPB_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int spb_style_fc(const float* style, const float* W, const float* bias, float* out, int B, int N, spb_stream_t stream) {
+  if (!style || !W || !bias || !out || B <= 0 || N <= 0) return SPB_E_ARG;
+  hipLaunchKernelGGL(style_fc_kernel, dim3((B * N + 255) / 256), dim3(256), 0, (hipStream_t)stream, style, W, bias, out, B, N);
+  SPB_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int spb_in_apply(const void* X, const float* coef, const void* res, void* Y, int B, long long hw, int C, int relu,
+                            spb_stream_t stream) {
+  if (!X || !coef || !Y || B <= 0 || hw <= 0 || (C & 7)) return SPB_E_ARG;
+  const long long n8 = (long long)B * hw * (C >> 3);
+  hipLaunchKernelGGL(in_apply_kernel, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)X, coef,
+                     (const bf16_t*)res, (bf16_t*)Y, hw, C, relu, n8);
+  SPB_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int spb_final_sigmoid(const void* Z, const float* coef, float* out, int B, long long hw, int ldc, spb_stream_t stream) {
+  if (!Z || !coef || !out || B <= 0 || hw <= 0 || ldc < 3) return SPB_E_ARG;
+  const long long n = (long long)B * hw;
+  hipLaunchKernelGGL(final_sigmoid_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)Z, coef,
+                     out, B, hw, ldc);
+  SPB_CHECK_LAUNCH();
+  return 0;
+}

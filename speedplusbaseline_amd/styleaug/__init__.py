@@ -1,9 +1,266 @@
-"""Style augmentation surface (reference src/styleaug/styleAugmentor.py:12-68, ghiasi.py:6-136).
-The Ghiasi decoder forward (implicit-GEMM 3x3/9x9 convolutions with reflection padding, conditional instance norm) is
-the next MFMA-bound row of the hot-path table and is not built yet; the class fails loudly instead of running PyTorch."""
+"""Style augmentation surface of the reference (src/styleaug/styleAugmentor.py:12-68, ghiasi.py:6-136) on the MI355X.
+
+`Ghiasi` keeps the reference's parameter layout (84 state-dict tensors, `layers.N.{conv,conv1,conv2,fc_*}.{weight,bias}`)
+as a parameter container; its forward is HIP only (speedplusbaseline_amd/csrc/ghiasi.hip through the C-ABI in
+include/spb_hip.h): implicit-GEMM convolutions on the matrix cores with reflection padding / stride / nearest upsampling
+resolved while the input tile is staged, instance normalisation carried as per-(image, channel) sums and applied by the
+consumer.  Inference only (the reference runs it under no_grad and detaches the result, styleAugmentor.py:56-68).
+There is no CPU or eager-PyTorch fallback.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import _lib as L
+
+IN_EPS = 1e-5
 
 
-class StyleAugmentor:
-    def __init__(self, alpha, device):
-        raise NotImplementedError("--randomize_texture (Ghiasi style decoder) has no HIP path yet in this build; "
-                                  "see DESIGN.md (scope / next rows)")
+def _p(t):
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class _Conv(nn.Module):
+    """parameter container with nn.Conv2d's state-dict names"""
+
+    def __init__(self, cin, cout, k):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(cout, cin, k, k))
+        self.bias = nn.Parameter(torch.empty(cout))
+        nn.init.kaiming_uniform_(self.weight, a=5 ** 0.5)
+        nn.init.uniform_(self.bias, -0.05, 0.05)
+
+
+class _ConvInRelu(nn.Module):                      # ghiasi.py:6-23
+    def __init__(self, cin, cout, k):
+        super().__init__()
+        self.n_params = 0
+        self.conv = _Conv(cin, cout, k)
+
+
+class _UpsampleConvInRelu(nn.Module):              # ghiasi.py:26-59
+    def __init__(self, cin, cout, k):
+        super().__init__()
+        self.n_params = cout * 2
+        self.conv = _Conv(cin, cout, k)
+        self.fc_beta = nn.Linear(100, cout)
+        self.fc_gamma = nn.Linear(100, cout)
+
+
+class _ResidualBlock(nn.Module):                   # ghiasi.py:62-104
+    def __init__(self, c):
+        super().__init__()
+        self.n_params = c * 4
+        self.conv1 = _Conv(c, c, 3)
+        self.fc_beta1 = nn.Linear(100, c)
+        self.fc_gamma1 = nn.Linear(100, c)
+        self.fc_beta2 = nn.Linear(100, c)
+        self.fc_gamma2 = nn.Linear(100, c)
+        self.conv2 = _Conv(c, c, 3)
+
+
+class Ghiasi(nn.Module):
+    """Ghiasi(): same constructor, attributes (`layers`, `n_params`) and state_dict as ghiasi.py:107-123; forward(x, styles)
+    returns the sigmoid image like ghiasi.py:125-135, computed by the HIP kernels."""
+
+    def __init__(self):
+        super().__init__()
+        self.layers = nn.ModuleList([
+            _ConvInRelu(3, 32, 9), _ConvInRelu(32, 64, 3), _ConvInRelu(64, 128, 3),
+            _ResidualBlock(128), _ResidualBlock(128), _ResidualBlock(128), _ResidualBlock(128), _ResidualBlock(128),
+            _UpsampleConvInRelu(128, 64, 3), _UpsampleConvInRelu(64, 32, 3), _UpsampleConvInRelu(32, 3, 9)])
+        self.n_params = sum(layer.n_params for layer in self.layers)
+        self._packed = None
+        self._ws = {}
+        self.profile = None   # set to a list to collect (label, cuda event) marks of one forward (scratch/bench_ghiasi.py)
+
+    def _mark(self, label):
+        if self.profile is not None:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            self.profile.append((label, ev))
+
+    # ---- compute copies: conv weights as bf16 [Cout][K*K][Cin], every fc stacked into one [N,100] matrix
+    def _pack(self):
+        dev = self.layers[0].conv.weight.device
+        if dev.type != "cuda":
+            raise RuntimeError("Ghiasi runs on the MI355X only; move the module to a cuda device")
+        convs, fcw, fcb, off = {}, [], [], {}
+        n = 0
+        for i, layer in enumerate(self.layers):
+            for name in ("conv", "conv1", "conv2"):
+                if hasattr(layer, name):
+                    c = getattr(layer, name)
+                    if i == 0:
+                        convs[(i, name)] = (c.weight.detach().float().contiguous(), c.bias.detach().float().contiguous())
+                    else:
+                        w = c.weight.detach().permute(0, 2, 3, 1).contiguous().to(torch.bfloat16)
+                        convs[(i, name)] = (w, c.bias.detach().float().contiguous())
+            for name in ("fc_beta", "fc_gamma", "fc_beta1", "fc_gamma1", "fc_beta2", "fc_gamma2"):
+                if hasattr(layer, name):
+                    fc = getattr(layer, name)
+                    off[(i, name)] = n
+                    n += fc.weight.shape[0]
+                    fcw.append(fc.weight.detach().float()); fcb.append(fc.bias.detach().float())
+        self._packed = dict(convs=convs, fcw=torch.cat(fcw).contiguous(), fcb=torch.cat(fcb).contiguous(), off=off, n=n)
+
+    def load_state_dict(self, *a, **k):
+        r = super().load_state_dict(*a, **k)
+        self._packed = None
+        return r
+
+    def _apply(self, fn, *a, **k):
+        r = super()._apply(fn, *a, **k)
+        self._packed = None
+        self._ws = {}
+        return r
+
+    def _buf(self, key, shape, dtype, dev):
+        t = self._ws.get(key)
+        if t is None or tuple(t.shape) != tuple(shape) or t.dtype != dtype:
+            t = torch.empty(shape, dtype=dtype, device=dev)
+            self._ws[key] = t
+        return t
+
+    @torch.no_grad()
+    def forward(self, x, styles):
+        lib = L.lib()
+        if not (x.is_cuda and styles.is_cuda):
+            raise RuntimeError("Ghiasi.forward needs cuda tensors (no CPU path)")
+        if self._packed is None:
+            self._pack()
+        pk = self._packed
+        B, _, H, W = x.shape
+        if H % 32 or W % 32:
+            raise ValueError("image size must be a multiple of 32 (two stride-2 stages, 8x8 output tiles); got %dx%d" % (H, W))
+        dev = x.device
+        x = x.contiguous().float()
+        styles = styles.contiguous().float()
+        bf = torch.bfloat16
+        st = _stream()
+        fc = self._buf("fc", (B, pk["n"]), torch.float32, dev)
+        L.check(lib.spb_style_fc(_p(styles), _p(pk["fcw"]), _p(pk["fcb"]), _p(fc), B, pk["n"], st), "spb_style_fc")
+        stats = self._buf("stats", (16, B, 128, 2), torch.float32, dev)
+        stats.zero_()
+        coef = self._buf("coef", (16, B, 128, 2), torch.float32, dev)
+        si = [0]
+
+        def norm_of(C_, hw, gamma_key=None, beta_key=None):
+            """coefficients of the tensor whose sums were just accumulated in stats[si]"""
+            k = si[0]
+            g = fc[:, pk["off"][gamma_key]:] if gamma_key else None
+            b = fc[:, pk["off"][beta_key]:] if beta_key else None
+            L.check(lib.spb_in_coef(_p(stats[k]), _p(g), _p(b), pk["n"], _p(coef[k]), B, C_, hw, IN_EPS, st), "spb_in_coef")
+            si[0] += 1
+            return coef[k]
+
+        def gconv(key, X, Hin, Win, Cin, Cout, k, stride=1, up=1, cf=None, relu=0, ldc=None, name=None):
+            w, bias = pk["convs"][key]
+            Hout, Wout = Hin * up // stride, Win * up // stride
+            ldc = ldc or Cout
+            Y = self._buf(name or ("z%d%s" % key), (B, Hout, Wout, ldc), bf, dev)
+            a = L.GconvArgs()
+            a.X = _p(X); a.W = _p(w); a.bias = _p(bias); a.coef = _p(cf); a.Y = _p(Y); a.stats = _p(stats[si[0]])
+            a.B = B; a.Hin = Hin; a.Win = Win; a.Cin = Cin; a.Cout = Cout; a.KH = k; a.stride = stride; a.upsample = up
+            a.relu = relu; a.ldc = ldc
+            L.check(lib.spb_gconv(L.BF16, C.byref(a), st), "spb_gconv")
+            self._mark("gconv %dx%d %d->%d s%d u%d @%d" % (k, k, Cin, Cout, stride, up, Hout))
+            return Y, Hout, Wout
+
+        # ConvInRelu x3 (no style renormalisation, ghiasi.py:128-131)
+        w0, b0 = pk["convs"][(0, "conv")]
+        z0 = self._buf("z0", (B, H, W, 32), bf, dev)
+        self._mark("start")
+        L.check(lib.spb_conv9_rgb(_p(x), _p(w0), _p(b0), _p(z0), _p(stats[si[0]]), B, H, W, st), "spb_conv9_rgb")
+        self._mark("conv9_rgb")
+        c0 = norm_of(32, H * W)
+        z1, H1, W1 = gconv((1, "conv"), z0, H, W, 32, 64, 3, stride=2, cf=c0, relu=1)
+        c1 = norm_of(64, H1 * W1)
+        z2, H2, W2 = gconv((2, "conv"), z1, H1, W1, 64, 128, 3, stride=2, cf=c1, relu=1)
+        c2 = norm_of(128, H2 * W2)
+        hw2 = H2 * W2
+        r = self._buf("r0", (B, H2, W2, 128), bf, dev)
+        L.check(lib.spb_in_apply(_p(z2), _p(c2), None, _p(r), B, hw2, 128, 1, st), "spb_in_apply")
+        # ResidualBlock x5 (ghiasi.py:92-104)
+        for i in range(3, 8):
+            za, _, _ = gconv((i, "conv1"), r, H2, W2, 128, 128, 3, name="za")
+            ca = norm_of(128, hw2, (i, "fc_gamma1"), (i, "fc_beta1"))
+            zb, _, _ = gconv((i, "conv2"), za, H2, W2, 128, 128, 3, cf=ca, relu=1, name="zb")
+            cb = norm_of(128, hw2, (i, "fc_gamma2"), (i, "fc_beta2"))
+            rn = self._buf("r1" if r is self._ws.get("r0") else "r0", (B, H2, W2, 128), bf, dev)
+            L.check(lib.spb_in_apply(_p(zb), _p(cb), _p(r), _p(rn), B, hw2, 128, 0, st), "spb_in_apply")
+            r = rn
+        # UpsampleConvInRelu x3 (ghiasi.py:46-59)
+        z8, H8, W8 = gconv((8, "conv"), r, H2, W2, 128, 64, 3, up=2)
+        c8 = norm_of(64, H8 * W8, (8, "fc_gamma"), (8, "fc_beta"))
+        z9, H9, W9 = gconv((9, "conv"), z8, H8, W8, 64, 32, 3, up=2, cf=c8, relu=1)
+        c9 = norm_of(32, H9 * W9, (9, "fc_gamma"), (9, "fc_beta"))
+        z10, _, _ = gconv((10, "conv"), z9, H9, W9, 32, 3, 9, cf=c9, relu=1, ldc=4)
+        c10 = norm_of(3, H9 * W9, (10, "fc_gamma"), (10, "fc_beta"))
+        out = torch.empty(B, 3, H, W, dtype=torch.float32, device=dev)
+        L.check(lib.spb_final_sigmoid(_p(z10), _p(c10), _p(out), B, H * W, 4, st), "spb_final_sigmoid")
+        self._mark("final")
+        return out
+
+
+class StyleAugmentor(nn.Module):
+    """StyleAugmentor(alpha, device) as styleAugmentor.py:12-68.  The reference's checkpoints (transformer weights,
+    embedding mean/covariance, SPEED+ base embedding) are data files of the reference repository: pass their directory as
+    `checkpoint_dir` (default: <this package>/styleaug/checkpoints, mirroring styleAugmentor.py:23-31).  For tests and
+    synthetic benchmarks `StyleAugmentor.synthetic(alpha, device, seed)` builds one with random weights and a synthetic
+    SPD covariance."""
+
+    def __init__(self, alpha, device, checkpoint_dir=None, _parts=None):
+        super().__init__()
+        self.alpha = alpha
+        self.device = device
+        self.ghiasi = Ghiasi()
+        if _parts is None:
+            d = checkpoint_dir or os.path.join(os.path.dirname(__file__), "checkpoints")
+            need = [os.path.join(d, f) for f in ("checkpoint_transformer.pth", "checkpoint_embeddings.pth", "embedding_mean_speedplus.npy")]
+            missing = [f for f in need if not os.path.exists(f)]
+            if missing:
+                raise FileNotFoundError("style augmentation checkpoints not found (they ship with the reference repository, "
+                                        "src/styleaug/checkpoints): %s" % ", ".join(missing))
+            ck = torch.load(need[0], map_location="cpu")
+            emb = torch.load(need[1], map_location="cpu")
+            self.ghiasi.load_state_dict(ck["state_dict_ghiasi"], strict=False)
+            base = torch.from_numpy(np.load(need[2])).float()
+            mean, cov = emb["pbn_embedding_mean"], emb["pbn_embedding_covariance"]
+        else:
+            sd, base, mean, cov = _parts
+            self.ghiasi.load_state_dict(sd, strict=True)
+        self.ghiasi.to(device)
+        self.imagenet_embedding = base.float().to(device)       # SPEED+ embedding, despite the name (styleAugmentor.py:33)
+        self.mean = mean.float().to(device)                       # 1 x 100
+        self.cov = cov
+        u, s, _ = np.linalg.svd(np.asarray(cov, dtype=np.float64))
+        self.A = torch.tensor(np.matmul(u, np.diag(s ** 0.5))).float().to(device)   # 100 x 100
+
+    @classmethod
+    def synthetic(cls, alpha, device, state_dict, seed=0):
+        g = torch.Generator().manual_seed(seed)
+        q = torch.randn(100, 100, generator=g, dtype=torch.float64)
+        cov = (q @ q.t() / 100.0 + 0.05 * torch.eye(100, dtype=torch.float64)).numpy()
+        mean = torch.randn(1, 100, generator=g) * 0.3
+        base = torch.randn(100, generator=g) * 0.3
+        return cls(alpha, device, _parts=(state_dict, base, mean, cov))
+
+    def sample_embedding(self, n):
+        embedding = torch.randn(n, 100).to(self.device)
+        return torch.mm(embedding, self.A.transpose(1, 0)) + self.mean
+
+    def forward(self, x):
+        base = self.imagenet_embedding
+        with torch.no_grad():
+            embedding = self.sample_embedding(x.size(0))
+            embedding = self.alpha * embedding + (1 - self.alpha) * base
+            restyled = self.ghiasi(x, embedding)
+        return restyled.detach()

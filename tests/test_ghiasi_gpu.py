@@ -1,0 +1,104 @@
+"""GPU: the HIP style decoder (speedplusbaseline_amd.styleaug.Ghiasi, C-ABI spb_gconv & co) against the CPU oracle
+(oracle/ghiasi_oracle.py, itself pinned to the reference's ghiasi.py by tests/golden/ghiasi_golden.npz)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import ghiasi_oracle as G
+from speedplusbaseline_amd import _lib as L
+from speedplusbaseline_amd.styleaug import Ghiasi, StyleAugmentor
+
+pytestmark = pytest.mark.gpu
+GOLD = np.load(os.path.join(os.path.dirname(__file__), "golden", "ghiasi_golden.npz"))
+
+
+def _bf(t):
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+def test_state_dict_matches_reference_layout():
+    net = Ghiasi()
+    assert list(net.state_dict().keys()) == list(GOLD["keys"])
+    assert sum(v.numel() for v in net.state_dict().values()) == int(GOLD["n_params"])
+    assert net.n_params == int(GOLD["n_params_attr"])
+    net.load_state_dict(G.init_state(), strict=True)
+
+
+@pytest.mark.parametrize("cin,cout,k,stride,up,hw", [(32, 64, 3, 2, 1, 32), (64, 128, 3, 2, 1, 16), (128, 128, 3, 1, 1, 16),
+                                                     (128, 64, 3, 1, 2, 8), (64, 32, 3, 1, 2, 16), (32, 3, 9, 1, 1, 16)])
+def test_gconv_against_torch(device, cin, cout, k, stride, up, hw):
+    """one implicit-GEMM convolution with its prologue (per-(image,channel) scale/shift + relu) and its output sums"""
+    import ctypes as C
+    torch.manual_seed(cin + cout + k + stride + up)
+    B = 3
+    x = _bf(torch.randn(B, cin, hw, hw))
+    w = _bf(torch.randn(cout, cin, k, k) / (cin * k * k) ** 0.5)
+    bias = torch.randn(cout) * 0.1
+    coef = torch.stack([torch.rand(B, cin) + 0.5, torch.randn(B, cin) * 0.3], dim=2).contiguous()
+    a = _bf(F.relu(x * coef[:, :, 0, None, None] + coef[:, :, 1, None, None]))   # what the kernel parks in LDS
+    if up == 2:
+        a = F.interpolate(a, scale_factor=2, mode="nearest")
+    ref = F.conv2d(F.pad(a.double(), (k // 2,) * 4, mode="reflect"), w.double(), bias.double(), stride)
+    Hout = hw * up // stride
+    ldc = 4 if cout == 3 else cout
+    Y = torch.zeros(B, Hout, Hout, ldc, dtype=torch.bfloat16, device=device)
+    stats = torch.zeros(B, cout, 2, dtype=torch.float32, device=device)
+    g = L.GconvArgs()
+    xd = x.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).to(device)
+    wd = w.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).to(device)
+    bd, cd = bias.to(device), coef.to(device)
+    p = lambda t: C.c_void_p(t.data_ptr())
+    g.X = p(xd); g.W = p(wd); g.bias = p(bd); g.coef = p(cd); g.Y = p(Y); g.stats = p(stats)
+    g.B = B; g.Hin = hw; g.Win = hw; g.Cin = cin; g.Cout = cout; g.KH = k; g.stride = stride; g.upsample = up; g.relu = 1; g.ldc = ldc
+    L.check(L.lib().spb_gconv(L.BF16, C.byref(g), C.c_void_p(torch.cuda.current_stream().cuda_stream)), "spb_gconv")
+    torch.cuda.synchronize()
+    got = Y.float().cpu()[..., :cout].permute(0, 3, 1, 2).double()
+    err = float((got - ref).abs().max() / ref.abs().max())
+    assert err < 1.5e-2, err                     # bf16 storage of the result
+    s = stats.double().cpu()
+    assert float((s[..., 0] - got.sum((2, 3))).abs().max() / got.sum((2, 3)).abs().max()) < 1e-3
+    assert float((s[..., 1] - (got * got).sum((2, 3))).abs().max() / (got * got).sum((2, 3)).abs().max()) < 1e-3
+
+
+@pytest.mark.parametrize("B,hw", [(2, 64), (1, 96)])
+def test_decoder_forward_matches_oracle(device, B, hw):
+    sd = G.init_state()
+    x, s = G.synth_inputs(B, hw, seed=2021 + B)
+    feats = {}
+    with torch.no_grad():
+        ref = G.forward(sd, x, s, collect=feats)
+    net = Ghiasi()
+    net.load_state_dict(sd, strict=True)
+    net.to(device)
+    out = net(x.to(device), s.to(device))
+    torch.cuda.synchronize()
+    assert out.shape == ref.shape and out.dtype == torch.float32
+    d = (out.cpu() - ref).abs()
+    print("decoder bf16 vs f32 oracle: max abs %.3e, mean abs %.3e" % (float(d.max()), float(d.mean())))
+    # sigmoid image in (0,1): bf16 operands/storage through 16 normalised layers
+    assert float(d.mean()) < 6e-3 and float(d.max()) < 8e-2
+    assert float(out.min()) > 0.0 and float(out.max()) < 1.0
+    # same crop the reference itself produced (golden), through the oracle's tolerance
+    tag = "a" if B == 2 else "b"
+    assert float(np.abs(out[:, :, :16, :16].cpu().numpy() - GOLD[tag + "_out_crop"]).mean()) < 6e-3
+
+
+def test_style_augmentor_surface(device):
+    sd = G.init_state()
+    aug = StyleAugmentor.synthetic(0.5, device, sd, seed=1)
+    x, _ = G.synth_inputs(2, 64, seed=5)
+    torch.manual_seed(3)
+    y = aug(x.to(device))
+    assert y.shape == x.shape and y.device.type == "cuda" and not y.requires_grad
+    # the embedding algebra of styleAugmentor.py:41-63 against the oracle's restatement, same normal draw
+    torch.manual_seed(3)
+    z = torch.randn(2, 100)
+    emb = G.restyle_embedding(z, aug.A.cpu(), aug.mean.cpu(), aug.imagenet_embedding.cpu(), 0.5)
+    with torch.no_grad():
+        ref = G.forward(sd, x, emb)
+    assert float((y.cpu() - ref).abs().mean()) < 6e-3
+    e = aug.sample_embedding(5)
+    assert e.shape == (5, 100)
