@@ -37,6 +37,8 @@ def main():
     ap.add_argument("--graph", action="store_true", help="replay a captured hipGraph instead of enqueuing the launches "
                     "eagerly (eager + side-stream weight gradients is the faster, default mode)")
     ap.add_argument("--no-graph", action="store_true", help=argparse.SUPPRESS)  # old spelling of the default
+    ap.add_argument("--styleaug", action="store_true", help="BASELINE configs[4] flavour: restyle the batch with the Ghiasi "
+                    "decoder on a rank-synchronous coin (p=0.5, alpha=0.5) before the train step (trainer.py:68-69)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=3)
     ap.add_argument("--cpu-threads", type=int, default=32)
@@ -86,19 +88,31 @@ def main():
     step = FusedTrainStep(eng, B, kind="adamw", lr=1e-3, momentum=0.9, weight_decay=0.01, max_norm=1.0,
                           dist_group=group, world_size=world, use_graph=args.graph)
 
+    aug = None
+    if args.styleaug:
+        from speedplusbaseline_amd.styleaug import Ghiasi, StyleAugmentor
+        from speedplusbaseline_amd.parallel import shared_coin
+        torch.manual_seed(2021)
+        aug = StyleAugmentor.synthetic(0.5, dev, Ghiasi().state_dict(), seed=2021)   # random decoder weights (none offline)
+
+    def one_step(i, xs, ys):
+        if aug is not None and shared_coin(i, 2021, 0.5):
+            xs = aug(xs)
+        return step(xs, ys)
+
     def sync_all():
         if world > 1:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step(x, y)
+    for i in range(args.warmup):
+        one_step(i, x, y)
     if step.static_inputs() is not None:  # replay straight from the graph's input buffers
         x, y = step.static_inputs()
     sync_all()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        scal = step(x, y)
+    for i in range(args.steps):
+        scal = one_step(args.warmup + i, x, y)
     sync_all()
     dt = time.perf_counter() - t0
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -197,7 +211,8 @@ def main():
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.precision, "data": "synthetic",
             "config": {"workload": "KRN (MobileNetV2 features + ConvDw extras + 7x7 keypoint head) train step, 224x224, "
-                                   "bs=%d/GPU, AdamW lr 1e-3 wd 0.01 + clip_grad_norm 1.0" % B,
+                                   "bs=%d/GPU, AdamW lr 1e-3 wd 0.01 + clip_grad_norm 1.0" % B +
+                                   (" + style augmentation (Ghiasi decoder, p=0.5, alpha=0.5)" if args.styleaug else ""),
                        "per_gpu_batch": B, "global_batch": B * world, "parallelism": "dp%d" % world,
                        "launch": "hipGraph replay (fwd+bwd | all-reduce | clip+AdamW)" if args.graph else
                                  "eager enqueue, weight-gradient GEMMs on a side stream",

@@ -6,12 +6,24 @@ import logging
 import random
 import time
 
+import torch
+
 from torch.nn.utils import clip_grad_norm_
 
 from ..optim import FusedOptimizer
 from ..utils import AverageMeter, report_progress
 
 logger = logging.getLogger("Training")
+
+
+def _texture_coin(cfg, step):
+    """the reference's per-batch coin (random.random() < cfg.texture_ratio).  Under data parallelism every rank must take
+    the same branch (the decoder adds ~6 ms to the step; a rank that restyles alone stalls the all-reduce of the
+    others), so the draw is a function of (seed, step) there."""
+    if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+        from ..parallel import shared_coin
+        return shared_coin(step, getattr(cfg, "seed", 2021), cfg.texture_ratio)
+    return random.random() < cfg.texture_ratio
 
 
 def train_single_epoch_krn(epoch, cfg, model, data_loader, optimizer, writer, device, styleAugmentor=None, scaler=None):
@@ -27,7 +39,7 @@ def train_single_epoch_krn(epoch, cfg, model, data_loader, optimizer, writer, de
         B = images.shape[0]
         images = images.to(device, non_blocking=True)
         target = target.to(device, non_blocking=True)
-        if styleAugmentor is not None and random.random() < cfg.texture_ratio:
+        if styleAugmentor is not None and _texture_coin(cfg, epoch * n_iter + idx):   # trainer.py:68-69
             images = styleAugmentor(images)
         if fused:
             lx, ly = optimizer.train_step(images, target)[1:3].tolist()  # host floats per step, as the reference reports

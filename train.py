@@ -42,7 +42,14 @@ def main():
     styleAugmentor = None
     if cfg.randomize_texture:
         from speedplusbaseline_amd.styleaug import StyleAugmentor
-        styleAugmentor = StyleAugmentor(cfg.texture_alpha, device)
+        try:
+            styleAugmentor = StyleAugmentor(cfg.texture_alpha, device)
+        except FileNotFoundError:
+            if not getattr(cfg, 'synthetic_batches', 0):
+                raise
+            # synthetic run: random decoder weights and a synthetic embedding distribution (no checkpoints offline)
+            from speedplusbaseline_amd.styleaug import Ghiasi
+            styleAugmentor = StyleAugmentor.synthetic(cfg.texture_alpha, device, Ghiasi().state_dict())
     optimizer = get_optimizer(cfg, model)
     checkpoint_file = osp.join(cfg.savedir, 'checkpoint.pth.tar')
     if cfg.auto_resume and osp.exists(checkpoint_file):
