@@ -616,6 +616,7 @@ int launch_gemm_dma(const spb_gemm_args_t& g, hipStream_t stream) {
 // The LDS-DMA ring variant is kept for experiments (spb_debug_set_gemm_dma(1)); measured in the full KRN step it is
 // slower than the register-prefetch kernel on the small-M layers it was written for (dgrad 1.52 vs 1.38 ms / step).
 bool g_disable_dma = true;
+int g_bk64_min_k = 256;
 
 template <typename T, int PRO, int EPI>
 int dispatch_bn(const spb_gemm_args_t& g, hipStream_t stream) {
@@ -635,6 +636,9 @@ int dispatch_bn(const spb_gemm_args_t& g, hipStream_t stream) {
   if (small_m) {
     if (bn == 32) return launch_gemm<T, 1, 32, 32, PRO, EPI>(g, stream);
     if (g.K >= 64 && sizeof(T) == 2 && !g_disable_dma) return launch_gemm_dma<PRO, EPI>(g, stream);
+    // long reductions (the 7x7 ConvDw layers, K up to 1280): 64-wide chunks halve the number of latency-bound steps
+    // (forward-type only: the backward variant spills 87 dwords at 128 VGPRs with two 64-wide prefetch sets: 0.68 -> 0.75 ms)
+    if (sizeof(T) == 2 && PRO == 1 && g.K >= g_bk64_min_k) return launch_gemm<T, 1, 64, 64, PRO, EPI>(g, stream);
     return launch_gemm<T, 1, 64, 32, PRO, EPI>(g, stream);
   }
   if (bn == 32) return launch_gemm<T, 2, 32, 32, PRO, EPI>(g, stream);
@@ -847,5 +851,6 @@ extern "C" int spb_debug_trread(const unsigned short* in4096, unsigned short* ou
 }
 
 extern "C" int spb_debug_set_gemm_dma(int on) { g_disable_dma = (on == 0); return 0; }
+extern "C" int spb_debug_set_gemm_bk64_min_k(int k) { g_bk64_min_k = k; return 0; }
 
 extern "C" const char* spb_version(void) { return "speedplusbaseline_amd gfx950 r1"; }
