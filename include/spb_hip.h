@@ -335,6 +335,7 @@ int spb_debug_set_dw_mode(int mode); /* depthwise fwd/dgrad: 1 row-unit kernels 
 int spb_debug_set_fused_pw_bwd(int on); /* 0: the KRN plan never uses spb_pwconv_bwd_fused */
 int spb_debug_set_stem_mfma(int on); /* 0: bf16 stem uses the scalar kernels instead of the MFMA implicit GEMM */
 int spb_debug_set_gemm_bk64_min_k(int k); /* small-M bf16 GEMMs with K >= k use 64-wide reduction chunks (default 256) */
+int spb_debug_set_gconv_slab(int on); /* 0: wide decoder convs use the per-wave weight-streaming kernel */
 int spb_debug_set_side_wgrad(int on); /* 0: pointwise weight gradients stay on the launch stream */
 int spb_debug_set_dw_rows(int rows); /* rows per row unit (0: automatic) */
 const char* spb_version(void);

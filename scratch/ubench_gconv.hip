@@ -1,0 +1,31 @@
+// ablation timing of the wide decoder convolution (128->128 3x3 at 56x56, B=48); not part of the product
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I include -DGABL=<bits> scratch/ubench_gconv.hip -o scratch/ubench_gconv_<bits>
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstring>
+#include "../speedplusbaseline_amd/csrc/ghiasi.hip"
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("err %s line %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
+int main() {
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  struct Sh { int B, H, Cin, Cout, K, st, up; } shapes[] = {{48, 56, 128, 128, 3, 1, 1}, {48, 56, 128, 64, 3, 1, 2}, {48, 112, 64, 32, 3, 1, 2}, {48, 224, 32, 3, 9, 1, 1}};
+  printf("GABL=%d\n", GABL);
+  for (auto sh : shapes) {
+    const int Hout = sh.H * sh.up / sh.st;
+    size_t nin = (size_t)sh.B * sh.H * sh.H * sh.Cin, nout = (size_t)sh.B * Hout * Hout * (sh.Cout < 4 ? 4 : sh.Cout);
+    void *x, *w, *y; float *coef, *stats, *bias;
+    CK(hipMalloc(&x, nin * 2)); CK(hipMalloc(&w, (size_t)sh.Cout * sh.K * sh.K * sh.Cin * 2)); CK(hipMalloc(&y, nout * 2));
+    CK(hipMalloc(&coef, sh.B * sh.Cin * 8)); CK(hipMalloc(&stats, sh.B * 128 * 8)); CK(hipMalloc(&bias, 512));
+    CK(hipMemset(x, 0, nin * 2)); CK(hipMemset(w, 0, (size_t)sh.Cout * sh.K * sh.K * sh.Cin * 2)); CK(hipMemset(coef, 0, sh.B * sh.Cin * 8));
+    CK(hipMemset(stats, 0, sh.B * 128 * 8)); CK(hipMemset(bias, 0, 512));
+    spb_gconv_args_t a; std::memset(&a, 0, sizeof(a));
+    a.X = x; a.W = w; a.bias = bias; a.coef = coef; a.Y = y; a.stats = stats; a.B = sh.B; a.Hin = sh.H; a.Win = sh.H; a.Cin = sh.Cin;
+    a.Cout = sh.Cout; a.KH = sh.K; a.stride = sh.st; a.upsample = sh.up; a.relu = 1; a.ldc = sh.Cout < 4 ? 4 : sh.Cout;
+    for (int k = 0; k < 3; ++k) if (spb_gconv(SPB_BF16, &a, 0)) { printf("launch failed\n"); return 1; }
+    CK(hipEventRecord(e0)); for (int k = 0; k < 10; ++k) spb_gconv(SPB_BF16, &a, 0);
+    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    const double fl = 2.0 * sh.B * Hout * Hout * sh.Cout * sh.Cin * sh.K * sh.K;
+    printf("gconv %dx%d %3d->%3d s%d u%d @%3d: %8.2f us  %7.1f TFLOP/s\n", sh.K, sh.K, sh.Cin, sh.Cout, sh.st, sh.up, Hout, ms * 100, fl / (ms / 10 * 1e-3) / 1e12);
+    hipFree(x); hipFree(w); hipFree(y); hipFree(coef); hipFree(stats); hipFree(bias);
+  }
+  return 0;
+}

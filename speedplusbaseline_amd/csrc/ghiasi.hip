@@ -20,9 +20,59 @@
 // bf16 storage and MFMA operands, f32 accumulation.
 #include "common.h"
 
+// ablation switches for scratch/ubench_gconv.hip (0 in the product build): 1 no K loop, 2 no halo staging, 4 no weight
+// slab traffic, 8 no MFMA (fragment reads only), 16 no barrier in the K loop
+#ifndef GABL
+#define GABL 0
+#endif
+
 namespace {
 
 __device__ __forceinline__ int reflecti(int i, int n) { i = i < 0 ? -i : i; return i >= n ? 2 * n - 2 - i : i; }
+
+// Stage `count` halo vectors (8 channels each) of PXG tiles: upsample (nearest), reflect, normalise + activate, bf16.
+// Loads are issued SU at a time before any of them is consumed (a load -> transform -> store loop exposed one L2 round
+// trip per iteration: 25 iterations x ~1.5 us per workgroup in the 128-channel layers).
+template <int PXG, int SU>
+__device__ __forceinline__ void stage_halo(const spb_gconv_args_t& g, const bf16_t* X, bf16_t* halo, const float* cf, int b,
+                                           const int* oy0, const int* ox0, int HT, int LDP, int Hu, int Wu, int st, int up,
+                                           int pad, int t) {
+  const int Cin = g.Cin, CV = Cin >> 3;
+  const int per = HT * HT * CV, total = PXG * per;
+  for (int i0 = t; i0 < total; i0 += 256 * SU) {
+    Raw8<bf16_t> r[SU];
+    int dst[SU], cvs[SU];
+#pragma unroll
+    for (int u = 0; u < SU; ++u) {
+      const int i = i0 + 256 * u;
+      const int ic = i < total ? i : total - 1;
+      const int p = ic / per, ii = ic % per;
+      const int hp = ii / CV, cv = ii % CV;
+      const int hy = hp / HT, hx = hp % HT;
+      const int sy = reflecti(oy0[p] * st - pad + hy, Hu) / up, sx = reflecti(ox0[p] * st - pad + hx, Wu) / up;
+      r[u] = ldraw<bf16_t>(X + ((size_t)(b * g.Hin + sy) * g.Win + sx) * Cin + cv * 8);
+      dst[u] = i < total ? (p * HT * HT + hp) * LDP + cv * 8 : -1;
+      cvs[u] = cv;
+    }
+#pragma unroll
+    for (int u = 0; u < SU; ++u) {
+      if (dst[u] < 0) continue;
+      float v[8], sc[8], sh[8];
+      cvt8(r[u], v);
+#pragma unroll
+      for (int j = 0; j < 8; j += 4) {
+        *reinterpret_cast<float4*>(sc + j) = *reinterpret_cast<const float4*>(cf + cvs[u] * 8 + j);
+        *reinterpret_cast<float4*>(sh + j) = *reinterpret_cast<const float4*>(cf + Cin + cvs[u] * 8 + j);
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float uu = v[j] * sc[j] + sh[j];
+        v[j] = g.relu ? fmaxf(uu, 0.f) : uu;
+      }
+      st8<bf16_t>(halo + dst[u], v);
+    }
+  }
+}
 
 // ---------------------------------------------------------------------------------------------- implicit-GEMM conv
 // WLDS: the whole weight tensor sits in LDS (<= 64 KB: the 32/64-channel layers); otherwise weights stream from L2 with a
@@ -59,13 +109,14 @@ __global__ __launch_bounds__(256) void gconv_kernel(const spb_gconv_args_t g, in
   for (int c = t; c < Cin; c += 256) {
     float sc = 1.f, sh = 0.f;
     if (g.coef) { sc = g.coef[((size_t)b * Cin + c) * 2]; sh = g.coef[((size_t)b * Cin + c) * 2 + 1]; }
-    cf[c * 2] = sc; cf[c * 2 + 1] = sh;
+    cf[c] = sc; cf[Cin + c] = sh;
   }
   if (WLDS) {   // Cout rows; lanes whose (permuted) row is >= Cout use a zero fragment
     const int RV = (KK * Cin) >> 3;
-    for (int i = t; i < Cout * RV; i += 256) {
+    for (int i = t; i < Cout * RV; i += 256) {   // LDS rows in fragment order [nb][li]: conflict-free fragment reads
       const int r = i / RV, v = i % RV;
-      *reinterpret_cast<uint4*>(wl + r * LDW + v * 8) = *reinterpret_cast<const uint4*>(Wg + (size_t)r * KK * Cin + v * 8);
+      const int slot = ((r % (4 * NB)) >> 2) * 16 + (r / (4 * NB)) * 4 + (r & 3);
+      *reinterpret_cast<uint4*>(wl + slot * LDW + v * 8) = *reinterpret_cast<const uint4*>(Wg + (size_t)r * KK * Cin + v * 8);
     }
   }
   const bf16_t* X = reinterpret_cast<const bf16_t*>(g.X);
@@ -84,7 +135,11 @@ __global__ __launch_bounds__(256) void gconv_kernel(const spb_gconv_args_t g, in
     wco[nb] = wok[nb] ? co : 0;
   }
   const int co0 = lq * 4 * NB;
-  for (int i = t; i < 4 * NB * 16 * 2; i += 256) red[i] = 0.f;   // per-wave (image, channel) sums, kept in LDS
+  float s1[NB][4], s2[NB][4];   // sums of the stored values over all tiles of this workgroup, reduced once at the end
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { s1[nb][e] = 0.f; s2[nb][e] = 0.f; }
 
   for (int ti = 0; ti < tpw; ++ti) {
     int oy0[PXG], ox0[PXG];
@@ -97,21 +152,8 @@ __global__ __launch_bounds__(256) void gconv_kernel(const spb_gconv_args_t g, in
       oy0[p] = (tr / tiles_x) * 8; ox0[p] = (tr % tiles_x) * 8;
     }
     __syncthreads();   // previous tile's taps are done with the halo (first pass: coefficient / weight tables written)
-    // ---- stage the input halo(s): upsample (nearest), reflect, normalise + activate, bf16
-    for (int i = t; i < PXG * HT * HT * CV; i += 256) {
-      const int p = i / (HT * HT * CV), ii = i % (HT * HT * CV);
-      const int hp = ii / CV, cv = ii % CV;
-      const int hy = hp / HT, hx = hp % HT;
-      const int sy = reflecti(oy0[PXG > 1 ? p : 0] * st - pad + hy, Hu) / up, sx = reflecti(ox0[PXG > 1 ? p : 0] * st - pad + hx, Wu) / up;
-      float v[8];
-      ld8<bf16_t>(X + ((size_t)(b * g.Hin + sy) * g.Win + sx) * Cin + cv * 8, v);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        float u = v[j] * cf[(cv * 8 + j) * 2] + cf[(cv * 8 + j) * 2 + 1];
-        v[j] = g.relu ? fmaxf(u, 0.f) : u;
-      }
-      st8<bf16_t>(halo + (p * HT * HT + hp) * LDP + cv * 8, v);
-    }
+    // ---- stage the input halo(s)
+    stage_halo<PXG, 4>(g, X, halo, cf, b, oy0, ox0, HT, LDP, Hu, Wu, st, up, pad, t);
     __syncthreads();
     // ---- K loop: taps x 32-channel chunks.  lane (li, lq): pixel li of this wave's 2x8 strip, channels lq*8..+7
     f32x4_t acc[PXG][NB];
@@ -129,7 +171,7 @@ __global__ __launch_bounds__(256) void gconv_kernel(const spb_gconv_args_t g, in
         const int ko = (ky * KH + kx) * Cin + cc * 32 + lq * 8;
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
-          uint4 au = *reinterpret_cast<const uint4*>(wl + wco[nb] * LDW + ko);
+          uint4 au = *reinterpret_cast<const uint4*>(wl + (wok[nb] ? nb * 16 + li : 0) * LDW + ko);
           if (!wok[nb]) au = make_uint4(0, 0, 0, 0);
 #pragma unroll
           for (int p = 0; p < PXG; ++p)
@@ -173,12 +215,13 @@ __global__ __launch_bounds__(256) void gconv_kernel(const spb_gconv_args_t g, in
         }
       }
     }
-    // ---- epilogue: lane (li = pixel, lq): channels lq*4*NB + nb*4 + e
+    // ---- epilogue: lane (li = pixel, lq): channels lq*4*NB + nb*4 + e -- one contiguous run, 16-byte stores
 #pragma unroll
     for (int p = 0; p < PXG; ++p) {
       if (!tvalid[p]) continue;
       const int oy = oy0[p] + prow, ox = ox0[p] + pcol;
       bf16_t* dst = Y + ((size_t)(b * Hout + oy) * Wout + ox) * g.ldc + co0;
+      uint2 o[NB];
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) {
         float v[4];
@@ -187,25 +230,36 @@ __global__ __launch_bounds__(256) void gconv_kernel(const spb_gconv_args_t g, in
           const int co = co0 + nb * 4 + e;
           v[e] = acc[p][nb][e] + ((g.bias && co < Cout) ? g.bias[co] : 0.f);
         }
-        uint2 o;
-        o.x = pack_bf16x2(v[0], v[1]); o.y = pack_bf16x2(v[2], v[3]);
-        if (co0 + nb * 4 < g.ldc) *reinterpret_cast<uint2*>(dst + nb * 4) = o;
-        if (g.stats) {   // sums of the stored values: 16-lane butterfly, then the owning lane adds into its wave's LDS slot
-          const float r[4] = {__uint_as_float(o.x << 16), __uint_as_float(o.x & 0xffff0000u), __uint_as_float(o.y << 16),
-                              __uint_as_float(o.y & 0xffff0000u)};
+        o[nb].x = pack_bf16x2(v[0], v[1]); o[nb].y = pack_bf16x2(v[2], v[3]);
+        const float r[4] = {__uint_as_float(o[nb].x << 16), __uint_as_float(o[nb].x & 0xffff0000u),
+                            __uint_as_float(o[nb].y << 16), __uint_as_float(o[nb].y & 0xffff0000u)};
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            float a1 = r[e], a2 = r[e] * r[e];
+        for (int e = 0; e < 4; ++e) { s1[nb][e] += r[e]; s2[nb][e] += r[e] * r[e]; }
+      }
+      if constexpr ((NB & 1) == 0) {
 #pragma unroll
-            for (int o2 = 1; o2 < 16; o2 <<= 1) { a1 += __shfl_xor(a1, o2, 16); a2 += __shfl_xor(a2, o2, 16); }
-            if (li == 0) {
-              red[(wave * NB * 16 + co0 + nb * 4 + e) * 2] += a1;
-              red[(wave * NB * 16 + co0 + nb * 4 + e) * 2 + 1] += a2;
-            }
-          }
-        }
+        for (int nb = 0; nb < NB; nb += 2)
+          if (co0 + nb * 4 < g.ldc) *reinterpret_cast<uint4*>(dst + nb * 4) = make_uint4(o[nb].x, o[nb].y, o[nb + 1].x, o[nb + 1].y);
+      } else {
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+          if (co0 + nb * 4 < g.ldc) *reinterpret_cast<uint2*>(dst + nb * 4) = o[nb];
       }
     }
+  }
+  if (g.stats) {
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float a1 = s1[nb][e], a2 = s2[nb][e];
+#pragma unroll
+        for (int o2 = 1; o2 < 16; o2 <<= 1) { a1 += __shfl_xor(a1, o2, 16); a2 += __shfl_xor(a2, o2, 16); }
+        if (li == 0) {
+          red[(wave * NB * 16 + co0 + nb * 4 + e) * 2] = a1;
+          red[(wave * NB * 16 + co0 + nb * 4 + e) * 2 + 1] = a2;
+        }
+      }
   }
   if (g.stats) {   // 4 waves -> one atomic per (image, channel, moment) and workgroup
     __syncthreads();
@@ -215,6 +269,183 @@ __global__ __launch_bounds__(256) void gconv_kernel(const spb_gconv_args_t g, in
         atomicAdd(g.stats + ((size_t)b * Cout + co) * 2 + (i & 1),
                   red[i] + red[NB * 32 + i] + red[2 * NB * 32 + i] + red[3 * NB * 32 + i]);
     }
+  }
+}
+
+// ------------------------------------------------------------------------------------ implicit-GEMM conv, wide layers
+// The 128-channel layers (weights 147..295 KB: not LDS resident).  Each wave computes FOUR 8x8 tiles' worth of its two
+// rows (64 pixels x all output channels): every weight fragment read feeds 4 MFMAs and every pixel fragment NB of them,
+// so per 32-channel step a wave issues 32 MFMAs (512 matrix-core cycles) for 12 KB of LDS reads.  The step's weight slab
+// [Cout x 32] is fetched from L2 ONCE per workgroup (cooperatively, through registers, double-buffered in LDS; one barrier
+// per step) instead of once per wave: the per-wave variant above was bound by L1 bandwidth at 149 TFLOP/s.
+template <int NB>
+__global__ __launch_bounds__(256, 1) void gconv_slab_kernel(const spb_gconv_args_t g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int PXG = 4, ROWS = NB * 16, SLD = 40;             // slab row = 32 k + 8 pad (bf16)
+  constexpr int SPT = (ROWS * 4 + 255) / 256;                  // 16-byte slab granules per thread
+  const int Cin = g.Cin, Cout = g.Cout, KH = g.KH, st = g.stride, up = g.upsample;
+  const int Hu = g.Hin * up, Wu = g.Win * up;
+  const int Hout = Hu / st, Wout = Wu / st;
+  const int pad = KH / 2;
+  const int HT = 7 * st + KH;
+  const int LDP = Cin + 8;
+  const int KK = KH * KH;
+  float* cf = reinterpret_cast<float*>(smem);                 // [Cin][2]
+  float* red = cf + Cin * 2;                                  // [4 waves][ROWS][2]
+  bf16_t* slab = reinterpret_cast<bf16_t*>(red + 4 * ROWS * 2);   // [2][ROWS][SLD]
+  bf16_t* halo = slab + 2 * ROWS * SLD;                       // [PXG][HT*HT][LDP]
+  const int t = threadIdx.x, lane = t & 63, li = lane & 15, lq = lane >> 4, wave = t >> 6;
+  const int tiles_x = Wout >> 3, tiles_y = Hout >> 3;
+  const int tpi = tiles_x * tiles_y;
+  const int gpi = (tpi + PXG - 1) / PXG;
+  const int b = blockIdx.x / gpi;
+  const int grp = blockIdx.x % gpi;
+  const bf16_t* Wg = reinterpret_cast<const bf16_t*>(g.W);
+  const bf16_t* X = reinterpret_cast<const bf16_t*>(g.X);
+  bf16_t* Y = reinterpret_cast<bf16_t*>(g.Y);
+
+  for (int c = t; c < Cin; c += 256) {
+    float sc = 1.f, sh = 0.f;
+    if (g.coef) { sc = g.coef[((size_t)b * Cin + c) * 2]; sh = g.coef[((size_t)b * Cin + c) * 2 + 1]; }
+    cf[c] = sc; cf[Cin + c] = sh;
+  }
+  for (int i = t; i < 4 * ROWS * 2; i += 256) red[i] = 0.f;
+  int oy0[PXG], ox0[PXG];
+  bool tvalid[PXG];
+#pragma unroll
+  for (int p = 0; p < PXG; ++p) {
+    int tr = grp * PXG + p;
+    tvalid[p] = tr < tpi;
+    tr = tvalid[p] ? tr : tpi - 1;
+    oy0[p] = (tr / tiles_x) * 8; ox0[p] = (tr % tiles_x) * 8;
+  }
+  // slab granules of this thread: row, 16-byte part
+  int srow[SPT], spart[SPT];
+#pragma unroll
+  for (int j = 0; j < SPT; ++j) {
+    const int gidx = t + 256 * j;
+    srow[j] = (gidx >> 2) < ROWS ? (gidx >> 2) : ROWS - 1; spart[j] = gidx & 3;
+  }
+  // LDS slot of weight row r: fragment order [nb][li] (li = (r / 4NB) * 4 + r % 4, nb = (r % 4NB) / 4), so that the 16 rows
+  // of one A fragment are contiguous (with the natural order they are 4NB rows apart = a multiple of 256 B: 4-way bank
+  // conflicts on every fragment read)
+  int sslot[SPT];
+#pragma unroll
+  for (int j = 0; j < SPT; ++j) {
+    const int r = srow[j];
+    sslot[j] = (((r % (4 * NB)) >> 2) * 16 + (r / (4 * NB)) * 4 + (r & 3)) * SLD + spart[j] * 8;
+  }
+  const int nch = Cin >> 5;
+  const int nsteps = (GABL & 1) ? 0 : KK * nch;
+  // weight slabs travel global -> registers -> LDS three steps ahead (one step ahead left the L2 round trip exposed on
+  // every step: 36 x ~1.5 us per workgroup, 10 % matrix-core utilisation); nsteps is a multiple of 3 (9 taps x Cin/32)
+  uint4 sreg[3][SPT];
+#pragma unroll
+  for (int d = 0; d < 3; ++d)
+#pragma unroll
+    for (int j = 0; j < SPT; ++j)
+      sreg[d][j] = *reinterpret_cast<const uint4*>(Wg + (size_t)srow[j] * KK * Cin + (size_t)d * 32 + spart[j] * 8);
+  __syncthreads();
+  // ---- stage the four input halos
+  if (!(GABL & 2)) stage_halo<PXG, 5>(g, X, halo, cf, b, oy0, ox0, HT, LDP, Hu, Wu, st, up, pad, t);
+#pragma unroll
+  for (int j = 0; j < SPT; ++j)
+    if (t + 256 * j < ROWS * 4) *reinterpret_cast<uint4*>(slab + sslot[j]) = sreg[0][j];
+  __syncthreads();
+
+  const int prow = wave * 2 + (li >> 3), pcol = li & 7;
+  const bf16_t* hbase = halo + ((prow * st) * HT + pcol * st) * LDP + lq * 8;
+  int arow[NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) arow[nb] = (nb * 16 + li) * SLD + lq * 8;
+  f32x4_t acc[PXG][NB];
+#pragma unroll
+  for (int p = 0; p < PXG; ++p)
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) acc[p][nb] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  int ky = 0, kx = 0, cc = 0;
+  for (int s0 = 0; s0 < nsteps; s0 += 3) {
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      const int s = s0 + d;
+      const bf16_t* sl = slab + (s & 1) * ROWS * SLD;
+      bf16x8_t bf[PXG];
+#pragma unroll
+      for (int p = 0; p < PXG; ++p)
+        bf[p] = *reinterpret_cast<const bf16x8_t*>(hbase + (p * HT * HT + ky * HT + kx) * LDP + cc * 32);
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        const bf16x8_t af = *reinterpret_cast<const bf16x8_t*>(sl + arow[nb]);
+#pragma unroll
+        for (int p = 0; p < PXG; ++p) {
+          if (GABL & 8) acc[p][nb][0] += (float)af[0] * (float)bf[p][0];
+          else acc[p][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bf[p], acc[p][nb], 0, 0, 0);
+        }
+      }
+      if (!(GABL & 4) && s + 1 < nsteps) {   // slab of step s+1 (fetched during step s-2) -> the other LDS buffer
+        bf16_t* sn = slab + ((s + 1) & 1) * ROWS * SLD;
+#pragma unroll
+        for (int j = 0; j < SPT; ++j)
+          if (t + 256 * j < ROWS * 4) *reinterpret_cast<uint4*>(sn + sslot[j]) = sreg[(d + 1) % 3][j];
+      }
+      if (!(GABL & 4) && s + 3 < nsteps) {   // and the fetch of step s+3 takes the register set step s just released
+#pragma unroll
+        for (int j = 0; j < SPT; ++j)
+          sreg[d][j] = *reinterpret_cast<const uint4*>(Wg + (size_t)srow[j] * KK * Cin + (size_t)(s + 3) * 32 + spart[j] * 8);
+      }
+      if (!(GABL & 16)) __syncthreads();
+      if (++cc == nch) { cc = 0; if (++kx == KH) { kx = 0; ++ky; } }
+    }
+  }
+  // ---- epilogue: each lane owns 4*NB consecutive channels of its pixel -> 16-byte stores (8-byte stores, one per
+  // accumulator, cost 62 us of the 235 us launch: 64 scattered 8-byte pieces per instruction); the sums of the stored
+  // values are accumulated over the four tiles first and reduced once (per-tile butterflies: 41 us)
+  const int co0 = lq * 4 * NB;
+  float s1[NB][4], s2[NB][4];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { s1[nb][e] = 0.f; s2[nb][e] = 0.f; }
+#pragma unroll
+  for (int p = 0; p < PXG; ++p) {
+    if (!tvalid[p] || (GABL & 64)) continue;
+    const int oy = oy0[p] + prow, ox = ox0[p] + pcol;
+    bf16_t* dst = Y + ((size_t)(b * Hout + oy) * Wout + ox) * g.ldc + co0;
+    uint2 o[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+      float v[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = acc[p][nb][e] + (g.bias ? g.bias[co0 + nb * 4 + e] : 0.f);
+      o[nb].x = pack_bf16x2(v[0], v[1]); o[nb].y = pack_bf16x2(v[2], v[3]);
+      const float r[4] = {__uint_as_float(o[nb].x << 16), __uint_as_float(o[nb].x & 0xffff0000u), __uint_as_float(o[nb].y << 16),
+                          __uint_as_float(o[nb].y & 0xffff0000u)};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { s1[nb][e] += r[e]; s2[nb][e] += r[e] * r[e]; }
+    }
+#pragma unroll
+    for (int nb = 0; nb < NB; nb += 2)
+      *reinterpret_cast<uint4*>(dst + nb * 4) = make_uint4(o[nb].x, o[nb].y, o[nb + 1].x, o[nb + 1].y);
+  }
+  if (g.stats && !(GABL & 32)) {
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float a1 = s1[nb][e], a2 = s2[nb][e];
+#pragma unroll
+        for (int o2 = 1; o2 < 16; o2 <<= 1) { a1 += __shfl_xor(a1, o2, 16); a2 += __shfl_xor(a2, o2, 16); }
+        if (li == 0) {
+          red[(wave * ROWS + co0 + nb * 4 + e) * 2] = a1;
+          red[(wave * ROWS + co0 + nb * 4 + e) * 2 + 1] = a2;
+        }
+      }
+  }
+  if (g.stats) {
+    __syncthreads();
+    for (int i = t; i < ROWS * 2; i += 256)
+      atomicAdd(g.stats + ((size_t)b * Cout + (i >> 1)) * 2 + (i & 1),
+                red[i] + red[ROWS * 2 + i] + red[2 * ROWS * 2 + i] + red[3 * ROWS * 2 + i]);
   }
 }
 
@@ -370,6 +601,9 @@ __global__ void final_sigmoid_kernel(const bf16_t* Z, const float* coef, float* 
 
 }  // namespace
 
+static int g_gconv_slab = 1;
+extern "C" int spb_debug_set_gconv_slab(int on) { g_gconv_slab = on; return 0; }
+
 extern "C" int spb_gconv(int dtype, const spb_gconv_args_t* a, spb_stream_t stream) {
   if (!a || !a->X || !a->W || !a->Y) return SPB_E_ARG;
   if (dtype != SPB_BF16) return SPB_E_UNSUPPORTED;
@@ -382,9 +616,30 @@ extern "C" int spb_gconv(int dtype, const spb_gconv_args_t* a, spb_stream_t stre
   if (a->KH / 2 >= Hu || a->KH / 2 >= Wu) return SPB_E_SHAPE;   // reflection padding needs pad < size
   const int HT = 7 * a->stride + a->KH, KK = a->KH * a->KH;
   const int NB = a->Cout <= 16 ? 1 : (a->Cout <= 32 ? 2 : (a->Cout <= 64 ? 4 : 8));
-  const size_t wbytes = (size_t)a->Cout * (KK * a->Cin + 8) * 2;
+  // fragment-order slots span all NB*16 rows (NB == 1: slot == row, Cout rows are enough)
+  const size_t wbytes = (size_t)(NB == 1 ? a->Cout : NB * 16) * (KK * a->Cin + 8) * 2;
   const bool wlds = wbytes <= 64 * 1024;
   if (!wlds && a->Cout != NB * 16) return SPB_E_SHAPE;   // the streaming variant has no zero rows
+  if (!wlds) {   // wide layers: shared weight slab, four tiles per workgroup
+    const int tpi4 = (Hout >> 3) * (Wout >> 3);
+    const int gpi4 = (tpi4 + 3) / 4;
+    const size_t lds4 = (size_t)a->Cin * 2 * sizeof(float) + (size_t)4 * NB * 16 * 2 * sizeof(float) +
+                        (size_t)2 * NB * 16 * 40 * 2 + (size_t)4 * HT * HT * (a->Cin + 8) * 2;
+    if (lds4 <= 160 * 1024 && (NB == 4 || NB == 8) && g_gconv_slab && (KK * (a->Cin >> 5)) % 3 == 0) {
+      const dim3 grid4((unsigned)(a->B * gpi4));
+      hipStream_t s4 = (hipStream_t)stream;
+      static bool once4 = false, once8 = false;
+      if (NB == 4) {
+        if (!once4) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gconv_slab_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); once4 = true; }
+        hipLaunchKernelGGL((gconv_slab_kernel<4>), grid4, dim3(256), lds4, s4, *a);
+      } else {
+        if (!once8) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gconv_slab_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); once8 = true; }
+        hipLaunchKernelGGL((gconv_slab_kernel<8>), grid4, dim3(256), lds4, s4, *a);
+      }
+      SPB_CHECK_LAUNCH();
+      return 0;
+    }
+  }
   const int pxg = wlds ? 1 : 2;
   const size_t lds = (size_t)a->Cin * 2 * sizeof(float) + (size_t)4 * NB * 16 * 2 * sizeof(float) +
                      (size_t)pxg * HT * HT * (a->Cin + 8) * 2 + (wlds ? wbytes : 0);
