@@ -94,14 +94,16 @@ __global__ __launch_bounds__(256, 1) void pwb_kernel(const spb_pwbwd_args_t g, l
     pep[i] = sc; pep[KW + i] = sh; pep[2 * KW + i] = mu; pep[3 * KW + i] = is;
     pa[i] = asc; pa[KW + i] = ash;
   }
-  // W^T fragments (A operand of the input-gradient MFMA): lane (li, lq) = row k0+kb*16+li, columns ns*32+lq*8..+7
+  // W^T fragments (A operand of the input-gradient MFMA), rows permuted: fragment kb, lane row li  <->  input channel
+  // k0 + (li>>2)*4*KB + kb*4 + (li&3).  The KB accumulators of a lane then cover 4*KB CONSECUTIVE channels of its row:
+  // 16-byte output stores instead of one scattered 8-byte store per accumulator (64 pieces per instruction).
   const bf16_t* Wt = reinterpret_cast<const bf16_t*>(g.Wt);
   bf16x8_t Wf[KB][NS];
 #pragma unroll
   for (int kb = 0; kb < KB; ++kb)
 #pragma unroll
     for (int ns = 0; ns < NS; ++ns) {
-      const int k = k0 + kb * 16 + li, n = ns * 32 + lq * 8;
+      const int k = k0 + (li >> 2) * 4 * KB + kb * 4 + (li & 3), n = ns * 32 + lq * 8;
       uint4 u = make_uint4(0, 0, 0, 0);
       if (k < K && n < N) u = *reinterpret_cast<const uint4*>(Wt + (size_t)k * N + n);
       Wf[kb][ns] = __builtin_bit_cast(bf16x8_t, u);
@@ -204,9 +206,10 @@ __global__ __launch_bounds__(256, 1) void pwb_kernel(const spb_pwbwd_args_t g, l
       }
       const int row = h * 16 + li;
       const long long m = m0 + row;
+      uint2 oo[KB];
 #pragma unroll
       for (int kb = 0; kb < KB; ++kb) {
-        const int kl = kb * 16 + lq * 4, k = k0 + kl;
+        const int kl = lq * 4 * KB + kb * 4, k = k0 + kl;    // lane (li = row, lq): channels lq*4*KB + kb*4 + i
         const bool ok = m < M && k < K;
         float zf[4], xf[4], sc[4], sh[4], asc[4], ash[4], v[4], a[4];
         const uint2 zraw = *reinterpret_cast<const uint2*>(st + L.oZo + (row * KW + kl) * 2);
@@ -238,11 +241,26 @@ __global__ __launch_bounds__(256, 1) void pwb_kernel(const spb_pwbwd_args_t g, l
         for (int i = 0; i < 4; ++i) v[i] *= act_grad(zf[i] * sc[i] + sh[i], eact, eslope);
         uint2 o;
         o.x = pack_bf16x2(v[0], v[1]); o.y = pack_bf16x2(v[2], v[3]);
+        oo[kb] = o;
         unpack4(o, v);                                     // the rounded values are what the sums must see
         if (ok) {
 #pragma unroll
           for (int i = 0; i < 4; ++i) { s1[kb][i] += v[i]; s2[kb][i] += v[i] * zf[i]; }
-          *reinterpret_cast<uint2*>(Y + (size_t)m * K + k) = o;
+        }
+      }
+      if (m < M) {   // one contiguous run of 4*KB channels per lane (16-byte aligned when KB is even)
+        bf16_t* dst = Y + (size_t)m * K + k0 + lq * 4 * KB;
+        const int kbase = k0 + lq * 4 * KB;
+        if constexpr ((KB & 1) == 0) {
+#pragma unroll
+          for (int kb = 0; kb < KB; kb += 2) {
+            if (kbase + kb * 4 + 4 < K) *reinterpret_cast<uint4*>(dst + kb * 4) = make_uint4(oo[kb].x, oo[kb].y, oo[kb + 1].x, oo[kb + 1].y);
+            else if (kbase + kb * 4 < K) *reinterpret_cast<uint2*>(dst + kb * 4) = oo[kb];
+          }
+        } else {
+#pragma unroll
+          for (int kb = 0; kb < KB; ++kb)
+            if (kbase + kb * 4 < K) *reinterpret_cast<uint2*>(dst + kb * 4) = oo[kb];
         }
       }
     }
@@ -290,8 +308,8 @@ __global__ __launch_bounds__(256, 1) void pwb_kernel(const spb_pwbwd_args_t g, l
 #pragma unroll
       for (int o = 1; o < 16; o <<= 1) { a += __shfl_xor(a, o, 16); b += __shfl_xor(b, o, 16); }
       if (li == 0) {
-        red[(wave * 2 + 0) * KW + kb * 16 + lq * 4 + i] = a;
-        red[(wave * 2 + 1) * KW + kb * 16 + lq * 4 + i] = b;
+        red[(wave * 2 + 0) * KW + lq * 4 * KB + kb * 4 + i] = a;
+        red[(wave * 2 + 1) * KW + lq * 4 * KB + kb * 4 + i] = b;
       }
     }
   __syncthreads();
