@@ -1,0 +1,63 @@
+"""Generates tests/golden/spn_golden.npz by IMPORTING the reference's own src/nets/spn.py (read-only at /root/reference;
+no stubs needed) with pretrain=False.  Only data travels: weights/inputs come from the portable RNG recipe, outputs are
+stored as arrays.  num_classes=64 keeps the fixture small (the class count only sizes fc8/fc11).
+
+Run:  python tests/golden/make_golden_spn.py
+"""
+import importlib.util
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+from oracle import spn_oracle as S  # noqa: E402
+
+spec = importlib.util.spec_from_file_location("ref_spn", "/root/reference/src/nets/spn.py")
+ref = importlib.util.module_from_spec(spec)
+spec.loader.exec_module(ref)
+
+
+def main():
+    NC = 64
+    net = ref.SpacecraftPoseNet(NC, keep_prob=0.5, pretrain=False)
+    sd = S.init_state(NC)
+    assert list(net.state_dict().keys()) == list(sd.keys())
+    net.load_state_dict(sd, strict=True)
+    out = {"keys": np.array(list(sd.keys())), "n_params_5000": np.int64(sum(int(np.prod(s)) for s in S.param_shapes(5000).values()))}
+    x, yc, yw = S.synth_batch(2, NC, seed=11)
+    net.eval()
+    feats = {}
+    hooks = [getattr(net, n).register_forward_hook(lambda m, a, o, n=n: feats.__setitem__(n, o.detach().clone()))
+             for n in ("norm1", "norm2", "pool5", "conv3")]
+    with torch.no_grad():
+        c, r = net(x)
+    for h in hooks:
+        h.remove()
+    out["eval_c"] = c.numpy(); out["eval_r"] = r.numpy()
+    for n in ("norm1", "norm2", "pool5"):
+        out["eval_%s_sum" % n] = np.array(S.checksum(feats[n]))
+    out["eval_norm1_crop"] = feats["norm1"][:, :6, :5, :5].numpy()
+    out["loss_mean"] = np.float64(ref.softmax_cross_entropy_with_logits(c, yc, "mean"))
+    out["loss_sum"] = np.float64(ref.softmax_cross_entropy_with_logits(r, yw, "sum"))
+    out["loss_none"] = ref.softmax_cross_entropy_with_logits(c, yw, "none").numpy()
+    # training-mode gradient with dropout disabled through p=0 modules is not the reference's path; instead pin the
+    # eval-mode gradient (dropout identity) of the reference loss assembly (trainer.py:160-165)
+    net.zero_grad()
+    c, r = net(x)
+    loss = ref.softmax_cross_entropy_with_logits(c, yc, "mean") + 10.0 * ref.softmax_cross_entropy_with_logits(r, yw, "mean")
+    loss.backward()
+    out["grad_loss"] = np.float64(loss.detach())
+    for k, p in net.named_parameters():
+        out["grad_sum/" + k] = np.array(S.checksum(p.grad))
+    out["grad_conv1_crop"] = net.conv1.weight.grad[:4, :, :3, :3].numpy()
+    out["grad_fc8_crop"] = net.fc8.weight.grad[:8, :16].numpy()
+    np.savez_compressed(os.path.join(HERE, "spn_golden.npz"), **out)
+    print("wrote spn_golden.npz", out["n_params_5000"], float(out["grad_loss"]))
+
+
+if __name__ == "__main__":
+    main()
