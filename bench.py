@@ -37,6 +37,8 @@ def main():
     ap.add_argument("--graph", action="store_true", help="replay a captured hipGraph instead of enqueuing the launches "
                     "eagerly (eager + side-stream weight gradients is the faster, default mode)")
     ap.add_argument("--no-graph", action="store_true", help=argparse.SUPPRESS)  # old spelling of the default
+    ap.add_argument("--model", default="krn", choices=["krn", "spn"], help="krn: the headline benchmark (BASELINE configs[1]); "
+                    "spn: Spacecraft Pose Network train step, 227x227, bs=32, 5000 classes (configs[5] flavour, 1 GPU)")
     ap.add_argument("--styleaug", action="store_true", help="BASELINE configs[4] flavour: restyle the batch with the Ghiasi "
                     "decoder on a rank-synchronous coin (p=0.5, alpha=0.5) before the train step (trainer.py:68-69)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -44,6 +46,8 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=32)
     args = ap.parse_args()
 
+    if args.model == "spn":
+        return bench_spn(args)
     from speedplusbaseline_amd.engine import KrnEngine
     from speedplusbaseline_amd.step import FusedTrainStep
     from oracle import krn_oracle as O  # checker / cpu_baseline leg only
@@ -222,6 +226,43 @@ def main():
         print(json.dumps(out))
     if world > 1:
         torch.distributed.destroy_process_group()
+
+
+def bench_spn(args):
+    """SPN train step (trainer.py:114-199): forward, soft-target CE x2, backward, clip_grad_value_(1.0), AdamW; one GPU."""
+    from speedplusbaseline_amd.nets.spn import SpacecraftPoseNet
+    from speedplusbaseline_amd.optim import SpnOptimizer
+    from speedplusbaseline_amd.data import SyntheticSpnLoader
+    if args.gpus != 1 or int(os.environ.get("WORLD_SIZE", "1")) != 1:
+        raise SystemExit("--model spn is a single-GPU measurement (the SPN gradient exchange is not built yet)")
+    dev = torch.device("cuda", 0)
+    B = 32 if args.batch == 48 else args.batch
+    torch.manual_seed(2021)
+    net = SpacecraftPoseNet(5000, keep_prob=0.5, pretrain=False, precision=args.precision).to(dev).train()
+    opt = SpnOptimizer(list(net.parameters()), kind="adamw", lr=1e-4, momentum=0.9, weight_decay=0.0, model=net)
+    x, yc, yw = next(iter(SyntheticSpnLoader(B, 1, 5000, 5)))
+    x, yc, yw = x.to(dev), yc.to(dev), yw.to(dev)
+
+    def one():
+        out = net.loss_and_grads(x, yc, yw)
+        opt.step()
+        return out
+    for _ in range(args.warmup):
+        one()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = one()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    print(json.dumps({
+        "metric": "images/sec SPN 227x227 bs=32/GPU train step", "value": round(B * args.steps / dt, 1), "unit": "images/sec",
+        "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+        "config": {"workload": "SPN (AlexNet trunk + two 5000-class attitude heads) train step, 227x227, bs=%d, AdamW + "
+                               "clip_grad_value 1.0, dropout 0.5" % B, "per_gpu_batch": B, "weights": "random init",
+                   "loss_last_step": [float(v) for v in out.cpu()]},
+        "roofline": None, "cpu_baseline": None}))
 
 
 if __name__ == "__main__":

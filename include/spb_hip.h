@@ -328,6 +328,38 @@ int spb_in_apply(const void* X, const float* coef, const void* res, void* Y, int
 /* out (fp32 NCHW, 3 channels) = sigmoid(Z*scale + shift), Z NHWC bf16 with channel stride ldc (ghiasi.py:135) */
 int spb_final_sigmoid(const void* Z, const float* coef, float* out, int B, long long hw, int ldc, spb_stream_t stream);
 
+/* ---- Spacecraft Pose Network building blocks (src/nets/spn.py:37-143; loss assembly src/core/trainer.py:160-165).
+ * Convolutions and fully connected layers run through spb_pwconv_gemm / spb_pwconv_wgrad on im2col'd operands; all
+ * tensors NHWC, dtype SPB_BF16 or SPB_F32. */
+/* dst[(b,oy,ox)][(ky*KW+kx)*C + c] = src[b, oy*stride-pad+ky, ox*stride-pad+kx, c] (0 outside); C % 8 == 0, Kpad >= KH*KW*C */
+int spb_im2col(int dtype, const void* src, void* dst, int B, int H, int W, int C, int KH, int KW, int stride, int pad, int Kpad,
+               spb_stream_t stream);
+/* first layer: fp32 NCHW image (3 channels), valid padding; k = (ky*KW+kx)*3 + ci */
+int spb_im2col_rgb(int dtype, const float* x, void* dst, int B, int H, int W, int KH, int KW, int stride, int Kpad,
+                   spb_stream_t stream);
+/* adjoint of spb_im2col for stride 1: dx[b,iy,ix,c] = sum over taps of dcol */
+int spb_col2im(int dtype, const void* dcol, void* dx, int B, int H, int W, int C, int KH, int KW, int pad, int Kpad,
+               spb_stream_t stream);
+/* nn.MaxPool2d(3, stride=2): argmax (0..8, first maximum in scan order) is needed by the backward gather */
+int spb_maxpool3s2_fwd(int dtype, const void* x, void* y, unsigned char* argmax, int B, int H, int W, int C, spb_stream_t stream);
+int spb_maxpool3s2_bwd(int dtype, const void* dy, const unsigned char* argmax, void* dx, int B, int H, int W, int C,
+                       spb_stream_t stream);
+/* nn.LocalResponseNorm(2, alpha, beta, k) over the channel axis of [npix, C] */
+int spb_lrn2_fwd(int dtype, const void* x, void* y, long long npix, int C, float alpha, float beta, float k, spb_stream_t stream);
+int spb_lrn2_bwd(int dtype, const void* x, const void* g, void* dx, long long npix, int C, float alpha, float beta, float k,
+                 spb_stream_t stream);
+/* g = (dy [+ add]) * (y > 0) * scale: ReLU backward (y = activation output; with inverted dropout y is post-dropout) */
+int spb_relu_bwd(int dtype, const void* dy, const void* y, const void* add, void* g, long long n, float scale, spb_stream_t stream);
+/* nn.Dropout(p), in place: y *= keep/(1-p); keep from a counter hash of (seed, index) and written to mask, or read from it */
+int spb_dropout(int dtype, void* y, unsigned char* mask, long long n, float p, unsigned long long seed, int use_given_mask,
+                spb_stream_t stream);
+/* softmax_cross_entropy_with_logits(logits, target, 'mean') (spn.py:37-48): out[0] += weight*loss, out[slot] += loss;
+ * dlogits (may be NULL) = d(weight*loss)/dlogits */
+int spb_softce(int dtype, const void* logits, const float* target, void* dlogits, float* out, int slot, int B, int C, float weight,
+               spb_stream_t stream);
+/* out[n] += sum_m g[m][n] (bias gradients) */
+int spb_colsum(int dtype, const void* g, float* out, long long M, int N, spb_stream_t stream);
+
 /* debug / test helpers */
 int spb_debug_trread(const unsigned short* in4096, unsigned short* out256, spb_stream_t stream);
 int spb_debug_set_gemm_dma(int on); /* 1: small-M bf16 pointwise GEMMs use the LDS-DMA ring kernel (default 0) */

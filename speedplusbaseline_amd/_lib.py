@@ -147,6 +147,17 @@ SYMBOLS = {
     "spb_style_fc": (i32, [vp, vp, vp, vp, i32, i32, vp]),
     "spb_in_apply": (i32, [vp, vp, vp, vp, i32, i64, i32, i32, vp]),
     "spb_final_sigmoid": (i32, [vp, vp, vp, i32, i64, i32, vp]),
+    "spb_im2col": (i32, [i32, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
+    "spb_im2col_rgb": (i32, [i32, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
+    "spb_col2im": (i32, [i32, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
+    "spb_maxpool3s2_fwd": (i32, [i32, vp, vp, vp, i32, i32, i32, i32, vp]),
+    "spb_maxpool3s2_bwd": (i32, [i32, vp, vp, vp, i32, i32, i32, i32, vp]),
+    "spb_lrn2_fwd": (i32, [i32, vp, vp, i64, i32, f32, f32, f32, vp]),
+    "spb_lrn2_bwd": (i32, [i32, vp, vp, vp, i64, i32, f32, f32, f32, vp]),
+    "spb_relu_bwd": (i32, [i32, vp, vp, vp, vp, i64, f32, vp]),
+    "spb_dropout": (i32, [i32, vp, vp, i64, f32, C.c_ulonglong, i32, vp]),
+    "spb_softce": (i32, [i32, vp, vp, vp, vp, i32, i32, i32, f32, vp]),
+    "spb_colsum": (i32, [i32, vp, vp, i64, i32, vp]),
     "spb_debug_trread": (i32, [vp, vp, vp]),
     "spb_debug_set_gemm_dma": (i32, [i32]),
     "spb_debug_set_dw_mode": (i32, [i32]),

@@ -68,4 +68,31 @@ def train_single_epoch_krn(epoch, cfg, model, data_loader, optimizer, writer, de
 
 
 def train_single_epoch_spn(epoch, cfg, model, data_loader, optimizer, writer, device, styleAugmentor=None, scaler=None):
-    raise NotImplementedError("the SPN training step has no HIP path yet (DESIGN.md: scope / next rows)")
+    """trainer.py:114-199.  One step = forward, loss = softCE(c, yClasses) + 10 softCE(r, yWeights), backward,
+    clip_grad_value_(1.0), optimizer step -- all HIP launches (SpacecraftPoseNet.loss_and_grads + SpnOptimizer.step);
+    `scaler` is accepted for signature compatibility (bf16 needs no loss scaling)."""
+    training_time_meter = AverageMeter('ms')
+    loss_class_meter = AverageMeter('-')
+    loss_weight_meter = AverageMeter('-')
+    model.train()
+    lr = optimizer.param_groups[-1]['lr']
+    n_iter = len(data_loader)
+    for idx, (images, yClasses, yWeights) in enumerate(data_loader):
+        start = time.time()
+        B = images.shape[0]
+        images = images.to(device, non_blocking=True)
+        yClasses = yClasses.to(device, non_blocking=True)
+        yWeights = yWeights.to(device, non_blocking=True)
+        if styleAugmentor is not None and _texture_coin(cfg, epoch * n_iter + idx):
+            images = styleAugmentor(images)
+        out = model.loss_and_grads(images, yClasses, yWeights)   # gradients land in p.grad (no autograd)
+        optimizer.step()                                         # clip_grad_value_(1.0) + update, fused per tensor
+        lc, lr_ = out[1:3].tolist()                              # host floats per step, as the reference reports
+        training_time_meter.update((time.time() - start) * 1000, B)
+        loss_class_meter.update(lc, B)
+        loss_weight_meter.update(lr_, B)
+        report_progress(epoch=epoch, lr=lr, epoch_iter=idx + 1, epoch_size=n_iter, time=training_time_meter, is_train=True,
+                        loss_c=loss_class_meter, loss_r=loss_weight_meter)
+    if writer is not None:
+        writer.add_scalar('train/loss_c', loss_class_meter.avg, epoch)
+        writer.add_scalar('train/loss_r', loss_weight_meter.avg, epoch)

@@ -1,0 +1,411 @@
+// Spacecraft Pose Network (AlexNet trunk + two attitude heads) building blocks, forward and backward.
+// Reference: src/nets/spn.py:50-143 (SpacecraftPoseNet), :37-48 (softmax_cross_entropy_with_logits), step order and loss
+// assembly in src/core/trainer.py:136-185.
+//
+// First version of this row.  Every convolution and fully connected layer runs on the matrix cores through the
+// pointwise GEMM kernels of gemm_pw.hip (spb_pwconv_gemm with the bias + ReLU epilogue, spb_pwconv_wgrad); this file
+// supplies what turns AlexNet into GEMMs and the layers in between, NHWC throughout:
+//   im2col / im2col_rgb   K x K patches -> rows of [M = B*OH*OW, K*K*C] (zero padding, stride); grouped convolutions
+//                         use the full patch with block-diagonal weights (their FLOPs are irrelevant at this size)
+//   col2im                the adjoint gather for the input gradient (stride 1)
+//   maxpool 3x3 s2        forward with argmax byte, backward as a gather over the (<= 4) windows covering a pixel
+//   lrn (size 2)          nn.LocalResponseNorm(2, alpha, beta, k): out[c] = x[c] * (k + alpha/2 (x[c-1]^2 + x[c]^2))^-beta
+//   relu_drop_bwd         gradient through ReLU (and inverted dropout): g = dy * (y > 0) * scale
+//   dropout               keep-mask from a counter hash (seed, element), y *= mask / (1 - p), mask kept for the test
+//   softce                -sum t * log_softmax(x) per row (mean over rows), and its gradient
+//   colsum                bias gradients
+// The SPN step is bound by weight traffic (152 M parameters), not by these kernels.
+#include "common.h"
+
+namespace {
+
+template <typename T> __device__ __forceinline__ float ldf(const T* p);
+template <> __device__ __forceinline__ float ldf<float>(const float* p) { return *p; }
+template <> __device__ __forceinline__ float ldf<bf16_t>(const bf16_t* p) { return bf2f(*p); }
+template <typename T> __device__ __forceinline__ void stf(T* p, float v);
+template <> __device__ __forceinline__ void stf<float>(float* p, float v) { *p = v; }
+template <> __device__ __forceinline__ void stf<bf16_t>(bf16_t* p, float v) { *p = f2bf(v); }
+
+// dst[m][k], k = (ky*KW + kx)*C + c; 8 channels per thread (C % 8 == 0)
+template <typename T>
+__global__ void im2col_kernel(const T* __restrict__ src, T* __restrict__ dst, int B, int H, int W, int C, int KH, int KW, int st,
+                              int pad, int OH, int OW, int Kpad) {
+  const int CV = C >> 3;
+  const long long total = (long long)B * OH * OW * KH * KW * CV;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int cv = (int)(i % CV);
+    long long r = i / CV;
+    const int tap = (int)(r % (KH * KW)); r /= KH * KW;
+    const int ox = (int)(r % OW); r /= OW;
+    const int oy = (int)(r % OH);
+    const int b = (int)(r / OH);
+    const int iy = oy * st - pad + tap / KW, ix = ox * st - pad + tap % KW;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = 0.f;
+    if (iy >= 0 && iy < H && ix >= 0 && ix < W) ld8<T>(src + ((size_t)(b * H + iy) * W + ix) * C + cv * 8, v);
+    st8<T>(dst + ((size_t)(b * OH + oy) * OW + ox) * Kpad + (size_t)tap * C + cv * 8, v);
+  }
+}
+
+// first layer: fp32 NCHW image, C = 3: k = (ky*KW + kx)*3 + ci, padded with zeros up to Kpad
+template <typename T>
+__global__ void im2col_rgb_kernel(const float* __restrict__ x, T* __restrict__ dst, int B, int H, int W, int KH, int KW, int st,
+                                  int OH, int OW, int Kpad) {
+  const long long total = (long long)B * OH * OW * Kpad;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int k = (int)(i % Kpad);
+    long long r = i / Kpad;
+    const int ox = (int)(r % OW); r /= OW;
+    const int oy = (int)(r % OH);
+    const int b = (int)(r / OH);
+    float v = 0.f;
+    if (k < KH * KW * 3) {
+      const int tap = k / 3, ci = k % 3;
+      v = x[((size_t)(b * 3 + ci) * H + oy * st + tap / KW) * W + ox * st + tap % KW];   // valid padding
+    }
+    stf<T>(dst + i, v);
+  }
+}
+
+// dx[b,iy,ix,c] = sum over taps of dcol[(b, iy+pad-ky, ix+pad-kx)][(ky*KW+kx)*C + c]   (stride 1)
+template <typename T>
+__global__ void col2im_kernel(const T* __restrict__ dcol, T* __restrict__ dx, int B, int H, int W, int C, int KH, int KW, int pad,
+                              int OH, int OW, int Kpad) {
+  const int CV = C >> 3;
+  const long long total = (long long)B * H * W * CV;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int cv = (int)(i % CV);
+    long long r = i / CV;
+    const int ix = (int)(r % W); r /= W;
+    const int iy = (int)(r % H);
+    const int b = (int)(r / H);
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+    for (int ky = 0; ky < KH; ++ky) {
+      const int oy = iy + pad - ky;
+      if (oy < 0 || oy >= OH) continue;
+      for (int kx = 0; kx < KW; ++kx) {
+        const int ox = ix + pad - kx;
+        if (ox < 0 || ox >= OW) continue;
+        float v[8];
+        ld8<T>(dcol + ((size_t)(b * OH + oy) * OW + ox) * Kpad + (size_t)(ky * KW + kx) * C + cv * 8, v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] += v[j];
+      }
+    }
+    st8<T>(dx + i * 8, acc);
+  }
+}
+
+template <typename T>
+__global__ void maxpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, unsigned char* __restrict__ arg, int B, int H, int W,
+                                   int C, int OH, int OW) {
+  const int CV = C >> 3;
+  const long long total = (long long)B * OH * OW * CV;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int cv = (int)(i % CV);
+    long long r = i / CV;
+    const int ox = (int)(r % OW); r /= OW;
+    const int oy = (int)(r % OH);
+    const int b = (int)(r / OH);
+    float m[8]; unsigned char am[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { m[j] = -3.0e38f; am[j] = 0; }
+    for (int k = 0; k < 9; ++k) {   // scan order of the reference kernel: first maximum wins
+      float v[8];
+      ld8<T>(x + ((size_t)(b * H + oy * 2 + k / 3) * W + ox * 2 + k % 3) * C + cv * 8, v);
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (v[j] > m[j]) { m[j] = v[j]; am[j] = (unsigned char)k; }
+    }
+    st8<T>(y + i * 8, m);
+    if (arg) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) arg[i * 8 + j] = am[j];
+    }
+  }
+}
+
+template <typename T>
+__global__ void maxpool_bwd_kernel(const T* __restrict__ dy, const unsigned char* __restrict__ arg, T* __restrict__ dx, int B, int H,
+                                   int W, int C, int OH, int OW) {
+  const int CV = C >> 3;
+  const long long total = (long long)B * H * W * CV;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int cv = (int)(i % CV);
+    long long r = i / CV;
+    const int ix = (int)(r % W); r /= W;
+    const int iy = (int)(r % H);
+    const int b = (int)(r / H);
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+    for (int oy = iy >= 1 ? (iy - 1) / 2 : 0; oy <= iy / 2 && oy < OH; ++oy) {   // windows 2oy..2oy+2 containing iy
+      const int ky = iy - 2 * oy;
+      if (ky < 0 || ky > 2) continue;
+      for (int ox = ix >= 1 ? (ix - 1) / 2 : 0; ox <= ix / 2 && ox < OW; ++ox) {
+        const int kx = ix - 2 * ox;
+        if (kx < 0 || kx > 2) continue;
+        const size_t o = (((size_t)(b * OH + oy) * OW + ox) * CV + cv) * 8;
+        float g[8];
+        ld8<T>(dy + o, g);
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          if (arg[o + j] == ky * 3 + kx) acc[j] += g[j];
+      }
+    }
+    st8<T>(dx + i * 8, acc);
+  }
+}
+
+// nn.LocalResponseNorm(2): s[c] = k + alpha/2 * (x[c-1]^2 + x[c]^2);  y[c] = x[c] * s[c]^-beta
+template <typename T>
+__global__ void lrn_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, long long npix, int C, float alpha, float beta, float k) {
+  const long long total = npix * C;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    const float xc = ldf<T>(x + i), xp = c > 0 ? ldf<T>(x + i - 1) : 0.f;
+    const float s = k + 0.5f * alpha * (xp * xp + xc * xc);
+    stf<T>(y + i, xc * powf(s, -beta));
+  }
+}
+// dx[c] = g[c] s[c]^-b - alpha*beta*x[c] * (g[c] x[c] s[c]^(-b-1) + g[c+1] x[c+1] s[c+1]^(-b-1))
+template <typename T>
+__global__ void lrn_bwd_kernel(const T* __restrict__ x, const T* __restrict__ g, T* __restrict__ dx, long long npix, int C, float alpha,
+                               float beta, float k) {
+  const long long total = npix * C;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    const float xc = ldf<T>(x + i), xp = c > 0 ? ldf<T>(x + i - 1) : 0.f;
+    const float gc = ldf<T>(g + i);
+    const float sc = k + 0.5f * alpha * (xp * xp + xc * xc);
+    float t = gc * xc * powf(sc, -beta - 1.f);
+    if (c + 1 < C) {
+      const float xn = ldf<T>(x + i + 1), gn = ldf<T>(g + i + 1);
+      const float sn = k + 0.5f * alpha * (xc * xc + xn * xn);
+      t += gn * xn * powf(sn, -beta - 1.f);
+    }
+    stf<T>(dx + i, gc * powf(sc, -beta) - alpha * beta * xc * t);
+  }
+}
+
+// g = dy * (y > 0) * scale [+ add]   (ReLU, and inverted dropout when y is the post-dropout activation)
+template <typename T>
+__global__ void relu_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ y, const T* __restrict__ add, T* __restrict__ g,
+                                long long n, float scale) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    float v = ldf<T>(dy + i);
+    if (add) v += ldf<T>(add + i);
+    stf<T>(g + i, ldf<T>(y + i) > 0.f ? v * scale : 0.f);
+  }
+}
+
+__device__ __forceinline__ unsigned hash32(unsigned long long z) {
+  z += 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return (unsigned)((z ^ (z >> 31)) >> 32);
+}
+// nn.Dropout(p): y = x * keep / (1 - p), keep ~ Bernoulli(1 - p) from a counter hash of (seed, element index)
+template <typename T>
+__global__ void dropout_kernel(T* __restrict__ y, unsigned char* __restrict__ mask, long long n, float p, unsigned long long seed,
+                               int use_given_mask) {
+  const float scale = 1.f / (1.f - p);
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    unsigned char keep;
+    if (use_given_mask) keep = mask[i];
+    else {
+      keep = (hash32(seed * 0x100000001B3ull + (unsigned long long)i) * (1.0f / 4294967296.0f)) >= p ? 1 : 0;
+      mask[i] = keep;
+    }
+    stf<T>(y + i, keep ? ldf<T>(y + i) * scale : 0.f);
+  }
+}
+
+// one workgroup per row: loss_row = lse * sum(t) - sum(t*x);  dlogits = (softmax * sum(t) - t) * gscale
+// out[0] += weight * mean-over-rows contribution, out[slot] += unweighted mean (for the two reported losses)
+template <typename T>
+__global__ __launch_bounds__(256) void softce_kernel(const T* __restrict__ logits, const float* __restrict__ target, T* __restrict__ dlogits,
+                                                     float* out, int slot, int Bn, int Cn, float weight) {
+  __shared__ float red[256];
+  const int b = blockIdx.x, t = threadIdx.x;
+  const T* x = logits + (size_t)b * Cn;
+  const float* tg = target + (size_t)b * Cn;
+  float m = -3.0e38f;
+  for (int c = t; c < Cn; c += 256) m = fmaxf(m, ldf<T>(x + c));
+  red[t] = m; __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) { if (t < s) red[t] = fmaxf(red[t], red[t + s]); __syncthreads(); }
+  m = red[0]; __syncthreads();
+  float se = 0.f, st = 0.f, sx = 0.f;
+  for (int c = t; c < Cn; c += 256) { const float v = ldf<T>(x + c); se += expf(v - m); st += tg[c]; sx += tg[c] * v; }
+  red[t] = se; __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) { if (t < s) red[t] += red[t + s]; __syncthreads(); }
+  se = red[0]; __syncthreads();
+  red[t] = st; __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) { if (t < s) red[t] += red[t + s]; __syncthreads(); }
+  st = red[0]; __syncthreads();
+  red[t] = sx; __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) { if (t < s) red[t] += red[t + s]; __syncthreads(); }
+  sx = red[0];
+  const float lse = m + logf(se);
+  if (t == 0) {
+    const float l = (lse * st - sx) / (float)Bn;
+    atomicAdd(out, weight * l);
+    atomicAdd(out + slot, l);
+  }
+  if (dlogits) {
+    const float gs = weight / (float)Bn;
+    for (int c = t; c < Cn; c += 256) stf<T>(dlogits + (size_t)b * Cn + c, (expf(ldf<T>(x + c) - lse) * st - tg[c]) * gs);
+  }
+}
+
+// out[n] += sum_m g[m][n]
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ g, float* __restrict__ out, long long M, int N,
+                                                     long long rows_per_block) {
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  if (n >= N) return;
+  const long long m0 = (long long)blockIdx.y * rows_per_block;
+  const long long m1 = m0 + rows_per_block < M ? m0 + rows_per_block : M;
+  float s = 0.f;
+  for (long long m = m0; m < m1; ++m) s += ldf<T>(g + m * N + n);
+  atomicAdd(out + n, s);
+}
+
+inline unsigned grid_for(long long total) {
+  long long g = (total + 255) / 256;
+  return (unsigned)(g > 65535 * 4 ? 65535 * 4 : (g < 1 ? 1 : g));
+}
+
+}  // namespace
+
+#define SPN_T(dtype, CALL_BF, CALL_F32) \
+  if ((dtype) == SPB_BF16) { CALL_BF; } else if ((dtype) == SPB_F32) { CALL_F32; } else return SPB_E_ARG;
+
+extern "C" int spb_im2col(int dtype, const void* src, void* dst, int B, int H, int W, int C, int KH, int KW, int stride, int pad,
+                          int Kpad, spb_stream_t stream) {
+  if (!src || !dst || B <= 0 || (C & 7) || Kpad < KH * KW * C || (Kpad & 7)) return SPB_E_ARG;
+  const int OH = (H + 2 * pad - KH) / stride + 1, OW = (W + 2 * pad - KW) / stride + 1;
+  const long long total = (long long)B * OH * OW * KH * KW * (C >> 3);
+  hipStream_t s = (hipStream_t)stream;
+  if (Kpad != KH * KW * C) {
+    const size_t es = dtype == SPB_BF16 ? 2 : 4;
+    hipError_t e = hipMemsetAsync(dst, 0, (size_t)B * OH * OW * Kpad * es, s);
+    if (e != hipSuccess) return (int)e;
+  }
+  SPN_T(dtype, hipLaunchKernelGGL(im2col_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, s, (const bf16_t*)src, (bf16_t*)dst, B, H, W, C, KH, KW, stride, pad, OH, OW, Kpad),
+        hipLaunchKernelGGL(im2col_kernel<float>, dim3(grid_for(total)), dim3(256), 0, s, (const float*)src, (float*)dst, B, H, W, C, KH, KW, stride, pad, OH, OW, Kpad))
+  SPB_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int spb_im2col_rgb(int dtype, const float* x, void* dst, int B, int H, int W, int KH, int KW, int stride, int Kpad,
+                              spb_stream_t stream) {
+  if (!x || !dst || B <= 0 || Kpad < KH * KW * 3 || (Kpad & 7)) return SPB_E_ARG;
+  const int OH = (H - KH) / stride + 1, OW = (W - KW) / stride + 1;
+  const long long total = (long long)B * OH * OW * Kpad;
+  hipStream_t s = (hipStream_t)stream;
+  SPN_T(dtype, hipLaunchKernelGGL(im2col_rgb_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, s, x, (bf16_t*)dst, B, H, W, KH, KW, stride, OH, OW, Kpad),
+        hipLaunchKernelGGL(im2col_rgb_kernel<float>, dim3(grid_for(total)), dim3(256), 0, s, x, (float*)dst, B, H, W, KH, KW, stride, OH, OW, Kpad))
+  SPB_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int spb_col2im(int dtype, const void* dcol, void* dx, int B, int H, int W, int C, int KH, int KW, int pad, int Kpad,
+                          spb_stream_t stream) {
+  if (!dcol || !dx || B <= 0 || (C & 7)) return SPB_E_ARG;
+  const int OH = H + 2 * pad - KH + 1, OW = W + 2 * pad - KW + 1;
+  const long long total = (long long)B * H * W * (C >> 3);
+  hipStream_t s = (hipStream_t)stream;
+  SPN_T(dtype, hipLaunchKernelGGL(col2im_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, s, (const bf16_t*)dcol, (bf16_t*)dx, B, H, W, C, KH, KW, pad, OH, OW, Kpad),
+        hipLaunchKernelGGL(col2im_kernel<float>, dim3(grid_for(total)), dim3(256), 0, s, (const float*)dcol, (float*)dx, B, H, W, C, KH, KW, pad, OH, OW, Kpad))
+  SPB_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int spb_maxpool3s2_fwd(int dtype, const void* x, void* y, unsigned char* argmax, int B, int H, int W, int C,
+                                  spb_stream_t stream) {
+  if (!x || !y || B <= 0 || (C & 7) || H < 3 || W < 3) return SPB_E_ARG;
+  const int OH = (H - 3) / 2 + 1, OW = (W - 3) / 2 + 1;
+  const long long total = (long long)B * OH * OW * (C >> 3);
+  hipStream_t s = (hipStream_t)stream;
+  SPN_T(dtype, hipLaunchKernelGGL(maxpool_fwd_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, argmax, B, H, W, C, OH, OW),
+        hipLaunchKernelGGL(maxpool_fwd_kernel<float>, dim3(grid_for(total)), dim3(256), 0, s, (const float*)x, (float*)y, argmax, B, H, W, C, OH, OW))
+  SPB_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int spb_maxpool3s2_bwd(int dtype, const void* dy, const unsigned char* argmax, void* dx, int B, int H, int W, int C,
+                                  spb_stream_t stream) {
+  if (!dy || !argmax || !dx || B <= 0 || (C & 7)) return SPB_E_ARG;
+  const int OH = (H - 3) / 2 + 1, OW = (W - 3) / 2 + 1;
+  const long long total = (long long)B * H * W * (C >> 3);
+  hipStream_t s = (hipStream_t)stream;
+  SPN_T(dtype, hipLaunchKernelGGL(maxpool_bwd_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, s, (const bf16_t*)dy, argmax, (bf16_t*)dx, B, H, W, C, OH, OW),
+        hipLaunchKernelGGL(maxpool_bwd_kernel<float>, dim3(grid_for(total)), dim3(256), 0, s, (const float*)dy, argmax, (float*)dx, B, H, W, C, OH, OW))
+  SPB_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int spb_lrn2_fwd(int dtype, const void* x, void* y, long long npix, int C, float alpha, float beta, float k,
+                            spb_stream_t stream) {
+  if (!x || !y || npix <= 0 || C <= 0) return SPB_E_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  SPN_T(dtype, hipLaunchKernelGGL(lrn_fwd_kernel<bf16_t>, dim3(grid_for(npix * C)), dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, npix, C, alpha, beta, k),
+        hipLaunchKernelGGL(lrn_fwd_kernel<float>, dim3(grid_for(npix * C)), dim3(256), 0, s, (const float*)x, (float*)y, npix, C, alpha, beta, k))
+  SPB_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int spb_lrn2_bwd(int dtype, const void* x, const void* g, void* dx, long long npix, int C, float alpha, float beta,
+                            float k, spb_stream_t stream) {
+  if (!x || !g || !dx || npix <= 0 || C <= 0) return SPB_E_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  SPN_T(dtype, hipLaunchKernelGGL(lrn_bwd_kernel<bf16_t>, dim3(grid_for(npix * C)), dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)g, (bf16_t*)dx, npix, C, alpha, beta, k),
+        hipLaunchKernelGGL(lrn_bwd_kernel<float>, dim3(grid_for(npix * C)), dim3(256), 0, s, (const float*)x, (const float*)g, (float*)dx, npix, C, alpha, beta, k))
+  SPB_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int spb_relu_bwd(int dtype, const void* dy, const void* y, const void* add, void* g, long long n, float scale,
+                            spb_stream_t stream) {
+  if (!dy || !y || !g || n <= 0) return SPB_E_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  SPN_T(dtype, hipLaunchKernelGGL(relu_bwd_kernel<bf16_t>, dim3(grid_for(n)), dim3(256), 0, s, (const bf16_t*)dy, (const bf16_t*)y, (const bf16_t*)add, (bf16_t*)g, n, scale),
+        hipLaunchKernelGGL(relu_bwd_kernel<float>, dim3(grid_for(n)), dim3(256), 0, s, (const float*)dy, (const float*)y, (const float*)add, (float*)g, n, scale))
+  SPB_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int spb_dropout(int dtype, void* y, unsigned char* mask, long long n, float p, unsigned long long seed, int use_given_mask,
+                           spb_stream_t stream) {
+  if (!y || !mask || n <= 0 || p < 0.f || p >= 1.f) return SPB_E_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  SPN_T(dtype, hipLaunchKernelGGL(dropout_kernel<bf16_t>, dim3(grid_for(n)), dim3(256), 0, s, (bf16_t*)y, mask, n, p, seed, use_given_mask),
+        hipLaunchKernelGGL(dropout_kernel<float>, dim3(grid_for(n)), dim3(256), 0, s, (float*)y, mask, n, p, seed, use_given_mask))
+  SPB_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int spb_softce(int dtype, const void* logits, const float* target, void* dlogits, float* out, int slot, int B, int C,
+                          float weight, spb_stream_t stream) {
+  if (!logits || !target || !out || B <= 0 || C <= 0 || slot < 1) return SPB_E_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  SPN_T(dtype, hipLaunchKernelGGL(softce_kernel<bf16_t>, dim3(B), dim3(256), 0, s, (const bf16_t*)logits, target, (bf16_t*)dlogits, out, slot, B, C, weight),
+        hipLaunchKernelGGL(softce_kernel<float>, dim3(B), dim3(256), 0, s, (const float*)logits, target, (float*)dlogits, out, slot, B, C, weight))
+  SPB_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int spb_colsum(int dtype, const void* g, float* out, long long M, int N, spb_stream_t stream) {
+  if (!g || !out || M <= 0 || N <= 0) return SPB_E_ARG;
+  const long long rpb = M > 4096 ? 1024 : (M > 256 ? 64 : M);
+  const dim3 grid((unsigned)((N + 255) / 256), (unsigned)((M + rpb - 1) / rpb));
+  hipStream_t s = (hipStream_t)stream;
+  SPN_T(dtype, hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)g, out, M, N, rpb),
+        hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, s, (const float*)g, out, M, N, rpb))
+  SPB_CHECK_LAUNCH();
+  return 0;
+}

@@ -23,7 +23,13 @@ def get_model(cfg):
             model = KeypointRegressionNet(cfg.num_keypoints, precision=_precision(cfg))
             logger.info('KRN created')
         else:
-            model = SpacecraftPoseNet(cfg.num_classes, pretrain=True)
+            try:
+                model = SpacecraftPoseNet(cfg.num_classes, pretrain=True, precision=_precision(cfg))   # build.py:48
+            except FileNotFoundError:
+                if not getattr(cfg, 'synthetic_batches', 0):
+                    raise
+                # synthetic run: the AlexNet npy (checkpoints/pretrained/bvlc_alexnet.npy) is not available offline
+                model = SpacecraftPoseNet(cfg.num_classes, pretrain=False, precision=_precision(cfg))
             logger.info('SPN created')
     else:
         model = RevGrad(cfg.num_keypoints, precision=_precision(cfg))
@@ -40,6 +46,12 @@ def get_optimizer(cfg, model):
     if cfg.optimizer not in ('sgd', 'rmsprop', 'adam', 'adamw'):
         raise ValueError('unknown optimizer %r' % cfg.optimizer)
     params = [p for p in model.parameters() if p.requires_grad]
+    if isinstance(model, SpacecraftPoseNet):
+        from ..optim import SpnOptimizer
+        optimizer = SpnOptimizer(params, kind=cfg.optimizer, lr=cfg.lr, momentum=cfg.momentum, weight_decay=cfg.weight_decay,
+                                 model=model, clip_value=1.0)
+        logger.info('Optimizer created: {}'.format(cfg.optimizer))
+        return optimizer
     optimizer = FusedOptimizer(params, kind=cfg.optimizer, lr=cfg.lr, momentum=cfg.momentum,
                                weight_decay=cfg.weight_decay, model=model)
     logger.info('Optimizer created: {}'.format(cfg.optimizer))

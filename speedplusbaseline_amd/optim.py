@@ -131,3 +131,44 @@ class FusedOptimizer(torch.optim.Optimizer):
             for key, arena in (("exp_avg", ts.m), ("exp_avg_sq", ts.v), ("square_avg", ts.v), ("momentum_buffer", ts.m)):
                 if key in st and st[key] is not None:
                     eng.param_view(info, arena).copy_(st[key].to(arena.device))
+
+
+class SpnOptimizer(torch.optim.Optimizer):
+    """Optimizer of the Spacecraft Pose Network (reference build.py:60-78 kinds; trainer.py:177-184: clip_grad_value_(1.0)
+    then step).  SPN parameters are ordinary tensors (22 of them, 152 M elements), so the update is one fused HIP pass
+    per tensor: clamp of every gradient element to [-clip_value, clip_value] + sgd / rmsprop / adam / adamw, f32."""
+
+    def __init__(self, params, kind="adamw", lr=1e-3, momentum=0.9, weight_decay=0.0, model=None, clip_value=1.0):
+        super().__init__(params, dict(lr=lr, momentum=momentum, weight_decay=weight_decay, kind=kind))
+        self._model = model
+        self.clip_value = clip_value
+        self._t = 0
+
+    def _betas(self, kind, momentum):
+        if kind == "rmsprop":
+            return 0.0, momentum
+        if kind in ("adam", "adamw"):
+            return momentum, 0.999
+        return momentum, 0.0
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        from . import ops
+        self._t += 1
+        for g in self.param_groups:
+            b1, b2 = self._betas(g["kind"], g["momentum"])
+            for p in g["params"]:
+                if p.grad is None:
+                    continue
+                if not p.is_cuda:
+                    raise RuntimeError("SpnOptimizer updates parameters on the MI355X only")
+                st = self.state[p]
+                if not st:
+                    st["m"] = torch.zeros_like(p, dtype=torch.float32).view(-1)
+                    st["v"] = torch.zeros_like(p, dtype=torch.float32).view(-1)
+                ops.optim_step(g["kind"], p.data.view(-1), p.grad.view(-1), m=st["m"], v=st["v"], lr=g["lr"], beta1=b1, beta2=b2,
+                               eps=1e-8, weight_decay=g["weight_decay"], max_norm=0.0, clip_value=self.clip_value, step=self._t,
+                               first_step=(self._t == 1))
+        if self._model is not None:
+            self._model.invalidate()   # compute-dtype weight copies are stale now
+        return None

@@ -80,8 +80,18 @@ def test_factory_optimizer_and_alpha_schedule():
     assert sd["param_groups"][0]["kind"] == "adamw" and len(sd["param_groups"][0]["params"]) == 176
     for i in range(2):
         assert abs(dann_alpha(i, 1, 2, 5) - G["g6_alphas"][i]) < 1e-12
-    with pytest.raises(NotImplementedError):
-        cfg.model_name = "spn"; get_model(cfg)
+    # SPN: get_model hard-wires pretrain=True like the reference (build.py:48); without the AlexNet npy it must fail
+    # loudly (FileNotFoundError) unless the run is synthetic, where it falls back to random init
+    cfg.model_name = "spn"; cfg.num_classes = 16
+    with pytest.raises(FileNotFoundError):
+        get_model(cfg)
+    cfg.synthetic_batches = 2
+    spn = get_model(cfg)
+    from speedplusbaseline_amd.optim import SpnOptimizer
+    assert isinstance(get_optimizer(cfg, spn), SpnOptimizer)
+    assert list(spn.state_dict().keys())[:2] == ["conv1.weight", "conv1.bias"] and spn.fc8.weight.shape == (16, 4096)
+    with pytest.raises(RuntimeError):   # no CPU path
+        spn(torch.zeros(1, 3, 227, 227))
 
 
 def _free_port():

@@ -9,7 +9,7 @@ import torch
 from config import cfg
 from speedplusbaseline_amd.core.trainer import train_single_epoch_krn, train_single_epoch_spn  # noqa: F401 (looked up by name)
 from speedplusbaseline_amd.core.inference import valid_krn, valid_spn  # noqa: F401
-from speedplusbaseline_amd.data import SyntheticKeypointLoader
+from speedplusbaseline_amd.data import SyntheticKeypointLoader, SyntheticSpnLoader
 from speedplusbaseline_amd.nets import get_model, get_optimizer
 from speedplusbaseline_amd.utils import load_checkpoint, save_checkpoint, set_all_seeds, setup_logger
 
@@ -62,7 +62,10 @@ def main():
     if cfg.synthetic_batches <= 0:
         raise SystemExit("The SPEED+ dataset pipeline (reference src/datasets) is not part of this build; pass "
                          "--synthetic_batches N to train on synthetic 224x224 batches.")
-    train_loader = SyntheticKeypointLoader(cfg.batch_size, cfg.synthetic_batches, cfg.num_keypoints, cfg.input_shape, seed=cfg.seed)
+    if cfg.model_name == 'spn':
+        train_loader = SyntheticSpnLoader(cfg.batch_size, cfg.synthetic_batches, cfg.num_classes, cfg.num_neighbors, (227, 227), seed=cfg.seed)
+    else:
+        train_loader = SyntheticKeypointLoader(cfg.batch_size, cfg.synthetic_batches, cfg.num_keypoints, cfg.input_shape, seed=cfg.seed)
     for epoch in range(begin_epoch, cfg.max_epochs):
         eval('train_single_epoch_' + cfg.model_name)(epoch + 1, cfg, model, train_loader, optimizer, writer, device,
                                                      styleAugmentor=styleAugmentor, scaler=None)
