@@ -65,6 +65,8 @@ typedef struct spb_gemm_args {
   int out_act;       /* epi_mode 0 */
   int oR;
   float out_scale;   /* epi_mode 0: y = out_act(acc*out_scale + bias); callers pass 1 for a plain product */
+  int lda, ldc;      /* row strides (elements) of A/A2 and of Y/res/Zout; 0 = dense (K and N).  Lets one group of a grouped
+                        convolution run on a column slab of the im2col / output matrices (SPN conv2, conv4, conv5) */
 } spb_gemm_args_t;
 int spb_pwconv_gemm(int dtype, const spb_gemm_args_t* args, spb_stream_t stream);
 
@@ -77,6 +79,7 @@ typedef struct spb_wgrad_args {
   spb_bnref_t pro_dz;
   spb_bnref_t pro_a;
   int M, K, N;
+  int ldg, ldx;   /* row strides (elements) of G/Zn and X; 0 = dense (N and K) */
 } spb_wgrad_args_t;
 int spb_pwconv_wgrad(int dtype, const spb_wgrad_args_t* args, spb_stream_t stream);
 
@@ -234,6 +237,8 @@ typedef struct spb_optim_args {
   float lr, beta1, beta2, eps, weight_decay, max_norm, clip_value; /* max_norm<=0: no norm clip; clip_value<=0: none */
   float bias_c1, bias_c2; /* 1-beta1^t, 1-beta2^t */
   int first_step;       /* sgd momentum buffer initialisation */
+  void* shadow_bf16;    /* optional bf16 arena with the parameter arena's offsets: receives the updated value of every
+                           element, so the next forward needs no separate conversion pass (SPN, 152 M parameters) */
 } spb_optim_args_t;
 int spb_optim_step(const spb_optim_args_t* a, spb_stream_t stream);
 
@@ -331,15 +336,17 @@ int spb_final_sigmoid(const void* Z, const float* coef, float* out, int B, long 
 /* ---- Spacecraft Pose Network building blocks (src/nets/spn.py:37-143; loss assembly src/core/trainer.py:160-165).
  * Convolutions and fully connected layers run through spb_pwconv_gemm / spb_pwconv_wgrad on im2col'd operands; all
  * tensors NHWC, dtype SPB_BF16 or SPB_F32. */
-/* dst[(b,oy,ox)][(ky*KW+kx)*C + c] = src[b, oy*stride-pad+ky, ox*stride-pad+kx, c] (0 outside); C % 8 == 0, Kpad >= KH*KW*C */
+/* dst[(b,oy,ox)][gi*Kg + (ky*KW+kx)*cig + cl] = src[b, oy*stride-pad+ky, ox*stride-pad+kx, gi*cig + cl] (0 outside), cig = C/groups,
+ * Kg = Kpad/groups: one contiguous column slab per convolution group, so a grouped nn.Conv2d (spn.py:60,66,68) is one dense
+ * GEMM per group on a slab (spb_gemm_args_t.lda / ldc).  C/groups % 8 == 0, Kpad >= KH*KW*C */
 int spb_im2col(int dtype, const void* src, void* dst, int B, int H, int W, int C, int KH, int KW, int stride, int pad, int Kpad,
-               spb_stream_t stream);
+               int groups, spb_stream_t stream);
 /* first layer: fp32 NCHW image (3 channels), valid padding; k = (ky*KW+kx)*3 + ci */
 int spb_im2col_rgb(int dtype, const float* x, void* dst, int B, int H, int W, int KH, int KW, int stride, int Kpad,
                    spb_stream_t stream);
 /* adjoint of spb_im2col for stride 1: dx[b,iy,ix,c] = sum over taps of dcol */
 int spb_col2im(int dtype, const void* dcol, void* dx, int B, int H, int W, int C, int KH, int KW, int pad, int Kpad,
-               spb_stream_t stream);
+               int groups, spb_stream_t stream);
 /* nn.MaxPool2d(3, stride=2): argmax (0..8, first maximum in scan order) is needed by the backward gather */
 int spb_maxpool3s2_fwd(int dtype, const void* x, void* y, unsigned char* argmax, int B, int H, int W, int C, spb_stream_t stream);
 int spb_maxpool3s2_bwd(int dtype, const void* dy, const unsigned char* argmax, void* dx, int B, int H, int W, int C,
@@ -360,7 +367,48 @@ int spb_softce(int dtype, const void* logits, const float* target, void* dlogits
 /* out[n] += sum_m g[m][n] (bias gradients) */
 int spb_colsum(int dtype, const void* g, float* out, long long M, int N, spb_stream_t stream);
 
+/* nn.Conv2d weights [Cout][Cin/groups][KH][KW] f32 (spn.py:56-70) -> Wp [Cout][Kg]: row co holds its group's filter in
+ * (ky,kx,c_local) order, zero padded to Kg (i.e. `groups` stacked [Cout/groups][Kg] GEMM operands matching spb_im2col's
+ * slabs), and WpT [groups][Kg][Cout/groups], the per-group transposes the input gradient needs (may be NULL).  dtype = output. */
+int spb_spn_pack_conv(int dtype, const float* W, void* Wp, void* WpT, int Cout, int Cin, int groups, int KH, int KW, int Kg,
+                      spb_stream_t stream);
+/* inverse for gradients: dWp f32 [Cout][Kg] -> dW f32 [Cout][Cin/groups][KH][KW] */
+int spb_spn_unpack_conv_grad(const float* dWp, float* dW, int Cout, int Cin, int groups, int KH, int KW, int Kg, spb_stream_t stream);
+
+/* ---- SPN fully connected layers at training batch sizes (M <= 64 rows; nn.Linear fc6..fc11, spn.py:71-99), bf16 only.
+ * accT is a feature-major f32 accumulator [features][MP], MP = 32 (M <= 32) or 64, zero between uses; the epilogue
+ * consumes and re-zeroes it.  Return SPB_E_UNSUPPORTED for shapes outside the streamed kernels' reach (the caller then
+ * uses spb_pwconv_gemm / spb_pwconv_wgrad).
+ *   spb_fc_fwd    accT[n][m] += sum_k W[n][k] X[m][k]          X [M][K], W [N][K];  K % 64 == 0
+ *   spb_fc_dgrad  accT[k][m] += sum_n W[n][k] G[m][n]          G [M][N];            K % 128 == 0, N % 8 == 0
+ *   spb_fc_wgrad  dW[n][k]    = sum_m GT[n][m] XT[k][m]        GT [N][MP], XT [K][MP] (written by the epilogue); K % 4 == 0 */
+int spb_fc_fwd(const void* X, const void* W, float* accT, int M, int N, int K, spb_stream_t stream);
+int spb_fc_dgrad(const void* G, const void* W, float* accT, int M, int N, int K, spb_stream_t stream);
+int spb_fc_wgrad(const void* GT, const void* XT, float* dW, int M, int N, int K, spb_stream_t stream);
+typedef struct spb_fc_epi_args {
+  float* accT;              /* [F][MP] f32 accumulator (consumed and zeroed) or NULL */
+  const void* src;          /* accT == NULL: bf16 [M][F] values to use instead (e.g. dlogits from spb_softce) */
+  const float* bias;        /* mode 0: [F] or NULL */
+  const void* H;            /* mode 1: bf16 [M][F] forward activation (after ReLU / dropout); gradient passes where H > 0; NULL: everywhere */
+  void* Y;                  /* bf16 [M][F] or NULL */
+  void* YT;                 /* bf16 [F][MP] (rows >= M zero) or NULL */
+  unsigned char* mask;      /* mode 0, p > 0: keep mask [M][F] (written, or read when mask_given) */
+  float* db;                /* mode 1: [F] column sums of the result (bias gradient) or NULL */
+  int M, F;
+  int mode;                 /* 0 forward: bias, ReLU (relu != 0), nn.Dropout(p);  1 backward: * scale where H > 0 */
+  int relu;
+  float p, scale;
+  unsigned long long seed;
+  int mask_given;
+} spb_fc_epi_args_t;
+int spb_fc_epilogue(const spb_fc_epi_args_t* a, spb_stream_t stream);
+/* pool5 output NHWC bf16 [B][HW][C] -> Fm [B][C*HW] in the NCHW order of x.view(-1, 9216) (spn.py:131) and FT [C*HW][MP] */
+int spb_spn_flatten(const void* P, void* Fm, void* FT, int B, int HW, int C, spb_stream_t stream);
+/* accT [C*HW][MP] (both heads' fc6 / fc9 input gradients summed) -> NHWC bf16 gradient of pool5's output; accT zeroed */
+int spb_spn_unflatten_grad(float* accT, void* Gp, int B, int HW, int C, spb_stream_t stream);
+
 /* debug / test helpers */
+int spb_debug_set_optim(int vec, int per_thread, int nontemporal); /* optimizer launch shape A/B: lanes of 1|4 floats, 1|2|4 per thread, nt accesses */
 int spb_debug_trread(const unsigned short* in4096, unsigned short* out256, spb_stream_t stream);
 int spb_debug_set_gemm_dma(int on); /* 1: small-M bf16 pointwise GEMMs use the LDS-DMA ring kernel (default 0) */
 int spb_debug_set_dw_mode(int mode); /* depthwise fwd/dgrad: 1 row-unit kernels (default), 0 LDS-tiled kernels */

@@ -26,12 +26,12 @@ class BNRef(C.Structure):
 class GemmArgs(C.Structure):
     _fields_ = [("A", vp), ("A2", vp), ("Bw", vp), ("Y", vp), ("res", vp), ("Zout", vp), ("bias", vp), ("osums", vp),
                 ("pro", BNRef), ("epi", BNRef), ("M", i32), ("K", i32), ("N", i32), ("pro_mode", i32),
-                ("epi_mode", i32), ("out_act", i32), ("oR", i32), ("out_scale", f32)]
+                ("epi_mode", i32), ("out_act", i32), ("oR", i32), ("out_scale", f32), ("lda", i32), ("ldc", i32)]
 
 
 class WgradArgs(C.Structure):
     _fields_ = [("G", vp), ("Zn", vp), ("X", vp), ("dW", vp), ("pro_dz", BNRef), ("pro_a", BNRef), ("M", i32),
-                ("K", i32), ("N", i32)]
+                ("K", i32), ("N", i32), ("ldg", i32), ("ldx", i32)]
 
 
 class PwBwdArgs(C.Structure):
@@ -88,7 +88,13 @@ class OptimArgs(C.Structure):
     _fields_ = [("params", vp), ("grads", vp), ("m", vp), ("v", vp), ("sqnorm", vp), ("gmul", vp), ("hyper", vp),
                 ("n", i64), ("kind", i32), ("lr", f32), ("beta1", f32), ("beta2", f32), ("eps", f32),
                 ("weight_decay", f32), ("max_norm", f32), ("clip_value", f32), ("bias_c1", f32), ("bias_c2", f32),
-                ("first_step", i32)]
+                ("first_step", i32), ("shadow_bf16", vp)]
+
+
+class FcEpiArgs(C.Structure):
+    _fields_ = [("accT", vp), ("src", vp), ("bias", vp), ("H", vp), ("Y", vp), ("YT", vp), ("mask", vp), ("db", vp),
+                ("M", i32), ("F", i32), ("mode", i32), ("relu", i32), ("p", f32), ("scale", f32), ("seed", C.c_ulonglong),
+                ("mask_given", i32)]
 
 
 class TensorInfo(C.Structure):
@@ -147,9 +153,9 @@ SYMBOLS = {
     "spb_style_fc": (i32, [vp, vp, vp, vp, i32, i32, vp]),
     "spb_in_apply": (i32, [vp, vp, vp, vp, i32, i64, i32, i32, vp]),
     "spb_final_sigmoid": (i32, [vp, vp, vp, i32, i64, i32, vp]),
-    "spb_im2col": (i32, [i32, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
+    "spb_im2col": (i32, [i32, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
     "spb_im2col_rgb": (i32, [i32, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
-    "spb_col2im": (i32, [i32, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
+    "spb_col2im": (i32, [i32, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
     "spb_maxpool3s2_fwd": (i32, [i32, vp, vp, vp, i32, i32, i32, i32, vp]),
     "spb_maxpool3s2_bwd": (i32, [i32, vp, vp, vp, i32, i32, i32, i32, vp]),
     "spb_lrn2_fwd": (i32, [i32, vp, vp, i64, i32, f32, f32, f32, vp]),
@@ -158,6 +164,15 @@ SYMBOLS = {
     "spb_dropout": (i32, [i32, vp, vp, i64, f32, C.c_ulonglong, i32, vp]),
     "spb_softce": (i32, [i32, vp, vp, vp, vp, i32, i32, i32, f32, vp]),
     "spb_colsum": (i32, [i32, vp, vp, i64, i32, vp]),
+    "spb_debug_set_optim": (i32, [i32, i32, i32]),
+    "spb_spn_pack_conv": (i32, [i32, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
+    "spb_spn_unpack_conv_grad": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, vp]),
+    "spb_fc_fwd": (i32, [vp, vp, vp, i32, i32, i32, vp]),
+    "spb_fc_dgrad": (i32, [vp, vp, vp, i32, i32, i32, vp]),
+    "spb_fc_wgrad": (i32, [vp, vp, vp, i32, i32, i32, vp]),
+    "spb_fc_epilogue": (i32, [C.POINTER(FcEpiArgs), vp]),
+    "spb_spn_flatten": (i32, [vp, vp, vp, i32, i32, i32, vp]),
+    "spb_spn_unflatten_grad": (i32, [vp, vp, i32, i32, i32, vp]),
     "spb_debug_trread": (i32, [vp, vp, vp]),
     "spb_debug_set_gemm_dma": (i32, [i32]),
     "spb_debug_set_dw_mode": (i32, [i32]),

@@ -213,6 +213,52 @@ __global__ __launch_bounds__(256) void grad_sqnorm_kernel(const float* __restric
   if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
 }
 
+// one element of the update; m / v are the moment values (read and written back by the caller when the kind uses them)
+__device__ __forceinline__ float optim_one(const spb_optim_args_t& a, float gs, float lr, float bias_c1, float bias_c2, float p, float g,
+                                           float& m, float& v) {
+  g *= gs;
+  if (a.clip_value > 0.f) g = fminf(fmaxf(g, -a.clip_value), a.clip_value);
+  if (a.kind == 3) {  // adamw (decoupled decay)
+    p *= 1.f - lr * a.weight_decay;
+    m = a.beta1 * m + (1.f - a.beta1) * g;
+    v = a.beta2 * v + (1.f - a.beta2) * g * g;
+    const float denom = sqrtf(v) / sqrtf(bias_c2) + a.eps;
+    p -= (lr / bias_c1) * (m / denom);
+  } else if (a.kind == 2) {  // adam (L2 folded into the gradient)
+    g += a.weight_decay * p;
+    m = a.beta1 * m + (1.f - a.beta1) * g;
+    v = a.beta2 * v + (1.f - a.beta2) * g * g;
+    const float denom = sqrtf(v) / sqrtf(bias_c2) + a.eps;
+    p -= (lr / bias_c1) * (m / denom);
+  } else if (a.kind == 1) {  // rmsprop (alpha = beta2 slot), no momentum, not centred
+    g += a.weight_decay * p;
+    v = a.beta2 * v + (1.f - a.beta2) * g * g;
+    p -= lr * g / (sqrtf(v) + a.eps);
+  } else {  // sgd with momentum (beta1), dampening 0
+    g += a.weight_decay * p;
+    if (a.beta1 != 0.f && a.m) {
+      m = a.first_step ? g : a.beta1 * m + g;
+      g = m;
+    }
+    p -= lr * g;
+  }
+  return p;
+}
+
+// VEC = 4: 16-byte accesses (n % 4 == 0, 16-byte aligned arenas); VEC = 1: scalar.  NT: non-temporal accesses (a 150 M
+// element arena is a pure stream: nothing is reused from L2 / MALL)
+template <bool NT> __device__ __forceinline__ f32x4_t ldv(const float* p, long long i) {
+  const f32x4_t* q = reinterpret_cast<const f32x4_t*>(p) + i;
+  if constexpr (NT) return __builtin_nontemporal_load(q); else return *q;
+}
+template <bool NT> __device__ __forceinline__ void stv(float* p, long long i, f32x4_t v) {
+  f32x4_t* q = reinterpret_cast<f32x4_t*>(p) + i;
+  if constexpr (NT) __builtin_nontemporal_store(v, q); else *q = v;
+}
+// Work assignment: block b owns the contiguous run of 256*U vectors starting at b*256*U (no grid-stride loop: blocks are
+// dispatched in order, so at any moment the chip works on one compact window of each of the seven streams, which keeps
+// HBM pages open; measured 5.9 TB/s against 5.0 TB/s for a 2048-block grid-stride loop on the 152 M element SPN arena).
+template <int VEC, bool NT, int U>
 __global__ __launch_bounds__(256) void optim_step_kernel(const spb_optim_args_t a) {
   float gm = a.gmul ? *a.gmul : 1.f;
   float coef = 1.f;
@@ -224,41 +270,56 @@ __global__ __launch_bounds__(256) void optim_step_kernel(const spb_optim_args_t 
   const float lr = a.hyper ? a.hyper[0] : a.lr;
   const float bias_c1 = a.hyper ? a.hyper[1] : a.bias_c1;
   const float bias_c2 = a.hyper ? a.hyper[2] : a.bias_c2;
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < a.n; i += (long long)gridDim.x * 256) {
-    float p = a.params[i];
-    float g = a.grads[i] * gs;
-    if (a.clip_value > 0.f) g = fminf(fmaxf(g, -a.clip_value), a.clip_value);
-    if (a.kind == 3) {  // adamw (decoupled decay)
-      p *= 1.f - lr * a.weight_decay;
-      const float m = a.beta1 * a.m[i] + (1.f - a.beta1) * g;
-      const float v = a.beta2 * a.v[i] + (1.f - a.beta2) * g * g;
-      a.m[i] = m; a.v[i] = v;
-      const float denom = sqrtf(v) / sqrtf(bias_c2) + a.eps;
-      p -= (lr / bias_c1) * (m / denom);
-    } else if (a.kind == 2) {  // adam (L2 folded into the gradient)
-      g += a.weight_decay * p;
-      const float m = a.beta1 * a.m[i] + (1.f - a.beta1) * g;
-      const float v = a.beta2 * a.v[i] + (1.f - a.beta2) * g * g;
-      a.m[i] = m; a.v[i] = v;
-      const float denom = sqrtf(v) / sqrtf(bias_c2) + a.eps;
-      p -= (lr / bias_c1) * (m / denom);
-    } else if (a.kind == 1) {  // rmsprop (alpha = beta2 slot), no momentum, not centred
-      g += a.weight_decay * p;
-      const float v = a.beta2 * a.v[i] + (1.f - a.beta2) * g * g;
-      a.v[i] = v;
-      p -= lr * g / (sqrtf(v) + a.eps);
-    } else {  // sgd with momentum (beta1), dampening 0
-      g += a.weight_decay * p;
-      if (a.beta1 != 0.f && a.m) {
-        const float b = a.first_step ? g : a.beta1 * a.m[i] + g;
-        a.m[i] = b;
-        g = b;
+  const bool has_m = a.m && (a.kind >= 2 || (a.kind == 0 && a.beta1 != 0.f));
+  const bool has_v = a.v && a.kind >= 1;
+  bf16_t* sh = reinterpret_cast<bf16_t*>(a.shadow_bf16);
+  const long long nv = a.n / VEC;
+  const long long base = (long long)blockIdx.x * (256 * U) + threadIdx.x;
+  if constexpr (VEC == 4) {
+    f32x4_t p[U], g[U], m[U], v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const long long i = base + u * 256;
+      if (i < nv) {
+        p[u] = ldv<NT>(a.params, i);
+        g[u] = ldv<NT>(a.grads, i);
+        m[u] = has_m ? ldv<NT>(a.m, i) : f32x4_t{0.f, 0.f, 0.f, 0.f};
+        v[u] = has_v ? ldv<NT>(a.v, i) : f32x4_t{0.f, 0.f, 0.f, 0.f};
       }
-      p -= lr * g;
     }
-    a.params[i] = p;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const long long i = base + u * 256;
+      if (i < nv) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float me = m[u][e], ve = v[u][e];
+          p[u][e] = optim_one(a, gs, lr, bias_c1, bias_c2, p[u][e], g[u][e], me, ve);
+          m[u][e] = me; v[u][e] = ve;
+        }
+        if (has_m) stv<NT>(a.m, i, m[u]);
+        if (has_v) stv<NT>(a.v, i, v[u]);
+        stv<NT>(a.params, i, p[u]);
+        if (sh) reinterpret_cast<uint2*>(sh)[i] = make_uint2(pack_bf16x2(p[u][0], p[u][1]), pack_bf16x2(p[u][2], p[u][3]));
+      }
+    }
+  } else {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const long long i = base + u * 256;
+      if (i < nv) {
+        float m = has_m ? a.m[i] : 0.f, v = has_v ? a.v[i] : 0.f;
+        const float p = optim_one(a, gs, lr, bias_c1, bias_c2, a.params[i], a.grads[i], m, v);
+        if (has_m) a.m[i] = m;
+        if (has_v) a.v[i] = v;
+        a.params[i] = p;
+        if (sh) sh[i] = f2bf(p);
+      }
+    }
   }
 }
+
+int g_opt_vec = 1, g_opt_blocks = 2, g_opt_nt = 0;   // measured best on the 152 M element arena: scalar lanes, 2 per thread
 
 int elem_grid(long long items) {
   long long g = (items + 255) / 256;
@@ -350,7 +411,26 @@ extern "C" int spb_optim_step(const spb_optim_args_t* a, spb_stream_t stream) {
   if (a->kind < 0 || a->kind > 3) return SPB_E_ARG;
   if (a->kind >= 2 && (!a->m || !a->v)) return SPB_E_ARG;
   if (a->kind == 1 && !a->v) return SPB_E_ARG;
-  hipLaunchKernelGGL(optim_step_kernel, dim3(elem_grid(a->n)), dim3(256), 0, (hipStream_t)stream, *a);
+  const bool vec = !(a->n & 3) && !(((uintptr_t)a->params | (uintptr_t)a->grads | (uintptr_t)a->m | (uintptr_t)a->v) & 15) &&
+                   !((uintptr_t)a->shadow_bf16 & 7);
+  const bool v4 = vec && g_opt_vec == 4;
+  const long long items = v4 ? a->n / 4 : a->n;
+  const int U = g_opt_blocks > 0 ? g_opt_blocks : 1;      // debug knob reused: vectors per thread
+  const unsigned blocks = (unsigned)((items + 256 * U - 1) / (256 * U));
+  hipStream_t hs = (hipStream_t)stream;
+#define SPB_OPT_LAUNCH(V, NTF, UU) hipLaunchKernelGGL((optim_step_kernel<V, NTF, UU>), dim3(blocks), dim3(256), 0, hs, *a)
+  if (v4) {
+    if (g_opt_nt) { if (U == 4) SPB_OPT_LAUNCH(4, true, 4); else if (U == 2) SPB_OPT_LAUNCH(4, true, 2); else SPB_OPT_LAUNCH(4, true, 1); }
+    else { if (U == 4) SPB_OPT_LAUNCH(4, false, 4); else if (U == 2) SPB_OPT_LAUNCH(4, false, 2); else SPB_OPT_LAUNCH(4, false, 1); }
+  } else {
+    if (U == 4) SPB_OPT_LAUNCH(1, false, 4); else if (U == 2) SPB_OPT_LAUNCH(1, false, 2); else SPB_OPT_LAUNCH(1, false, 1);
+  }
+#undef SPB_OPT_LAUNCH
   SPB_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int spb_debug_set_optim(int vec, int blocks, int nontemporal) {
+  g_opt_vec = vec == 4 ? 4 : 1; g_opt_blocks = blocks; g_opt_nt = nontemporal;
   return 0;
 }

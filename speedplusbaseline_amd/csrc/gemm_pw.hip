@@ -60,6 +60,7 @@ __global__ __launch_bounds__(256, (RF == 1 && sizeof(T) == 2) ? 4 : 1) void pw_g
   extern __shared__ __attribute__((aligned(16))) char smem[];
   SPB_TS(0);
   const int M = g.M, K = g.K, N = g.N;
+  const int lda = g.lda > 0 ? g.lda : K, ldc = g.ldc > 0 ? g.ldc : N;   // row strides of A (and A2) / Y (and res, Zout)
   const int Kp = (K + GBK - 1) / GBK * GBK;
   float* coef = reinterpret_cast<float*>(smem);  // [3][Kp]
   float* ecoef = coef + 3 * Kp;                   // [2][BN] (EPI 2): scale, shift of the input-side BN
@@ -137,7 +138,7 @@ __global__ __launch_bounds__(256, (RF == 1 && sizeof(T) == 2) ? 4 : 1) void pw_g
       const int kc = k < K ? k : K - 8;                                                       \
       _Pragma("unroll") for (int i = 0; i < NA; ++i) {                                        \
         const int m = (m0_) + rowA + AROWS * i;                                               \
-        const size_t o = (size_t)(m < M ? m : M - 1) * K + kc;                                \
+        const size_t o = (size_t)(m < M ? m : M - 1) * lda + kc;                                \
         ra[S][i] = ldraw<T>(Ag + o);                                                          \
         if (PRO == 2) { if (A2g) ra2[S][i] = ldraw<T>(A2g + o); }                             \
       }                                                                                       \
@@ -245,7 +246,7 @@ __global__ __launch_bounds__(256, (RF == 1 && sizeof(T) == 2) ? 4 : 1) void pw_g
 #pragma unroll
       for (int s = 0; s < VRI; ++s) {
         const int m = m0 + vrow0 + s * VR;
-        const size_t o = (size_t)(m < M ? m : M - 1) * N + (colok ? nE : 0);
+        const size_t o = (size_t)(m < M ? m : M - 1) * ldc + (colok ? nE : 0);
         zr[EPI == 2 ? s : 0] = ldraw<T>(Zg + o);
         if (Rg) rr[EPI == 2 ? s : 0] = ldraw<T>(Rg + o);
       }
@@ -270,7 +271,7 @@ __global__ __launch_bounds__(256, (RF == 1 && sizeof(T) == 2) ? 4 : 1) void pw_g
         if (r < BM && m < M) {
           float v[8];
           ld8<T>(Os + r * LDO + vcol * 8, v);
-          const size_t o = (size_t)m * N + nE;
+          const size_t o = (size_t)m * ldc + nE;
           if (EPI == 0) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] = act_fwd(v[j] * g.out_scale + e_bias[j], g.out_act, 0.f);
@@ -635,7 +636,7 @@ int dispatch_bn(const spb_gemm_args_t& g, hipStream_t stream) {
   if (small_m && bn == 128) bn = 64;
   if (small_m) {
     if (bn == 32) return launch_gemm<T, 1, 32, 32, PRO, EPI>(g, stream);
-    if (g.K >= 64 && sizeof(T) == 2 && !g_disable_dma) return launch_gemm_dma<PRO, EPI>(g, stream);
+    if (g.K >= 64 && sizeof(T) == 2 && !g_disable_dma && g.lda <= 0 && g.ldc <= 0) return launch_gemm_dma<PRO, EPI>(g, stream);
     // long reductions (the 7x7 ConvDw layers, K up to 1280): 64-wide chunks halve the number of latency-bound steps
     // (forward-type only: the backward variant spills 87 dwords at 128 VGPRs with two 64-wide prefetch sets: 0.68 -> 0.75 ms)
     if (sizeof(T) == 2 && PRO == 1 && g.K >= g_bk64_min_k) return launch_gemm<T, 1, 64, 64, PRO, EPI>(g, stream);
@@ -703,6 +704,7 @@ __global__ __launch_bounds__(256) void pw_wgrad_kernel(const spb_wgrad_args_t g,
 #pragma unroll
     for (int b = 0; b < 2; ++b) acc[a][b] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
+  const size_t ldg = g.ldg > 0 ? g.ldg : N, ldx = g.ldx > 0 ? g.ldx : K;   // row strides of G (and Zn) / X
   const int cv = t & 7, rw = t >> 3;  // rows rw, rw+32; columns cv*8..cv*8+7
   const int nl = n0 + cv * 8, kl = k0 + cv * 8;
   const int nlc = nl < N ? nl : N - 8, klc = kl < K ? kl : K - 8;
@@ -713,9 +715,9 @@ __global__ __launch_bounds__(256) void pw_wgrad_kernel(const spb_wgrad_args_t g,
   _Pragma("unroll") for (int i = 0; i < 2; ++i) {                             \
     const int m = (mb_) + rw + 32 * i;                                        \
     const size_t mc_ = (size_t)(m < mend ? m : mend - 1);                     \
-    gr[i] = ldraw<T>(Gg + mc_ * N + nlc);                                     \
-    if (Zg) zr[i] = ldraw<T>(Zg + mc_ * N + nlc);                             \
-    xr[i] = ldraw<T>(Xg + mc_ * K + klc);                                     \
+    gr[i] = ldraw<T>(Gg + mc_ * ldg + nlc);                                   \
+    if (Zg) zr[i] = ldraw<T>(Zg + mc_ * ldg + nlc);                           \
+    xr[i] = ldraw<T>(Xg + mc_ * ldx + klc);                                   \
   }
   if (mbeg < mend) WG_LOAD(mbeg);
   for (int mb = mbeg; mb < mend; mb += WM) {

@@ -26,11 +26,12 @@ template <typename T> __device__ __forceinline__ void stf(T* p, float v);
 template <> __device__ __forceinline__ void stf<float>(float* p, float v) { *p = v; }
 template <> __device__ __forceinline__ void stf<bf16_t>(bf16_t* p, float v) { *p = f2bf(v); }
 
-// dst[m][k], k = (ky*KW + kx)*C + c; 8 channels per thread (C % 8 == 0)
+// dst[m][k], k = gi*Kg + (ky*KW + kx)*cig + c_local for channel c = gi*cig + c_local of group gi (Kg = Kpad / groups; one
+// contiguous column slab per group, so a grouped convolution is one dense GEMM per group); 8 channels per thread
 template <typename T>
 __global__ void im2col_kernel(const T* __restrict__ src, T* __restrict__ dst, int B, int H, int W, int C, int KH, int KW, int st,
-                              int pad, int OH, int OW, int Kpad) {
-  const int CV = C >> 3;
+                              int pad, int OH, int OW, int Kpad, int groups) {
+  const int CV = C >> 3, cig = C / groups, Kg = Kpad / groups;
   const long long total = (long long)B * OH * OW * KH * KW * CV;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
     const int cv = (int)(i % CV);
@@ -44,7 +45,8 @@ __global__ void im2col_kernel(const T* __restrict__ src, T* __restrict__ dst, in
 #pragma unroll
     for (int j = 0; j < 8; ++j) v[j] = 0.f;
     if (iy >= 0 && iy < H && ix >= 0 && ix < W) ld8<T>(src + ((size_t)(b * H + iy) * W + ix) * C + cv * 8, v);
-    st8<T>(dst + ((size_t)(b * OH + oy) * OW + ox) * Kpad + (size_t)tap * C + cv * 8, v);
+    const int c = cv * 8, gi = c / cig;
+    st8<T>(dst + ((size_t)(b * OH + oy) * OW + ox) * Kpad + (size_t)gi * Kg + (size_t)tap * cig + (c - gi * cig), v);
   }
 }
 
@@ -71,8 +73,8 @@ __global__ void im2col_rgb_kernel(const float* __restrict__ x, T* __restrict__ d
 // dx[b,iy,ix,c] = sum over taps of dcol[(b, iy+pad-ky, ix+pad-kx)][(ky*KW+kx)*C + c]   (stride 1)
 template <typename T>
 __global__ void col2im_kernel(const T* __restrict__ dcol, T* __restrict__ dx, int B, int H, int W, int C, int KH, int KW, int pad,
-                              int OH, int OW, int Kpad) {
-  const int CV = C >> 3;
+                              int OH, int OW, int Kpad, int groups) {
+  const int CV = C >> 3, cig = C / groups, Kg = Kpad / groups;
   const long long total = (long long)B * H * W * CV;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
     const int cv = (int)(i % CV);
@@ -83,6 +85,8 @@ __global__ void col2im_kernel(const T* __restrict__ dcol, T* __restrict__ dx, in
     float acc[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+    const int c = cv * 8, gi = c / cig;
+    const size_t cbase = (size_t)gi * Kg + (c - gi * cig);
     for (int ky = 0; ky < KH; ++ky) {
       const int oy = iy + pad - ky;
       if (oy < 0 || oy >= OH) continue;
@@ -90,7 +94,7 @@ __global__ void col2im_kernel(const T* __restrict__ dcol, T* __restrict__ dx, in
         const int ox = ix + pad - kx;
         if (ox < 0 || ox >= OW) continue;
         float v[8];
-        ld8<T>(dcol + ((size_t)(b * OH + oy) * OW + ox) * Kpad + (size_t)(ky * KW + kx) * C + cv * 8, v);
+        ld8<T>(dcol + ((size_t)(b * OH + oy) * OW + ox) * Kpad + cbase + (size_t)(ky * KW + kx) * cig, v);
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[j] += v[j];
       }
@@ -274,6 +278,63 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ g, fl
   atomicAdd(out + n, s);
 }
 
+// N % 8 == 0, N <= 2048: a block walks its rows RP at a time, every thread owning 8 adjacent columns (16-byte loads for
+// bf16), then sums its row lanes through LDS: M*N/2048 blocks' worth of parallelism instead of one thread per column
+template <typename T>
+__global__ __launch_bounds__(256) void colsum8_kernel(const T* __restrict__ g, float* __restrict__ out, long long M, int N,
+                                                      long long rows_per_block) {
+  __shared__ float red[2048];
+  const int CV = N >> 3, RP = 256 / CV;
+  const int t = threadIdx.x, cv = t % CV, r = t / CV;
+  const long long m0 = (long long)blockIdx.x * rows_per_block;
+  const long long m1 = m0 + rows_per_block < M ? m0 + rows_per_block : M;
+  float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (r < RP)
+    for (long long m = m0 + r; m < m1; m += RP) {
+      float v[8];
+      ld8<T>(g + m * N + cv * 8, v);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s[j] += v[j];
+    }
+  if (r < RP)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) red[r * N + cv * 8 + j] = s[j];
+  __syncthreads();
+  for (int n = t; n < N; n += 256) {
+    float a = 0.f;
+    for (int q = 0; q < RP; ++q) a += red[q * N + n];
+    atomicAdd(out + n, a);
+  }
+}
+
+// nn.Conv2d weight [Cout][Cin/G][KH][KW] -> Wp [Cout][Kg], row co = its group's filter in (ky,kx,c_local) order (zero padded up
+// to Kg), i.e. G stacked [Cout/G][Kg] GEMM operands; WpT [G][Kg][Cout/G] holds the per-group transposes (input gradient)
+template <typename T>
+__global__ void pack_conv_kernel(const float* __restrict__ W, T* __restrict__ Wp, T* __restrict__ WpT, int Cout, int Cin, int G, int KH,
+                                 int KW, int Kg) {
+  const long long total = (long long)Cout * Kg;
+  const int cog = Cout / G, cig = Cin / G;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int co = (int)(i / Kg), k = (int)(i % Kg);
+    float v = 0.f;
+    if (k < KH * KW * cig) v = W[((size_t)co * cig + (k % cig)) * KH * KW + k / cig];
+    stf<T>(Wp + i, v);
+    const int gi = co / cog;
+    if (WpT) stf<T>(WpT + ((size_t)gi * Kg + k) * cog + (co - gi * cog), v);
+  }
+}
+__global__ void unpack_conv_grad_kernel(const float* __restrict__ dWp, float* __restrict__ dW, int Cout, int Cin, int G, int KH, int KW,
+                                        int Kg) {
+  const int cig = Cin / G;
+  const long long total = (long long)Cout * cig * KH * KW;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int tap = (int)(i % (KH * KW));
+    const int ci = (int)((i / (KH * KW)) % cig);
+    const int co = (int)(i / ((long long)KH * KW * cig));
+    dW[i] = dWp[(size_t)co * Kg + (size_t)tap * cig + ci];
+  }
+}
+
 inline unsigned grid_for(long long total) {
   long long g = (total + 255) / 256;
   return (unsigned)(g > 65535 * 4 ? 65535 * 4 : (g < 1 ? 1 : g));
@@ -285,8 +346,10 @@ inline unsigned grid_for(long long total) {
   if ((dtype) == SPB_BF16) { CALL_BF; } else if ((dtype) == SPB_F32) { CALL_F32; } else return SPB_E_ARG;
 
 extern "C" int spb_im2col(int dtype, const void* src, void* dst, int B, int H, int W, int C, int KH, int KW, int stride, int pad,
-                          int Kpad, spb_stream_t stream) {
-  if (!src || !dst || B <= 0 || (C & 7) || Kpad < KH * KW * C || (Kpad & 7)) return SPB_E_ARG;
+                          int Kpad, int groups, spb_stream_t stream) {
+  if (!src || !dst || B <= 0 || (C & 7) || Kpad < KH * KW * C || (Kpad & 7) || groups < 1 || (C % groups) || ((C / groups) & 7) ||
+      (Kpad % groups))
+    return SPB_E_ARG;
   const int OH = (H + 2 * pad - KH) / stride + 1, OW = (W + 2 * pad - KW) / stride + 1;
   const long long total = (long long)B * OH * OW * KH * KW * (C >> 3);
   hipStream_t s = (hipStream_t)stream;
@@ -295,8 +358,8 @@ extern "C" int spb_im2col(int dtype, const void* src, void* dst, int B, int H, i
     hipError_t e = hipMemsetAsync(dst, 0, (size_t)B * OH * OW * Kpad * es, s);
     if (e != hipSuccess) return (int)e;
   }
-  SPN_T(dtype, hipLaunchKernelGGL(im2col_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, s, (const bf16_t*)src, (bf16_t*)dst, B, H, W, C, KH, KW, stride, pad, OH, OW, Kpad),
-        hipLaunchKernelGGL(im2col_kernel<float>, dim3(grid_for(total)), dim3(256), 0, s, (const float*)src, (float*)dst, B, H, W, C, KH, KW, stride, pad, OH, OW, Kpad))
+  SPN_T(dtype, hipLaunchKernelGGL(im2col_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, s, (const bf16_t*)src, (bf16_t*)dst, B, H, W, C, KH, KW, stride, pad, OH, OW, Kpad, groups),
+        hipLaunchKernelGGL(im2col_kernel<float>, dim3(grid_for(total)), dim3(256), 0, s, (const float*)src, (float*)dst, B, H, W, C, KH, KW, stride, pad, OH, OW, Kpad, groups))
   SPB_CHECK_LAUNCH();
   return 0;
 }
@@ -314,13 +377,13 @@ extern "C" int spb_im2col_rgb(int dtype, const float* x, void* dst, int B, int H
 }
 
 extern "C" int spb_col2im(int dtype, const void* dcol, void* dx, int B, int H, int W, int C, int KH, int KW, int pad, int Kpad,
-                          spb_stream_t stream) {
-  if (!dcol || !dx || B <= 0 || (C & 7)) return SPB_E_ARG;
+                          int groups, spb_stream_t stream) {
+  if (!dcol || !dx || B <= 0 || (C & 7) || groups < 1 || (C % groups) || ((C / groups) & 7) || (Kpad % groups)) return SPB_E_ARG;
   const int OH = H + 2 * pad - KH + 1, OW = W + 2 * pad - KW + 1;
   const long long total = (long long)B * H * W * (C >> 3);
   hipStream_t s = (hipStream_t)stream;
-  SPN_T(dtype, hipLaunchKernelGGL(col2im_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, s, (const bf16_t*)dcol, (bf16_t*)dx, B, H, W, C, KH, KW, pad, OH, OW, Kpad),
-        hipLaunchKernelGGL(col2im_kernel<float>, dim3(grid_for(total)), dim3(256), 0, s, (const float*)dcol, (float*)dx, B, H, W, C, KH, KW, pad, OH, OW, Kpad))
+  SPN_T(dtype, hipLaunchKernelGGL(col2im_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, s, (const bf16_t*)dcol, (bf16_t*)dx, B, H, W, C, KH, KW, pad, OH, OW, Kpad, groups),
+        hipLaunchKernelGGL(col2im_kernel<float>, dim3(grid_for(total)), dim3(256), 0, s, (const float*)dcol, (float*)dx, B, H, W, C, KH, KW, pad, OH, OW, Kpad, groups))
   SPB_CHECK_LAUNCH();
   return 0;
 }
@@ -401,11 +464,41 @@ extern "C" int spb_softce(int dtype, const void* logits, const float* target, vo
 
 extern "C" int spb_colsum(int dtype, const void* g, float* out, long long M, int N, spb_stream_t stream) {
   if (!g || !out || M <= 0 || N <= 0) return SPB_E_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  if (!(N & 7) && N <= 2048 && M >= 64) {
+    const int RP = 256 / (N >> 3);
+    long long rpb = (M + 1023) / 1024;
+    rpb = (rpb + RP - 1) / RP * RP;
+    const dim3 g8((unsigned)((M + rpb - 1) / rpb));
+    SPN_T(dtype, hipLaunchKernelGGL(colsum8_kernel<bf16_t>, g8, dim3(256), 0, s, (const bf16_t*)g, out, M, N, rpb),
+          hipLaunchKernelGGL(colsum8_kernel<float>, g8, dim3(256), 0, s, (const float*)g, out, M, N, rpb))
+    SPB_CHECK_LAUNCH();
+    return 0;
+  }
   const long long rpb = M > 4096 ? 1024 : (M > 256 ? 64 : M);
   const dim3 grid((unsigned)((N + 255) / 256), (unsigned)((M + rpb - 1) / rpb));
-  hipStream_t s = (hipStream_t)stream;
   SPN_T(dtype, hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)g, out, M, N, rpb),
         hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, s, (const float*)g, out, M, N, rpb))
+  SPB_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int spb_spn_pack_conv(int dtype, const float* W, void* Wp, void* WpT, int Cout, int Cin, int groups, int KH, int KW, int Kg,
+                                 spb_stream_t stream) {
+  if (!W || !Wp || Cout <= 0 || Cin <= 0 || groups <= 0 || (Cout % groups) || (Cin % groups) || Kg < KH * KW * (Cin / groups)) return SPB_E_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  const unsigned grid = grid_for((long long)Cout * Kg);
+  SPN_T(dtype, hipLaunchKernelGGL(pack_conv_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, W, (bf16_t*)Wp, (bf16_t*)WpT, Cout, Cin, groups, KH, KW, Kg),
+        hipLaunchKernelGGL(pack_conv_kernel<float>, dim3(grid), dim3(256), 0, s, W, (float*)Wp, (float*)WpT, Cout, Cin, groups, KH, KW, Kg))
+  SPB_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int spb_spn_unpack_conv_grad(const float* dWp, float* dW, int Cout, int Cin, int groups, int KH, int KW, int Kg,
+                                        spb_stream_t stream) {
+  if (!dWp || !dW || Cout <= 0 || Cin <= 0 || groups <= 0 || (Cout % groups) || (Cin % groups) || Kg < KH * KW * (Cin / groups)) return SPB_E_ARG;
+  hipLaunchKernelGGL(unpack_conv_grad_kernel, dim3(grid_for((long long)Cout * (Cin / groups) * KH * KW)), dim3(256), 0, (hipStream_t)stream,
+                     dWp, dW, Cout, Cin, groups, KH, KW, Kg);
   SPB_CHECK_LAUNCH();
   return 0;
 }

@@ -2,10 +2,15 @@
 
 Same constructor, attributes, state_dict keys (conv1..conv5, fc6..fc11 `.weight` / `.bias`) and return values as the
 reference class; forward, loss and backward are HIP launches through the C-ABI (include/spb_hip.h):
-every convolution / fully connected layer is a matrix-core GEMM (spb_pwconv_gemm with the bias + ReLU epilogue,
-spb_pwconv_wgrad) on im2col'd NHWC operands, with the pooling / LRN / dropout / soft-target cross-entropy kernels of
-csrc/spn.hip in between.  Grouped convolutions run as block-diagonal full convolutions.  First version of this row:
-correct and matrix-core based, not tuned (weight re-layouts are torch copies per step).  No CPU / eager fallback.
+every convolution is a matrix-core GEMM (spb_pwconv_gemm with the bias + ReLU epilogue, spb_pwconv_wgrad) on im2col'd NHWC
+operands, with the pooling / LRN / soft-target cross-entropy kernels of csrc/spn.hip in between; grouped convolutions run
+as block-diagonal full convolutions.  The fully connected layers (150 M of the 152 M parameters) are weight streams at
+training batch sizes: in bf16 with B <= 64 they use the skinny kernels of csrc/spn_fc.hip (each weight element read once
+per pass straight from a bf16 shadow arena the optimizer maintains; gradients written once, in place, into the flat
+gradient arena).  f32 (parity mode) and larger batches go through the general GEMM kernels.  No CPU / eager fallback.
+
+Memory: parameters and gradients are two flat f32 arenas in state-dict order (nn.Parameter.data / .grad are views), so the
+clip + update is one launch and the data-parallel exchange one all-reduce.
 """
 import ctypes as C
 
@@ -72,6 +77,7 @@ class SpacecraftPoseNet(nn.Module):
                            ("fc10", 4096, 4096), ("fc11", num_classes, 4096)):
             setattr(self, name, _Layer((o, i)))
         self.precision = precision
+        self._flat = self._gflat = self._shadow = None
         self._version = 0          # bumped whenever parameters change: compute copies are rebuilt lazily
         self._copies = None
         self._ws = {}
@@ -97,7 +103,50 @@ class SpacecraftPoseNet(nn.Module):
         self.invalidate()
 
     def invalidate(self):
+        """parameters were changed by someone other than SpnOptimizer: compute copies and the bf16 shadow are stale"""
         self._version += 1
+
+    # ---- flat arenas: parameter i lives at [off, off + numel) of self._flat (offsets multiples of 8 elements)
+    def _ensure_arena(self):
+        if self._flat is not None:
+            return
+        dev = self.conv1.weight.device
+        if dev.type != "cuda":
+            raise RuntimeError("SpacecraftPoseNet runs on the MI355X only (no CPU path)")
+        offs, off = {}, 0
+        for n, p_ in self.named_parameters():
+            offs[n] = (off, p_.numel())
+            off += (p_.numel() + 7) // 8 * 8
+        flat = torch.zeros(off, dtype=torch.float32, device=dev)
+        gflat = torch.zeros(off, dtype=torch.float32, device=dev)
+        with torch.no_grad():
+            for n, p_ in self.named_parameters():
+                o, k = offs[n]
+                flat[o:o + k].copy_(p_.detach().reshape(-1).float())
+                p_.data = flat[o:o + k].view(p_.shape)
+                p_.grad = gflat[o:o + k].view(p_.shape)
+        self._flat, self._gflat, self._offs = flat, gflat, offs
+        self._shadow = torch.empty(off, dtype=torch.bfloat16, device=dev) if self.precision == "bf16" else None
+        self._shadow_version = -1
+        self._conv_end = offs["fc6.weight"][0]
+
+    def flat_parameters(self):
+        self._ensure_arena()
+        return self._flat
+
+    def flat_grads(self):
+        self._ensure_arena()
+        return self._gflat
+
+    def _sh(self, name):
+        """bf16 shadow view of parameter `name` (valid after _refresh)"""
+        o, k = self._offs[name]
+        return self._shadow[o:o + k]
+
+    def optimizer_updated(self):
+        """SpnOptimizer wrote new parameters AND their bf16 shadow"""
+        self._version += 1
+        self._shadow_version = self._version
 
     def load_state_dict(self, *a, **k):
         r = super().load_state_dict(*a, **k)
@@ -106,7 +155,7 @@ class SpacecraftPoseNet(nn.Module):
 
     def _apply(self, fn, *a, **k):
         r = super()._apply(fn, *a, **k)
-        self.invalidate(); self._ws = {}; self._copies = None
+        self.invalidate(); self._ws = {}; self._copies = None; self._flat = self._gflat = self._shadow = None
         return r
 
     # ---- compute-dtype copies: conv weights as [Cout][Kpad] in (ky,kx,c_full) order (block diagonal for groups),
@@ -114,31 +163,35 @@ class SpacecraftPoseNet(nn.Module):
     def _dt(self):
         return torch.bfloat16 if self.precision == "bf16" else torch.float32
 
-    def _build_copies(self, need_t):
-        if self._copies is not None and self._copies["v"] == self._version and (self._copies["t"] or not need_t):
-            return self._copies
-        dt = self._dt()
-        cp = {"v": self._version, "t": need_t}
+    def _fast(self, B):
+        return self.precision == "bf16" and B <= 64 and self.num_classes % 8 == 0
+
+    def _build_copies(self, need_t, fast):
+        cpo = self._copies
+        if cpo is not None and cpo["v"] == self._version and (cpo["t"] or not need_t) and (cpo["fc"] or fast):
+            return cpo
+        lib, st = L.lib(), _st()
+        dt, dc = self._dt(), (L.BF16 if self.precision == "bf16" else L.F32)
+        cp = {"v": self._version, "t": need_t, "fc": not fast}
         for name, cout, cin, g, k, _, _ in _CONVS:
-            w = getattr(self, name).weight.detach()
-            kk = k * k * cin
-            kpad = (kk + 7) // 8 * 8
-            full = torch.zeros(cout, k, k, cin, dtype=torch.float32, device=w.device)
-            cog, cig = cout // g, cin // g
-            for gi in range(g):
-                full[gi * cog:(gi + 1) * cog, :, :, gi * cig:(gi + 1) * cig] = w[gi * cog:(gi + 1) * cog].permute(0, 2, 3, 1)
-            wf = torch.zeros(cout, kpad, dtype=torch.float32, device=w.device)
-            wf[:, :kk] = full.reshape(cout, kk)
-            cp[name] = wf.to(dt).contiguous()
-            if need_t and name != "conv1":
-                cp[name + "T"] = wf.t().contiguous().to(dt)
-        for name in ("fc6", "fc7", "fc8", "fc9", "fc10", "fc11"):
-            w = getattr(self, name).weight.detach()
-            if name in ("fc6", "fc9"):
-                w = w.view(4096, 256, 6, 6).permute(0, 2, 3, 1).reshape(4096, 9216)
-            cp[name] = w.to(dt).contiguous()
-            if need_t:
-                cp[name + "T"] = w.t().contiguous().to(dt)
+            kg = (k * k * (cin // g) + 7) // 8 * 8             # one column slab / one [cout/g][kg] operand per group
+            wp = self._buf("wp" + name, (cout, kg), dt)
+            wt = self._buf("wpT" + name, (g, kg, cout // g), dt) if (need_t and name != "conv1") else None
+            L.check(lib.spb_spn_pack_conv(dc, _p(getattr(self, name).weight.detach()), _p(wp), _p(wt), cout, cin, g, k, k, kg, st),
+                    "spb_spn_pack_conv")
+            cp[name] = wp
+            if wt is not None:
+                cp[name + "T"] = wt
+        if fast:
+            if self._shadow_version != self._version:     # load_state_dict / load_weights / manual edits: rare
+                self._shadow.copy_(self._flat)
+                self._shadow_version = self._version
+        else:
+            for name in ("fc6", "fc7", "fc8", "fc9", "fc10", "fc11"):
+                w = getattr(self, name).weight.detach()
+                cp[name] = w.to(dt).contiguous()
+                if need_t:
+                    cp[name + "T"] = w.t().contiguous().to(dt)
         self._copies = cp
         return cp
 
@@ -154,28 +207,42 @@ class SpacecraftPoseNet(nn.Module):
     def _gemm(self, A, W, bias, Y, relu):
         ops.pwconv_gemm(A, W, Y, ops.bnref(A.shape[1]), 1, 0, bias=bias, out_act=L.ACT_RELU if relu else L.ACT_NONE, out_scale=1.0)
 
-    def _forward_impl(self, x, training, masks=None):
-        lib = L.lib()
-        if not x.is_cuda:
-            raise RuntimeError("SpacecraftPoseNet runs on the MI355X only (no CPU path)")
+    def _epi(self, B, F, mode, accT=None, src=None, bias=None, H=None, Y=None, YT=None, mask=None, db=None, relu=0, p=0.0, scale=1.0,
+             seed=0, given=0):
+        a = L.FcEpiArgs()
+        a.accT, a.src, a.bias, a.H, a.Y, a.YT, a.mask, a.db = (_p(accT).value, _p(src).value, _p(bias).value, _p(H).value, _p(Y).value,
+                                                                _p(YT).value, _p(mask).value, _p(db).value)
+        a.M, a.F, a.mode, a.relu, a.p, a.scale, a.seed, a.mask_given = B, F, mode, relu, p, scale, seed, given
+        L.check(L.lib().spb_fc_epilogue(C.byref(a), _st()), "spb_fc_epilogue")
+
+    def _acc(self, key, F, MP):
+        """zero-initialised feature-major f32 accumulator; the epilogue kernels hand it back zeroed"""
+        t = self._ws.get(key)
+        if t is None or t.shape != (F, MP):
+            t = torch.zeros(F, MP, dtype=torch.float32, device=self.conv1.weight.device)
+            self._ws[key] = t
+        return t
+
+    def _trunk(self, x, cp, sv):
+        lib, st = L.lib(), _st()
         B, _, H, W = x.shape
         dt, dc = self._dt(), (L.BF16 if self.precision == "bf16" else L.F32)
-        cp = self._build_copies(need_t=training)
         x = x.contiguous().float()
-        st = _st()
-        sv = {"B": B}
-        # conv1 .. conv5
         cur, Hc, Wc, Cc = None, H, W, 3
         for li, (name, cout, cin, g, k, stride, pad) in enumerate(_CONVS):
             OH, OW = (Hc + 2 * pad - k) // stride + 1, (Wc + 2 * pad - k) // stride + 1
-            kpad = cp[name].shape[1]
+            kg = cp[name].shape[1]
+            kpad, cog = kg * g, cout // g
             col = self._buf("col" + name, (B * OH * OW, kpad), dt)
             if li == 0:
                 L.check(lib.spb_im2col_rgb(dc, _p(x), _p(col), B, Hc, Wc, k, k, stride, kpad, st), "spb_im2col_rgb")
             else:
-                L.check(lib.spb_im2col(dc, _p(cur), _p(col), B, Hc, Wc, Cc, k, k, stride, pad, kpad, st), "spb_im2col")
+                L.check(lib.spb_im2col(dc, _p(cur), _p(col), B, Hc, Wc, Cc, k, k, stride, pad, kpad, g, st), "spb_im2col")
             y = self._buf("y" + name, (B * OH * OW, cout), dt)
-            self._gemm(col, cp[name], getattr(self, name).bias.detach().float(), y, relu=True)
+            bias = getattr(self, name).bias.detach()
+            for gi in range(g):      # one dense GEMM per convolution group on its column slab
+                self._gemm(col[:, gi * kg:(gi + 1) * kg], cp[name][gi * cog:(gi + 1) * cog], bias[gi * cog:(gi + 1) * cog],
+                           y[:, gi * cog:(gi + 1) * cog], relu=True)
             sv["col" + name], sv["y" + name], sv["in" + name] = col, y, (Hc, Wc, Cc)
             cur, Hc, Wc, Cc = y, OH, OW, cout
             if name in ("conv1", "conv2", "conv5"):
@@ -190,29 +257,79 @@ class SpacecraftPoseNet(nn.Module):
                     L.check(lib.spb_lrn2_fwd(dc, _p(cur), _p(n), B * PH * PW, Cc, LRN_ALPHA, LRN_BETA, LRN_K, st), "spb_lrn2_fwd")
                     sv["lrn" + name] = (cur, n)
                     cur = n
-        f = cur.view(B, Hc * Wc * Cc)   # NHWC flatten; fc6 / fc9 columns are permuted accordingly
-        if f.shape[1] != 9216:
+        if Hc * Wc * Cc != 9216:
             raise ValueError("SpacecraftPoseNet needs 227x227 inputs (pool5 must be 6x6x256); got %dx%d" % (H, W))
-        sv["f"] = f
+        return cur
+
+    def _drop_seed(self, hi, second):
+        return self.dropout_seed * 1000003 + self._step * 16 + hi * 4 + (1 if second else 0)
+
+    def _forward_impl(self, x, training, masks=None):
+        lib = L.lib()
+        if not x.is_cuda:
+            raise RuntimeError("SpacecraftPoseNet runs on the MI355X only (no CPU path)")
+        self._ensure_arena()
+        B = x.shape[0]
+        fast = self._fast(B)
+        dt, dc = self._dt(), (L.BF16 if self.precision == "bf16" else L.F32)
+        cp = self._build_copies(need_t=training, fast=fast)
+        st = _st()
+        sv = {"B": B, "fast": fast}
+        p5 = self._trunk(x, cp, sv)                 # pool5 output, NHWC [B, 6, 6, 256]
+        NC = self.num_classes
         outs = []
-        for hi, (a, b_, c_) in enumerate((("fc6", "fc7", "fc8"), ("fc9", "fc10", "fc11"))):
-            h = f
-            for name in (a, b_):
-                y = self._buf("h" + name, (B, 4096), dt)
-                self._gemm(h, cp[name], getattr(self, name).bias.detach().float(), y, relu=True)
-                if training:
-                    m = self._buf("m" + name, (B, 4096), torch.uint8)
-                    given = 0
-                    if masks is not None:
-                        m.copy_(masks[name].to(torch.uint8)); given = 1
-                    seed = self.dropout_seed * 1000003 + self._step * 16 + hi * 4 + (0 if name == a else 1)
-                    L.check(lib.spb_dropout(dc, _p(y), _p(m), B * 4096, float(self.keep_prob), seed, given, st), "spb_dropout")
-                sv["in" + name] = h; sv["h" + name] = y
-                h = y
-            o = self._buf("o" + c_, (B, self.num_classes), dt)
-            self._gemm(h, cp[c_], getattr(self, c_).bias.detach().float(), o, relu=False)
-            sv["in" + c_] = h
-            outs.append(o)
+        if fast:
+            MP = 32 if B <= 32 else 64
+            f, fT = self._buf("f", (B, 9216), dt), self._buf("fT", (9216, MP), dt)
+            L.check(lib.spb_spn_flatten(_p(p5), _p(f), _p(fT), B, 36, 256, st), "spb_spn_flatten")
+            sv["f"], sv["fT"], sv["MP"] = f, fT, MP
+            acc = self._acc("acc", max(4096, NC), MP)
+            for hi, names in enumerate((("fc6", "fc7", "fc8"), ("fc9", "fc10", "fc11"))):
+                h, K = f, 9216
+                for j, name in enumerate(names):
+                    N = NC if j == 2 else 4096
+                    L.check(lib.spb_fc_fwd(_p(h), _p(self._sh(name + ".weight")), _p(acc), B, N, K, st), "spb_fc_fwd")
+                    y = self._buf("h" + name, (B, N), dt)
+                    bias = getattr(self, name).bias.detach()
+                    if j == 2:
+                        self._epi(B, N, 0, accT=acc, bias=bias, Y=y)
+                    else:
+                        yT = self._buf("hT" + name, (N, MP), dt)
+                        m = None
+                        pdrop, given = 0.0, 0
+                        if training:
+                            m = self._buf("m" + name, (B, N), torch.uint8)
+                            pdrop = float(self.keep_prob)
+                            if masks is not None:
+                                m.copy_(masks[name].to(torch.uint8)); given = 1
+                        self._epi(B, N, 0, accT=acc, bias=bias, Y=y, YT=yT, mask=m, relu=1, p=pdrop, seed=self._drop_seed(hi, j == 1),
+                                  given=given)
+                        sv["hT" + name] = yT
+                    sv["in" + name], sv["h" + name] = h, y
+                    h, K = y, N
+                outs.append(h)
+        else:
+            # reference flatten order (NCHW): a small permuting copy on this general path
+            f = p5.reshape(B, 36, 256).permute(0, 2, 1).reshape(B, 9216).contiguous()
+            sv["f"] = f
+            for hi, (a, b_, c_) in enumerate((("fc6", "fc7", "fc8"), ("fc9", "fc10", "fc11"))):
+                h = f
+                for name in (a, b_):
+                    y = self._buf("h" + name, (B, 4096), dt)
+                    self._gemm(h, cp[name], getattr(self, name).bias.detach(), y, relu=True)
+                    if training:
+                        m = self._buf("m" + name, (B, 4096), torch.uint8)
+                        given = 0
+                        if masks is not None:
+                            m.copy_(masks[name].to(torch.uint8)); given = 1
+                        L.check(lib.spb_dropout(dc, _p(y), _p(m), B * 4096, float(self.keep_prob), self._drop_seed(hi, name == b_), given, st),
+                                "spb_dropout")
+                    sv["in" + name] = h; sv["h" + name] = y
+                    h = y
+                o = self._buf("h" + c_, (B, NC), dt)
+                self._gemm(h, cp[c_], getattr(self, c_).bias.detach(), o, relu=False)
+                sv["in" + c_] = h
+                outs.append(o)
         self._saved = sv if training else None
         return outs[0], outs[1]
 
@@ -223,14 +340,14 @@ class SpacecraftPoseNet(nn.Module):
 
     # ---- one training step's loss + gradients (trainer.py:146-177): loss = softCE(c, yClasses) + 10 softCE(r, yWeights)
     def loss_and_grads(self, x, y_classes, y_weights, masks=None):
-        """Runs forward (training mode), the loss and the backward pass; gradients land in p.grad of every parameter.
-        Returns a device tensor (loss, loss_class, loss_regress)."""
+        """Runs forward (training mode), the loss and the backward pass; gradients land in p.grad of every parameter
+        (views of the flat gradient arena).  Returns a device tensor (loss, loss_class, loss_regress)."""
         lib = L.lib()
         dt, dc = self._dt(), (L.BF16 if self.precision == "bf16" else L.F32)
         c, r = self._forward_impl(x, True, masks)
         self._step += 1
         sv, cp = self._saved, self._copies
-        B = sv["B"]
+        B, fast = sv["B"], sv["fast"]
         st = _st()
         NC = self.num_classes
         out = torch.zeros(3, dtype=torch.float32, device=c.device)
@@ -238,45 +355,52 @@ class SpacecraftPoseNet(nn.Module):
         L.check(lib.spb_softce(dc, _p(c), _p(y_classes.float().contiguous()), _p(dcg), _p(out), 1, B, NC, 1.0, st), "spb_softce")
         L.check(lib.spb_softce(dc, _p(r), _p(y_weights.float().contiguous()), _p(drg), _p(out), 2, B, NC, 10.0, st), "spb_softce")
         ident = ops.bnref
-
-        def grads_of(name, g, xin):
-            """weight / bias gradient of layer `name` from g [M][N] and its GEMM input xin [M][K] -> p.grad"""
-            lay = getattr(self, name)
-            N, K = g.shape[1], xin.shape[1]
-            dW = self._buf("dW" + name, (N, K), torch.float32); dW.zero_()
-            ops.pwconv_wgrad(g, xin, dW, ident(N), ident(K))
-            db = self._buf("db" + name, (N,), torch.float32); db.zero_()
-            L.check(lib.spb_colsum(dc, _p(g), _p(db), g.shape[0], N, st), "spb_colsum")
-            return dW, db
-
-        def set_grad(p, val):
-            if p.grad is None:
-                p.grad = torch.empty_like(p)
-            p.grad.copy_(val)
-
         scale = 1.0 / (1.0 - self.keep_prob)
-        df = None
-        for (a, b_, c_), g in ((("fc6", "fc7", "fc8"), dcg), (("fc9", "fc10", "fc11"), drg)):
-            for name, prev in ((c_, b_), (b_, a), (a, None)):
-                xin = sv["in" + name]
-                dW, db = grads_of(name, g, xin)
-                if name in ("fc6", "fc9"):   # back to the reference's NCHW-flatten column order
-                    dW = dW.view(4096, 6, 6, 256).permute(0, 3, 1, 2).reshape(4096, 9216)
-                set_grad(getattr(self, name).weight, dW); set_grad(getattr(self, name).bias, db)
-                dx = self._buf("dx" + name, (B, xin.shape[1]), dt)
-                ops.pwconv_gemm(g, cp[name + "T"], dx, ident(g.shape[1]), 1, 0, out_scale=1.0)
-                if prev is not None:       # through inverted dropout and ReLU of the previous fc
-                    gn = self._buf("g" + prev, (B, 4096), dt)
-                    L.check(lib.spb_relu_bwd(dc, _p(dx), _p(sv["h" + prev]), None, _p(gn), B * 4096, scale, st), "spb_relu_bwd")
-                    g = gn
-                else:
-                    if df is None:
-                        df = dx
+        self._gflat[:self._conv_end].zero_()          # conv bias gradients are accumulated with atomics
+        if fast:
+            MP = sv["MP"]
+            acc, accF = self._acc("acc", max(4096, NC), MP), self._acc("accF", 9216, MP)
+            for names, g in ((("fc6", "fc7", "fc8"), dcg), (("fc9", "fc10", "fc11"), drg)):
+                a, b_, c_ = names
+                gT = self._buf("gT" + c_, (NC, MP), dt)
+                self._epi(B, NC, 1, src=g, YT=gT, db=getattr(self, c_).bias.grad)
+                for name, prev, xT in ((c_, b_, sv["hT" + b_]), (b_, a, sv["hT" + a]), (a, None, sv["fT"])):
+                    lay = getattr(self, name)
+                    N, K = lay.weight.shape
+                    L.check(lib.spb_fc_wgrad(_p(gT), _p(xT), _p(lay.weight.grad), B, N, K, st), "spb_fc_wgrad")
+                    tgt = acc if prev is not None else accF
+                    L.check(lib.spb_fc_dgrad(_p(g), _p(self._sh(name + ".weight")), _p(tgt), B, N, K, st), "spb_fc_dgrad")
+                    if prev is not None:     # through inverted dropout and ReLU of the previous fc, + its bias gradient
+                        g = self._buf("g" + prev, (B, 4096), dt)
+                        gT = self._buf("gT" + prev, (4096, MP), dt)
+                        self._epi(B, 4096, 1, accT=acc, H=sv["h" + prev], Y=g, YT=gT, db=getattr(self, prev).bias.grad, scale=scale)
+            g_act = self._buf("dp5", (B, 6, 6, 256), dt)   # the two heads met in accF
+            L.check(lib.spb_spn_unflatten_grad(_p(accF), _p(g_act), B, 36, 256, st), "spb_spn_unflatten_grad")
+        else:
+            df = None
+            for (a, b_, c_), g in ((("fc6", "fc7", "fc8"), dcg), (("fc9", "fc10", "fc11"), drg)):
+                for name, prev in ((c_, b_), (b_, a), (a, None)):
+                    lay = getattr(self, name)
+                    xin = sv["in" + name]
+                    N, K = g.shape[1], xin.shape[1]
+                    lay.weight.grad.zero_(); lay.bias.grad.zero_()
+                    ops.pwconv_wgrad(g, xin, lay.weight.grad, ident(N), ident(K))
+                    L.check(lib.spb_colsum(dc, _p(g), _p(lay.bias.grad), B, N, st), "spb_colsum")
+                    dx = self._buf("dx" + name, (B, K), dt)
+                    ops.pwconv_gemm(g, cp[name + "T"], dx, ident(N), 1, 0, out_scale=1.0)
+                    if prev is not None:
+                        gn = self._buf("g" + prev, (B, 4096), dt)
+                        L.check(lib.spb_relu_bwd(dc, _p(dx), _p(sv["h" + prev]), None, _p(gn), B * 4096, scale, st), "spb_relu_bwd")
+                        g = gn
                     else:
-                        df = df + dx       # the two heads meet at pool5's output (tiny: B x 9216)
+                        df = dx if df is None else df + dx
+            g_act = df.view(B, 256, 36).permute(0, 2, 1).contiguous()    # NCHW flatten order -> NHWC
         # trunk, last to first
-        g_act = df.contiguous()            # gradient w.r.t. the current layer's (pooled / normalised) output, NHWC
+        dwp = self._buf("dWp", (sum(cp[n].numel() for n, *_ in _CONVS),), torch.float32)
+        dwp.zero_()
+        woff = 0
         for name, cout, cin, grp, k, stride, pad in reversed(_CONVS):
+            lay = getattr(self, name)
             Hc, Wc, Cc = sv["in" + name]
             y = sv["y" + name]
             OH, OW = (Hc + 2 * pad - k) // stride + 1, (Wc + 2 * pad - k) // stride + 1
@@ -294,16 +418,20 @@ class SpacecraftPoseNet(nn.Module):
             g = self._buf("gy" + name, (B * OH * OW, cout), dt)
             L.check(lib.spb_relu_bwd(dc, _p(g_act), _p(y), None, _p(g), g.numel(), 1.0, st), "spb_relu_bwd")
             col = sv["col" + name]
-            dW, db = grads_of(name, g, col)
-            kk = k * k * cin
-            full = dW[:, :kk].reshape(cout, k, k, cin)
-            cog, cig = cout // grp, cin // grp
-            wg = torch.cat([full[gi * cog:(gi + 1) * cog, :, :, gi * cig:(gi + 1) * cig] for gi in range(grp)], 0).permute(0, 3, 1, 2)
-            set_grad(getattr(self, name).weight, wg); set_grad(getattr(self, name).bias, db)
+            kpad = col.shape[1]
+            kg, cog = kpad // grp, cout // grp
+            dW = dwp[woff:woff + cout * kg].view(cout, kg)
+            woff += cout * kg
+            for gi in range(grp):
+                ops.pwconv_wgrad(g[:, gi * cog:(gi + 1) * cog], col[:, gi * kg:(gi + 1) * kg], dW[gi * cog:(gi + 1) * cog], ident(cog), ident(kg))
+            L.check(lib.spb_spn_unpack_conv_grad(_p(dW), _p(lay.weight.grad), cout, cin, grp, k, k, kg, st), "spb_spn_unpack_conv_grad")
+            L.check(lib.spb_colsum(dc, _p(g), _p(lay.bias.grad), g.shape[0], cout, st), "spb_colsum")
             if name != "conv1":
                 dcol = self._buf("dcol" + name, tuple(col.shape), dt)
-                ops.pwconv_gemm(g, cp[name + "T"], dcol, ident(cout), 1, 0, out_scale=1.0)
+                for gi in range(grp):
+                    ops.pwconv_gemm(g[:, gi * cog:(gi + 1) * cog], cp[name + "T"][gi], dcol[:, gi * kg:(gi + 1) * kg], ident(cog), 1, 0,
+                                    out_scale=1.0)
                 dx = self._buf("dxin" + name, (B, Hc, Wc, Cc), dt)
-                L.check(lib.spb_col2im(dc, _p(dcol), _p(dx), B, Hc, Wc, Cc, k, k, pad, col.shape[1], st), "spb_col2im")
+                L.check(lib.spb_col2im(dc, _p(dcol), _p(dx), B, Hc, Wc, Cc, k, k, pad, kpad, grp, st), "spb_col2im")
                 g_act = dx
         return out

@@ -26,6 +26,15 @@ def _need_cuda(*ts):
             raise RuntimeError("speedplusbaseline_amd ops need contiguous tensors")
 
 
+def _need_rows(*ts):
+    """2-D operands that may be column slabs of a wider row-major matrix (unit column stride, any row stride)"""
+    for t in ts:
+        if not t.is_cuda:
+            raise RuntimeError("speedplusbaseline_amd ops run on the GPU only (got a %s tensor)" % t.device)
+        if t.dim() != 2 or t.stride(1) != 1 or (t.stride(0) & 7) or (t.storage_offset() & 7):
+            raise RuntimeError("speedplusbaseline_amd GEMM operands are row-major 2-D tensors or 8-aligned column slabs of one")
+
+
 def dtype_code(t):
     try:
         return _DT[t.dtype]
@@ -45,21 +54,27 @@ def bnref(C_, sums=None, gamma=None, beta=None, bsums=None, n=1, R=1, act=L.ACT_
 
 def pwconv_gemm(A, Bw, Y, pro, pro_mode, epi_mode, A2=None, res=None, Zout=None, bias=None, osums=None, epi=None,
                 out_act=L.ACT_NONE, oR=1, out_scale=1.0):
-    _need_cuda(A, Bw, Y, A2, res, Zout, bias, osums)
+    _need_rows(A, Y)
+    _need_cuda(Bw, A2, res, Zout, bias, osums)
     g = L.GemmArgs()
     g.A = _ptr(A); g.A2 = _ptr(A2); g.Bw = _ptr(Bw); g.Y = _ptr(Y); g.res = _ptr(res); g.Zout = _ptr(Zout)
     g.bias = _ptr(bias); g.osums = _ptr(osums); g.pro = pro
     g.epi = epi if epi is not None else bnref(Y.shape[-1])
     g.M, g.K = A.shape[0], A.shape[1]; g.N = Bw.shape[0]
+    g.lda = A.stride(0) if A.stride(0) != A.shape[1] else 0     # column slabs of wider matrices (grouped convolutions)
+    g.ldc = Y.stride(0) if Y.stride(0) != Y.shape[1] else 0
     g.pro_mode = pro_mode; g.epi_mode = epi_mode; g.out_act = out_act; g.oR = oR; g.out_scale = out_scale
     L.check(L.lib().spb_pwconv_gemm(dtype_code(A), C.byref(g), _stream()), "spb_pwconv_gemm")
 
 
 def pwconv_wgrad(G, X, dW, pro_dz, pro_a, Zn=None):
-    _need_cuda(G, X, dW, Zn)
+    _need_rows(G, X)
+    _need_cuda(dW, Zn)
     w = L.WgradArgs()
     w.G = _ptr(G); w.Zn = _ptr(Zn); w.X = _ptr(X); w.dW = _ptr(dW); w.pro_dz = pro_dz; w.pro_a = pro_a
     w.M = G.shape[0]; w.N = G.shape[1]; w.K = X.shape[1]
+    w.ldg = G.stride(0) if G.stride(0) != G.shape[1] else 0
+    w.ldx = X.stride(0) if X.stride(0) != X.shape[1] else 0
     L.check(L.lib().spb_pwconv_wgrad(dtype_code(G), C.byref(w), _stream()), "spb_pwconv_wgrad")
 
 
@@ -199,13 +214,13 @@ OPT_KIND = {"sgd": 0, "rmsprop": 1, "adam": 2, "adamw": 3}
 
 
 def optim_step(kind, params, grads, m=None, v=None, sqnorm=None, gmul=None, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8,
-               weight_decay=0.0, max_norm=0.0, clip_value=0.0, step=1, first_step=False, hyper=None):
-    _need_cuda(params, grads, m, v, sqnorm, gmul, hyper)
+               weight_decay=0.0, max_norm=0.0, clip_value=0.0, step=1, first_step=False, hyper=None, shadow=None):
+    _need_cuda(params, grads, m, v, sqnorm, gmul, hyper, shadow)
     a = L.OptimArgs()
     a.params = _ptr(params); a.grads = _ptr(grads); a.m = _ptr(m); a.v = _ptr(v); a.sqnorm = _ptr(sqnorm)
     a.gmul = _ptr(gmul); a.hyper = _ptr(hyper); a.n = params.numel(); a.kind = OPT_KIND[kind]
     a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.weight_decay = weight_decay
-    a.max_norm = max_norm; a.clip_value = clip_value
+    a.max_norm = max_norm; a.clip_value = clip_value; a.shadow_bf16 = _ptr(shadow)
     a.bias_c1 = 1.0 - beta1 ** step; a.bias_c2 = 1.0 - beta2 ** step; a.first_step = 1 if first_step else 0
     L.check(L.lib().spb_optim_step(C.byref(a), _stream()), "spb_optim_step")
 

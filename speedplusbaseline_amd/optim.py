@@ -135,14 +135,19 @@ class FusedOptimizer(torch.optim.Optimizer):
 
 class SpnOptimizer(torch.optim.Optimizer):
     """Optimizer of the Spacecraft Pose Network (reference build.py:60-78 kinds; trainer.py:177-184: clip_grad_value_(1.0)
-    then step).  SPN parameters are ordinary tensors (22 of them, 152 M elements), so the update is one fused HIP pass
-    per tensor: clamp of every gradient element to [-clip_value, clip_value] + sgd / rmsprop / adam / adamw, f32."""
+    then step).  The model keeps its 152 M parameters and their gradients in two flat f32 arenas, so the whole update is ONE
+    HIP pass: (data-parallel mean,) clamp of every gradient element to [-clip_value, clip_value], sgd / rmsprop / adam /
+    adamw in f32, and the refreshed bf16 shadow the next forward streams its weights from.  With world_size > 1 the gradient
+    arena is summed across ranks first (one all-reduce, RCCL on the MI355X node)."""
 
     def __init__(self, params, kind="adamw", lr=1e-3, momentum=0.9, weight_decay=0.0, model=None, clip_value=1.0):
         super().__init__(params, dict(lr=lr, momentum=momentum, weight_decay=weight_decay, kind=kind))
+        if model is None:
+            raise RuntimeError("SpnOptimizer needs the HIP-backed model it was built for (get_optimizer(cfg, model))")
         self._model = model
         self.clip_value = clip_value
         self._t = 0
+        self._m = self._v = self._gmul = None
 
     def _betas(self, kind, momentum):
         if kind == "rmsprop":
@@ -152,23 +157,40 @@ class SpnOptimizer(torch.optim.Optimizer):
         return momentum, 0.0
 
     @torch.no_grad()
-    def step(self, closure=None):
+    def step(self, closure=None, world_size=1, group=None):
         from . import ops
+        from .parallel import allreduce_sum_, mean_scale
+        mdl = self._model
+        flat, gflat = mdl.flat_parameters(), mdl.flat_grads()
+        if self._m is None or self._m.numel() != flat.numel() or self._m.device != flat.device:
+            self._m, self._v = torch.zeros_like(flat), torch.zeros_like(flat)
+        g = self.param_groups[0]
+        b1, b2 = self._betas(g["kind"], g["momentum"])
         self._t += 1
-        for g in self.param_groups:
-            b1, b2 = self._betas(g["kind"], g["momentum"])
-            for p in g["params"]:
-                if p.grad is None:
-                    continue
-                if not p.is_cuda:
-                    raise RuntimeError("SpnOptimizer updates parameters on the MI355X only")
-                st = self.state[p]
-                if not st:
-                    st["m"] = torch.zeros_like(p, dtype=torch.float32).view(-1)
-                    st["v"] = torch.zeros_like(p, dtype=torch.float32).view(-1)
-                ops.optim_step(g["kind"], p.data.view(-1), p.grad.view(-1), m=st["m"], v=st["v"], lr=g["lr"], beta1=b1, beta2=b2,
-                               eps=1e-8, weight_decay=g["weight_decay"], max_norm=0.0, clip_value=self.clip_value, step=self._t,
-                               first_step=(self._t == 1))
-        if self._model is not None:
-            self._model.invalidate()   # compute-dtype weight copies are stale now
+        gmul = None
+        if world_size > 1:
+            allreduce_sum_(gflat, group)
+            if self._gmul is None:
+                self._gmul = torch.full((1,), mean_scale(world_size), dtype=torch.float32, device=flat.device)
+            gmul = self._gmul
+        ops.optim_step(g["kind"], flat, gflat, m=self._m, v=self._v, gmul=gmul, lr=g["lr"], beta1=b1, beta2=b2, eps=1e-8,
+                       weight_decay=g["weight_decay"], max_norm=0.0, clip_value=self.clip_value, step=self._t,
+                       first_step=(self._t == 1), shadow=mdl._shadow)
+        mdl.optimizer_updated()
         return None
+
+    def state_dict(self):
+        sd = super().state_dict()
+        sd["spn_fused"] = {"t": self._t, "m": None if self._m is None else self._m.detach().cpu(),
+                           "v": None if self._v is None else self._v.detach().cpu()}
+        return sd
+
+    def load_state_dict(self, sd):
+        sd = dict(sd)
+        st = sd.pop("spn_fused", None)
+        super().load_state_dict(sd)
+        if st is not None:
+            self._t = st["t"]
+            dev = self._model.flat_parameters().device
+            self._m = None if st["m"] is None else st["m"].to(dev)
+            self._v = None if st["v"] is None else st["v"].to(dev)

@@ -81,9 +81,10 @@ def test_training_step_gradients_match_oracle(device, precision, tol):
     assert not bad, bad
 
 
-def test_own_dropout_stream(device):
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_own_dropout_stream(device, precision):
     """without given masks the kernel draws its own keep-masks: about half kept, scaled by 2, reproducible per step"""
-    net = _net(device, "fp32").train()
+    net = _net(device, precision).train()
     x, yc, yw = S.synth_batch(2, NC, seed=11)
     net.loss_and_grads(x.to(device), yc.to(device), yw.to(device))
     m = net._ws["mfc6"].float()
@@ -119,3 +120,174 @@ def test_one_training_step_matches_torch_sgd(device):
     with torch.no_grad():
         co, _ = S.forward({k: v.detach() for k, v in ps.items()}, x, None)
     assert rel(c2, co) < 2e-3
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# the weight-streaming fully connected kernels (csrc/spn_fc.hip) on their own, through the C-ABI, at the real layer sizes
+def _vp(t):
+    import ctypes as C
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+@pytest.mark.parametrize("M,N,K", [(32, 4096, 9216), (32, 5000, 4096), (2, 64, 4096), (48, 4096, 4096), (7, 1000, 9216)])
+def test_fc_stream_kernels(device, M, N, K):
+    import ctypes as C
+    from speedplusbaseline_amd import _lib as L
+    lib = L.lib()
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    g = torch.Generator().manual_seed(M * 7 + N)
+    X = torch.randn(M, K, generator=g).to(torch.bfloat16).to(device)
+    W = (torch.randn(N, K, generator=g) / K ** 0.5).to(torch.bfloat16).to(device)
+    G = torch.randn(M, N, generator=g).to(torch.bfloat16).to(device)
+    bias = torch.randn(N, generator=g).to(device)
+    MP = 32 if M <= 32 else 64
+    # forward: accT[n][m] = sum_k W[n][k] X[m][k]
+    acc = torch.zeros(max(N, K), MP, device=device)
+    L.check(lib.spb_fc_fwd(_vp(X), _vp(W), _vp(acc), M, N, K, st), "fc_fwd")
+    ref = X.float() @ W.float().t()
+    assert rel(acc[:N, :M].t(), ref) < 1e-5
+    assert float(acc[:N, M:].abs().max() if M < MP else 0.0) == 0.0
+    # forward epilogue: bias, ReLU, dropout(0.5) with a given mask; Y, its transpose; accumulator handed back zeroed
+    mask = (torch.rand(M, N, generator=g) < 0.5).to(torch.uint8).to(device)
+    Y = torch.empty(M, N, dtype=torch.bfloat16, device=device)
+    YT = torch.full((N, MP), 7.0, dtype=torch.bfloat16, device=device)
+    a = L.FcEpiArgs()
+    a.accT, a.bias, a.Y, a.YT, a.mask = acc.data_ptr(), bias.data_ptr(), Y.data_ptr(), YT.data_ptr(), mask.data_ptr()
+    a.M, a.F, a.mode, a.relu, a.p, a.scale, a.seed, a.mask_given = M, N, 0, 1, 0.5, 1.0, 1, 1
+    L.check(lib.spb_fc_epilogue(C.byref(a), st), "fc_epilogue")
+    want = (torch.relu(ref + bias).to(torch.bfloat16).float() * mask.float() * 2.0).to(torch.bfloat16)
+    assert rel(Y, want) < 1e-2 and float((Y.float() - want.float()).abs().max()) <= 2 ** -6 * float(want.float().abs().max())
+    assert torch.equal(YT[:, :M].t().contiguous(), Y)
+    if M < MP:
+        assert float(YT[:, M:].float().abs().max()) == 0.0
+    assert float(acc.abs().max()) == 0.0
+    # own mask stream: about half kept, reproducible for the same seed
+    L.check(lib.spb_fc_fwd(_vp(X), _vp(W), _vp(acc), M, N, K, st), "fc_fwd")
+    a.mask_given, a.seed = 0, 1234
+    L.check(lib.spb_fc_epilogue(C.byref(a), st), "fc_epilogue")
+    m1 = mask.clone()
+    assert 0.45 < float(m1.float().mean()) < 0.55
+    assert float(Y[m1 == 0].float().abs().max()) == 0.0
+    # input gradient: accT[k][m] = sum_n W[n][k] G[m][n]
+    L.check(lib.spb_fc_dgrad(_vp(G), _vp(W), _vp(acc), M, N, K, st), "fc_dgrad")
+    assert rel(acc[:K, :M].t(), G.float() @ W.float()) < 1e-5
+    # backward epilogue: gate by Y > 0, scale 2, bias-gradient column sums, transposes
+    Hh = torch.randn(M, K, generator=g).to(torch.bfloat16).to(device)
+    Gn = torch.empty(M, K, dtype=torch.bfloat16, device=device)
+    GnT = torch.empty(K, MP, dtype=torch.bfloat16, device=device)
+    db = torch.empty(K, device=device)
+    b = L.FcEpiArgs()
+    b.accT, b.H, b.Y, b.YT, b.db = acc.data_ptr(), Hh.data_ptr(), Gn.data_ptr(), GnT.data_ptr(), db.data_ptr()
+    b.M, b.F, b.mode, b.relu, b.p, b.scale, b.seed, b.mask_given = M, K, 1, 0, 0.0, 2.0, 0, 0
+    L.check(lib.spb_fc_epilogue(C.byref(b), st), "fc_epilogue")
+    wantg = (torch.where(Hh.float() > 0, (G.float() @ W.float()) * 2.0, torch.zeros((), device=device))).to(torch.bfloat16)
+    assert rel(Gn, wantg) < 1e-2
+    assert torch.equal(GnT[:, :M].t().contiguous(), Gn)
+    assert rel(db, Gn.float().sum(0)) < 1e-5
+    assert float(acc.abs().max()) == 0.0
+    # weight gradient from the transposed operands: dW[n][k] = sum_m G[m][n] X[m][k]
+    GT = torch.zeros(N, MP, dtype=torch.bfloat16, device=device); GT[:, :M] = G.t()
+    XT = torch.zeros(K, MP, dtype=torch.bfloat16, device=device); XT[:, :M] = X.t()
+    dW = torch.full((N, K), float("nan"), device=device)
+    L.check(lib.spb_fc_wgrad(_vp(GT), _vp(XT), _vp(dW), M, N, K, st), "fc_wgrad")
+    assert rel(dW, G.float().t() @ X.float()) < 1e-5
+    # epilogue from a bf16 source (the soft-CE gradient): transposes + column sums, no accumulator
+    c = L.FcEpiArgs()
+    GT2 = torch.empty(N, MP, dtype=torch.bfloat16, device=device)
+    db2 = torch.empty(N, device=device)
+    c.src, c.YT, c.db = G.data_ptr(), GT2.data_ptr(), db2.data_ptr()
+    c.M, c.F, c.mode, c.scale = M, N, 1, 1.0
+    L.check(lib.spb_fc_epilogue(C.byref(c), st), "fc_epilogue")
+    assert torch.equal(GT2, GT) and rel(db2, G.float().sum(0)) < 1e-5
+
+
+def test_flatten_roundtrip(device):
+    import ctypes as C
+    from speedplusbaseline_amd import _lib as L
+    lib = L.lib()
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    B = 5
+    P = torch.randn(B, 6, 6, 256).to(torch.bfloat16).to(device)          # NHWC
+    Fm = torch.empty(B, 9216, dtype=torch.bfloat16, device=device)
+    FT = torch.empty(9216, 32, dtype=torch.bfloat16, device=device)
+    L.check(lib.spb_spn_flatten(_vp(P), _vp(Fm), _vp(FT), B, 36, 256, st), "flatten")
+    want = P.permute(0, 3, 1, 2).reshape(B, 9216)                          # the reference's x.view(-1, 9216) on NCHW
+    assert torch.equal(Fm, want) and torch.equal(FT[:, :B].t().contiguous(), want) and float(FT[:, B:].float().abs().max()) == 0.0
+    acc = torch.zeros(9216, 32, device=device)
+    acc[:, :B] = want.float().t()
+    Gp = torch.empty(B, 6, 6, 256, dtype=torch.bfloat16, device=device)
+    L.check(lib.spb_spn_unflatten_grad(_vp(acc), _vp(Gp), B, 36, 256, st), "unflatten")
+    assert torch.equal(Gp, P) and float(acc.abs().max()) == 0.0
+
+
+def test_conv_pack_unpack_and_colsum(device):
+    import ctypes as C
+    from speedplusbaseline_amd import _lib as L
+    lib = L.lib()
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    cout, cin, g, k = 256, 96, 2, 5
+    cog, cig = cout // g, cin // g
+    kg = (k * k * cig + 7) // 8 * 8
+    W = torch.randn(cout, cig, k, k, device=device)
+    Wp = torch.empty(cout, kg, device=device); WpT = torch.empty(g, kg, cog, device=device)
+    L.check(lib.spb_spn_pack_conv(L.F32, _vp(W), _vp(Wp), _vp(WpT), cout, cin, g, k, k, kg, st), "pack")
+    assert torch.equal(Wp[:, :k * k * cig], W.permute(0, 2, 3, 1).reshape(cout, -1))       # (ky, kx, c_local) per output row
+    for gi in range(g):
+        assert torch.equal(WpT[gi], Wp[gi * cog:(gi + 1) * cog].t().contiguous())
+    dW = torch.empty_like(W)
+    L.check(lib.spb_spn_unpack_conv_grad(_vp(Wp), _vp(dW), cout, cin, g, k, k, kg, st), "unpack")
+    assert torch.equal(dW, W)
+    # grouped convolution = im2col with one column slab per group + one dense GEMM per slab, against torch's conv2d
+    from speedplusbaseline_amd import ops
+    B, H = 2, 9
+    x = torch.randn(B, cin, H, H, device=device)
+    xh = x.permute(0, 2, 3, 1).contiguous()
+    col = torch.empty(B * H * H, g * kg, device=device)
+    L.check(lib.spb_im2col(L.F32, _vp(xh), _vp(col), B, H, H, cin, k, k, 1, 2, g * kg, g, st), "im2col")
+    y = torch.empty(B * H * H, cout, device=device)
+    bias = torch.randn(cout, device=device)
+    for gi in range(g):
+        ops.pwconv_gemm(col[:, gi * kg:(gi + 1) * kg], Wp[gi * cog:(gi + 1) * cog], y[:, gi * cog:(gi + 1) * cog], ops.bnref(kg), 1, 0,
+                        bias=bias[gi * cog:(gi + 1) * cog], out_scale=1.0)
+    want = torch.nn.functional.conv2d(x, W, bias, padding=2, groups=g).permute(0, 2, 3, 1).reshape(B * H * H, cout)
+    assert rel(y, want) < 1e-4
+    # ... its input gradient (per-group transposed operands + col2im) and weight gradient (per-group wgrad on the slabs)
+    gy = torch.randn(B * H * H, cout, device=device)
+    dcol = torch.empty_like(col)
+    dWp = torch.zeros(cout, kg, device=device)
+    for gi in range(g):
+        ops.pwconv_gemm(gy[:, gi * cog:(gi + 1) * cog], WpT[gi], dcol[:, gi * kg:(gi + 1) * kg], ops.bnref(cog), 1, 0, out_scale=1.0)
+        ops.pwconv_wgrad(gy[:, gi * cog:(gi + 1) * cog], col[:, gi * kg:(gi + 1) * kg], dWp[gi * cog:(gi + 1) * cog], ops.bnref(cog), ops.bnref(kg))
+    dx = torch.empty(B, H, H, cin, device=device)
+    L.check(lib.spb_col2im(L.F32, _vp(dcol), _vp(dx), B, H, H, cin, k, k, 2, g * kg, g, st), "col2im")
+    L.check(lib.spb_spn_unpack_conv_grad(_vp(dWp), _vp(dW), cout, cin, g, k, k, kg, st), "unpack")
+    xr = x.clone().requires_grad_(True); Wr = W.clone().requires_grad_(True)
+    torch.nn.functional.conv2d(xr, Wr, None, padding=2, groups=g).backward(gy.view(B, H, H, cout).permute(0, 3, 1, 2))
+    assert rel(dx, xr.grad.permute(0, 2, 3, 1)) < 1e-4 and rel(dW, Wr.grad) < 1e-4
+    for M, N in ((96800, 96), (23328, 256), (5408, 384), (100, 24)):
+        G = torch.randn(M, N, device=device).to(torch.bfloat16)
+        out = torch.zeros(N, device=device)
+        L.check(lib.spb_colsum(L.BF16, _vp(G), _vp(out), M, N, st), "colsum")
+        assert rel(out, G.float().sum(0)) < 1e-4
+
+
+def test_adamw_step_updates_bf16_shadow(device):
+    """SpnOptimizer: clip_grad_value_(1.0) + AdamW over the flat arena in one launch against torch on the CPU; the bf16
+    shadow the next forward streams from equals the rounded new parameters"""
+    from speedplusbaseline_amd.optim import SpnOptimizer
+    net = _net(device, "bf16").train()
+    x, yc, yw = S.synth_batch(2, NC, seed=11)
+    opt = SpnOptimizer([p for p in net.parameters()], kind="adamw", lr=1e-3, momentum=0.9, weight_decay=1e-2, model=net)
+    net.loss_and_grads(x.to(device), yc.to(device), yw.to(device))
+    ps = {k: torch.nn.Parameter(v.detach().cpu().clone()) for k, v in net.named_parameters()}
+    for k, p in net.named_parameters():
+        ps[k].grad = p.grad.detach().cpu().clone()
+    opt.step()
+    torch.cuda.synchronize()
+    torch.nn.utils.clip_grad_value_(ps.values(), 1.0)
+    torch.optim.AdamW(ps.values(), lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2).step()
+    for k, p in net.named_parameters():
+        assert float((p.detach().cpu() - ps[k].detach()).abs().max()) < 2e-6, k
+        o, n = net._offs[k]
+        assert torch.equal(net._shadow[o:o + n].cpu(), p.detach().reshape(-1).to(torch.bfloat16).cpu()), k
+    assert net._shadow_version == net._version
