@@ -60,7 +60,7 @@ typedef struct spb_gemm_args {
   spb_bnref_t pro;   /* BN/activation applied to A while loading (pro_mode 1) or BN-backward (pro_mode 2) */
   spb_bnref_t epi;   /* epi_mode 2: BN/activation of the output-side tensor */
   int M, K, N;
-  int pro_mode;      /* 1: a = act(bn(A));  2: a = bn_backward(g=A, z=A2) */
+  int pro_mode;      /* 0: a = A (plain operand; `pro` must still be a valid identity reference);  1: a = act(bn(A));  2: a = bn_backward(g=A, z=A2) */
   int epi_mode;      /* 0: y = out_act(acc*out_scale + bias);  1: y = acc, accumulate batch sums;  2: g = (acc+res)*act'(bn(Zout)) */
   int out_act;       /* epi_mode 0 */
   int oR;
@@ -341,7 +341,7 @@ int spb_final_sigmoid(const void* Z, const float* coef, float* out, int B, long 
  * GEMM per group on a slab (spb_gemm_args_t.lda / ldc).  C/groups % 8 == 0, Kpad >= KH*KW*C */
 int spb_im2col(int dtype, const void* src, void* dst, int B, int H, int W, int C, int KH, int KW, int stride, int pad, int Kpad,
                int groups, spb_stream_t stream);
-/* first layer: fp32 NCHW image (3 channels), valid padding; k = (ky*KW+kx)*3 + ci */
+/* first layer: fp32 NCHW image (3 channels), valid padding; k = (ci*KH + ky)*KW + kx (chw_order of spb_spn_pack_conv) */
 int spb_im2col_rgb(int dtype, const float* x, void* dst, int B, int H, int W, int KH, int KW, int stride, int Kpad,
                    spb_stream_t stream);
 /* adjoint of spb_im2col for stride 1: dx[b,iy,ix,c] = sum over taps of dcol */
@@ -371,9 +371,10 @@ int spb_colsum(int dtype, const void* g, float* out, long long M, int N, spb_str
  * (ky,kx,c_local) order, zero padded to Kg (i.e. `groups` stacked [Cout/groups][Kg] GEMM operands matching spb_im2col's
  * slabs), and WpT [groups][Kg][Cout/groups], the per-group transposes the input gradient needs (may be NULL).  dtype = output. */
 int spb_spn_pack_conv(int dtype, const float* W, void* Wp, void* WpT, int Cout, int Cin, int groups, int KH, int KW, int Kg,
-                      spb_stream_t stream);
+                      int chw_order, spb_stream_t stream);   /* chw_order != 0: rows keep nn.Conv2d's (c,ky,kx) order (conv1 / spb_im2col_rgb) */
 /* inverse for gradients: dWp f32 [Cout][Kg] -> dW f32 [Cout][Cin/groups][KH][KW] */
-int spb_spn_unpack_conv_grad(const float* dWp, float* dW, int Cout, int Cin, int groups, int KH, int KW, int Kg, spb_stream_t stream);
+int spb_spn_unpack_conv_grad(const float* dWp, float* dW, int Cout, int Cin, int groups, int KH, int KW, int Kg, int chw_order,
+                             spb_stream_t stream);
 
 /* ---- SPN fully connected layers at training batch sizes (M <= 64 rows; nn.Linear fc6..fc11, spn.py:71-99), bf16 only.
  * accT is a feature-major f32 accumulator [features][MP], MP = 32 (M <= 32) or 64, zero between uses; the epilogue
@@ -408,6 +409,7 @@ int spb_spn_flatten(const void* P, void* Fm, void* FT, int B, int HW, int C, spb
 int spb_spn_unflatten_grad(float* accT, void* Gp, int B, int HW, int C, spb_stream_t stream);
 
 /* debug / test helpers */
+int spb_debug_set_gemm_plain_dma(int on); /* pro_mode 0 bf16 GEMMs: LDS-DMA ring kernel (1, default) or the register-prefetch kernel */
 int spb_debug_set_optim(int vec, int per_thread, int nontemporal); /* optimizer launch shape A/B: lanes of 1|4 floats, 1|2|4 per thread, nt accesses */
 int spb_debug_trread(const unsigned short* in4096, unsigned short* out256, spb_stream_t stream);
 int spb_debug_set_gemm_dma(int on); /* 1: small-M bf16 pointwise GEMMs use the LDS-DMA ring kernel (default 0) */

@@ -388,9 +388,10 @@ __global__ __launch_bounds__(256) void pw_gemm_dma_kernel(const spb_gemm_args_t 
   constexpr int LDO = DBN + 8, NV = DBN / 8, VR = 256 / NV, VRI = DBM / VR;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int M = g.M, K = g.K, N = g.N;
+  const int lda = g.lda > 0 ? g.lda : K, ldc = g.ldc > 0 ? g.ldc : N;
   const int Kp = (K + DBK - 1) / DBK * DBK, KT = Kp / DBK;
-  float* coef = reinterpret_cast<float*>(smem);                // [3][Kp]
-  char* stages = smem + (size_t)3 * Kp * sizeof(float);
+  float* coef = reinterpret_cast<float*>(smem);                // [3][Kp]; PRO 0 (plain operands, SPN): no table
+  char* stages = smem + (PRO == 0 ? 0 : (size_t)3 * Kp * sizeof(float));
   T* Os = reinterpret_cast<T*>(stages);                        // aliases the stage ring after the K loop
 
   const int t = threadIdx.x, l = t & 63, w = t >> 6, li = l & 15, lq = l >> 4;
@@ -412,7 +413,7 @@ __global__ __launch_bounds__(256) void pw_gemm_dma_kernel(const spb_gemm_args_t 
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int m = m0 + drow + 8 * i, n = n0 + drow + 8 * i;
-    arow[i] = (size_t)(m < M ? m : M - 1) * K;
+    arow[i] = (size_t)(m < M ? m : M - 1) * lda;
     brow[i] = (size_t)(n < N ? n : N - 1) * K;
   }
   const unsigned stages_lds = lds_addr(stages);
@@ -432,6 +433,7 @@ __global__ __launch_bounds__(256) void pw_gemm_dma_kernel(const spb_gemm_args_t 
   for (int s = 0; s < DS - 1 && s < KT; ++s) DMA_STAGE(s);
 
   // ---- prologue coefficients (ordinary loads; they complete before the first counted wait)
+  if (PRO != 0)
   for (int c = t; c < Kp; c += 256) {
     float c0 = 0.f, c1 = 0.f, c2 = 0.f;
     if (c < K) {
@@ -465,7 +467,7 @@ __global__ __launch_bounds__(256) void pw_gemm_dma_kernel(const spb_gemm_args_t 
 #pragma unroll
     for (int s = 0; s < VRI; ++s) {
       const int m = m0 + vrow0 + s * VR;
-      const size_t o = (size_t)(m < M ? m : M - 1) * N + (colok ? nE : 0);
+      const size_t o = (size_t)(m < M ? m : M - 1) * ldc + (colok ? nE : 0);
       zr[EPI == 2 ? s : 0] = ldraw<T>(Zg + o);
       if (Rg) rr[EPI == 2 ? s : 0] = ldraw<T>(Rg + o);
     }
@@ -497,6 +499,10 @@ __global__ __launch_bounds__(256) void pw_gemm_dma_kernel(const spb_gemm_args_t 
       const int so = frow * (DBK * 2) + ((v ^ (frow & 7)) << 4);
       Raw8<T> ar, a2r;
       ar.u = *reinterpret_cast<const uint4*>(sb + so);
+      uint4 pa;
+      if constexpr (PRO == 0) {
+        pa = ar.u;
+      } else {
       if (PRO == 2) a2r.u = *reinterpret_cast<const uint4*>(sb + DBM * DBK * 2 + so);
       float a[8], a2[8], x[8];
       cvt8(ar, a);
@@ -517,9 +523,9 @@ __global__ __launch_bounds__(256) void pw_gemm_dma_kernel(const spb_gemm_args_t 
 #pragma unroll
         for (int j = 0; j < 8; ++j) x[j] = a[j] * c0[j] + a2[j] * c1[j] + c2[j];
       }
-      uint4 pa;
       pa.x = (uint32_t)f2bf(x[0]) | ((uint32_t)f2bf(x[1]) << 16); pa.y = (uint32_t)f2bf(x[2]) | ((uint32_t)f2bf(x[3]) << 16);
       pa.z = (uint32_t)f2bf(x[4]) | ((uint32_t)f2bf(x[5]) << 16); pa.w = (uint32_t)f2bf(x[6]) | ((uint32_t)f2bf(x[7]) << 16);
+      }
       if (kb >= K) pa = make_uint4(0, 0, 0, 0);    // reduction padding: clamped (finite) data times an explicit zero
       const bf16x8_t af = __builtin_bit_cast(bf16x8_t, pa);
 #pragma unroll
@@ -551,7 +557,7 @@ __global__ __launch_bounds__(256) void pw_gemm_dma_kernel(const spb_gemm_args_t 
       if (m < M) {
         float v[8];
         ld8<T>(Os + r * LDO + vcol * 8, v);
-        const size_t o = (size_t)m * N + nE;
+        const size_t o = (size_t)m * ldc + nE;
         if (EPI == 0) {
 #pragma unroll
           for (int j = 0; j < 8; ++j) v[j] = act_fwd(v[j] * g.out_scale + e_bias[j], g.out_act, 0.f);
@@ -602,7 +608,7 @@ template <int PRO, int EPI>
 int launch_gemm_dma(const spb_gemm_args_t& g, hipStream_t stream) {
   const int NT = (g.N + DBN - 1) / DBN, MT = (g.M + DBM - 1) / DBM;
   const int Kp = (g.K + DBK - 1) / DBK * DBK;
-  const size_t lds = (size_t)3 * Kp * sizeof(float) + (size_t)DS * (PRO == 2 ? 3 : 2) * DBM * DBK * 2;
+  const size_t lds = (PRO == 0 ? 0 : (size_t)3 * Kp * sizeof(float)) + (size_t)DS * (PRO == 2 ? 3 : 2) * DBM * DBK * 2;
   static bool attr_done = false;
   if (!attr_done) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(&pw_gemm_dma_kernel<PRO, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -617,6 +623,7 @@ int launch_gemm_dma(const spb_gemm_args_t& g, hipStream_t stream) {
 // The LDS-DMA ring variant is kept for experiments (spb_debug_set_gemm_dma(1)); measured in the full KRN step it is
 // slower than the register-prefetch kernel on the small-M layers it was written for (dgrad 1.52 vs 1.38 ms / step).
 bool g_disable_dma = true;
+bool g_plain_dma = true;
 int g_bk64_min_k = 256;
 
 template <typename T, int PRO, int EPI>
@@ -636,7 +643,7 @@ int dispatch_bn(const spb_gemm_args_t& g, hipStream_t stream) {
   if (small_m && bn == 128) bn = 64;
   if (small_m) {
     if (bn == 32) return launch_gemm<T, 1, 32, 32, PRO, EPI>(g, stream);
-    if (g.K >= 64 && sizeof(T) == 2 && !g_disable_dma && g.lda <= 0 && g.ldc <= 0) return launch_gemm_dma<PRO, EPI>(g, stream);
+    if (g.K >= 64 && sizeof(T) == 2 && !g_disable_dma) return launch_gemm_dma<PRO, EPI>(g, stream);
     // long reductions (the 7x7 ConvDw layers, K up to 1280): 64-wide chunks halve the number of latency-bound steps
     // (forward-type only: the backward variant spills 87 dwords at 128 VGPRs with two 64-wide prefetch sets: 0.68 -> 0.75 ms)
     if (sizeof(T) == 2 && PRO == 1 && g.K >= g_bk64_min_k) return launch_gemm<T, 1, 64, 64, PRO, EPI>(g, stream);
@@ -649,6 +656,10 @@ int dispatch_bn(const spb_gemm_args_t& g, hipStream_t stream) {
 
 template <typename T>
 int dispatch_modes(const spb_gemm_args_t& g, hipStream_t stream) {
+  if (g.pro_mode == 0 && g.epi_mode == 0) {   // plain operands (SPN): bf16 streams both tiles through the LDS-DMA ring
+    if (sizeof(T) == 2 && g.K >= 64 && g_plain_dma) return launch_gemm_dma<0, 0>(g, stream);
+    return dispatch_bn<T, 1, 0>(g, stream);   // the caller's identity `pro` reference makes the prologue a no-op
+  }
   if (g.pro_mode == 1 && g.epi_mode == 1) return dispatch_bn<T, 1, 1>(g, stream);
   if (g.pro_mode == 1 && g.epi_mode == 0) return dispatch_bn<T, 1, 0>(g, stream);
   if (g.pro_mode == 2 && g.epi_mode == 0) return dispatch_bn<T, 2, 0>(g, stream);
@@ -853,6 +864,7 @@ extern "C" int spb_debug_trread(const unsigned short* in4096, unsigned short* ou
 }
 
 extern "C" int spb_debug_set_gemm_dma(int on) { g_disable_dma = (on == 0); return 0; }
+extern "C" int spb_debug_set_gemm_plain_dma(int on) { g_plain_dma = (on != 0); return 0; }
 extern "C" int spb_debug_set_gemm_bk64_min_k(int k) { g_bk64_min_k = k; return 0; }
 
 extern "C" const char* spb_version(void) { return "speedplusbaseline_amd gfx950 r1"; }

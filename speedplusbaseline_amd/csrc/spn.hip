@@ -50,23 +50,30 @@ __global__ void im2col_kernel(const T* __restrict__ src, T* __restrict__ dst, in
   }
 }
 
-// first layer: fp32 NCHW image, C = 3: k = (ky*KW + kx)*3 + ci, padded with zeros up to Kpad
+// first layer: fp32 NCHW image, C = 3: k = (ci*KH + ky)*KW + kx (the order of nn.Conv2d's own weight rows, and the one in which
+// consecutive k are consecutive pixels of an image row), zero padded up to Kpad; one thread = 8 consecutive k = one 16-byte store
 template <typename T>
 __global__ void im2col_rgb_kernel(const float* __restrict__ x, T* __restrict__ dst, int B, int H, int W, int KH, int KW, int st,
                                   int OH, int OW, int Kpad) {
-  const long long total = (long long)B * OH * OW * Kpad;
+  const int KV = Kpad >> 3, KK = 3 * KH * KW;
+  const long long total = (long long)B * OH * OW * KV;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    const int k = (int)(i % Kpad);
-    long long r = i / Kpad;
+    const int kv = (int)(i % KV);
+    long long r = i / KV;
     const int ox = (int)(r % OW); r /= OW;
     const int oy = (int)(r % OH);
     const int b = (int)(r / OH);
-    float v = 0.f;
-    if (k < KH * KW * 3) {
-      const int tap = k / 3, ci = k % 3;
-      v = x[((size_t)(b * 3 + ci) * H + oy * st + tap / KW) * W + ox * st + tap % KW];   // valid padding
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int k = kv * 8 + j;
+      v[j] = 0.f;
+      if (k < KK) {
+        const int ci = k / (KH * KW), rem = k - ci * KH * KW, ky = rem / KW, kx = rem - ky * KW;
+        v[j] = x[((size_t)(b * 3 + ci) * H + oy * st + ky) * W + ox * st + kx];   // valid padding
+      }
     }
-    stf<T>(dst + i, v);
+    st8<T>(dst + i * 8, v);
   }
 }
 
@@ -311,27 +318,27 @@ __global__ __launch_bounds__(256) void colsum8_kernel(const T* __restrict__ g, f
 // to Kg), i.e. G stacked [Cout/G][Kg] GEMM operands; WpT [G][Kg][Cout/G] holds the per-group transposes (input gradient)
 template <typename T>
 __global__ void pack_conv_kernel(const float* __restrict__ W, T* __restrict__ Wp, T* __restrict__ WpT, int Cout, int Cin, int G, int KH,
-                                 int KW, int Kg) {
+                                 int KW, int Kg, int chw) {
   const long long total = (long long)Cout * Kg;
   const int cog = Cout / G, cig = Cin / G;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
     const int co = (int)(i / Kg), k = (int)(i % Kg);
     float v = 0.f;
-    if (k < KH * KW * cig) v = W[((size_t)co * cig + (k % cig)) * KH * KW + k / cig];
+    if (k < KH * KW * cig) v = chw ? W[(size_t)co * cig * KH * KW + k] : W[((size_t)co * cig + (k % cig)) * KH * KW + k / cig];
     stf<T>(Wp + i, v);
     const int gi = co / cog;
     if (WpT) stf<T>(WpT + ((size_t)gi * Kg + k) * cog + (co - gi * cog), v);
   }
 }
 __global__ void unpack_conv_grad_kernel(const float* __restrict__ dWp, float* __restrict__ dW, int Cout, int Cin, int G, int KH, int KW,
-                                        int Kg) {
+                                        int Kg, int chw) {
   const int cig = Cin / G;
   const long long total = (long long)Cout * cig * KH * KW;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
     const int tap = (int)(i % (KH * KW));
     const int ci = (int)((i / (KH * KW)) % cig);
     const int co = (int)(i / ((long long)KH * KW * cig));
-    dW[i] = dWp[(size_t)co * Kg + (size_t)tap * cig + ci];
+    dW[i] = chw ? dWp[(size_t)co * Kg + (size_t)ci * KH * KW + tap] : dWp[(size_t)co * Kg + (size_t)tap * cig + ci];
   }
 }
 
@@ -368,7 +375,7 @@ extern "C" int spb_im2col_rgb(int dtype, const float* x, void* dst, int B, int H
                               spb_stream_t stream) {
   if (!x || !dst || B <= 0 || Kpad < KH * KW * 3 || (Kpad & 7)) return SPB_E_ARG;
   const int OH = (H - KH) / stride + 1, OW = (W - KW) / stride + 1;
-  const long long total = (long long)B * OH * OW * Kpad;
+  const long long total = (long long)B * OH * OW * (Kpad >> 3);
   hipStream_t s = (hipStream_t)stream;
   SPN_T(dtype, hipLaunchKernelGGL(im2col_rgb_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, s, x, (bf16_t*)dst, B, H, W, KH, KW, stride, OH, OW, Kpad),
         hipLaunchKernelGGL(im2col_rgb_kernel<float>, dim3(grid_for(total)), dim3(256), 0, s, x, (float*)dst, B, H, W, KH, KW, stride, OH, OW, Kpad))
@@ -467,7 +474,7 @@ extern "C" int spb_colsum(int dtype, const void* g, float* out, long long M, int
   hipStream_t s = (hipStream_t)stream;
   if (!(N & 7) && N <= 2048 && M >= 64) {
     const int RP = 256 / (N >> 3);
-    long long rpb = (M + 1023) / 1024;
+    long long rpb = (M + 255) / 256;     // ~256 blocks: each ends in N same-address atomics (~25 ns apiece, serialised)
     rpb = (rpb + RP - 1) / RP * RP;
     const dim3 g8((unsigned)((M + rpb - 1) / rpb));
     SPN_T(dtype, hipLaunchKernelGGL(colsum8_kernel<bf16_t>, g8, dim3(256), 0, s, (const bf16_t*)g, out, M, N, rpb),
@@ -484,21 +491,21 @@ extern "C" int spb_colsum(int dtype, const void* g, float* out, long long M, int
 }
 
 extern "C" int spb_spn_pack_conv(int dtype, const float* W, void* Wp, void* WpT, int Cout, int Cin, int groups, int KH, int KW, int Kg,
-                                 spb_stream_t stream) {
+                                 int chw_order, spb_stream_t stream) {
   if (!W || !Wp || Cout <= 0 || Cin <= 0 || groups <= 0 || (Cout % groups) || (Cin % groups) || Kg < KH * KW * (Cin / groups)) return SPB_E_ARG;
   hipStream_t s = (hipStream_t)stream;
   const unsigned grid = grid_for((long long)Cout * Kg);
-  SPN_T(dtype, hipLaunchKernelGGL(pack_conv_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, W, (bf16_t*)Wp, (bf16_t*)WpT, Cout, Cin, groups, KH, KW, Kg),
-        hipLaunchKernelGGL(pack_conv_kernel<float>, dim3(grid), dim3(256), 0, s, W, (float*)Wp, (float*)WpT, Cout, Cin, groups, KH, KW, Kg))
+  SPN_T(dtype, hipLaunchKernelGGL(pack_conv_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, W, (bf16_t*)Wp, (bf16_t*)WpT, Cout, Cin, groups, KH, KW, Kg, chw_order),
+        hipLaunchKernelGGL(pack_conv_kernel<float>, dim3(grid), dim3(256), 0, s, W, (float*)Wp, (float*)WpT, Cout, Cin, groups, KH, KW, Kg, chw_order))
   SPB_CHECK_LAUNCH();
   return 0;
 }
 
 extern "C" int spb_spn_unpack_conv_grad(const float* dWp, float* dW, int Cout, int Cin, int groups, int KH, int KW, int Kg,
-                                        spb_stream_t stream) {
+                                        int chw_order, spb_stream_t stream) {
   if (!dWp || !dW || Cout <= 0 || Cin <= 0 || groups <= 0 || (Cout % groups) || (Cin % groups) || Kg < KH * KW * (Cin / groups)) return SPB_E_ARG;
   hipLaunchKernelGGL(unpack_conv_grad_kernel, dim3(grid_for((long long)Cout * (Cin / groups) * KH * KW)), dim3(256), 0, (hipStream_t)stream,
-                     dWp, dW, Cout, Cin, groups, KH, KW, Kg);
+                     dWp, dW, Cout, Cin, groups, KH, KW, Kg, chw_order);
   SPB_CHECK_LAUNCH();
   return 0;
 }

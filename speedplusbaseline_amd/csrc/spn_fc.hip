@@ -212,36 +212,39 @@ __device__ __forceinline__ unsigned hash32(unsigned long long z) {
   return (unsigned)((z ^ (z >> 31)) >> 32);
 }
 
-// one thread per feature f.  mode 0 (forward): v = acc + bias; ReLU if relu; inverted dropout with probability p if p > 0
-//   (mask [M][F] written, or read when given); Y [M][F], YT [F][MP].
+// A thread owns 4 batch rows of one feature (block = 256/MG features x MG row groups, MG = MP/4).
+// mode 0 (forward): v = acc + bias; ReLU if relu; inverted dropout with probability p if p > 0 (mask [M][F] written, or read
+//   when given); Y [M][F], YT [F][MP].
 // mode 1 (backward): v = (acc or src) * scale where H > 0 (H NULL: everywhere); Y, YT as above; db[f] = sum_m v.
 template <int MT>
-__global__ void fc_epi_kernel(float* __restrict__ accT, const bf16_t* __restrict__ src, const float* __restrict__ bias,
+__global__ __launch_bounds__(256) void fc_epi_kernel(float* __restrict__ accT, const bf16_t* __restrict__ src, const float* __restrict__ bias,
                               const bf16_t* __restrict__ H, bf16_t* __restrict__ Y, bf16_t* __restrict__ YT, unsigned char* __restrict__ mask,
                               float* __restrict__ db, int M, int F, int mode, int relu, float p, float scale, unsigned long long seed, int given) {
-  constexpr int MP = 16 * MT;
-  const int f = blockIdx.x * blockDim.x + threadIdx.x;
-  if (f >= F) return;
-  float v[MP];
-  if (accT) {
-    float4* a4 = reinterpret_cast<float4*>(accT + (size_t)f * MP);
+  constexpr int MP = 16 * MT, MG = MP / 4, FPB = 256 / MG;
+  __shared__ float red[256];
+  const int fl = threadIdx.x % FPB, mg = threadIdx.x / FPB;
+  const int f = blockIdx.x * FPB + fl;
+  const bool fok = f < F;
+  float v[4] = {0.f, 0.f, 0.f, 0.f};
+  if (fok) {
+    if (accT) {
+      float4* a4 = reinterpret_cast<float4*>(accT + (size_t)f * MP + mg * 4);
+      const float4 q = *a4;
+      v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+      *a4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    } else {
 #pragma unroll
-    for (int i = 0; i < MP / 4; ++i) {
-      const float4 q = a4[i];
-      v[4 * i] = q.x; v[4 * i + 1] = q.y; v[4 * i + 2] = q.z; v[4 * i + 3] = q.w;
-      a4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int e = 0; e < 4; ++e) { const int m = mg * 4 + e; v[e] = m < M ? bf2f(src[(size_t)m * F + f]) : 0.f; }
     }
-  } else {
-#pragma unroll
-    for (int m = 0; m < MP; ++m) v[m] = m < M ? bf2f(src[(size_t)m * F + f]) : 0.f;
   }
   float s = 0.f;
-  const float bv = (mode == 0 && bias) ? bias[f] : 0.f;
+  const float bv = (fok && mode == 0 && bias) ? bias[f] : 0.f;
   const float ds = p > 0.f ? 1.f / (1.f - p) : 1.f;
 #pragma unroll
-  for (int m = 0; m < MP; ++m) {
-    float x = v[m];
-    if (m >= M) x = 0.f;
+  for (int e = 0; e < 4; ++e) {
+    const int m = mg * 4 + e;
+    float x = v[e];
+    if (m >= M || !fok) x = 0.f;
     else if (mode == 0) {
       x += bv;
       if (relu) x = fmaxf(x, 0.f);
@@ -258,19 +261,24 @@ __global__ void fc_epi_kernel(float* __restrict__ accT, const bf16_t* __restrict
       x = bf2f(f2bf(x));
       s += x;
     }
-    v[m] = x;
+    v[e] = x;
   }
-  if (Y)
+  if (fok) {
+    if (Y)
 #pragma unroll
-    for (int m = 0; m < MP; ++m) if (m < M) Y[(size_t)m * F + f] = f2bf(v[m]);
-  if (YT) {
-    uint4* o = reinterpret_cast<uint4*>(YT + (size_t)f * MP);
-#pragma unroll
-    for (int i = 0; i < MP / 8; ++i)
-      o[i] = make_uint4(pack_bf16x2(v[8 * i], v[8 * i + 1]), pack_bf16x2(v[8 * i + 2], v[8 * i + 3]),
-                        pack_bf16x2(v[8 * i + 4], v[8 * i + 5]), pack_bf16x2(v[8 * i + 6], v[8 * i + 7]));
+      for (int e = 0; e < 4; ++e) if (mg * 4 + e < M) Y[(size_t)(mg * 4 + e) * F + f] = f2bf(v[e]);
+    if (YT) *reinterpret_cast<uint2*>(YT + (size_t)f * MP + mg * 4) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
   }
-  if (mode == 1 && db) db[f] = s;
+  if (mode == 1 && db) {      // bias gradient: sum over the MG row groups of a feature
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (mg == 0 && fok) {
+      float a = 0.f;
+#pragma unroll
+      for (int q = 0; q < MG; ++q) a += red[q * FPB + fl];
+      db[f] = a;
+    }
+  }
 }
 
 // pool5 output NHWC [B][HW][C] -> f [B][C*HW] in the reference's NCHW flatten order (spn.py:131 x.view(-1, 9216)) + fT
@@ -363,7 +371,8 @@ extern "C" int spb_fc_epilogue(const spb_fc_epi_args_t* a, spb_stream_t stream) 
   if (a->M > 64) return SPB_E_UNSUPPORTED;
   if (a->mode == 0 && a->p > 0.f && !a->mask) return SPB_E_ARG;
   hipStream_t s = (hipStream_t)stream;
-  const dim3 grid((a->F + 63) / 64), blk(64);
+  const int fpb = a->M <= 32 ? 32 : 16;
+  const dim3 grid((a->F + fpb - 1) / fpb), blk(256);
   FC_MT(a->M,
         hipLaunchKernelGGL(fc_epi_kernel<2>, grid, blk, 0, s, a->accT, (const bf16_t*)a->src, a->bias, (const bf16_t*)a->H, (bf16_t*)a->Y,
                            (bf16_t*)a->YT, a->mask, a->db, a->M, a->F, a->mode, a->relu, a->p, a->scale, a->seed, a->mask_given),

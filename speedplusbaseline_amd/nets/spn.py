@@ -177,7 +177,7 @@ class SpacecraftPoseNet(nn.Module):
             kg = (k * k * (cin // g) + 7) // 8 * 8             # one column slab / one [cout/g][kg] operand per group
             wp = self._buf("wp" + name, (cout, kg), dt)
             wt = self._buf("wpT" + name, (g, kg, cout // g), dt) if (need_t and name != "conv1") else None
-            L.check(lib.spb_spn_pack_conv(dc, _p(getattr(self, name).weight.detach()), _p(wp), _p(wt), cout, cin, g, k, k, kg, st),
+            L.check(lib.spb_spn_pack_conv(dc, _p(getattr(self, name).weight.detach()), _p(wp), _p(wt), cout, cin, g, k, k, kg, 1 if name == "conv1" else 0, st),
                     "spb_spn_pack_conv")
             cp[name] = wp
             if wt is not None:
@@ -205,7 +205,7 @@ class SpacecraftPoseNet(nn.Module):
 
     # ---- pieces
     def _gemm(self, A, W, bias, Y, relu):
-        ops.pwconv_gemm(A, W, Y, ops.bnref(A.shape[1]), 1, 0, bias=bias, out_act=L.ACT_RELU if relu else L.ACT_NONE, out_scale=1.0)
+        ops.pwconv_gemm(A, W, Y, ops.bnref(A.shape[1]), 0, 0, bias=bias, out_act=L.ACT_RELU if relu else L.ACT_NONE, out_scale=1.0)
 
     def _epi(self, B, F, mode, accT=None, src=None, bias=None, H=None, Y=None, YT=None, mask=None, db=None, relu=0, p=0.0, scale=1.0,
              seed=0, given=0):
@@ -387,7 +387,7 @@ class SpacecraftPoseNet(nn.Module):
                     ops.pwconv_wgrad(g, xin, lay.weight.grad, ident(N), ident(K))
                     L.check(lib.spb_colsum(dc, _p(g), _p(lay.bias.grad), B, N, st), "spb_colsum")
                     dx = self._buf("dx" + name, (B, K), dt)
-                    ops.pwconv_gemm(g, cp[name + "T"], dx, ident(N), 1, 0, out_scale=1.0)
+                    ops.pwconv_gemm(g, cp[name + "T"], dx, ident(N), 0, 0, out_scale=1.0)
                     if prev is not None:
                         gn = self._buf("g" + prev, (B, 4096), dt)
                         L.check(lib.spb_relu_bwd(dc, _p(dx), _p(sv["h" + prev]), None, _p(gn), B * 4096, scale, st), "spb_relu_bwd")
@@ -424,12 +424,12 @@ class SpacecraftPoseNet(nn.Module):
             woff += cout * kg
             for gi in range(grp):
                 ops.pwconv_wgrad(g[:, gi * cog:(gi + 1) * cog], col[:, gi * kg:(gi + 1) * kg], dW[gi * cog:(gi + 1) * cog], ident(cog), ident(kg))
-            L.check(lib.spb_spn_unpack_conv_grad(_p(dW), _p(lay.weight.grad), cout, cin, grp, k, k, kg, st), "spb_spn_unpack_conv_grad")
+            L.check(lib.spb_spn_unpack_conv_grad(_p(dW), _p(lay.weight.grad), cout, cin, grp, k, k, kg, 1 if name == "conv1" else 0, st), "spb_spn_unpack_conv_grad")
             L.check(lib.spb_colsum(dc, _p(g), _p(lay.bias.grad), g.shape[0], cout, st), "spb_colsum")
             if name != "conv1":
                 dcol = self._buf("dcol" + name, tuple(col.shape), dt)
                 for gi in range(grp):
-                    ops.pwconv_gemm(g[:, gi * cog:(gi + 1) * cog], cp[name + "T"][gi], dcol[:, gi * kg:(gi + 1) * kg], ident(cog), 1, 0,
+                    ops.pwconv_gemm(g[:, gi * cog:(gi + 1) * cog], cp[name + "T"][gi], dcol[:, gi * kg:(gi + 1) * kg], ident(cog), 0, 0,
                                     out_scale=1.0)
                 dx = self._buf("dxin" + name, (B, Hc, Wc, Cc), dt)
                 L.check(lib.spb_col2im(dc, _p(dcol), _p(dx), B, Hc, Wc, Cc, k, k, pad, kpad, grp, st), "spb_col2im")

@@ -230,12 +230,12 @@ def test_conv_pack_unpack_and_colsum(device):
     kg = (k * k * cig + 7) // 8 * 8
     W = torch.randn(cout, cig, k, k, device=device)
     Wp = torch.empty(cout, kg, device=device); WpT = torch.empty(g, kg, cog, device=device)
-    L.check(lib.spb_spn_pack_conv(L.F32, _vp(W), _vp(Wp), _vp(WpT), cout, cin, g, k, k, kg, st), "pack")
+    L.check(lib.spb_spn_pack_conv(L.F32, _vp(W), _vp(Wp), _vp(WpT), cout, cin, g, k, k, kg, 0, st), "pack")
     assert torch.equal(Wp[:, :k * k * cig], W.permute(0, 2, 3, 1).reshape(cout, -1))       # (ky, kx, c_local) per output row
     for gi in range(g):
         assert torch.equal(WpT[gi], Wp[gi * cog:(gi + 1) * cog].t().contiguous())
     dW = torch.empty_like(W)
-    L.check(lib.spb_spn_unpack_conv_grad(_vp(Wp), _vp(dW), cout, cin, g, k, k, kg, st), "unpack")
+    L.check(lib.spb_spn_unpack_conv_grad(_vp(Wp), _vp(dW), cout, cin, g, k, k, kg, 0, st), "unpack")
     assert torch.equal(dW, W)
     # grouped convolution = im2col with one column slab per group + one dense GEMM per slab, against torch's conv2d
     from speedplusbaseline_amd import ops
@@ -260,7 +260,7 @@ def test_conv_pack_unpack_and_colsum(device):
         ops.pwconv_wgrad(gy[:, gi * cog:(gi + 1) * cog], col[:, gi * kg:(gi + 1) * kg], dWp[gi * cog:(gi + 1) * cog], ops.bnref(cog), ops.bnref(kg))
     dx = torch.empty(B, H, H, cin, device=device)
     L.check(lib.spb_col2im(L.F32, _vp(dcol), _vp(dx), B, H, H, cin, k, k, 2, g * kg, g, st), "col2im")
-    L.check(lib.spb_spn_unpack_conv_grad(_vp(dWp), _vp(dW), cout, cin, g, k, k, kg, st), "unpack")
+    L.check(lib.spb_spn_unpack_conv_grad(_vp(dWp), _vp(dW), cout, cin, g, k, k, kg, 0, st), "unpack")
     xr = x.clone().requires_grad_(True); Wr = W.clone().requires_grad_(True)
     torch.nn.functional.conv2d(xr, Wr, None, padding=2, groups=g).backward(gy.view(B, H, H, cout).permute(0, 3, 1, 2))
     assert rel(dx, xr.grad.permute(0, 2, 3, 1)) < 1e-4 and rel(dW, Wr.grad) < 1e-4
