@@ -26,6 +26,13 @@ def _texture_coin(cfg, step):
     return random.random() < cfg.texture_ratio
 
 
+def _world():
+    """(world_size, group) of the data-parallel job this process belongs to (one process per GPU); (1, None) when single"""
+    if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+        return torch.distributed.get_world_size(), torch.distributed.group.WORLD
+    return 1, None
+
+
 def train_single_epoch_krn(epoch, cfg, model, data_loader, optimizer, writer, device, styleAugmentor=None, scaler=None):
     training_time_meter = AverageMeter('ms')
     loss_x_meter = AverageMeter('-')
@@ -33,6 +40,7 @@ def train_single_epoch_krn(epoch, cfg, model, data_loader, optimizer, writer, de
     model.train()
     lr = optimizer.param_groups[-1]['lr']
     fused = isinstance(optimizer, FusedOptimizer) and scaler is None
+    world, group = _world()
     n_iter = len(data_loader)
     for idx, (images, target) in enumerate(data_loader):
         start = time.time()
@@ -42,7 +50,7 @@ def train_single_epoch_krn(epoch, cfg, model, data_loader, optimizer, writer, de
         if styleAugmentor is not None and _texture_coin(cfg, epoch * n_iter + idx):   # trainer.py:68-69
             images = styleAugmentor(images)
         if fused:
-            lx, ly = optimizer.train_step(images, target)[1:3].tolist()  # host floats per step, as the reference reports
+            lx, ly = optimizer.train_step(images, target, world_size=world, group=group)[1:3].tolist()  # host floats per step, as the reference reports
         else:
             loss, summary = model(images, target)
             optimizer.zero_grad(set_to_none=True)
@@ -76,6 +84,7 @@ def train_single_epoch_spn(epoch, cfg, model, data_loader, optimizer, writer, de
     loss_weight_meter = AverageMeter('-')
     model.train()
     lr = optimizer.param_groups[-1]['lr']
+    world, group = _world()
     n_iter = len(data_loader)
     for idx, (images, yClasses, yWeights) in enumerate(data_loader):
         start = time.time()
@@ -86,7 +95,7 @@ def train_single_epoch_spn(epoch, cfg, model, data_loader, optimizer, writer, de
         if styleAugmentor is not None and _texture_coin(cfg, epoch * n_iter + idx):
             images = styleAugmentor(images)
         out = model.loss_and_grads(images, yClasses, yWeights)   # gradients land in p.grad (no autograd)
-        optimizer.step()                                         # clip_grad_value_(1.0) + update, fused per tensor
+        optimizer.step(world_size=world, group=group)            # [all-reduce,] clip_grad_value_(1.0) + update: one launch
         lc, lr_ = out[1:3].tolist()                              # host floats per step, as the reference reports
         training_time_meter.update((time.time() - start) * 1000, B)
         loss_class_meter.update(lc, B)

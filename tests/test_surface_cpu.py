@@ -110,7 +110,8 @@ def _dp_worker(rank, world, port, out):
     p = torch.full((4,), float(rank))
     parallel.broadcast_([p], 0)
     coins = [parallel.shared_coin(s, 2021, 0.5) for s in range(16)]
-    out[rank] = (lo, hi, g.tolist(), p.tolist(), coins)
+    from speedplusbaseline_amd.core.trainer import _world       # what the KRN / SPN trainers hand to their optimizers
+    out[rank] = (lo, hi, g.tolist(), p.tolist(), coins, _world()[0])
     dist.destroy_process_group()
 
 
@@ -124,3 +125,4 @@ def test_data_parallel_host_logic_two_gloo_ranks():
     assert out[0][2] == mean and out[1][2] == mean
     assert out[0][3] == [0.0] * 4 and out[1][3] == [0.0] * 4                  # rank 0's parameters everywhere
     assert out[0][4] == out[1][4] and 2 < sum(out[0][4]) < 14                 # rank-synchronous style-augmentation coin
+    assert out[0][5] == 2 and out[1][5] == 2                                  # trainers see the data-parallel job
