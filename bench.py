@@ -37,8 +37,9 @@ def main():
     ap.add_argument("--graph", action="store_true", help="replay a captured hipGraph instead of enqueuing the launches "
                     "eagerly (eager + side-stream weight gradients is the faster, default mode)")
     ap.add_argument("--no-graph", action="store_true", help=argparse.SUPPRESS)  # old spelling of the default
-    ap.add_argument("--model", default="krn", choices=["krn", "spn"], help="krn: the headline benchmark (BASELINE configs[1]); "
-                    "spn: Spacecraft Pose Network train step, 227x227, bs=32, 5000 classes (configs[5] flavour, 1 GPU)")
+    ap.add_argument("--model", default="krn", choices=["krn", "spn", "dann"], help="krn: the headline benchmark (BASELINE configs[1]); "
+                    "spn: Spacecraft Pose Network train step, 227x227, bs=32, 5000 classes (configs[5] flavour); "
+                    "dann: RevGrad domain-adversarial step, source + target batch (configs[3] flavour; --batch 16 is the README recipe)")
     ap.add_argument("--styleaug", action="store_true", help="BASELINE configs[4] flavour: restyle the batch with the Ghiasi "
                     "decoder on a rank-synchronous coin (p=0.5, alpha=0.5) before the train step (trainer.py:68-69)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -48,6 +49,8 @@ def main():
 
     if args.model == "spn":
         return bench_spn(args)
+    if args.model == "dann":
+        return bench_dann(args)
     from speedplusbaseline_amd.engine import KrnEngine
     from speedplusbaseline_amd.step import FusedTrainStep
     from oracle import krn_oracle as O  # checker / cpu_baseline leg only
@@ -225,6 +228,86 @@ def main():
             "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels,
         }
         print(json.dumps(out))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+def bench_dann(args):
+    """RevGrad / DANN step (dann.py:68-100): source forward (pose loss + domain BCE vs 1), target forward (domain BCE vs 0),
+    one backward through both passes with the gradient reversed at the 7x7x320 feature, clip_grad_norm_(1.0), AdamW.
+    One step = B source + B target images; `value` counts source images (the reference's epoch unit)."""
+    from speedplusbaseline_amd.engine import KrnEngine
+    from speedplusbaseline_amd.step import FusedTrainStep
+    from oracle import krn_oracle as O  # checker / cpu_baseline leg only
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        raise SystemExit("--gpus (%d) != WORLD_SIZE (%d): launch with python -m torch.distributed.run --nproc-per-node N" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X; there is no CPU path for the product")
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+    group = None
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.distributed.init_process_group("nccl", device_id=dev)
+        group = torch.distributed.group.WORLD
+    B = args.batch
+    eng = KrnEngine(11, dann=True).attach(dev, args.precision)
+    sd = O.init_state(11, dann=True)
+    for info in eng.param_infos:
+        eng.param_view(info).copy_(sd[info[0]].to(dev))
+    for name, shape, off, numel in eng.buffer_infos:
+        eng.buffers[off: off + numel].copy_(sd[name].flatten().to(dev))
+    if world > 1:
+        torch.distributed.broadcast(eng.params, 0); torch.distributed.broadcast(eng.buffers, 0)
+    gen = torch.Generator(device="cpu"); gen.manual_seed(2021 + rank)
+    xs = torch.rand(B, 3, 224, 224, generator=gen).to(dev)
+    ys = torch.rand(B, 2, 11, generator=gen).to(dev)
+    xt = torch.rand(B, 3, 224, 224, generator=gen).to(dev)
+    step = FusedTrainStep(eng, B, kind="adamw", lr=1e-3, momentum=0.9, weight_decay=0.01, max_norm=1.0, dist_group=group,
+                          world_size=world, use_graph=False, dann=True)
+    alpha = O.dann_alpha(5, 1, 100, 10)
+
+    def sync_all():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+    for _ in range(args.warmup):
+        step(xs, ys, xt, alpha)
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        scal = step(xs, ys, xt, alpha)
+    sync_all()
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+    dt = float(t.item())
+    cpu = None
+    if rank == 0 and not args.no_cpu_baseline:
+        ncores = min(os.cpu_count() or 1, args.cpu_threads)
+        torch.set_num_threads(ncores)
+        tr = O.DannTrainer(O.init_state(11, dann=True), "adamw", lr=1e-3, momentum=0.9, weight_decay=0.01)
+        a, b, c = xs.cpu(), ys.cpu(), xt.cpu()
+        t1 = time.perf_counter(); tr.step(a, b, c, alpha); warm = time.perf_counter() - t1
+        n_cpu = max(1, min(10, int(12.0 / max(warm, 1e-3))))
+        t1 = time.perf_counter()
+        for _ in range(n_cpu):
+            tr.step(a, b, c, alpha)
+        cdt = time.perf_counter() - t1
+        cpu = dict(value=round(B * n_cpu / cdt, 2), unit="images/sec", cores=torch.get_num_threads(), kind="port",
+                   sample="%d DANN steps of the same bs=%d source + bs=%d target batch, fp32, PyTorch CPU oracle (%.1f s)" % (n_cpu, B, B, cdt))
+    if rank == 0:
+        print(json.dumps({
+            "metric": "source images/sec RevGrad (DANN) 224x224 train step", "value": round(world * B * args.steps / dt, 1),
+            "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+            "config": {"workload": "RevGrad (KRN + gradient-reversal domain classifier) step: bs=%d source + bs=%d target images/GPU, "
+                                   "AdamW lr 1e-3 wd 0.01 + clip_grad_norm 1.0" % (B, B), "per_gpu_batch": B, "global_batch": B * world,
+                       "parallelism": "dp%d" % world, "weights": "random init", "loss_last_step": [float(v) for v in scal.cpu()]},
+            "roofline": None, "cpu_baseline": cpu}))
     if world > 1:
         torch.distributed.destroy_process_group()
 

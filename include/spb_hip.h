@@ -281,11 +281,16 @@ int spb_krn_ctx_set_side_stream(spb_krn_ctx_t* c, int on);
 
 /* refresh compute-dtype weight copies (W, W^T, permuted head) from the f32 parameters */
 int spb_krn_prepare_weights(spb_krn_t* m, spb_stream_t stream);
-/* forward.  training=1: batch statistics + running-stat update.  target NULL => prediction only.
+/* forward.  training=1: batch statistics + running-stat update; training=2: batch statistics, the running-stat update is
+ * left to a later spb_krn_update_running (two passes on two streams, see below).  target NULL => prediction only.
  * pred [B][2K] f32 (interleaved x,y as the head emits them), scalars [3] = loss, loss_x, loss_y.
  * alpha_valid=1 with a dann plan also runs the domain classifier: domain_logits [B].                           */
 int spb_krn_forward(spb_krn_ctx_t* c, const float* x_nchw, const float* target, int training, float* pred,
                     float* scalars, float* domain_logits, spb_stream_t stream);
+/* BatchNorm running_mean / running_var / num_batches_tracked update from the batch sums of this context's last training
+ * forward (what training=1 does at the end of the forward).  DANN (dann.py:81-92) runs its source and target passes
+ * concurrently on two streams; the shared buffers are still updated source first, then target, on one stream. */
+int spb_krn_update_running(spb_krn_ctx_t* c, spb_stream_t stream);
 /* backward of loss*gscale (+ sum_b domain_logit_grad[b]*logit[b] through the gradient-reversal layer with alpha).
  * ACCUMULATES into `grads` (f32 arena with the parameter layout; NULL = the arena given to spb_krn_bind); the caller
  * zeroes it, as optimizer.zero_grad does.                                                                       */

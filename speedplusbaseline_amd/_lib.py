@@ -140,6 +140,7 @@ SYMBOLS = {
     "spb_krn_ctx_set_side_stream": (i32, [vp, i32]),
     "spb_krn_prepare_weights": (i32, [vp, vp]),
     "spb_krn_forward": (i32, [vp, vp, vp, i32, vp, vp, vp, vp]),
+    "spb_krn_update_running": (i32, [vp, vp]),
     "spb_krn_backward": (i32, [vp, vp, f32, i32, vp, f32, vp]),
     "spb_bce_logits": (i32, [vp, f32, i32, vp, vp, f32, vp]),
     "spb_krn_prof_enable": (i32, [vp, i32]),

@@ -677,7 +677,7 @@ extern "C" int spb_krn_forward(spb_krn_ctx_t* c, const float* x, const float* ta
                        reinterpret_cast<float*>(c->ws + c->dompool_off), domain_logits, 49, 1280);
     r.toc();
   }
-  if (tr) {
+  if (tr && training != 2) {   // training == 2: the caller applies the running-statistics update later (spb_krn_update_running)
     r.tic(PC_BN_UPDATE, (double)c->stats_floats * 2 + (double)m->n_buffers * 8);
     r.ok(spb_bn_running_update(tab, (int)m->bns.size(), r.stats(), m->Bf, m->nbt, kMomentum, stream));
     r.toc();
@@ -685,6 +685,17 @@ extern "C" int spb_krn_forward(spb_krn_ctx_t* c, const float* x, const float* ta
   hipError_t le = hipGetLastError();
   if (le != hipSuccess && r.err == 0) r.err = (int)le;
   return r.err;
+}
+
+// BatchNorm running statistics + num_batches_tracked from the batch sums of this context's last training forward
+// (momentum 0.1, unbiased variance).  For forwards enqueued with training == 2: two passes that run concurrently on two
+// streams (DANN source / target) must still update the shared buffers in the reference's order.
+extern "C" int spb_krn_update_running(spb_krn_ctx_t* c, spb_stream_t stream) {
+  if (!c || !c->last_training) return SPB_E_STATE;
+  spb_krn* m = c->m;
+  Runner r(c, (hipStream_t)stream);
+  const spb_bnupd_entry_t* tab = reinterpret_cast<const spb_bnupd_entry_t*>(c->ws + c->table_off);
+  return spb_bn_running_update(tab, (int)m->bns.size(), r.stats(), m->Bf, m->nbt, kMomentum, stream);
 }
 
 // ---- backward --------------------------------------------------------------------------------------------------

@@ -109,15 +109,18 @@ class KrnEngine:
                                % (tuple(x.shape),))
         return x.detach().to(torch.float32).contiguous()
 
-    def forward(self, x, target=None, training=True, slot=0, domain=False):
+    def forward(self, x, target=None, training=True, slot=0, domain=False, prepare=True, update_running=True):
         """Enqueue one forward.  Returns (pred [B,2K], scalars [3] or None, domain_logits [B] or None); x is kept
-        alive by the caller/ctx until backward."""
+        alive by the caller/ctx until backward.  prepare=False: the compute-dtype weight copies are already current
+        (second pass of a DANN step); update_running=False: training forward whose BatchNorm running-statistics update is
+        applied later by update_running(batch, slot)."""
         x = self._check_input(x)
         B = x.shape[0]
         ctx = self.context(B, slot)
         with torch.cuda.device(self.device):
             st = _stream()
-            L.check(self.lib.spb_krn_prepare_weights(self.h, st), "spb_krn_prepare_weights")
+            if prepare:
+                L.check(self.lib.spb_krn_prepare_weights(self.h, st), "spb_krn_prepare_weights")
             pred = torch.empty(B, 2 * self.num_keypoints, dtype=torch.float32, device=self.device)
             scalars = None
             if target is not None:
@@ -126,11 +129,20 @@ class KrnEngine:
                     raise RuntimeError("target must be [B,2,%d], got %s" % (self.num_keypoints, tuple(target.shape)))
                 scalars = torch.empty(3, dtype=torch.float32, device=self.device)
             dom = torch.empty(B, dtype=torch.float32, device=self.device) if (domain and self.dann) else None
-            L.check(self.lib.spb_krn_forward(ctx, _p(x), _p(target), 1 if training else 0, _p(pred), _p(scalars), _p(dom),
-                                             st), "spb_krn_forward")
+            L.check(self.lib.spb_krn_forward(ctx, _p(x), _p(target), (1 if update_running else 2) if training else 0, _p(pred),
+                                             _p(scalars), _p(dom), st), "spb_krn_forward")
         self._last_x = getattr(self, "_last_x", {})
         self._last_x[(B, slot)] = (x, target)
         return pred, scalars, dom
+
+    def prepare_weights(self):
+        """refresh the compute-dtype weight copies from the f32 parameter arena (forward() does this unless prepare=False)"""
+        with torch.cuda.device(self.device):
+            L.check(self.lib.spb_krn_prepare_weights(self.h, _stream()), "spb_krn_prepare_weights")
+
+    def update_running(self, batch, slot=0):
+        with torch.cuda.device(self.device):
+            L.check(self.lib.spb_krn_update_running(self.context(batch, slot), _stream()), "spb_krn_update_running")
 
     def backward(self, batch, slot=0, grads=None, gscale=1.0, with_pose=True, dlogit=None, alpha=0.0):
         ctx = self.context(batch, slot)

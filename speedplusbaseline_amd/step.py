@@ -8,6 +8,8 @@ edges inside a graph cost more than they hide, so the side stream is switched of
 The per-step scalars that change between replays (lr, Adam bias corrections) live in a 3-float device buffer that is
 refreshed by an async H2D copy before each step, so the captured launch arguments stay valid.
 """
+import os
+
 import torch
 
 from . import ops
@@ -31,6 +33,8 @@ class FusedTrainStep:
         self.group = dist_group
         self.use_graph = bool(use_graph)
         self.dann = bool(dann)
+        self.dann_overlap = os.environ.get("SPB_DANN_OVERLAP", "1") != "0"   # source / target passes on two streams
+        self._g2 = self._s2 = None
         dev = engine.device
         n = engine.n_params
         self.m = torch.zeros(n, dtype=torch.float32, device=dev)
@@ -67,14 +71,39 @@ class FusedTrainStep:
             e.grads.zero_()
             e.backward(self.B, slot=0)
             return scal
-        # DANN: zero_grad, source pass (pose + domain=1), target pass (domain=0), one backward of the sum
-        e.grads.zero_()
-        _, scal, dom_s = e.forward(x, y, training=True, slot=0, domain=True)
+        # DANN: zero_grad, source pass (pose + domain=1), target pass (domain=0), one backward of the sum (dann.py:81-95).
+        # The two passes only meet in the gradient arena and the BatchNorm running statistics, and both are chains of
+        # ~100 dependent, latency-bound launches at bs=16: they run CONCURRENTLY on two streams.  The target pass
+        # accumulates into its own gradient arena (summed in afterwards) and leaves its running-statistics update to the
+        # main stream, so the shared buffers see source first, then target, as in the reference.
+        if not self.dann_overlap:
+            e.grads.zero_()
+            _, scal, dom_s = e.forward(x, y, training=True, slot=0, domain=True)
+            loss_s, dl_s = e.bce_logits(dom_s, 1.0)
+            _, _, dom_t = e.forward(xt, None, training=True, slot=1, domain=True)
+            loss_t, dl_t = e.bce_logits(dom_t, 0.0)
+            e.backward(self.B, slot=0, with_pose=True, dlogit=dl_s, alpha=alpha)
+            e.backward(self.B, slot=1, with_pose=False, dlogit=dl_t, alpha=alpha)
+            return torch.cat([scal, loss_s, loss_t])
+        main = torch.cuda.current_stream()
+        if self._g2 is None:
+            self._g2 = torch.zeros_like(e.grads)
+            self._s2 = torch.cuda.Stream(device=e.device)
+        e.prepare_weights()
+        e.grads.zero_(); self._g2.zero_()
+        self._s2.wait_stream(main)
+        with torch.cuda.stream(self._s2):
+            _, _, dom_t = e.forward(xt, None, training=True, slot=1, domain=True, prepare=False, update_running=False)
+            loss_t, dl_t = e.bce_logits(dom_t, 0.0)
+            e.backward(self.B, slot=1, grads=self._g2, with_pose=False, dlogit=dl_t, alpha=alpha)
+        _, scal, dom_s = e.forward(x, y, training=True, slot=0, domain=True, prepare=False)
         loss_s, dl_s = e.bce_logits(dom_s, 1.0)
-        _, _, dom_t = e.forward(xt, None, training=True, slot=1, domain=True)
-        loss_t, dl_t = e.bce_logits(dom_t, 0.0)
         e.backward(self.B, slot=0, with_pose=True, dlogit=dl_s, alpha=alpha)
-        e.backward(self.B, slot=1, with_pose=False, dlogit=dl_t, alpha=alpha)
+        main.wait_stream(self._s2)
+        for t_ in (dom_t, loss_t, dl_t, xt):
+            t_.record_stream(main)
+        e.update_running(self.B, slot=1)
+        e.grads.add_(self._g2)
         return torch.cat([scal, loss_s, loss_t])
 
     def _allreduce(self):
