@@ -103,10 +103,31 @@ def main():
         torch.manual_seed(2021)
         aug = StyleAugmentor.synthetic(0.5, dev, Ghiasi().state_dict(), seed=2021)   # random decoder weights (none offline)
 
+    # style augmentation one batch ahead on a side stream, as core/trainer.py's AugLookahead does for a real loader: the
+    # decoder of step i+1 is enqueued before train step i.  Every timed step still pays for exactly one coin / restyle.
+    aug_stream = torch.cuda.Stream(device=dev) if aug is not None else None
+    staged = {}
+
+    def stage(i, xs):
+        if not shared_coin(i, 2021, 0.5):
+            return xs, None
+        aug_stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(aug_stream):
+            out = aug(xs)
+            ev = torch.cuda.Event(); ev.record(aug_stream)
+        return out, ev
+
     def one_step(i, xs, ys):
-        if aug is not None and shared_coin(i, 2021, 0.5):
-            xs = aug(xs)
-        return step(xs, ys)
+        if aug is None:
+            return step(xs, ys)
+        cur = staged.pop(i, None) or stage(i, xs)
+        if os.environ.get("SPB_AUG_LOOKAHEAD", "1") != "0":
+            staged[i + 1] = stage(i + 1, xs)
+        xin, ev = cur
+        if ev is not None:
+            torch.cuda.current_stream().wait_event(ev)
+            xin.record_stream(torch.cuda.current_stream())
+        return step(xin, ys)
 
     def sync_all():
         if world > 1:

@@ -26,6 +26,56 @@ def _texture_coin(cfg, step):
     return random.random() < cfg.texture_ratio
 
 
+class AugLookahead:
+    """One-batch lookahead for the style augmentation (trainer.py:63-69 does it inline): the host-to-device copy and the
+    Ghiasi decoder of batch i+1 run on a side stream while batch i trains.  The decoder is matrix-core bound (4.7 ms per 48
+    images) and the train step a chain of latency-bound launches, so the two overlap almost for free; the augmentation
+    does not depend on the weights, so results are unchanged.  The per-batch coin is drawn in batch order."""
+
+    def __init__(self, loader, device, augmentor, coin):
+        self.loader, self.device, self.aug, self.coin = loader, device, augmentor, coin
+        self.stream = torch.cuda.Stream(device=device)
+
+    def _stage(self, idx, batch):
+        images, rest = batch[0], batch[1:]
+        restyle = self.coin(idx)                       # drawn here, in batch order
+        self.stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self.stream):
+            images = images.to(self.device, non_blocking=True)
+            rest = tuple(t.to(self.device, non_blocking=True) for t in rest)
+            if restyle:
+                images = self.aug(images)
+            ev = torch.cuda.Event()
+            ev.record(self.stream)
+        return images, rest, ev
+
+    def __len__(self):
+        return len(self.loader)
+
+    def __iter__(self):
+        it = iter(self.loader)
+        idx = 0
+        try:
+            nxt = self._stage(idx, next(it))
+        except StopIteration:
+            return
+        while nxt is not None:
+            cur = nxt
+            try:
+                batch = next(it)
+            except StopIteration:
+                batch = None
+            idx += 1
+            nxt = self._stage(idx, batch) if batch is not None else None     # enqueued BEFORE the current batch trains
+            images, rest, ev = cur
+            main = torch.cuda.current_stream()
+            main.wait_event(ev)
+            images.record_stream(main)
+            for t in rest:
+                t.record_stream(main)
+            yield (images,) + rest
+
+
 def _world():
     """(world_size, group) of the data-parallel job this process belongs to (one process per GPU); (1, None) when single"""
     if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
@@ -42,12 +92,15 @@ def train_single_epoch_krn(epoch, cfg, model, data_loader, optimizer, writer, de
     fused = isinstance(optimizer, FusedOptimizer) and scaler is None
     world, group = _world()
     n_iter = len(data_loader)
+    lookahead = styleAugmentor is not None and torch.device(device).type == "cuda"
+    if lookahead:   # trainer.py:68-69, one batch ahead on a side stream
+        data_loader = AugLookahead(data_loader, device, styleAugmentor, lambda i: _texture_coin(cfg, epoch * n_iter + i))
     for idx, (images, target) in enumerate(data_loader):
         start = time.time()
         B = images.shape[0]
         images = images.to(device, non_blocking=True)
         target = target.to(device, non_blocking=True)
-        if styleAugmentor is not None and _texture_coin(cfg, epoch * n_iter + idx):   # trainer.py:68-69
+        if styleAugmentor is not None and not lookahead and _texture_coin(cfg, epoch * n_iter + idx):   # trainer.py:68-69
             images = styleAugmentor(images)
         if fused:
             lx, ly = optimizer.train_step(images, target, world_size=world, group=group)[1:3].tolist()  # host floats per step, as the reference reports

@@ -145,3 +145,23 @@ def test_dann_generic_path_matches_fused_path(device):
         d_g = finals["generic"][1][k].double() - sd0[k].double()
         d_f = finals["fused"][1][k].double() - sd0[k].double()
         assert _rel(d_g, d_f) < 0.05, k
+
+
+def test_style_augmentation_lookahead_keeps_the_batches(device):
+    """AugLookahead (the trainer's one-batch-ahead restyling on a side stream) yields every batch once, in order, restyled
+    exactly where the coin says so, with targets untouched"""
+    import torch
+    from speedplusbaseline_amd.core.trainer import AugLookahead
+
+    class Aug:
+        def __call__(self, x):
+            return x * 0.5 + 0.25
+
+    batches = [(torch.full((2, 3, 8, 8), float(i)), torch.full((2, 2, 11), float(i))) for i in range(5)]
+    coins = [True, False, True, True, False]
+    out = list(AugLookahead(batches, device, Aug(), lambda i: coins[i]))
+    torch.cuda.synchronize()
+    assert len(out) == 5
+    for i, (x, y) in enumerate(out):
+        want = i * 0.5 + 0.25 if coins[i] else float(i)
+        assert x.is_cuda and float(x.mean()) == want and float(y.mean()) == float(i)
