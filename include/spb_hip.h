@@ -287,6 +287,14 @@ int spb_krn_prepare_weights(spb_krn_t* m, spb_stream_t stream);
  * alpha_valid=1 with a dann plan also runs the domain classifier: domain_logits [B].                           */
 int spb_krn_forward(spb_krn_ctx_t* c, const float* x_nchw, const float* target, int training, float* pred,
                     float* scalars, float* domain_logits, spb_stream_t stream);
+/* Data-parallel gradient exchange overlapped with backward (one process per GPU, RCCL).  The arena tail
+ * [spb_krn_bucket_split(m), n_params) -- inverted-residual blocks 14..17, the ConvDw extras, the head and the RevGrad domain
+ * classifier: ~90 % of the elements -- is final after the 7x7 part of the backward pass; spb_krn_backward records an event
+ * there and spb_krn_ctx_wait_bucket makes the communication stream wait on it, so that bucket's all-reduce runs beside the
+ * backward of blocks 13..1 and the stem.  The head of the arena is reduced after backward. */
+long long spb_krn_bucket_split(const spb_krn_t* m);
+int spb_krn_ctx_set_bucket(spb_krn_ctx_t* c, int on);   /* off (default): no mid-backward join, no event */
+int spb_krn_ctx_wait_bucket(spb_krn_ctx_t* c, spb_stream_t comm_stream);
 /* BatchNorm running_mean / running_var / num_batches_tracked update from the batch sums of this context's last training
  * forward (what training=1 does at the end of the forward).  DANN (dann.py:81-92) runs its source and target passes
  * concurrently on two streams; the shared buffers are still updated source first, then target, on one stream. */

@@ -141,6 +141,9 @@ SYMBOLS = {
     "spb_krn_prepare_weights": (i32, [vp, vp]),
     "spb_krn_forward": (i32, [vp, vp, vp, i32, vp, vp, vp, vp]),
     "spb_krn_update_running": (i32, [vp, vp]),
+    "spb_krn_bucket_split": (i64, [vp]),
+    "spb_krn_ctx_wait_bucket": (i32, [vp, vp]),
+    "spb_krn_ctx_set_bucket": (i32, [vp, i32]),
     "spb_krn_backward": (i32, [vp, vp, f32, i32, vp, f32, vp]),
     "spb_bce_logits": (i32, [vp, f32, i32, vp, vp, f32, vp]),
     "spb_krn_prof_enable": (i32, [vp, i32]),

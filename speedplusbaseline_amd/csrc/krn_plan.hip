@@ -26,6 +26,7 @@ struct Block { int t, cin, cout, stride, hid, Hin, Hout; bool res; PWDef E, P; D
 constexpr float kEps = 1e-5f;
 constexpr float kMomentum = 0.1f;
 constexpr int kIn = 224;
+constexpr int kSplitBlock = 14;   // first inverted-residual block of the early gradient bucket (7x7 maps from here on)
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
@@ -45,6 +46,9 @@ struct spb_krn {
   long long head_w_off = 0, head_b_off = 0, head_wc_off = 0;
   PWDef dc0; long long dc3_w_off = 0, dc3_b_off = 0;
   long long n_params = 0, n_buffers = 0, wc_elems = 0;
+  // data-parallel exchange: parameters [split_off, n_params) (blocks 14..17, extras, head, domain classifier: ~90 % of the
+  // elements) are complete after a quarter of the backward pass; BatchNorm entries [split_bn, end) belong to them
+  long long split_off = 0; int split_bn = 0;
   // bound state
   float* P = nullptr; float* G = nullptr; float* Bf = nullptr; long long* nbt = nullptr;
   char* wc = nullptr; spb_prep_entry_t* prep_d = nullptr; int n_prep = 0, n_prep_tiles = 0;
@@ -114,11 +118,15 @@ struct spb_krn_ctx {
   bool side_on = true;
   std::vector<hipEvent_t> fork_ev;
   hipEvent_t join_ev = nullptr;
+  hipEvent_t bucket_ev = nullptr;   // recorded when the gradients of [split_off, n_params) are final
+  bool bucket_recorded = false;
+  bool bucket_on = false;           // spb_krn_ctx_set_bucket: single-GPU runs skip the mid-backward join
   int n_fork = 0;
   ~spb_krn_ctx() {
     for (hipEvent_t e : fork_ev) hipEventDestroy(e);
     for (hipEvent_t e : prof_ev) hipEventDestroy(e);
     if (join_ev) hipEventDestroy(join_ev);
+    if (bucket_ev) hipEventDestroy(bucket_ev);
     if (side) hipStreamDestroy(side);
   }
 };
@@ -153,6 +161,7 @@ void build_model(spb_krn* m, int nK, bool dann) {
         b.E = m->add_pw(pre + "0.0", cin, b.hid);
         b.aE = m->add_act(H, H, b.hid, m->add_bn(pre + "0.1", b.hid), SPB_ACT_RELU6);
         idx = 1;
+        if (k == kSplitBlock) { m->split_off = b.E.w_off; m->split_bn = m->acts[b.aE].bn; }
       }
       b.D = m->add_dw(pre + std::to_string(idx) + ".0", b.hid, b.stride);
       b.aD = m->add_act(b.Hout, b.Hout, b.hid, m->add_bn(pre + std::to_string(idx) + ".1", b.hid), SPB_ACT_RELU6);
@@ -572,6 +581,7 @@ extern "C" int spb_krn_ctx_create(spb_krn_t* m, int batch, void* workspace, spb_
   // side stream + events are created here, outside any stream capture
   if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess) c->side = nullptr;
   if (hipEventCreateWithFlags(&c->join_ev, hipEventDisableTiming) != hipSuccess) { delete c; return SPB_E_STATE; }
+  if (hipEventCreateWithFlags(&c->bucket_ev, hipEventDisableTiming) != hipSuccess) { delete c; return SPB_E_STATE; }
   for (int i = 0; i < 64; ++i) {
     hipEvent_t ev;
     if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) break;
@@ -720,6 +730,7 @@ extern "C" int spb_krn_backward(spb_krn_ctx_t* c, float* grads, float gscale, in
   hipStream_t st = (hipStream_t)stream;
   Runner r(c, st);
   c->n_fork = 0;
+  c->bucket_recorded = false;
   const int dt = m->dtype;
   const int aF = m->blk[17].aP;  // feature = bn(z) of block 17's projection (no residual there)
   void* ddom = nullptr;
@@ -799,6 +810,17 @@ extern "C" int spb_krn_backward(spb_krn_ctx_t* c, float* grads, float gscale, in
     } else {
       r.dw_bwd(b.D, in, b.Hin, b.aD, atgt, nullptr, res);
     }
+    if (k == kSplitBlock && c->bucket_on) {
+      // early gradient bucket: everything from block 14 to the head (and the domain classifier) is final once the side
+      // stream's weight gradients so far have landed and the BatchNorm affine gradients of those layers are written
+      r.join_side();
+      const spb_bnupd_entry_t* tab = reinterpret_cast<const spb_bnupd_entry_t*>(c->ws + c->table_off);
+      r.tic(PC_BN_PARAM_GRADS, (double)c->stats_floats);
+      r.ok(spb_bn_param_grads(tab + m->split_bn, (int)m->bns.size() - m->split_bn, r.stats(), m->G, stream));
+      r.toc();
+      hipEventRecord(c->bucket_ev, st);
+      c->bucket_recorded = true;
+    }
   }
   // stem weight gradient (the image needs no gradient)
   {
@@ -810,12 +832,29 @@ extern "C" int spb_krn_backward(spb_krn_ctx_t* c, float* grads, float gscale, in
   r.join_side();
   r.tic(PC_BN_PARAM_GRADS, (double)c->stats_floats * 2);
   // BatchNorm affine gradients: dgamma += sum(g*xhat), dbeta += sum(g)
-  r.ok(spb_bn_param_grads(reinterpret_cast<const spb_bnupd_entry_t*>(c->ws + c->table_off), (int)m->bns.size(), r.stats(),
-                          m->G, stream));
+  r.ok(spb_bn_param_grads(reinterpret_cast<const spb_bnupd_entry_t*>(c->ws + c->table_off),
+                          c->bucket_on ? m->split_bn : (int)m->bns.size(), r.stats(), m->G, stream));
   r.toc();
   hipError_t le = hipGetLastError();
   if (le != hipSuccess && r.err == 0) r.err = (int)le;
   return r.err;
+}
+
+// ---- data-parallel gradient exchange, overlapped with backward ------------------------------------------------------
+// Element offset in the parameter / gradient arena where the early bucket starts.
+extern "C" long long spb_krn_bucket_split(const spb_krn_t* m) { return m ? m->split_off : -1; }
+// Makes `comm_stream` wait until the last spb_krn_backward on this context has finished the gradients of
+// [spb_krn_bucket_split, n_params): the caller then enqueues that bucket's all-reduce on comm_stream while the launch
+// stream continues with blocks 13..1 and the stem.
+extern "C" int spb_krn_ctx_set_bucket(spb_krn_ctx_t* c, int on) {
+  if (!c) return SPB_E_ARG;
+  c->bucket_on = on != 0; c->bucket_recorded = false;
+  return 0;
+}
+extern "C" int spb_krn_ctx_wait_bucket(spb_krn_ctx_t* c, spb_stream_t comm_stream) {
+  if (!c || !c->bucket_recorded) return SPB_E_STATE;
+  hipError_t e = hipStreamWaitEvent((hipStream_t)comm_stream, c->bucket_ev, 0);
+  return e == hipSuccess ? 0 : (int)e;
 }
 
 // ---- live per-launch timing ------------------------------------------------------------------------------------

@@ -135,6 +135,17 @@ class KrnEngine:
         self._last_x[(B, slot)] = (x, target)
         return pred, scalars, dom
 
+    def bucket_split(self):
+        """element offset where the early gradient bucket (blocks 14..17, extras, head, domain classifier) starts"""
+        return int(self.lib.spb_krn_bucket_split(self.h))
+
+    def set_bucket(self, batch, slot=0, on=True):
+        L.check(self.lib.spb_krn_ctx_set_bucket(self.context(batch, slot), 1 if on else 0), "spb_krn_ctx_set_bucket")
+
+    def wait_bucket(self, batch, slot, stream):
+        """`stream` (a torch.cuda.Stream) waits until the last backward finished the early bucket's gradients"""
+        L.check(self.lib.spb_krn_ctx_wait_bucket(self.context(batch, slot), C.c_void_p(stream.cuda_stream)), "spb_krn_ctx_wait_bucket")
+
     def prepare_weights(self):
         """refresh the compute-dtype weight copies from the f32 parameter arena (forward() does this unless prepare=False)"""
         with torch.cuda.device(self.device):

@@ -1,10 +1,12 @@
 """Data-parallel helpers: one process per GPU (torch.distributed, backend "nccl" = RCCL over xGMI on the MI355X node).
 
 The reference has no distributed code; data parallelism is this build's addition: every rank runs the
-full model on its own bs/GPU shard of the global batch, the flat f32 gradient arena is summed with ONE all-reduce
-(KRN: 22.6 MB, RevGrad: 24.2 MB -- a single bucket is already below the xGMI latency-bandwidth knee) and the 1/world
-mean is folded into the optimizer kernel's gradient multiplier.  BatchNorm statistics stay per-rank: the reference
-normalises over exactly the per-GPU batch, so this preserves its semantics at bs=48/GPU.
+full model on its own bs/GPU shard of the global batch; the flat f32 gradient arena (KRN: 22.6 MB, RevGrad: 24.2 MB) is summed
+in TWO buckets: the tail of the arena (inverted-residual blocks 14..17, extras, head: 90 % of the elements) is final after the
+7x7 part of the backward pass and is all-reduced on a communication stream while the backward of blocks 13..1 runs; the
+small head of the arena follows after backward.  The 1/world mean is folded into the optimizer kernel's gradient multiplier.
+BatchNorm statistics stay per-rank: the reference normalises over exactly the per-GPU batch, so this preserves its semantics
+at bs=48/GPU.
 """
 import torch
 import torch.distributed as dist
@@ -23,6 +25,15 @@ def allreduce_sum_(flat, group=None):
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
         dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
     return flat
+
+
+def allreduce_sum_async(flat, group=None, force=False):
+    """enqueue the in-place sum of `flat` over ranks (on the current stream's communicator); returns the work handle
+    (call .wait() before the optimizer reads the arena) or None when there is nothing to do.  force: also with a single
+    rank (exercises the stream plumbing on a one-GPU box)"""
+    if dist.is_available() and dist.is_initialized() and (force or dist.get_world_size(group) > 1):
+        return dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group, async_op=True)
+    return None
 
 
 def mean_scale(world):

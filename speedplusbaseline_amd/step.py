@@ -13,7 +13,7 @@ import os
 import torch
 
 from . import ops
-from .parallel import allreduce_sum_, mean_scale
+from .parallel import allreduce_sum_, allreduce_sum_async, mean_scale
 
 _KIND_DEFAULT_EPS = 1e-8
 
@@ -35,6 +35,15 @@ class FusedTrainStep:
         self.dann = bool(dann)
         self.dann_overlap = os.environ.get("SPB_DANN_OVERLAP", "1") != "0"   # source / target passes on two streams
         self._g2 = self._s2 = None
+        self._works = None
+        # data-parallel: the arena tail is all-reduced while blocks 13..1 are still in backward (eager mode, plain KRN)
+        mode = os.environ.get("SPB_DDP_OVERLAP", "1")      # "0": one all-reduce after backward; "force": also with one rank (tests)
+        self._force = mode == "force"
+        self._overlap = ((world_size > 1 or self._force) and not self.dann and not use_graph and mode != "0")
+        if self._overlap:
+            self._split = engine.bucket_split()
+            self._comm = torch.cuda.Stream(device=engine.device)
+            engine.set_bucket(batch, 0, True)
         dev = engine.device
         n = engine.n_params
         self.m = torch.zeros(n, dtype=torch.float32, device=dev)
@@ -70,6 +79,11 @@ class FusedTrainStep:
             _, scal, _ = e.forward(x, y, training=True, slot=0)
             e.grads.zero_()
             e.backward(self.B, slot=0)
+            if self._overlap:   # early bucket: all-reduce on the communication stream beside the rest of the backward
+                e.wait_bucket(self.B, 0, self._comm)
+                with torch.cuda.stream(self._comm):
+                    self._works = [allreduce_sum_async(e.grads[self._split:], self.group, self._force)]
+                self._works.append(allreduce_sum_async(e.grads[:self._split], self.group, self._force))   # after backward, launch stream
             return scal
         # DANN: zero_grad, source pass (pose + domain=1), target pass (domain=0), one backward of the sum (dann.py:81-95).
         # The two passes only meet in the gradient arena and the BatchNorm running statistics, and both are chains of
@@ -107,7 +121,12 @@ class FusedTrainStep:
         return torch.cat([scal, loss_s, loss_t])
 
     def _allreduce(self):
-        if self.world > 1:
+        if self._works is not None:      # issued from _fwd_bwd, overlapped with backward
+            for w in self._works:
+                if w is not None:
+                    w.wait()             # the launch stream waits for the communicator's stream
+            self._works = None
+        elif self.world > 1:
             allreduce_sum_(self.e.grads, self.group)  # RCCL sum; the 1/world mean is folded into gmul
 
     def _update(self):

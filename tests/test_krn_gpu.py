@@ -262,3 +262,53 @@ def test_revgrad_forward_and_dann_step(device):
     assert int(eng.nbt[0]) == 2
     name, shape, off, numel = eng.buffer_infos[0]
     assert relerr(eng.buffers[off: off + numel], sd[name]) < 1e-4
+
+
+def test_overlapped_gradient_exchange_plumbing_single_rank(device, monkeypatch):
+    """The data-parallel path that all-reduces the arena tail (blocks 14..17, extras, head) on a communication stream while
+    the rest of the backward runs: with ONE rank the all-reduce is the identity, so a step through that path (RCCL
+    communicator, mid-backward event, split BatchNorm-gradient launches, work.wait()) must move the parameters like a plain
+    step.  "Like": at this random-init point the BatchNorm chains cancel the gradient's common mode so strongly that the
+    order of the f32 atomics alone moves the f32 gradient by 1-2 % (relative L2) between two identical plain runs
+    (scratch/det_check.py; same with the side stream and the fused kernels switched off), so the bar is 10 % per bucket --
+    a lost, doubled or stale bucket shows up as ~100 %."""
+    import os
+    import socket
+    import torch.distributed as dist
+    from speedplusbaseline_amd.engine import KrnEngine
+    from speedplusbaseline_amd.step import FusedTrainStep
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=device)
+    try:
+        B = 8
+        g = torch.Generator().manual_seed(3)
+        x = torch.rand(B, 3, 224, 224, generator=g).to(device); y = torch.rand(B, 2, 11, generator=g).to(device)
+        outs = []
+        for mode in ("0", "force"):
+            monkeypatch.setenv("SPB_DDP_OVERLAP", mode)
+            eng = KrnEngine(11).attach(device, "fp32")
+            sd = O.init_state(11)
+            for info in eng.param_infos:
+                eng.param_view(info).copy_(sd[info[0]].to(device))
+            for name, shape, off, numel in eng.buffer_infos:
+                eng.buffers[off: off + numel].copy_(sd[name].flatten().to(device))
+            # SGD: the parameter change is linear in the gradient (AdamW's sign-like first steps would amplify the
+            # run-to-run noise of the float atomics in the weight-gradient kernels into +-lr flips)
+            ts = FusedTrainStep(eng, B, kind="sgd", lr=0.05, momentum=0.9, weight_decay=1e-4, max_norm=1.0,
+                                dist_group=dist.group.WORLD, world_size=1)
+            assert ts._overlap == (mode == "force")
+            p_init = eng.params.clone()
+            scal = ts(x, y)
+            torch.cuda.synchronize()
+            outs.append((eng.params - p_init, scal.clone(), eng.bucket_split()))
+        (d0, s0, split), (d1, s1, _) = outs
+        assert 0 < split < d0.numel() and (d0.numel() - split) > 0.8 * d0.numel()     # the early bucket is most of the arena
+        assert float(d0.norm()) > 0
+        for lo, hi in ((0, split), (split, d0.numel())):                              # both buckets moved identically
+            assert float(d1[lo:hi].norm()) > 0
+            assert float((d0[lo:hi] - d1[lo:hi]).norm() / d0[lo:hi].norm()) < 0.1
+        assert float((s0 - s1).abs().max()) < 1e-5 * float(s0.abs().max())       # the forward is reproducible
+    finally:
+        dist.destroy_process_group()

@@ -111,7 +111,12 @@ def _dp_worker(rank, world, port, out):
     parallel.broadcast_([p], 0)
     coins = [parallel.shared_coin(s, 2021, 0.5) for s in range(16)]
     from speedplusbaseline_amd.core.trainer import _world       # what the KRN / SPN trainers hand to their optimizers
-    out[rank] = (lo, hi, g.tolist(), p.tolist(), coins, _world()[0])
+    # the two-bucket exchange of FusedTrainStep: arena tail first (issued mid-backward on the GPU), head after backward
+    arena = torch.arange(12, dtype=torch.float32) * (rank + 1)
+    works = [parallel.allreduce_sum_async(arena[7:]), parallel.allreduce_sum_async(arena[:7])]
+    for w in works:
+        w.wait()
+    out[rank] = (lo, hi, g.tolist(), p.tolist(), coins, _world()[0], arena.tolist())
     dist.destroy_process_group()
 
 
@@ -126,3 +131,4 @@ def test_data_parallel_host_logic_two_gloo_ranks():
     assert out[0][3] == [0.0] * 4 and out[1][3] == [0.0] * 4                  # rank 0's parameters everywhere
     assert out[0][4] == out[1][4] and 2 < sum(out[0][4]) < 14                 # rank-synchronous style-augmentation coin
     assert out[0][5] == 2 and out[1][5] == 2                                  # trainers see the data-parallel job
+    assert out[0][6] == [3.0 * i for i in range(12)] and out[1][6] == out[0][6]  # both buckets summed in place
