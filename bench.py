@@ -27,6 +27,19 @@ HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s a
 MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}
 
 
+def _device_index(local_rank):
+    # SPB_ONE_DEVICE=1 (test rigs with one GPU): every rank on device 0, with SPB_DIST_BACKEND=gloo for the collectives
+    return 0 if os.environ.get("SPB_ONE_DEVICE") == "1" else local_rank
+
+
+def _init_dist(dev):
+    backend = os.environ.get("SPB_DIST_BACKEND", "nccl")       # "nccl" is RCCL on ROCm
+    if backend == "nccl":
+        torch.distributed.init_process_group("nccl", device_id=dev)
+    else:
+        torch.distributed.init_process_group(backend)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -65,12 +78,12 @@ def main():
         raise SystemExit("--gpus (%d) != WORLD_SIZE (%d)" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; there is no CPU path for the product")
-    dev = torch.device("cuda", local)
+    dev = torch.device("cuda", _device_index(local))
     torch.cuda.set_device(dev)
     group = None
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.distributed.init_process_group("nccl", device_id=dev)
+        _init_dist(dev)
         group = torch.distributed.group.WORLD
 
     # A/B switches for experiments (defaults are the product configuration)
@@ -266,12 +279,12 @@ def bench_dann(args):
         raise SystemExit("--gpus (%d) != WORLD_SIZE (%d): launch with python -m torch.distributed.run --nproc-per-node N" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; there is no CPU path for the product")
-    dev = torch.device("cuda", local)
+    dev = torch.device("cuda", _device_index(local))
     torch.cuda.set_device(dev)
     group = None
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.distributed.init_process_group("nccl", device_id=dev)
+        _init_dist(dev)
         group = torch.distributed.group.WORLD
     B = args.batch
     eng = KrnEngine(11, dann=True).attach(dev, args.precision)
@@ -346,12 +359,12 @@ def bench_spn(args):
         raise SystemExit("--gpus (%d) != WORLD_SIZE (%d): launch with python -m torch.distributed.run --nproc-per-node N" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; there is no CPU path for the product")
-    dev = torch.device("cuda", local)
+    dev = torch.device("cuda", _device_index(local))
     torch.cuda.set_device(dev)
     group = None
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.distributed.init_process_group("nccl", device_id=dev)
+        _init_dist(dev)
         group = torch.distributed.group.WORLD
     from speedplusbaseline_amd import _lib as _L
     if os.environ.get("SPB_PLAIN_DMA") is not None:

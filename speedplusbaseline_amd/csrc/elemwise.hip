@@ -197,8 +197,13 @@ __global__ __launch_bounds__(256) void weight_prep_kernel(const spb_prep_entry_t
 }
 
 // ------------------------------------------------------------------------------------------------ optimiser
-__global__ __launch_bounds__(256) void grad_sqnorm_kernel(const float* __restrict__ g, long long n, float* out) {
+// Deterministic: every block writes its partial sum, the last block to arrive adds them in block order.  (An atomicAdd per
+// block made the clip coefficient differ in the last bit between runs -- and between the ranks of a data-parallel job, whose
+// replicas then drift apart by an ulp per step.)
+__global__ __launch_bounds__(256) void grad_sqnorm_kernel(const float* __restrict__ g, long long n, float* out, float* partial,
+                                                          unsigned* counter) {
   __shared__ float red[4];
+  __shared__ bool last;
   float s = 0.f;
   const long long n4 = n >> 2;
   const float4* g4 = reinterpret_cast<const float4*>(g);
@@ -210,7 +215,20 @@ __global__ __launch_bounds__(256) void grad_sqnorm_kernel(const float* __restric
   s = wave_sum(s);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
   __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
+  if (threadIdx.x == 0) {
+    partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+    __threadfence();
+    last = atomicAdd(counter, 1u) == gridDim.x - 1;
+  }
+  __syncthreads();
+  if (!last) return;
+  __threadfence();
+  float t = 0.f;
+  for (unsigned i = threadIdx.x; i < gridDim.x; i += 256) t += __builtin_nontemporal_load(partial + i);   // fixed order per lane
+  t = wave_sum(t);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = t;
+  __syncthreads();
+  if (threadIdx.x == 0) { *out = red[0] + red[1] + red[2] + red[3]; *counter = 0; }
 }
 
 // one element of the update; m / v are the moment values (read and written back by the caller when the kind uses them)
@@ -399,9 +417,14 @@ extern "C" int spb_weight_prep(int dtype, const spb_prep_entry_t* tab, int n_ent
 
 extern "C" int spb_grad_sqnorm(const float* grads, long long n, float* out, spb_stream_t stream) {
   if (!grads || !out || n <= 0) return SPB_E_ARG;
-  hipError_t e = hipMemsetAsync(out, 0, sizeof(float), (hipStream_t)stream);
-  if (e != hipSuccess) return (int)e;
-  hipLaunchKernelGGL(grad_sqnorm_kernel, dim3(elem_grid((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, grads, n, out);
+  // library-owned scratch: <= 2048 block partials + the arrival counter (zero between launches; one optimizer per process)
+  static float* scratch = nullptr;
+  if (!scratch) {
+    if (hipMalloc(&scratch, 2049 * sizeof(float)) != hipSuccess) return SPB_E_STATE;
+    if (hipMemset(scratch, 0, 2049 * sizeof(float)) != hipSuccess) return SPB_E_STATE;
+  }
+  hipLaunchKernelGGL(grad_sqnorm_kernel, dim3(elem_grid((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, grads, n, out, scratch,
+                     reinterpret_cast<unsigned*>(scratch + 2048));
   SPB_CHECK_LAUNCH();
   return 0;
 }

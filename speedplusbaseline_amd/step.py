@@ -49,6 +49,7 @@ class FusedTrainStep:
         self.m = torch.zeros(n, dtype=torch.float32, device=dev)
         self.v = torch.zeros(n, dtype=torch.float32, device=dev)
         self.sq = torch.zeros(1, dtype=torch.float32, device=dev)
+        ops.grad_sqnorm(engine.grads, self.sq)     # first call allocates the library's reduction scratch (never inside a graph capture)
         self.gmul = torch.full((1,), mean_scale(self.world), dtype=torch.float32, device=dev) if self.world > 1 else None
         self.hyper = torch.zeros(3, dtype=torch.float32, device=dev)
         self.hyper_host = torch.zeros(3, dtype=torch.float32).pin_memory()
