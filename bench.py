@@ -93,6 +93,8 @@ def main():
                     ("SPB_PLAIN_DMA", "spb_debug_set_gemm_plain_dma")):
         if os.environ.get(env) is not None:
             getattr(_L.lib(), fn)(int(os.environ[env]))
+    if os.environ.get("SPB_STEM_GRID"):      # "fwd,wgrad" workgroup caps
+        _L.lib().spb_debug_set_stem_grid(*[int(v) for v in os.environ["SPB_STEM_GRID"].split(",")])
 
     B = args.batch
     eng = KrnEngine(11).attach(dev, args.precision)

@@ -156,10 +156,14 @@ template <typename T>
 __global__ __launch_bounds__(256) void weight_prep_kernel(const spb_prep_entry_t* tab, int n_entries,
                                                           const float* params, T* wc) {
   __shared__ float tile[32][33];
-  int ei = 0;
-  for (int i = 1; i < n_entries; ++i)
-    if ((int)blockIdx.x >= tab[i].tile0) ei = i;
-  const spb_prep_entry_t e = tab[ei];
+  // entry owning this tile: last i with tab[i].tile0 <= blockIdx.x (tile0 ascending).  Binary search: the linear scan this
+  // replaces cost every one of the ~10 000 blocks ~110 serial L2 loads (60 us for 45 MB of copies)
+  int lo = 0, hi = n_entries - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if ((int)blockIdx.x >= tab[mid].tile0) lo = mid; else hi = mid - 1;
+  }
+  const spb_prep_entry_t e = tab[lo];
   int tl = blockIdx.x - e.tile0;
   int rows = e.rows, cols = e.cols;
   const float* src = params + e.src_off;
@@ -204,13 +208,22 @@ __global__ __launch_bounds__(256) void grad_sqnorm_kernel(const float* __restric
                                                           unsigned* counter) {
   __shared__ float red[4];
   __shared__ bool last;
-  float s = 0.f;
+  // block b owns the contiguous run of float4 [b*per, (b+1)*per): independent 16-byte loads, 4 in flight per thread
   const long long n4 = n >> 2;
+  const long long per = (n4 + gridDim.x - 1) / gridDim.x;
+  const long long lo = (long long)blockIdx.x * per, hi = lo + per < n4 ? lo + per : n4;
   const float4* g4 = reinterpret_cast<const float4*>(g);
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
-    const float4 v = g4[i];
-    s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  long long i = lo + threadIdx.x;
+  for (; i + 768 < hi; i += 1024) {
+    const float4 a = g4[i], b = g4[i + 256], c = g4[i + 512], d = g4[i + 768];
+    s0 += a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w;
+    s1 += b.x * b.x + b.y * b.y + b.z * b.z + b.w * b.w;
+    s2 += c.x * c.x + c.y * c.y + c.z * c.z + c.w * c.w;
+    s3 += d.x * d.x + d.y * d.y + d.z * d.z + d.w * d.w;
   }
+  for (; i < hi; i += 256) { const float4 a = g4[i]; s0 += a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w; }
+  float s = (s0 + s1) + (s2 + s3);
   if (blockIdx.x == 0 && threadIdx.x < (n & 3)) { const float v = g[(n4 << 2) + threadIdx.x]; s += v * v; }
   s = wave_sum(s);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
@@ -224,7 +237,7 @@ __global__ __launch_bounds__(256) void grad_sqnorm_kernel(const float* __restric
   if (!last) return;
   __threadfence();
   float t = 0.f;
-  for (unsigned i = threadIdx.x; i < gridDim.x; i += 256) t += __builtin_nontemporal_load(partial + i);   // fixed order per lane
+  for (unsigned j = threadIdx.x; j < gridDim.x; j += 256) t += __builtin_nontemporal_load(partial + j);   // fixed order per lane
   t = wave_sum(t);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = t;
   __syncthreads();
@@ -423,7 +436,9 @@ extern "C" int spb_grad_sqnorm(const float* grads, long long n, float* out, spb_
     if (hipMalloc(&scratch, 2049 * sizeof(float)) != hipSuccess) return SPB_E_STATE;
     if (hipMemset(scratch, 0, 2049 * sizeof(float)) != hipSuccess) return SPB_E_STATE;
   }
-  hipLaunchKernelGGL(grad_sqnorm_kernel, dim3(elem_grid((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, grads, n, out, scratch,
+  const long long n4 = n >> 2;
+  const int nblk = (int)(n4 >= 512 * 1024 ? 512 : (n4 + 1023) / 1024 > 0 ? (n4 + 1023) / 1024 : 1);
+  hipLaunchKernelGGL(grad_sqnorm_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, grads, n, out, scratch,
                      reinterpret_cast<unsigned*>(scratch + 2048));
   SPB_CHECK_LAUNCH();
   return 0;
