@@ -422,6 +422,7 @@ int spb_spn_flatten(const void* P, void* Fm, void* FT, int B, int HW, int C, spb
 int spb_spn_unflatten_grad(float* accT, void* Gp, int B, int HW, int C, spb_stream_t stream);
 
 /* debug / test helpers */
+int spb_debug_set_dw_xcd(int on); /* depthwise row kernels: channel quads of one task range on one XCD (1, default) or quad-major ids */
 int spb_debug_set_stem_grid(int fwd, int wgrad); /* workgroup caps of the stem forward / weight-gradient launches (A/B) */
 int spb_debug_set_gemm_plain_dma(int on); /* pro_mode 0 bf16 GEMMs: LDS-DMA ring kernel (1, default) or the register-prefetch kernel */
 int spb_debug_set_optim(int vec, int per_thread, int nontemporal); /* optimizer launch shape A/B: lanes of 1|4 floats, 1|2|4 per thread, nt accesses */

@@ -169,6 +169,7 @@ SYMBOLS = {
     "spb_softce": (i32, [i32, vp, vp, vp, vp, i32, i32, i32, f32, vp]),
     "spb_colsum": (i32, [i32, vp, vp, i64, i32, vp]),
     "spb_debug_set_optim": (i32, [i32, i32, i32]),
+    "spb_debug_set_dw_xcd": (i32, [i32]),
     "spb_debug_set_stem_grid": (i32, [i32, i32]),
     "spb_debug_set_gemm_plain_dma": (i32, [i32]),
     "spb_spn_pack_conv": (i32, [i32, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),

@@ -64,6 +64,7 @@ struct Geo {
   int E;        // stream elements per task (R + halo)
   int nseg, nstrip, ntasks;
   int nb;       // blocks per channel quad
+  int xcd;      // 1: blocks of one task range (bq) and ALL channel quads sit on one XCD (nb % 8 == 0)
 };
 
 // wave-uniform position in the stream of (task, element) pairs
@@ -144,7 +145,16 @@ __global__ __launch_bounds__(256, 2) void dwr_fwd_kernel(const spb_dw_args_t a, 
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int C = a.C, H = a.H, W = a.W, ncg = C >> 3;
   const int OH = (H - 1) / ST + 1, OW = (W - 1) / ST + 1;
-  const int quad = blockIdx.x / g.nb, bq = blockIdx.x % g.nb;
+  // A wave reads / writes 64 contiguous bytes per pixel (4 channel groups) = HALF a 128-byte L2 line; the other half belongs
+  // to the neighbouring channel quad.  With quad-major block ids the two halves were fetched by workgroups on different XCDs
+  // (different L2s): rocprofv3 FETCH_SIZE / WRITE_SIZE showed 2.1x the algorithmic bytes.  Here the dispatcher's round-robin
+  // (block b -> XCD b % 8) is undone so that the workgroups of one task range and all channel quads share an XCD and start
+  // together: the second half of every line is an L2 hit.
+  int quad, bq;
+  if (g.xcd) {
+    const int nquads = gridDim.x / g.nb, x = blockIdx.x & 7, j = blockIdx.x >> 3;
+    quad = j % nquads; bq = (j / nquads) * 8 + x;
+  } else { quad = blockIdx.x / g.nb; bq = blockIdx.x % g.nb; }
   const int cgi = quad * 4 + row;
   const bool cgok = cgi < ncg;
   const int c0 = (cgok ? cgi : ncg - 1) * 8;
@@ -301,7 +311,16 @@ __global__ __launch_bounds__(256, 2) void dwr_bwd_kernel(const spb_dw_args_t a, 
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int C = a.C, H = a.H, W = a.W, ncg = C >> 3;
   const int OH = (H - 1) / ST + 1, OW = (W - 1) / ST + 1;
-  const int quad = blockIdx.x / g.nb, bq = blockIdx.x % g.nb;
+  // A wave reads / writes 64 contiguous bytes per pixel (4 channel groups) = HALF a 128-byte L2 line; the other half belongs
+  // to the neighbouring channel quad.  With quad-major block ids the two halves were fetched by workgroups on different XCDs
+  // (different L2s): rocprofv3 FETCH_SIZE / WRITE_SIZE showed 2.1x the algorithmic bytes.  Here the dispatcher's round-robin
+  // (block b -> XCD b % 8) is undone so that the workgroups of one task range and all channel quads share an XCD and start
+  // together: the second half of every line is an L2 hit.
+  int quad, bq;
+  if (g.xcd) {
+    const int nquads = gridDim.x / g.nb, x = blockIdx.x & 7, j = blockIdx.x >> 3;
+    quad = j % nquads; bq = (j / nquads) * 8 + x;
+  } else { quad = blockIdx.x / g.nb; bq = blockIdx.x % g.nb; }
   const int cgi = quad * 4 + row;
   const bool cgok = cgi < ncg;
   const int c0 = (cgok ? cgi : ncg - 1) * 8;
@@ -527,6 +546,7 @@ __global__ __launch_bounds__(256, 2) void dwr_bwd_kernel(const spb_dw_args_t a, 
 // Task shape.  ~2 blocks per CU; rows per task R as long as possible (2/R of the rows are re-read as halo, 1/R for the
 // stride-2 backward) while the tasks still split evenly over the waves of a channel quad.
 int g_rows_override = 0;
+int g_xcd_pair = 1;
 int g_blocks_override = 0;
 Geo make_geo(int B, int C, int lane_rows, int lane_cols, int NP, int halo, int target_blocks) {
   Geo g;
@@ -537,6 +557,8 @@ Geo make_geo(int B, int C, int lane_rows, int lane_cols, int NP, int halo, int t
   const long long per_seg = (long long)B * g.nstrip;
   if ((long long)g.nb * 4 > per_seg * lane_rows) g.nb = (int)((per_seg * lane_rows + 3) / 4);
   if (g.nb < 1) g.nb = 1;
+  g.xcd = 0;
+  if (g_xcd_pair && g.nb >= 8 && nquads > 1) { g.nb &= ~7; g.xcd = 1; }
   const int nw = g.nb * 4;
   int bestR = lane_rows; double best = 1e30;
   for (int R = 1; R <= lane_rows; ++R) {
@@ -566,6 +588,7 @@ void allow_lds(K kernel, size_t bytes) {
 }  // namespace
 
 // rows > 0: rows per task; rows < 0: -rows = target block count (experiments)
+extern "C" int spb_debug_set_dw_xcd(int on) { g_xcd_pair = on; return 0; }
 extern "C" int spb_debug_set_dw_rows(int rows) { if (rows >= 0) g_rows_override = rows; else g_blocks_override = -rows; return 0; }
 
 int spb_dwr_fwd(int dtype, const spb_dw_args_t* a, hipStream_t s) {
