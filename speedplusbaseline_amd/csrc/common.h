@@ -174,8 +174,8 @@ __device__ __forceinline__ float wave_sum(float v) {
 // XCD-aware remap of a linear workgroup id: the dispatcher places block b on XCD b%8, so give
 // each XCD a contiguous chunk of the logical id space (neighbouring tiles then share one L2).
 __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
-  if (nblk & 7) return bid;
-  return (bid & 7) * (nblk >> 3) + (bid >> 3);
+  const int q = nblk >> 3, r = nblk & 7, x = bid & 7;      // XCD x runs blocks x, x+8, ...: q of them, one more if x < r
+  return x * q + (x < r ? x : r) + (bid >> 3);
 }
 
 static inline int spb_ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }

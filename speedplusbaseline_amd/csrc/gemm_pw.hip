@@ -684,7 +684,10 @@ __global__ __launch_bounds__(256) void pw_wgrad_kernel(const spb_wgrad_args_t g,
 
   const int M = g.M, K = g.K, N = g.N;
   const int NT = (N + WT - 1) / WT, KT = (K + WT - 1) / WT;
-  const int tile = blockIdx.x % (NT * KT), split = blockIdx.x / (NT * KT);
+  // the NT*KT output tiles of one row split read the same rows of G and X: keep them on one XCD (one L2), back to back
+  // (rocprofv3 FETCH_SIZE showed 3x the algorithmic bytes with the tiles of a split spread over the 8 XCDs)
+  const int lbid = xcd_remap(blockIdx.x, gridDim.x);
+  const int tile = lbid % (NT * KT), split = lbid / (NT * KT);
   const int n0 = (tile / KT) * WT, k0 = (tile % KT) * WT;
   const int mbeg = split * rows_per_split;
   const int mend = min(M, mbeg + rows_per_split);
