@@ -421,6 +421,30 @@ int spb_spn_flatten(const void* P, void* Fm, void* FT, int B, int HW, int C, spb
 /* accT [C*HW][MP] (both heads' fc6 / fc9 input gradients summed) -> NHWC bf16 gradient of pool5's output; accT zeroed */
 int spb_spn_unflatten_grad(float* accT, void* Gp, int B, int HW, int C, spb_stream_t stream);
 
+/* ---- GPU input pipeline: resize of the host-cropped region of interest + ToTensor + augmentations for a
+ * whole batch.  Replaces, per sample, T.resized_crop (torchvision 0.9.0 on a PIL image = crop + Image.resize(BILINEAR)),
+ * T.to_tensor, Rotate / Flip / BrightnessContrast / GaussianNoise of src/datasets/transforms.py:38-196 as composed by
+ * build_transforms (transforms.py:217-244) and called from Park2019KRNDataset.__getitem__ (Park2019KRNDataset.py:81-109).
+ * Bit-exact against Pillow's Resample.c arithmetic and the reference's float32 tensor ops for given random draws; the draws
+ * themselves (crop jitter, coins, angle, a, b, noise) are the host's (speedplusbaseline_amd/transforms.py). */
+typedef struct spb_preproc_args {
+  const void* src;      /* packed uint8 crops: image b starts at byte table[b].off, rows of w pixels, C interleaved channels */
+  const int* table;     /* device [B][8] int32: off_lo, off_hi, h, w, rot (quarter turns counter-clockwise 0..3),
+                           flip (0 none, 1 horizontal, 2 vertical), flags (1 brightness/contrast, 2 noise), 0 */
+  const float* ftable;  /* device [B][2]: a, b of clamp(a*x + b, 0, 1) */
+  const float* noise;   /* device [B][3][S][S] standard-normal draws, read where flag 2 is set; NULL if no image has it */
+  float* out;           /* [B][3][S][S] float32 in [0, 1] */
+  int* bounds;          /* workspace [B][2][S][2] int32 */
+  int* coeffs;          /* workspace [B][2][S][spb_preproc_max_taps()] int32 */
+  void* tmp;            /* workspace [B][max_h][S][C] bytes (horizontal pass) */
+  int B, S, C;          /* C = 1 (grey frame, replicated to 3 bands like convert('RGB')) or 3 */
+  int max_h;            /* largest crop height in the batch */
+  int flags_any;        /* OR of the per-image flags */
+  float noise_std;      /* GaussianNoise.std = 25/255 (transforms.py:100) */
+} spb_preproc_args_t;
+int spb_preproc_max_taps(void);   /* crops larger than (taps-1)/2 x S per side need more filter taps than the kernels hold */
+int spb_preproc_batch(const spb_preproc_args_t* a, spb_stream_t stream);
+
 /* debug / test helpers */
 int spb_debug_set_dw_xcd(int on); /* depthwise row kernels: channel quads of one task range on one XCD (1, default) or quad-major ids */
 int spb_debug_set_stem_grid(int fwd, int wgrad); /* workgroup caps of the stem forward / weight-gradient launches (A/B) */

@@ -91,6 +91,11 @@ class OptimArgs(C.Structure):
                 ("first_step", i32), ("shadow_bf16", vp)]
 
 
+class PreprocArgs(C.Structure):
+    _fields_ = [("src", vp), ("table", vp), ("ftable", vp), ("noise", vp), ("out", vp), ("bounds", vp), ("coeffs", vp), ("tmp", vp),
+                ("B", i32), ("S", i32), ("C", i32), ("max_h", i32), ("flags_any", i32), ("noise_std", f32)]
+
+
 class FcEpiArgs(C.Structure):
     _fields_ = [("accT", vp), ("src", vp), ("bias", vp), ("H", vp), ("Y", vp), ("YT", vp), ("mask", vp), ("db", vp),
                 ("M", i32), ("F", i32), ("mode", i32), ("relu", i32), ("p", f32), ("scale", f32), ("seed", C.c_ulonglong),
@@ -168,6 +173,8 @@ SYMBOLS = {
     "spb_dropout": (i32, [i32, vp, vp, i64, f32, C.c_ulonglong, i32, vp]),
     "spb_softce": (i32, [i32, vp, vp, vp, vp, i32, i32, i32, f32, vp]),
     "spb_colsum": (i32, [i32, vp, vp, i64, i32, vp]),
+    "spb_preproc_max_taps": (i32, []),
+    "spb_preproc_batch": (i32, [C.POINTER(PreprocArgs), vp]),
     "spb_debug_set_optim": (i32, [i32, i32, i32]),
     "spb_debug_set_dw_xcd": (i32, [i32]),
     "spb_debug_set_stem_grid": (i32, [i32, i32]),

@@ -1,0 +1,90 @@
+"""GPU: the batched input pipeline (speedplusbaseline_amd.transforms + csrc/preproc.hip) -- bit-exact against the reference's
+golden outputs, against Pillow at the real frame / input sizes, and against the oracle for every augmentation."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import preproc_oracle as P
+from speedplusbaseline_amd.transforms import build_transforms
+
+pytestmark = pytest.mark.gpu
+GOLD = np.load(os.path.join(os.path.dirname(__file__), "golden", "preproc_golden.npz"), allow_pickle=False)
+
+
+def _case(i):
+    model, is_train, seed, fh, fw, fseed = [int(v) for v in GOLD["case%d_meta" % i]]
+    return ("krn", "spn")[model], bool(is_train), seed, P.synth_frame(fh, fw, fseed), float(GOLD["case%d_p" % i])
+
+
+@pytest.mark.parametrize("i", range(int(GOLD["n"])))
+def test_golden_cases_bit_exact(device, i):
+    """one-sample batches with the reference's seed: same crop box, same coins, same pixels (float32 equality)"""
+    model, is_train, seed, frame, p = _case(i)
+    t = build_transforms(model, (int(GOLD["S"]),) * 2, p_aug=p, is_train=is_train, device=device, device_noise=False)
+    torch.manual_seed(seed)
+    img, box, k = t([frame], [GOLD["case%d_bbox" % i]], [GOLD["case%d_kp" % i].copy()])
+    torch.cuda.synchronize()
+    assert torch.equal(img[0].cpu(), torch.from_numpy(GOLD["case%d_image" % i]))
+    assert np.array_equal(box[0].numpy(), GOLD["case%d_obox" % i])
+    assert np.array_equal(k[0].numpy(), GOLD["case%d_okp" % i])
+
+
+def test_batch_of_full_size_frames_matches_pillow_and_oracle(device):
+    """1920x1200 frames (SPEED+), 224x224 input, a ragged batch of 12 regions of interest incl. grey single-channel frames:
+    every sample equals the oracle run with the same generator state (Pillow resize + the reference's tensor ops)"""
+    B, S = 12, 224
+    frames = [P.synth_frame(1200, 1920, 50 + i) for i in range(3)]
+    rng = np.random.default_rng(5)
+    fr, boxes, kps = [], [], []
+    for i in range(B):
+        f = frames[i % 3]
+        cx, cy, half = rng.uniform(500, 1400), rng.uniform(350, 850), rng.uniform(60, 420)
+        boxes.append(np.array([cx - half, cx + half, cy - half * 0.8, cy + half * 0.8], dtype=np.float32))
+        kps.append(rng.uniform([[cx - half], [cy - half]], [[cx + half], [cy + half]], (2, 11)).astype(np.float32))
+        fr.append(f)
+    t = build_transforms("krn", (S, S), p_aug=0.6, is_train=True, device=device, device_noise=False)
+    torch.manual_seed(77)
+    img, box, k = t(fr, boxes, [kp.copy() for kp in kps])
+    torch.cuda.synchronize()
+    torch.manual_seed(77)
+    seen = set()
+    for i in range(B):
+        oi, ob, ok, rec = P.krn_sample(fr[i], boxes[i], kps[i].copy(), S, 0.6, True)
+        seen.add((rec["rot"], rec["flip"], rec["bc"] is not None, rec["noise"] is not None))
+        assert torch.equal(img[i].cpu(), oi), i
+        assert torch.equal(box[i], ob) and torch.equal(k[i], ok), i
+    assert len(seen) >= 6          # the batch exercised a mix of augmentations
+    # single-channel frames take the C = 1 path and come out as three equal bands, like convert('RGB')
+    torch.manual_seed(78)
+    g1, _, _ = t([f[:, :, 0] for f in fr[:4]], boxes[:4], [kp.copy() for kp in kps[:4]])
+    torch.manual_seed(78)
+    g3, _, _ = t(fr[:4], boxes[:4], [kp.copy() for kp in kps[:4]])
+    torch.cuda.synchronize()
+    assert torch.equal(g1, g3)
+
+
+def test_eval_and_spn_modes_and_device_noise(device):
+    S = 224
+    f = P.synth_frame(600, 800, 9)
+    bbox = np.array([200.0, 520.0, 150.0, 430.0], dtype=np.float32)
+    te = build_transforms("krn", (S, S), is_train=False, device=device)
+    img, box, k = te([f], [bbox], [np.zeros((2, 11), dtype=np.float32)])
+    b = P.random_crop_box(bbox, 800, 600, False, None)
+    want = P.to_tensor(P.resize_pil(np.ascontiguousarray(f[b[2]:b[3], b[0]:b[1]]), S, S))
+    assert torch.equal(img[0].cpu(), want) and tuple(int(v) for v in box[0]) == b
+    ts = build_transforms("spn", (227, 227), device=device)
+    img, box, _ = ts([f], [bbox])
+    b = P.resize_crop_box(bbox, 800, 600)
+    want = P.to_tensor(P.resize_pil(np.ascontiguousarray(f[b[2]:b[3], b[0]:b[1]]), 227, 227))
+    assert torch.equal(img[0].cpu(), want) and np.array_equal(box[0].numpy(), bbox)
+    # production setting: the noise is drawn on the GPU -- same statistics (std 25/255 before clamping), different stream
+    tn = build_transforms("krn", (S, S), p_aug=1.0, is_train=True, device=device, device_noise=True)
+    torch.manual_seed(3)
+    a, _, _ = tn([f] * 8, [bbox] * 8, [np.zeros((2, 11), dtype=np.float32)] * 8)
+    assert a.shape == (8, 3, S, S) and float(a.min()) >= 0.0 and float(a.max()) <= 1.0
+    with pytest.raises(ValueError):
+        te([P.synth_frame(2700, 2700, 1)], [np.array([0.0, 2700.0, 0.0, 2700.0], dtype=np.float32)], [np.zeros((2, 11), dtype=np.float32)])
+    with pytest.raises(RuntimeError):
+        build_transforms("krn", (S, S), device="cpu")
