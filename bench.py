@@ -18,6 +18,7 @@ import os
 import sys
 import time
 
+import numpy as np
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -50,7 +51,7 @@ def main():
     ap.add_argument("--graph", action="store_true", help="replay a captured hipGraph instead of enqueuing the launches "
                     "eagerly (eager + side-stream weight gradients is the faster, default mode)")
     ap.add_argument("--no-graph", action="store_true", help=argparse.SUPPRESS)  # old spelling of the default
-    ap.add_argument("--model", default="krn", choices=["krn", "spn", "dann"], help="krn: the headline benchmark (BASELINE configs[1]); "
+    ap.add_argument("--model", default="krn", choices=["krn", "spn", "dann", "preproc"], help="krn: the headline benchmark (BASELINE configs[1]); "
                     "spn: Spacecraft Pose Network train step, 227x227, bs=32, 5000 classes (configs[5] flavour); "
                     "dann: RevGrad domain-adversarial step, source + target batch (configs[3] flavour; --batch 16 is the README recipe)")
     ap.add_argument("--styleaug", action="store_true", help="BASELINE configs[4] flavour: restyle the batch with the Ghiasi "
@@ -64,6 +65,8 @@ def main():
         return bench_spn(args)
     if args.model == "dann":
         return bench_dann(args)
+    if args.model == "preproc":
+        return bench_preproc(args)
     from speedplusbaseline_amd.engine import KrnEngine
     from speedplusbaseline_amd.step import FusedTrainStep
     from oracle import krn_oracle as O  # checker / cpu_baseline leg only
@@ -266,6 +269,72 @@ def main():
         print(json.dumps(out))
     if world > 1:
         torch.distributed.destroy_process_group()
+
+
+def bench_preproc(args):
+    """GPU input pipeline: bs=48 regions of interest cut from 1920x1200 grey frames -> Pillow-exact bilinear
+    resize to 224x224, ToTensor, rotate / flip / brightness-contrast / noise (p = 0.5 each), crops resident in HBM."""
+    from speedplusbaseline_amd.transforms import build_transforms
+    from oracle import preproc_oracle as P   # synthetic frames; cpu_baseline leg
+    dev = torch.device("cuda", 0)
+    B, S = args.batch, 224
+    frames = [P.synth_frame(1200, 1920, 40 + i)[:, :, 0] for i in range(4)]          # grey, like SPEED+
+    rng = np.random.default_rng(2021)
+    fr, boxes, kps = [], [], []
+    for i in range(B):
+        cx, cy, half = rng.uniform(600, 1300), rng.uniform(400, 800), rng.uniform(120, 380)
+        boxes.append(np.array([cx - half, cx + half, cy - half, cy + half], dtype=np.float32))
+        kps.append(rng.uniform(0, 1, (2, 11)).astype(np.float32))
+        fr.append(frames[i % 4])
+    t = build_transforms("krn", (S, S), p_aug=0.5, is_train=True, device=dev, device_noise=True)
+    torch.manual_seed(2021)
+    a, out, _, _ = t.stage(fr, boxes, kps)
+    for _ in range(args.warmup):
+        t.launch(a)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(args.steps):
+        t.launch(a)
+    e1.record()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    us = e0.elapsed_time(e1) / args.steps * 1e3
+    # algorithmic bytes per batch: crops read once, uint8 intermediate written + read once, float32 output written, noise read
+    tab_h = [int(round(float(b[3] - b[2]) * 1.25)) for b in boxes]
+    alg = a.src_bytes + 2 * sum(min(h, 1200) * S for h in tab_h) + B * 3 * S * S * 4 + (B // 2) * 3 * S * S * 4
+    roofline = dict(bound="hbm", kernel="preproc (coeffs + horizontal pass + vertical pass/ToTensor/augment)", achieved=round(alg / (us * 1e-6) / 1e9, 1),
+                    peak=HBM_PEAK_GBS, unit="GB/s", frac=round(alg / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4), traffic=None, launches_per_step=3,
+                    avg_launch_us=round(us / 3, 1), alg_bytes_per_step=alg)
+    # host half (decisions, crop slices, packing, upload) for the same batch, one core
+    t1 = time.perf_counter()
+    for _ in range(5):
+        torch.manual_seed(2021)
+        t.stage(fr, boxes, kps)
+    torch.cuda.synchronize()
+    host_ms = (time.perf_counter() - t1) / 5 * 1e3
+    cpu = None
+    if not args.no_cpu_baseline:
+        n = 0
+        t1 = time.perf_counter()
+        torch.manual_seed(2021)
+        while time.perf_counter() - t1 < 10.0:
+            i = n % B
+            P.krn_sample(np.repeat(fr[i][:, :, None], 3, axis=2), boxes[i], kps[i].copy(), S, 0.5, True)
+            n += 1
+        cdt = time.perf_counter() - t1
+        cpu = dict(value=round(n / cdt, 1), unit="images/sec", cores=1, kind="port",
+                   sample="%d samples through the per-sample CPU pipeline (Pillow resize + torch ops, as the reference's DataLoader "
+                          "workers run it), one process (%.1f s)" % (n, cdt))
+    print(json.dumps({
+        "metric": "images/sec input pipeline: RoI crop -> 224x224 + augmentations, bs=%d" % B, "value": round(B * args.steps / dt, 1),
+        "unit": "images/sec", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8 -> f32 (22-bit fixed-point filter)", "data": "synthetic",
+        "config": {"workload": "GPU half of the input pipeline on %d regions of interest (240..760 px squares, enlarged x1..1.5) of 1920x1200 grey "
+                               "frames, crops resident in HBM" % B, "per_gpu_batch": B, "host_half_ms_per_batch": round(host_ms, 2),
+                   "host_half_note": "crop decisions + slicing + packing + one upload, single Python process, not in `value`"},
+        "roofline": roofline, "cpu_baseline": cpu}))
 
 
 def bench_dann(args):

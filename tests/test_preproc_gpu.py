@@ -88,3 +88,38 @@ def test_eval_and_spn_modes_and_device_noise(device):
         te([P.synth_frame(2700, 2700, 1)], [np.array([0.0, 2700.0, 0.0, 2700.0], dtype=np.float32)], [np.zeros((2, 11), dtype=np.float32)])
     with pytest.raises(RuntimeError):
         build_transforms("krn", (S, S), device="cpu")
+
+
+def test_csv_dataset_through_the_gpu_loader(device, tmp_path):
+    """a three-frame dataset on disk in the reference's layout (CSV without header, PNG frames): make_dataloader yields
+    batches whose images equal the oracle's for the same generator state"""
+    import types
+    from PIL import Image
+    from speedplusbaseline_amd.datasets import make_dataloader
+    root = tmp_path / "speedplus"
+    (root / "synthetic" / "images").mkdir(parents=True)
+    (root / "synthetic" / "splits_krn").mkdir(parents=True)
+    rows, frames = [], []
+    rng = np.random.default_rng(0)
+    for i in range(4):
+        f = P.synth_frame(300, 400, 20 + i)
+        frames.append(f)
+        Image.fromarray(f[:, :, 0], "L").save(root / "synthetic" / "images" / ("img%03d.png" % i))
+        box = [100.0 + i, 300.0 - i, 60.0, 250.0]
+        kp = rng.uniform(100, 250, 22)
+        rows.append(["synthetic/images/img%03d.png" % i] + box + [1, 0, 0, 0, 0.1, 0.2, 5.0] + list(kp))
+    import csv
+    with open(root / "synthetic" / "splits_krn" / "train.csv", "w", newline="") as fh:
+        csv.writer(fh).writerows(rows)
+    cfg = types.SimpleNamespace(dataroot=str(tmp_path), dataname="speedplus", num_keypoints=11, train_domain="synthetic",
+                                test_domain="synthetic", model_name="krn", train_csv="train.csv", test_csv="train.csv",
+                                batch_size=2, num_workers=0, input_shape=(64, 64))
+    loader = make_dataloader(cfg, is_train=False, device=device)           # deterministic order, batch size 1
+    assert len(loader) == 4
+    for i, (img, box, q, t) in enumerate(loader):
+        b = P.random_crop_box(np.array(rows[i][1:5], dtype=np.float32), 400, 300, False, None)
+        want = P.to_tensor(P.resize_pil(np.ascontiguousarray(frames[i][b[2]:b[3], b[0]:b[1]]), 64, 64))
+        assert torch.equal(img[0].cpu(), want) and q.shape == (1, 4) and t.shape == (1, 3)
+    tl = make_dataloader(cfg, is_train=True, device=device)
+    images, kps = next(iter(tl))
+    assert images.shape == (2, 3, 64, 64) and images.is_cuda and kps.shape == (2, 2, 11)

@@ -60,9 +60,14 @@ def main():
     model = model.to(device)
     lr_scheduler = torch.optim.lr_scheduler.StepLR(optimizer, step_size=cfg.lr_decay_step, gamma=cfg.lr_decay_alpha)
     if cfg.synthetic_batches <= 0:
-        raise SystemExit("The SPEED+ dataset pipeline (reference src/datasets) is not part of this build; pass "
-                         "--synthetic_batches N to train on synthetic 224x224 batches.")
-    if cfg.model_name == 'spn':
+        if cfg.model_name != 'krn':
+            raise SystemExit("Only the KRN dataset loader is built (speedplusbaseline_amd.datasets); pass --synthetic_batches N "
+                             "to train SPN on synthetic batches.")
+        # SPEED+ on disk (train.py:112 of the reference): frames decoded by DataLoader workers, crop + resize + ToTensor +
+        # augmentation of the batch on the GPU (speedplusbaseline_amd.transforms)
+        from speedplusbaseline_amd.datasets import make_dataloader
+        train_loader = make_dataloader(cfg, is_train=True, is_source=True, device=device)
+    elif cfg.model_name == 'spn':
         train_loader = SyntheticSpnLoader(cfg.batch_size, cfg.synthetic_batches, cfg.num_classes, cfg.num_neighbors, (227, 227), seed=cfg.seed)
     else:
         train_loader = SyntheticKeypointLoader(cfg.batch_size, cfg.synthetic_batches, cfg.num_keypoints, cfg.input_shape, seed=cfg.seed)
