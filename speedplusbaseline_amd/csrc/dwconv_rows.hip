@@ -53,8 +53,14 @@ __device__ __forceinline__ float from_right(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x101 /*row_shl:1*/, 0xf, 0xf, true));
 }
 // sum over the 16 lanes of a row, result in every lane
+// DPP butterflies (VALU, no LDS crossbar): quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror, row_mirror.  The
+// __shfl_xor form compiled to ds_bpermute_b32: 352 of them in the backward kernel's final reduction (88 values), ~3 us
+// of every launch of a kernel whose whole job is 9 row steps on the 14x14 maps.
+template <int CTRL> __device__ __forceinline__ float dpp_f(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
 __device__ __forceinline__ float row_sum(float v) {
-  v += __shfl_xor(v, 1, 16); v += __shfl_xor(v, 2, 16); v += __shfl_xor(v, 4, 16); v += __shfl_xor(v, 8, 16);
+  v += dpp_f<0xB1>(v); v += dpp_f<0x4E>(v); v += dpp_f<0x141>(v); v += dpp_f<0x140>(v);
   return v;
 }
 
