@@ -165,6 +165,15 @@ __device__ __forceinline__ void bn_bwd_coef(const BNRef& r, int c, float& p0, fl
 
 // ---------------------------------------------------------------------------------------------
 // wave64 reductions via DPP-lowered shuffles
+// sum over the 16 lanes of a DPP row, result in every lane: VALU-only butterflies (quad_perm [1,0,3,2], quad_perm [2,3,0,1],
+// row_half_mirror, row_mirror).  __shfl_xor compiles to ds_bpermute_b32 (LDS crossbar), several times slower.
+template <int CTRL> __device__ __forceinline__ float spb_dpp_f(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float row16_sum(float v) {
+  v += spb_dpp_f<0xB1>(v); v += spb_dpp_f<0x4E>(v); v += spb_dpp_f<0x141>(v); v += spb_dpp_f<0x140>(v);
+  return v;
+}
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

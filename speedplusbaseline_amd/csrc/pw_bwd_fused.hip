@@ -304,9 +304,7 @@ __global__ __launch_bounds__(256, 1) void pwb_kernel(const spb_pwbwd_args_t g, l
   for (int kb = 0; kb < KB; ++kb)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      float a = s1[kb][i], b = s2[kb][i];
-#pragma unroll
-      for (int o = 1; o < 16; o <<= 1) { a += __shfl_xor(a, o, 16); b += __shfl_xor(b, o, 16); }
+      const float a = row16_sum(s1[kb][i]), b = row16_sum(s2[kb][i]);
       if (li == 0) {
         red[(wave * 2 + 0) * KW + lq * 4 * KB + kb * 4 + i] = a;
         red[(wave * 2 + 1) * KW + lq * 4 * KB + kb * 4 + i] = b;

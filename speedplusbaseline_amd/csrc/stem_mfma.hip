@@ -105,9 +105,7 @@ __global__ __launch_bounds__(256) void stem_fwd_mfma_kernel(const float* __restr
     for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        float a = s1[cb][e], b2 = s2[cb][e];
-#pragma unroll
-        for (int o = 1; o < 16; o <<= 1) { a += __shfl_xor(a, o, 16); b2 += __shfl_xor(b2, o, 16); }
+        const float a = row16_sum(s1[cb][e]), b2 = row16_sum(s2[cb][e]);
         if (li == 0) { red[wave][0][cb * 16 + lq * 4 + e] = a; red[wave][1][cb * 16 + lq * 4 + e] = b2; }
       }
     __syncthreads();
