@@ -623,6 +623,7 @@ int launch_gemm_dma(const spb_gemm_args_t& g, hipStream_t stream) {
 // The LDS-DMA ring variant is kept for experiments (spb_debug_set_gemm_dma(1)); measured in the full KRN step it is
 // slower than the register-prefetch kernel on the small-M layers it was written for (dgrad 1.52 vs 1.38 ms / step).
 bool g_disable_dma = true;
+int g_dma_min_k = 64;      // spb_debug_set_gemm_dma(v): v == 1 -> every K >= 64, v > 1 -> only reductions K >= v
 bool g_plain_dma = true;
 int g_bk64_min_k = 256;
 
@@ -643,7 +644,7 @@ int dispatch_bn(const spb_gemm_args_t& g, hipStream_t stream) {
   if (small_m && bn == 128) bn = 64;
   if (small_m) {
     if (bn == 32) return launch_gemm<T, 1, 32, 32, PRO, EPI>(g, stream);
-    if (g.K >= 64 && sizeof(T) == 2 && !g_disable_dma) return launch_gemm_dma<PRO, EPI>(g, stream);
+    if (g.K >= g_dma_min_k && sizeof(T) == 2 && !g_disable_dma) return launch_gemm_dma<PRO, EPI>(g, stream);
     // long reductions (the 7x7 ConvDw layers, K up to 1280): 64-wide chunks halve the number of latency-bound steps
     // (forward-type only: the backward variant spills 87 dwords at 128 VGPRs with two 64-wide prefetch sets: 0.68 -> 0.75 ms)
     if (sizeof(T) == 2 && PRO == 1 && g.K >= g_bk64_min_k) return launch_gemm<T, 1, 64, 64, PRO, EPI>(g, stream);
@@ -866,7 +867,7 @@ extern "C" int spb_debug_trread(const unsigned short* in4096, unsigned short* ou
   return 0;
 }
 
-extern "C" int spb_debug_set_gemm_dma(int on) { g_disable_dma = (on == 0); return 0; }
+extern "C" int spb_debug_set_gemm_dma(int on) { g_disable_dma = (on == 0); g_dma_min_k = on > 1 ? on : 64; return 0; }
 extern "C" int spb_debug_set_gemm_plain_dma(int on) { g_plain_dma = (on != 0); return 0; }
 extern "C" int spb_debug_set_gemm_bk64_min_k(int k) { g_bk64_min_k = k; return 0; }
 
