@@ -252,9 +252,7 @@ __global__ __launch_bounds__(256) void gconv_kernel(const spb_gconv_args_t g, in
     for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        float a1 = s1[nb][e], a2 = s2[nb][e];
-#pragma unroll
-        for (int o2 = 1; o2 < 16; o2 <<= 1) { a1 += __shfl_xor(a1, o2, 16); a2 += __shfl_xor(a2, o2, 16); }
+        const float a1 = row16_sum(s1[nb][e]), a2 = row16_sum(s2[nb][e]);   // DPP butterflies, not ds_bpermute
         if (li == 0) {
           red[(wave * NB * 16 + co0 + nb * 4 + e) * 2] = a1;
           red[(wave * NB * 16 + co0 + nb * 4 + e) * 2 + 1] = a2;
@@ -432,9 +430,7 @@ __global__ __launch_bounds__(256, 1) void gconv_slab_kernel(const spb_gconv_args
     for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        float a1 = s1[nb][e], a2 = s2[nb][e];
-#pragma unroll
-        for (int o2 = 1; o2 < 16; o2 <<= 1) { a1 += __shfl_xor(a1, o2, 16); a2 += __shfl_xor(a2, o2, 16); }
+        const float a1 = row16_sum(s1[nb][e]), a2 = row16_sum(s2[nb][e]);   // DPP butterflies, not ds_bpermute
         if (li == 0) {
           red[(wave * ROWS + co0 + nb * 4 + e) * 2] = a1;
           red[(wave * ROWS + co0 + nb * 4 + e) * 2 + 1] = a2;
@@ -529,9 +525,7 @@ __global__ __launch_bounds__(256) void conv9_rgb_kernel(const float* __restrict_
     for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        float a1 = s1[cb][e], a2 = s2[cb][e];
-#pragma unroll
-        for (int o2 = 1; o2 < 16; o2 <<= 1) { a1 += __shfl_xor(a1, o2, 16); a2 += __shfl_xor(a2, o2, 16); }
+        const float a1 = row16_sum(s1[cb][e]), a2 = row16_sum(s2[cb][e]);
         if (li == 0) { red[wave][(cb * 16 + lq * 4 + e) * 2] = a1; red[wave][(cb * 16 + lq * 4 + e) * 2 + 1] = a2; }
       }
     __syncthreads();
