@@ -189,6 +189,8 @@ typedef struct spb_head_bwd_args {
   spb_bnref_t pro;
   float gscale;        /* upstream d(loss) */
   int B, J, Jp, HW, C, oR;
+  int roles;           /* 0: everything on `stream`;  1: input gradient + BN sums only;  2: weight + bias gradient only (so the
+                          caller can put the latter on a side stream: only the optimizer consumes it) */
 } spb_head_bwd_args_t;
 int spb_head_bwd(int dtype, const spb_head_bwd_args_t* a, spb_stream_t stream);
 

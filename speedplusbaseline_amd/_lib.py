@@ -71,7 +71,7 @@ class HeadArgs(C.Structure):
 class HeadBwdArgs(C.Structure):
     _fields_ = [("Z", vp), ("Wp", vp), ("dout", vp), ("G", vp), ("osums", vp), ("dW", vp), ("dbias", vp),
                 ("pro", BNRef), ("gscale", f32), ("B", i32), ("J", i32), ("Jp", i32), ("HW", i32), ("C", i32),
-                ("oR", i32)]
+                ("oR", i32), ("roles", i32)]
 
 
 class BnUpdEntry(C.Structure):

@@ -760,6 +760,9 @@ extern "C" int spb_krn_backward(spb_krn_ctx_t* c, float* grads, float gscale, in
       h.oR = c->R[m->aEP[3]];
       r.tic(PC_HEAD_BWD, (3.0 * r.elems(m->aEP[3]) + (double)m->Jp * 49 * 1024) * r.es() + 4.0 * m->J * 49 * 1024,
             4.0 * c->B * m->J * 49 * 1024);
+      h.roles = 2;   // weight + bias gradient: side stream (beside the input-gradient chain), like the pointwise weight gradients
+      r.ok(spb_head_bwd(dt, &h, r.side_stream()));
+      h.roles = 1;
       r.ok(spb_head_bwd(dt, &h, stream));
       r.toc();
     }

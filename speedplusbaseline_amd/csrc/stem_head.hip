@@ -259,8 +259,7 @@ __global__ __launch_bounds__(256) void head_reduce_kernel(const spb_head_args_t 
 }
 
 // ------------------------------------------------------------------------------------------------ head backward
-// blockIdx.y == 0: dA = dout * Wp, masked by relu'(bn(z)), plus sum(g), sum(g*xhat) for the BN below
-// blockIdx.y == 1: dW[j,c,hw] += sum_b dout[b,j] * relu(bn(z))[b,hw,c];  block 0 also adds dbias
+// dA = dout * Wp, masked by relu'(bn(z)), plus sum(g), sum(g*xhat) for the BN below (the weight gradient is head_wgrad_kernel)
 template <typename T>
 __global__ __launch_bounds__(256) void head_bwd_kernel(const spb_head_bwd_args_t a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -286,7 +285,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const spb_head_bwd_args_t
       sh[j] = a.pro.beta[c0 + j] - mu[j] * sc[j];
     }
   }
-  if (blockIdx.y == 0) {
+  {
     for (int i = t; i < a.J * 64; i += 256) {
       const int j = i >> 6, v8 = i & 63;
       float v[8];
@@ -341,45 +340,65 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const spb_head_bwd_args_t
         atomicAdd(a.osums + (size_t)rep * 2 * a.C + (size_t)which * a.C + (kk % a.C), red[i]);
       }
     }
-  } else {
-    __syncthreads();
-    if (blockIdx.x == 0 && t < a.J) {
-      float s = 0.f;
-      for (int b = 0; b < a.B; ++b) s += ds[b * a.J + t];
-      a.dbias[t] += s;
-    }
-    if (kok) {
-      // this thread owns j = sub, sub+4, ... (at most 8 of them for J <= 32)
-      float aw[8][8];
+  }
+}
+
+// Weight gradient of the 7x7 head convolution: dW[j][c][hw] += sum_b dout[b][j] * relu(bn(z))[b][hw][c], dbias[j] += sum_b dout.
+// One workgroup owns 8 channels and every spatial position: a thread keeps (hw, channel) pairs and all J outputs in registers,
+// the 8 channels of a position are 16 contiguous bytes of z, and each dW[j][c0..c0+7][*] block is one contiguous 8*HW-float
+// region written by this workgroup alone.  (The earlier mapping -- 512 consecutive k = one position, 512 channels -- scattered
+// 4-byte read-modify-writes 196 bytes apart: 60 us and 2.4x the algorithmic HBM traffic.)
+template <typename T>
+__global__ __launch_bounds__(256) void head_wgrad_kernel(const spb_head_bwd_args_t a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* ds = reinterpret_cast<float*>(smem);                 // [B][32] upstream gradient * gscale, zero beyond J: the inner
+                                                              // loop is then branch-free with 16-byte LDS reads (a runtime
+                                                              // `j < J` test per term cost a branch + a dependent read each)
+  T* zs = reinterpret_cast<T*>(smem + (size_t)a.B * 32 * 4);  // [B][HW][8] this workgroup's slab of z
+  const int t = threadIdx.x;
+  const int c0 = blockIdx.x * 8, KH = a.HW * a.C, npair = a.HW * 8;
+  const T* Z = reinterpret_cast<const T*>(a.Z);
+  // the whole slab in one burst of independent 16-byte (bf16) loads: one memory round trip instead of one per image
+  for (int i = t; i < a.B * a.HW; i += 256) {
+    const int b = i / a.HW, hw = i % a.HW;
+    const Raw8<T> r = ldraw<T>(Z + (size_t)b * KH + (size_t)hw * a.C + c0);
+    *reinterpret_cast<Raw8<T>*>(zs + (size_t)i * 8) = r;
+  }
+  for (int i = t; i < a.B * 32; i += 256) ds[i] = (i & 31) < a.J ? a.dout[(i >> 5) * a.J + (i & 31)] * a.gscale : 0.f;
+  const int ci = t & 7;
+  float mu, is;
+  bn_moments(a.pro, c0 + ci, mu, is);
+  const float sc = a.pro.gamma[c0 + ci] * is, sh = a.pro.beta[c0 + ci] - mu * sc;
+  __syncthreads();
+  if (blockIdx.x == 0 && t < a.J) {
+    float s = 0.f;
+    for (int b = 0; b < a.B; ++b) s += ds[b * 32 + t];
+    a.dbias[t] += s;
+  }
+  for (int p = t; p < npair; p += 256) {          // pair = (hw = p >> 3, channel c0 + (p & 7)); p & 7 == t & 7 since 256 % 8 == 0
+    float acc[32];
 #pragma unroll
-      for (int q = 0; q < 8; ++q)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) aw[q][e] = 0.f;
-      for (int b = 0; b < a.B; ++b) {
-        float z[8];
-        ld8<T>(Z + (size_t)b * KH + k, z);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) z[e] = act_fwd(z[e] * sc[e] + sh[e], a.pro.act, a.pro.slope);
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-          const int j = sub + 4 * q;
-          if (j < a.J) {
-            const float d = ds[b * a.J + j];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) aw[q][e] += d * z[e];
-          }
-        }
-      }
-      const int hw = k / a.C;
+    for (int j = 0; j < 32; ++j) acc[j] = 0.f;
+    for (int b = 0; b < a.B; ++b) {
+      const float v = act_fwd(to_f<T>(zs[(size_t)b * npair + p]) * sc + sh, a.pro.act, a.pro.slope);
+      const float4* d = reinterpret_cast<const float4*>(ds + b * 32);
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
-        const int j = sub + 4 * q;
-        if (j < a.J) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) a.dW[((size_t)j * a.C + c0 + e) * a.HW + hw] += aw[q][e];
-        }
+        const float4 dv = d[q];
+        acc[4 * q] += dv.x * v; acc[4 * q + 1] += dv.y * v; acc[4 * q + 2] += dv.z * v; acc[4 * q + 3] += dv.w * v;
       }
     }
+    // accumulate into dW: all J loads first (the compiler cannot prove the J addresses distinct, and a load / add / store
+    // chain per j is J serialised memory round trips: 88 of this kernel's first 115 us)
+    const int hw = p >> 3;
+    float* dwp = a.dW + (size_t)(c0 + ci) * a.HW + hw;
+    const size_t js = (size_t)a.C * a.HW;
+    float old[32];
+#pragma unroll
+    for (int j = 0; j < 32; ++j) old[j] = j < a.J ? dwp[j * js] : 0.f;
+#pragma unroll
+    for (int j = 0; j < 32; ++j)
+      if (j < a.J) dwp[j * js] = old[j] + acc[j];
   }
 }
 
@@ -470,11 +489,24 @@ extern "C" int spb_head_bwd(int dtype, const spb_head_bwd_args_t* a, spb_stream_
     hipFuncSetAttribute(reinterpret_cast<const void*>(&head_bwd_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done = true;
   }
-  if (dtype == SPB_BF16)
-    hipLaunchKernelGGL(head_bwd_kernel<bf16_t>, dim3(gx, 2), dim3(256), lds, (hipStream_t)stream, *a);
-  else if (dtype == SPB_F32)
-    hipLaunchKernelGGL(head_bwd_kernel<float>, dim3(gx, 2), dim3(256), lds, (hipStream_t)stream, *a);
-  else return SPB_E_ARG;
+  if (dtype != SPB_BF16 && dtype != SPB_F32) return SPB_E_ARG;
+  hipStream_t hs = (hipStream_t)stream;
+  if (a->roles != 2) {     // input gradient + BatchNorm sums
+    if (dtype == SPB_BF16) hipLaunchKernelGGL(head_bwd_kernel<bf16_t>, dim3(gx, 1), dim3(256), lds, hs, *a);
+    else hipLaunchKernelGGL(head_bwd_kernel<float>, dim3(gx, 1), dim3(256), lds, hs, *a);
+  }
+  if (a->roles != 1) {     // weight + bias gradient: one workgroup per 8 channels, all HW positions
+    const size_t l2 = (size_t)a->B * 32 * sizeof(float) + (size_t)a->B * a->HW * 8 * (dtype == SPB_BF16 ? 2 : 4);
+    if (l2 > 160 * 1024) return SPB_E_SHAPE;
+    static bool wg_attr = false;
+    if (!wg_attr) {
+      hipFuncSetAttribute(reinterpret_cast<const void*>(&head_wgrad_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      hipFuncSetAttribute(reinterpret_cast<const void*>(&head_wgrad_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      wg_attr = true;
+    }
+    if (dtype == SPB_BF16) hipLaunchKernelGGL(head_wgrad_kernel<bf16_t>, dim3(a->C / 8), dim3(256), l2, hs, *a);
+    else hipLaunchKernelGGL(head_wgrad_kernel<float>, dim3(a->C / 8), dim3(256), l2, hs, *a);
+  }
   SPB_CHECK_LAUNCH();
   return 0;
 }
