@@ -222,6 +222,8 @@ void build_model(spb_krn* m, int nK, bool dann) {
 struct Src { const void* ptr; spb_bnref_t ref; };
 
 static int g_side_wgrad = 1;
+static long long g_replica_min_rows = 32768;   // BN-sum replicas (8) from this many rows up; spb_debug_set_replica_rows
+extern "C" int spb_debug_set_replica_rows(long long rows) { g_replica_min_rows = rows; return 0; }
 static int g_fused_pw_bwd = 1;
 struct Runner {
   spb_krn_ctx* c; spb_krn* m; hipStream_t st; int dt; int err = 0;
@@ -519,7 +521,7 @@ static void layout_ctx(const spb_krn* m, int B, int dtype, spb_krn_ctx* c, size_
   for (int a = 0; a < nA; ++a) {
     const ActDef& d = m->acts[a];
     const long long Mrows = (long long)B * d.H * d.W;
-    Rv[a] = Mrows >= 32768 ? 8 : 1;
+    Rv[a] = Mrows >= g_replica_min_rows ? 8 : 1;
     so[a] = sf; sf += (size_t)Rv[a] * 2 * d.C;
     bo[a] = sf; sf += (size_t)Rv[a] * 2 * d.C;
   }
