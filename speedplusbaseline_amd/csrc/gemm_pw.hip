@@ -626,6 +626,7 @@ bool g_disable_dma = true;
 int g_dma_min_k = 64;      // spb_debug_set_gemm_dma(v): v == 1 -> every K >= 64, v > 1 -> only reductions K >= v
 bool g_plain_dma = true;
 int g_bk64_min_k = 256;
+int g_bk64_dgrad_min_k = 1 << 30;   // spb_debug_set_gemm_bk64_dgrad_min_k
 
 template <typename T, int PRO, int EPI>
 int dispatch_bn(const spb_gemm_args_t& g, hipStream_t stream) {
@@ -648,6 +649,11 @@ int dispatch_bn(const spb_gemm_args_t& g, hipStream_t stream) {
     // long reductions (the 7x7 ConvDw layers, K up to 1280): 64-wide chunks halve the number of latency-bound steps
     // (forward-type only: the backward variant spills 87 dwords at 128 VGPRs with two 64-wide prefetch sets: 0.68 -> 0.75 ms)
     if (sizeof(T) == 2 && PRO == 1 && g.K >= g_bk64_min_k) return launch_gemm<T, 1, 64, 64, PRO, EPI>(g, stream);
+    // backward-type with a long reduction: 32-column tiles leave room in the register file for 64-wide chunks (half the
+    // latency-bound steps) and double the workgroup count of launches that fill less than half the chip
+    if constexpr (sizeof(T) == 2 && PRO == 2) {
+      if (g.K >= g_bk64_dgrad_min_k) return launch_gemm<T, 1, 32, 64, PRO, EPI>(g, stream);
+    }
     return launch_gemm<T, 1, 64, 32, PRO, EPI>(g, stream);
   }
   if (bn == 32) return launch_gemm<T, 2, 32, 32, PRO, EPI>(g, stream);
@@ -870,5 +876,6 @@ extern "C" int spb_debug_trread(const unsigned short* in4096, unsigned short* ou
 extern "C" int spb_debug_set_gemm_dma(int on) { g_disable_dma = (on == 0); g_dma_min_k = on > 1 ? on : 64; return 0; }
 extern "C" int spb_debug_set_gemm_plain_dma(int on) { g_plain_dma = (on != 0); return 0; }
 extern "C" int spb_debug_set_gemm_bk64_min_k(int k) { g_bk64_min_k = k; return 0; }
+extern "C" int spb_debug_set_gemm_bk64_dgrad_min_k(int k) { g_bk64_dgrad_min_k = k; return 0; }
 
 extern "C" const char* spb_version(void) { return "speedplusbaseline_amd gfx950 r1"; }
