@@ -222,6 +222,18 @@ void build_model(spb_krn* m, int nK, bool dann) {
 struct Src { const void* ptr; spb_bnref_t ref; };
 
 static int g_side_wgrad = 1;
+// Pointwise weight gradients are queued and handed to the side stream right before the next depthwise backward kernel (one
+// fork per inverted-residual block instead of two, and they then run beside a memory-bound kernel rather than beside the
+// input-gradient GEMMs); at most g_wgrad_batch are held back.  Measured: fork per GEMM 3.52 ms, per 3 GEMMs 3.43 ms, at the
+// depthwise kernels 3.37 ms per step.  spb_debug_set_wgrad_batch(n): n > 0 plain batches of n, n < 0 flush at depthwise, cap -n.
+static int g_wgrad_flush_at_dw = 1;
+static int g_wgrad_batch = 8;
+extern "C" int spb_debug_set_wgrad_batch(int n) {
+  g_wgrad_flush_at_dw = n < 0;
+  if (n < 0) n = -n;
+  g_wgrad_batch = n < 1 ? 1 : n;
+  return 0;
+}
 static long long g_replica_min_rows = 32768;   // BN-sum replicas (8) from this many rows up; spb_debug_set_replica_rows
 extern "C" int spb_debug_set_replica_rows(long long rows) { g_replica_min_rows = rows; return 0; }
 static int g_fused_pw_bwd = 1;
@@ -314,7 +326,7 @@ struct Runner {
     w.G = this->g(aout); w.Zn = z(aout); w.X = in.ptr; w.dW = m->G + L.w_off; w.pro_dz = ref(aout, true);
     w.pro_a = in.ref; w.M = M(aout); w.K = L.K; w.N = L.N;
     tic(PC_PW_WGRAD, ((double)w.M * (2 * L.N + L.K)) * es() + 4.0 * L.K * L.N, 2.0 * w.M * L.K * L.N);
-    ok(spb_pwconv_wgrad(dt, &w, side_stream()));
+    queue_wgrad(w);
     toc();
     spb_gemm_args_t g; std::memset(&g, 0, sizeof(g));
     g.A = this->g(aout); g.A2 = z(aout); g.Bw = wc(L.wct_off); g.pro = ref(aout, true);
@@ -345,7 +357,24 @@ struct Runner {
     forked = true;
     return c->side;
   }
+  // Weight-gradient GEMMs are handed to the side stream in batches: every fork costs the launch stream an event record, and
+  // the kernel trace shows ~7.5 us of dispatch bubble on the launch stream for each (30 forks = 0.22 ms of a 3.5 ms step).
+  // Their inputs (g, z, batch sums of the output tensor, the forward activations) are not overwritten during backward, so a
+  // weight gradient may start any time after its layer's pw_bwd was reached.
+  std::vector<spb_wgrad_args_t> pend;
+  void queue_wgrad(const spb_wgrad_args_t& w) {
+    if (c->prof_on || !c->side || !c->side_on || !g_side_wgrad) { ok(spb_pwconv_wgrad(dt, &w, st)); return; }
+    pend.push_back(w);
+    if ((int)pend.size() >= g_wgrad_batch) flush_wgrads();
+  }
+  void flush_wgrads() {
+    if (pend.empty()) return;
+    hipStream_t s = side_stream();       // one event for the whole batch
+    for (const spb_wgrad_args_t& w : pend) ok(spb_pwconv_wgrad(dt, &w, s));
+    pend.clear();
+  }
   void join_side() {
+    flush_wgrads();
     if (!forked) return;
     hipEventRecord(c->join_ev, c->side);
     hipStreamWaitEvent(st, c->join_ev, 0);
@@ -353,6 +382,7 @@ struct Runner {
   }
   bool forked = false;
   void dw_bwd(const DWDef& L, const Src& in, int Hin, int aout, int atgt, void* plain, const void* res) {
+    if (g_wgrad_flush_at_dw) flush_wgrads();   // the queued weight-gradient GEMMs run beside this (memory-bound) kernel
     // one fused pass: input gradient (+ activation mask / BN sums of the input-side tensor) and weight gradient
     spb_dw_args_t d; std::memset(&d, 0, sizeof(d));
     d.X = this->g(aout); d.X2 = z(aout); d.Xin = in.ptr; d.Wd = m->P + L.w_off; d.dW = m->G + L.w_off;
