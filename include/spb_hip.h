@@ -448,6 +448,7 @@ int spb_preproc_max_taps(void);   /* crops larger than (taps-1)/2 x S per side n
 int spb_preproc_batch(const spb_preproc_args_t* a, spb_stream_t stream);
 
 /* debug / test helpers */
+int spb_debug_set_wgrad_min_flush(int n); /* fork at a depthwise backward kernel only when >= n weight gradients are queued */
 int spb_debug_set_wgrad_batch(int n); /* pointwise weight-gradient GEMMs handed to the side stream per fork event */
 int spb_debug_set_gemm_bk64_dgrad_min_k(int k); /* backward-type small-M GEMMs with K >= k: 64x32 tiles with 64-deep chunks */
 int spb_debug_set_replica_rows(long long rows); /* BatchNorm batch sums get 8 atomic replicas for tensors with at least this many rows (contexts created afterwards) */

@@ -176,6 +176,7 @@ SYMBOLS = {
     "spb_preproc_max_taps": (i32, []),
     "spb_preproc_batch": (i32, [C.POINTER(PreprocArgs), vp]),
     "spb_debug_set_optim": (i32, [i32, i32, i32]),
+    "spb_debug_set_wgrad_min_flush": (i32, [i32]),
     "spb_debug_set_wgrad_batch": (i32, [i32]),
     "spb_debug_set_gemm_bk64_dgrad_min_k": (i32, [i32]),
     "spb_debug_set_replica_rows": (i32, [i64]),

@@ -227,6 +227,8 @@ static int g_side_wgrad = 1;
 // input-gradient GEMMs); at most g_wgrad_batch are held back.  Measured: fork per GEMM 3.52 ms, per 3 GEMMs 3.43 ms, at the
 // depthwise kernels 3.37 ms per step.  spb_debug_set_wgrad_batch(n): n > 0 plain batches of n, n < 0 flush at depthwise, cap -n.
 static int g_wgrad_flush_at_dw = 1;
+static int g_wgrad_min_flush = 1;      // flush at a depthwise kernel only with at least this many queued
+extern "C" int spb_debug_set_wgrad_min_flush(int n) { g_wgrad_min_flush = n < 1 ? 1 : n; return 0; }
 static int g_wgrad_batch = 8;
 extern "C" int spb_debug_set_wgrad_batch(int n) {
   g_wgrad_flush_at_dw = n < 0;
@@ -382,7 +384,7 @@ struct Runner {
   }
   bool forked = false;
   void dw_bwd(const DWDef& L, const Src& in, int Hin, int aout, int atgt, void* plain, const void* res) {
-    if (g_wgrad_flush_at_dw) flush_wgrads();   // the queued weight-gradient GEMMs run beside this (memory-bound) kernel
+    if (g_wgrad_flush_at_dw && (int)pend.size() >= g_wgrad_min_flush) flush_wgrads();   // they run beside this memory-bound kernel
     // one fused pass: input gradient (+ activation mask / BN sums of the input-side tensor) and weight gradient
     spb_dw_args_t d; std::memset(&d, 0, sizeof(d));
     d.X = this->g(aout); d.X2 = z(aout); d.Xin = in.ptr; d.Wd = m->P + L.w_off; d.dW = m->G + L.w_off;
