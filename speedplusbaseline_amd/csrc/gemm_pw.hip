@@ -43,7 +43,7 @@ constexpr size_t gemm_region_bytes() {
 
 // RF = 16-row fragments per wave (workgroup tile = 64*RF rows x BN columns)
 template <typename T, int RF, int BN, int BK, int PRO, int EPI>
-__global__ __launch_bounds__(256, (RF == 1 && sizeof(T) == 2) ? 4 : 1) void pw_gemm_kernel(const spb_gemm_args_t g) {
+__global__ __launch_bounds__(256, (RF == 1 && sizeof(T) == 2) ? ((BK == 64 && PRO == 2) ? 2 : 4) : 1) void pw_gemm_kernel(const spb_gemm_args_t g) {
   constexpr int BM = 64 * RF;
   constexpr int GBK = BK;
   constexpr int LDK = LdsPad<T, BK>::LDK;
@@ -652,7 +652,7 @@ int dispatch_bn(const spb_gemm_args_t& g, hipStream_t stream) {
     // backward-type with a long reduction: 32-column tiles leave room in the register file for 64-wide chunks (half the
     // latency-bound steps) and double the workgroup count of launches that fill less than half the chip
     if constexpr (sizeof(T) == 2 && PRO == 2) {
-      if (g.K >= g_bk64_dgrad_min_k) return launch_gemm<T, 1, 32, 64, PRO, EPI>(g, stream);
+      if (g.K >= g_bk64_dgrad_min_k) return launch_gemm<T, 1, 64, 64, PRO, EPI>(g, stream);
     }
     return launch_gemm<T, 1, 64, 32, PRO, EPI>(g, stream);
   }

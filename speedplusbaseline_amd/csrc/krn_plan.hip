@@ -237,7 +237,12 @@ extern "C" int spb_debug_set_wgrad_batch(int n) {
   return 0;
 }
 static long long g_replica_min_rows = 32768;   // BN-sum replicas (8) from this many rows up; spb_debug_set_replica_rows
-extern "C" int spb_debug_set_replica_rows(long long rows) { g_replica_min_rows = rows; return 0; }
+static int g_replica_mid = 1;   // replicas for tensors with 4096 <= rows < g_replica_min_rows (the 14x14 maps at bs=48)
+extern "C" int spb_debug_set_replica_rows(long long rows) {
+  if (rows < 0) { g_replica_mid = (int)-rows; return 0; }   // negative: set the mid-size replica count instead
+  g_replica_min_rows = rows;
+  return 0;
+}
 static int g_fused_pw_bwd = 1;
 struct Runner {
   spb_krn_ctx* c; spb_krn* m; hipStream_t st; int dt; int err = 0;
@@ -553,7 +558,7 @@ static void layout_ctx(const spb_krn* m, int B, int dtype, spb_krn_ctx* c, size_
   for (int a = 0; a < nA; ++a) {
     const ActDef& d = m->acts[a];
     const long long Mrows = (long long)B * d.H * d.W;
-    Rv[a] = Mrows >= g_replica_min_rows ? 8 : 1;
+    Rv[a] = Mrows >= g_replica_min_rows ? 8 : (Mrows >= 4096 ? g_replica_mid : 1);
     so[a] = sf; sf += (size_t)Rv[a] * 2 * d.C;
     bo[a] = sf; sf += (size_t)Rv[a] * 2 * d.C;
   }
