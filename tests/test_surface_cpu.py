@@ -132,3 +132,15 @@ def test_data_parallel_host_logic_two_gloo_ranks():
     assert out[0][4] == out[1][4] and 2 < sum(out[0][4]) < 14                 # rank-synchronous style-augmentation coin
     assert out[0][5] == 2 and out[1][5] == 2                                  # trainers see the data-parallel job
     assert out[0][6] == [3.0 * i for i in range(12)] and out[1][6] == out[0][6]  # both buckets summed in place
+
+
+def test_dataset_import_paths_of_the_reference():
+    """train.py / adapt.py / test.py of the reference import src.datasets.build.make_dataloader; the transforms module keeps
+    build_transforms.  The GPU-batched transform refuses to run without a GPU (no CPU path)."""
+    from src.datasets.build import make_dataloader
+    from src.datasets.transforms import build_transforms
+    import inspect
+    assert list(inspect.signature(make_dataloader).parameters)[:4] == ["cfg", "is_train", "is_source", "load_labels"]
+    assert list(inspect.signature(build_transforms).parameters)[:4] == ["model_name", "input_size", "p_aug", "is_train"]
+    with pytest.raises(RuntimeError):
+        build_transforms("krn", (224, 224), device="cpu")
