@@ -454,7 +454,7 @@ def bench_spn(args):
     x, yc, yw = x.to(dev), yc.to(dev), yw.to(dev)
 
     def one():
-        out = net.loss_and_grads(x, yc, yw)
+        out = net.loss_and_grads(x, yc, yw, world_size=world, group=group, compress_bf16=os.environ.get("SPB_SPN_BF16_GRADS") == "1")
         opt.step(world_size=world, group=group)
         return out
 

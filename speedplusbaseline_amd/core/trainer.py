@@ -147,7 +147,7 @@ def train_single_epoch_spn(epoch, cfg, model, data_loader, optimizer, writer, de
         yWeights = yWeights.to(device, non_blocking=True)
         if styleAugmentor is not None and _texture_coin(cfg, epoch * n_iter + idx):
             images = styleAugmentor(images)
-        out = model.loss_and_grads(images, yClasses, yWeights)   # gradients land in p.grad (no autograd)
+        out = model.loss_and_grads(images, yClasses, yWeights, world_size=world, group=group)   # gradients land in p.grad (no autograd)
         optimizer.step(world_size=world, group=group)            # [all-reduce,] clip_grad_value_(1.0) + update: one launch
         lc, lr_ = out[1:3].tolist()                              # host floats per step, as the reference reports
         training_time_meter.update((time.time() - start) * 1000, B)

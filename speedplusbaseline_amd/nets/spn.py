@@ -338,10 +338,47 @@ class SpacecraftPoseNet(nn.Module):
         c, r = self._forward_impl(x, self.training)
         return c.float(), r.float()
 
+    def _start_fc_exchange(self, group, compress_bf16):
+        """all-reduce of gflat[conv_end:] on the communication stream, ordered after everything enqueued so far"""
+        from ..parallel import allreduce_sum_async
+        if getattr(self, "_comm", None) is None:
+            self._comm = torch.cuda.Stream(device=self._gflat.device)
+        tail = self._gflat[self._conv_end:]
+        self._comm.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self._comm):
+            if compress_bf16:
+                buf = self._buf("ddp_bf16", (tail.numel(),), torch.bfloat16)
+                buf.copy_(tail)
+                w = allreduce_sum_async(buf, group)
+                return [("bf16", w, buf, tail)]
+            return [("f32", allreduce_sum_async(tail, group), None, tail)]
+
+    def finish_gradient_exchange(self, group=None):
+        """called by SpnOptimizer.step before the update: waits for the overlapped bucket, reduces the convolution bucket"""
+        from ..parallel import allreduce_sum_
+        works, self._ddp_works = getattr(self, "_ddp_works", None), None
+        if works is None:
+            allreduce_sum_(self._gflat, group)
+            return
+        for kind, w, buf, tail in works:
+            with torch.cuda.stream(self._comm):
+                if w is not None:
+                    w.wait()                      # the communication stream waits for the collective
+                if kind == "bf16":
+                    tail.copy_(buf)
+        torch.cuda.current_stream().wait_stream(self._comm)
+        allreduce_sum_(self._gflat[:self._conv_end], group)
+
     # ---- one training step's loss + gradients (trainer.py:146-177): loss = softCE(c, yClasses) + 10 softCE(r, yWeights)
-    def loss_and_grads(self, x, y_classes, y_weights, masks=None):
+    def loss_and_grads(self, x, y_classes, y_weights, masks=None, world_size=1, group=None, compress_bf16=False):
         """Runs forward (training mode), the loss and the backward pass; gradients land in p.grad of every parameter
-        (views of the flat gradient arena).  Returns a device tensor (loss, loss_class, loss_regress)."""
+        (views of the flat gradient arena).  Returns a device tensor (loss, loss_class, loss_regress).
+
+        world_size > 1 (one process per GPU): the fully connected layers' gradients -- the tail of the arena, 600 of the 609 MB,
+        final before the convolution trunk's backward starts -- are summed across ranks on a communication stream while the
+        trunk's backward runs; SpnOptimizer.step waits for that work and reduces the small convolution bucket itself.
+        compress_bf16 sends that bucket as bfloat16 (half the bytes on the xGMI links; the sum is then rounded to bfloat16
+        per hop, like torch's bf16_compress_hook)."""
         lib = L.lib()
         dt, dc = self._dt(), (L.BF16 if self.precision == "bf16" else L.F32)
         c, r = self._forward_impl(x, True, masks)
@@ -395,6 +432,9 @@ class SpacecraftPoseNet(nn.Module):
                     else:
                         df = dx if df is None else df + dx
             g_act = df.view(B, 256, 36).permute(0, 2, 1).contiguous()    # NCHW flatten order -> NHWC
+        self._ddp_works = None
+        if world_size > 1:
+            self._ddp_works = self._start_fc_exchange(group, compress_bf16)
         # trunk, last to first
         dwp = self._buf("dWp", (sum(cp[n].numel() for n, *_ in _CONVS),), torch.float32)
         dwp.zero_()

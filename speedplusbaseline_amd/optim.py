@@ -169,7 +169,7 @@ class SpnOptimizer(torch.optim.Optimizer):
         self._t += 1
         gmul = None
         if world_size > 1:
-            allreduce_sum_(gflat, group)
+            mdl.finish_gradient_exchange(group)     # the fc bucket was started from inside backward (loss_and_grads)
             if self._gmul is None:
                 self._gmul = torch.full((1,), mean_scale(world_size), dtype=torch.float32, device=flat.device)
             gmul = self._gmul
