@@ -67,6 +67,8 @@ typedef struct spb_gemm_args {
   float out_scale;   /* epi_mode 0: y = out_act(acc*out_scale + bias); callers pass 1 for a plain product */
   int lda, ldc;      /* row strides (elements) of A/A2 and of Y/res/Zout; 0 = dense (K and N).  Lets one group of a grouped
                         convolution run on a column slab of the im2col / output matrices (SPN conv2, conv4, conv5) */
+  void* stop_event;  /* host side only: optional hipEvent_t completed by THIS launch (attached to its dispatch packet), so
+                        another stream can wait for it without an event-record packet in the launch stream */
 } spb_gemm_args_t;
 int spb_pwconv_gemm(int dtype, const spb_gemm_args_t* args, spb_stream_t stream);
 
@@ -448,6 +450,7 @@ int spb_preproc_max_taps(void);   /* crops larger than (taps-1)/2 x S per side n
 int spb_preproc_batch(const spb_preproc_args_t* a, spb_stream_t stream);
 
 /* debug / test helpers */
+int spb_debug_set_launch_events(int on); /* side-stream forks wait on the preceding GEMM launch's completion event (1) or on a recorded event (0) */
 int spb_debug_set_wgrad_min_flush(int n); /* fork at a depthwise backward kernel only when >= n weight gradients are queued */
 int spb_debug_set_wgrad_batch(int n); /* pointwise weight-gradient GEMMs handed to the side stream per fork event */
 int spb_debug_set_gemm_bk64_dgrad_min_k(int k); /* backward-type small-M GEMMs with K >= k: 64x32 tiles with 64-deep chunks */

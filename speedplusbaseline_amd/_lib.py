@@ -26,7 +26,7 @@ class BNRef(C.Structure):
 class GemmArgs(C.Structure):
     _fields_ = [("A", vp), ("A2", vp), ("Bw", vp), ("Y", vp), ("res", vp), ("Zout", vp), ("bias", vp), ("osums", vp),
                 ("pro", BNRef), ("epi", BNRef), ("M", i32), ("K", i32), ("N", i32), ("pro_mode", i32),
-                ("epi_mode", i32), ("out_act", i32), ("oR", i32), ("out_scale", f32), ("lda", i32), ("ldc", i32)]
+                ("epi_mode", i32), ("out_act", i32), ("oR", i32), ("out_scale", f32), ("lda", i32), ("ldc", i32), ("stop_event", vp)]
 
 
 class WgradArgs(C.Structure):
@@ -176,6 +176,7 @@ SYMBOLS = {
     "spb_preproc_max_taps": (i32, []),
     "spb_preproc_batch": (i32, [C.POINTER(PreprocArgs), vp]),
     "spb_debug_set_optim": (i32, [i32, i32, i32]),
+    "spb_debug_set_launch_events": (i32, [i32]),
     "spb_debug_set_wgrad_min_flush": (i32, [i32]),
     "spb_debug_set_wgrad_batch": (i32, [i32]),
     "spb_debug_set_gemm_bk64_dgrad_min_k": (i32, [i32]),

@@ -17,6 +17,7 @@
 //     atomics per workgroup at the end, spread over `oR` replicas of the accumulator.
 //   * logical workgroup ids are remapped so the N tiles that share an A tile run on one XCD (one L2).
 #include "common.h"
+#include <hip/hip_ext.h>
 
 // phase timestamps for scratch/ubench_gemm.hip (compiled out in the product build)
 #ifndef SPB_TS
@@ -364,7 +365,11 @@ int launch_gemm(const spb_gemm_args_t& g, hipStream_t stream) {
     attr_done = true;
   }
   if (lds > 160 * 1024) return SPB_E_SHAPE;
-  hipLaunchKernelGGL((pw_gemm_kernel<T, RF, BN, BK, PRO, EPI>), dim3(NT * GM), dim3(256), lds, stream, g);
+  if (g.stop_event)
+    hipExtLaunchKernelGGL((pw_gemm_kernel<T, RF, BN, BK, PRO, EPI>), dim3(NT * GM), dim3(256), (unsigned)lds, stream, nullptr,
+                          (hipEvent_t)g.stop_event, 0, g);
+  else
+    hipLaunchKernelGGL((pw_gemm_kernel<T, RF, BN, BK, PRO, EPI>), dim3(NT * GM), dim3(256), lds, stream, g);
   SPB_CHECK_LAUNCH();
   return 0;
 }

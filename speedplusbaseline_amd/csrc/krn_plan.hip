@@ -226,6 +226,8 @@ static int g_side_wgrad = 1;
 // fork per inverted-residual block instead of two, and they then run beside a memory-bound kernel rather than beside the
 // input-gradient GEMMs); at most g_wgrad_batch are held back.  Measured: fork per GEMM 3.52 ms, per 3 GEMMs 3.43 ms, at the
 // depthwise kernels 3.37 ms per step.  spb_debug_set_wgrad_batch(n): n > 0 plain batches of n, n < 0 flush at depthwise, cap -n.
+static int g_launch_events = 1;        // fork on the completion event of the preceding GEMM launch instead of an event record
+extern "C" int spb_debug_set_launch_events(int on) { g_launch_events = on; return 0; }
 static int g_wgrad_flush_at_dw = 1;
 static int g_wgrad_min_flush = 1;      // flush at a depthwise kernel only with at least this many queued
 extern "C" int spb_debug_set_wgrad_min_flush(int n) { g_wgrad_min_flush = n < 1 ? 1 : n; return 0; }
@@ -346,19 +348,26 @@ struct Runner {
       const double mn = (double)g.M * L.N, mk = (double)g.M * L.K;
       tic(PC_PW_DGRAD, (2 * mn + (atgt >= 0 ? 2 : 1) * mk + (res ? mk : 0) + (double)L.K * L.N) * es(), 2.0 * g.M * L.K * L.N);
     }
+    // this launch's own completion event: what the queued weight gradients wait for (see flush_wgrads)
+    launch_ev = nullptr;
+    if (g_launch_events && !pend.empty()) { launch_ev = next_event(); g.stop_event = launch_ev; }
     ok(spb_pwconv_gemm(dt, &g, st));
     toc();
   }
   // Stream for work that only the optimizer consumes.  Forked from the launch stream at the current point (everything
   // the weight gradient reads -- g, z, bsums of the output, the forward activations -- is final before pw_bwd starts);
   // joined at the end of spb_krn_backward.  With the profiler on everything stays on the launch stream.
-  hipStream_t side_stream() {
-    if (c->prof_on || !c->side || !c->side_on || !g_side_wgrad) return st;
+  hipEvent_t launch_ev = nullptr;   // completion event attached to the last input-gradient GEMM launch (or null)
+  hipEvent_t next_event() {
     if ((size_t)c->n_fork >= c->fork_ev.size()) {
       hipEvent_t e; hipEventCreateWithFlags(&e, hipEventDisableTiming);
       c->fork_ev.push_back(e);
     }
-    hipEvent_t e = c->fork_ev[c->n_fork++];
+    return c->fork_ev[c->n_fork++];
+  }
+  hipStream_t side_stream() {
+    if (c->prof_on || !c->side || !c->side_on || !g_side_wgrad) return st;
+    hipEvent_t e = next_event();
     hipEventRecord(e, st);
     hipStreamWaitEvent(c->side, e, 0);
     forked = true;
@@ -376,7 +385,11 @@ struct Runner {
   }
   void flush_wgrads() {
     if (pend.empty()) return;
-    hipStream_t s = side_stream();       // one event for the whole batch
+    hipStream_t s;
+    if (launch_ev) {   // everything the queued GEMMs read was final before that launch: wait for it, record nothing
+      hipStreamWaitEvent(c->side, launch_ev, 0);
+      launch_ev = nullptr; forked = true; s = c->side;
+    } else s = side_stream();            // one event record for the whole batch
     for (const spb_wgrad_args_t& w : pend) ok(spb_pwconv_wgrad(dt, &w, s));
     pend.clear();
   }
