@@ -314,7 +314,9 @@ struct Runner {
     toc();
   }
   // ---- backward pieces.  `atgt` is the Act whose g / bsums the input gradient lands in (-1: plain output to `plain`)
-  void pw_bwd(const PWDef& L, const Src& in, int aout, int atgt, void* plain, const void* res, float plain_scale = 1.f) {
+  // before_dw: the next launch is a depthwise backward kernel, where the queued weight gradients fork off (flush_wgrads)
+  void pw_bwd(const PWDef& L, const Src& in, int aout, int atgt, void* plain, const void* res, float plain_scale = 1.f,
+              bool before_dw = false) {
     // wide, shallow layers (the 112x112 / 56x56 maps): one fused pass over g and z for both gradients
     if (g_fused_pw_bwd && dt == SPB_BF16 && atgt >= 0 && M(aout) >= 32768) {
       spb_pwbwd_args_t f; std::memset(&f, 0, sizeof(f));
@@ -350,7 +352,7 @@ struct Runner {
     }
     // this launch's own completion event: what the queued weight gradients wait for (see flush_wgrads)
     launch_ev = nullptr;
-    if (g_launch_events && !pend.empty()) { launch_ev = next_event(); g.stop_event = launch_ev; }
+    if (g_launch_events && before_dw && (!pend.empty() || head_pending)) { launch_ev = next_event(); g.stop_event = launch_ev; }
     ok(spb_pwconv_gemm(dt, &g, st));
     toc();
   }
@@ -383,13 +385,20 @@ struct Runner {
     pend.push_back(w);
     if ((int)pend.size() >= g_wgrad_batch) flush_wgrads();
   }
+  bool head_pending = false;
+  spb_head_bwd_args_t head_args;
+  void queue_head_wgrad(const spb_head_bwd_args_t& h) {
+    if (c->prof_on || !c->side || !c->side_on || !g_side_wgrad) { ok(spb_head_bwd(dt, &h, st)); return; }
+    head_args = h; head_pending = true;
+  }
   void flush_wgrads() {
-    if (pend.empty()) return;
+    if (pend.empty() && !head_pending) return;
     hipStream_t s;
     if (launch_ev) {   // everything the queued GEMMs read was final before that launch: wait for it, record nothing
       hipStreamWaitEvent(c->side, launch_ev, 0);
       launch_ev = nullptr; forked = true; s = c->side;
     } else s = side_stream();            // one event record for the whole batch
+    if (head_pending) { ok(spb_head_bwd(dt, &head_args, s)); head_pending = false; }
     for (const spb_wgrad_args_t& w : pend) ok(spb_pwconv_wgrad(dt, &w, s));
     pend.clear();
   }
@@ -812,14 +821,14 @@ extern "C" int spb_krn_backward(spb_krn_ctx_t* c, float* grads, float gscale, in
       h.oR = c->R[m->aEP[3]];
       r.tic(PC_HEAD_BWD, (3.0 * r.elems(m->aEP[3]) + (double)m->Jp * 49 * 1024) * r.es() + 4.0 * m->J * 49 * 1024,
             4.0 * c->B * m->J * 49 * 1024);
-      h.roles = 2;   // weight + bias gradient: side stream (beside the input-gradient chain), like the pointwise weight gradients
-      r.ok(spb_head_bwd(dt, &h, r.side_stream()));
       h.roles = 1;
       r.ok(spb_head_bwd(dt, &h, stream));
+      h.roles = 2;   // weight + bias gradient: side stream (beside the input-gradient chain), with the first batch of queued
+      r.queue_head_wgrad(h);   // pointwise weight gradients (its own fork would cost the launch stream another bubble)
       r.toc();
     }
     // extras[3] = ConvDw(1280,1024) on the concat
-    r.pw_bwd(m->eP[3], r.src_act(m->aED[3], true), m->aEP[3], m->aED[3], nullptr, nullptr);
+    r.pw_bwd(m->eP[3], r.src_act(m->aED[3], true), m->aEP[3], m->aED[3], nullptr, nullptr, 1.f, true);
     r.dw_bwd(m->eD[3], r.src_mat(m->matCat), 7, m->aED[3], -1, c->ws + c->dcat_off, nullptr);
     {  // split the concat gradient: channels [256,1280) -> extras[1] output, [0,256) -> un-reorg -> router output
       spb_bnbwd_args_t a; std::memset(&a, 0, sizeof(a));
@@ -836,9 +845,9 @@ extern "C" int spb_krn_backward(spb_krn_ctx_t* c, float* grads, float gscale, in
       r.toc();
     }
     r.pw_bwd(m->router, r.block_out(13, true), m->aR, -1, c->ws + c->dtap_off, nullptr);
-    r.pw_bwd(m->eP[1], r.src_act(m->aED[1], true), m->aEP[1], m->aED[1], nullptr, nullptr);
+    r.pw_bwd(m->eP[1], r.src_act(m->aED[1], true), m->aEP[1], m->aED[1], nullptr, nullptr, 1.f, true);
     r.dw_bwd(m->eD[1], r.src_act(m->aEP[0], true), 7, m->aED[1], m->aEP[0], nullptr, nullptr);
-    r.pw_bwd(m->eP[0], r.src_act(m->aED[0], true), m->aEP[0], m->aED[0], nullptr, nullptr);
+    r.pw_bwd(m->eP[0], r.src_act(m->aED[0], true), m->aEP[0], m->aED[0], nullptr, nullptr, 1.f, true);
     r.dw_bwd(m->eD[0], r.block_out(17, true), 7, m->aED[0], aF, nullptr, ddom);
   } else {
     // target-domain pass of DANN: only the domain loss reaches the backbone (dann.py:89-92)
@@ -858,7 +867,7 @@ extern "C" int spb_krn_backward(spb_krn_ctx_t* c, float* grads, float gscale, in
     const void* res = nullptr;
     if (b.res) res = r.g(b.aP);                                  // skip connection: d y_{k-1} += d y_k
     else if (k == 14 && with_pose) res = c->ws + c->dtap_off;    // RouterV2 branch taps block 13's output
-    r.pw_bwd(b.P, r.src_act(b.aD, true), b.aP, b.aD, nullptr, nullptr);
+    r.pw_bwd(b.P, r.src_act(b.aD, true), b.aP, b.aD, nullptr, nullptr, 1.f, true);
     if (b.t != 1) {
       r.dw_bwd(b.D, r.src_act(b.aE, true), b.Hin, b.aD, b.aE, nullptr, nullptr);
       r.pw_bwd(b.E, in, b.aE, atgt, nullptr, res);
