@@ -83,6 +83,7 @@ class SpacecraftPoseNet(nn.Module):
         self._ws = {}
         self._saved = None
         self.dropout_seed = 2021
+        self.side_wgrad = True     # weight gradients on a side stream (False: everything on the launch stream)
         self._step = 0
         if pretrain:
             self.load_weights('checkpoints/pretrained/bvlc_alexnet.npy')
@@ -338,6 +339,29 @@ class SpacecraftPoseNet(nn.Module):
         c, r = self._forward_impl(x, self.training)
         return c.float(), r.float()
 
+    # ---- weight / bias gradients only feed the optimizer: they are queued and run on a side stream beside the input-gradient
+    #      chain (forked at a few points only -- every fork costs the launch stream an event record), joined before returning
+    def _on_side(self, fns):
+        if not fns:
+            return
+        if getattr(self, "_side", None) is None:
+            self._side = torch.cuda.Stream(device=self._gflat.device)
+        if not self.side_wgrad:
+            for f in fns:
+                f(_st())
+            return
+        self._side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self._side):
+            sst = _st()
+            for f in fns:
+                f(sst)
+        self._side_used = True
+
+    def _join_side(self):
+        if getattr(self, "_side_used", False):
+            torch.cuda.current_stream().wait_stream(self._side)
+            self._side_used = False
+
     def _start_fc_exchange(self, group, compress_bf16):
         """all-reduce of gflat[conv_end:] on the communication stream, ordered after everything enqueued so far"""
         from ..parallel import allreduce_sum_async
@@ -345,6 +369,8 @@ class SpacecraftPoseNet(nn.Module):
             self._comm = torch.cuda.Stream(device=self._gflat.device)
         tail = self._gflat[self._conv_end:]
         self._comm.wait_stream(torch.cuda.current_stream())
+        if getattr(self, "_side_used", False):
+            self._comm.wait_stream(self._side)        # the fc weight gradients come from the side stream
         with torch.cuda.stream(self._comm):
             if compress_bf16:
                 buf = self._buf("ddp_bf16", (tail.numel(),), torch.bfloat16)
@@ -397,14 +423,17 @@ class SpacecraftPoseNet(nn.Module):
         if fast:
             MP = sv["MP"]
             acc, accF = self._acc("acc", max(4096, NC), MP), self._acc("accF", 9216, MP)
+            pend = []
             for names, g in ((("fc6", "fc7", "fc8"), dcg), (("fc9", "fc10", "fc11"), drg)):
+                self._on_side(pend); pend = []       # the first head's weight gradients run beside the second head's chain
                 a, b_, c_ = names
                 gT = self._buf("gT" + c_, (NC, MP), dt)
                 self._epi(B, NC, 1, src=g, YT=gT, db=getattr(self, c_).bias.grad)
                 for name, prev, xT in ((c_, b_, sv["hT" + b_]), (b_, a, sv["hT" + a]), (a, None, sv["fT"])):
                     lay = getattr(self, name)
                     N, K = lay.weight.shape
-                    L.check(lib.spb_fc_wgrad(_p(gT), _p(xT), _p(lay.weight.grad), B, N, K, st), "spb_fc_wgrad")
+                    pend.append(lambda s_, gT=gT, xT=xT, lay=lay, N=N, K=K:
+                                L.check(lib.spb_fc_wgrad(_p(gT), _p(xT), _p(lay.weight.grad), B, N, K, s_), "spb_fc_wgrad"))
                     tgt = acc if prev is not None else accF
                     L.check(lib.spb_fc_dgrad(_p(g), _p(self._sh(name + ".weight")), _p(tgt), B, N, K, st), "spb_fc_dgrad")
                     if prev is not None:     # through inverted dropout and ReLU of the previous fc, + its bias gradient
@@ -413,6 +442,7 @@ class SpacecraftPoseNet(nn.Module):
                         self._epi(B, 4096, 1, accT=acc, H=sv["h" + prev], Y=g, YT=gT, db=getattr(self, prev).bias.grad, scale=scale)
             g_act = self._buf("dp5", (B, 6, 6, 256), dt)   # the two heads met in accF
             L.check(lib.spb_spn_unflatten_grad(_p(accF), _p(g_act), B, 36, 256, st), "spb_spn_unflatten_grad")
+            self._on_side(pend)                            # ... the second head's beside the start of the trunk
         else:
             df = None
             for (a, b_, c_), g in ((("fc6", "fc7", "fc8"), dcg), (("fc9", "fc10", "fc11"), drg)):
@@ -462,10 +492,13 @@ class SpacecraftPoseNet(nn.Module):
             kg, cog = kpad // grp, cout // grp
             dW = dwp[woff:woff + cout * kg].view(cout, kg)
             woff += cout * kg
-            for gi in range(grp):
-                ops.pwconv_wgrad(g[:, gi * cog:(gi + 1) * cog], col[:, gi * kg:(gi + 1) * kg], dW[gi * cog:(gi + 1) * cog], ident(cog), ident(kg))
-            L.check(lib.spb_spn_unpack_conv_grad(_p(dW), _p(lay.weight.grad), cout, cin, grp, k, k, kg, 1 if name == "conv1" else 0, st), "spb_spn_unpack_conv_grad")
-            L.check(lib.spb_colsum(dc, _p(g), _p(lay.bias.grad), g.shape[0], cout, st), "spb_colsum")
+            def conv_wgrad(s_, g=g, col=col, dW=dW, lay=lay, cout=cout, cin=cin, grp=grp, k=k, kg=kg, cog=cog, name=name):
+                for gi in range(grp):       # ops.* launch on the current stream = the side stream inside _on_side
+                    ops.pwconv_wgrad(g[:, gi * cog:(gi + 1) * cog], col[:, gi * kg:(gi + 1) * kg], dW[gi * cog:(gi + 1) * cog], ident(cog), ident(kg))
+                L.check(lib.spb_spn_unpack_conv_grad(_p(dW), _p(lay.weight.grad), cout, cin, grp, k, k, kg, 1 if name == "conv1" else 0, s_),
+                        "spb_spn_unpack_conv_grad")
+                L.check(lib.spb_colsum(dc, _p(g), _p(lay.bias.grad), g.shape[0], cout, s_), "spb_colsum")
+            self._on_side([conv_wgrad])
             if name != "conv1":
                 dcol = self._buf("dcol" + name, tuple(col.shape), dt)
                 for gi in range(grp):
@@ -474,4 +507,5 @@ class SpacecraftPoseNet(nn.Module):
                 dx = self._buf("dxin" + name, (B, Hc, Wc, Cc), dt)
                 L.check(lib.spb_col2im(dc, _p(dcol), _p(dx), B, Hc, Wc, Cc, k, k, pad, kpad, grp, st), "spb_col2im")
                 g_act = dx
+        self._join_side()          # every gradient is in the arena before the caller's next launch (the optimizer)
         return out
