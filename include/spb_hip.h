@@ -450,6 +450,7 @@ int spb_preproc_max_taps(void);   /* crops larger than (taps-1)/2 x S per side n
 int spb_preproc_batch(const spb_preproc_args_t* a, spb_stream_t stream);
 
 /* debug / test helpers */
+int spb_debug_set_conv9_band(int on); /* decoder's last 9x9 layer: band-staged kernel (1, default) or the generic 8x8-tile kernel */
 int spb_debug_set_launch_events(int on); /* side-stream forks wait on the preceding GEMM launch's completion event (1) or on a recorded event (0) */
 int spb_debug_set_wgrad_min_flush(int n); /* fork at a depthwise backward kernel only when >= n weight gradients are queued */
 int spb_debug_set_wgrad_batch(int n); /* pointwise weight-gradient GEMMs handed to the side stream per fork event */

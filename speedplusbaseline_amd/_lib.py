@@ -176,6 +176,7 @@ SYMBOLS = {
     "spb_preproc_max_taps": (i32, []),
     "spb_preproc_batch": (i32, [C.POINTER(PreprocArgs), vp]),
     "spb_debug_set_optim": (i32, [i32, i32, i32]),
+    "spb_debug_set_conv9_band": (i32, [i32]),
     "spb_debug_set_launch_events": (i32, [i32]),
     "spb_debug_set_wgrad_min_flush": (i32, [i32]),
     "spb_debug_set_wgrad_batch": (i32, [i32]),

@@ -445,6 +445,117 @@ __global__ __launch_bounds__(256, 1) void gconv_slab_kernel(const spb_gconv_args
   }
 }
 
+// ------------------------------------------------------------------------------------------- last layer: 32 -> 3, 9x9
+// (ghiasi.py:70, the convolution before the final instance norm + sigmoid).  The generic 8x8-tile kernel stages a 16x16 halo per
+// 64 output pixels (4x the input) and reads a weight fragment per MFMA.  Here a workgroup owns a band of C9O_R rows x 32 columns:
+// the halo is 2.5 staged pixels per output pixel, the <= 4 weight rows sit in LDS, and each wave keeps four 16-pixel groups in
+// flight per weight-fragment read (81 taps x (1 + 4) 16-byte LDS reads x 4 MFMAs).
+constexpr int C9O_R = 8, C9O_W = 32;
+__global__ __launch_bounds__(256) void conv9_band_kernel(const spb_gconv_args_t g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int HW_ = C9O_W + 8, HR = C9O_R + 8, LDP = 40, KK = 81, LDW = KK * 32 + 8;
+  float* cf = reinterpret_cast<float*>(smem);                      // [32][2] scale | shift
+  float* red = cf + 64;                                            // [4 waves][4 ch][2]
+  bf16_t* halo = reinterpret_cast<bf16_t*>(red + 32);              // [HR][HW_][LDP]
+  bf16_t* wl = halo + HR * HW_ * LDP;                              // [4][LDW]
+  const int t = threadIdx.x, lane = t & 63, li = lane & 15, lq = lane >> 4, wave = t >> 6;
+  const int H = g.Hin, W = g.Win, Cout = g.Cout;
+  const int bx = W / C9O_W;
+  const int b = blockIdx.y, y0 = (blockIdx.x / bx) * C9O_R, x0 = (blockIdx.x % bx) * C9O_W;
+  const bf16_t* X = reinterpret_cast<const bf16_t*>(g.X);
+  const bf16_t* Wg = reinterpret_cast<const bf16_t*>(g.W);
+  bf16_t* Y = reinterpret_cast<bf16_t*>(g.Y);
+  if (t < 32) {
+    float sc = 1.f, sh = 0.f;
+    if (g.coef) { sc = g.coef[((size_t)b * 32 + t) * 2]; sh = g.coef[((size_t)b * 32 + t) * 2 + 1]; }
+    cf[t] = sc; cf[32 + t] = sh;
+  }
+  for (int i = t; i < 4 * (KK * 4); i += 256) {                    // weight rows (zero rows past Cout), 16-byte granules
+    const int r = i / (KK * 4), v = i % (KK * 4);
+    uint4 u = make_uint4(0, 0, 0, 0);
+    if (r < Cout) u = *reinterpret_cast<const uint4*>(Wg + (size_t)r * KK * 32 + v * 8);
+    *reinterpret_cast<uint4*>(wl + r * LDW + v * 8) = u;
+  }
+  __syncthreads();
+  // halo: HR x HW_ pixels x 4 channel vectors, reflection + instance norm + style affine + ReLU on the way in, 5 loads in flight
+  constexpr int total = HR * HW_ * 4;
+  for (int i0 = t; i0 < total; i0 += 256 * 5) {
+    Raw8<bf16_t> r[5];
+    int dst[5], cvs[5];
+#pragma unroll
+    for (int u = 0; u < 5; ++u) {
+      const int i = i0 + 256 * u, ic = i < total ? i : total - 1;
+      const int cv = ic & 3, hp = ic >> 2, hy = hp / HW_, hx = hp % HW_;
+      const int sy = reflecti(y0 - 4 + hy, H), sx = reflecti(x0 - 4 + hx, W);
+      r[u] = ldraw<bf16_t>(X + ((size_t)(b * H + sy) * W + sx) * 32 + cv * 8);
+      dst[u] = i < total ? hp * LDP + cv * 8 : -1;
+      cvs[u] = cv;
+    }
+#pragma unroll
+    for (int u = 0; u < 5; ++u) {
+      if (dst[u] < 0) continue;
+      float v[8];
+      cvt8(r[u], v);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float uu = v[j] * cf[cvs[u] * 8 + j] + cf[32 + cvs[u] * 8 + j];
+        v[j] = g.relu ? fmaxf(uu, 0.f) : uu;
+      }
+      st8<bf16_t>(halo + dst[u], v);
+    }
+  }
+  __syncthreads();
+  // wave w: rows 2w, 2w+1 x two 16-column groups
+  f32x4_t acc[4];
+#pragma unroll
+  for (int p = 0; p < 4; ++p) acc[p] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  const bf16_t* hb[4];
+#pragma unroll
+  for (int p = 0; p < 4; ++p) hb[p] = halo + ((wave * 2 + (p >> 1)) * HW_ + (p & 1) * 16 + li) * LDP + lq * 8;
+  const bf16_t* wrow = wl + (li < 4 ? li : 0) * LDW + lq * 8;
+  const bool wok = li < 4;
+  for (int ky = 0; ky < 9; ++ky)
+#pragma unroll
+    for (int kx = 0; kx < 9; ++kx) {
+      uint4 au = make_uint4(0, 0, 0, 0);
+      if (wok) au = *reinterpret_cast<const uint4*>(wrow + (ky * 9 + kx) * 32);
+      const bf16x8_t af = __builtin_bit_cast(bf16x8_t, au);
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        const bf16x8_t bf = *reinterpret_cast<const bf16x8_t*>(hb[p] + (ky * HW_ + kx) * LDP);
+        acc[p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bf, acc[p], 0, 0, 0);
+      }
+    }
+  // epilogue: lanes lq == 0 hold channels 0..3 of their pixel
+  float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+  if (lq == 0) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int oy = y0 + wave * 2 + (p >> 1), ox = x0 + (p & 1) * 16 + li;
+      float v[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = acc[p][e] + ((g.bias && e < Cout) ? g.bias[e] : 0.f);
+      uint2 o;
+      o.x = pack_bf16x2(v[0], v[1]); o.y = pack_bf16x2(v[2], v[3]);
+      *reinterpret_cast<uint2*>(Y + ((size_t)(b * H + oy) * W + ox) * g.ldc) = o;
+      const float r[4] = {__uint_as_float(o.x << 16), __uint_as_float(o.x & 0xffff0000u), __uint_as_float(o.y << 16),
+                          __uint_as_float(o.y & 0xffff0000u)};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { s1[e] += r[e]; s2[e] += r[e] * r[e]; }
+    }
+  }
+  if (g.stats) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float a1 = row16_sum(s1[e]), a2 = row16_sum(s2[e]);
+      if (lane == 0) { red[(wave * 4 + e) * 2] = a1; red[(wave * 4 + e) * 2 + 1] = a2; }
+    }
+    __syncthreads();
+    if (t < Cout * 2)
+      atomicAdd(g.stats + (size_t)b * Cout * 2 + t, red[t] + red[8 + t] + red[16 + t] + red[24 + t]);
+  }
+}
+
 // ------------------------------------------------------------------------------------------- first layer: 3 -> 32, 9x9
 // x fp32 NCHW [B,3,H,W]; w fp32 [32][3][9][9] (PyTorch layout); y bf16 NHWC [B,H,W,32] raw conv (+bias); stats [B][32][2].
 // A workgroup owns a band of C9_R output rows of one image (blockIdx.y): the C9_R+8 input rows it needs are staged ONCE in LDS
@@ -603,6 +714,9 @@ __global__ void final_sigmoid_kernel(const bf16_t* Z, const float* coef, float* 
 static int g_gconv_slab = 1;
 extern "C" int spb_debug_set_gconv_slab(int on) { g_gconv_slab = on; return 0; }
 
+static int g_conv9_band = 1;
+extern "C" int spb_debug_set_conv9_band(int on) { g_conv9_band = on; return 0; }
+
 extern "C" int spb_gconv(int dtype, const spb_gconv_args_t* a, spb_stream_t stream) {
   if (!a || !a->X || !a->W || !a->Y) return SPB_E_ARG;
   if (dtype != SPB_BF16) return SPB_E_UNSUPPORTED;
@@ -613,6 +727,15 @@ extern "C" int spb_gconv(int dtype, const spb_gconv_args_t* a, spb_stream_t stre
   const int Hout = Hu / a->stride, Wout = Wu / a->stride;
   if ((Hout & 7) || (Wout & 7) || a->ldc < a->Cout || (a->ldc & 3)) return SPB_E_SHAPE;
   if (a->KH / 2 >= Hu || a->KH / 2 >= Wu) return SPB_E_SHAPE;   // reflection padding needs pad < size
+  if (g_conv9_band && a->KH == 9 && a->Cin == 32 && a->Cout <= 4 && a->stride == 1 && a->upsample == 1 && !(Wout % C9O_W) &&
+      !(Hout % C9O_R) && a->ldc >= 4) {
+    const size_t ldsb = (64 + 32) * sizeof(float) + ((size_t)(C9O_R + 8) * (C9O_W + 8) * 40 + (size_t)4 * (81 * 32 + 8)) * sizeof(bf16_t);
+    static bool onceb = false;
+    if (!onceb) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv9_band_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); onceb = true; }
+    hipLaunchKernelGGL(conv9_band_kernel, dim3((unsigned)((Hout / C9O_R) * (Wout / C9O_W)), (unsigned)a->B), dim3(256), ldsb, (hipStream_t)stream, *a);
+    SPB_CHECK_LAUNCH();
+    return 0;
+  }
   const int HT = 7 * a->stride + a->KH, KK = a->KH * a->KH;
   const int NB = a->Cout <= 16 ? 1 : (a->Cout <= 32 ? 2 : (a->Cout <= 64 ? 4 : 8));
   // fragment-order slots span all NB*16 rows (NB == 1: slot == row, Cout rows are enough)
