@@ -29,7 +29,8 @@ parser.add_argument('--randomize_texture', dest='randomize_texture', action='sto
 parser.add_argument('--perform_dann', dest='dann', action='store_true', default=False)
 parser.add_argument('--texture_alpha', type=float, default=0.5)
 parser.add_argument('--texture_ratio', type=float, default=0.5)
-parser.add_argument('--use_fp16', dest='fp16', action='store_true', default=False)
+parser.add_argument('--use_fp16', dest='fp16', action='store_true', default=False,
+                    help='reference: fp16 autocast + GradScaler; here: bfloat16 compute, no loss scaling (a warning is logged)')
 parser.add_argument('--batch_size', type=int, default=32)
 parser.add_argument('--max_epochs', type=int, default=75)
 parser.add_argument('--num_workers', type=int, default=8)

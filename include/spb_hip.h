@@ -381,6 +381,8 @@ int spb_dropout(int dtype, void* y, unsigned char* mask, long long n, float p, u
  * dlogits (may be NULL) = d(weight*loss)/dlogits */
 int spb_softce(int dtype, const void* logits, const float* target, void* dlogits, float* out, int slot, int B, int C, float weight,
                spb_stream_t stream);
+/* the same with reduction='none' (spn.py:43-44): rows[b] = -sum_c target[b][c] * log_softmax(logits[b])[c] */
+int spb_softce_rows(int dtype, const void* logits, const float* target, float* rows, int B, int C, spb_stream_t stream);
 /* out[n] += sum_m g[m][n] (bias gradients) */
 int spb_colsum(int dtype, const void* g, float* out, long long M, int N, spb_stream_t stream);
 
@@ -469,6 +471,7 @@ int spb_debug_set_gemm_bk64_min_k(int k); /* small-M bf16 GEMMs with K >= k use 
 int spb_debug_set_gconv_slab(int on); /* 0: wide decoder convs use the per-wave weight-streaming kernel */
 int spb_debug_set_side_wgrad(int on); /* 0: pointwise weight gradients stay on the launch stream */
 int spb_debug_set_dw_rows(int rows); /* rows per row unit (0: automatic) */
+int spb_debug_set_gemm_sk(int on, int min_k, int rf); /* small-M bf16 GEMMs with K >= min_k (default 192): split-K-over-waves kernel (on=1, default); rf > 0 forces 16*rf-row tiles */
 const char* spb_version(void);
 
 #ifdef __cplusplus

@@ -172,6 +172,7 @@ SYMBOLS = {
     "spb_relu_bwd": (i32, [i32, vp, vp, vp, vp, i64, f32, vp]),
     "spb_dropout": (i32, [i32, vp, vp, i64, f32, C.c_ulonglong, i32, vp]),
     "spb_softce": (i32, [i32, vp, vp, vp, vp, i32, i32, i32, f32, vp]),
+    "spb_softce_rows": (i32, [i32, vp, vp, vp, i32, i32, vp]),
     "spb_colsum": (i32, [i32, vp, vp, i64, i32, vp]),
     "spb_preproc_max_taps": (i32, []),
     "spb_preproc_batch": (i32, [C.POINTER(PreprocArgs), vp]),
@@ -202,6 +203,7 @@ SYMBOLS = {
     "spb_debug_set_stem_mfma": (i32, [i32]),
     "spb_debug_set_fused_pw_bwd": (i32, [i32]),
     "spb_debug_set_dw_rows": (i32, [i32]),
+    "spb_debug_set_gemm_sk": (i32, [i32, i32, i32]),
     "spb_version": (C.c_char_p, []),
 }
 

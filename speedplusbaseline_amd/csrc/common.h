@@ -123,6 +123,23 @@ __device__ __forceinline__ float act_grad(float u, int act, float slope) {
 // between a convolution and the next one.
 typedef spb_bnref_t BNRef;
 
+// The two per-channel sums of a tensor, added over its R <= SPB_MAX_REPLICAS replicas.  All 2 * SPB_MAX_REPLICAS loads are
+// issued back to back on clamped replica indices and masked afterwards: a loop with the runtime bound R makes every load
+// wait for the previous one (one memory round trip per replica -- measured: ~1 us per kernel per 14 loads), which is what
+// kept the replica count of the small tensors at 1 and their atomics serialised on one address.
+#define SPB_MAX_REPLICAS 8
+__device__ __forceinline__ void bn_replica_sums(const float* base, int R, int C, int c, float& a, float& b) {
+  float va[SPB_MAX_REPLICAS], vb[SPB_MAX_REPLICAS];
+#pragma unroll
+  for (int i = 0; i < SPB_MAX_REPLICAS; ++i) {
+    const size_t o = (size_t)(i < R ? i : 0) * 2 * C + c;
+    va[i] = base[o]; vb[i] = base[o + C];
+  }
+  a = 0.f; b = 0.f;
+#pragma unroll
+  for (int i = 0; i < SPB_MAX_REPLICAS; ++i) { a += i < R ? va[i] : 0.f; b += i < R ? vb[i] : 0.f; }
+}
+
 // mean / inverse std of channel c
 __device__ __forceinline__ void bn_moments(const BNRef& r, int c, float& mean, float& invstd) {
   if (r.moments) {  // eval: sums holds [mean | var]
@@ -130,11 +147,8 @@ __device__ __forceinline__ void bn_moments(const BNRef& r, int c, float& mean, f
     invstd = rsqrtf(r.sums[r.C + c] + r.eps);
     return;
   }
-  float s = 0.f, q = 0.f;
-  for (int i = 0; i < r.R; ++i) {
-    s += r.sums[(size_t)i * 2 * r.C + c];
-    q += r.sums[(size_t)i * 2 * r.C + r.C + c];
-  }
+  float s, q;
+  bn_replica_sums(r.sums, r.R, r.C, c, s, q);
   mean = s * r.inv_n;
   float var = fmaxf(q * r.inv_n - mean * mean, 0.f);
   invstd = rsqrtf(var + r.eps);
@@ -152,15 +166,41 @@ __device__ __forceinline__ void bn_bwd_coef(const BNRef& r, int c, float& p0, fl
   if (r.gamma == nullptr) { p0 = 1.f; p1 = 0.f; p2 = 0.f; return; }
   float mean, is;
   bn_moments(r, c, mean, is);
-  float s1 = 0.f, s2 = 0.f;
-  for (int i = 0; i < r.R; ++i) {
-    s1 += r.bsums[(size_t)i * 2 * r.C + c];
-    s2 += r.bsums[(size_t)i * 2 * r.C + r.C + c];
-  }
+  float s1, s2;
+  bn_replica_sums(r.bsums, r.R, r.C, c, s1, s2);
   s1 *= r.inv_n; s2 *= r.inv_n;
   p0 = r.gamma[c] * is;
   p1 = -p0 * is * s2;
   p2 = p0 * (mean * is * s2 - s1);
+}
+
+// Per-channel prologue table of a 256-thread workgroup: coef[0..Kp) = c0, coef[Kp..2Kp) = c1, coef[2Kp..3Kp) = c2 for
+// MODE 1 (forward: scale, shift, 0) or MODE 2 (BN backward: p0, p1, p2); channels >= K get zeros.  A thread owns channels
+// t, t+256, ...; it derives G of them per pass from clamped, branch-free loads, so a 960-channel table costs two memory
+// round trips instead of four (a `for (c = t; c < K; c += 256)` loop waits for every channel's loads before the next
+// channel's are issued: measured ~1.5 us per iteration on the 7x7 layers).
+template <int MODE>
+__device__ __forceinline__ void bn_coef_table(const BNRef& r, int K, int Kp, float* coef, int t) {
+  constexpr int G = MODE == 1 ? 3 : 2;
+  for (int cb = t; cb < Kp; cb += 256 * G) {
+    float c0[G], c1[G], c2[G];
+#pragma unroll
+    for (int j = 0; j < G; ++j) {
+      const int c = cb + 256 * j;
+      const int cc = c < K ? c : K - 1;
+      c0[j] = 0.f; c1[j] = 0.f; c2[j] = 0.f;
+      if (MODE == 1) bn_fwd_coef(r, cc, c0[j], c1[j]);
+      else bn_bwd_coef(r, cc, c0[j], c1[j], c2[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < G; ++j) {
+      const int c = cb + 256 * j;
+      if (c < Kp) {
+        const bool ok = c < K;
+        coef[c] = ok ? c0[j] : 0.f; coef[Kp + c] = ok ? c1[j] : 0.f; coef[2 * Kp + c] = ok ? c2[j] : 0.f;
+      }
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -19,6 +19,8 @@
 #include "common.h"
 #include <hip/hip_ext.h>
 
+int spb_gemm_sk(const spb_gemm_args_t* a, hipStream_t stream);   // gemm_sk.hip
+
 // phase timestamps for scratch/ubench_gemm.hip (compiled out in the product build)
 #ifndef SPB_TS
 #define SPB_TS(i)
@@ -74,14 +76,7 @@ __global__ __launch_bounds__(256, (RF == 1 && sizeof(T) == 2) ? ((BK == 64 && PR
   const int li = l & 15, lq = l >> 4;
 
   // ---- prologue coefficients for every reduction channel (derived from the producer's raw batch sums)
-  for (int c = t; c < Kp; c += 256) {
-    float c0 = 0.f, c1 = 0.f, c2 = 0.f;
-    if (c < K) {
-      if (PRO == 1) bn_fwd_coef(g.pro, c, c0, c1);
-      else bn_bwd_coef(g.pro, c, c0, c1, c2);
-    }
-    coef[c] = c0; coef[Kp + c] = c1; coef[2 * Kp + c] = c2;
-  }
+  bn_coef_table<PRO == 1 ? 1 : 2>(g.pro, K, Kp, coef, t);
 
   const int NT = (N + BN - 1) / BN;
   const int MT = (M + BM - 1) / BM;
@@ -439,14 +434,7 @@ __global__ __launch_bounds__(256) void pw_gemm_dma_kernel(const spb_gemm_args_t 
 
   // ---- prologue coefficients (ordinary loads; they complete before the first counted wait)
   if (PRO != 0)
-  for (int c = t; c < Kp; c += 256) {
-    float c0 = 0.f, c1 = 0.f, c2 = 0.f;
-    if (c < K) {
-      if (PRO == 1) bn_fwd_coef(g.pro, c, c0, c1);
-      else bn_bwd_coef(g.pro, c, c0, c1, c2);
-    }
-    coef[c] = c0; coef[Kp + c] = c1; coef[2 * Kp + c] = c2;
-  }
+  bn_coef_table<PRO == 1 ? 1 : 2>(g.pro, K, Kp, coef, t);
   const int vcol = t % NV, vrow0 = t / NV;
   const int nE = n0 + vcol * 8;
   const bool colok = nE < N;
@@ -859,7 +847,12 @@ extern "C" int spb_pwconv_gemm(int dtype, const spb_gemm_args_t* a, spb_stream_t
   if (a->M <= 0 || a->K <= 0 || a->N <= 0 || (a->K & 7) || (a->N & 7)) return SPB_E_SHAPE;
   if (a->epi_mode != 0 && (!a->osums || a->oR < 1)) return SPB_E_ARG;
   if (a->epi_mode == 2 && !a->Zout) return SPB_E_ARG;
-  if (dtype == SPB_BF16) return dispatch_modes<bf16_t>(*a, (hipStream_t)stream);
+  if (dtype == SPB_BF16) {
+    // the 14x14 / 7x7 maps with a long reduction: split-K over the waves of a workgroup (gemm_sk.hip)
+    const int e = spb_gemm_sk(a, (hipStream_t)stream);
+    if (e != SPB_E_UNSUPPORTED) return e;
+    return dispatch_modes<bf16_t>(*a, (hipStream_t)stream);
+  }
   if (dtype == SPB_F32) return dispatch_modes<float>(*a, (hipStream_t)stream);
   return SPB_E_ARG;
 }

@@ -239,9 +239,11 @@ extern "C" int spb_debug_set_wgrad_batch(int n) {
   return 0;
 }
 static long long g_replica_min_rows = 32768;   // BN-sum replicas (8) from this many rows up; spb_debug_set_replica_rows
-static int g_replica_mid = 1;   // replicas for tensors with 4096 <= rows < g_replica_min_rows (the 14x14 maps at bs=48)
+static int g_replica_mid = 1;   // replicas for tensors with 4096 <= rows < g_replica_min_rows (the 14x14 maps at bs=48).  Measured with 8
+                                // (round 2, all replica loads of a channel in flight together): producers -1 us (their atomics
+                                // spread over 8 addresses), every consumer +2 us (16 instead of 2 loads per channel): stays 1
 extern "C" int spb_debug_set_replica_rows(long long rows) {
-  if (rows < 0) { g_replica_mid = (int)-rows; return 0; }   // negative: set the mid-size replica count instead
+  if (rows < 0) { g_replica_mid = (int)(-rows > SPB_MAX_REPLICAS ? SPB_MAX_REPLICAS : -rows); return 0; }   // negative: set the mid-size replica count instead
   g_replica_min_rows = rows;
   return 0;
 }

@@ -239,7 +239,7 @@ __global__ void dropout_kernel(T* __restrict__ y, unsigned char* __restrict__ ma
 // out[0] += weight * mean-over-rows contribution, out[slot] += unweighted mean (for the two reported losses)
 template <typename T>
 __global__ __launch_bounds__(256) void softce_kernel(const T* __restrict__ logits, const float* __restrict__ target, T* __restrict__ dlogits,
-                                                     float* out, int slot, int Bn, int Cn, float weight) {
+                                                     float* out, int slot, int Bn, int Cn, float weight, float* rows) {
   __shared__ float red[256];
   const int b = blockIdx.x, t = threadIdx.x;
   const T* x = logits + (size_t)b * Cn;
@@ -263,8 +263,11 @@ __global__ __launch_bounds__(256) void softce_kernel(const T* __restrict__ logit
   const float lse = m + logf(se);
   if (t == 0) {
     const float l = (lse * st - sx) / (float)Bn;
-    atomicAdd(out, weight * l);
-    atomicAdd(out + slot, l);
+    if (out) {
+      atomicAdd(out, weight * l);
+      atomicAdd(out + slot, l);
+    }
+    if (rows) rows[b] = lse * st - sx;      // reduction='none' (spn.py:43-44): the per-sample loss
   }
   if (dlogits) {
     const float gs = weight / (float)Bn;
@@ -463,8 +466,16 @@ extern "C" int spb_softce(int dtype, const void* logits, const float* target, vo
                           float weight, spb_stream_t stream) {
   if (!logits || !target || !out || B <= 0 || C <= 0 || slot < 1) return SPB_E_ARG;
   hipStream_t s = (hipStream_t)stream;
-  SPN_T(dtype, hipLaunchKernelGGL(softce_kernel<bf16_t>, dim3(B), dim3(256), 0, s, (const bf16_t*)logits, target, (bf16_t*)dlogits, out, slot, B, C, weight),
-        hipLaunchKernelGGL(softce_kernel<float>, dim3(B), dim3(256), 0, s, (const float*)logits, target, (float*)dlogits, out, slot, B, C, weight))
+  SPN_T(dtype, hipLaunchKernelGGL(softce_kernel<bf16_t>, dim3(B), dim3(256), 0, s, (const bf16_t*)logits, target, (bf16_t*)dlogits, out, slot, B, C, weight, (float*)nullptr),
+        hipLaunchKernelGGL(softce_kernel<float>, dim3(B), dim3(256), 0, s, (const float*)logits, target, (float*)dlogits, out, slot, B, C, weight, (float*)nullptr))
+  SPB_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int spb_softce_rows(int dtype, const void* logits, const float* target, float* rows, int B, int C, spb_stream_t stream) {
+  if (!logits || !target || !rows || B <= 0 || C <= 0) return SPB_E_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  SPN_T(dtype, hipLaunchKernelGGL(softce_kernel<bf16_t>, dim3(B), dim3(256), 0, s, (const bf16_t*)logits, target, (bf16_t*)nullptr, (float*)nullptr, 0, B, C, 1.f, rows),
+        hipLaunchKernelGGL(softce_kernel<float>, dim3(B), dim3(256), 0, s, (const float*)logits, target, (float*)nullptr, (float*)nullptr, 0, B, C, 1.f, rows))
   SPB_CHECK_LAUNCH();
   return 0;
 }

@@ -13,7 +13,20 @@ def _precision(cfg):
     p = getattr(cfg, "precision", None)
     if p:
         return p
-    return "bf16" if getattr(cfg, "fp16", False) else None  # --use_fp16 selects the reduced-precision (bf16) kernels
+    if getattr(cfg, "fp16", False):
+        # reference: torch.cuda.amp autocast (float16) + GradScaler (train.py:101-104, trainer.py:73-94).  The MI355X kernels
+        # compute in bfloat16 with f32 accumulation / master weights / statistics instead: same 16-bit operand width and
+        # matrix-core rate, f32's exponent range, so no loss scaling (and no inf-check host sync) is needed.
+        global _warned_fp16
+        if not _warned_fp16:
+            logger.warning("--use_fp16: float16 autocast + GradScaler is replaced by bfloat16 compute (no loss scaling); "
+                           "pass --precision bf16 to select it explicitly")
+            _warned_fp16 = True
+        return "bf16"
+    return None
+
+
+_warned_fp16 = False
 
 
 def get_model(cfg):

@@ -3,8 +3,8 @@
 Same constructor, attributes, state_dict keys (conv1..conv5, fc6..fc11 `.weight` / `.bias`) and return values as the
 reference class; forward, loss and backward are HIP launches through the C-ABI (include/spb_hip.h):
 every convolution is a matrix-core GEMM (spb_pwconv_gemm with the bias + ReLU epilogue, spb_pwconv_wgrad) on im2col'd NHWC
-operands, with the pooling / LRN / soft-target cross-entropy kernels of csrc/spn.hip in between; grouped convolutions run
-as block-diagonal full convolutions.  The fully connected layers (150 M of the 152 M parameters) are weight streams at
+operands, with the pooling / LRN / soft-target cross-entropy kernels of csrc/spn.hip in between; grouped convolutions
+(conv2/4/5, groups=2) run as one dense GEMM per group on that group's own column slab.  The fully connected layers (150 M of the 152 M parameters) are weight streams at
 training batch sizes: in bf16 with B <= 64 they use the skinny kernels of csrc/spn_fc.hip (each weight element read once
 per pass straight from a bf16 shadow arena the optimizer maintains; gradients written once, in place, into the flat
 gradient arena).  f32 (parity mode) and larger batches go through the general GEMM kernels.  No CPU / eager fallback.
@@ -39,14 +39,18 @@ def softmax_cross_entropy_with_logits(logits, target, reduction="mean"):
     """spn.py:37-48 on the GPU (HIP kernel): -sum(target * log_softmax(logits), 1) reduced over the batch"""
     if not logits.is_cuda:
         raise RuntimeError("softmax_cross_entropy_with_logits needs cuda tensors (no CPU path)")
-    if reduction not in ("mean", "sum"):
-        raise NotImplementedError("reduction='none' is not provided by the HIP kernel")
+    if reduction not in ("mean", "sum", "none"):
+        raise ValueError("reduction must be 'mean', 'sum' or 'none' (spn.py:45-48)")
     B, Cn = logits.shape
     lg = logits.detach().contiguous()
     lg = lg if lg.dtype in (torch.float32, torch.bfloat16) else lg.float()
+    tg = target.detach().float().contiguous()
+    if reduction == "none":
+        rows = torch.empty(B, dtype=torch.float32, device=logits.device)
+        L.check(L.lib().spb_softce_rows(ops.dtype_code(lg), _p(lg), _p(tg), _p(rows), B, Cn, _st()), "spb_softce_rows")
+        return rows
     out = torch.zeros(3, dtype=torch.float32, device=logits.device)
-    L.check(L.lib().spb_softce(ops.dtype_code(lg), _p(lg), _p(target.detach().float().contiguous()), None, _p(out), 1, B, Cn, 1.0,
-                               _st()), "spb_softce")
+    L.check(L.lib().spb_softce(ops.dtype_code(lg), _p(lg), _p(tg), None, _p(out), 1, B, Cn, 1.0, _st()), "spb_softce")
     return out[1] * (B if reduction == "sum" else 1)
 
 
@@ -88,19 +92,23 @@ class SpacecraftPoseNet(nn.Module):
         if pretrain:
             self.load_weights('checkpoints/pretrained/bvlc_alexnet.npy')
 
-    # ---- spn.py:104-123
     def load_weights(self, weight_path):
+        """AlexNet trunk from a caffe-tensorflow `bvlc_alexnet.npy` (spn.py:104-123): a pickled dict layer -> [filters HWIO,
+        bias]; only conv1..conv5 are taken (the fully connected layers start from their random init), filters go to
+        nn.Conv2d's [Cout, Cin/groups, KH, KW] order."""
         import numpy as np
-        weights_dict = np.load(weight_path, allow_pickle=True, encoding='bytes').item()
+        blob = np.load(weight_path, allow_pickle=True, encoding='bytes').item()
+        blob = {(k.decode() if isinstance(k, bytes) else k): v for k, v in blob.items()}
         with torch.no_grad():
-            for name in weights_dict:
-                if name in ['conv1', 'conv2', 'conv3', 'conv4', 'conv5']:
-                    for data in weights_dict[name]:
-                        if len(data.shape) == 4:
-                            data = np.transpose(data, (3, 2, 0, 1))   # [H, W, Cin, Cout] -> [Cout, Cin, H, W]
-                            getattr(self, name).weight.copy_(torch.from_numpy(data).float())
-                        else:
-                            getattr(self, name).bias.copy_(torch.from_numpy(data).float())
+            for layer in ('conv1', 'conv2', 'conv3', 'conv4', 'conv5'):
+                for arr in blob.get(layer, ()):
+                    arr = np.asarray(arr)
+                    is_filter = arr.ndim == 4
+                    dst = getattr(self, layer).weight if is_filter else getattr(self, layer).bias
+                    src = torch.from_numpy(np.ascontiguousarray(arr.transpose(3, 2, 0, 1) if is_filter else arr)).float()
+                    if src.shape != dst.shape:
+                        raise ValueError("%s: %s in %s does not fit %s" % (layer, tuple(src.shape), weight_path, tuple(dst.shape)))
+                    dst.copy_(src)
         self.invalidate()
 
     def invalidate(self):
@@ -362,53 +370,64 @@ class SpacecraftPoseNet(nn.Module):
             torch.cuda.current_stream().wait_stream(self._side)
             self._side_used = False
 
-    def _start_fc_exchange(self, group, compress_bf16):
-        """all-reduce of gflat[conv_end:] on the communication stream, ordered after everything enqueued so far"""
+    def _start_exchange(self, group, compress_bf16, lo, hi):
+        """all-reduce of gflat[lo:hi] on the communication stream, ordered after everything enqueued so far (launch stream and
+        the weight-gradient side stream).  compress_bf16: the bucket travels as bfloat16 -- half the bytes on the xGMI links;
+        the sum is then rounded to bfloat16 per hop, like torch's bf16_compress_hook."""
         from ..parallel import allreduce_sum_async
         if getattr(self, "_comm", None) is None:
             self._comm = torch.cuda.Stream(device=self._gflat.device)
-        tail = self._gflat[self._conv_end:]
+        part = self._gflat[lo:hi]
         self._comm.wait_stream(torch.cuda.current_stream())
         if getattr(self, "_side_used", False):
             self._comm.wait_stream(self._side)        # the fc weight gradients come from the side stream
         with torch.cuda.stream(self._comm):
             if compress_bf16:
-                buf = self._buf("ddp_bf16", (tail.numel(),), torch.bfloat16)
-                buf.copy_(tail)
-                w = allreduce_sum_async(buf, group)
-                return [("bf16", w, buf, tail)]
-            return [("f32", allreduce_sum_async(tail, group), None, tail)]
+                buf = self._buf("ddp_bf16_%d" % lo, (part.numel(),), torch.bfloat16)
+                buf.copy_(part)
+                return ("bf16", allreduce_sum_async(buf, group), buf, part)
+            return ("f32", allreduce_sum_async(part, group), None, part)
 
     def finish_gradient_exchange(self, group=None):
-        """called by SpnOptimizer.step before the update: waits for the overlapped bucket, reduces the convolution bucket"""
+        """called by SpnOptimizer.step before the update (idempotent per backward pass): waits for the overlapped buckets and
+        reduces what has not been exchanged yet (the convolution bucket; everything when no exchange was started)"""
         from ..parallel import allreduce_sum_
+        if getattr(self, "_ddp_finished", True):
+            return
+        self._ddp_finished = True
         works, self._ddp_works = getattr(self, "_ddp_works", None), None
-        if works is None:
+        if not works:
             allreduce_sum_(self._gflat, group)
             return
-        for kind, w, buf, tail in works:
+        for kind, w, buf, part in works:
             with torch.cuda.stream(self._comm):
                 if w is not None:
                     w.wait()                      # the communication stream waits for the collective
                 if kind == "bf16":
-                    tail.copy_(buf)
+                    part.copy_(buf)
         torch.cuda.current_stream().wait_stream(self._comm)
         allreduce_sum_(self._gflat[:self._conv_end], group)
 
     # ---- one training step's loss + gradients (trainer.py:146-177): loss = softCE(c, yClasses) + 10 softCE(r, yWeights)
-    def loss_and_grads(self, x, y_classes, y_weights, masks=None, world_size=1, group=None, compress_bf16=False):
+    def loss_and_grads(self, x, y_classes, y_weights, masks=None, world_size=1, group=None, compress_bf16=None):
         """Runs forward (training mode), the loss and the backward pass; gradients land in p.grad of every parameter
         (views of the flat gradient arena).  Returns a device tensor (loss, loss_class, loss_regress).
 
         world_size > 1 (one process per GPU): the fully connected layers' gradients -- the tail of the arena, 600 of the 609 MB,
         final before the convolution trunk's backward starts -- are summed across ranks on a communication stream while the
-        trunk's backward runs; SpnOptimizer.step waits for that work and reduces the small convolution bucket itself.
-        compress_bf16 sends that bucket as bfloat16 (half the bytes on the xGMI links; the sum is then rounded to bfloat16
-        per hop, like torch's bf16_compress_hook)."""
+        trunk's backward runs, in two buckets (the class head's as soon as its weight gradients are queued, beside the regression
+        head's backward; the regression head's beside the trunk); SpnOptimizer.step waits for them and reduces the small
+        convolution bucket itself.  compress_bf16 (default: on in bf16 mode) sends those buckets as bfloat16: half the bytes
+        on the xGMI links, the sum rounded to bfloat16 per hop like torch's bf16_compress_hook; False keeps float32."""
         lib = L.lib()
         dt, dc = self._dt(), (L.BF16 if self.precision == "bf16" else L.F32)
         c, r = self._forward_impl(x, True, masks)
         self._step += 1
+        self._ddp_finished = False       # SpnOptimizer.step(world_size > 1) exchanges whatever has not been exchanged yet
+        self._ddp_works = []
+        if compress_bf16 is None:
+            compress_bf16 = self.precision == "bf16"
+        head2_lo = self._offs["fc9.weight"][0]
         sv, cp = self._saved, self._copies
         B, fast = sv["B"], sv["fast"]
         st = _st()
@@ -425,7 +444,10 @@ class SpacecraftPoseNet(nn.Module):
             acc, accF = self._acc("acc", max(4096, NC), MP), self._acc("accF", 9216, MP)
             pend = []
             for names, g in ((("fc6", "fc7", "fc8"), dcg), (("fc9", "fc10", "fc11"), drg)):
-                self._on_side(pend); pend = []       # the first head's weight gradients run beside the second head's chain
+                self._on_side(pend)                  # the first head's weight gradients run beside the second head's chain
+                if pend and world_size > 1:          # ... and their exchange starts as soon as they are through
+                    self._ddp_works.append(self._start_exchange(group, compress_bf16, self._conv_end, head2_lo))
+                pend = []
                 a, b_, c_ = names
                 gT = self._buf("gT" + c_, (NC, MP), dt)
                 self._epi(B, NC, 1, src=g, YT=gT, db=getattr(self, c_).bias.grad)
@@ -462,9 +484,9 @@ class SpacecraftPoseNet(nn.Module):
                     else:
                         df = dx if df is None else df + dx
             g_act = df.view(B, 256, 36).permute(0, 2, 1).contiguous()    # NCHW flatten order -> NHWC
-        self._ddp_works = None
         if world_size > 1:
-            self._ddp_works = self._start_fc_exchange(group, compress_bf16)
+            lo = head2_lo if self._ddp_works else self._conv_end
+            self._ddp_works.append(self._start_exchange(group, compress_bf16, lo, self._gflat.numel()))
         # trunk, last to first
         dwp = self._buf("dWp", (sum(cp[n].numel() for n, *_ in _CONVS),), torch.float32)
         dwp.zero_()

@@ -162,7 +162,9 @@ class SpnOptimizer(torch.optim.Optimizer):
         from .parallel import allreduce_sum_, mean_scale
         mdl = self._model
         flat, gflat = mdl.flat_parameters(), mdl.flat_grads()
-        if self._m is None or self._m.numel() != flat.numel() or self._m.device != flat.device:
+        if self._m is not None and self._m.numel() == flat.numel() and self._m.device != flat.device:
+            self._m, self._v = self._m.to(flat.device), self._v.to(flat.device)       # restored from a checkpoint (CPU)
+        if self._m is None or self._m.numel() != flat.numel():
             self._m, self._v = torch.zeros_like(flat), torch.zeros_like(flat)
         g = self.param_groups[0]
         b1, b2 = self._betas(g["kind"], g["momentum"])
@@ -186,11 +188,12 @@ class SpnOptimizer(torch.optim.Optimizer):
         return sd
 
     def load_state_dict(self, sd):
+        """train.py keeps the reference's order (get_optimizer, load_checkpoint, model.to(device)), so the model may still be
+        on the CPU here: the moments stay where the checkpoint put them and step() moves them next to the arena."""
         sd = dict(sd)
         st = sd.pop("spn_fused", None)
         super().load_state_dict(sd)
         if st is not None:
-            self._t = st["t"]
-            dev = self._model.flat_parameters().device
-            self._m = None if st["m"] is None else st["m"].to(dev)
-            self._v = None if st["v"] is None else st["v"].to(dev)
+            self._t = int(st["t"])
+            self._m = None if st["m"] is None else st["m"].detach().float().reshape(-1)
+            self._v = None if st["v"] is None else st["v"].detach().float().reshape(-1)

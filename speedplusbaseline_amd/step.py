@@ -52,7 +52,11 @@ class FusedTrainStep:
         ops.grad_sqnorm(engine.grads, self.sq)     # first call allocates the library's reduction scratch (never inside a graph capture)
         self.gmul = torch.full((1,), mean_scale(self.world), dtype=torch.float32, device=dev) if self.world > 1 else None
         self.hyper = torch.zeros(3, dtype=torch.float32, device=dev)
-        self.hyper_host = torch.zeros(3, dtype=torch.float32).pin_memory()
+        # pinned ring for the per-step scalars: the host may run several steps ahead of the GPU (nothing below synchronises),
+        # so the slot of step t is rewritten only after the event recorded behind its upload has completed
+        self._hslots = 8
+        self.hyper_host = torch.zeros(self._hslots, 3, dtype=torch.float32).pin_memory()
+        self._hyper_ev = [None] * self._hslots
         self.t = 0
         self._graphs = None
         self._static = None
@@ -68,10 +72,18 @@ class FusedTrainStep:
 
     def _refresh_hyper(self):
         b1, b2 = self._betas()
-        self.hyper_host[0] = self.lr
-        self.hyper_host[1] = 1.0 - b1 ** self.t if b1 > 0 else 1.0
-        self.hyper_host[2] = 1.0 - b2 ** self.t if b2 > 0 else 1.0
-        self.hyper.copy_(self.hyper_host, non_blocking=True)
+        i = self.t % self._hslots
+        ev = self._hyper_ev[i]
+        if ev is not None:
+            ev.synchronize()            # the upload that last read this slot (8 steps ago) is done
+        row = self.hyper_host[i]
+        row[0] = self.lr
+        row[1] = 1.0 - b1 ** self.t if b1 > 0 else 1.0
+        row[2] = 1.0 - b2 ** self.t if b2 > 0 else 1.0
+        self.hyper.copy_(row, non_blocking=True)
+        if ev is None:
+            ev = self._hyper_ev[i] = torch.cuda.Event()
+        ev.record()
 
     # ---- the three phases (phase 2, the collective, is never captured)
     def _fwd_bwd(self, x, y, xt=None, alpha=0.0):

@@ -160,16 +160,27 @@ class GpuBatchTransform:
             off = (off + 15) // 16 * 16
             out_k.append(k)
         # ---- one packed upload, three launches
-        pin = self._pin
+        # two pinned staging slots: the upload of batch i may still be in flight when batch i+1 is packed on the host
+        # (AugLookahead stages one batch ahead with no synchronisation), so a slot is rewritten only after the event recorded
+        # behind its last host-to-device copy has completed
+        slot = self._pin_slot = (getattr(self, "_pin_slot", 1) + 1) % 2
+        if self._pin is None:
+            self._pin, self._pin_ev = [None, None], [None, None]
+        if self._pin_ev[slot] is not None:
+            self._pin_ev[slot].synchronize()
+        pin = self._pin[slot]
         if pin is None or pin.numel() < off:
-            pin = self._pin = torch.empty(max(off, 1), dtype=torch.uint8).pin_memory()
+            pin = self._pin[slot] = torch.empty(max(off, 1), dtype=torch.uint8).pin_memory()
         packed = pin.numpy()
         pos = 0
         for c in crops:
             packed[pos:pos + c.size].reshape(c.shape)[...] = c
             pos = (pos + c.size + 15) // 16 * 16
         dev = self.device
-        src = self._buf("src", (off,), torch.uint8); src.copy_(pin[:off], non_blocking=True)
+        src = self._buf("src%d" % slot, (off,), torch.uint8); src.copy_(pin[:off], non_blocking=True)
+        if self._pin_ev[slot] is None:
+            self._pin_ev[slot] = torch.cuda.Event()
+        self._pin_ev[slot].record(torch.cuda.current_stream(dev))
         tab = self._buf("tab", (B, 8), torch.int32); tab.copy_(torch.from_numpy(table), non_blocking=True)
         ftab = self._buf("ftab", (B, 2), torch.float32); ftab.copy_(torch.from_numpy(ftable), non_blocking=True)
         flags_any = int(np.bitwise_or.reduce(table[:, 6])) if B else 0

@@ -21,6 +21,43 @@ ref = importlib.util.module_from_spec(spec)
 spec.loader.exec_module(ref)
 
 
+def caffe_weights(out):
+    """spn.py:104-123 run on a synthetic AlexNet file: per-tensor digests + a crop of what the reference's loader leaves"""
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "bvlc_alexnet.npy")
+        S.caffe_file(path)
+        net = ref.SpacecraftPoseNet(64, keep_prob=0.5, pretrain=False)
+        net.load_state_dict(S.init_state(64), strict=True)
+        net.load_weights(path)
+    for k, v in net.state_dict().items():
+        out["caffe_sum/" + k] = np.array(S.checksum(v))
+    out["caffe_conv2_crop"] = net.conv2.weight[:3, :4].detach().numpy().copy()
+
+
+def full_size(out):
+    """BASELINE configs[5] sizes: 5000 classes, batch 32 at 227x227.  Logit digests, a crop, the three reductions of the
+    soft-target cross-entropy and the trainer's loss; digests of the gradients of the reference loss (eval mode: dropout
+    is the identity) for every parameter."""
+    NC, B = 5000, 32
+    net = ref.SpacecraftPoseNet(NC, keep_prob=0.5, pretrain=False)
+    net.load_state_dict(S.init_state(NC), strict=True)
+    x, yc, yw = S.synth_batch(B, NC, seed=23)
+    net.eval()
+    c, r = net(x)
+    lc = ref.softmax_cross_entropy_with_logits(c, yc, "mean"); lr = ref.softmax_cross_entropy_with_logits(r, yw, "mean")
+    loss = lc + 10.0 * lr
+    loss.backward()
+    out["full_c_sum"] = np.array(S.checksum(c)); out["full_r_sum"] = np.array(S.checksum(r))
+    out["full_c_crop"] = c[:4, :8].detach().numpy().copy(); out["full_r_crop"] = r[-4:, -8:].detach().numpy().copy()
+    out["full_losses"] = np.array([float(loss), float(lc), float(lr)])
+    out["full_loss_none"] = ref.softmax_cross_entropy_with_logits(r, yw, "none").detach().numpy().copy()
+    for k, p in net.named_parameters():
+        out["full_grad_sum/" + k] = np.array(S.checksum(p.grad))
+    out["full_grad_fc11_crop"] = net.fc11.weight.grad[:6, :6].numpy().copy()
+    print("full size: loss %.6f (class %.6f, regress %.6f)" % (float(loss), float(lc), float(lr)))
+
+
 def main():
     NC = 64
     net = ref.SpacecraftPoseNet(NC, keep_prob=0.5, pretrain=False)
@@ -55,6 +92,8 @@ def main():
         out["grad_sum/" + k] = np.array(S.checksum(p.grad))
     out["grad_conv1_crop"] = net.conv1.weight.grad[:4, :, :3, :3].numpy()
     out["grad_fc8_crop"] = net.fc8.weight.grad[:8, :16].numpy()
+    full_size(out)
+    caffe_weights(out)
     np.savez_compressed(os.path.join(HERE, "spn_golden.npz"), **out)
     print("wrote spn_golden.npz", out["n_params_5000"], float(out["grad_loss"]))
 

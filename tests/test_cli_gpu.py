@@ -1,0 +1,80 @@
+"""The command-line surface end to end on the MI355X: train.py (KRN and SPN, with resume), adapt.py (DANN) and test.py as
+subprocesses on synthetic batches, and the SPN epoch driver called the way train.py calls it (reference train.py:125-155,
+adapt.py:112-140, test.py:42-91, trainer.py:114-199)."""
+import os
+import subprocess
+import sys
+import types
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run(script, *args, cwd=ROOT):
+    p = subprocess.run([sys.executable, os.path.join(ROOT, script)] + [str(a) for a in args], cwd=cwd, capture_output=True, text=True,
+                       timeout=900, env=dict(os.environ, PYTHONPATH=ROOT))
+    assert p.returncode == 0, (script, args, p.stdout[-1500:], p.stderr[-3000:])
+    return p.stdout + p.stderr
+
+
+def test_train_krn_resume_then_test(device, tmp_path):
+    common = ["--model_name", "krn", "--batch_size", 4, "--synthetic_batches", 3, "--optimizer", "adamw", "--lr", "1e-3", "--weight_decay",
+              "0.01", "--savedir", tmp_path / "save", "--logdir", tmp_path / "log", "--precision", "bf16"]
+    out = run("train.py", *common, "--max_epochs", 1)
+    assert os.path.exists(tmp_path / "save" / "checkpoint.pth.tar") and os.path.exists(tmp_path / "save" / "model_best.pth.tar")
+    ck = torch.load(tmp_path / "save" / "checkpoint.pth.tar", map_location="cpu")
+    assert ck["epoch"] == 1 and ck["model"] == "krn" and len(ck["state_dict"]) == 350 and ck["optimizer"]["state"]
+    out = run("train.py", *common, "--max_epochs", 2)                        # auto-resume: loads epoch 1, trains epoch 2 only
+    assert "Checkpoint loaded" in out and "Training 002" in out and "Training 001" not in out
+    assert torch.load(tmp_path / "save" / "checkpoint.pth.tar", map_location="cpu")["epoch"] == 2
+    res = tmp_path / "pred.pt"
+    run("test.py", "--model_name", "krn", "--synthetic_batches", 2, "--pretrained", tmp_path / "save" / "model_best.pth.tar", "--resultfn", res,
+        "--logdir", tmp_path / "log")
+    assert os.path.exists(res)
+
+
+def test_train_spn_with_use_fp16_flag_warns_and_resumes(device, tmp_path):
+    common = ["--model_name", "spn", "--num_classes", 64, "--batch_size", 4, "--synthetic_batches", 2, "--optimizer", "adamw", "--savedir",
+              tmp_path / "save", "--logdir", tmp_path / "log", "--use_fp16"]
+    out = run("train.py", *common, "--max_epochs", 1)
+    assert "bfloat16" in out and "loss_c" in out                             # the documented substitution is announced
+    out = run("train.py", *common, "--max_epochs", 2)                        # resume with the model still on the CPU
+    assert "Checkpoint loaded" in out
+    ck = torch.load(tmp_path / "save" / "checkpoint.pth.tar", map_location="cpu")
+    assert ck["epoch"] == 2 and ck["optimizer"]["spn_fused"]["t"] == 4
+
+
+def test_adapt_dann(device, tmp_path):
+    out = run("adapt.py", "--perform_dann", "--model_name", "krn", "--batch_size", 4, "--synthetic_batches", 2, "--max_epochs", 1, "--optimizer",
+              "adamw", "--savedir", tmp_path / "save", "--logdir", tmp_path / "log", "--precision", "bf16")
+    ck = torch.load(tmp_path / "save" / "checkpoint.pth.tar", map_location="cpu")
+    assert len(ck["state_dict"]) == 354 and "domain_classifier.0.weight" in ck["state_dict"]
+
+
+def test_train_single_epoch_spn_driver(device, capsys):
+    from oracle import spn_oracle as S
+    from speedplusbaseline_amd.core.trainer import train_single_epoch_spn
+    from speedplusbaseline_amd.data import SyntheticSpnLoader
+    from speedplusbaseline_amd.nets import get_model, get_optimizer
+    cfg = types.SimpleNamespace(model_name="spn", num_keypoints=11, num_classes=64, dann=False, optimizer="adamw", lr=1e-3, momentum=0.9,
+                                weight_decay=0.01, fp16=False, precision="bf16", synthetic_batches=1, texture_ratio=0.5, seed=1)
+    model = get_model(cfg)
+    model.load_state_dict(S.init_state(64), strict=True)
+    opt = get_optimizer(cfg, model)
+    model = model.to(device)
+    before = model.flat_parameters().clone()
+
+    class Writer:
+        def __init__(self): self.s = {}
+        def add_scalar(self, k, v, e): self.s[k] = (v, e)
+    w = Writer()
+    loader = SyntheticSpnLoader(4, 5, 64, 5, (227, 227), seed=3)
+    train_single_epoch_spn(1, cfg, model, loader, opt, w, device, styleAugmentor=None, scaler=None)
+    out = capsys.readouterr().out
+    assert "loss_c" in out and "loss_r" in out and "0005/0005" in out
+    assert set(w.s) == {"train/loss_c", "train/loss_r"} and all(v[0] == v[0] and v[0] > 0 for v in w.s.values())
+    assert opt._t == 5 and float((model.flat_parameters() - before).abs().max()) > 0
+    assert torch.isfinite(model.flat_parameters()).all()

@@ -72,12 +72,15 @@ def test_trread_semantics(device):
     assert torch.equal(out, exp), (out[:20], exp[:20])
 
 
-@pytest.fixture(params=["prefetch", "lds_dma"])
+@pytest.fixture(params=["default", "lds_dma", "tiled"])
 def gemm_variant(request):
-    """both pointwise-GEMM kernels: the default register-prefetch one and the LDS-DMA ring (small M, bf16, K >= 64)"""
+    """the pointwise-GEMM kernels: the default dispatch (split-K-over-waves kernel for small M with a long reduction, the
+    register-prefetch tiled kernel otherwise), the LDS-DMA ring (small M, bf16, K >= 64) and the tiled kernel alone"""
     L.lib().spb_debug_set_gemm_dma(1 if request.param == "lds_dma" else 0)
+    L.lib().spb_debug_set_gemm_sk(0 if request.param != "default" else 1, 0, 0)
     yield request.param
     L.lib().spb_debug_set_gemm_dma(0)
+    L.lib().spb_debug_set_gemm_sk(1, 0, 0)
 
 
 @pytest.fixture(params=["rows", "tiles"])
@@ -91,7 +94,10 @@ def dw_variant(request):
 @pytest.mark.parametrize("dt", DTYPES)
 @pytest.mark.parametrize("M,K,N,act,R", [(300, 24, 144, L.ACT_RELU6, 1), (1000, 144, 32, L.ACT_RELU6, 3),
                                           (257, 320, 1024, L.ACT_NONE, 1), (2352, 96, 64, L.ACT_RELU, 2),
-                                          (129, 16, 96, L.ACT_NONE, 8)])
+                                          (129, 16, 96, L.ACT_NONE, 8),
+                                          # project convolutions of the 14x14 / 7x7 maps at bs=48 and the ConvDw pointwise layers
+                                          (9408, 384, 64, L.ACT_RELU6, 1), (9408, 576, 96, L.ACT_RELU6, 1), (2352, 960, 160, L.ACT_RELU6, 1),
+                                          (2352, 960, 320, L.ACT_RELU6, 1), (2352, 1280, 1024, L.ACT_RELU, 1), (2349, 200, 72, L.ACT_LEAKY, 2)])
 def test_pw_gemm_fwd(device, gemm_variant, dt, M, K, N, act, R):
     torch.manual_seed(M + K + N)
     zin = rt(torch.randn(M, K, dtype=torch.float64) * 1.5 + 0.3, dt)
@@ -140,7 +146,11 @@ def _composite(M, K, N, act1, act2, dt, seed):
 
 @pytest.mark.parametrize("dt", DTYPES)
 @pytest.mark.parametrize("M,K,N,act1,act2", [(300, 24, 144, L.ACT_RELU6, L.ACT_RELU6), (513, 144, 32, L.ACT_RELU6, L.ACT_NONE),
-                                             (260, 96, 64, L.ACT_NONE, L.ACT_LEAKY), (200, 1024, 1024, L.ACT_RELU, L.ACT_RELU)])
+                                             (260, 96, 64, L.ACT_NONE, L.ACT_LEAKY), (200, 1024, 1024, L.ACT_RELU, L.ACT_RELU),
+                                             # expand convolutions of the 14x14 / 7x7 maps at bs=48 (the input gradient reduces over N)
+                                             (9408, 64, 384, L.ACT_NONE, L.ACT_RELU6), (9408, 96, 576, L.ACT_NONE, L.ACT_RELU6),
+                                             (2352, 160, 960, L.ACT_NONE, L.ACT_RELU6), (2352, 320, 1024, L.ACT_NONE, L.ACT_RELU),
+                                             (2352, 1024, 1024, L.ACT_RELU, L.ACT_RELU), (2349, 72, 200, L.ACT_RELU6, L.ACT_LEAKY)])
 def test_pw_gemm_bwd(device, gemm_variant, dt, M, K, N, act1, act2):
     c = _composite(M, K, N, act1, act2, dt, seed=M * 7 + N)
     dev = device

@@ -1,0 +1,254 @@
+"""bf16 -- the benchmarked compute type -- against the float64 oracle at the north-star tolerance, on a CONDITIONED state.
+
+At random init this BatchNorm/ReLU6 stack amplifies any perturbation ~350x (tests/test_krn_gpu.py), which says nothing
+about a network someone would deploy.  Here the network is first trained on the MI355X (f32 HIP path, a few hundred AdamW
+steps on structured synthetic frames whose keypoints are a function of the picture) until its BatchNorm statistics,
+weights and outputs are trained-like, then frozen, and the bf16 HIP path is compared with the float64 CPU oracle ON THE
+SAME WEIGHTS at the BASELINE batch size (48):
+
+  * eval forward: keypoint MSE <= 1e-4 (BASELINE.json north_star: "keypoint MSE within 1e-4 of reference");
+  * train forward + backward: loss, per-layer BatchNorm batch statistics (error growth with depth bounded), gradient
+    direction and norm;
+  * the DANN step FusedTrainStep(dann=True) runs for bench.py --model dann (source and target passes on two streams,
+    step.py) against oracle.DannTrainer (dann.py:68-100).
+Reference: park2019.py:126-165, trainer.py:72-98, dann.py:68-100.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import krn_oracle as O  # noqa: E402
+from speedplusbaseline_amd.engine import KrnEngine  # noqa: E402
+from speedplusbaseline_amd.step import FusedTrainStep  # noqa: E402
+
+B = 48
+K = 11
+STEPS = 1000
+LR_AT = {300: 3e-4, 600: 1e-4}
+
+
+def structured_batch(n, seed, device=None):
+    """frames with a soft blob at (cx, cy) of size s over low-amplitude noise; the 11 keypoints sit on a fixed constellation
+    around the blob, so the targets are a learnable function of the image (as real keypoints are).  device=None: CPU
+    generator (the batches both sides are compared on); a cuda device: generated there (conditioning stream only)"""
+    dev = torch.device("cpu") if device is None else torch.device(device)
+    g = torch.Generator(device=dev).manual_seed(seed)
+    r = lambda *sh: torch.rand(*sh, generator=g, device=dev)
+    cx = 0.25 + 0.5 * r(n); cy = 0.25 + 0.5 * r(n)
+    s = 0.08 + 0.08 * r(n)
+    yy, xx = torch.meshgrid(torch.linspace(0, 1, 224, device=dev), torch.linspace(0, 1, 224, device=dev), indexing="ij")
+    d2 = (xx[None] - cx[:, None, None]) ** 2 + (yy[None] - cy[:, None, None]) ** 2
+    blob = torch.exp(-d2 / (2 * s[:, None, None] ** 2))
+    img = 0.25 * r(n, 3, 224, 224) + 0.7 * blob[:, None] * torch.tensor([1.0, 0.8, 0.6], device=dev)[None, :, None, None]
+    ang = torch.arange(K, device=dev) * (2 * math.pi / K)
+    kx = cx[:, None] + 1.5 * s[:, None] * torch.cos(ang)[None]
+    ky = cy[:, None] + 1.5 * s[:, None] * torch.sin(ang)[None]
+    y = torch.stack([kx, ky], dim=1).clamp(0, 1)
+    return img, y
+
+
+def load_state(eng, sd):
+    for info in eng.param_infos:
+        eng.param_view(info).copy_(sd[info[0]].detach().to(device=eng.device, dtype=torch.float32))
+    for name, shape, off, numel in eng.buffer_infos:
+        eng.buffers[off: off + numel].copy_(sd[name].detach().flatten().to(device=eng.device, dtype=torch.float32))
+    for i, n in enumerate(eng.bn_names):
+        eng.nbt[i] = int(sd[n])
+
+
+def dump_state(eng, dtype=torch.float64):
+    sd = {}
+    for info in eng.param_infos:
+        sd[info[0]] = eng.param_view(info).detach().cpu().to(dtype).clone()
+    for name, shape, off, numel in eng.buffer_infos:
+        sd[name] = eng.buffers[off: off + numel].detach().cpu().to(dtype).view(shape).clone()
+    for i, n in enumerate(eng.bn_names):
+        sd[n] = torch.tensor(int(eng.nbt[i]), dtype=torch.int64)
+    # the oracle walks the reference's state_dict order
+    order = list(O.krn_param_shapes(K, dann=eng.dann).keys())
+    return {k: sd[k] for k in order}
+
+
+def _condition(device, dann, B=B):
+    """train the f32 HIP path: AdamW (wd 0.01, clip 1.0), lr 1e-3 -> 3e-4 -> 1e-4, a fresh structured batch every step"""
+    eng = KrnEngine(K, dann=dann).attach(device, "fp32")
+    load_state(eng, O.init_state(K, dann=dann))
+    ts = FusedTrainStep(eng, B, kind="adamw", lr=1e-3, momentum=0.9, weight_decay=0.01, max_norm=1.0, dann=dann)
+    hist = []
+    for it in range(STEPS):
+        if it in LR_AT:
+            ts.lr = LR_AT[it]
+        x, y = structured_batch(B, 100 + it, device)        # a fresh batch every step: the network has to generalise
+        xt = structured_batch(B, 900 + it, device)[0].flip(3) * 0.8 if dann else None
+        s = ts(x, y, xt, alpha=O.dann_alpha(it, 0, STEPS, 1) if dann else 0.0)
+        if it % 100 == 0 or it == STEPS - 1:
+            hist.append(round(float(s[0]), 4))
+    torch.cuda.synchronize()
+    print("conditioning (dann=%s) loss every 100 steps: %s" % (dann, hist))
+    assert hist[-1] < 0.1 * hist[0], hist       # trained-like: per-keypoint error of a few percent of the frame
+    return dump_state(eng), hist
+
+
+@pytest.fixture(scope="module")
+def conditioned(device):
+    return _condition(device, dann=False)[0]
+
+
+@pytest.fixture(scope="module")
+def conditioned_dann(device):
+    return _condition(device, dann=True, B=16)[0]        # the README's DANN recipe trains at batch 16 (README.md:105)
+
+
+def _rel(a, b):
+    a = torch.as_tensor(a).double().cpu().flatten(); b = torch.as_tensor(b).double().cpu().flatten()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def test_bf16_eval_keypoints_within_1e4_of_float64_oracle_at_bs48(device, conditioned):
+    x, y = structured_batch(B, 7)                      # a batch the network has not seen
+    sd = {k: v.clone() for k, v in conditioned.items()}
+    with torch.no_grad():
+        xc, yc = O.krn_forward(sd, x.double(), None, training=False)
+    ref = torch.stack([xc, yc], dim=1)                  # [B,2,K]
+    out = {}
+    for prec in ("fp32", "bf16"):
+        eng = KrnEngine(K).attach(device, prec)
+        load_state(eng, conditioned)
+        pred, _, _ = eng.forward(x.to(device), None, training=False)
+        torch.cuda.synchronize()
+        p = torch.stack([pred[:, 0::2], pred[:, 1::2]], dim=1).double().cpu()
+        out[prec] = (float(((p - ref) ** 2).mean()), float((p - ref).abs().max()))
+    fit = float(((ref - y.double()) ** 2).mean())
+    print("conditioned eval, B=48: keypoint MSE vs float64 oracle  fp32 %.3e (max |d| %.2e)   bf16 %.3e (max |d| %.2e);  "
+          "oracle-vs-target MSE %.3e, reference mean square %.3e" % (out["fp32"] + out["bf16"] + (fit, float((ref ** 2).mean()))))
+    assert out["fp32"][0] <= 1e-8
+    assert out["bf16"][0] <= 1e-4, out             # the north-star bar, in the benchmarked dtype
+
+
+def test_bf16_train_pass_tracks_float64_oracle_at_bs48(device, conditioned):
+    x, y = structured_batch(B, 8)
+    sd = {k: v.clone() for k, v in conditioned.items()}
+    names = O._leafify(sd)
+    O._Net.momentum = 1.0                              # running statistics := this batch's statistics (per-layer probe)
+    try:
+        loss, lx, ly = O.krn_forward(sd, x.double(), y.double(), training=True)
+    finally:
+        O._Net.momentum = O.BN_MOM
+    loss.backward()
+    g_ref = torch.cat([sd[k].grad.flatten() for k in names])
+    eng = KrnEngine(K).attach(device, "bf16")
+    load_state(eng, conditioned)
+    eng.grads.zero_()
+    _, scal, _ = eng.forward(x.to(device), y.to(device), training=True)
+    eng.backward(B)
+    torch.cuda.synchronize()
+    s = scal.cpu().double()
+    print("conditioned train pass, B=48: loss bf16 %.6f float64 %.6f" % (float(s[0]), float(loss)))
+    # a per-coordinate keypoint budget of 1e-4 (mean square) moves the summed loss by at most 2 sqrt(L * 2K * 1e-4) + 2K * 1e-4
+    budget = 2 * math.sqrt(float(loss) * 2 * K * 1e-4) + 2 * K * 1e-4
+    assert abs(float(s[0]) - float(loss)) <= budget, (float(s[0]), float(loss), budget)
+    # per-layer batch means (running_mean after a momentum-0.1 update from the same start): error growth with depth
+    n = x.shape[0]
+    errs = []
+    start = conditioned
+    for name, shape, off, numel in eng.buffer_infos:
+        if not name.endswith("running_mean"):
+            continue
+        got = (eng.buffers[off: off + numel].double().cpu() - 0.9 * start[name].flatten()) / 0.1     # batch mean seen by HIP
+        errs.append(_rel(got, sd[name]))
+    print("per-layer batch-mean relative error (58 BN layers): first %.2e  median %.2e  max %.2e  last %.2e"
+          % (errs[0], sorted(errs)[len(errs) // 2], max(errs), errs[-1]))
+    assert errs[0] < 5e-3 and max(errs) < 5e-2 and errs[-1] < 5e-2      # bf16 operand rounding (2^-9) at the stem, bounded growth after
+    g_hip = torch.cat([eng.param_view(i, eng.grads).double().cpu().flatten() for i in eng.param_infos])
+    cos = float(torch.dot(g_hip, g_ref) / (g_hip.norm() * g_ref.norm()))
+    # where the deviation sits: per-tensor share of |g_hip - g_ref|^2, against the same for a float64 oracle that rounds to
+    # bf16 at the HIP path's storage / operand points (what ANY bf16 evaluation with these rounding points would give)
+    sd_q = {k: v.clone() for k, v in conditioned.items()}
+    names_q = O._leafify(sd_q)
+    O._Net.quant = True
+    try:
+        lq, _, _ = O.krn_forward(sd_q, x.double(), y.double(), training=True)
+        lq.backward()
+    finally:
+        O._Net.quant = False
+    g_emu = torch.cat([sd_q[k].grad.flatten() for k in names_q])
+    cos_emu = float(torch.dot(g_emu, g_ref) / (g_emu.norm() * g_ref.norm()))
+    tot = float((g_hip - g_ref).pow(2).sum()); tot_e = float((g_emu - g_ref).pow(2).sum())
+    rows = []
+    for i in eng.param_infos:
+        gh = eng.param_view(i, eng.grads).double().cpu(); gr = sd[i[0]].grad; ge = sd_q[i[0]].grad
+        rows.append((float((gh - gr).pow(2).sum()) / tot, float((ge - gr).pow(2).sum()) / tot_e, float(gr.norm()), float(gh.norm()), i[0]))
+    rows.sort(reverse=True)
+    print("emulated-bf16 oracle: loss %.6f, gradient cosine to float64 %.4f, norm %.4e" % (float(lq), cos_emu, float(g_emu.norm())))
+    print("largest shares of the squared gradient deviation (hip share, emulated share, |g| float64, |g| hip, tensor):")
+    for r in rows[:14]:
+        print("   %.3f  %.3f  %.3e  %.3e  %s" % r)
+    print("gradient: cosine to float64 %.4f, norm bf16 %.4e float64 %.4e" % (cos, float(g_hip.norm()), float(g_ref.norm())))
+    assert cos > min(0.9, cos_emu - 0.05) and 0.5 < float(g_hip.norm() / g_ref.norm()) < 2.0
+
+
+def test_bf16_dann_step_overlapped_streams_vs_oracle(device, conditioned_dann):
+    """one DANN step through FusedTrainStep(dann=True) -- source and target passes concurrently on two streams, as
+    bench.py --model dann times it -- in bf16, against oracle.DannTrainer in float64 from the same conditioned state"""
+    xs, ys = structured_batch(16, 21); xt = structured_batch(16, 22)[0].flip(3) * 0.8
+    alpha = 0.7
+    sd = {k: v.clone() for k, v in conditioned_dann.items()}
+    tr = O.DannTrainer(sd, kind="sgd", lr=0.05, momentum=0.0, weight_decay=0.0)
+    p0 = torch.cat([sd[k].detach().flatten().clone() for k in tr.names])
+    _orig = (torch.ones, torch.zeros)
+    lp, ls, lt, gn = _dann_step_f64(tr, xs.double(), ys.double(), xt.double(), alpha)
+    d_ref = torch.cat([sd[k].detach().flatten() for k in tr.names]) - p0
+    import os
+    budget = 2 * math.sqrt(lp * 2 * K * 1e-4) + 2 * K * 1e-4
+    # yardstick: the same step in float64 with bf16 rounding at the HIP path's storage / operand points
+    sd_q = {k: v.clone() for k, v in conditioned_dann.items()}
+    trq = O.DannTrainer(sd_q, kind="sgd", lr=0.05, momentum=0.0, weight_decay=0.0)
+    O._Net.quant = True
+    try:
+        _dann_step_f64(trq, xs.double(), ys.double(), xt.double(), alpha)
+    finally:
+        O._Net.quant = False
+    d_emu = torch.cat([sd_q[k].detach().flatten() for k in trq.names]) - p0
+    cos_emu = float(torch.dot(d_emu, d_ref) / (d_emu.norm() * d_ref.norm()))
+    print("emulated-bf16 oracle: SGD update cosine to float64 %.4f" % cos_emu)
+    for prec, overlap in (("fp32", "1"), ("bf16", "1"), ("bf16", "0")):
+        os.environ["SPB_DANN_OVERLAP"] = overlap
+        eng = KrnEngine(K, dann=True).attach(device, prec)
+        load_state(eng, conditioned_dann)
+        ts = FusedTrainStep(eng, 16, kind="sgd", lr=0.05, momentum=0.0, weight_decay=0.0, max_norm=1.0, dann=True)
+        q0 = eng.params.clone()
+        s = ts(xs.to(device), ys.to(device), xt.to(device), alpha=alpha)
+        torch.cuda.synchronize()
+        s = s.cpu().double()
+        print("DANN %s (overlap=%s): pose %.5f / %.5f   bce source %.5f / %.5f   bce target %.5f / %.5f  (hip / float64)"
+              % (prec, overlap, float(s[0]), lp, float(s[3]), ls, float(s[4]), lt))
+        d_hip = torch.cat([(eng.param_view(i) - eng.param_view(i, q0)).double().cpu().flatten() for i in eng.param_infos])
+        cos = float(torch.dot(d_hip, d_ref) / (d_hip.norm() * d_ref.norm()))
+        print("   SGD update after clip: cosine to float64 %.4f, norm ratio %.4f" % (cos, float(d_hip.norm() / d_ref.norm())))
+        if prec == "fp32":
+            assert abs(float(s[0]) - lp) <= 1e-3 * lp + 1e-5 and abs(float(s[3]) - ls) <= 1e-4 and abs(float(s[4]) - lt) <= 1e-4
+            assert cos > 0.99
+            continue
+        assert abs(float(s[0]) - lp) <= budget, (float(s[0]), lp, budget)
+        assert abs(float(s[3]) - ls) <= 2e-2 and abs(float(s[4]) - lt) <= 2e-2
+        assert cos > min(0.85, cos_emu - 0.07) and 0.8 < float(d_hip.norm() / d_ref.norm()) < 1.25
+    os.environ.pop("SPB_DANN_OVERLAP", None)
+
+
+def _dann_step_f64(tr, xs, ys, xt, alpha):
+    """oracle.DannTrainer.step with float64 domain labels (F.binary_cross_entropy_with_logits needs matching dtypes)"""
+    import torch.nn.functional as F
+    n = xs.shape[0]
+    tr.opt.zero_grad(set_to_none=True)
+    (lp, lx, ly), ds = O.revgrad_forward(tr.sd, xs, ys, alpha, True)
+    l_src = F.binary_cross_entropy_with_logits(ds, torch.ones(n, dtype=ds.dtype))
+    _, dt = O.revgrad_forward(tr.sd, xt, None, alpha, True)
+    l_tgt = F.binary_cross_entropy_with_logits(dt, torch.zeros(n, dtype=dt.dtype))
+    (lp + l_src + l_tgt).backward()
+    gn = torch.nn.utils.clip_grad_norm_([tr.sd[k] for k in tr.names], 1.0)
+    tr.opt.step()
+    return float(lp), float(l_src), float(l_tgt), float(gn)

@@ -1,0 +1,74 @@
+"""SPN at the sizes of BASELINE.json configs[5] -- 5000 attitude classes, batch 32, 227x227 -- against golden vectors the
+reference's own SpacecraftPoseNet produced on the CPU (tests/golden/make_golden_spn.py: full_size): logits, the soft-target
+cross-entropy in its three reductions, the trainer's loss (trainer.py:152-156) and the gradient of every parameter.
+The golden gradients are eval-mode ones (dropout = identity), so the HIP step runs with keep_prob = 0 (nn.Dropout(p=0))."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import spn_oracle as S
+from speedplusbaseline_amd.nets.spn import SpacecraftPoseNet, softmax_cross_entropy_with_logits
+
+pytestmark = pytest.mark.gpu
+GOLD = np.load(os.path.join(os.path.dirname(__file__), "golden", "spn_golden.npz"))
+NC, B = 5000, 32
+
+
+@pytest.fixture(scope="module")
+def init():
+    return S.init_state(NC), S.synth_batch(B, NC, seed=23)
+
+
+def digest(t):
+    return np.array(S.checksum(t.detach().float().cpu()))
+
+
+@pytest.mark.parametrize("precision,tol", [("fp32", 2e-4), ("bf16", 3e-2)])
+def test_full_size_logits_and_losses(device, init, precision, tol):
+    sd, (x, yc, yw) = init
+    net = SpacecraftPoseNet(NC, keep_prob=0.5, pretrain=False, precision=precision)
+    net.load_state_dict(sd, strict=True)
+    net = net.to(device).eval()
+    c, r = net(x.to(device))
+    torch.cuda.synchronize()
+    assert c.shape == (B, NC) and r.shape == (B, NC)
+    scale_c, scale_r = float(GOLD["full_c_sum"][1]), float(GOLD["full_r_sum"][1])            # mean |logit|
+    assert np.abs(c[:4, :8].cpu().numpy() - GOLD["full_c_crop"]).max() < tol * 10 * scale_c
+    assert np.abs(r[-4:, -8:].cpu().numpy() - GOLD["full_r_crop"]).max() < tol * 10 * scale_r
+    assert abs(digest(c)[1] - scale_c) < tol * scale_c and abs(digest(r)[1] - scale_r) < tol * scale_r
+    yc_d, yw_d = yc.to(device), yw.to(device)
+    lc = softmax_cross_entropy_with_logits(c, yc_d, "mean"); lr = softmax_cross_entropy_with_logits(r, yw_d, "mean")
+    loss, lc_ref, lr_ref = GOLD["full_losses"]
+    print("%s: loss %.6f / %.6f  class %.6f / %.6f  regress %.6f / %.6f (hip / reference)"
+          % (precision, float(lc + 10 * lr), loss, float(lc), lc_ref, float(lr), lr_ref))
+    assert abs(float(lc) - lc_ref) < tol * lc_ref and abs(float(lr) - lr_ref) < tol * lr_ref
+    rows = softmax_cross_entropy_with_logits(r, yw_d, "none")                          # spn.py:43-48, all three reductions
+    assert rows.shape == (B,) and np.abs(rows.cpu().numpy() - GOLD["full_loss_none"]).max() < tol * lr_ref
+    assert abs(float(softmax_cross_entropy_with_logits(r, yw_d, "sum")) - float(GOLD["full_loss_none"].sum())) < tol * B * lr_ref
+    with pytest.raises(ValueError):
+        softmax_cross_entropy_with_logits(r, yw_d, "median")
+
+
+def test_full_size_training_gradients_bf16(device, init):
+    """the benchmarked configuration (bf16, weight-streaming fc kernels, flat arenas) at full size: loss and the gradient of
+    every parameter against the reference's (per-tensor mean |g| within 8 %, weighted digest within 10 % of mean |g| * sqrt(n))"""
+    sd, (x, yc, yw) = init
+    net = SpacecraftPoseNet(NC, keep_prob=0.0, pretrain=False, precision="bf16")
+    net.load_state_dict(sd, strict=True)
+    net = net.to(device).train()
+    out = net.loss_and_grads(x.to(device), yc.to(device), yw.to(device))
+    torch.cuda.synchronize()
+    o = out.cpu().numpy()
+    loss, lc_ref, lr_ref = GOLD["full_losses"]
+    print("bf16 train pass: loss %.5f / %.5f" % (o[0], loss))
+    assert abs(o[0] - loss) < 3e-2 * loss and abs(o[1] - lc_ref) < 3e-2 * lc_ref and abs(o[2] - lr_ref) < 3e-2 * lr_ref
+    for k, p in net.named_parameters():
+        got, want = digest(p.grad), GOLD["full_grad_sum/" + k]
+        n = p.numel()
+        print("  %-12s mean|g| %.4e / %.4e   digest %.4e / %.4e" % (k, got[1], want[1], got[0], want[0]))
+        assert abs(got[1] - want[1]) < 0.08 * want[1], k
+        assert abs(got[0] - want[0]) < 0.10 * want[1] * n ** 0.5 + 0.02 * abs(want[0]), k
+    crop = net.fc11.weight.grad[:6, :6].float().cpu().numpy()
+    assert np.abs(crop - GOLD["full_grad_fc11_crop"]).max() < 0.05 * np.abs(GOLD["full_grad_fc11_crop"]).max() + 1e-7

@@ -1,0 +1,128 @@
+"""Two data-parallel ranks on ONE MI355X (gloo collectives on device tensors), launched by tests/test_ddp2_gpu.py with
+`python -m torch.distributed.run --nproc-per-node 2`.  Prints one JSON line from rank 0.
+
+KRN: FusedTrainStep with the bucketed exchange overlapped with backward (step.py) and without; SPN: loss_and_grads +
+SpnOptimizer.step with the fully connected bucket exchanged beside the trunk's backward (nets/spn.py).  Each rank trains on
+its own shard.  Reported: largest parameter difference between the replicas after the steps, and the exchanged (summed)
+gradient of the first step against the sum of the two ranks' local gradients computed without any exchange."""
+import json
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+
+
+def gather(t):
+    out = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return out
+
+
+def krn(rank, world, dev):
+    from oracle import krn_oracle as O
+    from speedplusbaseline_amd.engine import KrnEngine
+    from speedplusbaseline_amd.step import FusedTrainStep
+    B, res = 8, {}
+    g = torch.Generator().manual_seed(3 + rank)
+    x = torch.rand(B, 3, 224, 224, generator=g).to(dev); y = torch.rand(B, 2, 11, generator=g).to(dev)
+
+    def fresh():
+        eng = KrnEngine(11).attach(dev, "fp32")
+        sd = O.init_state(11)
+        for info in eng.param_infos:
+            eng.param_view(info).copy_(sd[info[0]].to(dev))
+        for name, shape, off, numel in eng.buffer_infos:
+            eng.buffers[off: off + numel].copy_(sd[name].flatten().to(dev))
+        return eng
+    # local gradient of this rank's shard, no exchange
+    eng = fresh()
+    eng.forward(x, y, training=True); eng.grads.zero_(); eng.backward(B)
+    torch.cuda.synchronize()
+    want = sum(gather(eng.grads.clone()))
+    for mode in ("0", "1"):
+        os.environ["SPB_DDP_OVERLAP"] = mode
+        eng = fresh()
+        ts = FusedTrainStep(eng, B, kind="sgd", lr=0.05, momentum=0.9, weight_decay=1e-4, max_norm=1.0, dist_group=dist.group.WORLD,
+                            world_size=world)
+        ts(x, y)
+        torch.cuda.synchronize()
+        got = eng.grads.clone()                      # the summed gradient the clip and the update saw
+        for _ in range(2):
+            ts(x, y)
+        torch.cuda.synchronize()
+        both = gather(eng.params.clone())
+        sp = eng.bucket_split()
+        res["overlap" + mode] = dict(active=bool(ts._overlap), replica_diff=float((both[0] - both[1]).abs().max()),
+                                     grad_rel_shallow=float((got[:sp] - want[:sp]).norm() / want[:sp].norm()),
+                                     grad_rel_deep=float((got[sp:] - want[sp:]).norm() / want[sp:].norm()),
+                                     moved=float((both[0] - O_flat(eng, O)).abs().max()))
+    return res
+
+
+def O_flat(eng, O):
+    sd = O.init_state(11)
+    out = torch.zeros_like(eng.params)
+    for info in eng.param_infos:
+        eng.param_view(info, out).copy_(sd[info[0]].to(out.device))
+    return out
+
+
+def spn(rank, world, dev):
+    from oracle import spn_oracle as S
+    from speedplusbaseline_amd.nets.spn import SpacecraftPoseNet
+    from speedplusbaseline_amd.optim import SpnOptimizer
+    NC, res = 64, {}
+    init = S.init_state(NC)
+    x, yc, yw = (t.to(dev) for t in S.synth_batch(4, NC, seed=11 + rank))
+    masks = {k: v.to(dev) for k, v in S.synth_masks(4, seed=5 + rank).items()}
+
+    def fresh():
+        net = SpacecraftPoseNet(NC, keep_prob=0.5, pretrain=False, precision="bf16")
+        net.load_state_dict(init, strict=True)
+        return net.to(dev).train()
+    net = fresh()
+    net.loss_and_grads(x, yc, yw, masks=masks)
+    torch.cuda.synchronize()
+    want = sum(gather(net.flat_grads().clone()))
+    for mode in ("plain", "overlap", "overlap_f32"):
+        net = fresh()
+        opt = SpnOptimizer(list(net.parameters()), kind="sgd", lr=0.05, momentum=0.9, weight_decay=1e-4, model=net)
+        p0 = net.flat_parameters().clone()
+        got = None
+        for it in range(2):
+            if mode == "plain":
+                net.loss_and_grads(x, yc, yw, masks=masks)
+            else:
+                net.loss_and_grads(x, yc, yw, masks=masks, world_size=world, group=dist.group.WORLD,
+                                   compress_bf16=None if mode == "overlap" else False)
+            if it == 0:
+                net.finish_gradient_exchange(dist.group.WORLD)
+                torch.cuda.synchronize()
+                got = net.flat_grads().clone()
+            opt.step(world_size=world, group=dist.group.WORLD)
+        torch.cuda.synchronize()
+        both = gather(net.flat_parameters().clone())
+        ce = net._conv_end
+        res[mode] = dict(replica_diff=float((both[0] - both[1]).abs().max()),
+                         grad_rel_conv=float((got[:ce] - want[:ce]).norm() / want[:ce].norm()),
+                         grad_rel_fc=float((got[ce:] - want[ce:]).norm() / want[ce:].norm()),
+                         moved=float((both[0] - p0).abs().max()))
+    return res
+
+
+def main():
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("gloo")
+    out = {"krn": krn, "spn": spn}[sys.argv[1]](rank, world, dev)
+    if rank == 0:
+        print("DDP2 " + json.dumps(out))
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
