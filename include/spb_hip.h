@@ -468,9 +468,11 @@ int spb_debug_set_dw_mode(int mode); /* depthwise fwd/dgrad: 1 row-unit kernels 
 int spb_debug_set_fused_pw_bwd(int on); /* 0: the KRN plan never uses spb_pwconv_bwd_fused */
 int spb_debug_set_stem_mfma(int on); /* 0: bf16 stem uses the scalar kernels instead of the MFMA implicit GEMM */
 int spb_debug_set_gemm_bk64_min_k(int k); /* small-M bf16 GEMMs with K >= k use 64-wide reduction chunks (default 256) */
-int spb_debug_set_gconv_slab(int on); /* 0: wide decoder convs use the per-wave weight-streaming kernel */
+int spb_debug_set_gconv_slab(int mode); /* wide decoder convs: 0 per-wave weight streaming; 1 slab kernel with 4 tiles (1 workgroup per CU); 2 (default) 2 tiles, 2 per CU */
 int spb_debug_set_side_wgrad(int on); /* 0: pointwise weight gradients stay on the launch stream */
 int spb_debug_set_dw_rows(int rows); /* rows per row unit (0: automatic) */
+int spb_debug_set_gconv_slab_pf(int n); /* wide decoder convs: weight slabs in flight per workgroup (3 | 6, default 6) */
+int spb_debug_set_gconv_wlds_pxg(int n); /* decoder convs with LDS-resident weights: 8x8 tiles per workgroup side by side (1 | 2) */
 int spb_debug_set_gemm_sk(int on, int min_k, int rf); /* small-M bf16 GEMMs with K >= min_k (default 192): split-K-over-waves kernel (on=1, default); rf > 0 forces 16*rf-row tiles */
 const char* spb_version(void);
 

@@ -4,6 +4,16 @@ sys.path.insert(0, ".")
 from oracle import ghiasi_oracle as G
 from speedplusbaseline_amd.styleaug import Ghiasi
 dev = torch.device("cuda:0")
+import os
+if os.environ.get("GCONV_WLDS_PXG"):
+    from speedplusbaseline_amd import _lib as L
+    L.lib().spb_debug_set_gconv_wlds_pxg(int(os.environ["GCONV_WLDS_PXG"]))
+if os.environ.get("GCONV_SLAB_PF"):
+    from speedplusbaseline_amd import _lib as L
+    L.lib().spb_debug_set_gconv_slab_pf(int(os.environ["GCONV_SLAB_PF"]))
+if os.environ.get("GCONV_SLAB"):
+    from speedplusbaseline_amd import _lib as L
+    L.lib().spb_debug_set_gconv_slab(int(os.environ["GCONV_SLAB"]))
 net = Ghiasi(); net.load_state_dict(G.init_state()); net.to(dev)
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 48
 x = torch.rand(B, 3, 224, 224, device=dev); s = torch.randn(B, 100, device=dev)

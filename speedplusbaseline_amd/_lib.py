@@ -204,6 +204,8 @@ SYMBOLS = {
     "spb_debug_set_fused_pw_bwd": (i32, [i32]),
     "spb_debug_set_dw_rows": (i32, [i32]),
     "spb_debug_set_gemm_sk": (i32, [i32, i32, i32]),
+    "spb_debug_set_gconv_wlds_pxg": (i32, [i32]),
+    "spb_debug_set_gconv_slab_pf": (i32, [i32]),
     "spb_version": (C.c_char_p, []),
 }
 

@@ -116,11 +116,8 @@ __global__ __launch_bounds__(256) void bn_running_update_kernel(const spb_bnupd_
                                                                 float* buffers, long long* nbt, float momentum) {
   const spb_bnupd_entry_t e = tab[blockIdx.x];
   for (int c = threadIdx.x; c < e.C; c += 256) {
-    float s = 0.f, q = 0.f;
-    for (int r = 0; r < e.R; ++r) {
-      s += stats[e.sums_off + (size_t)r * 2 * e.C + c];
-      q += stats[e.sums_off + (size_t)r * 2 * e.C + e.C + c];
-    }
+    float s, q;
+    bn_replica_sums(stats + e.sums_off, e.R, e.C, c, s, q);     // all replicas in one memory round trip
     const float mean = s * e.inv_n;
     const float var = fmaxf(q * e.inv_n - mean * mean, 0.f);
     float* rm = buffers + e.rm_off;
@@ -135,11 +132,8 @@ __global__ __launch_bounds__(256) void bn_param_grads_kernel(const spb_bnupd_ent
   const spb_bnupd_entry_t e = tab[blockIdx.x];
   if (e.bsums_off < 0) return;
   for (int c = threadIdx.x; c < e.C; c += 256) {
-    float s1 = 0.f, s2 = 0.f;
-    for (int r = 0; r < e.R; ++r) {
-      s1 += stats[e.bsums_off + (size_t)r * 2 * e.C + c];
-      s2 += stats[e.bsums_off + (size_t)r * 2 * e.C + e.C + c];
-    }
+    float s1, s2;
+    bn_replica_sums(stats + e.bsums_off, e.R, e.C, c, s1, s2);
     grads[e.gamma_off + c] += s2;
     grads[e.beta_off + c] += s1;
   }

@@ -49,7 +49,10 @@ __device__ __forceinline__ void stage_halo(const spb_gconv_args_t& g, const bf16
       const int p = ic / per, ii = ic % per;
       const int hp = ii / CV, cv = ii % CV;
       const int hy = hp / HT, hx = hp % HT;
-      const int sy = reflecti(oy0[p] * st - pad + hy, Hu) / up, sx = reflecti(ox0[p] * st - pad + hx, Wu) / up;
+      int oyp = oy0[0], oxp = ox0[0];       // select, not oy0[p]: a dynamically indexed array lives in scratch memory
+#pragma unroll
+      for (int q = 1; q < PXG; ++q) { oyp = p == q ? oy0[q] : oyp; oxp = p == q ? ox0[q] : oxp; }
+      const int sy = reflecti(oyp * st - pad + hy, Hu) / up, sx = reflecti(oxp * st - pad + hx, Wu) / up;
       r[u] = ldraw<bf16_t>(X + ((size_t)(b * g.Hin + sy) * g.Win + sx) * Cin + cv * 8);
       dst[u] = i < total ? (p * HT * HT + hp) * LDP + cv * 8 : -1;
       cvs[u] = cv;
@@ -276,10 +279,18 @@ __global__ __launch_bounds__(256) void gconv_kernel(const spb_gconv_args_t g, in
 // so per 32-channel step a wave issues 32 MFMAs (512 matrix-core cycles) for 12 KB of LDS reads.  The step's weight slab
 // [Cout x 32] is fetched from L2 ONCE per workgroup (cooperatively, through registers, double-buffered in LDS; one barrier
 // per step) instead of once per wave: the per-wave variant above was bound by L1 bandwidth at 149 TFLOP/s.
-template <int NB>
-__global__ __launch_bounds__(256, 1) void gconv_slab_kernel(const spb_gconv_args_t g) {
+// PXG = 8x8 tiles per workgroup.  4: 130 KB of LDS, one workgroup per CU -- halo staging, the reduction loop and the epilogue
+// of a workgroup overlap with nothing (round 1: 214 TFLOP/s over the whole decoder).  2: 75 KB and <= 256 registers, TWO
+// workgroups per CU: one is in its matrix-core loop while the other stages its halo or stores its tile; a weight fragment then
+// feeds 2 MFMAs per wave instead of 4 (10 instead of 12 LDS reads per 16 instead of 32 MFMAs: 147 B/clk/CU, under the 256 peak).
+// PF = weight slabs in flight per workgroup (global -> registers -> LDS).  The ablation of round 2 (scratch/ubench_gconv.hip, 128->128
+// at 56x56, B=48, PXG=2: 151 us) puts 73 us on this stream and 7 us on the matrix cores: with 3 slabs (24 KB) in flight per
+// workgroup the L2 round trip (~1.5 us under load) bounds the stream at ~16 GB/s per workgroup, and every workgroup needs the
+// whole 295 KB weight tensor.
+template <int NB, int PXG, int PF>
+__global__ __launch_bounds__(256, PXG >= 4 ? 1 : 2) void gconv_slab_kernel(const spb_gconv_args_t g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int PXG = 4, ROWS = NB * 16, SLD = 40;             // slab row = 32 k + 8 pad (bf16)
+  constexpr int ROWS = NB * 16, SLD = 40;                      // slab row = 32 k + 8 pad (bf16)
   constexpr int SPT = (ROWS * 4 + 255) / 256;                  // 16-byte slab granules per thread
   const int Cin = g.Cin, Cout = g.Cout, KH = g.KH, st = g.stride, up = g.upsample;
   const int Hu = g.Hin * up, Wu = g.Win * up;
@@ -335,20 +346,25 @@ __global__ __launch_bounds__(256, 1) void gconv_slab_kernel(const spb_gconv_args
   }
   const int nch = Cin >> 5;
   const int nsteps = (GABL & 1) ? 0 : KK * nch;
+#ifdef GSLABMAJOR   // experiment: weights stored slab-major [step][row][32] (a slab = 8 KB contiguous)
+#define SLAB_OFF(row, step, part) (((size_t)(step) * ROWS + (row)) * 32 + (part) * 8)
+#else
+#define SLAB_OFF(row, step, part) ((size_t)(row) * KK * Cin + (size_t)(step) * 32 + (part) * 8)
+#endif
   // weight slabs travel global -> registers -> LDS three steps ahead (one step ahead left the L2 round trip exposed on
   // every step: 36 x ~1.5 us per workgroup, 10 % matrix-core utilisation); nsteps is a multiple of 3 (9 taps x Cin/32)
-  uint4 sreg[3][SPT];
+  typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+  u32x4_t sreg[PF * SPT];   // flat, native vectors, constant indices only: stays in registers (uint4 [PF][SPT] lived in scratch)
 #pragma unroll
-  for (int d = 0; d < 3; ++d)
+  for (int d = 0; d < PF; ++d)
 #pragma unroll
     for (int j = 0; j < SPT; ++j)
-      sreg[d][j] = *reinterpret_cast<const uint4*>(Wg + (size_t)srow[j] * KK * Cin + (size_t)d * 32 + spart[j] * 8);
+      sreg[d * SPT + j] = *reinterpret_cast<const u32x4_t*>(Wg + SLAB_OFF(srow[j], d, spart[j]));
   __syncthreads();
   // ---- stage the four input halos
   if (!(GABL & 2)) stage_halo<PXG, 5>(g, X, halo, cf, b, oy0, ox0, HT, LDP, Hu, Wu, st, up, pad, t);
 #pragma unroll
-  for (int j = 0; j < SPT; ++j)
-    if (t + 256 * j < ROWS * 4) *reinterpret_cast<uint4*>(slab + sslot[j]) = sreg[0][j];
+  for (int j = 0; j < SPT; ++j) *reinterpret_cast<u32x4_t*>(slab + sslot[j]) = sreg[j];
   __syncthreads();
 
   const int prow = wave * 2 + (li >> 3), pcol = li & 7;
@@ -362,9 +378,9 @@ __global__ __launch_bounds__(256, 1) void gconv_slab_kernel(const spb_gconv_args
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) acc[p][nb] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
   int ky = 0, kx = 0, cc = 0;
-  for (int s0 = 0; s0 < nsteps; s0 += 3) {
+  for (int s0 = 0; s0 < nsteps; s0 += PF) {
 #pragma unroll
-    for (int d = 0; d < 3; ++d) {
+    for (int d = 0; d < PF; ++d) {
       const int s = s0 + d;
       const bf16_t* sl = slab + (s & 1) * ROWS * SLD;
       bf16x8_t bf[PXG];
@@ -380,16 +396,19 @@ __global__ __launch_bounds__(256, 1) void gconv_slab_kernel(const spb_gconv_args
           else acc[p][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bf[p], acc[p][nb], 0, 0, 0);
         }
       }
-      if (!(GABL & 4) && s + 1 < nsteps) {   // slab of step s+1 (fetched during step s-2) -> the other LDS buffer
+      // NO branch around these stores and loads (ROWS * 4 is a multiple of 256; the step index is clamped, the last steps
+      // re-fetch the last slab and park it in the idle buffer): with `if (s + PF < nsteps)` / `if (t + 256 j < ROWS * 4)` around
+      // them the compiler waited vmcnt(0) before every slab store -- the PF-deep prefetch collapsed to one exposed L2 round
+      // trip per step (36 x ~2 us = 71 of the 151 us of a 128->128 layer, round-2 ablation)
+      static_assert((ROWS * 4) % 256 == 0, "slab granules must tile the workgroup");
+      if (!(GABL & 4)) {   // slab of step s+1 (fetched PF-1 steps ago) -> the other LDS buffer
         bf16_t* sn = slab + ((s + 1) & 1) * ROWS * SLD;
 #pragma unroll
-        for (int j = 0; j < SPT; ++j)
-          if (t + 256 * j < ROWS * 4) *reinterpret_cast<uint4*>(sn + sslot[j]) = sreg[(d + 1) % 3][j];
-      }
-      if (!(GABL & 4) && s + 3 < nsteps) {   // and the fetch of step s+3 takes the register set step s just released
+        for (int j = 0; j < SPT; ++j) *reinterpret_cast<u32x4_t*>(sn + sslot[j]) = sreg[((d + 1) % PF) * SPT + j];
+        const int sf = s + PF < nsteps ? s + PF : nsteps - 1;   // the fetch of step s+PF takes the register set step s released
 #pragma unroll
         for (int j = 0; j < SPT; ++j)
-          sreg[d][j] = *reinterpret_cast<const uint4*>(Wg + (size_t)srow[j] * KK * Cin + (size_t)(s + 3) * 32 + spart[j] * 8);
+          sreg[d * SPT + j] = *reinterpret_cast<const u32x4_t*>(Wg + SLAB_OFF(srow[j], sf, spart[j]));
       }
       if (!(GABL & 16)) __syncthreads();
       if (++cc == nch) { cc = 0; if (++kx == KH) { kx = 0; ++ky; } }
@@ -711,8 +730,15 @@ __global__ void final_sigmoid_kernel(const bf16_t* Z, const float* coef, float* 
 
 }  // namespace
 
-static int g_gconv_slab = 1;
+static int g_gconv_slab = 2;   // 0: per-wave weight streaming; 1: slab kernel, 4 tiles / 1 workgroup per CU; 2: 2 tiles / 2 per CU
 extern "C" int spb_debug_set_gconv_slab(int on) { g_gconv_slab = on; return 0; }
+
+// 8x8 tiles side by side per workgroup in the LDS-resident-weight layers (32->64 stride 2, 64->32 after upsampling): with one,
+// a wave reads 1 pixel + NB weight fragments per NB MFMAs (294..353 B/clk/CU of LDS reads at matrix-core speed, over the 256 peak)
+static int g_slab_pf = 6;    // weight slabs in flight per workgroup of the wide layers (3 | 6)
+extern "C" int spb_debug_set_gconv_slab_pf(int n) { g_slab_pf = n; return 0; }
+static int g_wlds_pxg = 1;
+extern "C" int spb_debug_set_gconv_wlds_pxg(int n) { g_wlds_pxg = n; return 0; }
 
 static int g_conv9_band = 1;
 extern "C" int spb_debug_set_conv9_band(int on) { g_conv9_band = on; return 0; }
@@ -742,27 +768,37 @@ extern "C" int spb_gconv(int dtype, const spb_gconv_args_t* a, spb_stream_t stre
   const size_t wbytes = (size_t)(NB == 1 ? a->Cout : NB * 16) * (KK * a->Cin + 8) * 2;
   const bool wlds = wbytes <= 64 * 1024;
   if (!wlds && a->Cout != NB * 16) return SPB_E_SHAPE;   // the streaming variant has no zero rows
-  if (!wlds) {   // wide layers: shared weight slab, four tiles per workgroup
+  if (!wlds) {   // wide layers: shared weight slab, PXG tiles per workgroup
+    const int PX = g_gconv_slab == 1 ? 4 : 2;
     const int tpi4 = (Hout >> 3) * (Wout >> 3);
-    const int gpi4 = (tpi4 + 3) / 4;
+    const int gpi4 = (tpi4 + PX - 1) / PX;
     const size_t lds4 = (size_t)a->Cin * 2 * sizeof(float) + (size_t)4 * NB * 16 * 2 * sizeof(float) +
-                        (size_t)2 * NB * 16 * 40 * 2 + (size_t)4 * HT * HT * (a->Cin + 8) * 2;
+                        (size_t)2 * NB * 16 * 40 * 2 + (size_t)PX * HT * HT * (a->Cin + 8) * 2;
+    const int PFd = ((KK * (a->Cin >> 5)) % 6 == 0 && g_slab_pf == 6) ? 6 : 3;
     if (lds4 <= 160 * 1024 && (NB == 4 || NB == 8) && g_gconv_slab && (KK * (a->Cin >> 5)) % 3 == 0) {
       const dim3 grid4((unsigned)(a->B * gpi4));
       hipStream_t s4 = (hipStream_t)stream;
-      static bool once4 = false, once8 = false;
-      if (NB == 4) {
-        if (!once4) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gconv_slab_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); once4 = true; }
-        hipLaunchKernelGGL((gconv_slab_kernel<4>), grid4, dim3(256), lds4, s4, *a);
-      } else {
-        if (!once8) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gconv_slab_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); once8 = true; }
-        hipLaunchKernelGGL((gconv_slab_kernel<8>), grid4, dim3(256), lds4, s4, *a);
+#define S_(NB_, PX_)                                                                                                   \
+      { if (PFd == 6) S2_(NB_, PX_, 6) else S2_(NB_, PX_, 3) }
+#define S2_(NB_, PX_, PF_)                                                                                             \
+      {                                                                                                                \
+        static bool once = false;                                                                                      \
+        if (!once) {                                                                                                   \
+          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gconv_slab_kernel<NB_, PX_, PF_>),                       \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                           \
+          once = true;                                                                                                 \
+        }                                                                                                              \
+        hipLaunchKernelGGL((gconv_slab_kernel<NB_, PX_, PF_>), grid4, dim3(256), lds4, s4, *a);                             \
       }
+      if (NB == 4) { if (PX == 4) S_(4, 4) else S_(4, 2) }
+      else { if (PX == 4) S_(8, 4) else S_(8, 2) }
+#undef S_
+#undef S2_
       SPB_CHECK_LAUNCH();
       return 0;
     }
   }
-  const int pxg = wlds ? 1 : 2;
+  const int pxg = wlds ? ((g_wlds_pxg == 2 && (NB == 2 || NB == 4)) ? 2 : 1) : 2;
   const size_t lds = (size_t)a->Cin * 2 * sizeof(float) + (size_t)4 * NB * 16 * 2 * sizeof(float) +
                      (size_t)pxg * HT * HT * (a->Cin + 8) * 2 + (wlds ? wbytes : 0);
   // tile groups per workgroup: the largest divisor of the groups of one image that still leaves >= 1024 workgroups
@@ -784,8 +820,8 @@ extern "C" int spb_gconv(int dtype, const spb_gconv_args_t* a, spb_stream_t stre
     hipLaunchKernelGGL((gconv_kernel<NB_, WL_, PX_>), grid, dim3(256), lds, s, *a, tpw);                             \
   }
   if (NB == 1) { if (wlds) G_(1, true, 1) else return SPB_E_SHAPE; }
-  else if (NB == 2) { if (wlds) G_(2, true, 1) else G_(2, false, 2) }
-  else if (NB == 4) { if (wlds) G_(4, true, 1) else G_(4, false, 2) }
+  else if (NB == 2) { if (wlds) { if (pxg == 2) G_(2, true, 2) else G_(2, true, 1) } else G_(2, false, 2) }
+  else if (NB == 4) { if (wlds) { if (pxg == 2) G_(4, true, 2) else G_(4, true, 1) } else G_(4, false, 2) }
   else G_(8, false, 2)
 #undef G_
   SPB_CHECK_LAUNCH();

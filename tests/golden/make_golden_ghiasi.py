@@ -31,7 +31,7 @@ def main():
     out = {"n_params": np.int64(sum(v.numel() for v in net.state_dict().values())), "keys": np.array(list(sd.keys())),
            "n_params_attr": np.int64(net.n_params)}
     with torch.no_grad():
-        for tag, B, hw in (("a", 2, 64), ("b", 1, 96)):
+        for tag, B, hw in (("a", 2, 64), ("b", 1, 96), ("c", 1, 224)):      # c: the training resolution
             x, s = G.synth_inputs(B, hw, seed=2021 + B)
             feats = {}
             hooks = [net.layers[i].register_forward_hook(lambda m, a, o, i=i: feats.__setitem__(i, o.detach().clone()))

@@ -24,7 +24,7 @@ def test_state_dict_layout_matches_reference():
 
 def test_decoder_forward_matches_reference():
     sd = G.init_state()
-    for tag, B, hw in (("a", 2, 64), ("b", 1, 96)):
+    for tag, B, hw in (("a", 2, 64), ("b", 1, 96), ("c", 1, 224)):       # c: the training resolution
         x, s = G.synth_inputs(B, hw, seed=2021 + B)
         feats = {}
         with torch.no_grad():

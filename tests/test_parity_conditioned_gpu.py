@@ -209,12 +209,15 @@ def test_bf16_dann_step_overlapped_streams_vs_oracle(device, conditioned_dann):
     trq = O.DannTrainer(sd_q, kind="sgd", lr=0.05, momentum=0.0, weight_decay=0.0)
     O._Net.quant = True
     try:
-        _dann_step_f64(trq, xs.double(), ys.double(), xt.double(), alpha)
+        lp_emu = _dann_step_f64(trq, xs.double(), ys.double(), xt.double(), alpha)[0]
     finally:
         O._Net.quant = False
     d_emu = torch.cat([sd_q[k].detach().flatten() for k in trq.names]) - p0
     cos_emu = float(torch.dot(d_emu, d_ref) / (d_emu.norm() * d_ref.norm()))
-    print("emulated-bf16 oracle: SGD update cosine to float64 %.4f" % cos_emu)
+    print("emulated-bf16 oracle: pose loss %.5f (float64 %.5f), SGD update cosine to float64 %.4f" % (lp_emu, lp, cos_emu))
+    # batch statistics over 16 images (784 samples per channel at 7x7) leave some channels with a tiny variance; how far bf16
+    # storage moves the training-mode loss from there is a property of the state, measured by the emulating oracle
+    budget = max(budget, 3.0 * abs(lp_emu - lp))
     for prec, overlap in (("fp32", "1"), ("bf16", "1"), ("bf16", "0")):
         os.environ["SPB_DANN_OVERLAP"] = overlap
         eng = KrnEngine(K, dann=True).attach(device, prec)
