@@ -28,6 +28,32 @@ HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s a
 MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}
 
 
+def _host():
+    """CPU model and core count of this box (stated beside the CPU baseline)"""
+    model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.lower().startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    return dict(cpu_model=model, host_cores=os.cpu_count())
+
+
+def _pmc_traffic(family):
+    """HBM bytes per launch of a kernel family from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE, separate runs,
+    corrected as MI355X_MICROARCH.md prescribes; scratch/pmc_summary.py) -- rocprofv3 cannot run inside bench.py"""
+    for name in ("r2_pmc_traffic.json", "r1_pmc_traffic.json"):
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                return json.load(f)["families"][family]["hbm_bytes_per_launch"], name
+        except Exception:
+            continue
+    return None, None
+
+
 def _device_index(local_rank):
     # SPB_ONE_DEVICE=1 (test rigs with one GPU): every rank on device 0, with SPB_DIST_BACKEND=gloo for the collectives
     return 0 if os.environ.get("SPB_ONE_DEVICE") == "1" else local_rank
@@ -217,14 +243,9 @@ def main():
         achieved = dv["bytes"] / (dv["ms"] * 1e-3) / 1e9
         # HBM bytes per launch of that family from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE, separate
         # runs, corrected as MI355X_MICROARCH.md prescribes; scratch/pmc_summary.py) -- rocprofv3 cannot run inside bench.py
-        traffic = None
-        try:
-            with open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")) as f:
-                traffic = json.load(f)["families"][dk]["hbm_bytes_per_launch"]
-        except Exception:
-            traffic = None
+        traffic, traffic_src = _pmc_traffic(dk)
         roofline = dict(bound="hbm", kernel=dk, achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
-                        frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic,
+                        frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic, traffic_source=traffic_src,
                         launches_per_step=dv["launches"] // n_prof,
                         avg_launch_us=round(dv["ms"] / dv["launches"] * 1e3, 2),
                         alg_bytes_per_launch=round(dv["bytes"] / dv["launches"]),
@@ -232,6 +253,27 @@ def main():
                         step_alg_GBps=round(sum(v["bytes"] for v in agg.values()) / n_prof / (ms_per_step * 1e-3) / 1e9, 1),
                         step_alg_TFLOPs=round(sum(v["flops"] for v in agg.values()) / n_prof / (ms_per_step * 1e-3) / 1e12, 2),
                         mfma_peak_TFLOPs=MFMA_PEAK_TFLOPS[args.precision])
+
+    # ---- style augmentation: the decoder is the matrix-core-bound kernel family of this workload (15.43 GFLOP per
+    # image, 0.74 TFLOP per restyled batch); its achieved rate, timed alone with HIP events on the launch stream
+    if rank == 0 and aug is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for _ in range(3):
+            aug(x)
+        torch.cuda.synchronize()
+        n_dec = 10
+        e0.record()
+        for _ in range(n_dec):
+            aug(x)
+        e1.record()
+        torch.cuda.synchronize()
+        dec_ms = e0.elapsed_time(e1) / n_dec
+        dec_tf = 15.43e9 * B / (dec_ms * 1e-3) / 1e12
+        krn_roofline = roofline
+        roofline = dict(bound="mfma", kernel="Ghiasi decoder (all launches of one restyle, %d images)" % B, achieved=round(dec_tf, 1),
+                        peak=MFMA_PEAK_TFLOPS["bf16"], unit="TFLOP/s", frac=round(dec_tf / MFMA_PEAK_TFLOPS["bf16"], 4), traffic=None,
+                        decoder_ms_per_batch=round(dec_ms, 3), alg_flops_per_batch=15.43e9 * B,
+                        train_step_dominant_kernel=krn_roofline)
 
     # ---- CPU baseline: the oracle's train step (reference --no_cuda fp32 path) on this box's host cores, rank 0 only
     cpu = None
@@ -251,7 +293,7 @@ def main():
             tr.step(xc, yc)
         cdt = time.perf_counter() - t1
         args.cpu_steps = n_cpu
-        cpu = dict(value=round(B * args.cpu_steps / cdt, 2), unit="images/sec", cores=torch.get_num_threads(), kind="port",
+        cpu = dict(value=round(B * args.cpu_steps / cdt, 2), unit="images/sec", cores=torch.get_num_threads(), kind="port", **_host(),
                    sample="%d train steps of the same bs=%d 224x224 batch, fp32, PyTorch CPU oracle (%.1f s)" % (args.cpu_steps, B, cdt))
 
     if rank == 0:
@@ -327,7 +369,7 @@ def bench_preproc(args):
             P.krn_sample(np.repeat(fr[i][:, :, None], 3, axis=2), boxes[i], kps[i].copy(), S, 0.5, True)
             n += 1
         cdt = time.perf_counter() - t1
-        cpu = dict(value=round(n / cdt, 1), unit="images/sec", cores=1, kind="port",
+        cpu = dict(value=round(n / cdt, 1), unit="images/sec", cores=1, kind="port", **_host(),
                    sample="%d samples through the per-sample CPU pipeline (Pillow resize + torch ops, as the reference's DataLoader "
                           "workers run it), one process (%.1f s)" % (n, cdt))
     print(json.dumps({
@@ -405,7 +447,7 @@ def bench_dann(args):
         for _ in range(n_cpu):
             tr.step(a, b, c, alpha)
         cdt = time.perf_counter() - t1
-        cpu = dict(value=round(B * n_cpu / cdt, 2), unit="images/sec", cores=torch.get_num_threads(), kind="port",
+        cpu = dict(value=round(B * n_cpu / cdt, 2), unit="images/sec", cores=torch.get_num_threads(), kind="port", **_host(),
                    sample="%d DANN steps of the same bs=%d source + bs=%d target batch, fp32, PyTorch CPU oracle (%.1f s)" % (n_cpu, B, B, cdt))
     if rank == 0:
         print(json.dumps({
@@ -510,7 +552,7 @@ def bench_spn(args):
         for _ in range(nst):
             S.train_grads(sd, xc, ycc, ywc, masks)
         cdt = time.perf_counter() - t1
-        cpu = dict(value=round(Bc * nst / cdt, 2), unit="images/sec", cores=torch.get_num_threads(), kind="port",
+        cpu = dict(value=round(Bc * nst / cdt, 2), unit="images/sec", cores=torch.get_num_threads(), kind="port", **_host(),
                    sample="%d forward+backward passes of a bs=%d 227x227 batch, fp32, PyTorch CPU oracle, optimizer not included (%.1f s)"
                           % (nst, Bc, cdt))
     if rank == 0:

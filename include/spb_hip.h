@@ -230,6 +230,10 @@ int spb_weight_prep(int dtype, const spb_prep_entry_t* table_dev, int n_entries,
 
 /* ---- optimiser: global-norm clip (trainer.py:90,97; dann.py:99) fused with the update (build.py:60-78) ----- */
 int spb_grad_sqnorm(const float* grads, long long n, float* sqnorm_out /*[1], zeroed by this call*/, spb_stream_t stream);
+/* optimizer.zero_grad() on the flat f32 gradient arena (trainer.py:81, dann.py:74), and dst += src over two arenas (the two
+ * backward passes of a DANN step accumulate into one gradient, dann.py:95); n elements, n % 4 == 0 for the add */
+int spb_arena_zero(float* arena, long long n, spb_stream_t stream);
+int spb_arena_add(float* dst, const float* src, long long n, spb_stream_t stream);
 typedef struct spb_optim_args {
   float* params; float* grads; float* m; float* v; /* flat f32 arenas; m/v may be NULL for sgd w/o momentum */
   const float* sqnorm;  /* optional device scalar: clip coefficient = min(1, max_norm/(sqrt(sqnorm)+1e-6)) */
@@ -472,6 +476,7 @@ int spb_debug_set_gconv_slab(int mode); /* wide decoder convs: 0 per-wave weight
 int spb_debug_set_side_wgrad(int on); /* 0: pointwise weight gradients stay on the launch stream */
 int spb_debug_set_dw_rows(int rows); /* rows per row unit (0: automatic) */
 int spb_debug_set_gconv_slab_pf(int n); /* wide decoder convs: weight slabs in flight per workgroup (3 | 6, default 6) */
+int spb_debug_set_gconv_halo_prefetch(int on); /* decoder convs with LDS-resident weights: prefetch the next tile's halo (1, default) */
 int spb_debug_set_gconv_wlds_pxg(int n); /* decoder convs with LDS-resident weights: 8x8 tiles per workgroup side by side (1 | 2) */
 int spb_debug_set_gemm_sk(int on, int min_k, int rf); /* small-M bf16 GEMMs with K >= min_k (default 192): split-K-over-waves kernel (on=1, default); rf > 0 forces 16*rf-row tiles */
 const char* spb_version(void);

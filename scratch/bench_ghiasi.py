@@ -1,6 +1,6 @@
 """time the HIP style decoder at the training shape (B=48, 224x224)"""
-import sys, time, torch
-sys.path.insert(0, ".")
+import os, sys, time, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import ghiasi_oracle as G
 from speedplusbaseline_amd.styleaug import Ghiasi
 dev = torch.device("cuda:0")

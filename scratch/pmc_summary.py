@@ -9,6 +9,9 @@ def family(name):
     if m:
         pro, epi = int(m.group(1)), int(m.group(2))
         return "pw_gemm_dgrad" if pro == 2 else ("pw_gemm_fwd" if epi == 1 else "pw_gemm_plain")
+    m = re.search(r"pw_sk_kernel<(\d+), *(\d+)", name)               # split-K kernel: PRO, EPI lead the template list
+    if m:
+        return "pw_gemm_dgrad" if int(m.group(1)) == 2 else "pw_gemm_fwd"
     for pat, fam in (("pwb_kernel", "pw_bwd_fused"), ("dwr_fwd_kernel", "dw_fwd"), ("dwr_bwd_kernel", "dw_dgrad"),
                      ("stem_fwd_mfma", "stem_fwd"), ("stem_wgrad_mfma", "stem_wgrad"), ("pw_gemm_dma_kernel", "pw_gemm_dma")):
         if pat in name:

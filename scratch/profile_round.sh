@@ -1,9 +1,11 @@
 #!/bin/bash
 # Collect the committed profiles of a round on the GPU box (run through gpurun from the repo root):
-#   kernel trace + stats of the bench command, then two separate PMC passes (FETCH_SIZE, WRITE_SIZE), each with
-#   --kernel-trace only, as /opt/skills/guides/MI355X_MICROARCH.md prescribes.  Outputs land in gpurun_out/prof_<tag>/.
+#   KRN: kernel trace + stats of the bench command, then two separate PMC passes (FETCH_SIZE, WRITE_SIZE), each with
+#   --kernel-trace only, as /opt/skills/guides/MI355X_MICROARCH.md prescribes;
+#   decoder / SPN: kernel stats, and one PMC pass with the matrix-core counters for the decoder.
+# Outputs land in gpurun_out/prof_<tag>/.
 set -u
-TAG=${1:-r1}
+TAG=${1:-r2}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
@@ -16,4 +18,17 @@ cp $(find /tmp/p_fetch -name "*counter_collection.csv" | head -1) $OUT/fetch.csv
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/p_write -o w -- python $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2> $OUT/write.err
 cp $(find /tmp/p_write -name "*counter_collection.csv" | head -1) $OUT/write.csv
 python $ROOT/scratch/pmc_summary.py $OUT/kernel_stats.csv $OUT/fetch.csv $OUT/write.csv $OUT/pmc_traffic.json 4 > $OUT/pmc_summary.txt 2>&1
+# decoder: kernel stats, then the matrix-core counters (own pass, kernel-trace only)
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_gh -o gh -- python $ROOT/scratch/bench_ghiasi.py > $OUT/ghiasi_bench.txt 2> $OUT/ghiasi.err
+cp $(find /tmp/p_gh -name "*kernel_stats.csv" | head -1) $OUT/ghiasi_kernel_stats.csv
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d /tmp/p_ghm -o ghm -- python $ROOT/scratch/bench_ghiasi.py > /dev/null 2> $OUT/ghiasi_mfma.err
+cp $(find /tmp/p_ghm -name "*counter_collection.csv" | head -1) $OUT/ghiasi_mfma.csv
+python $ROOT/scratch/mfma_summary.py $OUT/ghiasi_mfma.csv > $OUT/ghiasi_mfma_summary.txt 2>&1
+# KRN: the same matrix-core counters (the 7x7 GEMMs)
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d /tmp/p_km -o km -- python $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2> $OUT/krn_mfma.err
+cp $(find /tmp/p_km -name "*counter_collection.csv" | head -1) $OUT/krn_mfma.csv
+python $ROOT/scratch/mfma_summary.py $OUT/krn_mfma.csv > $OUT/krn_mfma_summary.txt 2>&1
+# SPN
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_spn -o spn -- python $ROOT/bench.py --model spn --steps 20 --warmup 5 --no-cpu-baseline > $OUT/spn_bench_under_rocprof.json 2> $OUT/spn.err
+cp $(find /tmp/p_spn -name "*kernel_stats.csv" | head -1) $OUT/spn_kernel_stats.csv
 ls -la $OUT

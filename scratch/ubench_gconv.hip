@@ -8,9 +8,10 @@
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("err %s line %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
 int main() {
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-  struct Sh { int B, H, Cin, Cout, K, st, up; } shapes[] = {{48, 56, 128, 128, 3, 1, 1}, {48, 56, 128, 64, 3, 1, 2}, {48, 112, 64, 32, 3, 1, 2}, {48, 224, 32, 3, 9, 1, 1}};
+  struct Sh { int B, H, Cin, Cout, K, st, up; } shapes[] = {{48, 56, 128, 128, 3, 1, 1}, {48, 56, 128, 64, 3, 1, 2}, {48, 112, 64, 32, 3, 1, 2}, {48, 224, 32, 3, 9, 1, 1}, {48, 224, 32, 64, 3, 2, 1}, {48, 112, 64, 128, 3, 2, 1}};
   if (getenv("PF")) spb_debug_set_gconv_slab_pf(atoi(getenv("PF")));
   if (getenv("SLAB")) spb_debug_set_gconv_slab(atoi(getenv("SLAB")));
+  if (getenv("HPRE")) spb_debug_set_gconv_halo_prefetch(atoi(getenv("HPRE")));
   if (getenv("WPXG")) spb_debug_set_gconv_wlds_pxg(atoi(getenv("WPXG")));
   printf("GABL=%d PF=%s SLAB=%s WPXG=%s\n", GABL, getenv("PF") ? getenv("PF") : "-", getenv("SLAB") ? getenv("SLAB") : "-", getenv("WPXG") ? getenv("WPXG") : "-");
   for (auto sh : shapes) {

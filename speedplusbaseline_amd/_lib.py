@@ -125,6 +125,8 @@ SYMBOLS = {
     "spb_bn_load_running": (i32, [vp, i32, vp, vp, vp]),
     "spb_weight_prep": (i32, [i32, vp, i32, i32, vp, vp, vp]),
     "spb_grad_sqnorm": (i32, [vp, i64, vp, vp]),
+    "spb_arena_zero": (i32, [vp, i64, vp]),
+    "spb_arena_add": (i32, [vp, vp, i64, vp]),
     "spb_optim_step": (i32, [C.POINTER(OptimArgs), vp]),
     "spb_krn_create": (i32, [i32, i32, C.POINTER(vp)]),
     "spb_krn_destroy": (None, [vp]),
@@ -205,6 +207,7 @@ SYMBOLS = {
     "spb_debug_set_dw_rows": (i32, [i32]),
     "spb_debug_set_gemm_sk": (i32, [i32, i32, i32]),
     "spb_debug_set_gconv_wlds_pxg": (i32, [i32]),
+    "spb_debug_set_gconv_halo_prefetch": (i32, [i32]),
     "spb_debug_set_gconv_slab_pf": (i32, [i32]),
     "spb_version": (C.c_char_p, []),
 }

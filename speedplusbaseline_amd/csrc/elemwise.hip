@@ -438,6 +438,29 @@ extern "C" int spb_grad_sqnorm(const float* grads, long long n, float* out, spb_
   return 0;
 }
 
+// ---- flat gradient arena maintenance (optimizer.zero_grad(), and the sum of the two DANN passes' arenas, dann.py:95)
+__global__ __launch_bounds__(256) void arena_add_kernel(float* __restrict__ dst, const float* __restrict__ src, long long n4) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+    float4 a = reinterpret_cast<float4*>(dst)[i];
+    const float4 b = reinterpret_cast<const float4*>(src)[i];
+    a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    reinterpret_cast<float4*>(dst)[i] = a;
+  }
+}
+extern "C" int spb_arena_zero(float* arena, long long n, spb_stream_t stream) {
+  if (!arena || n <= 0) return SPB_E_ARG;
+  const hipError_t e = hipMemsetAsync(arena, 0, (size_t)n * sizeof(float), (hipStream_t)stream);
+  return e == hipSuccess ? 0 : (int)e;
+}
+extern "C" int spb_arena_add(float* dst, const float* src, long long n, spb_stream_t stream) {
+  if (!dst || !src || n <= 0 || (n & 3)) return SPB_E_ARG;       // arenas are padded to 4 floats (16-byte aligned tensors)
+  const long long n4 = n >> 2;
+  const int nblk = (int)(n4 >= 2048LL * 256 ? 2048 : (n4 + 255) / 256);
+  hipLaunchKernelGGL(arena_add_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, dst, src, n4);
+  SPB_CHECK_LAUNCH();
+  return 0;
+}
+
 extern "C" int spb_optim_step(const spb_optim_args_t* a, spb_stream_t stream) {
   if (!a || !a->params || !a->grads || a->n <= 0) return SPB_E_ARG;
   if (a->kind < 0 || a->kind > 3) return SPB_E_ARG;

@@ -77,6 +77,54 @@ __device__ __forceinline__ void stage_halo(const spb_gconv_args_t& g, const bf16
   }
 }
 
+// The same in two halves for workgroups that walk several tiles: `halo_issue` puts the raw loads of ONE tile group in flight
+// (at most 256 * SU vectors), `halo_commit` transforms them into the LDS tile.  Between the two the workgroup runs the previous
+// tile's matrix-core loop and epilogue, so the L2 / HBM round trip of the halo is hidden (it was exposed once per tile: 28 tiles
+// per workgroup in the 64->32 layer at 224x224).
+template <int SU> struct HaloRegs { Raw8<bf16_t> r[SU]; int dst[SU]; int cvs[SU]; };
+template <int PXG, int SU>
+__device__ __forceinline__ void halo_issue(const spb_gconv_args_t& g, const bf16_t* X, HaloRegs<SU>& h, int b, const int* oy0,
+                                           const int* ox0, int HT, int LDP, int Hu, int Wu, int st, int up, int pad, int t) {
+  const int Cin = g.Cin, CV = Cin >> 3;
+  const int per = HT * HT * CV, total = PXG * per;
+#pragma unroll
+  for (int u = 0; u < SU; ++u) {
+    const int i = t + 256 * u;
+    const int ic = i < total ? i : total - 1;
+    const int p = ic / per, ii = ic % per;
+    const int hp = ii / CV, cv = ii % CV;
+    const int hy = hp / HT, hx = hp % HT;
+    int oyp = oy0[0], oxp = ox0[0];
+#pragma unroll
+    for (int q = 1; q < PXG; ++q) { oyp = p == q ? oy0[q] : oyp; oxp = p == q ? ox0[q] : oxp; }
+    const int sy = reflecti(oyp * st - pad + hy, Hu) / up, sx = reflecti(oxp * st - pad + hx, Wu) / up;
+    h.r[u] = ldraw<bf16_t>(X + ((size_t)(b * g.Hin + sy) * g.Win + sx) * Cin + cv * 8);
+    h.dst[u] = i < total ? (p * HT * HT + hp) * LDP + cv * 8 : -1;
+    h.cvs[u] = cv;
+  }
+}
+template <int SU>
+__device__ __forceinline__ void halo_commit(const spb_gconv_args_t& g, const HaloRegs<SU>& h, bf16_t* halo, const float* cf) {
+  const int Cin = g.Cin;
+#pragma unroll
+  for (int u = 0; u < SU; ++u) {
+    if (h.dst[u] < 0) continue;
+    float v[8], sc[8], sh[8];
+    cvt8(h.r[u], v);
+#pragma unroll
+    for (int j = 0; j < 8; j += 4) {
+      *reinterpret_cast<float4*>(sc + j) = *reinterpret_cast<const float4*>(cf + h.cvs[u] * 8 + j);
+      *reinterpret_cast<float4*>(sh + j) = *reinterpret_cast<const float4*>(cf + Cin + h.cvs[u] * 8 + j);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float uu = v[j] * sc[j] + sh[j];
+      v[j] = g.relu ? fmaxf(uu, 0.f) : uu;
+    }
+    st8<bf16_t>(halo + h.dst[u], v);
+  }
+}
+
 // ---------------------------------------------------------------------------------------------- implicit-GEMM conv
 // WLDS: the whole weight tensor sits in LDS (<= 64 KB: the 32/64-channel layers); otherwise weights stream from L2 with a
 // PD-step register prefetch.  A workgroup is persistent over `tpw` consecutive 8x8 tiles of ONE image: weights are staged
@@ -84,8 +132,9 @@ __device__ __forceinline__ void stage_halo(const spb_gconv_args_t& g, const bf16
 // prefetch step, per-wave atomics -- 9.6 M atomics and an exposed L2 round trip per tap: 5.5 ms for the 64->32 layer).
 // PXG = 8x8 tiles a workgroup computes side by side (the streaming variant uses 2: every weight fragment fetched from
 // L2 then feeds two MFMAs -- with one, the 128->128 layers were bound by 2.8 GB of weight re-reads per launch).
-template <int NB, bool WLDS, int PXG>
+template <int NB, bool WLDS, int PXG, bool PRE = false>
 __global__ __launch_bounds__(256) void gconv_kernel(const spb_gconv_args_t g, int tpw) {
+  constexpr int PSU = 5;                                       // PRE: halo vectors per thread (launcher checks PXG*HT*HT*Cin/8 <= 1280)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int PD = NB >= 8 ? 2 : 3;                          // weight prefetch depth (steps) when streaming
   const int Cin = g.Cin, Cout = g.Cout, KH = g.KH, st = g.stride, up = g.upsample;
@@ -144,20 +193,37 @@ __global__ __launch_bounds__(256) void gconv_kernel(const spb_gconv_args_t g, in
 #pragma unroll
     for (int e = 0; e < 4; ++e) { s1[nb][e] = 0.f; s2[nb][e] = 0.f; }
 
+  HaloRegs<PRE ? PSU : 1> hregs;
+  auto tile_origin = [&](int ti_, int* oy0_, int* ox0_, bool* tv_) {
+#pragma unroll
+    for (int p = 0; p < PXG; ++p) {
+      int tr = (grp0 + ti_) * PXG + p;
+      tv_[p] = tr < tpi;                                       // odd tile counts: the last group repeats its first tile
+      tr = tv_[p] ? tr : tpi - 1;
+      oy0_[p] = (tr / tiles_x) * 8; ox0_[p] = (tr % tiles_x) * 8;
+    }
+  };
+  if constexpr (PRE) {
+    int oy0[PXG], ox0[PXG]; bool tv[PXG];
+    tile_origin(0, oy0, ox0, tv);
+    halo_issue<PXG, PSU>(g, X, hregs, b, oy0, ox0, HT, LDP, Hu, Wu, st, up, pad, t);
+  }
   for (int ti = 0; ti < tpw; ++ti) {
     int oy0[PXG], ox0[PXG];
     bool tvalid[PXG];
-#pragma unroll
-    for (int p = 0; p < PXG; ++p) {
-      int tr = (grp0 + ti) * PXG + p;
-      tvalid[p] = tr < tpi;                                    // odd tile counts: the last group repeats its first tile
-      tr = tvalid[p] ? tr : tpi - 1;
-      oy0[p] = (tr / tiles_x) * 8; ox0[p] = (tr % tiles_x) * 8;
-    }
+    tile_origin(ti, oy0, ox0, tvalid);
     __syncthreads();   // previous tile's taps are done with the halo (first pass: coefficient / weight tables written)
     // ---- stage the input halo(s)
-    stage_halo<PXG, 4>(g, X, halo, cf, b, oy0, ox0, HT, LDP, Hu, Wu, st, up, pad, t);
-    __syncthreads();
+    if constexpr (PRE) {
+      if (!(GABL & 2)) halo_commit<PSU>(g, hregs, halo, cf);
+      __syncthreads();
+      int oyn[PXG], oxn[PXG]; bool tvn[PXG];                    // next tile's halo: in flight during this tile's taps and stores
+      tile_origin(ti + 1 < tpw ? ti + 1 : ti, oyn, oxn, tvn);   // (clamped, no branch around the loads: the last one is redundant)
+      halo_issue<PXG, PSU>(g, X, hregs, b, oyn, oxn, HT, LDP, Hu, Wu, st, up, pad, t);
+    } else {
+      stage_halo<PXG, 4>(g, X, halo, cf, b, oy0, ox0, HT, LDP, Hu, Wu, st, up, pad, t);
+      __syncthreads();
+    }
     // ---- K loop: taps x 32-channel chunks.  lane (li, lq): pixel li of this wave's 2x8 strip, channels lq*8..+7
     f32x4_t acc[PXG][NB];
 #pragma unroll
@@ -166,7 +232,7 @@ __global__ __launch_bounds__(256) void gconv_kernel(const spb_gconv_args_t g, in
       for (int nb = 0; nb < NB; ++nb) acc[p][nb] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
     if constexpr (WLDS) {
       int ky = 0, kx = 0, cc = 0;
-      for (int s = 0; s < nsteps; ++s) {
+      for (int s = 0; s < ((GABL & 1) ? 0 : nsteps); ++s) {
         bf16x8_t bf[PXG];
 #pragma unroll
         for (int p = 0; p < PXG; ++p)
@@ -221,7 +287,7 @@ __global__ __launch_bounds__(256) void gconv_kernel(const spb_gconv_args_t g, in
     // ---- epilogue: lane (li = pixel, lq): channels lq*4*NB + nb*4 + e -- one contiguous run, 16-byte stores
 #pragma unroll
     for (int p = 0; p < PXG; ++p) {
-      if (!tvalid[p]) continue;
+      if (!tvalid[p] || (GABL & 64)) continue;
       const int oy = oy0[p] + prow, ox = ox0[p] + pcol;
       bf16_t* dst = Y + ((size_t)(b * Hout + oy) * Wout + ox) * g.ldc + co0;
       uint2 o[NB];
@@ -737,6 +803,8 @@ extern "C" int spb_debug_set_gconv_slab(int on) { g_gconv_slab = on; return 0; }
 // a wave reads 1 pixel + NB weight fragments per NB MFMAs (294..353 B/clk/CU of LDS reads at matrix-core speed, over the 256 peak)
 static int g_slab_pf = 6;    // weight slabs in flight per workgroup of the wide layers (3 | 6)
 extern "C" int spb_debug_set_gconv_slab_pf(int n) { g_slab_pf = n; return 0; }
+static int g_halo_prefetch = 1;   // LDS-resident-weight layers: next tile's halo loads in flight during the current tile
+extern "C" int spb_debug_set_gconv_halo_prefetch(int on) { g_halo_prefetch = on; return 0; }
 static int g_wlds_pxg = 1;
 extern "C" int spb_debug_set_gconv_wlds_pxg(int n) { g_wlds_pxg = n; return 0; }
 
@@ -809,21 +877,24 @@ extern "C" int spb_gconv(int dtype, const spb_gconv_args_t* a, spb_stream_t stre
     if (gpi % d == 0 && (long long)a->B * (gpi / d) >= 1024) tpw = d;
   const dim3 grid((unsigned)(a->B * (gpi / tpw)));
   hipStream_t s = (hipStream_t)stream;
-#define G_(NB_, WL_, PX_)                                                                                            \
+  const bool pre = g_halo_prefetch && tpw > 1 && (long long)pxg * HT * HT * (a->Cin >> 3) <= 1280;
+#define G2_(NB_, WL_, PX_, PRE_)                                                                                     \
   {                                                                                                                  \
     static bool once = false;                                                                                        \
     if (!once) {                                                                                                     \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gconv_kernel<NB_, WL_, PX_>),                         \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gconv_kernel<NB_, WL_, PX_, PRE_>),                   \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                             \
       once = true;                                                                                                   \
     }                                                                                                                \
-    hipLaunchKernelGGL((gconv_kernel<NB_, WL_, PX_>), grid, dim3(256), lds, s, *a, tpw);                             \
+    hipLaunchKernelGGL((gconv_kernel<NB_, WL_, PX_, PRE_>), grid, dim3(256), lds, s, *a, tpw);                       \
   }
+#define G_(NB_, WL_, PX_) { if (pre && WL_) G2_(NB_, WL_, PX_, true) else G2_(NB_, WL_, PX_, false) }
   if (NB == 1) { if (wlds) G_(1, true, 1) else return SPB_E_SHAPE; }
   else if (NB == 2) { if (wlds) { if (pxg == 2) G_(2, true, 2) else G_(2, true, 1) } else G_(2, false, 2) }
   else if (NB == 4) { if (wlds) { if (pxg == 2) G_(4, true, 2) else G_(4, true, 1) } else G_(4, false, 2) }
   else G_(8, false, 2)
 #undef G_
+#undef G2_
   SPB_CHECK_LAUNCH();
   return 0;
 }

@@ -260,85 +260,97 @@ __global__ __launch_bounds__(256) void head_reduce_kernel(const spb_head_args_t 
 
 // ------------------------------------------------------------------------------------------------ head backward
 // dA = dout * Wp, masked by relu'(bn(z)), plus sum(g), sum(g*xhat) for the BN below (the weight gradient is head_wgrad_kernel)
+// HBK consecutive k (8-element vectors of one (position, channel) run) per workgroup.  256 (round 2; was 512): 196 workgroups
+// instead of 98 on 256 CUs, 8 instead of 4 batch subsets per workgroup, and the [J][HBK] weight slab is fetched with all of a
+// thread's loads in flight (the load -> LDS store loop cost one memory round trip per iteration, six of them): 32 -> ~18 us.
+constexpr int HBK = 256;
 template <typename T>
 __global__ __launch_bounds__(256) void head_bwd_kernel(const spb_head_bwd_args_t a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int KV = HBK / 8, NSUB = 256 / KV, WLD = 4;   // k vectors, batch subsets, weight vectors per thread (J * KV <= 1024: J <= 32)
   float* ds = reinterpret_cast<float*>(smem);     // [B][J] upstream gradient * gscale
-  float* wl = ds + ((a.B * a.J + 3) & ~3);        // role 0: [J][512] weight slab;  role 1 unused
-  float* red = wl + (size_t)a.J * 512;            // [2][512]
+  float* wl = ds + ((a.B * a.J + 3) & ~3);        // [J][HBK] weight slab
+  float* red = wl + (size_t)a.J * HBK;            // [2][HBK]
   const int t = threadIdx.x;
   const int KH = a.HW * a.C;
-  const int kbase = blockIdx.x * 512;
+  const int kbase = blockIdx.x * HBK;
   const T* Z = reinterpret_cast<const T*>(a.Z);
   const T* Wp = reinterpret_cast<const T*>(a.Wp);
+  // weight slab: every load of this thread first (clamped indices), then the LDS stores
+  Raw8<T> wr[WLD];
+#pragma unroll
+  for (int u = 0; u < WLD; ++u) {
+    const int i = t + 256 * u;
+    const int ic = i < a.J * KV ? i : a.J * KV - 1;
+    const int j = ic / KV, v8 = ic % KV;
+    const int kk = kbase + v8 * 8;
+    wr[u] = ldraw<T>(Wp + (size_t)j * KH + (kk < KH ? kk : KH - 8));
+  }
   for (int i = t; i < a.B * a.J; i += 256) ds[i] = a.dout[i] * a.gscale;
-  const int k8 = t & 63, sub = t >> 6;
+  const int k8 = t % KV, sub = t / KV;
   const int k = kbase + k8 * 8;
   const bool kok = k < KH;
-  const int c0 = k % a.C;
+  const int c0 = (kok ? k : 0) % a.C;
   float sc[8], sh[8], mu[8], is[8];
-  if (kok) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      bn_moments(a.pro, c0 + j, mu[j], is[j]);
-      sc[j] = a.pro.gamma[c0 + j] * is[j];
-      sh[j] = a.pro.beta[c0 + j] - mu[j] * sc[j];
+  for (int j = 0; j < 8; ++j) {
+    bn_moments(a.pro, c0 + j, mu[j], is[j]);
+    sc[j] = a.pro.gamma[c0 + j] * is[j];
+    sh[j] = a.pro.beta[c0 + j] - mu[j] * sc[j];
+  }
+#pragma unroll
+  for (int u = 0; u < WLD; ++u) {
+    const int i = t + 256 * u;
+    if (i < a.J * KV) {
+      const int j = i / KV, v8 = i % KV;
+      float v[8];
+      cvt8(wr[u], v);
+      const bool ok = kbase + v8 * 8 < KH;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) wl[j * HBK + v8 * 8 + e] = ok ? v[e] : 0.f;
     }
   }
-  {
-    for (int i = t; i < a.J * 64; i += 256) {
-      const int j = i >> 6, v8 = i & 63;
-      float v[8];
-      if (kbase + v8 * 8 < KH) ld8<T>(Wp + (size_t)j * KH + kbase + v8 * 8, v);
-      else {
+  for (int i = t; i < 2 * HBK; i += 256) red[i] = 0.f;
+  __syncthreads();
+  T* G = reinterpret_cast<T*>(a.G);
+  float s1[8], s2[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = 0.f;
+  for (int j = 0; j < 8; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
+  if (kok) {
+    for (int b = sub; b < a.B; b += NSUB) {
+      float da[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) da[e] = 0.f;
+      for (int j = 0; j < a.J; ++j) {
+        const float d = ds[b * a.J + j];
+        const float4 w0 = *reinterpret_cast<const float4*>(wl + j * HBK + k8 * 8);
+        const float4 w1 = *reinterpret_cast<const float4*>(wl + j * HBK + k8 * 8 + 4);
+        da[0] += d * w0.x; da[1] += d * w0.y; da[2] += d * w0.z; da[3] += d * w0.w;
+        da[4] += d * w1.x; da[5] += d * w1.y; da[6] += d * w1.z; da[7] += d * w1.w;
       }
-#pragma unroll
-      for (int e = 0; e < 8; ++e) wl[j * 512 + v8 * 8 + e] = v[e];
-    }
-    for (int i = t; i < 1024; i += 256) red[i] = 0.f;
-    __syncthreads();
-    T* G = reinterpret_cast<T*>(a.G);
-    float s1[8], s2[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
-    if (kok) {
-      for (int b = sub; b < a.B; b += 4) {
-        float da[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) da[e] = 0.f;
-        for (int j = 0; j < a.J; ++j) {
-          const float d = ds[b * a.J + j];
-          const float4 w0 = *reinterpret_cast<const float4*>(wl + j * 512 + k8 * 8);
-          const float4 w1 = *reinterpret_cast<const float4*>(wl + j * 512 + k8 * 8 + 4);
-          da[0] += d * w0.x; da[1] += d * w0.y; da[2] += d * w0.z; da[3] += d * w0.w;
-          da[4] += d * w1.x; da[5] += d * w1.y; da[6] += d * w1.z; da[7] += d * w1.w;
-        }
-        float z[8];
-        ld8<T>(Z + (size_t)b * KH + k, z);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const float u = z[e] * sc[e] + sh[e];
-          da[e] = rnd<T>(da[e] * act_grad(u, a.pro.act, a.pro.slope));
-          s1[e] += da[e];
-          s2[e] += da[e] * ((z[e] - mu[e]) * is[e]);
-        }
-        st8<T>(G + (size_t)b * KH + k, da);
-      }
+      float z[8];
+      ld8<T>(Z + (size_t)b * KH + k, z);
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        atomicAdd(&red[k8 * 8 + e], s1[e]);
-        atomicAdd(&red[512 + k8 * 8 + e], s2[e]);
+        const float u = z[e] * sc[e] + sh[e];
+        da[e] = rnd<T>(da[e] * act_grad(u, a.pro.act, a.pro.slope));
+        s1[e] += da[e];
+        s2[e] += da[e] * ((z[e] - mu[e]) * is[e]);
       }
+      st8<T>(G + (size_t)b * KH + k, da);
     }
-    __syncthreads();
-    for (int i = t; i < 1024; i += 256) {
-      const int which = i >> 9, kk = kbase + (i & 511);
-      if (kk < KH) {
-        const int rep = blockIdx.x % a.oR;
-        atomicAdd(a.osums + (size_t)rep * 2 * a.C + (size_t)which * a.C + (kk % a.C), red[i]);
-      }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      atomicAdd(&red[k8 * 8 + e], s1[e]);
+      atomicAdd(&red[HBK + k8 * 8 + e], s2[e]);
+    }
+  }
+  __syncthreads();
+  for (int i = t; i < 2 * HBK; i += 256) {
+    const int which = i / HBK, kk = kbase + (i % HBK);
+    if (kk < KH) {
+      const int rep = blockIdx.x % a.oR;
+      atomicAdd(a.osums + (size_t)rep * 2 * a.C + (size_t)which * a.C + (kk % a.C), red[i]);
     }
   }
 }
@@ -480,8 +492,9 @@ extern "C" int spb_head_bwd(int dtype, const spb_head_bwd_args_t* a, spb_stream_
   if (!a || !a->Z || !a->Wp || !a->dout || !a->G || !a->osums || !a->dW || !a->dbias || !a->pro.gamma) return SPB_E_ARG;
   if (a->B <= 0 || a->J <= 0 || a->J > 32 || (a->C & 7) || a->oR < 1) return SPB_E_SHAPE;
   const int KH = a->HW * a->C;
-  const int gx = spb_ceil_div(KH, 512);
-  const size_t lds = ((size_t)((a->B * a->J + 3) & ~3) + (size_t)a->J * 512 + 1024) * sizeof(float);
+  const int gx = spb_ceil_div(KH, HBK);
+  const size_t lds = ((size_t)((a->B * a->J + 3) & ~3) + (size_t)a->J * HBK + 2 * HBK) * sizeof(float);
+  if (a->J * (HBK / 8) > 1024) return SPB_E_SHAPE;
   if (lds > 160 * 1024) return SPB_E_SHAPE;
   static bool attr_done = false;
   if (!attr_done) {

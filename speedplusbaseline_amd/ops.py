@@ -210,6 +210,17 @@ def grad_sqnorm(grads, out):
     L.check(L.lib().spb_grad_sqnorm(_ptr(grads), grads.numel(), _ptr(out), _stream()), "spb_grad_sqnorm")
 
 
+def arena_zero(arena):
+    """optimizer.zero_grad() on a flat f32 arena (no ATen kernel on the hot path)"""
+    _need_cuda(arena)
+    L.check(L.lib().spb_arena_zero(_ptr(arena), arena.numel(), _stream()), "spb_arena_zero")
+
+
+def arena_add(dst, src):
+    _need_cuda(dst, src)
+    L.check(L.lib().spb_arena_add(_ptr(dst), _ptr(src), dst.numel(), _stream()), "spb_arena_add")
+
+
 OPT_KIND = {"sgd": 0, "rmsprop": 1, "adam": 2, "adamw": 3}
 
 

@@ -90,7 +90,7 @@ class FusedTrainStep:
         e = self.e
         if not self.dann:
             _, scal, _ = e.forward(x, y, training=True, slot=0)
-            e.grads.zero_()
+            ops.arena_zero(e.grads)
             e.backward(self.B, slot=0)
             if self._overlap:   # early bucket: all-reduce on the communication stream beside the rest of the backward
                 e.wait_bucket(self.B, 0, self._comm)
@@ -104,7 +104,7 @@ class FusedTrainStep:
         # accumulates into its own gradient arena (summed in afterwards) and leaves its running-statistics update to the
         # main stream, so the shared buffers see source first, then target, as in the reference.
         if not self.dann_overlap:
-            e.grads.zero_()
+            ops.arena_zero(e.grads)
             _, scal, dom_s = e.forward(x, y, training=True, slot=0, domain=True)
             loss_s, dl_s = e.bce_logits(dom_s, 1.0)
             _, _, dom_t = e.forward(xt, None, training=True, slot=1, domain=True)
@@ -117,7 +117,7 @@ class FusedTrainStep:
             self._g2 = torch.zeros_like(e.grads)
             self._s2 = torch.cuda.Stream(device=e.device)
         e.prepare_weights()
-        e.grads.zero_(); self._g2.zero_()
+        ops.arena_zero(e.grads); ops.arena_zero(self._g2)
         self._s2.wait_stream(main)
         with torch.cuda.stream(self._s2):
             _, _, dom_t = e.forward(xt, None, training=True, slot=1, domain=True, prepare=False, update_running=False)
@@ -130,7 +130,7 @@ class FusedTrainStep:
         for t_ in (dom_t, loss_t, dl_t, xt):
             t_.record_stream(main)
         e.update_running(self.B, slot=1)
-        e.grads.add_(self._g2)
+        ops.arena_add(e.grads, self._g2)
         return torch.cat([scal, loss_s, loss_t])
 
     def _allreduce(self):

@@ -202,7 +202,12 @@ def test_pw_gemm_bwd(device, gemm_variant, dt, M, K, N, act1, act2):
     (500, 96, 24, L.ACT_RELU6, L.ACT_NONE, False, False),    # 96 -> 24
     (1234, 24, 144, L.ACT_NONE, L.ACT_RELU6, True, False),   # 24 -> 144
     (901, 144, 24, L.ACT_RELU6, L.ACT_NONE, False, False),   # 144 -> 24: two K splits
-    (4133, 144, 32, L.ACT_RELU6, L.ACT_NONE, False, False)])
+    (4133, 144, 32, L.ACT_RELU6, L.ACT_NONE, False, False),
+    # the production sizes at bs=48 (BASELINE configs[1]): 112x112 and 56x56 maps, M = 602 112 and 150 528 rows
+    (602112, 16, 96, L.ACT_NONE, L.ACT_RELU6, False, False),  # block 2 expand 16 -> 96 @112
+    (602112, 32, 16, L.ACT_RELU6, L.ACT_NONE, False, False),  # block 1 project 32 -> 16 @112
+    (150528, 144, 24, L.ACT_RELU6, L.ACT_NONE, False, False), # block 3 project 144 -> 24 @56
+    (150528, 24, 144, L.ACT_NONE, L.ACT_RELU6, True, True)])  # block 3 expand 24 -> 144 @56, skip gradient, materialised input
 def test_pw_bwd_fused(device, M, K, N, act1, act2, with_res, mat):
     """fused dgrad+wgrad (bf16 only) against the same float64 composite as the two-kernel path"""
     dt = torch.bfloat16
