@@ -55,6 +55,10 @@ def full_size(out):
     for k, p in net.named_parameters():
         out["full_grad_sum/" + k] = np.array(S.checksum(p.grad))
     out["full_grad_fc11_crop"] = net.fc11.weight.grad[:6, :6].numpy().copy()
+    for k, p in net.named_parameters():      # 64 scattered elements of every gradient (index (j * 7919) % n): layout check
+        g = p.grad.flatten()
+        idx = (torch.arange(64, dtype=torch.int64) * 7919) % g.numel()
+        out["full_grad_samples/" + k] = g[idx].numpy().copy()
     print("full size: loss %.6f (class %.6f, regress %.6f)" % (float(loss), float(lc), float(lr)))
 
 

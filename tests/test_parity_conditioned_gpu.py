@@ -87,6 +87,17 @@ def _condition(device, dann, B=B):
         s = ts(x, y, xt, alpha=O.dann_alpha(it, 0, STEPS, 1) if dann else 0.0)
         if it % 100 == 0 or it == STEPS - 1:
             hist.append(round(float(s[0]), 4))
+    # the f32 atomics of the weight-gradient kernels make every run's trajectory its own: if this one ended in a spike, keep
+    # polishing at the small learning rate until the state is trained-like (the parity bars below are about such states)
+    extra = 0
+    while hist[-1] > 0.05 and extra < 3:
+        ts.lr = 1e-4
+        for it in range(STEPS + 300 * extra, STEPS + 300 * (extra + 1)):
+            x, y = structured_batch(B, 100 + it, device)
+            xt = structured_batch(B, 900 + it, device)[0].flip(3) * 0.8 if dann else None
+            s = ts(x, y, xt, alpha=1.0 if dann else 0.0)
+        hist.append(round(float(s[0]), 4))
+        extra += 1
     torch.cuda.synchronize()
     print("conditioning (dann=%s) loss every 100 steps: %s" % (dann, hist))
     assert hist[-1] < 0.1 * hist[0], hist       # trained-like: per-keypoint error of a few percent of the frame

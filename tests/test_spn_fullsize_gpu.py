@@ -69,6 +69,16 @@ def test_full_size_training_gradients_bf16(device, init):
         n = p.numel()
         print("  %-12s mean|g| %.4e / %.4e   digest %.4e / %.4e" % (k, got[1], want[1], got[0], want[0]))
         assert abs(got[1] - want[1]) < 0.08 * want[1], k
-        assert abs(got[0] - want[0]) < 0.10 * want[1] * n ** 0.5 + 0.02 * abs(want[0]), k
+        # The weighted digest is a near-cancelling sum.  bf16 dlogits do not sum to exactly zero over the classes (5e-5 per row
+        # instead of 0), which shifts the SUM of fc8 / fc11's 20 M gradient elements by sum_b rowsum_b * sum_k h[b,k] ~ 3 while each
+        # element moves by 5e-4 of its size: the digest gets the coherent bound, the layout is pinned by the scattered samples.
+        assert abs(got[0] - want[0]) < 0.10 * want[1] * n ** 0.5 + 0.02 * abs(want[0]) + 2.0 ** -9 * want[1] * n * 0.25, k
+        g = p.grad.flatten()
+        idx = (torch.arange(64, dtype=torch.int64) * 7919) % n
+        smp, ref = g[idx.to(g.device)].float().cpu().numpy(), GOLD["full_grad_samples/" + k]
+        # elementwise: bf16 storage moves most entries by a few percent; below a ReLU a single flipped unit (32 samples, sparse
+        # activations) moves an isolated entry by its own size; a layout error moves nearly all of them
+        err, top = np.abs(smp - ref), np.abs(ref).max()
+        assert np.median(err) < 0.03 * top + 0.02 * want[1] and (err > 0.3 * top).mean() < 0.1, (k, np.median(err), err.max(), top)
     crop = net.fc11.weight.grad[:6, :6].float().cpu().numpy()
     assert np.abs(crop - GOLD["full_grad_fc11_crop"]).max() < 0.05 * np.abs(GOLD["full_grad_fc11_crop"]).max() + 1e-7
