@@ -435,6 +435,37 @@ def bench_dann(args):
     if world > 1:
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
     dt = float(t.item())
+    # ---- instrumented pass (both passes back to back on the launch stream, HIP events around every launch): the dominant
+    # kernel family of the step and its achieved HBM rate, as for the KRN line
+    roofline = None
+    if rank == 0:
+        n_prof = 3
+        eng.prof_enable(B, 0, True); eng.prof_enable(B, 1, True)
+        agg = {}
+        from speedplusbaseline_amd import ops as _ops
+        for _ in range(n_prof):
+            _ops.arena_zero(eng.grads)
+            _, _, dom_s = eng.forward(xs, ys, training=True, slot=0, domain=True)
+            _, dl_s = eng.bce_logits(dom_s, 1.0)
+            _, _, dom_t = eng.forward(xt, None, training=True, slot=1, domain=True)
+            _, dl_t = eng.bce_logits(dom_t, 0.0)
+            eng.backward(B, slot=0, with_pose=True, dlogit=dl_s, alpha=alpha)
+            eng.backward(B, slot=1, with_pose=False, dlogit=dl_t, alpha=alpha)
+            torch.cuda.synchronize()
+            for slot in (0, 1):
+                for k, v in eng.prof_read(B, slot).items():
+                    a = agg.setdefault(k, dict(launches=0, ms=0.0, bytes=0.0, flops=0.0))
+                    for f in a:
+                        a[f] += v[f]
+        eng.prof_enable(B, 0, False); eng.prof_enable(B, 1, False)
+        dk, dv = max(agg.items(), key=lambda kv: kv[1]["ms"])
+        ach = dv["bytes"] / (dv["ms"] * 1e-3) / 1e9
+        traffic, traffic_src = _pmc_traffic(dk)
+        roofline = dict(bound="hbm", kernel=dk, achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4),
+                        traffic=None, traffic_note="PMC passes were taken at bs=48 (%s); this line runs bs=%d" % (traffic_src, B),
+                        launches_per_step=dv["launches"] // n_prof, avg_launch_us=round(dv["ms"] / dv["launches"] * 1e3, 2),
+                        alg_bytes_per_launch=round(dv["bytes"] / dv["launches"]),
+                        step_sum_of_kernels_ms=round(sum(v["ms"] for v in agg.values()) / n_prof, 3))
     cpu = None
     if rank == 0 and not args.no_cpu_baseline:
         ncores = min(os.cpu_count() or 1, args.cpu_threads)
@@ -457,7 +488,7 @@ def bench_dann(args):
             "config": {"workload": "RevGrad (KRN + gradient-reversal domain classifier) step: bs=%d source + bs=%d target images/GPU, "
                                    "AdamW lr 1e-3 wd 0.01 + clip_grad_norm 1.0" % (B, B), "per_gpu_batch": B, "global_batch": B * world,
                        "parallelism": "dp%d" % world, "weights": "random init", "loss_last_step": [float(v) for v in scal.cpu()]},
-            "roofline": None, "cpu_baseline": cpu}))
+            "roofline": roofline, "cpu_baseline": cpu}))
     if world > 1:
         torch.distributed.destroy_process_group()
 
