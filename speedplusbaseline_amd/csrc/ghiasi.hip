@@ -231,22 +231,45 @@ __global__ __launch_bounds__(256) void gconv_kernel(const spb_gconv_args_t g, in
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) acc[p][nb] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
     if constexpr (WLDS) {
+      // Two-stage software pipeline over the taps: the fragment reads of step s+1 are issued before the MFMAs of step s.  The
+      // loop is not unrollable (runtime tap count), and without this every step exposed the LDS latency (~130 cycles) in front of
+      // NB * PXG MFMAs (32 cycles for the 64->32 layer): 146 of that layer's 333 us (round-2 ablation).
+      const int ns = (GABL & 1) ? 0 : nsteps;
       int ky = 0, kx = 0, cc = 0;
-      for (int s = 0; s < ((GABL & 1) ? 0 : nsteps); ++s) {
-        bf16x8_t bf[PXG];
+      bf16x8_t bfc[PXG], bfn[PXG];
+      uint4 auc[NB], aun[NB];
+      auto frag_load = [&](bf16x8_t* bfv, uint4* auv) {
 #pragma unroll
         for (int p = 0; p < PXG; ++p)
-          bf[p] = *reinterpret_cast<const bf16x8_t*>(hbase + (p * HT * HT + ky * HT + kx) * LDP + cc * 32);
+          bfv[p] = *reinterpret_cast<const bf16x8_t*>(hbase + (p * HT * HT + ky * HT + kx) * LDP + cc * 32);
         const int ko = (ky * KH + kx) * Cin + cc * 32 + lq * 8;
 #pragma unroll
+        for (int nb = 0; nb < NB; ++nb) auv[nb] = *reinterpret_cast<const uint4*>(wl + (wok[nb] ? nb * 16 + li : 0) * LDW + ko);
+        if (++cc == nch) { cc = 0; if (++kx == KH) { kx = 0; ++ky; } }
+      };
+      auto frag_mma = [&](const bf16x8_t* bfv, const uint4* auv) {
+#pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
-          uint4 au = *reinterpret_cast<const uint4*>(wl + (wok[nb] ? nb * 16 + li : 0) * LDW + ko);
-          if (!wok[nb]) au = make_uint4(0, 0, 0, 0);
+          const uint4 au = wok[nb] ? auv[nb] : make_uint4(0, 0, 0, 0);
 #pragma unroll
           for (int p = 0; p < PXG; ++p)
-            acc[p][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, au), bf[p], acc[p][nb], 0, 0, 0);
+            acc[p][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, au), bfv[p], acc[p][nb], 0, 0, 0);
         }
-        if (++cc == nch) { cc = 0; if (++kx == KH) { kx = 0; ++ky; } }
+      };
+      if (ns > 0) frag_load(bfc, auc);
+      int s = 0;
+      for (; s + 2 < ns; s += 2) {
+        frag_load(bfn, aun);
+        frag_mma(bfc, auc);
+        frag_load(bfc, auc);
+        frag_mma(bfn, aun);
+      }
+      if (s + 1 < ns) {            // two steps left
+        frag_load(bfn, aun);
+        frag_mma(bfc, auc);
+        frag_mma(bfn, aun);
+      } else if (s < ns) {
+        frag_mma(bfc, auc);
       }
     } else {
       uint4 an[PD][NB];
