@@ -122,7 +122,7 @@ def main():
                     ("SPB_PLAIN_DMA", "spb_debug_set_gemm_plain_dma"), ("SPB_DW_XCD", "spb_debug_set_dw_xcd"),
                     ("SPB_REPLICA_ROWS", "spb_debug_set_replica_rows"), ("SPB_BK64_DGRAD_MIN_K", "spb_debug_set_gemm_bk64_dgrad_min_k"),
                     ("SPB_WGRAD_BATCH", "spb_debug_set_wgrad_batch"), ("SPB_WGRAD_MIN_FLUSH", "spb_debug_set_wgrad_min_flush"),
-                    ("SPB_LAUNCH_EVENTS", "spb_debug_set_launch_events")):
+                    ("SPB_LAUNCH_EVENTS", "spb_debug_set_launch_events"), ("SPB_DW_SPLIT", "spb_debug_set_dw_split")):
         if os.environ.get(env) is not None:
             getattr(_L.lib(), fn)(int(os.environ[env]))
     if os.environ.get("SPB_STEM_GRID"):      # "fwd,wgrad" workgroup caps
@@ -528,7 +528,8 @@ def bench_spn(args):
     x, yc, yw = x.to(dev), yc.to(dev), yw.to(dev)
 
     def one():
-        out = net.loss_and_grads(x, yc, yw, world_size=world, group=group, compress_bf16=os.environ.get("SPB_SPN_BF16_GRADS") == "1")
+        out = net.loss_and_grads(x, yc, yw, world_size=world, group=group, compress_bf16=os.environ.get("SPB_SPN_BF16_GRADS") == "1",
+                                 optimizer=None if os.environ.get("SPB_SPN_EARLY_UPDATE") == "0" else opt)
         opt.step(world_size=world, group=group)
         return out
 

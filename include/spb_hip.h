@@ -234,6 +234,11 @@ int spb_grad_sqnorm(const float* grads, long long n, float* sqnorm_out /*[1], ze
  * backward passes of a DANN step accumulate into one gradient, dann.py:95); n elements, n % 4 == 0 for the add */
 int spb_arena_zero(float* arena, long long n, spb_stream_t stream);
 int spb_arena_add(float* dst, const float* src, long long n, spb_stream_t stream);
+/* A HIP stream at the device's highest (level < 0), default (0) or lowest (level > 0) dispatch priority.  The SPN step runs
+ * its 0.8 ms HBM-bound parameter update on a lowest-priority stream beside the trunk's backward: the dispatcher then fills
+ * the launch stream's kernels first and the update takes what they leave (host side: nets/spn.py loss_and_grads). */
+int spb_stream_create(int level, spb_stream_t* out);
+int spb_stream_destroy(spb_stream_t stream);
 typedef struct spb_optim_args {
   float* params; float* grads; float* m; float* v; /* flat f32 arenas; m/v may be NULL for sgd w/o momentum */
   const float* sqnorm;  /* optional device scalar: clip coefficient = min(1, max_norm/(sqrt(sqnorm)+1e-6)) */
@@ -247,8 +252,15 @@ typedef struct spb_optim_args {
   int first_step;       /* sgd momentum buffer initialisation */
   void* shadow_bf16;    /* optional bf16 arena with the parameter arena's offsets: receives the updated value of every
                            element, so the next forward needs no separate conversion pass (SPN, 152 M parameters) */
+  int max_blocks;       /* > 0: at most this many workgroups, each walking the arena with a grid stride -- a background
+                           update that leaves the compute units to the kernels of another stream; 0: one block per run */
 } spb_optim_args_t;
 int spb_optim_step(const spb_optim_args_t* a, spb_stream_t stream);
+/* Weight gradient of a fully connected layer (spb_fc_wgrad's operands: GT [N][MP], XT [K][MP], batch M <= 64) fused with that
+ * layer's share of the optimizer step: opt->params / m / v / shadow_bf16 point at the layer's [N][K] weight (opt->n == N*K),
+ * opt->grads is NULL or receives the raw gradient.  Same arithmetic per element as spb_fc_wgrad followed by spb_optim_step;
+ * max_norm must be 0 (a global-norm clip needs all gradients first -- the SPN trainer clips by value, trainer.py:177). */
+int spb_fc_wgrad_update(const void* GT, const void* XT, int M, int N, int K, const spb_optim_args_t* opt, spb_stream_t stream);
 
 /* ---- whole-network plans (C++ runtime: layer graph, workspace layout, launch sequencing) -------------------- */
 typedef struct spb_krn spb_krn_t;
@@ -393,6 +405,23 @@ int spb_colsum(int dtype, const void* g, float* out, long long M, int N, spb_str
 /* nn.Conv2d weights [Cout][Cin/groups][KH][KW] f32 (spn.py:56-70) -> Wp [Cout][Kg]: row co holds its group's filter in
  * (ky,kx,c_local) order, zero padded to Kg (i.e. `groups` stacked [Cout/groups][Kg] GEMM operands matching spb_im2col's
  * slabs), and WpT [groups][Kg][Cout/groups], the per-group transposes the input gradient needs (may be NULL).  dtype = output. */
+/* ---- SPN trunk convolutions as implicit GEMMs (csrc/spn_conv.hip; reference spn.py:60-101 nn.Conv2d + ReLU) -------------
+ * X: bf16 NHWC [B][H][W][Cx]; Wp: bf16 [groups*Ng][Kp], row n = (ky, kx, c) of output channel n over its group's Cg input
+ * channels (spb_spn_pack_conv's layout), zero padded to Kp; Y: bf16 [B*OH*OW][groups*Ng] = act(conv + bias).
+ * mask (optional, same shape as Y): elements of Y where mask <= 0 are stored as 0 -- the ReLU backward of the layer below
+ * when the call computes an input gradient: X = output gradient, Wp = spb_spn_pack_conv_dgrad's mirrored weights,
+ * Cg <-> Ng swapped, pad = K-1-pad (stride-1 layers).  Cg, Cx, Kp must be multiples of 8 (16-byte operand vectors). */
+typedef struct spb_spn_conv_args {
+  const void* X; const void* Wp; const float* bias; const void* mask; void* Y;
+  int B, H, W, Cx, KH, KW, stride, pad, groups, Cg, Ng, Kp, relu;
+} spb_spn_conv_args_t;
+int spb_spn_conv(const spb_spn_conv_args_t* args, spb_stream_t stream);
+/* weight gradient of the same convolution (args as for the forward call; Wp / bias / mask / Y / relu unused):
+ * dWp f32 [groups*Ng][Kp] += sum over output pixels of G[m][n] * X[pixel(m, tap)][c]; G: bf16 [B*OH*OW][groups*Ng].
+ * Partial sums of the pixel ranges meet in dWp with float atomics: zero it first. */
+int spb_spn_conv_wgrad(const spb_spn_conv_args_t* args, const void* G, float* dWp, spb_stream_t stream);
+/* W: f32 [Cout][Cin/groups][KH][KW] -> WpD: bf16 [Cin][KpD], row g*Cg+ci = (mirrored tap, n) over the group's Cout/groups */
+int spb_spn_pack_conv_dgrad(const float* W, void* WpD, int Cout, int Cin, int groups, int KH, int KW, int KpD, spb_stream_t stream);
 int spb_spn_pack_conv(int dtype, const float* W, void* Wp, void* WpT, int Cout, int Cin, int groups, int KH, int KW, int Kg,
                       int chw_order, spb_stream_t stream);   /* chw_order != 0: rows keep nn.Conv2d's (c,ky,kx) order (conv1 / spb_im2col_rgb) */
 /* inverse for gradients: dWp f32 [Cout][Kg] -> dW f32 [Cout][Cin/groups][KH][KW] */
@@ -458,6 +487,8 @@ int spb_preproc_batch(const spb_preproc_args_t* a, spb_stream_t stream);
 /* debug / test helpers */
 int spb_debug_set_conv9_band(int on); /* decoder's last 9x9 layer: band-staged kernel (1, default) or the generic 8x8-tile kernel */
 int spb_debug_set_launch_events(int on); /* side-stream forks wait on the preceding GEMM launch's completion event (1) or on a recorded event (0) */
+int spb_debug_set_dw_split(int rows);      /* depthwise layers with fewer than `rows` input rows (B*H*W) run their weight gradient on
+                                              the side stream, apart from the input gradient (default 32768; 0 = always fused) */
 int spb_debug_set_wgrad_min_flush(int n); /* fork at a depthwise backward kernel only when >= n weight gradients are queued */
 int spb_debug_set_wgrad_batch(int n); /* pointwise weight-gradient GEMMs handed to the side stream per fork event */
 int spb_debug_set_gemm_bk64_dgrad_min_k(int k); /* backward-type small-M GEMMs with K >= k: 64x32 tiles with 64-deep chunks */

@@ -9,22 +9,22 @@ opt = SpnOptimizer(list(net.parameters()), kind="adamw", lr=1e-4, momentum=0.9, 
 x, yc, yw = next(iter(SyntheticSpnLoader(32, 1, 5000, 5)))
 x, yc, yw = x.to(dev), yc.to(dev), yw.to(dev)
 for _ in range(5):
-    net.loss_and_grads(x, yc, yw); opt.step()
+    net.loss_and_grads(x, yc, yw, optimizer=opt); opt.step()
 hs = []
 for _ in range(20):
     torch.cuda.synchronize()
-    t0 = time.perf_counter(); net.loss_and_grads(x, yc, yw); opt.step(); hs.append(time.perf_counter() - t0)
+    t0 = time.perf_counter(); net.loss_and_grads(x, yc, yw, optimizer=opt); opt.step(); hs.append(time.perf_counter() - t0)
 print("SPN host enqueue into an idle queue: median %.3f ms" % (statistics.median(hs) * 1e3))
 torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(50):
-    net.loss_and_grads(x, yc, yw); opt.step()
+    net.loss_and_grads(x, yc, yw, optimizer=opt); opt.step()
 t1 = time.perf_counter(); torch.cuda.synchronize(); t2 = time.perf_counter()
 print("50 steps: host %.3f ms/step, total %.3f ms/step" % ((t1 - t0) / 50 * 1e3, (t2 - t0) / 50 * 1e3))
 for sw in (False, True):
     net.side_wgrad = sw
     for _ in range(5):
-        net.loss_and_grads(x, yc, yw); opt.step()
+        net.loss_and_grads(x, yc, yw, optimizer=opt); opt.step()
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(50):
-        net.loss_and_grads(x, yc, yw); opt.step()
+        net.loss_and_grads(x, yc, yw, optimizer=opt); opt.step()
     torch.cuda.synchronize(); print("side_wgrad=%s: %.3f ms/step" % (sw, (time.perf_counter() - t0) / 50 * 1e3))

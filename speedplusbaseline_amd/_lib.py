@@ -88,7 +88,12 @@ class OptimArgs(C.Structure):
     _fields_ = [("params", vp), ("grads", vp), ("m", vp), ("v", vp), ("sqnorm", vp), ("gmul", vp), ("hyper", vp),
                 ("n", i64), ("kind", i32), ("lr", f32), ("beta1", f32), ("beta2", f32), ("eps", f32),
                 ("weight_decay", f32), ("max_norm", f32), ("clip_value", f32), ("bias_c1", f32), ("bias_c2", f32),
-                ("first_step", i32), ("shadow_bf16", vp)]
+                ("first_step", i32), ("shadow_bf16", vp), ("max_blocks", i32)]
+
+
+class SpnConvArgs(C.Structure):
+    _fields_ = [("X", vp), ("Wp", vp), ("bias", vp), ("mask", vp), ("Y", vp)] + [(k, i32) for k in
+                ("B", "H", "W", "Cx", "KH", "KW", "stride", "pad", "groups", "Cg", "Ng", "Kp", "relu")]
 
 
 class PreprocArgs(C.Structure):
@@ -127,7 +132,10 @@ SYMBOLS = {
     "spb_grad_sqnorm": (i32, [vp, i64, vp, vp]),
     "spb_arena_zero": (i32, [vp, i64, vp]),
     "spb_arena_add": (i32, [vp, vp, i64, vp]),
+    "spb_stream_create": (i32, [i32, C.POINTER(C.c_void_p)]),
+    "spb_stream_destroy": (i32, [vp]),
     "spb_optim_step": (i32, [C.POINTER(OptimArgs), vp]),
+    "spb_fc_wgrad_update": (i32, [vp, vp, i32, i32, i32, C.POINTER(OptimArgs), vp]),
     "spb_krn_create": (i32, [i32, i32, C.POINTER(vp)]),
     "spb_krn_destroy": (None, [vp]),
     "spb_krn_num_params": (i32, [vp]),
@@ -181,6 +189,7 @@ SYMBOLS = {
     "spb_debug_set_optim": (i32, [i32, i32, i32]),
     "spb_debug_set_conv9_band": (i32, [i32]),
     "spb_debug_set_launch_events": (i32, [i32]),
+    "spb_debug_set_dw_split": (i32, [i32]),
     "spb_debug_set_wgrad_min_flush": (i32, [i32]),
     "spb_debug_set_wgrad_batch": (i32, [i32]),
     "spb_debug_set_gemm_bk64_dgrad_min_k": (i32, [i32]),
@@ -190,6 +199,9 @@ SYMBOLS = {
     "spb_debug_set_gemm_plain_dma": (i32, [i32]),
     "spb_spn_pack_conv": (i32, [i32, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
     "spb_spn_unpack_conv_grad": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
+    "spb_spn_conv": (i32, [C.POINTER(SpnConvArgs), vp]),
+    "spb_spn_conv_wgrad": (i32, [C.POINTER(SpnConvArgs), vp, vp, vp]),
+    "spb_spn_pack_conv_dgrad": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "spb_fc_fwd": (i32, [vp, vp, vp, i32, i32, i32, vp]),
     "spb_fc_dgrad": (i32, [vp, vp, vp, i32, i32, i32, vp]),
     "spb_fc_wgrad": (i32, [vp, vp, vp, i32, i32, i32, vp]),

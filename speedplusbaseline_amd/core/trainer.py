@@ -147,7 +147,8 @@ def train_single_epoch_spn(epoch, cfg, model, data_loader, optimizer, writer, de
         yWeights = yWeights.to(device, non_blocking=True)
         if styleAugmentor is not None and _texture_coin(cfg, epoch * n_iter + idx):
             images = styleAugmentor(images)
-        out = model.loss_and_grads(images, yClasses, yWeights, world_size=world, group=group)   # gradients land in p.grad (no autograd)
+        out = model.loss_and_grads(images, yClasses, yWeights, world_size=world, group=group,   # gradients land in p.grad (no autograd);
+                                   optimizer=optimizer)       # the heads' share of the update runs beside the rest of backward
         optimizer.step(world_size=world, group=group)            # [all-reduce,] clip_grad_value_(1.0) + update: one launch
         lc, lr_ = out[1:3].tolist()                              # host floats per step, as the reference reports
         training_time_meter.update((time.time() - start) * 1000, B)
@@ -155,6 +156,7 @@ def train_single_epoch_spn(epoch, cfg, model, data_loader, optimizer, writer, de
         loss_weight_meter.update(lr_, B)
         report_progress(epoch=epoch, lr=lr, epoch_iter=idx + 1, epoch_size=n_iter, time=training_time_meter, is_train=True,
                         loss_c=loss_class_meter, loss_r=loss_weight_meter)
+    model.join_updates()     # the last step's update of the heads (it ran on beside this loop's tail) before anyone reads parameters
     if writer is not None:
         writer.add_scalar('train/loss_c', loss_class_meter.avg, epoch)
         writer.add_scalar('train/loss_r', loss_weight_meter.avg, epoch)

@@ -670,6 +670,7 @@ void dw_set_lds(K kernel) {
 // the LDS-tiled kernels of this file (A/B measurements, spb_debug_set_dw_mode)
 int spb_dwr_fwd(int dtype, const spb_dw_args_t* a, hipStream_t s);
 int spb_dwr_bwd(int dtype, const spb_dw_args_t* a, hipStream_t s);
+int spb_dwr_wgrad(int dtype, const spb_dw_args_t* a, hipStream_t s);
 static int g_dw_mode = 1;
 extern "C" int spb_debug_set_dw_mode(int mode) { g_dw_mode = mode; return 0; }
 
@@ -746,6 +747,15 @@ extern "C" int spb_dwconv_wgrad(int dtype, const spb_dw_args_t* a, spb_stream_t 
   int e = dw_check(a);
   if (e) return e;
   if (!a->dW || !a->Xin) return SPB_E_ARG;
+  if (dtype != SPB_BF16 && dtype != SPB_F32) return SPB_E_ARG;
+  if (g_dw_mode == 1) {    // row-unit kernel, weight-gradient-only instance: the input tensor travels as Zout / epi there
+    spb_dw_args_t k = *a;
+    k.Zout = a->Xin; k.epi = a->pro_in; k.Y = nullptr; k.epi_mode = 0; k.res = nullptr;
+    if (!k.X2) k.X2 = k.X;
+    spb_dwr_wgrad(dtype, &k, (hipStream_t)stream);
+    SPB_CHECK_LAUNCH();
+    return 0;
+  }
   const int st = a->stride;
   const int OH = (a->H - 1) / st + 1, OW = (a->W - 1) / st + 1;
   const Tiles tl = make_tiles(a->B, OH, OW, st);

@@ -302,8 +302,12 @@ __global__ __launch_bounds__(256, 2) void dwr_fwd_kernel(const spb_dw_args_t a, 
 // ST = 2: lane column = dz column q; element i = dz row r0+i (+ conv-input rows 2r, 2r+1, columns 2q, 2q+1 of step
 //         r = r0+i-1); from i >= 1 the lane produces the input pixels (2r | 2r+1, 2q | 2q+1) -- exactly the 9
 //         (tap, pixel) products of step r, none masked away.
-template <typename T, int ST, bool WG, bool EPI>
+// DG = false: weight gradient only (no input-gradient taps, nothing stored): the instance the KRN plan runs on its side stream
+// for the 14x14 / 7x7 maps, where the fused kernel is bound by VALU issue (18 FMAs per element instead of 9) on the launch
+// stream's critical path while most of the chip idles.
+template <typename T, int ST, bool WG, bool EPI, bool DG = true>
 __global__ __launch_bounds__(256, 2) void dwr_bwd_kernel(const spb_dw_args_t a, const Geo g) {
+  static_assert(DG || (WG && !EPI), "the weight-gradient-only instance has no epilogue");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NP = ST == 1 ? 14 : 15;
   constexpr int LH = ST == 1 ? 1 : 0;                    // stride 2 only needs the right neighbour
@@ -462,7 +466,7 @@ __global__ __launch_bounds__(256, 2) void dwr_bwd_kernel(const spb_dw_args_t a, 
           ld_lds8(cf + ((ky) * 3 + 2) * 8, w2);                                            \
           _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                  \
             const float vr = from_right(DR[j]), vl = from_left(DR[j]);                     \
-            acc[j] += vr * w0[j] + DR[j] * w1[j] + vl * w2[j];                             \
+            if (DG) acc[j] += vr * w0[j] + DR[j] * w1[j] + vl * w2[j];                     \
             if (WG) {                                                                      \
               aw[WG ? (ky) * 3 + 0 : 0][j] += vr * ap[j];                                  \
               aw[WG ? (ky) * 3 + 1 : 0][j] += DR[j] * ap[j];                               \
@@ -472,7 +476,7 @@ __global__ __launch_bounds__(256, 2) void dwr_bwd_kernel(const spb_dw_args_t a, 
         }
         DWR_ROW(0, dp) DWR_ROW(1, d0) DWR_ROW(2, dm)
 #undef DWR_ROW
-        fin(acc, zf, ok, ((size_t)(cc.b * H + clampi(r, 0, H - 1)) * W + clampi(q, 0, W - 1)) * C + c0);
+        if (DG) fin(acc, zf, ok, ((size_t)(cc.b * H + clampi(r, 0, H - 1)) * W + clampi(q, 0, W - 1)) * C + c0);
       }
 #pragma unroll
       for (int j = 0; j < 8; ++j) { dm[j] = d0[j]; d0[j] = dp[j]; }
@@ -500,7 +504,7 @@ __global__ __launch_bounds__(256, 2) void dwr_bwd_kernel(const spb_dw_args_t a, 
           if (WG) apf(zf, ok, ap);                                                         \
           _Pragma("unroll") for (int j = 0; j < 8; ++j) acc[j] = 0.f;                      \
           BODY                                                                             \
-          fin(acc, zf, ok, (OFF));                                                         \
+          if (DG) fin(acc, zf, ok, (OFF));                                                 \
         }
 #define DWR_TAP(k, V)                                                                      \
         {                                                                                  \
@@ -508,7 +512,7 @@ __global__ __launch_bounds__(256, 2) void dwr_bwd_kernel(const spb_dw_args_t a, 
           ld_lds8(cf + (k) * 8, w);                                                        \
           _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                  \
             const float v = (V);                                                           \
-            acc[j] += v * w[j];                                                            \
+            if (DG) acc[j] += v * w[j];                                                    \
             if (WG) aw[WG ? (k) : 0][j] += v * ap[j];                                      \
           }                                                                                \
         }
@@ -617,6 +621,31 @@ int spb_dwr_fwd(int dtype, const spb_dw_args_t* a, hipStream_t s) {
   if (dtype == SPB_BF16) { if (st == 1) L_(bf16_t, 1) else L_(bf16_t, 2) }
   else { if (st == 1) L_(float, 1) else L_(float, 2) }
 #undef L_
+  return 0;
+}
+
+// weight gradient alone (a->Zout / a->epi name the convolution's input tensor and its BN + activation, a->Y is unused)
+int spb_dwr_wgrad(int dtype, const spb_dw_args_t* a, hipStream_t s) {
+  const int st = a->stride;
+  const int OH = (a->H - 1) / st + 1, OW = (a->W - 1) / st + 1;
+  const Geo g = make_geo(a->B, a->C, OH, OW, st == 1 ? 14 : 15, st == 1 ? 2 : 1, 512);
+  const int nquads = ((a->C >> 3) + 3) / 4;
+  const dim3 grid((unsigned)(nquads * g.nb));
+  const int es = dtype == SPB_BF16 ? 1 : 2;
+  const int ns = 2 + (st == 1 ? 1 : 4);
+  const int rd = ring_depth_host(ns, es);
+  size_t lds = 4 * CFN * sizeof(float) + (size_t)4 * rd * ns * es * 1024;
+  const size_t red = (size_t)16 * 72 * sizeof(float) + 4 * CFN * sizeof(float);
+  if (lds < red) lds = red;
+#define W_(T_, ST_)                                                                                        \
+  {                                                                                                        \
+    static bool once = false;                                                                              \
+    if (!once) { allow_lds(dwr_bwd_kernel<T_, ST_, true, false, false>, 160 * 1024); once = true; }        \
+    hipLaunchKernelGGL((dwr_bwd_kernel<T_, ST_, true, false, false>), grid, dim3(256), lds, s, *a, g);     \
+  }
+  if (dtype == SPB_BF16) { if (st == 1) W_(bf16_t, 1) else W_(bf16_t, 2) }
+  else { if (st == 1) W_(float, 1) else W_(float, 2) }
+#undef W_
   return 0;
 }
 

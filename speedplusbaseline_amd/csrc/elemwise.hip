@@ -6,6 +6,7 @@
 //   * global-norm clip + optimiser update fused over the flat parameter arena
 //       (reference trainer.py:90,97  clip_grad_norm_; build.py:60-78 sgd/rmsprop/adam/adamw)
 #include "common.h"
+#include "optim_math.h"
 
 namespace {
 
@@ -238,38 +239,6 @@ __global__ __launch_bounds__(256) void grad_sqnorm_kernel(const float* __restric
   if (threadIdx.x == 0) { *out = red[0] + red[1] + red[2] + red[3]; *counter = 0; }
 }
 
-// one element of the update; m / v are the moment values (read and written back by the caller when the kind uses them)
-__device__ __forceinline__ float optim_one(const spb_optim_args_t& a, float gs, float lr, float bias_c1, float bias_c2, float p, float g,
-                                           float& m, float& v) {
-  g *= gs;
-  if (a.clip_value > 0.f) g = fminf(fmaxf(g, -a.clip_value), a.clip_value);
-  if (a.kind == 3) {  // adamw (decoupled decay)
-    p *= 1.f - lr * a.weight_decay;
-    m = a.beta1 * m + (1.f - a.beta1) * g;
-    v = a.beta2 * v + (1.f - a.beta2) * g * g;
-    const float denom = sqrtf(v) / sqrtf(bias_c2) + a.eps;
-    p -= (lr / bias_c1) * (m / denom);
-  } else if (a.kind == 2) {  // adam (L2 folded into the gradient)
-    g += a.weight_decay * p;
-    m = a.beta1 * m + (1.f - a.beta1) * g;
-    v = a.beta2 * v + (1.f - a.beta2) * g * g;
-    const float denom = sqrtf(v) / sqrtf(bias_c2) + a.eps;
-    p -= (lr / bias_c1) * (m / denom);
-  } else if (a.kind == 1) {  // rmsprop (alpha = beta2 slot), no momentum, not centred
-    g += a.weight_decay * p;
-    v = a.beta2 * v + (1.f - a.beta2) * g * g;
-    p -= lr * g / (sqrtf(v) + a.eps);
-  } else {  // sgd with momentum (beta1), dampening 0
-    g += a.weight_decay * p;
-    if (a.beta1 != 0.f && a.m) {
-      m = a.first_step ? g : a.beta1 * m + g;
-      g = m;
-    }
-    p -= lr * g;
-  }
-  return p;
-}
-
 // VEC = 4: 16-byte accesses (n % 4 == 0, 16-byte aligned arenas); VEC = 1: scalar.  NT: non-temporal accesses (a 150 M
 // element arena is a pure stream: nothing is reused from L2 / MALL)
 template <bool NT> __device__ __forceinline__ f32x4_t ldv(const float* p, long long i) {
@@ -299,7 +268,9 @@ __global__ __launch_bounds__(256) void optim_step_kernel(const spb_optim_args_t 
   const bool has_v = a.v && a.kind >= 1;
   bf16_t* sh = reinterpret_cast<bf16_t*>(a.shadow_bf16);
   const long long nv = a.n / VEC;
-  const long long base = (long long)blockIdx.x * (256 * U) + threadIdx.x;
+  // one pass unless the launch was capped (max_blocks): then every block walks the arena with a grid stride
+  for (long long run = blockIdx.x; run * (256 * U) < nv; run += gridDim.x) {
+  const long long base = run * (256 * U) + threadIdx.x;
   if constexpr (VEC == 4) {
     f32x4_t p[U], g[U], m[U], v[U];
 #pragma unroll
@@ -341,6 +312,7 @@ __global__ __launch_bounds__(256) void optim_step_kernel(const spb_optim_args_t 
         if (sh) sh[i] = f2bf(p);
       }
     }
+  }
   }
 }
 
@@ -468,10 +440,12 @@ extern "C" int spb_optim_step(const spb_optim_args_t* a, spb_stream_t stream) {
   if (a->kind == 1 && !a->v) return SPB_E_ARG;
   const bool vec = !(a->n & 3) && !(((uintptr_t)a->params | (uintptr_t)a->grads | (uintptr_t)a->m | (uintptr_t)a->v) & 15) &&
                    !((uintptr_t)a->shadow_bf16 & 7);
-  const bool v4 = vec && g_opt_vec == 4;
+  const bool capped = a->max_blocks > 0;     // few workgroups: each thread keeps 4 x 16 bytes of every stream in flight
+  const bool v4 = vec && (g_opt_vec == 4 || capped);
   const long long items = v4 ? a->n / 4 : a->n;
-  const int U = g_opt_blocks > 0 ? g_opt_blocks : 1;      // debug knob reused: vectors per thread
-  const unsigned blocks = (unsigned)((items + 256 * U - 1) / (256 * U));
+  const int U = capped ? 4 : (g_opt_blocks > 0 ? g_opt_blocks : 1);      // debug knob reused: vectors per thread
+  unsigned blocks = (unsigned)((items + 256 * U - 1) / (256 * U));
+  if (a->max_blocks > 0 && blocks > (unsigned)a->max_blocks) blocks = (unsigned)a->max_blocks;
   hipStream_t hs = (hipStream_t)stream;
 #define SPB_OPT_LAUNCH(V, NTF, UU) hipLaunchKernelGGL((optim_step_kernel<V, NTF, UU>), dim3(blocks), dim3(256), 0, hs, *a)
   if (v4) {
@@ -488,4 +462,23 @@ extern "C" int spb_optim_step(const spb_optim_args_t* a, spb_stream_t stream) {
 extern "C" int spb_debug_set_optim(int vec, int blocks, int nontemporal) {
   g_opt_vec = vec == 4 ? 4 : 1; g_opt_blocks = blocks; g_opt_nt = nontemporal;
   return 0;
+}
+
+// Streams for work that must not compete with the launch stream for the compute units: level -1 = the device's highest
+// dispatch priority, 0 = default, +1 = lowest (the workgroup dispatcher serves higher-priority queues first, so a low stream's
+// long memory-bound kernel fills the slots the launch stream's kernels leave free instead of taking half the chip from them).
+extern "C" int spb_stream_create(int level, spb_stream_t* out) {
+  if (!out) return SPB_E_ARG;
+  int least = 0, greatest = 0;
+  hipError_t e = hipDeviceGetStreamPriorityRange(&least, &greatest);
+  if (e != hipSuccess) return (int)e;
+  const int pr = level < 0 ? greatest : (level > 0 ? least : (least + greatest) / 2);
+  hipStream_t s = nullptr;
+  e = hipStreamCreateWithPriority(&s, hipStreamNonBlocking, pr);
+  if (e != hipSuccess) return (int)e;
+  *out = (spb_stream_t)s;
+  return 0;
+}
+extern "C" int spb_stream_destroy(spb_stream_t s) {
+  return s && hipStreamDestroy((hipStream_t)s) == hipSuccess ? 0 : SPB_E_ARG;
 }

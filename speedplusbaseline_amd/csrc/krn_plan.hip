@@ -232,6 +232,8 @@ static int g_wgrad_flush_at_dw = 1;
 static int g_wgrad_min_flush = 1;      // flush at a depthwise kernel only with at least this many queued
 extern "C" int spb_debug_set_wgrad_min_flush(int n) { g_wgrad_min_flush = n < 1 ? 1 : n; return 0; }
 static int g_wgrad_batch = 8;
+static long long g_dw_split_rows = 32768;   // depthwise layers with fewer input rows (B*H*W) send their weight gradient to the side stream
+extern "C" int spb_debug_set_dw_split(int rows) { g_dw_split_rows = rows; return 0; }
 extern "C" int spb_debug_set_wgrad_batch(int n) {
   g_wgrad_flush_at_dw = n < 0;
   if (n < 0) n = -n;
@@ -354,7 +356,9 @@ struct Runner {
     }
     // this launch's own completion event: what the queued weight gradients wait for (see flush_wgrads)
     launch_ev = nullptr;
-    if (g_launch_events && before_dw && (!pend.empty() || head_pending)) { launch_ev = next_event(); g.stop_event = launch_ev; }
+    if (g_launch_events && before_dw && (!pend.empty() || head_pending || g_dw_split_rows > 0) && side_usable()) {
+      launch_ev = next_event(); g.stop_event = launch_ev;
+    }
     ok(spb_pwconv_gemm(dt, &g, st));
     toc();
   }
@@ -369,8 +373,9 @@ struct Runner {
     }
     return c->fork_ev[c->n_fork++];
   }
+  bool side_usable() const { return !(c->prof_on || !c->side || !c->side_on || !g_side_wgrad); }
   hipStream_t side_stream() {
-    if (c->prof_on || !c->side || !c->side_on || !g_side_wgrad) return st;
+    if (!side_usable()) return st;
     hipEvent_t e = next_event();
     hipEventRecord(e, st);
     hipStreamWaitEvent(c->side, e, 0);
@@ -393,14 +398,17 @@ struct Runner {
     if (c->prof_on || !c->side || !c->side_on || !g_side_wgrad) { ok(spb_head_bwd(dt, &h, st)); return; }
     head_args = h; head_pending = true;
   }
+  std::vector<spb_dw_args_t> pend_dw;   // depthwise weight gradients of the small maps (see dw_bwd)
   void flush_wgrads() {
-    if (pend.empty() && !head_pending) return;
+    if (pend.empty() && pend_dw.empty() && !head_pending) return;
     hipStream_t s;
     if (launch_ev) {   // everything the queued GEMMs read was final before that launch: wait for it, record nothing
       hipStreamWaitEvent(c->side, launch_ev, 0);
       launch_ev = nullptr; forked = true; s = c->side;
     } else s = side_stream();            // one event record for the whole batch
     if (head_pending) { ok(spb_head_bwd(dt, &head_args, s)); head_pending = false; }
+    for (const spb_dw_args_t& d : pend_dw) ok(spb_dwconv_wgrad(dt, &d, s));
+    pend_dw.clear();
     for (const spb_wgrad_args_t& w : pend) ok(spb_pwconv_wgrad(dt, &w, s));
     pend.clear();
   }
@@ -413,12 +421,23 @@ struct Runner {
   }
   bool forked = false;
   void dw_bwd(const DWDef& L, const Src& in, int Hin, int aout, int atgt, void* plain, const void* res) {
-    if (g_wgrad_flush_at_dw && (int)pend.size() >= g_wgrad_min_flush) flush_wgrads();   // they run beside this memory-bound kernel
-    // one fused pass: input gradient (+ activation mask / BN sums of the input-side tensor) and weight gradient
     spb_dw_args_t d; std::memset(&d, 0, sizeof(d));
     d.X = this->g(aout); d.X2 = z(aout); d.Xin = in.ptr; d.Wd = m->P + L.w_off; d.dW = m->G + L.w_off;
     d.pro = ref(aout, true); d.pro_in = in.ref; d.B = c->B; d.H = Hin; d.W = Hin; d.C = L.C; d.stride = L.stride;
     d.Zout = in.ptr; d.epi = in.ref;  // the convolution's input and its BN/activation (== ref(atgt) when atgt >= 0)
+    // Small maps (14x14, 7x7): the fused kernel is bound by VALU issue in a few workgroups, not by memory, and it sits on the
+    // launch stream's critical path.  There the weight gradient goes to the side stream with the pointwise ones (everything it
+    // reads -- g, z and the batch sums of this layer's output, the forward input -- is final and never rewritten during
+    // backward) and the launch stream runs the input gradient alone.
+    const bool split = side_usable() && (long long)c->B * Hin * Hin < g_dw_split_rows;
+    if (split) {
+      pend_dw.push_back(d);
+      d.dW = nullptr;
+    }
+    // the queued weight gradients run beside this memory-bound kernel
+    if (g_wgrad_flush_at_dw && (int)(pend.size() + pend_dw.size()) >= g_wgrad_min_flush) flush_wgrads();
+    launch_ev = nullptr;   // the event belongs to the launch before this one: nothing queued later may fork on it
+    // one fused pass: input gradient (+ activation mask / BN sums of the input-side tensor) and weight gradient
     if (atgt >= 0) {
       d.Y = this->g(atgt); d.osums = bsums(atgt); d.oR = c->R[atgt]; d.res = res; d.epi_mode = 2;
     } else { d.Y = plain; d.epi_mode = 0; d.oR = 1; }

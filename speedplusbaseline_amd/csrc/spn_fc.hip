@@ -14,6 +14,7 @@
 //              row-major tensor, its transpose (operand of fc_wgrad) and re-zeroes the accumulator
 // accT is a feature-major f32 accumulator [features][MP] that is zero between uses (fc_epi / unflatten clean it).
 #include "common.h"
+#include "optim_math.h"
 
 namespace {
 
@@ -159,9 +160,24 @@ __global__ __launch_bounds__(256) void fc_dgrad_kernel(const bf16_t* __restrict_
 // ------------------------------------------------------------------------------------------------ weight gradient
 // grid = ceil(N/64) * ceil(K/(64*KW)) workgroups of 4 waves; a workgroup owns 64 output rows n; wave w writes the
 // 64-wide column blocks kb = (blk*4 + w)*KPW .. +KPW.
-template <int MT>
+// FUSED: the layer's share of the optimizer step in the epilogue (spb_fc_wgrad_update): every dW element is produced by exactly
+// one lane (the batch is the whole reduction), so clip_grad_value_ + update + bf16 shadow are applied to it in registers --
+// the 600 MB of float32 weight gradients are neither written nor read back (26 instead of 34 bytes of HBM traffic per
+// parameter for gradient + AdamW).  opt.params / m / v / shadow_bf16 point at this layer's [N][K] weight; opt.grads, when
+// given, still receives the raw gradient.
+template <int MT, bool FUSED = false>
 __global__ __launch_bounds__(256) void fc_wgrad_kernel(const bf16_t* __restrict__ GT, const bf16_t* __restrict__ XT, float* __restrict__ dW,
-                                                       int N, int K, int KPW) {
+                                                       int N, int K, int KPW, const spb_optim_args_t opt = spb_optim_args_t{}) {
+  float gs = 1.f, lr = 0.f, bc1 = 1.f, bc2 = 1.f;
+  bool has_m = false, has_v = false;
+  if constexpr (FUSED) {
+    gs = opt.gmul ? *opt.gmul : 1.f;
+    lr = opt.hyper ? opt.hyper[0] : opt.lr;
+    bc1 = opt.hyper ? opt.hyper[1] : opt.bias_c1;
+    bc2 = opt.hyper ? opt.hyper[2] : opt.bias_c2;
+    has_m = opt.m && (opt.kind >= 2 || (opt.kind == 0 && opt.beta1 != 0.f));
+    has_v = opt.v && opt.kind >= 1;
+  }
   constexpr int MP = 16 * MT;
   const int kblocks = (K + 63) >> 6;
   const int kgroups = (kblocks + 4 * KPW - 1) / (4 * KPW);
@@ -197,8 +213,29 @@ __global__ __launch_bounds__(256) void fc_wgrad_kernel(const bf16_t* __restrict_
         for (int h = 0; h < MT / 2; ++h) c = mfma(a[tt][h], b[nt][h], c);
         // lane: column j = n (li), rows i = lq*4+e <-> k = k0 + tt*16 + lq*4 + e : 16 contiguous bytes
         const int k = k0 + tt * 16 + lq * 4;
+        if constexpr (FUSED) {
+          if (n < N && k + 3 < K) {       // K % 4 == 0 (checked by the launcher): whole vectors only
+            const size_t o = (size_t)n * K + k;
+            f32x4_t p = *reinterpret_cast<const f32x4_t*>(opt.params + o);
+            f32x4_t m = has_m ? *reinterpret_cast<const f32x4_t*>(opt.m + o) : f32x4_t{0.f, 0.f, 0.f, 0.f};
+            f32x4_t v = has_v ? *reinterpret_cast<const f32x4_t*>(opt.v + o) : f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              float me = m[e], ve = v[e];
+              p[e] = optim_one(opt, gs, lr, bc1, bc2, p[e], c[e], me, ve);
+              m[e] = me; v[e] = ve;
+            }
+            if (has_m) *reinterpret_cast<f32x4_t*>(opt.m + o) = m;
+            if (has_v) *reinterpret_cast<f32x4_t*>(opt.v + o) = v;
+            *reinterpret_cast<f32x4_t*>(opt.params + o) = p;
+            if (opt.shadow_bf16)
+              *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(opt.shadow_bf16) + o) = make_uint2(pack_bf16x2(p[0], p[1]), pack_bf16x2(p[2], p[3]));
+            if (dW) *reinterpret_cast<f32x4_t*>(dW + o) = c;
+          }
+        } else {
         if (n < N && k + 3 < K) *reinterpret_cast<f32x4_t*>(dW + (size_t)n * K + k) = c;
         else if (n < N) for (int e = 0; e < 4; ++e) if (k + e < K) dW[(size_t)n * K + k + e] = c[e];
+        }
       }
     }
   }
@@ -362,6 +399,23 @@ extern "C" int spb_fc_wgrad(const void* GT, const void* XT, float* dW, int M, in
   hipStream_t s = (hipStream_t)stream;
   FC_MT(M, hipLaunchKernelGGL(fc_wgrad_kernel<2>, dim3(ngroups * kgroups), dim3(256), 0, s, (const bf16_t*)GT, (const bf16_t*)XT, dW, N, K, KPW),
         hipLaunchKernelGGL(fc_wgrad_kernel<4>, dim3(ngroups * kgroups), dim3(256), 0, s, (const bf16_t*)GT, (const bf16_t*)XT, dW, N, K, KPW))
+  SPB_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int spb_fc_wgrad_update(const void* GT, const void* XT, int M, int N, int K, const spb_optim_args_t* opt, spb_stream_t stream) {
+  if (!GT || !XT || !opt || !opt->params || M <= 0 || N <= 0 || K <= 0) return SPB_E_ARG;
+  if (opt->n != (long long)N * K || opt->kind < 0 || opt->kind > 3) return SPB_E_ARG;
+  if (opt->kind >= 2 && (!opt->m || !opt->v)) return SPB_E_ARG;
+  if (opt->kind == 1 && !opt->v) return SPB_E_ARG;
+  if (opt->max_norm > 0.f) return SPB_E_UNSUPPORTED;      // a global-norm clip needs every gradient first
+  if (M > 64 || (K & 3)) return SPB_E_UNSUPPORTED;
+  if (((uintptr_t)opt->params | (uintptr_t)opt->grads | (uintptr_t)opt->m | (uintptr_t)opt->v) & 15 || ((uintptr_t)opt->shadow_bf16 & 7)) return SPB_E_ARG;
+  const int kblocks = (K + 63) / 64, KPW = 2;
+  const int kgroups = (kblocks + 4 * KPW - 1) / (4 * KPW), ngroups = (N + 63) / 64;
+  hipStream_t s = (hipStream_t)stream;
+  FC_MT(M, hipLaunchKernelGGL((fc_wgrad_kernel<2, true>), dim3(ngroups * kgroups), dim3(256), 0, s, (const bf16_t*)GT, (const bf16_t*)XT, opt->grads, N, K, KPW, *opt),
+        hipLaunchKernelGGL((fc_wgrad_kernel<4, true>), dim3(ngroups * kgroups), dim3(256), 0, s, (const bf16_t*)GT, (const bf16_t*)XT, opt->grads, N, K, KPW, *opt))
   SPB_CHECK_LAUNCH();
   return 0;
 }

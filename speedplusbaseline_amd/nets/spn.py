@@ -13,6 +13,7 @@ Memory: parameters and gradients are two flat f32 arenas in state-dict order (nn
 clip + update is one launch and the data-parallel exchange one all-reduce.
 """
 import ctypes as C
+import os
 
 import torch
 import torch.nn as nn
@@ -69,6 +70,19 @@ class _Layer(nn.Module):
         nn.init.uniform_(self.bias, -bound, bound)
 
 
+_FUSED_FC_UPDATE = os.environ.get("SPB_SPN_FUSED_FC_UPDATE", "0") == "1"
+_HEAD1_EARLY = os.environ.get("SPB_SPN_HEAD1_EARLY", "1") != "0"   # the class head's update beside the regression head's backward
+
+
+def _low_priority_stream(device):
+    """lowest dispatch priority (spb_stream_create): its kernels take the compute units the launch stream leaves free.
+    SPB_SPN_UPDATE_PRIORITY = -1 / 0 / 1 overrides the level for experiments"""
+    h = C.c_void_p()
+    with torch.cuda.device(device):
+        L.check(L.lib().spb_stream_create(int(os.environ.get("SPB_SPN_UPDATE_PRIORITY", "1")), C.byref(h)), "spb_stream_create")
+    return torch.cuda.ExternalStream(h.value, device=device)
+
+
 class SpacecraftPoseNet(nn.Module):
     def __init__(self, num_classes, keep_prob=0.5, pretrain=True, precision="bf16"):
         super().__init__()
@@ -88,6 +102,7 @@ class SpacecraftPoseNet(nn.Module):
         self._saved = None
         self.dropout_seed = 2021
         self.side_wgrad = True     # weight gradients on a side stream (False: everything on the launch stream)
+        self.implicit_conv = os.environ.get("SPB_SPN_IMPLICIT", "1") != "0"   # conv2..5 as implicit GEMMs (bf16)
         self._step = 0
         if pretrain:
             self.load_weights('checkpoints/pretrained/bvlc_alexnet.npy')
@@ -113,6 +128,7 @@ class SpacecraftPoseNet(nn.Module):
 
     def invalidate(self):
         """parameters were changed by someone other than SpnOptimizer: compute copies and the bf16 shadow are stale"""
+        self.join_updates()
         self._version += 1
 
     # ---- flat arenas: parameter i lives at [off, off + numel) of self._flat (offsets multiples of 8 elements)
@@ -141,6 +157,7 @@ class SpacecraftPoseNet(nn.Module):
 
     def flat_parameters(self):
         self._ensure_arena()
+        self.join_updates()
         return self._flat
 
     def flat_grads(self):
@@ -158,6 +175,7 @@ class SpacecraftPoseNet(nn.Module):
         self._shadow_version = self._version
 
     def load_state_dict(self, *a, **k):
+        self.join_updates()
         r = super().load_state_dict(*a, **k)
         self.invalidate()
         return r
@@ -171,6 +189,17 @@ class SpacecraftPoseNet(nn.Module):
     #      fc6/fc9 columns permuted from the reference's NCHW flatten to NHWC, plus the transposes the input gradients need
     def _dt(self):
         return torch.bfloat16 if self.precision == "bf16" else torch.float32
+
+    def _implicit(self):
+        """bf16: conv2..conv5 run as implicit GEMMs (no column matrix); float32 keeps the im2col + GEMM path"""
+        return self.precision == "bf16" and self.implicit_conv
+
+    def _conv(self, X, Wp, bias, mask, Y, B, H, W, Cx, k, stride, pad, groups, Cg, Ng, relu):
+        a = L.SpnConvArgs()
+        a.X, a.Wp, a.bias, a.mask, a.Y = _p(X).value, _p(Wp).value, _p(bias).value, _p(mask).value, _p(Y).value
+        a.B, a.H, a.W, a.Cx, a.KH, a.KW, a.stride, a.pad = B, H, W, Cx, k, k, stride, pad
+        a.groups, a.Cg, a.Ng, a.Kp, a.relu = groups, Cg, Ng, Wp.shape[1], 1 if relu else 0
+        L.check(L.lib().spb_spn_conv(C.byref(a), _st()), "spb_spn_conv")
 
     def _fast(self, B):
         return self.precision == "bf16" and B <= 64 and self.num_classes % 8 == 0
@@ -191,8 +220,16 @@ class SpacecraftPoseNet(nn.Module):
             cp[name] = wp
             if wt is not None:
                 cp[name + "T"] = wt
+            if need_t and name != "conv1" and self._implicit():
+                # mirrored-tap weights of the input-gradient pass (csrc/spn_conv.hip): [cin][(tap', cout/g)]
+                kd = (k * k * (cout // g) + 7) // 8 * 8
+                wd = self._buf("wpD" + name, (cin, kd), dt)
+                L.check(lib.spb_spn_pack_conv_dgrad(_p(getattr(self, name).weight.detach()), _p(wd), cout, cin, g, k, k, kd, st),
+                        "spb_spn_pack_conv_dgrad")
+                cp[name + "D"] = wd
         if fast:
             if self._shadow_version != self._version:     # load_state_dict / load_weights / manual edits: rare
+                self.join_updates()
                 self._shadow.copy_(self._flat)
                 self._shadow_version = self._version
         else:
@@ -242,17 +279,22 @@ class SpacecraftPoseNet(nn.Module):
             OH, OW = (Hc + 2 * pad - k) // stride + 1, (Wc + 2 * pad - k) // stride + 1
             kg = cp[name].shape[1]
             kpad, cog = kg * g, cout // g
-            col = self._buf("col" + name, (B * OH * OW, kpad), dt)
-            if li == 0:
-                L.check(lib.spb_im2col_rgb(dc, _p(x), _p(col), B, Hc, Wc, k, k, stride, kpad, st), "spb_im2col_rgb")
-            else:
-                L.check(lib.spb_im2col(dc, _p(cur), _p(col), B, Hc, Wc, Cc, k, k, stride, pad, kpad, g, st), "spb_im2col")
             y = self._buf("y" + name, (B * OH * OW, cout), dt)
             bias = getattr(self, name).bias.detach()
-            for gi in range(g):      # one dense GEMM per convolution group on its column slab
-                self._gemm(col[:, gi * kg:(gi + 1) * kg], cp[name][gi * cog:(gi + 1) * cog], bias[gi * cog:(gi + 1) * cog],
-                           y[:, gi * cog:(gi + 1) * cog], relu=True)
-            sv["col" + name], sv["y" + name], sv["in" + name] = col, y, (Hc, Wc, Cc)
+            if li > 0 and self._implicit():
+                self._conv(cur, cp[name], bias, None, y, B, Hc, Wc, Cc, k, stride, pad, g, cin // g, cog, relu=True)
+                sv["x" + name] = cur
+            else:
+                col = self._buf("col" + name, (B * OH * OW, kpad), dt)
+                if li == 0:
+                    L.check(lib.spb_im2col_rgb(dc, _p(x), _p(col), B, Hc, Wc, k, k, stride, kpad, st), "spb_im2col_rgb")
+                else:
+                    L.check(lib.spb_im2col(dc, _p(cur), _p(col), B, Hc, Wc, Cc, k, k, stride, pad, kpad, g, st), "spb_im2col")
+                for gi in range(g):      # one dense GEMM per convolution group on its column slab
+                    self._gemm(col[:, gi * kg:(gi + 1) * kg], cp[name][gi * cog:(gi + 1) * cog], bias[gi * cog:(gi + 1) * cog],
+                               y[:, gi * cog:(gi + 1) * cog], relu=True)
+                sv["col" + name] = col
+            sv["y" + name], sv["in" + name] = y, (Hc, Wc, Cc)
             cur, Hc, Wc, Cc = y, OH, OW, cout
             if name in ("conv1", "conv2", "conv5"):
                 PH, PW = (Hc - 3) // 2 + 1, (Wc - 3) // 2 + 1
@@ -285,6 +327,7 @@ class SpacecraftPoseNet(nn.Module):
         st = _st()
         sv = {"B": B, "fast": fast}
         p5 = self._trunk(x, cp, sv)                 # pool5 output, NHWC [B, 6, 6, 256]
+        self.join_updates()                         # the previous step's update of the heads ran beside the trunk
         NC = self.num_classes
         outs = []
         if fast:
@@ -370,10 +413,22 @@ class SpacecraftPoseNet(nn.Module):
             torch.cuda.current_stream().wait_stream(self._side)
             self._side_used = False
 
-    def _start_exchange(self, group, compress_bf16, lo, hi):
+    def _run_updates(self, optimizer, jobs, B):
+        """the fully connected layers' weight gradient + parameter update kernels (SpnOptimizer.fused_fc_update) on a stream of
+        their own, ordered after everything enqueued so far; the convolution weight gradients keep the side stream"""
+        if getattr(self, "_upd", None) is None:
+            self._upd = _low_priority_stream(self._gflat.device)
+        self._upd.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self._upd):
+            for name, gT, xT in jobs:
+                optimizer.fused_fc_update(name, gT, xT, B)
+        self._early_on_upd = True
+
+    def _start_exchange(self, group, compress_bf16, lo, hi, optimizer=None, world_size=1):
         """all-reduce of gflat[lo:hi] on the communication stream, ordered after everything enqueued so far (launch stream and
         the weight-gradient side stream).  compress_bf16: the bucket travels as bfloat16 -- half the bytes on the xGMI links;
-        the sum is then rounded to bfloat16 per hop, like torch's bf16_compress_hook."""
+        the sum is then rounded to bfloat16 per hop, like torch's bf16_compress_hook.  With an optimizer the bucket's
+        parameters are updated on the communication stream as soon as the sum has arrived."""
         from ..parallel import allreduce_sum_async
         if getattr(self, "_comm", None) is None:
             self._comm = torch.cuda.Stream(device=self._gflat.device)
@@ -385,8 +440,46 @@ class SpacecraftPoseNet(nn.Module):
             if compress_bf16:
                 buf = self._buf("ddp_bf16_%d" % lo, (part.numel(),), torch.bfloat16)
                 buf.copy_(part)
-                return ("bf16", allreduce_sum_async(buf, group), buf, part)
-            return ("f32", allreduce_sum_async(part, group), None, part)
+                work = ("bf16", allreduce_sum_async(buf, group), buf, part)
+            else:
+                work = ("f32", allreduce_sum_async(part, group), None, part)
+            if optimizer is None:
+                return work
+            self._land(work)
+            optimizer.update_range_early(lo, hi, world_size)
+            self._early_on_comm = True
+            return ("done", None, None, part)
+
+    @staticmethod
+    def _land(work):
+        """on the communication stream: wait for the collective, bring a compressed bucket back into the f32 arena"""
+        kind, w, buf, part = work
+        if w is not None:
+            w.wait()
+        if kind == "bf16":
+            part.copy_(buf)
+
+    def finish_early_updates(self):
+        """SpnOptimizer.step: the launch stream waits for the parameter updates issued beside backward -- except the heads'
+        update on the single-GPU path, which may run on into the next step's trunk (join_updates)"""
+        if getattr(self, "_early_on_comm", False):
+            torch.cuda.current_stream().wait_stream(self._comm)
+            self._early_on_comm = False
+        self._join_side()
+
+    def join_updates(self):
+        """The heads' parameter update started by loss_and_grads(optimizer=...) may still be in flight on its own stream after
+        optimizer.step() returned: the next forward only needs the convolution parameters until pool5, so that stretch of
+        the trunk runs beside it.  This makes the current stream wait for it.  Called by the forward pass before the first
+        fully connected layer, by state_dict(), flat_parameters(), load_state_dict() and invalidate(); call it yourself
+        before reading parameter tensors directly on another stream (torch.cuda.synchronize() also does)."""
+        if getattr(self, "_early_on_upd", False):
+            torch.cuda.current_stream().wait_stream(self._upd)
+            self._early_on_upd = False
+
+    def state_dict(self, *a, **k):
+        self.join_updates()
+        return super().state_dict(*a, **k)
 
     def finish_gradient_exchange(self, group=None):
         """called by SpnOptimizer.step before the update (idempotent per backward pass): waits for the overlapped buckets and
@@ -399,17 +492,15 @@ class SpacecraftPoseNet(nn.Module):
         if not works:
             allreduce_sum_(self._gflat, group)
             return
-        for kind, w, buf, part in works:
-            with torch.cuda.stream(self._comm):
-                if w is not None:
-                    w.wait()                      # the communication stream waits for the collective
-                if kind == "bf16":
-                    part.copy_(buf)
+        for work in works:
+            if work[0] != "done":
+                with torch.cuda.stream(self._comm):
+                    self._land(work)              # the communication stream waits for the collective
         torch.cuda.current_stream().wait_stream(self._comm)
         allreduce_sum_(self._gflat[:self._conv_end], group)
 
     # ---- one training step's loss + gradients (trainer.py:146-177): loss = softCE(c, yClasses) + 10 softCE(r, yWeights)
-    def loss_and_grads(self, x, y_classes, y_weights, masks=None, world_size=1, group=None, compress_bf16=None):
+    def loss_and_grads(self, x, y_classes, y_weights, masks=None, world_size=1, group=None, compress_bf16=None, optimizer=None):
         """Runs forward (training mode), the loss and the backward pass; gradients land in p.grad of every parameter
         (views of the flat gradient arena).  Returns a device tensor (loss, loss_class, loss_regress).
 
@@ -418,7 +509,14 @@ class SpacecraftPoseNet(nn.Module):
         trunk's backward runs, in two buckets (the class head's as soon as its weight gradients are queued, beside the regression
         head's backward; the regression head's beside the trunk); SpnOptimizer.step waits for them and reduces the small
         convolution bucket itself.  compress_bf16 (default: on in bf16 mode) sends those buckets as bfloat16: half the bytes
-        on the xGMI links, the sum rounded to bfloat16 per hop like torch's bf16_compress_hook; False keeps float32."""
+        on the xGMI links, the sum rounded to bfloat16 per hop like torch's bf16_compress_hook; False keeps float32.
+
+        optimizer (the model's SpnOptimizer): the caller promises to call optimizer.step() next, as trainer.py:177-184 always
+        does.  The two heads' parameters -- 98 % of the arena, an HBM-bound 0.8 ms update -- are then updated from inside
+        this call as soon as their gradients are final, beside the rest of backward; optimizer.step() updates the convolution
+        parameters.  The result is the same as without it: clip_grad_value_ and the update rules are elementwise.  On one GPU the heads' update runs
+        on a stream of its own and may still be in flight when optimizer.step() returns -- the next forward needs only the
+        convolution parameters until pool5 and waits for it there; see join_updates() for who else waits."""
         lib = L.lib()
         dt, dc = self._dt(), (L.BF16 if self.precision == "bf16" else L.F32)
         c, r = self._forward_impl(x, True, masks)
@@ -442,20 +540,30 @@ class SpacecraftPoseNet(nn.Module):
         if fast:
             MP = sv["MP"]
             acc, accF = self._acc("acc", max(4096, NC), MP), self._acc("accF", 9216, MP)
-            pend = []
+            pend, jobs = [], []
+            # weight gradient + update of a layer in one kernel (spb_fc_wgrad_update): measured SLOWER than the two passes -- the
+            # matrix-core output layout gives every lane 16 bytes of a different weight row, and seven streams with that pattern
+            # run at a third of the arena-wide update's bandwidth (1.7 ms against 0.2 + 0.8 ms) -- so it is an experiment knob
+            fuse = optimizer is not None and world_size == 1 and _FUSED_FC_UPDATE
             for names, g in ((("fc6", "fc7", "fc8"), dcg), (("fc9", "fc10", "fc11"), drg)):
                 self._on_side(pend)                  # the first head's weight gradients run beside the second head's chain
                 if pend and world_size > 1:          # ... and their exchange starts as soon as they are through
-                    self._ddp_works.append(self._start_exchange(group, compress_bf16, self._conv_end, head2_lo))
+                    self._ddp_works.append(self._start_exchange(group, compress_bf16, self._conv_end, head2_lo, optimizer, world_size))
                 pend = []
+                if jobs and _HEAD1_EARLY:
+                    self._run_updates(optimizer, jobs, B)
+                    jobs = []
                 a, b_, c_ = names
                 gT = self._buf("gT" + c_, (NC, MP), dt)
                 self._epi(B, NC, 1, src=g, YT=gT, db=getattr(self, c_).bias.grad)
                 for name, prev, xT in ((c_, b_, sv["hT" + b_]), (b_, a, sv["hT" + a]), (a, None, sv["fT"])):
                     lay = getattr(self, name)
                     N, K = lay.weight.shape
-                    pend.append(lambda s_, gT=gT, xT=xT, lay=lay, N=N, K=K:
-                                L.check(lib.spb_fc_wgrad(_p(gT), _p(xT), _p(lay.weight.grad), B, N, K, s_), "spb_fc_wgrad"))
+                    if fuse:
+                        jobs.append((name, gT, xT))
+                    else:
+                        pend.append(lambda s_, gT=gT, xT=xT, lay=lay, N=N, K=K:
+                                    L.check(lib.spb_fc_wgrad(_p(gT), _p(xT), _p(lay.weight.grad), B, N, K, s_), "spb_fc_wgrad"))
                     tgt = acc if prev is not None else accF
                     L.check(lib.spb_fc_dgrad(_p(g), _p(self._sh(name + ".weight")), _p(tgt), B, N, K, st), "spb_fc_dgrad")
                     if prev is not None:     # through inverted dropout and ReLU of the previous fc, + its bias gradient
@@ -465,6 +573,19 @@ class SpacecraftPoseNet(nn.Module):
             g_act = self._buf("dp5", (B, 6, 6, 256), dt)   # the two heads met in accF
             L.check(lib.spb_spn_unflatten_grad(_p(accF), _p(g_act), B, 36, 256, st), "spb_spn_unflatten_grad")
             self._on_side(pend)                            # ... the second head's beside the start of the trunk
+            if fuse:
+                self._run_updates(optimizer, jobs, B)       # beside the trunk's backward (and the next step's trunk forward)
+            elif optimizer is not None and world_size == 1:
+                # both heads' update beside the trunk's backward (and the next step's trunk forward), on a stream of its own --
+                # the convolution weight gradients keep the side stream.  Not earlier: the second head's chain streams its
+                # weights from HBM like the update does.
+                if getattr(self, "_upd", None) is None:
+                    self._upd = _low_priority_stream(self._gflat.device)
+                self._upd.wait_stream(torch.cuda.current_stream())
+                self._upd.wait_stream(self._side)
+                with torch.cuda.stream(self._upd):
+                    optimizer.update_range_early(self._conv_end, self._gflat.numel())
+                self._early_on_upd = True
         else:
             df = None
             for (a, b_, c_), g in ((("fc6", "fc7", "fc8"), dcg), (("fc9", "fc10", "fc11"), drg)):
@@ -486,8 +607,10 @@ class SpacecraftPoseNet(nn.Module):
             g_act = df.view(B, 256, 36).permute(0, 2, 1).contiguous()    # NCHW flatten order -> NHWC
         if world_size > 1:
             lo = head2_lo if self._ddp_works else self._conv_end
-            self._ddp_works.append(self._start_exchange(group, compress_bf16, lo, self._gflat.numel()))
+            self._ddp_works.append(self._start_exchange(group, compress_bf16, lo, self._gflat.numel(), optimizer if fast else None,
+                                                        world_size))
         # trunk, last to first
+        masked = False
         dwp = self._buf("dWp", (sum(cp[n].numel() for n, *_ in _CONVS),), torch.float32)
         dwp.zero_()
         woff = 0
@@ -507,21 +630,42 @@ class SpacecraftPoseNet(nn.Module):
                 t = self._buf("dp" + name, (B, PHin, PWin, cout), dt)
                 L.check(lib.spb_maxpool3s2_bwd(dc, _p(g_act), _p(arg), _p(t), B, PHin, PWin, cout, st), "spb_maxpool3s2_bwd")
                 g_act = t
-            g = self._buf("gy" + name, (B * OH * OW, cout), dt)
-            L.check(lib.spb_relu_bwd(dc, _p(g_act), _p(y), None, _p(g), g.numel(), 1.0, st), "spb_relu_bwd")
-            col = sv["col" + name]
-            kpad = col.shape[1]
-            kg, cog = kpad // grp, cout // grp
+            if masked:          # the input-gradient kernel of the layer above already applied this layer's ReLU mask
+                g = g_act.view(B * OH * OW, cout)
+            else:
+                g = self._buf("gy" + name, (B * OH * OW, cout), dt)
+                L.check(lib.spb_relu_bwd(dc, _p(g_act), _p(y), None, _p(g), g.numel(), 1.0, st), "spb_relu_bwd")
+            masked = False
+            kg = cp[name].shape[1]
+            kpad, cog = kg * grp, cout // grp
+            col = sv.get("col" + name)
+            xin_ = sv.get("x" + name)           # implicit-GEMM layer: its NHWC input instead of a column matrix
             dW = dwp[woff:woff + cout * kg].view(cout, kg)
             woff += cout * kg
-            def conv_wgrad(s_, g=g, col=col, dW=dW, lay=lay, cout=cout, cin=cin, grp=grp, k=k, kg=kg, cog=cog, name=name):
-                for gi in range(grp):       # ops.* launch on the current stream = the side stream inside _on_side
+            def conv_wgrad(s_, g=g, col=col, xin_=xin_, dW=dW, lay=lay, cout=cout, cin=cin, grp=grp, k=k, kg=kg, cog=cog, name=name,
+                           Hc=Hc, Wc=Wc, Cc=Cc, stride=stride, pad=pad):
+                if col is None:
+                    a = L.SpnConvArgs()
+                    a.X = _p(xin_).value
+                    a.B, a.H, a.W, a.Cx, a.KH, a.KW, a.stride, a.pad = B, Hc, Wc, Cc, k, k, stride, pad
+                    a.groups, a.Cg, a.Ng, a.Kp = grp, cin // grp, cog, kg
+                    L.check(lib.spb_spn_conv_wgrad(C.byref(a), _p(g), _p(dW), s_), "spb_spn_conv_wgrad")
+                for gi in range(grp if col is not None else 0):   # ops.* launch on the current stream = the side stream inside _on_side
                     ops.pwconv_wgrad(g[:, gi * cog:(gi + 1) * cog], col[:, gi * kg:(gi + 1) * kg], dW[gi * cog:(gi + 1) * cog], ident(cog), ident(kg))
                 L.check(lib.spb_spn_unpack_conv_grad(_p(dW), _p(lay.weight.grad), cout, cin, grp, k, k, kg, 1 if name == "conv1" else 0, s_),
                         "spb_spn_unpack_conv_grad")
                 L.check(lib.spb_colsum(dc, _p(g), _p(lay.bias.grad), g.shape[0], cout, s_), "spb_colsum")
             self._on_side([conv_wgrad])
-            if name != "conv1":
+            if name != "conv1" and (name + "D") in cp:
+                # implicit GEMM over (mirrored tap, output channel); conv5 -> conv4 -> conv3 feed each other directly, so the
+                # ReLU mask of the layer below goes into the store
+                below = {"conv5": "conv4", "conv4": "conv3"}.get(name)
+                dx = self._buf("dxin" + name, (B, Hc, Wc, Cc), dt)
+                self._conv(g, cp[name + "D"], None, sv["y" + below] if below else None, dx, B, OH, OW, cout, k, 1, k - 1 - pad, grp,
+                           cog, Cc // grp, relu=False)
+                masked = below is not None
+                g_act = dx
+            elif name != "conv1":
                 dcol = self._buf("dcol" + name, tuple(col.shape), dt)
                 for gi in range(grp):
                     ops.pwconv_gemm(g[:, gi * cog:(gi + 1) * cog], cp[name + "T"][gi], dcol[:, gi * kg:(gi + 1) * kg], ident(cog), 0, 0,

@@ -225,15 +225,32 @@ OPT_KIND = {"sgd": 0, "rmsprop": 1, "adam": 2, "adamw": 3}
 
 
 def optim_step(kind, params, grads, m=None, v=None, sqnorm=None, gmul=None, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8,
-               weight_decay=0.0, max_norm=0.0, clip_value=0.0, step=1, first_step=False, hyper=None, shadow=None):
+               weight_decay=0.0, max_norm=0.0, clip_value=0.0, step=1, first_step=False, hyper=None, shadow=None, max_blocks=0):
+    a = _optim_args(kind, params, grads, m, v, sqnorm, gmul, lr, beta1, beta2, eps, weight_decay, max_norm, clip_value, step, first_step,
+                    hyper, shadow, max_blocks)
+    L.check(L.lib().spb_optim_step(C.byref(a), _stream()), "spb_optim_step")
+
+
+def _optim_args(kind, params, grads, m, v, sqnorm, gmul, lr, beta1, beta2, eps, weight_decay, max_norm, clip_value, step, first_step,
+                hyper, shadow, max_blocks):
     _need_cuda(params, grads, m, v, sqnorm, gmul, hyper, shadow)
     a = L.OptimArgs()
     a.params = _ptr(params); a.grads = _ptr(grads); a.m = _ptr(m); a.v = _ptr(v); a.sqnorm = _ptr(sqnorm)
     a.gmul = _ptr(gmul); a.hyper = _ptr(hyper); a.n = params.numel(); a.kind = OPT_KIND[kind]
     a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.weight_decay = weight_decay
-    a.max_norm = max_norm; a.clip_value = clip_value; a.shadow_bf16 = _ptr(shadow)
+    a.max_norm = max_norm; a.clip_value = clip_value; a.shadow_bf16 = _ptr(shadow); a.max_blocks = max_blocks
     a.bias_c1 = 1.0 - beta1 ** step; a.bias_c2 = 1.0 - beta2 ** step; a.first_step = 1 if first_step else 0
-    L.check(L.lib().spb_optim_step(C.byref(a), _stream()), "spb_optim_step")
+    return a
+
+
+def fc_wgrad_update(gT, xT, M, kind, params, grads=None, m=None, v=None, gmul=None, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8,
+                    weight_decay=0.0, clip_value=0.0, step=1, first_step=False, shadow=None):
+    """weight gradient of a fully connected layer (params: its [N][K] weight) fused with its optimizer step (spb_fc_wgrad_update)"""
+    _need_cuda(gT, xT)
+    N, K = params.shape
+    a = _optim_args(kind, params, grads, m, v, None, gmul, lr, beta1, beta2, eps, weight_decay, 0.0, clip_value, step, first_step, None,
+                    shadow, 0)
+    L.check(L.lib().spb_fc_wgrad_update(_ptr(gT), _ptr(xT), M, N, K, C.byref(a), _stream()), "spb_fc_wgrad_update")
 
 
 def debug_trread(inp, out):

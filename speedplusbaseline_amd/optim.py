@@ -148,6 +148,7 @@ class SpnOptimizer(torch.optim.Optimizer):
         self.clip_value = clip_value
         self._t = 0
         self._m = self._v = self._gmul = None
+        self._early = []       # arena ranges already updated for the step in flight (update_range_early)
 
     def _betas(self, kind, momentum):
         if kind == "rmsprop":
@@ -156,32 +157,88 @@ class SpnOptimizer(torch.optim.Optimizer):
             return momentum, 0.999
         return momentum, 0.0
 
-    @torch.no_grad()
-    def step(self, closure=None, world_size=1, group=None):
-        from . import ops
-        from .parallel import allreduce_sum_, mean_scale
-        mdl = self._model
-        flat, gflat = mdl.flat_parameters(), mdl.flat_grads()
+    def _state(self, flat):
         if self._m is not None and self._m.numel() == flat.numel() and self._m.device != flat.device:
             self._m, self._v = self._m.to(flat.device), self._v.to(flat.device)       # restored from a checkpoint (CPU)
         if self._m is None or self._m.numel() != flat.numel():
             self._m, self._v = torch.zeros_like(flat), torch.zeros_like(flat)
+
+    def _update(self, lo, hi, world_size, max_blocks=0):
+        """clamp + update + bf16 shadow of arena elements [lo, hi) on the current stream (every piece of the update is
+        elementwise, so a step may be made range by range)"""
+        from . import ops
+        from .parallel import mean_scale
+        mdl = self._model
+        flat, gflat = mdl._flat, mdl._gflat
         g = self.param_groups[0]
         b1, b2 = self._betas(g["kind"], g["momentum"])
-        self._t += 1
         gmul = None
         if world_size > 1:
-            mdl.finish_gradient_exchange(group)     # the fc bucket was started from inside backward (loss_and_grads)
             if self._gmul is None:
                 self._gmul = torch.full((1,), mean_scale(world_size), dtype=torch.float32, device=flat.device)
             gmul = self._gmul
-        ops.optim_step(g["kind"], flat, gflat, m=self._m, v=self._v, gmul=gmul, lr=g["lr"], beta1=b1, beta2=b2, eps=1e-8,
-                       weight_decay=g["weight_decay"], max_norm=0.0, clip_value=self.clip_value, step=self._t,
-                       first_step=(self._t == 1), shadow=mdl._shadow)
+        t = self._t
+        ops.optim_step(g["kind"], flat[lo:hi], gflat[lo:hi], m=self._m[lo:hi], v=self._v[lo:hi], gmul=gmul, lr=g["lr"], beta1=b1,
+                       beta2=b2, eps=1e-8, weight_decay=g["weight_decay"], max_norm=0.0, clip_value=self.clip_value, step=t,
+                       first_step=(t == 1), shadow=None if mdl._shadow is None else mdl._shadow[lo:hi], max_blocks=max_blocks)
+
+    @torch.no_grad()
+    def update_range_early(self, lo, hi, world_size=1, max_blocks=0):
+        """Called by SpacecraftPoseNet.loss_and_grads(..., optimizer=self) from inside the backward pass, on the stream that
+        produced (and, data parallel, exchanged) the gradients of arena elements [lo, hi): this step's update of that range,
+        issued while the rest of backward still runs.  step() then updates what is left.  Ranges must not overlap."""
+        self._model._ensure_arena()
+        self._state(self._model._flat)
+        if not self._early:
+            self._t += 1
+        self._early.append((lo, hi))
+        self._update(lo, hi, world_size, max_blocks)
+
+    @torch.no_grad()
+    def fused_fc_update(self, name, gT, xT, M):
+        """Called by SpacecraftPoseNet.loss_and_grads(..., optimizer=self) on its update stream: the weight gradient of fully
+        connected layer `name` and this step's update of that weight in one kernel (spb_fc_wgrad_update) -- the gradient never
+        reaches HBM, p.grad of that weight is not written -- followed by the bias' share (its gradient is already in the arena)."""
+        from . import ops
+        mdl = self._model
+        mdl._ensure_arena()
+        self._state(mdl._flat)
+        if not self._early:
+            self._t += 1
+        lay = getattr(mdl, name)
+        N, K = lay.weight.shape
+        o, n = mdl._offs[name + ".weight"]
+        g = self.param_groups[0]
+        b1, b2 = self._betas(g["kind"], g["momentum"])
+        self._early.append((o, o + (n + 7) // 8 * 8))
+        ops.fc_wgrad_update(gT, xT, M, g["kind"], mdl._flat[o:o + n].view(N, K), None, self._m[o:o + n], self._v[o:o + n], None, lr=g["lr"],
+                            beta1=b1, beta2=b2, eps=1e-8, weight_decay=g["weight_decay"], clip_value=self.clip_value, step=self._t,
+                            first_step=(self._t == 1), shadow=None if mdl._shadow is None else mdl._shadow[o:o + n])
+        o, n = mdl._offs[name + ".bias"]
+        self.update_range_early(o, o + (n + 7) // 8 * 8)
+
+    @torch.no_grad()
+    def step(self, closure=None, world_size=1, group=None):
+        mdl = self._model
+        mdl._ensure_arena()
+        flat = mdl._flat          # not flat_parameters(): that would wait for the heads' update still in flight
+        self._state(flat)
+        early, self._early = sorted(self._early), []
+        if not early:
+            self._t += 1
+        if world_size > 1:
+            mdl.finish_gradient_exchange(group)     # the fc buckets were started from inside backward (loss_and_grads)
+        mdl.finish_early_updates()                  # the launch stream waits for the updates made beside backward
+        pos = 0
+        for lo, hi in early + [(flat.numel(), flat.numel())]:
+            if lo > pos:
+                self._update(pos, lo, world_size)
+            pos = max(pos, hi)
         mdl.optimizer_updated()
         return None
 
     def state_dict(self):
+        self._model.join_updates()      # the heads' moments may still be written on the update stream
         sd = super().state_dict()
         sd["spn_fused"] = {"t": self._t, "m": None if self._m is None else self._m.detach().cpu(),
                            "v": None if self._v is None else self._v.detach().cpu()}

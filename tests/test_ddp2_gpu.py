@@ -42,9 +42,11 @@ def test_krn_two_ranks_replicas_identical_and_gradient_is_the_sum(device):
 def test_spn_two_ranks_replicas_identical_and_gradient_is_the_sum(device):
     r = run_two_ranks("spn")
     print(r)
-    for mode in ("plain", "overlap", "overlap_f32"):
+    for mode in ("plain", "overlap", "overlap_f32", "overlap_early"):
         assert r[mode]["replica_diff"] == 0.0, (mode, r[mode])
         assert r[mode]["moved"] > 0
         assert r[mode]["grad_rel_conv"] < 0.05, (mode, r[mode])
-    assert r["plain"]["grad_rel_fc"] < 1e-3 and r["overlap_f32"]["grad_rel_fc"] < 1e-3
+    assert r["plain"]["grad_rel_fc"] < 1e-3 and r["overlap_f32"]["grad_rel_fc"] < 1e-3 and r["overlap_early"]["grad_rel_fc"] < 1e-3
+    # the heads' buckets updated on the communication stream as they arrive: the same parameters as updating after backward
+    assert r["overlap_early"]["diff_fc"] < 1e-4 and r["overlap_early"]["diff_conv"] < 0.02, r["overlap_early"]
     assert r["overlap"]["grad_rel_fc"] < 1e-2          # bfloat16 on the wire (2^-9 per element), default in bf16 mode

@@ -291,3 +291,97 @@ def test_adamw_step_updates_bf16_shadow(device):
         o, n = net._offs[k]
         assert torch.equal(net._shadow[o:o + n].cpu(), p.detach().reshape(-1).to(torch.bfloat16).cpu()), k
     assert net._shadow_version == net._version
+
+
+@pytest.mark.parametrize("fused", [False, True])
+def test_update_beside_backward_equals_plain_step(device, fused, monkeypatch):
+    """loss_and_grads(optimizer=opt) updates the heads' parameters from inside backward (side stream) and opt.step() the
+    rest: after one step the heads' parameters, momentum and bf16 shadow equal the one-launch update's (their gradients are
+    deterministic up to the order of a few float32 atomics); the convolution range, whose weight gradients are summed with
+    atomics over row tiles, agrees to that noise.  One step only: this random-init state (loss ~ 60, nearly every gradient
+    element clipped) amplifies that noise to sign flips of whole gradients by the second step, with or without the overlap."""
+    from speedplusbaseline_amd.optim import SpnOptimizer
+    from speedplusbaseline_amd.nets import spn as spn_mod
+    monkeypatch.setattr(spn_mod, "_FUSED_FC_UPDATE", fused)     # True: spb_fc_wgrad_update (gradient + update in one kernel)
+    x, yc, yw = (t.to(device) for t in S.synth_batch(4, NC, seed=3))
+    masks = {k: v.to(device) for k, v in S.synth_masks(4, seed=9).items()}
+    res = []
+    for early in (False, True):
+        net = _net(device, "bf16").train()
+        opt = SpnOptimizer([p for p in net.parameters()], kind="sgd", lr=0.05, momentum=0.9, weight_decay=1e-4, model=net)
+        p0 = net.flat_parameters().clone()
+        net.loss_and_grads(x, yc, yw, masks=masks, optimizer=opt if early else None)
+        if early:
+            assert opt._t == 1 and len(opt._early) == (12 if fused else 1)    # six weights + six biases / both heads at once
+        opt.step()
+        torch.cuda.synchronize()
+        assert opt._t == 1 and not opt._early
+        res.append((net.flat_parameters().clone(), net._shadow.float(), opt._m.clone()))
+    ce = net._conv_end
+    moved = float((res[0][0] - p0).abs().max())
+    assert moved > 0.04                                            # lr * clip
+    for a, b in zip(*res):
+        assert float((a[ce:] - b[ce:]).abs().max()) < 1e-6 * max(1.0, float(a[ce:].abs().max()))
+        assert float((a[:ce] - b[:ce]).abs().max()) < 0.02 * max(1.0, float(a[:ce].abs().max()))
+    assert torch.equal(res[1][1], res[1][0].to(torch.bfloat16).float())   # the shadow is the rounded parameter arena
+
+
+@pytest.mark.parametrize("name,cout,cin,groups,k,pad,hw", [("conv2", 256, 96, 2, 5, 2, 27), ("conv3", 384, 256, 1, 3, 1, 13),
+                                                          ("conv4", 384, 384, 2, 3, 1, 13), ("conv5", 256, 384, 2, 3, 1, 13)])
+@pytest.mark.parametrize("B", [3, 32])
+def test_implicit_gemm_convolution(device, name, cout, cin, groups, k, pad, hw, B):
+    """csrc/spn_conv.hip at the trunk's layer shapes, through the C-ABI: forward (bias + ReLU) and the input-gradient pass
+    (mirrored taps, ReLU mask of the layer below in the store) against torch.nn.functional.conv2d in float32 on the same
+    bf16-rounded operands.  B = 3 leaves a ragged last row tile; B = 32 is the production batch (128-row tiles for conv2)."""
+    import ctypes as C
+    import torch.nn.functional as F
+    from speedplusbaseline_amd import _lib as L
+    lib, st = L.lib(), C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    g = torch.Generator().manual_seed(sum(map(ord, name)) + B)
+    w = (torch.randn(cout, cin // groups, k, k, generator=g) / (cin // groups * k * k) ** 0.5).to(device)
+    bias = (0.1 * torch.randn(cout, generator=g)).to(device)
+    x = torch.randn(B, cin, hw, hw, generator=g).to(device).to(torch.bfloat16)
+    cig, cog = cin // groups, cout // groups
+    kg, kd = (k * k * cig + 7) // 8 * 8, (k * k * cog + 7) // 8 * 8
+    wp = torch.empty(cout, kg, dtype=torch.bfloat16, device=device)
+    wd = torch.empty(cin, kd, dtype=torch.bfloat16, device=device)
+    L.check(lib.spb_spn_pack_conv(L.BF16, _vp(w), _vp(wp), None, cout, cin, groups, k, k, kg, 0, st), "pack")
+    L.check(lib.spb_spn_pack_conv_dgrad(_vp(w), _vp(wd), cout, cin, groups, k, k, kd, st), "pack_dgrad")
+    xh = x.permute(0, 2, 3, 1).contiguous()                        # NHWC
+    y = torch.empty(B * hw * hw, cout, dtype=torch.bfloat16, device=device)
+
+    def conv(X, Wp, bias_, mask, Y, Cx, pad_, Cg, Ng, relu):
+        a = L.SpnConvArgs()
+        a.X, a.Wp, a.bias, a.mask, a.Y = X.data_ptr(), Wp.data_ptr(), (bias_.data_ptr() if bias_ is not None else None), \
+            (mask.data_ptr() if mask is not None else None), Y.data_ptr()
+        a.B, a.H, a.W, a.Cx, a.KH, a.KW, a.stride, a.pad = B, hw, hw, Cx, k, k, 1, pad_
+        a.groups, a.Cg, a.Ng, a.Kp, a.relu = groups, Cg, Ng, Wp.shape[1], relu
+        L.check(lib.spb_spn_conv(C.byref(a), st), "spb_spn_conv")
+    conv(xh, wp, bias, None, y, cin, pad, cig, cog, 1)
+    wq = w.to(torch.bfloat16).float()
+    xr = x.float().requires_grad_(True)
+    ref = F.relu(F.conv2d(xr, wq, bias, padding=pad, groups=groups))
+    got = y.float().view(B, hw, hw, cout).permute(0, 3, 1, 2)
+    assert rel(got, ref.detach()) < 8e-3        # one bf16 ulp of the largest output
+    # input gradient of an upstream gradient gy, masked like relu_bwd of the layer below would
+    gy = torch.randn(B, hw, hw, cout, generator=g).to(device).to(torch.bfloat16)
+    below = torch.randn(B, hw, hw, cin, generator=g).to(device).to(torch.bfloat16)
+    a = L.SpnConvArgs()
+    a.X = xh.data_ptr()
+    a.B, a.H, a.W, a.Cx, a.KH, a.KW, a.stride, a.pad = B, hw, hw, cin, k, k, 1, pad
+    a.groups, a.Cg, a.Ng, a.Kp = groups, cig, cog, kg
+    dwp = torch.zeros(cout, kg, device=device)
+    L.check(lib.spb_spn_conv_wgrad(C.byref(a), _vp(gy), _vp(dwp), st), "spb_spn_conv_wgrad")
+    wl = w.detach().clone().requires_grad_(True)
+    F.conv2d(x.float(), wl, None, padding=pad, groups=groups).backward(gy.float().permute(0, 3, 1, 2))
+    dw = torch.empty_like(w)
+    L.check(lib.spb_spn_unpack_conv_grad(_vp(dwp), _vp(dw), cout, cin, groups, k, k, kg, 0, st), "unpack")
+    assert rel(dw, wl.grad) < 2e-3
+    for mask in (None, below):
+        dx = torch.empty(B * hw * hw, cin, dtype=torch.bfloat16, device=device)
+        conv(gy, wd, None, mask, dx, cout, k - 1 - pad, cog, cig, 0)
+        want = torch.autograd.grad(F.conv2d(xr, wq, None, padding=pad, groups=groups), xr, gy.float().permute(0, 3, 1, 2))[0]
+        want = want.permute(0, 2, 3, 1)
+        if mask is not None:
+            want = want * (mask.float() > 0)
+        assert rel(dx.float().view(B, hw, hw, cin), want) < 8e-3, mask is not None

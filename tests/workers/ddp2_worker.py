@@ -88,7 +88,7 @@ def spn(rank, world, dev):
     net.loss_and_grads(x, yc, yw, masks=masks)
     torch.cuda.synchronize()
     want = sum(gather(net.flat_grads().clone()))
-    for mode in ("plain", "overlap", "overlap_f32"):
+    for mode in ("plain", "overlap", "overlap_f32", "overlap_early"):
         net = fresh()
         opt = SpnOptimizer(list(net.parameters()), kind="sgd", lr=0.05, momentum=0.9, weight_decay=1e-4, model=net)
         p0 = net.flat_parameters().clone()
@@ -96,6 +96,9 @@ def spn(rank, world, dev):
         for it in range(2):
             if mode == "plain":
                 net.loss_and_grads(x, yc, yw, masks=masks)
+            elif mode == "overlap_early":      # the heads' buckets are updated on the communication stream as they arrive
+                net.loss_and_grads(x, yc, yw, masks=masks, world_size=world, group=dist.group.WORLD, compress_bf16=False,
+                                   optimizer=opt)
             else:
                 net.loss_and_grads(x, yc, yw, masks=masks, world_size=world, group=dist.group.WORLD,
                                    compress_bf16=None if mode == "overlap" else False)
@@ -104,13 +107,21 @@ def spn(rank, world, dev):
                 torch.cuda.synchronize()
                 got = net.flat_grads().clone()
             opt.step(world_size=world, group=dist.group.WORLD)
+            if it == 0:
+                torch.cuda.synchronize()
+                after1 = net.flat_parameters().clone()
         torch.cuda.synchronize()
         both = gather(net.flat_parameters().clone())
         ce = net._conv_end
+        if mode == "overlap_f32":
+            f32_params = after1
         res[mode] = dict(replica_diff=float((both[0] - both[1]).abs().max()),
                          grad_rel_conv=float((got[:ce] - want[:ce]).norm() / want[:ce].norm()),
                          grad_rel_fc=float((got[ce:] - want[ce:]).norm() / want[ce:].norm()),
                          moved=float((both[0] - p0).abs().max()))
+        if mode == "overlap_early":            # same float32 exchange, same update, compared after the first step (later
+            d = (after1 - f32_params).abs()    # steps amplify the atomics noise of the convolution gradients, see test_spn_gpu)
+            res[mode]["diff_conv"], res[mode]["diff_fc"] = float(d[:ce].max()), float(d[ce:].max())
     return res
 
 
