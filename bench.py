@@ -42,10 +42,10 @@ def _host():
     return dict(cpu_model=model, host_cores=os.cpu_count())
 
 
-def _pmc_traffic(family):
+def _pmc_traffic(family, files=("r2_pmc_traffic.json", "r1_pmc_traffic.json")):
     """HBM bytes per launch of a kernel family from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE, separate runs,
     corrected as MI355X_MICROARCH.md prescribes; scratch/pmc_summary.py) -- rocprofv3 cannot run inside bench.py"""
-    for name in ("r2_pmc_traffic.json", "r1_pmc_traffic.json"):
+    for name in files:
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 return json.load(f)["families"][family]["hbm_bytes_per_launch"], name
@@ -565,9 +565,12 @@ def bench_spn(args):
         us = sum(a.elapsed_time(b) for a, b in evs) / len(evs) * 1e3
         by = n * (28 + (2 if args.precision == "bf16" else 0))
         ach = by / (us * 1e-6) / 1e9
+        traffic, traffic_src = _pmc_traffic("optim_step_full", ("r2_spn_pmc_traffic.json",)) if (B == 32 and NC == 5000) else (None, None)
         roofline = dict(bound="hbm", kernel="optim_step (clip_grad_value + AdamW + bf16 shadow)", achieved=round(ach, 1), peak=HBM_PEAK_GBS,
-                        unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4), traffic=None, launches_per_step=1, avg_launch_us=round(us, 1),
-                        alg_bytes_per_launch=by)
+                        unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4), traffic=traffic, traffic_source=traffic_src, launches_per_step=1,
+                        avg_launch_us=round(us, 1), alg_bytes_per_launch=by,
+                        note="timed alone as one arena-wide launch; in the step it runs as two launches (convolution range, heads) and the "
+                             "heads' part overlaps the trunk's backward and the next step's trunk forward")
     if rank == 0 and not args.no_cpu_baseline:
         from oracle import spn_oracle as S
         ncores = min(os.cpu_count() or 1, args.cpu_threads)

@@ -420,6 +420,19 @@ int spb_spn_conv(const spb_spn_conv_args_t* args, spb_stream_t stream);
  * dWp f32 [groups*Ng][Kp] += sum over output pixels of G[m][n] * X[pixel(m, tap)][c]; G: bf16 [B*OH*OW][groups*Ng].
  * Partial sums of the pixel ranges meet in dWp with float atomics: zero it first. */
 int spb_spn_conv_wgrad(const spb_spn_conv_args_t* args, const void* G, float* dWp, spb_stream_t stream);
+/* conv1: float32 NCHW image [B][3][H][W] -> bf16 NHWC relu(conv + bias), K x K stride `stride`, no padding, N <= 96 output
+ * channels; Wp [N][Kp] in (c, ky, kx) order (spb_spn_pack_conv with chw_order = 1).  No column matrix. */
+int spb_spn_stem(const float* x, const void* Wp, const float* bias, void* Y, int B, int H, int W, int KH, int KW, int stride, int N, int Kp,
+                 int relu, spb_stream_t stream);
+/* All the repacks a step needs after the optimizer changed the convolution weights, in one launch.  mode 0: spb_spn_pack_conv
+ * (out [Cout][Kp], optional outT [groups][Kp][Cout/groups], chw = the RGB stem's (c, ky, kx) column order); mode 1:
+ * spb_spn_pack_conv_dgrad (out [Cin][Kp]).  dtype selects bf16 / f32 outputs for every job. */
+#define SPB_SPN_MAX_PACK_JOBS 12
+typedef struct spb_spn_pack_job {
+  const float* W; void* out; void* outT;
+  int Cout, Cin, groups, KH, KW, Kp, mode, chw;
+} spb_spn_pack_job_t;
+int spb_spn_pack_jobs(int dtype, const spb_spn_pack_job_t* jobs, int njobs, spb_stream_t stream);
 /* W: f32 [Cout][Cin/groups][KH][KW] -> WpD: bf16 [Cin][KpD], row g*Cg+ci = (mirrored tap, n) over the group's Cout/groups */
 int spb_spn_pack_conv_dgrad(const float* W, void* WpD, int Cout, int Cin, int groups, int KH, int KW, int KpD, spb_stream_t stream);
 int spb_spn_pack_conv(int dtype, const float* W, void* Wp, void* WpT, int Cout, int Cin, int groups, int KH, int KW, int Kg,
@@ -488,7 +501,7 @@ int spb_preproc_batch(const spb_preproc_args_t* a, spb_stream_t stream);
 int spb_debug_set_conv9_band(int on); /* decoder's last 9x9 layer: band-staged kernel (1, default) or the generic 8x8-tile kernel */
 int spb_debug_set_launch_events(int on); /* side-stream forks wait on the preceding GEMM launch's completion event (1) or on a recorded event (0) */
 int spb_debug_set_dw_split(int rows);      /* depthwise layers with fewer than `rows` input rows (B*H*W) run their weight gradient on
-                                              the side stream, apart from the input gradient (default 32768; 0 = always fused) */
+                                              the side stream, apart from the input gradient (default 0 = always fused: the split measured slower) */
 int spb_debug_set_wgrad_min_flush(int n); /* fork at a depthwise backward kernel only when >= n weight gradients are queued */
 int spb_debug_set_wgrad_batch(int n); /* pointwise weight-gradient GEMMs handed to the side stream per fork event */
 int spb_debug_set_gemm_bk64_dgrad_min_k(int k); /* backward-type small-M GEMMs with K >= k: 64x32 tiles with 64-deep chunks */

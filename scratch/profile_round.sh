@@ -31,4 +31,10 @@ python $ROOT/scratch/mfma_summary.py $OUT/krn_mfma.csv > $OUT/krn_mfma_summary.t
 # SPN
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_spn -o spn -- python $ROOT/bench.py --model spn --steps 20 --warmup 5 --no-cpu-baseline > $OUT/spn_bench_under_rocprof.json 2> $OUT/spn.err
 cp $(find /tmp/p_spn -name "*kernel_stats.csv" | head -1) $OUT/spn_kernel_stats.csv
+# SPN HBM traffic: two PMC passes of their own (kernel-trace only)
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/p_sf -o f -- python $ROOT/bench.py --model spn --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2> $OUT/spn_fetch.err
+cp $(find /tmp/p_sf -name "*counter_collection.csv" | head -1) $OUT/spn_fetch.csv
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/p_sw -o w -- python $ROOT/bench.py --model spn --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2> $OUT/spn_write.err
+cp $(find /tmp/p_sw -name "*counter_collection.csv" | head -1) $OUT/spn_write.csv
+python $ROOT/scratch/pmc_spn_summary.py $OUT/spn_fetch.csv $OUT/spn_write.csv $OUT/spn_pmc_traffic.json > $OUT/spn_pmc_summary.txt 2>&1
 ls -la $OUT

@@ -96,6 +96,10 @@ class SpnConvArgs(C.Structure):
                 ("B", "H", "W", "Cx", "KH", "KW", "stride", "pad", "groups", "Cg", "Ng", "Kp", "relu")]
 
 
+class SpnPackJob(C.Structure):
+    _fields_ = [("W", vp), ("out", vp), ("outT", vp)] + [(k, i32) for k in ("Cout", "Cin", "groups", "KH", "KW", "Kp", "mode", "chw")]
+
+
 class PreprocArgs(C.Structure):
     _fields_ = [("src", vp), ("table", vp), ("ftable", vp), ("noise", vp), ("out", vp), ("bounds", vp), ("coeffs", vp), ("tmp", vp),
                 ("B", i32), ("S", i32), ("C", i32), ("max_h", i32), ("flags_any", i32), ("noise_std", f32)]
@@ -201,6 +205,8 @@ SYMBOLS = {
     "spb_spn_unpack_conv_grad": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
     "spb_spn_conv": (i32, [C.POINTER(SpnConvArgs), vp]),
     "spb_spn_conv_wgrad": (i32, [C.POINTER(SpnConvArgs), vp, vp, vp]),
+    "spb_spn_stem": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
+    "spb_spn_pack_jobs": (i32, [i32, C.POINTER(SpnPackJob), i32, vp]),
     "spb_spn_pack_conv_dgrad": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "spb_fc_fwd": (i32, [vp, vp, vp, i32, i32, i32, vp]),
     "spb_fc_dgrad": (i32, [vp, vp, vp, i32, i32, i32, vp]),

@@ -172,6 +172,115 @@ __global__ __launch_bounds__(256) void spn_conv_kernel(const bf16_t* __restrict_
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------ RGB stem
+// conv1 (3 -> 96, 11x11, stride 4, no padding) straight from the float32 NCHW image: the A tile of a stage is gathered by the
+// lanes (8 scalar loads per 16-byte slot: 3-channel taps do not form 16-byte vectors), converted and stored to LDS one stage
+// ahead of the matrix cores; the weights ([N][Kp] in (c, ky, kx) order, spb_spn_pack_conv's chw layout) go through LDS-DMA.
+// The column matrix this replaces was 71 MB written and read back per step; the image is 20 MB.
+constexpr int SBN = 96;
+__global__ __launch_bounds__(256) void spn_stem_kernel(const float* __restrict__ x, const bf16_t* __restrict__ Wp, const float* __restrict__ bias,
+                                                       bf16_t* __restrict__ Y, int B, int H, int W, int KH, int KW, int st, int OH, int OW,
+                                                       int N, int Kp, int relu) {
+  constexpr int A_BYTES = 64 * 64 * 2, B_BYTES = SBN * 64 * 2, STAGE = A_BYTES + B_BYTES;
+  constexpr int LDO = SBN + 8;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int t = threadIdx.x, l = t & 63, w = t >> 6, li = l & 15, lq = l >> 4;
+  const int M = B * OH * OW, K = 3 * KH * KW, KT = (K + 63) / 64, taps = KH * KW;
+  const int m0 = blockIdx.x * 64;
+  const int dkv = (l & 7) ^ ((l >> 3) & 7);
+  size_t rowbase[2];
+  bool mok[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int m = m0 + w * 16 + i * 8 + (l >> 3);
+    mok[i] = m < M;
+    const int mc = mok[i] ? m : M - 1;
+    const int ox = mc % OW, oy = (mc / OW) % OH, b = mc / (OW * OH);
+    rowbase[i] = ((size_t)(b * 3) * H + oy * st) * W + ox * st;
+  }
+  size_t brow[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int n = w * 24 + i * 8 + (l >> 3);
+    brow[i] = (size_t)(n < N ? n : N - 1) * Kp;
+  }
+  const unsigned lds0 = lds_addr(smem);
+  const unsigned wave_b = __builtin_amdgcn_readfirstlane((unsigned)(A_BYTES + w * 24 * 128));
+  float av[2][8];
+#define STEM_LOAD(kt_)                                                                             \
+  {                                                                                                \
+    const unsigned sb = lds0 + (unsigned)(((kt_) & 1) * STAGE) + wave_b;                           \
+    const int kb = (kt_) * 64 + dkv * 8;                                                           \
+    const int kc = kb < Kp ? kb : Kp - 8;                                                          \
+    _Pragma("unroll") for (int i = 0; i < 3; ++i) dma16(Wp + brow[i] + kc, sb + (unsigned)(i * 8 * 128)); \
+    int c = kb / taps, rem = kb - c * taps;                                                        \
+    int ky = rem / KW, kx = rem - ky * KW;                                                         \
+    _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                \
+      const bool kok = kb + j < K;                                                                 \
+      const size_t off = kok ? ((size_t)c * H + ky) * W + kx : 0;                                  \
+      _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                              \
+        const float v = x[rowbase[i] + off];                                                       \
+        av[i][j] = (kok && mok[i]) ? v : 0.f;                                                      \
+      }                                                                                            \
+      if (++kx == KW) { kx = 0; if (++ky == KH) { ky = 0; ++c; } }                                 \
+    }                                                                                              \
+  }
+  STEM_LOAD(0);
+  f32x4_t acc[SBN / 16];
+#pragma unroll
+  for (int j = 0; j < SBN / 16; ++j) acc[j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  const int frow = w * 16 + li;
+  for (int kt = 0; kt < KT; ++kt) {
+    char* sbuf = smem + (size_t)(kt & 1) * STAGE;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {      // this lane's two 16-byte slots of stage kt (physical slot l&7 holds logical vector dkv)
+      uint4 u;
+      u.x = pack_bf16x2(av[i][0], av[i][1]); u.y = pack_bf16x2(av[i][2], av[i][3]);
+      u.z = pack_bf16x2(av[i][4], av[i][5]); u.w = pack_bf16x2(av[i][6], av[i][7]);
+      *reinterpret_cast<uint4*>(sbuf + (w * 16 + i * 8 + (l >> 3)) * 128 + (l & 7) * 16) = u;
+    }
+    wait_vmcnt<0>();                   // the weight tile of stage kt
+    __syncthreads();                   // stage kt complete in LDS; everyone is done with the other buffer (stage kt-1)
+    if (kt + 1 < KT) STEM_LOAD(kt + 1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int v = ks * 4 + lq;
+      const bf16x8_t af = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(sbuf + frow * 128 + ((v ^ (frow & 7)) << 4)));
+#pragma unroll
+      for (int j = 0; j < SBN / 16; ++j) {
+        const int br = j * 16 + li;
+        const bf16x8_t bf = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(sbuf + A_BYTES + br * 128 + ((v ^ (br & 7)) << 4)));
+        acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bf, acc[j], 0, 0, 0);
+      }
+    }
+  }
+#undef STEM_LOAD
+  __syncthreads();
+  bf16_t* Os = reinterpret_cast<bf16_t*>(smem);
+#pragma unroll
+  for (int j = 0; j < SBN / 16; ++j)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) Os[(w * 16 + lq * 4 + e) * LDO + j * 16 + li] = f2bf(acc[j][e]);
+  __syncthreads();
+  constexpr int NV = SBN / 8;
+  for (int i = t; i < 64 * NV; i += 256) {
+    const int r = i / NV, vc = i % NV;
+    const int m = m0 + r, n = vc * 8;
+    if (m < M && n < N) {
+      float v[8];
+      ld8<bf16_t>(Os + r * LDO + n, v);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        v[j] += (bias && n + j < N) ? bias[n + j] : 0.f;
+        if (relu) v[j] = fmaxf(v[j], 0.f);
+      }
+      if (n + 8 <= N) st8<bf16_t>(Y + (size_t)m * N + n, v);
+      else
+        for (int j = 0; j < 8; ++j) if (n + j < N) Y[(size_t)m * N + n + j] = f2bf(v[j]);
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------- weight gradient
 // dWp[n][k] += sum_m G[m][n] * X[pix(m, tap(k))][c(k)].  A workgroup owns a 64 x 64 tile of (n, k) and a range of output
 // pixels m; the reduction axis m is the slow axis of both operands, so the LDS tiles ([64 m][64] bf16, filled by LDS-DMA, CDS
@@ -298,6 +407,36 @@ __global__ void pack_conv_dgrad_kernel(const float* __restrict__ W, bf16_t* __re
   }
 }
 
+// every repack the next forward / backward needs after an optimizer step, in one launch (blockIdx.y = job): nine dependent
+// 5-20 us launches sat between the optimizer and the next step's first convolution
+struct PackJobs { spb_spn_pack_job_t j[SPB_SPN_MAX_PACK_JOBS]; };
+__global__ void pack_jobs_kernel(const PackJobs jobs, int bf16) {
+  const spb_spn_pack_job_t& q = jobs.j[blockIdx.y];
+  const int cog = q.Cout / q.groups, cig = q.Cin / q.groups;
+  const int rows = q.mode == 1 ? q.Cin : q.Cout;
+  const long long total = (long long)rows * q.Kp;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int row = (int)(i / q.Kp), k = (int)(i % q.Kp);
+    float v = 0.f;
+    if (q.mode == 1) {          // mirrored taps for the input gradient: [g*cig + ci][(tap', n)]
+      if (k < q.KH * q.KW * cog) {
+        const int tp = k / cog, n = k % cog;
+        const int ky = q.KH - 1 - tp / q.KW, kx = q.KW - 1 - tp % q.KW;
+        const int gi = row / cig, ci = row % cig;
+        v = q.W[(((size_t)(gi * cog + n) * cig + ci) * q.KH + ky) * q.KW + kx];
+      }
+    } else if (k < q.KH * q.KW * cig) {   // forward: [co][(tap, ci)], or [co][(ci, tap)] for the RGB stem's column order
+      v = q.chw ? q.W[(size_t)row * cig * q.KH * q.KW + k] : q.W[((size_t)row * cig + (k % cig)) * q.KH * q.KW + k / cig];
+    }
+    if (bf16) reinterpret_cast<bf16_t*>(q.out)[i] = f2bf(v); else reinterpret_cast<float*>(q.out)[i] = v;
+    if (q.mode == 0 && q.outT) {          // [g][k][co in group]: the explicit-GEMM input gradient's operand
+      const int gi = row / cog;
+      const size_t o = ((size_t)gi * q.Kp + k) * cog + (row - gi * cog);
+      if (bf16) reinterpret_cast<bf16_t*>(q.outT)[o] = f2bf(v); else reinterpret_cast<float*>(q.outT)[o] = v;
+    }
+  }
+}
+
 bf16_t* g_zero_page = nullptr;
 bf16_t* zero_page() {
   if (!g_zero_page) {
@@ -377,6 +516,39 @@ extern "C" int spb_spn_conv_wgrad(const spb_spn_conv_args_t* a, const void* G, f
   if (!once) { hipFuncSetAttribute(reinterpret_cast<const void*>(&spn_conv_wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); once = true; }
   hipLaunchKernelGGL(spn_conv_wgrad_kernel, dim3(tiles * S), dim3(256), lds, (hipStream_t)stream, (const bf16_t*)G, (const bf16_t*)a->X, dWp, zp, g,
                      rps, magic_div(g.OW), magic_div(g.OH));
+  SPB_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int spb_spn_stem(const float* x, const void* Wp, const float* bias, void* Y, int B, int H, int W, int KH, int KW, int stride,
+                            int N, int Kp, int relu, spb_stream_t stream) {
+  if (!x || !Wp || !Y || B <= 0 || H < KH || W < KW || KH <= 0 || KW <= 0 || stride <= 0 || N <= 0) return SPB_E_ARG;
+  if (N > SBN || (Kp & 7) || Kp < 3 * KH * KW || (N & 7)) return SPB_E_UNSUPPORTED;
+  const int OH = (H - KH) / stride + 1, OW = (W - KW) / stride + 1;
+  const int M = B * OH * OW;
+  const size_t lds = (size_t)2 * (64 * 64 * 2 + SBN * 64 * 2);
+  hipLaunchKernelGGL(spn_stem_kernel, dim3((M + 63) / 64), dim3(256), lds, (hipStream_t)stream, x, (const bf16_t*)Wp, bias, (bf16_t*)Y, B, H, W,
+                     KH, KW, stride, OH, OW, N, Kp, relu);
+  SPB_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int spb_spn_pack_jobs(int dtype, const spb_spn_pack_job_t* jobs, int njobs, spb_stream_t stream) {
+  if (!jobs || njobs <= 0 || njobs > SPB_SPN_MAX_PACK_JOBS || (dtype != SPB_BF16 && dtype != SPB_F32)) return SPB_E_ARG;
+  PackJobs pj;
+  long long biggest = 0;
+  for (int i = 0; i < njobs; ++i) {
+    const spb_spn_pack_job_t& q = jobs[i];
+    if (!q.W || !q.out || q.Cout <= 0 || q.Cin <= 0 || q.groups <= 0 || (q.Cout % q.groups) || (q.Cin % q.groups)) return SPB_E_ARG;
+    const int need = q.KH * q.KW * (q.mode == 1 ? q.Cout / q.groups : q.Cin / q.groups);
+    if (q.Kp < need || (q.mode != 0 && q.mode != 1)) return SPB_E_ARG;
+    pj.j[i] = q;
+    const long long total = (long long)(q.mode == 1 ? q.Cin : q.Cout) * q.Kp;
+    if (total > biggest) biggest = total;
+  }
+  long long gx = (biggest + 255) / 256;
+  if (gx > 1024) gx = 1024;
+  hipLaunchKernelGGL(pack_jobs_kernel, dim3((unsigned)gx, (unsigned)njobs), dim3(256), 0, (hipStream_t)stream, pj, dtype == SPB_BF16 ? 1 : 0);
   SPB_CHECK_LAUNCH();
   return 0;
 }

@@ -70,6 +70,8 @@ class _Layer(nn.Module):
         nn.init.uniform_(self.bias, -bound, bound)
 
 
+_BACKGROUND_BLOCKS = int(os.environ.get("SPB_SPN_UPDATE_BLOCKS", "0"))   # > 0: cap on the workgroups of the heads' update beside backward
+_STEM = os.environ.get("SPB_SPN_STEM", "0") == "1"    # direct conv1 (spb_spn_stem): 82 vs 108 us alone, but 350 us beside the update (scattered 4-byte loads); off
 _FUSED_FC_UPDATE = os.environ.get("SPB_SPN_FUSED_FC_UPDATE", "0") == "1"
 _HEAD1_EARLY = os.environ.get("SPB_SPN_HEAD1_EARLY", "1") != "0"   # the class head's update beside the regression head's backward
 
@@ -211,22 +213,29 @@ class SpacecraftPoseNet(nn.Module):
         lib, st = L.lib(), _st()
         dt, dc = self._dt(), (L.BF16 if self.precision == "bf16" else L.F32)
         cp = {"v": self._version, "t": need_t, "fc": not fast}
+        jobs = (L.SpnPackJob * 12)()
+        nj = 0
         for name, cout, cin, g, k, _, _ in _CONVS:
             kg = (k * k * (cin // g) + 7) // 8 * 8             # one column slab / one [cout/g][kg] operand per group
+            implicit = name != "conv1" and self._implicit()
             wp = self._buf("wp" + name, (cout, kg), dt)
-            wt = self._buf("wpT" + name, (g, kg, cout // g), dt) if (need_t and name != "conv1") else None
-            L.check(lib.spb_spn_pack_conv(dc, _p(getattr(self, name).weight.detach()), _p(wp), _p(wt), cout, cin, g, k, k, kg, 1 if name == "conv1" else 0, st),
-                    "spb_spn_pack_conv")
+            # [g][kg][cout/g]: operand of the explicit-GEMM input gradient (float32 parity mode / implicit_conv off)
+            wt = self._buf("wpT" + name, (g, kg, cout // g), dt) if (need_t and name != "conv1" and not implicit) else None
+            q = jobs[nj]; nj += 1
+            q.W, q.out, q.outT = _p(getattr(self, name).weight.detach()).value, _p(wp).value, _p(wt).value
+            q.Cout, q.Cin, q.groups, q.KH, q.KW, q.Kp, q.mode, q.chw = cout, cin, g, k, k, kg, 0, 1 if name == "conv1" else 0
             cp[name] = wp
             if wt is not None:
                 cp[name + "T"] = wt
-            if need_t and name != "conv1" and self._implicit():
+            if need_t and implicit:
                 # mirrored-tap weights of the input-gradient pass (csrc/spn_conv.hip): [cin][(tap', cout/g)]
                 kd = (k * k * (cout // g) + 7) // 8 * 8
                 wd = self._buf("wpD" + name, (cin, kd), dt)
-                L.check(lib.spb_spn_pack_conv_dgrad(_p(getattr(self, name).weight.detach()), _p(wd), cout, cin, g, k, k, kd, st),
-                        "spb_spn_pack_conv_dgrad")
+                q = jobs[nj]; nj += 1
+                q.W, q.out, q.outT = _p(getattr(self, name).weight.detach()).value, _p(wd).value, None
+                q.Cout, q.Cin, q.groups, q.KH, q.KW, q.Kp, q.mode, q.chw = cout, cin, g, k, k, kd, 1, 0
                 cp[name + "D"] = wd
+        L.check(lib.spb_spn_pack_jobs(dc, jobs, nj, st), "spb_spn_pack_jobs")      # one launch for all of them
         if fast:
             if self._shadow_version != self._version:     # load_state_dict / load_weights / manual edits: rare
                 self.join_updates()
@@ -284,6 +293,10 @@ class SpacecraftPoseNet(nn.Module):
             if li > 0 and self._implicit():
                 self._conv(cur, cp[name], bias, None, y, B, Hc, Wc, Cc, k, stride, pad, g, cin // g, cog, relu=True)
                 sv["x" + name] = cur
+            elif li == 0 and self._implicit() and _STEM:
+                # straight from the float32 NCHW image; backward builds the column matrix of its weight gradient on the side stream
+                L.check(lib.spb_spn_stem(_p(x), _p(cp[name]), _p(bias), _p(y), B, Hc, Wc, k, k, stride, cout, kg, 1, st), "spb_spn_stem")
+                sv["image"] = x
             else:
                 col = self._buf("col" + name, (B * OH * OW, kpad), dt)
                 if li == 0:
@@ -584,7 +597,7 @@ class SpacecraftPoseNet(nn.Module):
                 self._upd.wait_stream(torch.cuda.current_stream())
                 self._upd.wait_stream(self._side)
                 with torch.cuda.stream(self._upd):
-                    optimizer.update_range_early(self._conv_end, self._gflat.numel())
+                    optimizer.update_range_early(self._conv_end, self._gflat.numel(), max_blocks=_BACKGROUND_BLOCKS)
                 self._early_on_upd = True
         else:
             df = None
@@ -611,6 +624,14 @@ class SpacecraftPoseNet(nn.Module):
                                                         world_size))
         # trunk, last to first
         masked = False
+        if "image" in sv:       # conv1 ran without a column matrix: its weight gradient's operand, built beside the whole trunk
+            name, cout, cin, grp, k, stride, pad = _CONVS[0]
+            Hc, Wc, _ = sv["in" + name]
+            OH, OW = (Hc - k) // stride + 1, (Wc - k) // stride + 1
+            col1 = self._buf("col" + name, (B * OH * OW, cp[name].shape[1]), dt)
+            self._on_side([lambda s_, col1=col1, Hc=Hc, Wc=Wc, k=k, stride=stride: L.check(
+                lib.spb_im2col_rgb(dc, _p(sv["image"]), _p(col1), B, Hc, Wc, k, k, stride, col1.shape[1], s_), "spb_im2col_rgb")])
+            sv["col" + name] = col1
         dwp = self._buf("dWp", (sum(cp[n].numel() for n, *_ in _CONVS),), torch.float32)
         dwp.zero_()
         woff = 0

@@ -385,3 +385,23 @@ def test_implicit_gemm_convolution(device, name, cout, cin, groups, k, pad, hw, 
         if mask is not None:
             want = want * (mask.float() > 0)
         assert rel(dx.float().view(B, hw, hw, cin), want) < 8e-3, mask is not None
+
+
+@pytest.mark.parametrize("B", [2, 32])
+def test_rgb_stem_convolution(device, B):
+    """spb_spn_stem: conv1 (3 -> 96, 11x11, stride 4) + bias + ReLU straight from the float32 NCHW image against
+    torch.nn.functional.conv2d on the bf16-rounded operands"""
+    import ctypes as C
+    import torch.nn.functional as F
+    from speedplusbaseline_amd import _lib as L
+    lib, st = L.lib(), C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    g = torch.Generator().manual_seed(77 + B)
+    w = (torch.randn(96, 3, 11, 11, generator=g) / 363 ** 0.5).to(device)
+    bias = (0.1 * torch.randn(96, generator=g)).to(device)
+    x = torch.randn(B, 3, 227, 227, generator=g).to(device)
+    wp = torch.empty(96, 368, dtype=torch.bfloat16, device=device)
+    L.check(lib.spb_spn_pack_conv(L.BF16, _vp(w), _vp(wp), None, 96, 3, 1, 11, 11, 368, 1, st), "pack")
+    y = torch.empty(B * 55 * 55, 96, dtype=torch.bfloat16, device=device)
+    L.check(lib.spb_spn_stem(_vp(x), _vp(wp), _vp(bias), _vp(y), B, 227, 227, 11, 11, 4, 96, 368, 1, st), "spb_spn_stem")
+    ref = F.relu(F.conv2d(x.to(torch.bfloat16).float(), w.to(torch.bfloat16).float(), bias, stride=4))
+    assert rel(y.float().view(B, 55, 55, 96).permute(0, 3, 1, 2), ref) < 8e-3
