@@ -73,7 +73,6 @@ class _Layer(nn.Module):
 _BACKGROUND_BLOCKS = int(os.environ.get("SPB_SPN_UPDATE_BLOCKS", "0"))   # > 0: cap on the workgroups of the heads' update beside backward
 _STEM = os.environ.get("SPB_SPN_STEM", "0") == "1"    # direct conv1 (spb_spn_stem): 82 vs 108 us alone, but 350 us beside the update (scattered 4-byte loads); off
 _FUSED_FC_UPDATE = os.environ.get("SPB_SPN_FUSED_FC_UPDATE", "0") == "1"
-_HEAD1_EARLY = os.environ.get("SPB_SPN_HEAD1_EARLY", "1") != "0"   # the class head's update beside the regression head's backward
 
 
 def _low_priority_stream(device):
@@ -104,6 +103,7 @@ class SpacecraftPoseNet(nn.Module):
         self._saved = None
         self.dropout_seed = 2021
         self.side_wgrad = True     # weight gradients on a side stream (False: everything on the launch stream)
+        self.concurrent_heads = os.environ.get("SPB_SPN_CONCURRENT_HEADS", "1") != "0"
         self.implicit_conv = os.environ.get("SPB_SPN_IMPLICIT", "1") != "0"   # conv2..5 as implicit GEMMs (bf16)
         self._step = 0
         if pretrain:
@@ -348,12 +348,14 @@ class SpacecraftPoseNet(nn.Module):
             f, fT = self._buf("f", (B, 9216), dt), self._buf("fT", (9216, MP), dt)
             L.check(lib.spb_spn_flatten(_p(p5), _p(f), _p(fT), B, 36, 256, st), "spb_spn_flatten")
             sv["f"], sv["fT"], sv["MP"] = f, fT, MP
-            acc = self._acc("acc", max(4096, NC), MP)
-            for hi, names in enumerate((("fc6", "fc7", "fc8"), ("fc9", "fc10", "fc11"))):
+            outs = [None, None]
+            for hi, names in ((1, ("fc9", "fc10", "fc11")), (0, ("fc6", "fc7", "fc8"))):   # the forked head is enqueued first
+              with self._head_ctx(hi):       # the two heads are independent chains of weight-streaming kernels: side by side
+                acc = self._acc("acc%d" % hi, max(4096, NC), MP)
                 h, K = f, 9216
                 for j, name in enumerate(names):
                     N = NC if j == 2 else 4096
-                    L.check(lib.spb_fc_fwd(_p(h), _p(self._sh(name + ".weight")), _p(acc), B, N, K, st), "spb_fc_fwd")
+                    L.check(lib.spb_fc_fwd(_p(h), _p(self._sh(name + ".weight")), _p(acc), B, N, K, _st()), "spb_fc_fwd")
                     y = self._buf("h" + name, (B, N), dt)
                     bias = getattr(self, name).bias.detach()
                     if j == 2:
@@ -372,7 +374,8 @@ class SpacecraftPoseNet(nn.Module):
                         sv["hT" + name] = yT
                     sv["in" + name], sv["h" + name] = h, y
                     h, K = y, N
-                outs.append(h)
+                outs[hi] = h
+            self._join_heads()
         else:
             # reference flatten order (NCHW): a small permuting copy on this general path
             f = p5.reshape(B, 36, 256).permute(0, 2, 1).reshape(B, 9216).contiguous()
@@ -425,6 +428,24 @@ class SpacecraftPoseNet(nn.Module):
         if getattr(self, "_side_used", False):
             torch.cuda.current_stream().wait_stream(self._side)
             self._side_used = False
+
+    def _head_ctx(self, hi):
+        """stream context of head `hi`: the class head stays on the launch stream, the regression head runs on a stream of its
+        own forked here (each M <= 64 weight-streaming kernel alone reaches ~3 TB/s; two side by side share the HBM better,
+        and the 5 us epilogue launches between them overlap)"""
+        import contextlib
+        if hi == 0 or not self.concurrent_heads:
+            return contextlib.nullcontext()
+        if getattr(self, "_hs", None) is None:
+            self._hs = torch.cuda.Stream(device=self._gflat.device)
+        self._hs.wait_stream(torch.cuda.current_stream())
+        self._heads_forked = True
+        return torch.cuda.stream(self._hs)
+
+    def _join_heads(self):
+        if getattr(self, "_heads_forked", False):
+            torch.cuda.current_stream().wait_stream(self._hs)
+            self._heads_forked = False
 
     def _run_updates(self, optimizer, jobs, B):
         """the fully connected layers' weight gradient + parameter update kernels (SpnOptimizer.fused_fc_update) on a stream of
@@ -545,27 +566,28 @@ class SpacecraftPoseNet(nn.Module):
         NC = self.num_classes
         out = torch.zeros(3, dtype=torch.float32, device=c.device)
         dcg, drg = self._buf("dc", (B, NC), dt), self._buf("dr", (B, NC), dt)
-        L.check(lib.spb_softce(dc, _p(c), _p(y_classes.float().contiguous()), _p(dcg), _p(out), 1, B, NC, 1.0, st), "spb_softce")
-        L.check(lib.spb_softce(dc, _p(r), _p(y_weights.float().contiguous()), _p(drg), _p(out), 2, B, NC, 10.0, st), "spb_softce")
+        ycf, ywf = y_classes.float().contiguous(), y_weights.float().contiguous()
+        if not fast:
+            L.check(lib.spb_softce(dc, _p(c), _p(ycf), _p(dcg), _p(out), 1, B, NC, 1.0, st), "spb_softce")
+            L.check(lib.spb_softce(dc, _p(r), _p(ywf), _p(drg), _p(out), 2, B, NC, 10.0, st), "spb_softce")
         ident = ops.bnref
         scale = 1.0 / (1.0 - self.keep_prob)
         self._gflat[:self._conv_end].zero_()          # conv bias gradients are accumulated with atomics
         if fast:
             MP = sv["MP"]
-            acc, accF = self._acc("acc", max(4096, NC), MP), self._acc("accF", 9216, MP)
-            pend, jobs = [], []
+            accF = self._acc("accF", 9216, MP)       # both heads' gradient of the flattened pool5 output (float atomics)
+            jobs = []
             # weight gradient + update of a layer in one kernel (spb_fc_wgrad_update): measured SLOWER than the two passes -- the
             # matrix-core output layout gives every lane 16 bytes of a different weight row, and seven streams with that pattern
             # run at a third of the arena-wide update's bandwidth (1.7 ms against 0.2 + 0.8 ms) -- so it is an experiment knob
             fuse = optimizer is not None and world_size == 1 and _FUSED_FC_UPDATE
-            for names, g in ((("fc6", "fc7", "fc8"), dcg), (("fc9", "fc10", "fc11"), drg)):
-                self._on_side(pend)                  # the first head's weight gradients run beside the second head's chain
-                if pend and world_size > 1:          # ... and their exchange starts as soon as they are through
-                    self._ddp_works.append(self._start_exchange(group, compress_bf16, self._conv_end, head2_lo, optimizer, world_size))
+            for hi, names, g, lg, tgt_, slot, wgt in ((1, ("fc9", "fc10", "fc11"), drg, r, ywf, 2, 10.0),     # forked head first
+                                                      (0, ("fc6", "fc7", "fc8"), dcg, c, ycf, 1, 1.0)):
+              with self._head_ctx(hi):       # loss gradient + input-gradient chain of each head on its own stream
+                st = _st()
+                acc = self._acc("acc%d" % hi, max(4096, NC), MP)
                 pend = []
-                if jobs and _HEAD1_EARLY:
-                    self._run_updates(optimizer, jobs, B)
-                    jobs = []
+                L.check(lib.spb_softce(dc, _p(lg), _p(tgt_), _p(g), _p(out), slot, B, NC, wgt, st), "spb_softce")
                 a, b_, c_ = names
                 gT = self._buf("gT" + c_, (NC, MP), dt)
                 self._epi(B, NC, 1, src=g, YT=gT, db=getattr(self, c_).bias.grad)
@@ -583,9 +605,13 @@ class SpacecraftPoseNet(nn.Module):
                         g = self._buf("g" + prev, (B, 4096), dt)
                         gT = self._buf("gT" + prev, (4096, MP), dt)
                         self._epi(B, 4096, 1, accT=acc, H=sv["h" + prev], Y=g, YT=gT, db=getattr(self, prev).bias.grad, scale=scale)
+                self._on_side(pend)          # this head's weight gradients: forked from its own stream, beside what follows
+            self._join_heads()
+            st = _st()
+            if world_size > 1:               # the class head's bucket travels first, the regression head's follows below
+                self._ddp_works.append(self._start_exchange(group, compress_bf16, self._conv_end, head2_lo, optimizer, world_size))
             g_act = self._buf("dp5", (B, 6, 6, 256), dt)   # the two heads met in accF
             L.check(lib.spb_spn_unflatten_grad(_p(accF), _p(g_act), B, 36, 256, st), "spb_spn_unflatten_grad")
-            self._on_side(pend)                            # ... the second head's beside the start of the trunk
             if fuse:
                 self._run_updates(optimizer, jobs, B)       # beside the trunk's backward (and the next step's trunk forward)
             elif optimizer is not None and world_size == 1:
