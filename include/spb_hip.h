@@ -433,6 +433,8 @@ typedef struct spb_spn_pack_job {
   int Cout, Cin, groups, KH, KW, Kp, mode, chw;
 } spb_spn_pack_job_t;
 int spb_spn_pack_jobs(int dtype, const spb_spn_pack_job_t* jobs, int njobs, spb_stream_t stream);
+/* the same kernel on an explicit column matrix: dW f32 [N][lddw] += G^T (bf16 [M][N]) * col (bf16 [M][ldcol], K columns used) */
+int spb_spn_col_wgrad(const void* G, const void* col, float* dW, int M, int N, int K, int ldcol, int lddw, spb_stream_t stream);
 /* W: f32 [Cout][Cin/groups][KH][KW] -> WpD: bf16 [Cin][KpD], row g*Cg+ci = (mirrored tap, n) over the group's Cout/groups */
 int spb_spn_pack_conv_dgrad(const float* W, void* WpD, int Cout, int Cin, int groups, int KH, int KW, int KpD, spb_stream_t stream);
 int spb_spn_pack_conv(int dtype, const float* W, void* Wp, void* WpT, int Cout, int Cin, int groups, int KH, int KW, int Kg,

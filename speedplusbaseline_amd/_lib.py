@@ -205,6 +205,7 @@ SYMBOLS = {
     "spb_spn_unpack_conv_grad": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
     "spb_spn_conv": (i32, [C.POINTER(SpnConvArgs), vp]),
     "spb_spn_conv_wgrad": (i32, [C.POINTER(SpnConvArgs), vp, vp, vp]),
+    "spb_spn_col_wgrad": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "spb_spn_stem": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
     "spb_spn_pack_jobs": (i32, [i32, C.POINTER(SpnPackJob), i32, vp]),
     "spb_spn_pack_conv_dgrad": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, vp]),

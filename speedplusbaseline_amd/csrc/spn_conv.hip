@@ -15,6 +15,7 @@
 // map (read about once per column tile through L2), the weights and the output -- the column matrix the round-1 path wrote
 // and read back was 6x (3x3) to 25x (5x5) the input.
 #include "common.h"
+#include <cstring>
 
 namespace {
 
@@ -27,6 +28,7 @@ struct ConvGeo {
   int Kp;                   // packed weight row length (>= KH*KW*Cg, multiple of 8)
   int M;                    // B*OH*OW output pixels
   int kw_inv;               // ceil(65536 / KW): tap / KW without a division
+  int plain;                // weight gradient only: X is an explicit [M][Cx] column matrix (k = column), no gather
 };
 
 // RW: 16-row fragments per wave (workgroup tile = 64*RW rows x 64 columns)
@@ -297,7 +299,7 @@ __global__ __launch_bounds__(256) void spn_conv_wgrad_kernel(const bf16_t* __res
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int t = threadIdx.x, l = t & 63, w = t >> 6, li = l & 15, lq = l >> 4;
   const int wn = w >> 1, wk = w & 1;
-  const int K = g.KH * g.KW * g.Cg;
+  const int K = g.plain ? g.Cg : g.KH * g.KW * g.Cg;
   const int NTg = (g.Ng + 63) / 64, KTk = (K + 63) / 64;
   const int tiles = g.groups * NTg * KTk;
   const int lid = xcd_remap(blockIdx.x, gridDim.x);     // the tiles of one pixel range share G and X rows: one XCD, back to back
@@ -324,6 +326,9 @@ __global__ __launch_bounds__(256) void spn_conv_wgrad_kernel(const bf16_t* __res
       const int m = (mb_) + drow + 8 * i;                                                               \
       const int mc = m < mend ? m : mend - 1;                                                           \
       dma16(G + (size_t)mc * Ntot + gcol, sb + (unsigned)(i * 8 * 128));                                \
+      if (g.plain) {                                                                                    \
+        dma16((kok && m < mend) ? X + ((long long)mc * g.Cx + kv) : zero, sb + TILE + (unsigned)(i * 8 * 128)); \
+      } else {                                                                                          \
       const int q1 = (int)__umulhi((unsigned)mc, ow_magic);            /* mc / OW */                    \
       const int ox = mc - q1 * g.OW;                                                                    \
       const int b = (int)__umulhi((unsigned)q1, oh_magic);             /* q1 / OH */                    \
@@ -331,6 +336,7 @@ __global__ __launch_bounds__(256) void spn_conv_wgrad_kernel(const bf16_t* __res
       const int iy = oy * g.stride - g.pad + ky, ix = ox * g.stride - g.pad + kx;                       \
       const bool ok = kok && m < mend && (unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W;  \
       dma16(ok ? X + (((long long)(b * g.H + iy) * g.W + ix) * g.Cx + xcol) : zero, sb + TILE + (unsigned)(i * 8 * 128)); \
+      }                                                                                                 \
     }                                                                                                   \
   }
   const int nst = (mend - mbeg + 63) / 64;
@@ -461,6 +467,7 @@ extern "C" int spb_spn_conv(const spb_spn_conv_args_t* a, spb_stream_t stream) {
   if (g.OH <= 0 || g.OW <= 0) return SPB_E_SHAPE;
   g.groups = a->groups; g.Cg = a->Cg; g.Ng = a->Ng; g.Kp = a->Kp;
   g.M = a->B * g.OH * g.OW;
+  g.plain = 0;
   g.kw_inv = (65536 + a->KW - 1) / a->KW;
   if (a->KH * a->KW > 4096) return SPB_E_SHAPE;     // kw_inv is exact for tap < 2^16 / KW
   bf16_t* zp = zero_page();
@@ -499,6 +506,7 @@ extern "C" int spb_spn_conv_wgrad(const spb_spn_conv_args_t* a, const void* G, f
   if (g.OH <= 0 || g.OW <= 0) return SPB_E_SHAPE;
   g.groups = a->groups; g.Cg = a->Cg; g.Ng = a->Ng; g.Kp = a->Kp;
   g.M = a->B * g.OH * g.OW;
+  g.plain = 0;
   g.kw_inv = 0;
   if ((long long)g.M * (g.OW > g.OH ? g.OW : g.OH) >= (1ll << 31)) return SPB_E_SHAPE;     // magic_div's exact range
   bf16_t* zp = zero_page();
@@ -516,6 +524,33 @@ extern "C" int spb_spn_conv_wgrad(const spb_spn_conv_args_t* a, const void* G, f
   if (!once) { hipFuncSetAttribute(reinterpret_cast<const void*>(&spn_conv_wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); once = true; }
   hipLaunchKernelGGL(spn_conv_wgrad_kernel, dim3(tiles * S), dim3(256), lds, (hipStream_t)stream, (const bf16_t*)G, (const bf16_t*)a->X, dWp, zp, g,
                      rps, magic_div(g.OW), magic_div(g.OH));
+  SPB_CHECK_LAUNCH();
+  return 0;
+}
+
+// the same kernel on an explicit column matrix (conv1: 3-channel taps do not form 16-byte vectors, so its columns are built by
+// spb_im2col_rgb): dW[n][k] += sum_m G[m][n] * col[m][k]
+extern "C" int spb_spn_col_wgrad(const void* G, const void* col, float* dW, int M, int N, int K, int ldcol, int lddw, spb_stream_t stream) {
+  if (!G || !col || !dW || M <= 0 || N <= 0 || K <= 0) return SPB_E_ARG;
+  if ((N & 7) || (ldcol & 7) || ldcol < K || lddw < K || (long long)M >= (1ll << 30)) return SPB_E_UNSUPPORTED;
+  ConvGeo g;
+  std::memset(&g, 0, sizeof(g));
+  g.plain = 1; g.groups = 1; g.Cg = K; g.Ng = N; g.Cx = ldcol; g.Kp = lddw; g.M = M;
+  g.KH = g.KW = g.OH = g.OW = g.H = g.W = g.stride = 1;
+  bf16_t* zp = zero_page();
+  if (!zp) return SPB_E_STATE;
+  const int tiles = ((N + 63) / 64) * ((K + 63) / 64);
+  int S = (1024 + tiles - 1) / tiles;
+  const int maxS = (M + 255) / 256;
+  if (S > maxS) S = maxS;
+  if (S < 1) S = 1;
+  int rps = ((M + S - 1) / S + 63) / 64 * 64;
+  S = (M + rps - 1) / rps;
+  const size_t lds = (size_t)CDS * 2 * 64 * 64 * 2;
+  static bool once = false;
+  if (!once) { hipFuncSetAttribute(reinterpret_cast<const void*>(&spn_conv_wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); once = true; }
+  hipLaunchKernelGGL(spn_conv_wgrad_kernel, dim3(tiles * S), dim3(256), lds, (hipStream_t)stream, (const bf16_t*)G, (const bf16_t*)col, dW, zp, g,
+                     rps, 1u, 1u);
   SPB_CHECK_LAUNCH();
   return 0;
 }

@@ -697,12 +697,18 @@ class SpacecraftPoseNet(nn.Module):
                     a.B, a.H, a.W, a.Cx, a.KH, a.KW, a.stride, a.pad = B, Hc, Wc, Cc, k, k, stride, pad
                     a.groups, a.Cg, a.Ng, a.Kp = grp, cin // grp, cog, kg
                     L.check(lib.spb_spn_conv_wgrad(C.byref(a), _p(g), _p(dW), s_), "spb_spn_conv_wgrad")
+                if col is not None and grp == 1 and self._implicit():     # conv1: the same LDS-DMA kernel on its column matrix
+                    L.check(lib.spb_spn_col_wgrad(_p(g), _p(col), _p(dW), g.shape[0], cout, kg, kg, kg, s_), "spb_spn_col_wgrad")
+                    col = None
                 for gi in range(grp if col is not None else 0):   # ops.* launch on the current stream = the side stream inside _on_side
                     ops.pwconv_wgrad(g[:, gi * cog:(gi + 1) * cog], col[:, gi * kg:(gi + 1) * kg], dW[gi * cog:(gi + 1) * cog], ident(cog), ident(kg))
                 L.check(lib.spb_spn_unpack_conv_grad(_p(dW), _p(lay.weight.grad), cout, cin, grp, k, k, kg, 1 if name == "conv1" else 0, s_),
                         "spb_spn_unpack_conv_grad")
-                L.check(lib.spb_colsum(dc, _p(g), _p(lay.bias.grad), g.shape[0], cout, s_), "spb_colsum")
+                if name != "conv1":
+                    L.check(lib.spb_colsum(dc, _p(g), _p(lay.bias.grad), g.shape[0], cout, s_), "spb_colsum")
             self._on_side([conv_wgrad])
+            if name == "conv1":     # the last layer: nothing follows on the launch stream, so its bias gradient runs there, beside
+                L.check(lib.spb_colsum(dc, _p(g), _p(lay.bias.grad), g.shape[0], cout, st), "spb_colsum")    # the weight gradient
             if name != "conv1" and (name + "D") in cp:
                 # implicit GEMM over (mirrored tap, output channel); conv5 -> conv4 -> conv3 feed each other directly, so the
                 # ReLU mask of the layer below goes into the store
