@@ -384,6 +384,10 @@ int spb_col2im(int dtype, const void* dcol, void* dx, int B, int H, int W, int C
 int spb_maxpool3s2_fwd(int dtype, const void* x, void* y, unsigned char* argmax, int B, int H, int W, int C, spb_stream_t stream);
 int spb_maxpool3s2_bwd(int dtype, const void* dy, const unsigned char* argmax, void* dx, int B, int H, int W, int C,
                        spb_stream_t stream);
+/* the same with the ReLU backward of the pooled tensor folded in: dx = maxpool_bwd(dy) * (y > 0), y = the ReLU output that was
+ * pooled ([B][H][W][C]; spn.py:61,66,70 pool right after a ReLU) */
+int spb_maxpool3s2_relu_bwd(int dtype, const void* dy, const unsigned char* argmax, const void* y, void* dx, int B, int H, int W, int C,
+                            spb_stream_t stream);
 /* nn.LocalResponseNorm(2, alpha, beta, k) over the channel axis of [npix, C] */
 int spb_lrn2_fwd(int dtype, const void* x, void* y, long long npix, int C, float alpha, float beta, float k, spb_stream_t stream);
 int spb_lrn2_bwd(int dtype, const void* x, const void* g, void* dx, long long npix, int C, float alpha, float beta, float k,

@@ -181,6 +181,7 @@ SYMBOLS = {
     "spb_col2im": (i32, [i32, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
     "spb_maxpool3s2_fwd": (i32, [i32, vp, vp, vp, i32, i32, i32, i32, vp]),
     "spb_maxpool3s2_bwd": (i32, [i32, vp, vp, vp, i32, i32, i32, i32, vp]),
+    "spb_maxpool3s2_relu_bwd": (i32, [i32, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     "spb_lrn2_fwd": (i32, [i32, vp, vp, i64, i32, f32, f32, f32, vp]),
     "spb_lrn2_bwd": (i32, [i32, vp, vp, vp, i64, i32, f32, f32, f32, vp]),
     "spb_relu_bwd": (i32, [i32, vp, vp, vp, vp, i64, f32, vp]),

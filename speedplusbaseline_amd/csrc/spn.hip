@@ -140,8 +140,8 @@ __global__ void maxpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, u
 }
 
 template <typename T>
-__global__ void maxpool_bwd_kernel(const T* __restrict__ dy, const unsigned char* __restrict__ arg, T* __restrict__ dx, int B, int H,
-                                   int W, int C, int OH, int OW) {
+__global__ void maxpool_bwd_kernel(const T* __restrict__ dy, const unsigned char* __restrict__ arg, const T* __restrict__ y,
+                                   T* __restrict__ dx, int B, int H, int W, int C, int OH, int OW) {
   const int CV = C >> 3;
   const long long total = (long long)B * H * W * CV;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
@@ -166,6 +166,12 @@ __global__ void maxpool_bwd_kernel(const T* __restrict__ dy, const unsigned char
         for (int j = 0; j < 8; ++j)
           if (arg[o + j] == ky * 3 + kx) acc[j] += g[j];
       }
+    }
+    if (y) {        // the pooled tensor was a ReLU output: its backward in the same pass (relu_bwd: g * (y > 0))
+      float yv[8];
+      ld8<T>(y + i * 8, yv);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] = yv[j] > 0.f ? acc[j] : 0.f;
     }
     st8<T>(dx + i * 8, acc);
   }
@@ -416,8 +422,20 @@ extern "C" int spb_maxpool3s2_bwd(int dtype, const void* dy, const unsigned char
   const int OH = (H - 3) / 2 + 1, OW = (W - 3) / 2 + 1;
   const long long total = (long long)B * H * W * (C >> 3);
   hipStream_t s = (hipStream_t)stream;
-  SPN_T(dtype, hipLaunchKernelGGL(maxpool_bwd_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, s, (const bf16_t*)dy, argmax, (bf16_t*)dx, B, H, W, C, OH, OW),
-        hipLaunchKernelGGL(maxpool_bwd_kernel<float>, dim3(grid_for(total)), dim3(256), 0, s, (const float*)dy, argmax, (float*)dx, B, H, W, C, OH, OW))
+  SPN_T(dtype, hipLaunchKernelGGL(maxpool_bwd_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, s, (const bf16_t*)dy, argmax, (const bf16_t*)nullptr, (bf16_t*)dx, B, H, W, C, OH, OW),
+        hipLaunchKernelGGL(maxpool_bwd_kernel<float>, dim3(grid_for(total)), dim3(256), 0, s, (const float*)dy, argmax, (const float*)nullptr, (float*)dx, B, H, W, C, OH, OW))
+  SPB_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int spb_maxpool3s2_relu_bwd(int dtype, const void* dy, const unsigned char* argmax, const void* y, void* dx, int B, int H, int W,
+                                       int C, spb_stream_t stream) {
+  if (!dy || !argmax || !y || !dx || B <= 0 || (C & 7)) return SPB_E_ARG;
+  const int OH = (H - 3) / 2 + 1, OW = (W - 3) / 2 + 1;
+  const long long total = (long long)B * H * W * (C >> 3);
+  hipStream_t s = (hipStream_t)stream;
+  SPN_T(dtype, hipLaunchKernelGGL(maxpool_bwd_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, s, (const bf16_t*)dy, argmax, (const bf16_t*)y, (bf16_t*)dx, B, H, W, C, OH, OW),
+        hipLaunchKernelGGL(maxpool_bwd_kernel<float>, dim3(grid_for(total)), dim3(256), 0, s, (const float*)dy, argmax, (const float*)y, (float*)dx, B, H, W, C, OH, OW))
   SPB_CHECK_LAUNCH();
   return 0;
 }

@@ -672,11 +672,11 @@ class SpacecraftPoseNet(nn.Module):
                 L.check(lib.spb_lrn2_bwd(dc, _p(xin), _p(g_act), _p(t), xin.shape[0] * xin.shape[1] * xin.shape[2], xin.shape[3],
                                          LRN_ALPHA, LRN_BETA, LRN_K, st), "spb_lrn2_bwd")
                 g_act = t
-            if "pool" + name in sv:
+            if "pool" + name in sv:         # pool right after this layer's ReLU: both backward passes in one kernel
                 _, arg, PHin, PWin = sv["pool" + name]
                 t = self._buf("dp" + name, (B, PHin, PWin, cout), dt)
-                L.check(lib.spb_maxpool3s2_bwd(dc, _p(g_act), _p(arg), _p(t), B, PHin, PWin, cout, st), "spb_maxpool3s2_bwd")
-                g_act = t
+                L.check(lib.spb_maxpool3s2_relu_bwd(dc, _p(g_act), _p(arg), _p(y), _p(t), B, PHin, PWin, cout, st), "spb_maxpool3s2_relu_bwd")
+                g_act, masked = t, True
             if masked:          # the input-gradient kernel of the layer above already applied this layer's ReLU mask
                 g = g_act.view(B * OH * OW, cout)
             else:
