@@ -528,7 +528,7 @@ def bench_spn(args):
     x, yc, yw = x.to(dev), yc.to(dev), yw.to(dev)
 
     def one():
-        out = net.loss_and_grads(x, yc, yw, world_size=world, group=group, compress_bf16=os.environ.get("SPB_SPN_BF16_GRADS") == "1",
+        out = net.loss_and_grads(x, yc, yw, world_size=world, group=group, compress_bf16={"1": True, "0": False}.get(os.environ.get("SPB_SPN_BF16_GRADS")),   # default: the library's (on in bf16)
                                  optimizer=None if os.environ.get("SPB_SPN_EARLY_UPDATE") == "0" else opt)
         opt.step(world_size=world, group=group)
         return out
