@@ -18,6 +18,8 @@ import os
 import sys
 import time
 
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")   # before the HIP runtime starts: one hardware queue per stream (see the package's __init__)
+
 import numpy as np
 import torch
 
