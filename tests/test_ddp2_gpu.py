@@ -46,7 +46,10 @@ def test_spn_two_ranks_replicas_identical_and_gradient_is_the_sum(device):
         assert r[mode]["replica_diff"] == 0.0, (mode, r[mode])
         assert r[mode]["moved"] > 0
         assert r[mode]["grad_rel_conv"] < 0.05, (mode, r[mode])
-    assert r["plain"]["grad_rel_fc"] < 1e-3 and r["overlap_f32"]["grad_rel_fc"] < 1e-3 and r["overlap_early"]["grad_rel_fc"] < 1e-3
+    # run-to-run noise of the fc gradients themselves (split-K float atomics in the forward / input-gradient kernels change bf16
+    # roundings downstream): 1e-9 .. 4e-4 relative over a dozen runs
+    assert r["plain"]["grad_rel_fc"] < 5e-3 and r["overlap_f32"]["grad_rel_fc"] < 5e-3 and r["overlap_early"]["grad_rel_fc"] < 5e-3
     # the heads' buckets updated on the communication stream as they arrive: the same parameters as updating after backward
-    assert r["overlap_early"]["diff_fc"] < 1e-4 and r["overlap_early"]["diff_conv"] < 0.02, r["overlap_early"]
-    assert r["overlap"]["grad_rel_fc"] < 1e-2          # bfloat16 on the wire (2^-9 per element), default in bf16 mode
+    # (lr 0.05 x gradient noise: 1.5e-5 .. 3e-4 observed; a wrong or missing update would show as 0.05 = lr x clip)
+    assert r["overlap_early"]["diff_fc"] < 2e-3 and r["overlap_early"]["diff_conv"] < 0.02, r["overlap_early"]
+    assert r["overlap"]["grad_rel_fc"] < 2e-2          # bfloat16 on the wire (2^-9 per element), default in bf16 mode
