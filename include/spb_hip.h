@@ -352,6 +352,12 @@ typedef struct {
 /* KxK conv (K = 3 | 9), nn.ReflectionPad2d(K/2), stride 1|2, optional nearest x2 upsampling of the input
  * (torch.nn.Upsample(scale_factor=2)); Hout = Hin*upsample/stride must be a multiple of 8.  bf16 only. */
 int spb_gconv(int dtype, const spb_gconv_args_t* args, spb_stream_t stream);
+/* UpsampleConvInRelu's Upsample(2, nearest) + ReflectionPad2d(1) + Conv2d 3x3 (ghiasi.py:46-59) as four 2x2 convolutions on the
+ * LOW-RESOLUTION input, one per output phase (upsample == 2, stride == 1, KH == 3): args->W holds the phase weights
+ * [4 = py*2+px][Cout][4 = ty*2+tx][Cin] bf16 with (w0, w1+w2) / (w0+w1, w2) summed along each axis; index clamping on the
+ * low-resolution image equals the reflection padding of the upsampled one.  Same result as spb_gconv up to one bf16 rounding
+ * of the summed weights, 2.25x fewer matrix-core steps. */
+int spb_gconv_up2(int dtype, const spb_gconv_args_t* args, spb_stream_t stream);
 /* first layer: Conv2d(3,32,9) with reflection padding on the fp32 NCHW image -> NHWC bf16 [B,H,W,32] + stats; W % 16 == 0 */
 int spb_conv9_rgb(const float* x, const float* w_oihw, const float* bias, void* y, float* stats, int B, int H, int W,
                   spb_stream_t stream);

@@ -362,6 +362,257 @@ __global__ __launch_bounds__(256) void gconv_kernel(const spb_gconv_args_t g, in
   }
 }
 
+// ------------------------------------------------------------------- nearest x2 upsampling + 3x3 convolution, by phase
+// UpsampleConvInRelu (ghiasi.py:46-59): Upsample(scale 2, nearest) -> ReflectionPad2d(1) -> Conv2d 3x3.  Output pixel
+// (2i + py, 2j + px) sees only a 2x2 block of LOW-RESOLUTION pixels: along an axis the taps (o-1, o, o+1) of o = 2i + p land on
+// rows (i-1, i, i) for p = 0 and (i, i, i+1) for p = 1, so the 3x3 kernel collapses to a 2x2 one per output phase with summed
+// weights (w0, w1+w2) / (w0+w1, w2) -- and the reflection of the upsampled image at its border (-1 -> 1, i.e. low-res row 0)
+// is exactly CLAMPING the low-resolution index.  9 taps become 4 (2.25x fewer matrix-core steps), the halo of an 8x8 output tile
+// is 6x6 low-resolution pixels instead of 10x10 upsampled ones, and no pixel is staged twice.  A wave owns one phase: its 16
+// pixels are the 4x4 low-resolution positions of the tile, its A operand that phase's weights (packed by the host side:
+// [phase][Cout][tap 2x2][Cin], sums taken in float32).
+template <int NB, bool WLDS, int PXG>
+__global__ __launch_bounds__(256) void gconv_up2_kernel(const spb_gconv_args_t g, int tpw) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int PD = 2, HT = 6, KT = 4, SU = 4;
+  const int Cin = g.Cin, Cout = g.Cout;
+  const int Hout = 2 * g.Hin, Wout = 2 * g.Win;
+  const int LDP = Cin + 8;
+  const int LDW = KT * Cin + 8;
+  float* cf = reinterpret_cast<float*>(smem);                 // [Cin][2]
+  float* red = cf + Cin * 2;                                  // [4 waves][NB*16][2]
+  bf16_t* halo = reinterpret_cast<bf16_t*>(red + 4 * NB * 16 * 2);   // [PXG][36][LDP]
+  bf16_t* wl = halo + PXG * HT * HT * LDP;                    // [4 phases][NB*16 slots][LDW] (WLDS)
+  const int t = threadIdx.x, lane = t & 63, li = lane & 15, lq = lane >> 4, wave = t >> 6;
+  const int tiles_x = Wout >> 3, tiles_y = Hout >> 3;
+  const int tpi = tiles_x * tiles_y;
+  const int gpi = (tpi + PXG - 1) / PXG;
+  const int wpi = gpi / tpw;
+  const int b = blockIdx.x / wpi;
+  const int grp0 = (blockIdx.x % wpi) * tpw;
+  const bf16_t* Wg = reinterpret_cast<const bf16_t*>(g.W);
+  const int ph = wave, py = wave >> 1, px = wave & 1;
+
+  for (int c = t; c < Cin; c += 256) {
+    float sc = 1.f, sh = 0.f;
+    if (g.coef) { sc = g.coef[((size_t)b * Cin + c) * 2]; sh = g.coef[((size_t)b * Cin + c) * 2 + 1]; }
+    cf[c] = sc; cf[Cin + c] = sh;
+  }
+  if (WLDS) {
+    const int RV = (KT * Cin) >> 3;
+    for (int i = t; i < 4 * Cout * RV; i += 256) {   // rows in fragment order [nb][li] per phase: conflict-free fragment reads
+      const int v = i % RV, r = (i / RV) % Cout, p = i / (RV * Cout);
+      const int slot = ((r % (4 * NB)) >> 2) * 16 + (r / (4 * NB)) * 4 + (r & 3);
+      *reinterpret_cast<uint4*>(wl + (size_t)(p * NB * 16 + slot) * LDW + v * 8) =
+          *reinterpret_cast<const uint4*>(Wg + ((size_t)(p * Cout + r) * KT) * Cin + v * 8);
+    }
+  }
+  const bf16_t* X = reinterpret_cast<const bf16_t*>(g.X);
+  bf16_t* Y = reinterpret_cast<bf16_t*>(g.Y);
+  const int CV = Cin >> 3;
+  const int iy = li >> 2, ix = li & 3;                        // this lane's low-resolution position in the 4x4 block
+  const bf16_t* hbase = halo + ((iy + py) * HT + (ix + px)) * LDP + lq * 8;
+  const int nch = Cin >> 5;
+  const int nsteps = KT * nch;
+  int wco[NB];
+  bool wok[NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) {
+    const int co = (li >> 2) * 4 * NB + nb * 4 + (li & 3);
+    wok[nb] = co < Cout;
+    wco[nb] = wok[nb] ? co : 0;
+  }
+  const int co0 = lq * 4 * NB;
+  float s1[NB][4], s2[NB][4];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { s1[nb][e] = 0.f; s2[nb][e] = 0.f; }
+
+  for (int ti = 0; ti < tpw; ++ti) {
+    int oy0[PXG], ox0[PXG];
+    bool tvalid[PXG];
+#pragma unroll
+    for (int p = 0; p < PXG; ++p) {
+      int tr = (grp0 + ti) * PXG + p;
+      tvalid[p] = tr < tpi;
+      tr = tvalid[p] ? tr : tpi - 1;
+      oy0[p] = (tr / tiles_x) * 8; ox0[p] = (tr % tiles_x) * 8;
+    }
+    __syncthreads();   // previous tile's taps are done with the halo (first pass: coefficient / weight tables written)
+    {                  // ---- low-resolution halo(s): 6x6 pixels per tile, index clamped, normalised + activated on the way in
+      const int per = HT * HT * CV, total = PXG * per;
+      for (int i0 = t; i0 < total; i0 += 256 * SU) {
+        Raw8<bf16_t> r[SU];
+        int dst[SU], cvs[SU];
+#pragma unroll
+        for (int u = 0; u < SU; ++u) {
+          const int i = i0 + 256 * u;
+          const int ic = i < total ? i : total - 1;
+          const int p = ic / per, ii = ic % per;
+          const int hp = ii / CV, cv = ii % CV;
+          const int hy = hp / HT, hx = hp % HT;
+          int oyp = oy0[0], oxp = ox0[0];
+#pragma unroll
+          for (int q = 1; q < PXG; ++q) { oyp = p == q ? oy0[q] : oyp; oxp = p == q ? ox0[q] : oxp; }
+          const int sy = min(max((oyp >> 1) - 1 + hy, 0), g.Hin - 1), sx = min(max((oxp >> 1) - 1 + hx, 0), g.Win - 1);
+          r[u] = ldraw<bf16_t>(X + ((size_t)(b * g.Hin + sy) * g.Win + sx) * Cin + cv * 8);
+          dst[u] = i < total ? (p * HT * HT + hp) * LDP + cv * 8 : -1;
+          cvs[u] = cv;
+        }
+#pragma unroll
+        for (int u = 0; u < SU; ++u) {
+          if (dst[u] < 0) continue;
+          float v[8], sc[8], sh[8];
+          cvt8(r[u], v);
+#pragma unroll
+          for (int j = 0; j < 8; j += 4) {
+            *reinterpret_cast<float4*>(sc + j) = *reinterpret_cast<const float4*>(cf + cvs[u] * 8 + j);
+            *reinterpret_cast<float4*>(sh + j) = *reinterpret_cast<const float4*>(cf + Cin + cvs[u] * 8 + j);
+          }
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const float uu = v[j] * sc[j] + sh[j];
+            v[j] = g.relu ? fmaxf(uu, 0.f) : uu;
+          }
+          st8<bf16_t>(halo + dst[u], v);
+        }
+      }
+    }
+    __syncthreads();
+    f32x4_t acc[PXG][NB];
+#pragma unroll
+    for (int p = 0; p < PXG; ++p)
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) acc[p][nb] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    if constexpr (WLDS) {
+      int ky = 0, kx = 0, cc = 0;
+      bf16x8_t bfc[PXG], bfn[PXG];
+      uint4 auc[NB], aun[NB];
+      const bf16_t* wph = wl + (size_t)ph * NB * 16 * LDW;
+      auto frag_load = [&](bf16x8_t* bfv, uint4* auv) {
+#pragma unroll
+        for (int p = 0; p < PXG; ++p)
+          bfv[p] = *reinterpret_cast<const bf16x8_t*>(hbase + (p * HT * HT + ky * HT + kx) * LDP + cc * 32);
+        const int ko = (ky * 2 + kx) * Cin + cc * 32 + lq * 8;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) auv[nb] = *reinterpret_cast<const uint4*>(wph + (wok[nb] ? nb * 16 + li : 0) * LDW + ko);
+        if (++cc == nch) { cc = 0; if (++kx == 2) { kx = 0; ++ky; } }
+      };
+      auto frag_mma = [&](const bf16x8_t* bfv, const uint4* auv) {
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+          const uint4 au = wok[nb] ? auv[nb] : make_uint4(0, 0, 0, 0);
+#pragma unroll
+          for (int p = 0; p < PXG; ++p)
+            acc[p][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, au), bfv[p], acc[p][nb], 0, 0, 0);
+        }
+      };
+      frag_load(bfc, auc);
+      int s = 0;
+      for (; s + 2 < nsteps; s += 2) {
+        frag_load(bfn, aun);
+        frag_mma(bfc, auc);
+        frag_load(bfc, auc);
+        frag_mma(bfn, aun);
+      }
+      if (s + 1 < nsteps) {
+        frag_load(bfn, aun);
+        frag_mma(bfc, auc);
+        frag_mma(bfn, aun);
+      } else if (s < nsteps) {
+        frag_mma(bfc, auc);
+      }
+    } else {
+      const bf16_t* wrow[NB];
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) wrow[nb] = Wg + ((size_t)(ph * Cout + wco[nb]) * KT) * Cin + lq * 8;
+      uint4 an[PD][NB];
+#pragma unroll
+      for (int d = 0; d < PD; ++d)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) an[d][nb] = *reinterpret_cast<const uint4*>(wrow[nb] + (size_t)(d < nsteps ? d : 0) * 32);
+      int ky = 0, kx = 0, cc = 0;
+      for (int s0 = 0; s0 < nsteps; s0 += PD) {
+#pragma unroll
+        for (int d = 0; d < PD; ++d) {
+          const int s = s0 + d;
+          if (s < nsteps) {
+            uint4 a[NB];
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) a[nb] = an[d][nb];
+            bf16x8_t bf[PXG];
+#pragma unroll
+            for (int p = 0; p < PXG; ++p)
+              bf[p] = *reinterpret_cast<const bf16x8_t*>(hbase + (p * HT * HT + ky * HT + kx) * LDP + cc * 32);
+            const int sn = s + PD;
+            if (sn < nsteps) {
+#pragma unroll
+              for (int nb = 0; nb < NB; ++nb) an[d][nb] = *reinterpret_cast<const uint4*>(wrow[nb] + (size_t)sn * 32);
+            }
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+              for (int p = 0; p < PXG; ++p)
+                acc[p][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a[nb]), bf[p], acc[p][nb], 0, 0, 0);
+            if (++cc == nch) { cc = 0; if (++kx == 2) { kx = 0; ++ky; } }
+          }
+        }
+      }
+    }
+    // ---- epilogue: lane (li = low-resolution position, lq): channels lq*4*NB + nb*4 + e of output pixel (2 iy + py, 2 ix + px)
+#pragma unroll
+    for (int p = 0; p < PXG; ++p) {
+      if (!tvalid[p]) continue;
+      const int oy = oy0[p] + 2 * iy + py, ox = ox0[p] + 2 * ix + px;
+      bf16_t* dst = Y + ((size_t)(b * Hout + oy) * Wout + ox) * g.ldc + co0;
+      uint2 o[NB];
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int co = co0 + nb * 4 + e;
+          v[e] = acc[p][nb][e] + ((g.bias && co < Cout) ? g.bias[co] : 0.f);
+        }
+        o[nb].x = pack_bf16x2(v[0], v[1]); o[nb].y = pack_bf16x2(v[2], v[3]);
+        const float r[4] = {__uint_as_float(o[nb].x << 16), __uint_as_float(o[nb].x & 0xffff0000u),
+                            __uint_as_float(o[nb].y << 16), __uint_as_float(o[nb].y & 0xffff0000u)};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { s1[nb][e] += r[e]; s2[nb][e] += r[e] * r[e]; }
+      }
+      if constexpr ((NB & 1) == 0) {
+#pragma unroll
+        for (int nb = 0; nb < NB; nb += 2)
+          if (co0 + nb * 4 < g.ldc) *reinterpret_cast<uint4*>(dst + nb * 4) = make_uint4(o[nb].x, o[nb].y, o[nb + 1].x, o[nb + 1].y);
+      } else {
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+          if (co0 + nb * 4 < g.ldc) *reinterpret_cast<uint2*>(dst + nb * 4) = o[nb];
+      }
+    }
+  }
+  if (g.stats) {
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float a1 = row16_sum(s1[nb][e]), a2 = row16_sum(s2[nb][e]);
+        if (li == 0) {
+          red[(wave * NB * 16 + co0 + nb * 4 + e) * 2] = a1;
+          red[(wave * NB * 16 + co0 + nb * 4 + e) * 2 + 1] = a2;
+        }
+      }
+    __syncthreads();
+    for (int i = t; i < NB * 16 * 2; i += 256) {
+      const int co = i >> 1;
+      if (co < Cout)
+        atomicAdd(g.stats + ((size_t)b * Cout + co) * 2 + (i & 1),
+                  red[i] + red[NB * 32 + i] + red[2 * NB * 32 + i] + red[3 * NB * 32 + i]);
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------ implicit-GEMM conv, wide layers
 // The 128-channel layers (weights 147..295 KB: not LDS resident).  Each wave computes FOUR 8x8 tiles' worth of its two
 // rows (64 pixels x all output channels): every weight fragment read feeds 4 MFMAs and every pixel fragment NB of them,
@@ -918,6 +1169,45 @@ extern "C" int spb_gconv(int dtype, const spb_gconv_args_t* a, spb_stream_t stre
   else G_(8, false, 2)
 #undef G_
 #undef G2_
+  SPB_CHECK_LAUNCH();
+  return 0;
+}
+
+// a->W: phase weights [4][Cout][4][Cin] (Ghiasi._pack builds them); a->upsample must be 2, a->stride 1, a->KH 3
+extern "C" int spb_gconv_up2(int dtype, const spb_gconv_args_t* a, spb_stream_t stream) {
+  if (!a || !a->X || !a->W || !a->Y) return SPB_E_ARG;
+  if (dtype != SPB_BF16) return SPB_E_UNSUPPORTED;
+  if (a->B <= 0 || (a->Cin & 31) || a->Cout <= 0 || a->Cout > 128 || a->KH != 3 || a->stride != 1 || a->upsample != 2) return SPB_E_SHAPE;
+  const int Hout = 2 * a->Hin, Wout = 2 * a->Win;
+  if ((Hout & 7) || (Wout & 7) || a->ldc < a->Cout || (a->ldc & 3)) return SPB_E_SHAPE;
+  const int NB = a->Cout <= 16 ? 1 : (a->Cout <= 32 ? 2 : (a->Cout <= 64 ? 4 : 8));
+  const size_t wbytes = (size_t)4 * NB * 16 * (4 * a->Cin + 8) * 2;
+  const bool wlds = wbytes <= 72 * 1024;
+  if (!wlds && a->Cout != NB * 16) return SPB_E_SHAPE;
+  if (NB != 2 && NB != 4) return SPB_E_UNSUPPORTED;
+  const int pxg = wlds ? 2 : 4;
+  const size_t lds = (size_t)a->Cin * 2 * sizeof(float) + (size_t)4 * NB * 16 * 2 * sizeof(float) +
+                     (size_t)pxg * 36 * (a->Cin + 8) * 2 + (wlds ? wbytes : 0);
+  const int tpi = (Hout >> 3) * (Wout >> 3);
+  const int gpi = (tpi + pxg - 1) / pxg;
+  int tpw = 1;
+  for (int d = 1; d <= gpi; ++d)
+    if (gpi % d == 0 && (long long)a->B * (gpi / d) >= 1024) tpw = d;
+  const dim3 grid((unsigned)(a->B * (gpi / tpw)));
+  hipStream_t s = (hipStream_t)stream;
+#define U_(NB_, WL_, PX_)                                                                                            \
+  {                                                                                                                  \
+    static bool once = false;                                                                                        \
+    if (!once) {                                                                                                     \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gconv_up2_kernel<NB_, WL_, PX_>),                     \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                             \
+      once = true;                                                                                                   \
+    }                                                                                                                \
+    hipLaunchKernelGGL((gconv_up2_kernel<NB_, WL_, PX_>), grid, dim3(256), lds, s, *a, tpw);                         \
+  }
+  if (NB == 2) { if (wlds) U_(2, true, 2) else U_(2, false, 4) }
+  else { if (wlds) U_(4, true, 2) else U_(4, false, 4) }
+#undef U_
   SPB_CHECK_LAUNCH();
   return 0;
 }

@@ -27,6 +27,27 @@ def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+_UP2_BY_PHASE = os.environ.get("SPB_GCONV_UP2", "1") != "0"
+
+
+def _phase_weights(w):
+    """[Cout, Cin, 3, 3] float32 -> [4 = py*2+px][Cout][4 = ty*2+tx][Cin] bf16: the 2x2 kernels that nearest x2 upsampling +
+    ReflectionPad2d(1) + this 3x3 convolution amount to on the low-resolution input (csrc/ghiasi.hip gconv_up2_kernel): along an
+    axis, output phase 0 sees taps (w0, w1 + w2) of rows (i-1, i), phase 1 sees (w0 + w1, w2) of rows (i, i+1)"""
+    def split(t, dim, p):        # t indexed by a 3-tap axis `dim` -> the two summed taps of phase p
+        a, b, c = t.unbind(dim)
+        return (a, b + c) if p == 0 else (a + b, c)
+    out = []
+    for py in (0, 1):
+        rows = split(w, 2, py)                         # each [Cout, Cin, 3 (kx)]
+        for px in (0, 1):
+            taps = []
+            for r in rows:
+                taps += list(split(r, 2, px))          # (ty, tx) order, each [Cout, Cin]
+            out.append(torch.stack(taps, dim=1))       # [Cout, 4, Cin]
+    return torch.stack(out).to(torch.bfloat16).contiguous()
+
+
 class _Conv(nn.Module):
     """parameter container with nn.Conv2d's state-dict names"""
 
@@ -103,6 +124,8 @@ class Ghiasi(nn.Module):
                     else:
                         w = c.weight.detach().permute(0, 2, 3, 1).contiguous().to(torch.bfloat16)
                         convs[(i, name)] = (w, c.bias.detach().float().contiguous())
+                        if isinstance(layer, _UpsampleConvInRelu) and tuple(c.weight.shape[2:]) == (3, 3):
+                            convs[(i, name, "up2")] = _phase_weights(c.weight.detach().float())
             for name in ("fc_beta", "fc_gamma", "fc_beta1", "fc_gamma1", "fc_beta2", "fc_gamma2"):
                 if hasattr(layer, name):
                     fc = getattr(layer, name)
@@ -170,7 +193,12 @@ class Ghiasi(nn.Module):
             a.X = _p(X); a.W = _p(w); a.bias = _p(bias); a.coef = _p(cf); a.Y = _p(Y); a.stats = _p(stats[si[0]])
             a.B = B; a.Hin = Hin; a.Win = Win; a.Cin = Cin; a.Cout = Cout; a.KH = k; a.stride = stride; a.upsample = up
             a.relu = relu; a.ldc = ldc
-            L.check(lib.spb_gconv(L.BF16, C.byref(a), st), "spb_gconv")
+            wp = pk["convs"].get(key + ("up2",)) if (up == 2 and k == 3 and stride == 1 and _UP2_BY_PHASE) else None
+            if wp is not None:        # Upsample(2) + ReflectionPad(1) + 3x3 as four 2x2 phase convolutions on the low-res input
+                a.W = _p(wp)
+                L.check(lib.spb_gconv_up2(L.BF16, C.byref(a), st), "spb_gconv_up2")
+            else:
+                L.check(lib.spb_gconv(L.BF16, C.byref(a), st), "spb_gconv")
             self._mark("gconv %dx%d %d->%d s%d u%d @%d" % (k, k, Cin, Cout, stride, up, Hout))
             return Y, Hout, Wout
 

@@ -63,6 +63,42 @@ def test_gconv_against_torch(device, cin, cout, k, stride, up, hw):
     assert float((s[..., 1] - (got * got).sum((2, 3))).abs().max() / (got * got).sum((2, 3)).abs().max()) < 1e-3
 
 
+@pytest.mark.parametrize("cin,cout,hw", [(128, 64, 8), (64, 32, 16), (128, 64, 56), (64, 32, 28)])
+def test_upsample_conv_by_phase_against_torch(device, cin, cout, hw):
+    """spb_gconv_up2: Upsample(2, nearest) + ReflectionPad2d(1) + Conv2d 3x3 as four 2x2 phase convolutions on the low-resolution
+    input (summed weights, clamped index) against torch on the upsampled, reflection-padded tensor; tiles at every border, odd
+    numbers of tile groups, both weight paths (LDS-resident for 64->32, streamed for 128->64)"""
+    import ctypes as C
+    from speedplusbaseline_amd.styleaug import _phase_weights
+    torch.manual_seed(cin + hw)
+    B = 3
+    x = _bf(torch.randn(B, cin, hw, hw))
+    w = _bf(torch.randn(cout, cin, 3, 3) / (cin * 9) ** 0.5)
+    bias = torch.randn(cout) * 0.1
+    coef = torch.stack([torch.rand(B, cin) + 0.5, torch.randn(B, cin) * 0.3], dim=2).contiguous()
+    a = _bf(F.relu(x * coef[:, :, 0, None, None] + coef[:, :, 1, None, None]))
+    ref = F.conv2d(F.pad(F.interpolate(a, scale_factor=2, mode="nearest").double(), (1, 1, 1, 1), mode="reflect"), w.double(), bias.double())
+    Hout = 2 * hw
+    Y = torch.zeros(B, Hout, Hout, cout, dtype=torch.bfloat16, device=device)
+    stats = torch.zeros(B, cout, 2, dtype=torch.float32, device=device)
+    g = L.GconvArgs()
+    xd = x.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).to(device)
+    wd = _phase_weights(w.float()).to(device)
+    assert tuple(wd.shape) == (4, cout, 4, cin)
+    bd, cd = bias.to(device), coef.to(device)
+    p = lambda t: C.c_void_p(t.data_ptr())
+    g.X = p(xd); g.W = p(wd); g.bias = p(bd); g.coef = p(cd); g.Y = p(Y); g.stats = p(stats)
+    g.B = B; g.Hin = hw; g.Win = hw; g.Cin = cin; g.Cout = cout; g.KH = 3; g.stride = 1; g.upsample = 2; g.relu = 1; g.ldc = cout
+    L.check(L.lib().spb_gconv_up2(L.BF16, C.byref(g), C.c_void_p(torch.cuda.current_stream().cuda_stream)), "spb_gconv_up2")
+    torch.cuda.synchronize()
+    got = Y.float().cpu().permute(0, 3, 1, 2).double()
+    err = float((got - ref).abs().max() / ref.abs().max())
+    assert err < 1.5e-2, err                     # bf16 storage of the result and of the summed weights
+    s = stats.double().cpu()
+    assert float((s[..., 0] - got.sum((2, 3))).abs().max() / got.sum((2, 3)).abs().max()) < 1e-3
+    assert float((s[..., 1] - (got * got).sum((2, 3))).abs().max() / (got * got).sum((2, 3)).abs().max()) < 1e-3
+
+
 @pytest.mark.parametrize("B,hw", [(2, 64), (1, 96), (1, 224)])
 def test_decoder_forward_matches_oracle(device, B, hw):
     sd = G.init_state()

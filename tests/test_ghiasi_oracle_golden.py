@@ -70,3 +70,24 @@ def test_embedding_sampler_algebra():
     assert rel(G.restyle_embedding(z, A, mean, base, 0.5).numpy(), GOLD["emb_restyle"]) < 1e-5
     # A A^T reproduces the covariance
     assert rel((A.double() @ A.double().t()).numpy(), GOLD["emb_cov"]) < 1e-5
+
+
+def test_upsample_conv_phase_weights_identity():
+    """nearest x2 upsampling + ReflectionPad2d(1) + 3x3 convolution == four 2x2 convolutions on the replicate-padded low-resolution
+    input with the summed weights of styleaug._phase_weights (what csrc/ghiasi.hip gconv_up2_kernel computes)"""
+    import torch
+    import torch.nn.functional as F
+    from speedplusbaseline_amd.styleaug import _phase_weights
+    torch.manual_seed(3)
+    w = torch.randn(6, 8, 3, 3)
+    x = torch.randn(2, 8, 5, 7, dtype=torch.float64)
+    wp = _phase_weights(w)
+    assert tuple(wp.shape) == (4, 6, 4, 8) and wp.dtype == torch.bfloat16
+    ref = F.conv2d(F.pad(F.interpolate(x, scale_factor=2, mode="nearest"), (1, 1, 1, 1), mode="reflect"), w.double())
+    xp = F.pad(x, (1, 1, 1, 1), mode="replicate")
+    out = torch.zeros_like(ref)
+    for py in (0, 1):
+        for px in (0, 1):
+            k = wp[py * 2 + px].double().permute(0, 2, 1).reshape(6, 8, 2, 2)      # [Cout][tap][Cin] -> [Cout][Cin][ty][tx]
+            out[:, :, py::2, px::2] = F.conv2d(xp[:, :, py:py + 6, px:px + 8], k)
+    assert float((out - ref).abs().max() / ref.abs().max()) < 2e-2          # one bf16 rounding of the summed weights
