@@ -627,6 +627,9 @@ __global__ __launch_bounds__(256) void gconv_up2_kernel(const spb_gconv_args_t g
 // at 56x56, B=48, PXG=2: 151 us) puts 73 us on this stream and 7 us on the matrix cores: with 3 slabs (24 KB) in flight per
 // workgroup the L2 round trip (~1.5 us under load) bounds the stream at ~16 GB/s per workgroup, and every workgroup needs the
 // whole 295 KB weight tensor.
+#ifndef SLAB_SU
+#define SLAB_SU 5      // halo vectors a thread has in flight per round trip
+#endif
 template <int NB, int PXG, int PF>
 __global__ __launch_bounds__(256, PXG >= 4 ? 1 : 2) void gconv_slab_kernel(const spb_gconv_args_t g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -702,7 +705,7 @@ __global__ __launch_bounds__(256, PXG >= 4 ? 1 : 2) void gconv_slab_kernel(const
       sreg[d * SPT + j] = *reinterpret_cast<const u32x4_t*>(Wg + SLAB_OFF(srow[j], d, spart[j]));
   __syncthreads();
   // ---- stage the four input halos
-  if (!(GABL & 2)) stage_halo<PXG, 5>(g, X, halo, cf, b, oy0, ox0, HT, LDP, Hu, Wu, st, up, pad, t);
+  if (!(GABL & 2)) stage_halo<PXG, SLAB_SU>(g, X, halo, cf, b, oy0, ox0, HT, LDP, Hu, Wu, st, up, pad, t);
 #pragma unroll
   for (int j = 0; j < SPT; ++j) *reinterpret_cast<u32x4_t*>(slab + sslot[j]) = sreg[j];
   __syncthreads();
@@ -915,6 +918,138 @@ __global__ __launch_bounds__(256) void conv9_band_kernel(const spb_gconv_args_t 
   }
 }
 
+// The same layer with the kernel COLUMN folded into the matrix rows: A rows are the 27 (kx, co) pairs (two 16-row fragments, 84 %
+// real instead of 3 of 16), the reduction runs over (ky, channel) only, and the matrix cores produce per input column x'
+//   P[(kx, co)][x'] = sum_{ky, c} w[co][ky][kx][c] * a[y + ky][x'][c];          y[x][co] = sum_kx P[(kx, co)][x + kx]
+// -- 18 MFMAs per 16 input columns and output row instead of 81 per 16 output pixels (3.9x fewer per pixel); the shifted sum
+// over kx (27 LDS reads per pixel) runs on the vector units from an LDS copy of P that reuses the halo.  Band: 8 rows x 56
+// output columns = 64 input columns (4 column groups), C9K_W | W.
+#ifndef C9K_ROWS
+#define C9K_ROWS 4     // 4: 80 KB of LDS, two workgroups per CU (188 us at 224x224, B=48); 8: one per CU (206 us)
+#endif
+constexpr int C9K_R = C9K_ROWS, C9K_W = 56, C9K_RW = C9K_ROWS / 4;   // rows per wave
+__global__ __launch_bounds__(256) void conv9_kxrows_kernel(const spb_gconv_args_t g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int HW_ = C9K_W + 8, HR = C9K_R + 8, LDP = 40, LDWK = 32;   // weight rows unpadded: a fragment read is 1 KB contiguous
+  float* cf = reinterpret_cast<float*>(smem);                      // [32][2] scale | shift
+  float* red = cf + 64;                                            // [4 waves][4 ch][2]
+  bf16_t* halo = reinterpret_cast<bf16_t*>(red + 32);              // [HR][HW_][LDP]; after the reduction loop: P, float [8][32][64]
+  bf16_t* wl = halo + HR * HW_ * LDP;                              // [9 ky][32 rows = kx*3 + co][LDWK]
+  const int t = threadIdx.x, lane = t & 63, li = lane & 15, lq = lane >> 4, wave = t >> 6;
+  const int H = g.Hin, W = g.Win, Cout = g.Cout;
+  const int bx = W / C9K_W;
+  const int b = blockIdx.y, y0 = (blockIdx.x / bx) * C9K_R, x0 = (blockIdx.x % bx) * C9K_W;
+  const bf16_t* X = reinterpret_cast<const bf16_t*>(g.X);
+  const bf16_t* Wg = reinterpret_cast<const bf16_t*>(g.W);       // [Cout][9][9][32]
+  bf16_t* Y = reinterpret_cast<bf16_t*>(g.Y);
+  if (t < 32) {
+    float sc = 1.f, sh = 0.f;
+    if (g.coef) { sc = g.coef[((size_t)b * 32 + t) * 2]; sh = g.coef[((size_t)b * 32 + t) * 2 + 1]; }
+    cf[t] = sc; cf[32 + t] = sh;
+  }
+  for (int i = t; i < 9 * 32 * 4; i += 256) {                      // 16-byte granules of [ky][row][32 channels]
+    const int v = i & 3, r = (i >> 2) & 31, ky = i >> 7;
+    const int kx = r / 3, co = r - kx * 3;
+    uint4 u = make_uint4(0, 0, 0, 0);
+    if (r < 27 && co < Cout) u = *reinterpret_cast<const uint4*>(Wg + ((size_t)(co * 9 + ky) * 9 + kx) * 32 + v * 8);
+    *reinterpret_cast<uint4*>(wl + (ky * 32 + r) * LDWK + v * 8) = u;
+  }
+  __syncthreads();
+  constexpr int total = HR * HW_ * 4;
+  constexpr int SUK = (total + 255) / 256 <= 12 ? (total + 255) / 256 : 6;   // all of a thread's halo loads in ONE round trip when they fit
+  for (int i0 = t; i0 < total; i0 += 256 * SUK) {
+    Raw8<bf16_t> r[SUK];
+    int dst[SUK], cvs[SUK];
+#pragma unroll
+    for (int u = 0; u < SUK; ++u) {
+      const int i = i0 + 256 * u, ic = i < total ? i : total - 1;
+      const int cv = ic & 3, hp = ic >> 2, hy = hp / HW_, hx = hp % HW_;
+      const int sy = reflecti(y0 - 4 + hy, H), sx = reflecti(x0 - 4 + hx, W);
+      r[u] = ldraw<bf16_t>(X + ((size_t)(b * H + sy) * W + sx) * 32 + cv * 8);
+      dst[u] = i < total ? hp * LDP + cv * 8 : -1;
+      cvs[u] = cv;
+    }
+#pragma unroll
+    for (int u = 0; u < SUK; ++u) {
+      if (dst[u] < 0) continue;
+      float v[8];
+      cvt8(r[u], v);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float uu = v[j] * cf[cvs[u] * 8 + j] + cf[32 + cvs[u] * 8 + j];
+        v[j] = g.relu ? fmaxf(uu, 0.f) : uu;
+      }
+      st8<bf16_t>(halo + dst[u], v);
+    }
+  }
+  __syncthreads();
+  // wave w: output rows w*C9K_RW ..; per row four 16-column groups of INPUT columns x two row fragments
+  f32x4_t acc[C9K_RW][4][2];
+#pragma unroll
+  for (int r = 0; r < C9K_RW; ++r)
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int f = 0; f < 2; ++f) acc[r][q][f] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  const bf16_t* hb = halo + ((wave * C9K_RW) * HW_ + li) * LDP + lq * 8;
+  const bf16_t* wb = wl + li * LDWK + lq * 8;
+  for (int ky = 0; ky < 9; ++ky) {
+    const bf16x8_t a0 = *reinterpret_cast<const bf16x8_t*>(wb + (ky * 32) * LDWK);
+    const bf16x8_t a1 = *reinterpret_cast<const bf16x8_t*>(wb + (ky * 32 + 16) * LDWK);
+#pragma unroll
+    for (int r = 0; r < C9K_RW; ++r)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const bf16x8_t bf = *reinterpret_cast<const bf16x8_t*>(hb + ((r + ky) * HW_ + q * 16) * LDP);
+        acc[r][q][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, bf, acc[r][q][0], 0, 0, 0);
+        acc[r][q][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, bf, acc[r][q][1], 0, 0, 0);
+      }
+  }
+  __syncthreads();                                                 // everyone is done with the halo: it becomes P
+  float* P = reinterpret_cast<float*>(halo);                       // [8 rows][32 (kx, co)][64 input columns]
+#pragma unroll
+  for (int r = 0; r < C9K_RW; ++r)
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int f = 0; f < 2; ++f)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) P[((wave * C9K_RW + r) * 32 + f * 16 + lq * 4 + e) * 64 + q * 16 + li] = acc[r][q][f][e];
+  __syncthreads();
+  // lane = output column (56 of 64 lanes), every row of this wave: y[x][co] = sum_kx P[(kx, co)][x + kx]
+  float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+  if (lane < C9K_W) {
+#pragma unroll
+    for (int r = 0; r < C9K_RW; ++r) {
+      const float* Pr = P + (size_t)(wave * C9K_RW + r) * 32 * 64 + lane;
+      float v[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kx = 0; kx < 9; ++kx)
+#pragma unroll
+        for (int co = 0; co < 3; ++co) v[co] += Pr[(kx * 3 + co) * 64 + kx];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = (e < Cout ? v[e] : 0.f) + ((g.bias && e < Cout) ? g.bias[e] : 0.f);
+      uint2 o;
+      o.x = pack_bf16x2(v[0], v[1]); o.y = pack_bf16x2(v[2], v[3]);
+      *reinterpret_cast<uint2*>(Y + ((size_t)(b * H + y0 + wave * C9K_RW + r) * W + x0 + lane) * g.ldc) = o;
+      const float rr[4] = {__uint_as_float(o.x << 16), __uint_as_float(o.x & 0xffff0000u), __uint_as_float(o.y << 16),
+                           __uint_as_float(o.y & 0xffff0000u)};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { s1[e] += rr[e]; s2[e] += rr[e] * rr[e]; }
+    }
+  }
+  if (g.stats) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float a1 = wave_sum(s1[e]), a2 = wave_sum(s2[e]);
+      if (lane == 0) { red[(wave * 4 + e) * 2] = a1; red[(wave * 4 + e) * 2 + 1] = a2; }
+    }
+    __syncthreads();
+    if (t < Cout * 2)
+      atomicAdd(g.stats + (size_t)b * Cout * 2 + t, red[t] + red[8 + t] + red[16 + t] + red[24 + t]);
+  }
+}
+
 // ------------------------------------------------------------------------------------------- first layer: 3 -> 32, 9x9
 // x fp32 NCHW [B,3,H,W]; w fp32 [32][3][9][9] (PyTorch layout); y bf16 NHWC [B,H,W,32] raw conv (+bias); stats [B][32][2].
 // A workgroup owns a band of C9_R output rows of one image (blockIdx.y): the C9_R+8 input rows it needs are staged ONCE in LDS
@@ -1082,7 +1217,7 @@ extern "C" int spb_debug_set_gconv_halo_prefetch(int on) { g_halo_prefetch = on;
 static int g_wlds_pxg = 1;
 extern "C" int spb_debug_set_gconv_wlds_pxg(int n) { g_wlds_pxg = n; return 0; }
 
-static int g_conv9_band = 1;
+static int g_conv9_band = 2;   // 9x9 32->3: 0 generic tile kernel, 1 band kernel, 2 kernel columns folded into the matrix rows
 extern "C" int spb_debug_set_conv9_band(int on) { g_conv9_band = on; return 0; }
 
 extern "C" int spb_gconv(int dtype, const spb_gconv_args_t* a, spb_stream_t stream) {
@@ -1095,6 +1230,16 @@ extern "C" int spb_gconv(int dtype, const spb_gconv_args_t* a, spb_stream_t stre
   const int Hout = Hu / a->stride, Wout = Wu / a->stride;
   if ((Hout & 7) || (Wout & 7) || a->ldc < a->Cout || (a->ldc & 3)) return SPB_E_SHAPE;
   if (a->KH / 2 >= Hu || a->KH / 2 >= Wu) return SPB_E_SHAPE;   // reflection padding needs pad < size
+  if (g_conv9_band == 2 && a->KH == 9 && a->Cin == 32 && a->Cout <= 3 && a->stride == 1 && a->upsample == 1 && !(Wout % C9K_W) &&
+      !(Hout % C9K_R) && a->ldc >= 4) {
+    const size_t halo_b = (size_t)(C9K_R + 8) * (C9K_W + 8) * 40 * sizeof(bf16_t), p_b = (size_t)C9K_R * 32 * 64 * sizeof(float);
+    const size_t ldsk = (64 + 32) * sizeof(float) + (halo_b > p_b ? halo_b : p_b) + (size_t)9 * 32 * 32 * sizeof(bf16_t);
+    static bool oncek = false;
+    if (!oncek) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv9_kxrows_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); oncek = true; }
+    hipLaunchKernelGGL(conv9_kxrows_kernel, dim3((unsigned)((Hout / C9K_R) * (Wout / C9K_W)), (unsigned)a->B), dim3(256), ldsk, (hipStream_t)stream, *a);
+    SPB_CHECK_LAUNCH();
+    return 0;
+  }
   if (g_conv9_band && a->KH == 9 && a->Cin == 32 && a->Cout <= 4 && a->stride == 1 && a->upsample == 1 && !(Wout % C9O_W) &&
       !(Hout % C9O_R) && a->ldc >= 4) {
     const size_t ldsb = (64 + 32) * sizeof(float) + ((size_t)(C9O_R + 8) * (C9O_W + 8) * 40 + (size_t)4 * (81 * 32 + 8)) * sizeof(bf16_t);

@@ -28,7 +28,9 @@ def test_state_dict_matches_reference_layout():
 
 
 @pytest.mark.parametrize("cin,cout,k,stride,up,hw", [(32, 64, 3, 2, 1, 32), (64, 128, 3, 2, 1, 16), (128, 128, 3, 1, 1, 16),
-                                                     (128, 64, 3, 1, 2, 8), (64, 32, 3, 1, 2, 16), (32, 3, 9, 1, 1, 16)])
+                                                     (128, 64, 3, 1, 2, 8), (64, 32, 3, 1, 2, 16), (32, 3, 9, 1, 1, 16),
+                                                     (32, 3, 9, 1, 1, 32),      # band kernel (32-column bands)
+                                                     (32, 3, 9, 1, 1, 56), (32, 3, 9, 1, 1, 112)])   # kernel columns in the matrix rows
 def test_gconv_against_torch(device, cin, cout, k, stride, up, hw):
     """one implicit-GEMM convolution with its prologue (per-(image,channel) scale/shift + relu) and its output sums"""
     import ctypes as C
