@@ -430,13 +430,15 @@ int spb_spn_conv(const spb_spn_conv_args_t* args, spb_stream_t stream);
  * dWp f32 [groups*Ng][Kp] += sum over output pixels of G[m][n] * X[pixel(m, tap)][c]; G: bf16 [B*OH*OW][groups*Ng].
  * Partial sums of the pixel ranges meet in dWp with float atomics: zero it first. */
 int spb_spn_conv_wgrad(const spb_spn_conv_args_t* args, const void* G, float* dWp, spb_stream_t stream);
-/* conv1: float32 NCHW image [B][3][H][W] -> bf16 NHWC relu(conv + bias), K x K stride `stride`, no padding, N <= 96 output
- * channels; Wp [N][Kp] in (c, ky, kx) order (spb_spn_pack_conv with chw_order = 1).  No column matrix. */
-int spb_spn_stem(const float* x, const void* Wp, const float* bias, void* Y, int B, int H, int W, int KH, int KW, int stride, int N, int Kp,
+/* conv1: float32 NCHW image [B][3][H][W] -> bf16 NHWC relu(conv + bias), 11 x 11, stride 4, no padding, 96 output channels
+ * (other shapes: SPB_E_UNSUPPORTED); Wb [96][Kb = 544] in the band layout k' = (c*11 + ky)*16 + kx (spb_spn_pack_jobs mode 2:
+ * kernel rows padded to 16 columns with zeros).  No column matrix: a band of image rows is staged in LDS. */
+int spb_spn_stem(const float* x, const void* Wb, const float* bias, void* Y, int B, int H, int W, int KH, int KW, int stride, int N, int Kb,
                  int relu, spb_stream_t stream);
 /* All the repacks a step needs after the optimizer changed the convolution weights, in one launch.  mode 0: spb_spn_pack_conv
  * (out [Cout][Kp], optional outT [groups][Kp][Cout/groups], chw = the RGB stem's (c, ky, kx) column order); mode 1:
- * spb_spn_pack_conv_dgrad (out [Cin][Kp]).  dtype selects bf16 / f32 outputs for every job. */
+ * spb_spn_pack_conv_dgrad (out [Cin][Kp]); mode 2: the RGB stem's band layout (out [Cout][Kp], k' = (c*KH + ky)*16 + kx, KW <= 16).
+ * dtype selects bf16 / f32 outputs for every job. */
 #define SPB_SPN_MAX_PACK_JOBS 12
 typedef struct spb_spn_pack_job {
   const float* W; void* out; void* outT;

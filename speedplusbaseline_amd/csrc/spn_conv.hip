@@ -175,112 +175,127 @@ __global__ __launch_bounds__(256) void spn_conv_kernel(const bf16_t* __restrict_
 }
 
 // ------------------------------------------------------------------------------------------------------------ RGB stem
-// conv1 (3 -> 96, 11x11, stride 4, no padding) straight from the float32 NCHW image: the A tile of a stage is gathered by the
-// lanes (8 scalar loads per 16-byte slot: 3-channel taps do not form 16-byte vectors), converted and stored to LDS one stage
-// ahead of the matrix cores; the weights ([N][Kp] in (c, ky, kx) order, spb_spn_pack_conv's chw layout) go through LDS-DMA.
-// The column matrix this replaces was 71 MB written and read back per step; the image is 20 MB.
-constexpr int SBN = 96;
-__global__ __launch_bounds__(256) void spn_stem_kernel(const float* __restrict__ x, const bf16_t* __restrict__ Wp, const float* __restrict__ bias,
-                                                       bf16_t* __restrict__ Y, int B, int H, int W, int KH, int KW, int st, int OH, int OW,
-                                                       int N, int Kp, int relu) {
-  constexpr int A_BYTES = 64 * 64 * 2, B_BYTES = SBN * 64 * 2, STAGE = A_BYTES + B_BYTES;
-  constexpr int LDO = SBN + 8;
+// conv1 (3 -> 96, 11x11, stride 4, no padding) straight from the float32 NCHW image, no column matrix.  A workgroup owns a band
+// of STEM_R output rows of one image: the 4*STEM_R + 7 input rows are staged ONCE in LDS (bf16, planar per colour, coalesced
+// row loads), and every matrix operand is then two aligned 8-byte LDS reads: the reduction index is k' = (ci*11 + ky)*16 + kx
+// with the kernel row padded from 11 to 16 columns (zero weights), so a lane's 8 consecutive k' are 8 consecutive pixels of one
+// image row starting at 4*ox + {0, 8}.  y^T = W * patch^T as in the style decoder (rows of W permuted so a lane stores 24
+// consecutive channels).  The first version of this kernel gathered its operands from global memory with 8 scalar loads per
+// 16-byte slot: 82 us alone and 350 us beside the HBM-bound parameter update; the column-matrix path is 67 + 41 us.
+constexpr int STEM_R = 4, STEM_KH = 11, STEM_KW = 11, STEM_ST = 4, STEM_NB = 6, STEM_STEPS = (3 * STEM_KH + 1) / 2;
+constexpr int STEM_OW = 55, STEM_WP = (STEM_ST * (STEM_OW - 1) + 16 + 3) / 4 * 4;   // 227-wide images: 55 output columns, 232 staged
+__global__ __launch_bounds__(256) void spn_stem_kernel(const float* __restrict__ x, const bf16_t* __restrict__ Wb, const float* __restrict__ bias,
+                                                       bf16_t* __restrict__ Y, int B, int H, int W, int OH, int OW, int relu) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int t = threadIdx.x, l = t & 63, w = t >> 6, li = l & 15, lq = l >> 4;
-  const int M = B * OH * OW, K = 3 * KH * KW, KT = (K + 63) / 64, taps = KH * KW;
-  const int m0 = blockIdx.x * 64;
-  const int dkv = (l & 7) ^ ((l >> 3) & 7);
-  size_t rowbase[2];
-  bool mok[2];
+  constexpr int BR = STEM_ST * (STEM_R - 1) + STEM_KH;            // band rows
+  constexpr int N = STEM_NB * 16, KB = STEM_STEPS * 32;
+  constexpr int WP = STEM_WP, TOTAL = 3 * BR * WP, NLD = (TOTAL + 255) / 256;   // band elements, loads per thread
+  constexpr int WGRAN = STEM_STEPS * STEM_NB * 64, NWD = (WGRAN + 255) / 256;    // weight granules of 16 bytes, DMA instructions per thread
+  bf16_t* wl = reinterpret_cast<bf16_t*>(smem);                   // [STEPS][NB][16 rows][32]: fragment order, 1 KB per fragment
+  bf16_t* band = wl + STEM_STEPS * STEM_NB * 512;                 // [3][BR][WP]
+  const int t = threadIdx.x, lane = t & 63, li = lane & 15, lq = lane >> 4, wave = t >> 6;
+  const int nbands = (OH + STEM_R - 1) / STEM_R, total_bands = B * nbands;
+  // Everything this workgroup reads from memory is issued in as few dependent round trips as possible: beside the HBM-bound
+  // parameter update a round trip costs tens of microseconds (the memory system is saturated by ~300 k queued workgroups), and
+  // the versions that streamed the weights step by step (17 round trips) or staged the band 16 loads at a time took 250-500 us
+  // there against 40-55 us alone.  Weights (104 KB, fragment order) go global -> LDS by DMA, 26 instructions per thread back to
+  // back; the band's 63 loads per thread are all in flight at once; the next band's loads are issued before this band's
+  // matrix-core loop and consumed after it.
+  {
+    const unsigned wl_lds = lds_addr(wl) + __builtin_amdgcn_readfirstlane((unsigned)(wave * 64 * 16));   // wave-uniform for the DMA base
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int m = m0 + w * 16 + i * 8 + (l >> 3);
-    mok[i] = m < M;
-    const int mc = mok[i] ? m : M - 1;
-    const int ox = mc % OW, oy = (mc / OW) % OH, b = mc / (OW * OH);
-    rowbase[i] = ((size_t)(b * 3) * H + oy * st) * W + ox * st;
-  }
-  size_t brow[3];
-#pragma unroll
-  for (int i = 0; i < 3; ++i) {
-    const int n = w * 24 + i * 8 + (l >> 3);
-    brow[i] = (size_t)(n < N ? n : N - 1) * Kp;
-  }
-  const unsigned lds0 = lds_addr(smem);
-  const unsigned wave_b = __builtin_amdgcn_readfirstlane((unsigned)(A_BYTES + w * 24 * 128));
-  float av[2][8];
-#define STEM_LOAD(kt_)                                                                             \
-  {                                                                                                \
-    const unsigned sb = lds0 + (unsigned)(((kt_) & 1) * STAGE) + wave_b;                           \
-    const int kb = (kt_) * 64 + dkv * 8;                                                           \
-    const int kc = kb < Kp ? kb : Kp - 8;                                                          \
-    _Pragma("unroll") for (int i = 0; i < 3; ++i) dma16(Wp + brow[i] + kc, sb + (unsigned)(i * 8 * 128)); \
-    int c = kb / taps, rem = kb - c * taps;                                                        \
-    int ky = rem / KW, kx = rem - ky * KW;                                                         \
-    _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                \
-      const bool kok = kb + j < K;                                                                 \
-      const size_t off = kok ? ((size_t)c * H + ky) * W + kx : 0;                                  \
-      _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                              \
-        const float v = x[rowbase[i] + off];                                                       \
-        av[i][j] = (kok && mok[i]) ? v : 0.f;                                                      \
-      }                                                                                            \
-      if (++kx == KW) { kx = 0; if (++ky == KH) { ky = 0; ++c; } }                                 \
-    }                                                                                              \
-  }
-  STEM_LOAD(0);
-  f32x4_t acc[SBN / 16];
-#pragma unroll
-  for (int j = 0; j < SBN / 16; ++j) acc[j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-  const int frow = w * 16 + li;
-  for (int kt = 0; kt < KT; ++kt) {
-    char* sbuf = smem + (size_t)(kt & 1) * STAGE;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {      // this lane's two 16-byte slots of stage kt (physical slot l&7 holds logical vector dkv)
-      uint4 u;
-      u.x = pack_bf16x2(av[i][0], av[i][1]); u.y = pack_bf16x2(av[i][2], av[i][3]);
-      u.z = pack_bf16x2(av[i][4], av[i][5]); u.w = pack_bf16x2(av[i][6], av[i][7]);
-      *reinterpret_cast<uint4*>(sbuf + (w * 16 + i * 8 + (l >> 3)) * 128 + (l & 7) * 16) = u;
-    }
-    wait_vmcnt<0>();                   // the weight tile of stage kt
-    __syncthreads();                   // stage kt complete in LDS; everyone is done with the other buffer (stage kt-1)
-    if (kt + 1 < KT) STEM_LOAD(kt + 1);
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      const int v = ks * 4 + lq;
-      const bf16x8_t af = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(sbuf + frow * 128 + ((v ^ (frow & 7)) << 4)));
-#pragma unroll
-      for (int j = 0; j < SBN / 16; ++j) {
-        const int br = j * 16 + li;
-        const bf16x8_t bf = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(sbuf + A_BYTES + br * 128 + ((v ^ (br & 7)) << 4)));
-        acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bf, acc[j], 0, 0, 0);
-      }
+    for (int jj = 0; jj < NWD; ++jj) {
+      const int i = t + 256 * jj;
+      const int ic = i < WGRAN ? i : WGRAN - 1;                   // the surplus lanes of the last instruction land in the band area,
+      const int q = ic & 3, r = (ic >> 2) & 15, nb = (ic >> 6) % STEM_NB, st_ = ic / (64 * STEM_NB);   // which is written afterwards
+      const int co = (r >> 2) * 4 * STEM_NB + nb * 4 + (r & 3);   // channel permutation: a lane ends up with 4*NB consecutive channels
+      dma16(Wb + (size_t)co * KB + st_ * 32 + q * 8, wl_lds + (unsigned)(jj * 256 * 16));
     }
   }
-#undef STEM_LOAD
+  float v[NLD];
+  auto band_issue = [&](int bandi_) {                             // element e = (ci, row, x); outside the image: zeros
+    const int bb = bandi_ / nbands, iy0_ = (bandi_ % nbands) * STEM_R * STEM_ST;
+    const float* xb = x + (size_t)bb * 3 * H * W;
+#pragma unroll
+    for (int u = 0; u < NLD; ++u) {
+      const int e = t + 256 * u;
+      const int ec = e < TOTAL ? e : TOTAL - 1;
+      const int xx = ec % WP, rr = (ec / WP) % BR, ci = ec / (WP * BR);
+      const int iy = iy0_ + rr;
+      const bool ok = xx < W && iy < H;
+      const float val = xb[((size_t)ci * H + (ok ? iy : 0)) * W + (ok ? xx : 0)];
+      v[u] = ok ? val : 0.f;
+    }
+  };
+  auto band_commit = [&]() {
+#pragma unroll
+    for (int u = 0; u < NLD; ++u) {
+      const int e = t + 256 * u;
+      if (e < TOTAL) band[e] = f2bf(v[u]);
+    }
+  };
+  band_issue(blockIdx.x < total_bands ? blockIdx.x : 0);
+  wait_vmcnt<0>();                                                // weights (DMA) and the first band's loads
   __syncthreads();
-  bf16_t* Os = reinterpret_cast<bf16_t*>(smem);
+  band_commit();
+  for (int bandi = blockIdx.x; bandi < total_bands; bandi += gridDim.x) {
+  const int b = bandi / nbands, oy0 = (bandi % nbands) * STEM_R;
+  __syncthreads();                                                // band (and, first pass, weights) complete in LDS
+  const int nxt = bandi + gridDim.x;
+  band_issue(nxt < total_bands ? nxt : bandi);                    // in flight during the matrix-core loop (last pass: redundant)
+  const bf16_t* wfrag = wl + (li * 4 + lq) * 8;
+  // wave = output row of the band; four 16-pixel groups cover the 55 columns (pixel index clamped for the addresses)
+  f32x4_t acc[4][STEM_NB];
 #pragma unroll
-  for (int j = 0; j < SBN / 16; ++j)
+  for (int g = 0; g < 4; ++g)
 #pragma unroll
-    for (int e = 0; e < 4; ++e) Os[(w * 16 + lq * 4 + e) * LDO + j * 16 + li] = f2bf(acc[j][e]);
-  __syncthreads();
-  constexpr int NV = SBN / 8;
-  for (int i = t; i < 64 * NV; i += 256) {
-    const int r = i / NV, vc = i % NV;
-    const int m = m0 + r, n = vc * 8;
-    if (m < M && n < N) {
-      float v[8];
-      ld8<bf16_t>(Os + r * LDO + n, v);
+    for (int nb = 0; nb < STEM_NB; ++nb) acc[g][nb] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  int pxo[4];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        v[j] += (bias && n + j < N) ? bias[n + j] : 0.f;
-        if (relu) v[j] = fmaxf(v[j], 0.f);
-      }
-      if (n + 8 <= N) st8<bf16_t>(Y + (size_t)m * N + n, v);
-      else
-        for (int j = 0; j < 8; ++j) if (n + j < N) Y[(size_t)m * N + n + j] = f2bf(v[j]);
+  for (int g = 0; g < 4; ++g) pxo[g] = STEM_ST * min(g * 16 + li, OW - 1) + (lq & 1) * 8;
+  for (int s = 0; s < STEM_STEPS; ++s) {
+    uint4 a[STEM_NB];
+#pragma unroll
+    for (int nb = 0; nb < STEM_NB; ++nb) a[nb] = *reinterpret_cast<const uint4*>(wfrag + (s * STEM_NB + nb) * 512);
+    const int r = min(2 * s + (lq >> 1), 3 * STEM_KH - 1);        // (ci, ky) row of this lane's 8 reduction elements (pad row: zero weights)
+    const int ci = r / STEM_KH, ky = r - ci * STEM_KH;
+    const bf16_t* brow = band + ((size_t)(ci * BR + wave * STEM_ST + ky)) * WP;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const uint2 lo = *reinterpret_cast<const uint2*>(brow + pxo[g]), hi = *reinterpret_cast<const uint2*>(brow + pxo[g] + 4);
+      const bf16x8_t bf = __builtin_bit_cast(bf16x8_t, make_uint4(lo.x, lo.y, hi.x, hi.y));
+#pragma unroll
+      for (int nb = 0; nb < STEM_NB; ++nb)
+        acc[g][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a[nb]), bf, acc[g][nb], 0, 0, 0);
     }
   }
+  // ---- epilogue: lane (li = pixel, lq): channels lq*24 + nb*4 + e, 48 contiguous bytes
+  const int oy = oy0 + wave;
+  const int co0 = lq * 4 * STEM_NB;
+  if (oy < OH) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int ox = g * 16 + li;
+      if (ox >= OW) continue;
+      bf16_t* dst = Y + ((size_t)(b * OH + oy) * OW + ox) * N + co0;
+      uint2 o[STEM_NB];
+#pragma unroll
+      for (int nb = 0; nb < STEM_NB; ++nb) {
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          v[e] = acc[g][nb][e] + (bias ? bias[co0 + nb * 4 + e] : 0.f);
+          if (relu) v[e] = fmaxf(v[e], 0.f);
+        }
+        o[nb].x = pack_bf16x2(v[0], v[1]); o[nb].y = pack_bf16x2(v[2], v[3]);
+      }
+#pragma unroll
+      for (int nb = 0; nb < STEM_NB; nb += 2) *reinterpret_cast<uint4*>(dst + nb * 4) = make_uint4(o[nb].x, o[nb].y, o[nb + 1].x, o[nb + 1].y);
+    }
+  }
+  __syncthreads();                                                // every wave is done reading this band
+  band_commit();                                                  // the next one (prefetched above)
+  }   // bands of this workgroup
 }
 
 // ---------------------------------------------------------------------------------------------------- weight gradient
@@ -424,7 +439,10 @@ __global__ void pack_jobs_kernel(const PackJobs jobs, int bf16) {
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
     const int row = (int)(i / q.Kp), k = (int)(i % q.Kp);
     float v = 0.f;
-    if (q.mode == 1) {          // mirrored taps for the input gradient: [g*cig + ci][(tap', n)]
+    if (q.mode == 2) {          // RGB stem band layout: k' = (ci*KH + ky)*16 + kx, kernel rows padded to 16 columns with zeros
+      const int rr = k >> 4, kx = k & 15;
+      if (kx < q.KW && rr < q.Cin * q.KH) v = q.W[((size_t)row * q.Cin * q.KH + rr) * q.KW + kx];
+    } else if (q.mode == 1) {   // mirrored taps for the input gradient: [g*cig + ci][(tap', n)]
       if (k < q.KH * q.KW * cog) {
         const int tp = k / cog, n = k % cog;
         const int ky = q.KH - 1 - tp / q.KW, kx = q.KW - 1 - tp % q.KW;
@@ -555,15 +573,23 @@ extern "C" int spb_spn_col_wgrad(const void* G, const void* col, float* dW, int 
   return 0;
 }
 
-extern "C" int spb_spn_stem(const float* x, const void* Wp, const float* bias, void* Y, int B, int H, int W, int KH, int KW, int stride,
-                            int N, int Kp, int relu, spb_stream_t stream) {
-  if (!x || !Wp || !Y || B <= 0 || H < KH || W < KW || KH <= 0 || KW <= 0 || stride <= 0 || N <= 0) return SPB_E_ARG;
-  if (N > SBN || (Kp & 7) || Kp < 3 * KH * KW || (N & 7)) return SPB_E_UNSUPPORTED;
+extern "C" int spb_spn_stem(const float* x, const void* Wb, const float* bias, void* Y, int B, int H, int W, int KH, int KW, int stride,
+                            int N, int Kb, int relu, spb_stream_t stream) {
+  if (!x || !Wb || !Y || B <= 0 || H < KH || W < KW || KH <= 0 || KW <= 0 || stride <= 0 || N <= 0) return SPB_E_ARG;
+  if (KH != STEM_KH || KW != STEM_KW || stride != STEM_ST || N != STEM_NB * 16 || Kb != STEM_STEPS * 32) return SPB_E_UNSUPPORTED;
   const int OH = (H - KH) / stride + 1, OW = (W - KW) / stride + 1;
-  const int M = B * OH * OW;
-  const size_t lds = (size_t)2 * (64 * 64 * 2 + SBN * 64 * 2);
-  hipLaunchKernelGGL(spn_stem_kernel, dim3((M + 63) / 64), dim3(256), lds, (hipStream_t)stream, x, (const bf16_t*)Wp, bias, (bf16_t*)Y, B, H, W,
-                     KH, KW, stride, OH, OW, N, Kp, relu);
+  if (OW != STEM_OW) return SPB_E_UNSUPPORTED;                 // the staged row width is a compile-time constant (227-wide images)
+  const size_t lds = (size_t)STEM_STEPS * STEM_NB * 512 * sizeof(bf16_t) + (size_t)3 * (STEM_ST * (STEM_R - 1) + STEM_KH) * STEM_WP * sizeof(bf16_t);
+  if (lds > 160 * 1024) return SPB_E_SHAPE;
+  const int nbands = (OH + STEM_R - 1) / STEM_R;
+  const int total = B * nbands;
+  // one workgroup per CU (136 KB of LDS); each walks ceil(total / grid) bands -- grid chosen so that they all walk the same number
+  const int per = (total + 255) / 256;
+  const int grid = (total + per - 1) / per;
+  static bool once = false;
+  if (!once) { hipFuncSetAttribute(reinterpret_cast<const void*>(&spn_stem_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); once = true; }
+  hipLaunchKernelGGL(spn_stem_kernel, dim3((unsigned)grid), dim3(256), lds, (hipStream_t)stream, x, (const bf16_t*)Wb, bias, (bf16_t*)Y, B,
+                     H, W, OH, OW, relu);
   SPB_CHECK_LAUNCH();
   return 0;
 }
@@ -575,8 +601,8 @@ extern "C" int spb_spn_pack_jobs(int dtype, const spb_spn_pack_job_t* jobs, int 
   for (int i = 0; i < njobs; ++i) {
     const spb_spn_pack_job_t& q = jobs[i];
     if (!q.W || !q.out || q.Cout <= 0 || q.Cin <= 0 || q.groups <= 0 || (q.Cout % q.groups) || (q.Cin % q.groups)) return SPB_E_ARG;
-    const int need = q.KH * q.KW * (q.mode == 1 ? q.Cout / q.groups : q.Cin / q.groups);
-    if (q.Kp < need || (q.mode != 0 && q.mode != 1)) return SPB_E_ARG;
+    const int need = q.mode == 2 ? q.Cin * q.KH * 16 : q.KH * q.KW * (q.mode == 1 ? q.Cout / q.groups : q.Cin / q.groups);
+    if (q.Kp < need || q.mode < 0 || q.mode > 2 || (q.mode == 2 && (q.groups != 1 || q.KW > 16))) return SPB_E_ARG;
     pj.j[i] = q;
     const long long total = (long long)(q.mode == 1 ? q.Cin : q.Cout) * q.Kp;
     if (total > biggest) biggest = total;

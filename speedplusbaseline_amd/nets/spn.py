@@ -71,7 +71,10 @@ class _Layer(nn.Module):
 
 
 _BACKGROUND_BLOCKS = int(os.environ.get("SPB_SPN_UPDATE_BLOCKS", "0"))   # > 0: cap on the workgroups of the heads' update beside backward
-_STEM = os.environ.get("SPB_SPN_STEM", "0") == "1"    # direct conv1 (spb_spn_stem): 82 vs 108 us alone, but 350 us beside the update (scattered 4-byte loads); off
+# conv1 straight from the image through an LDS band (spb_spn_stem): 48 us alone against 67 + 41 us for column matrix + GEMM, but
+# 250-500 us beside the previous step's HBM-bound parameter update in every variant tried (a kernel with one workgroup per CU
+# has too few requests in flight to get its share of a saturated memory system), so: 1 = evaluation only, 2 = always, 0 = never
+_STEM = int(os.environ.get("SPB_SPN_STEM", "1"))
 _FUSED_FC_UPDATE = os.environ.get("SPB_SPN_FUSED_FC_UPDATE", "0") == "1"
 
 
@@ -235,6 +238,14 @@ class SpacecraftPoseNet(nn.Module):
                 q.W, q.out, q.outT = _p(getattr(self, name).weight.detach()).value, _p(wd).value, None
                 q.Cout, q.Cin, q.groups, q.KH, q.KW, q.Kp, q.mode, q.chw = cout, cin, g, k, k, kd, 1, 0
                 cp[name + "D"] = wd
+        if self._implicit() and (_STEM == 2 or (_STEM == 1 and not need_t)):      # conv1 straight from the image: k' = (ci*11 + ky)*16 + kx band layout (spb_spn_stem)
+            name, cout, cin, g, k, _, _ = _CONVS[0]
+            kb = (cin * k + 1) // 2 * 32
+            wb = self._buf("wb" + name, (cout, kb), dt)
+            q = jobs[nj]; nj += 1
+            q.W, q.out, q.outT = _p(getattr(self, name).weight.detach()).value, _p(wb).value, None
+            q.Cout, q.Cin, q.groups, q.KH, q.KW, q.Kp, q.mode, q.chw = cout, cin, 1, k, k, kb, 2, 0
+            cp[name + "b"] = wb
         L.check(lib.spb_spn_pack_jobs(dc, jobs, nj, st), "spb_spn_pack_jobs")      # one launch for all of them
         if fast:
             if self._shadow_version != self._version:     # load_state_dict / load_weights / manual edits: rare
@@ -293,9 +304,10 @@ class SpacecraftPoseNet(nn.Module):
             if li > 0 and self._implicit():
                 self._conv(cur, cp[name], bias, None, y, B, Hc, Wc, Cc, k, stride, pad, g, cin // g, cog, relu=True)
                 sv["x" + name] = cur
-            elif li == 0 and self._implicit() and _STEM:
+            elif li == 0 and (name + "b") in cp:
                 # straight from the float32 NCHW image; backward builds the column matrix of its weight gradient on the side stream
-                L.check(lib.spb_spn_stem(_p(x), _p(cp[name]), _p(bias), _p(y), B, Hc, Wc, k, k, stride, cout, kg, 1, st), "spb_spn_stem")
+                wb = cp[name + "b"]
+                L.check(lib.spb_spn_stem(_p(x), _p(wb), _p(bias), _p(y), B, Hc, Wc, k, k, stride, cout, wb.shape[1], 1, st), "spb_spn_stem")
                 sv["image"] = x
             else:
                 col = self._buf("col" + name, (B * OH * OW, kpad), dt)

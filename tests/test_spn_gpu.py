@@ -320,8 +320,11 @@ def test_update_beside_backward_equals_plain_step(device, fused, monkeypatch):
     ce = net._conv_end
     moved = float((res[0][0] - p0).abs().max())
     assert moved > 0.04                                            # lr * clip
-    for a, b in zip(*res):
-        assert float((a[ce:] - b[ce:]).abs().max()) < 1e-6 * max(1.0, float(a[ce:].abs().max()))
+    for k, (a, b) in enumerate(zip(*res)):
+        # heads: lr 0.05 x run-to-run gradient noise (a missed update would show as 0.05); the bf16 shadow (k == 1) may sit one
+        # ulp (2^-8 relative) apart where a parameter lands next to a rounding boundary
+        tol = 1e-4 if k != 1 else 2.0 ** -7
+        assert float((a[ce:] - b[ce:]).abs().max()) < tol * max(1.0, float(a[ce:].abs().max()))
         # convolution range: gradients here are sums of +-50-sized terms (loss ~ 60) accumulated with float atomics over row
         # tiles, so an element below the clip value carries absolute noise of a few 1e-2 from run to run: norm-wise bound
         assert float((a[:ce] - b[:ce]).norm() / b[:ce].norm()) < 2e-2 and float((a[:ce] - b[:ce]).abs().max()) < 0.5
@@ -401,9 +404,12 @@ def test_rgb_stem_convolution(device, B):
     w = (torch.randn(96, 3, 11, 11, generator=g) / 363 ** 0.5).to(device)
     bias = (0.1 * torch.randn(96, generator=g)).to(device)
     x = torch.randn(B, 3, 227, 227, generator=g).to(device)
-    wp = torch.empty(96, 368, dtype=torch.bfloat16, device=device)
-    L.check(lib.spb_spn_pack_conv(L.BF16, _vp(w), _vp(wp), None, 96, 3, 1, 11, 11, 368, 1, st), "pack")
+    wp = torch.empty(96, 544, dtype=torch.bfloat16, device=device)     # k' = (ci*11 + ky)*16 + kx, 17 steps of 32
+    job = (L.SpnPackJob * 1)()
+    job[0].W, job[0].out, job[0].outT = w.data_ptr(), wp.data_ptr(), None
+    job[0].Cout, job[0].Cin, job[0].groups, job[0].KH, job[0].KW, job[0].Kp, job[0].mode, job[0].chw = 96, 3, 1, 11, 11, 544, 2, 0
+    L.check(lib.spb_spn_pack_jobs(L.BF16, job, 1, st), "pack")
     y = torch.empty(B * 55 * 55, 96, dtype=torch.bfloat16, device=device)
-    L.check(lib.spb_spn_stem(_vp(x), _vp(wp), _vp(bias), _vp(y), B, 227, 227, 11, 11, 4, 96, 368, 1, st), "spb_spn_stem")
+    L.check(lib.spb_spn_stem(_vp(x), _vp(wp), _vp(bias), _vp(y), B, 227, 227, 11, 11, 4, 96, 544, 1, st), "spb_spn_stem")
     ref = F.relu(F.conv2d(x.to(torch.bfloat16).float(), w.to(torch.bfloat16).float(), bias, stride=4))
     assert rel(y.float().view(B, 55, 55, 96).permute(0, 3, 1, 2), ref) < 8e-3
