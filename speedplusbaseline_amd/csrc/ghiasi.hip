@@ -1062,39 +1062,50 @@ __global__ __launch_bounds__(256) void conv9_rgb_kernel(const float* __restrict_
                                                         const float* __restrict__ bias, bf16_t* __restrict__ y, float* stats,
                                                         int B, int H, int W) {
   extern __shared__ __attribute__((aligned(16))) char smem9[];
-  const int LDX = W + 8 + 2;                                   // staged row: 4 reflected columns each side (+2: bank skew)
-  uint4* wfrag = reinterpret_cast<uint4*>(smem9);              // [9 ky][2 cb][64 lanes]
-  bf16_t* xs = reinterpret_cast<bf16_t*>(smem9 + 9 * 2 * 64 * 16);   // [3][C9_R + 8][LDX]
-  float* red = reinterpret_cast<float*>(xs + 3 * (C9_R + 8) * LDX + 8);  // [4][64]
+  // Band in LDS as [row][column][4] bf16 (3 colours + a zero): 8 consecutive reduction elements k = kx*4 + ci of a pixel are the
+  // 16 bytes of two neighbouring columns -- two aligned 8-byte reads instead of the 8 two-byte reads + packing of the planar
+  // layout (72 LDS instructions per 16 pixels, the kernel's bound).  11 matrix steps per 16-pixel group: one per kernel row for
+  // kx = 0..7, and kx = 8 of all nine rows folded into two more (k = ky*4 + ci).
+  const int LDX = W + 8 + 1;                                   // staged columns: 4 reflected each side (+1: bank skew), x 4 channels
+  uint4* wfrag = reinterpret_cast<uint4*>(smem9);              // [11 steps][2 cb][64 lanes]
+  bf16_t* xs = reinterpret_cast<bf16_t*>(smem9 + 11 * 2 * 64 * 16);   // [C9_R + 8][LDX][4]
+  float* red = reinterpret_cast<float*>(xs + (C9_R + 8) * LDX * 4 + 8);  // [4][64]
   const int lane = threadIdx.x & 63, li = lane & 15, lq = lane >> 4, wave = threadIdx.x >> 6;
   const int b = blockIdx.y, y0 = blockIdx.x * C9_R;
   const int rows = min(C9_R, H - y0);
-  // A operand per kernel row: W[co = cb*16+li][k = lq*8+e], k = ci*9 + kx
-  for (int f = wave; f < 18; f += 4) {
-    const int ky = f >> 1, cb = f & 1;
+  // A operand: W[co = cb*16 + li][8 reduction elements of quarter lq]
+  for (int f = wave; f < 22; f += 4) {
+    const int st_ = f >> 1, cb = f & 1;
     float v[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      const int k = lq * 8 + e;
-      v[e] = k < 27 ? w[((cb * 16 + li) * 3 + k / 9) * 81 + ky * 9 + k % 9] : 0.f;
+      const int k = lq * 8 + e, ci = k & 3, q = k >> 2;        // q: kx (steps 0..8) or ky (steps 9, 10)
+      const int ky = st_ < 9 ? st_ : (st_ == 9 ? q : 8), kx = st_ < 9 ? q : 8;
+      const bool ok = ci < 3 && (st_ < 10 || q == 0);
+      v[e] = ok ? w[((cb * 16 + li) * 3 + ci) * 81 + ky * 9 + kx] : 0.f;
     }
-    wfrag[(ky * 2 + cb) * 64 + lane] = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
+    wfrag[(st_ * 2 + cb) * 64 + lane] = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
   }
-  // input band: rows y0-4 .. y0+rows+3, columns -4 .. W+3, reflected
+  // input band: rows y0-4 .. y0+rows+3, columns -4 .. W+3, reflected; one thread = one pixel (3 loads, one 8-byte store)
   const int nrow = rows + 8, ncol = W + 8;
-  for (int i = threadIdx.x; i < 3 * nrow * ncol; i += 256) {
-    const int cx = i % ncol, r = (i / ncol) % nrow, ci = i / (ncol * nrow);
-    const float v = x[((size_t)(b * 3 + ci) * H + reflecti(y0 - 4 + r, H)) * W + reflecti(cx - 4, W)];
-    xs[(ci * (C9_R + 8) + r) * LDX + cx] = f2bf(v);
+  const int npix = nrow * ncol;
+  for (int i0 = threadIdx.x; i0 < npix; i0 += 256 * 6) {       // 18 loads in flight per thread
+    float v[6][3];
+    int dst[6];
+#pragma unroll
+    for (int u = 0; u < 6; ++u) {
+      const int i = i0 + 256 * u, ic = i < npix ? i : npix - 1;
+      const int cx = ic % ncol, r = ic / ncol;
+      const size_t o = (size_t)reflecti(y0 - 4 + r, H) * W + reflecti(cx - 4, W);
+#pragma unroll
+      for (int ci = 0; ci < 3; ++ci) v[u][ci] = x[(size_t)(b * 3 + ci) * H * W + o];
+      dst[u] = i < npix ? (r * LDX + cx) * 4 : -1;
+    }
+#pragma unroll
+    for (int u = 0; u < 6; ++u)
+      if (dst[u] >= 0) *reinterpret_cast<uint2*>(xs + dst[u]) = make_uint2(pack_bf16x2(v[u][0], v[u][1]), pack_bf16x2(v[u][2], 0.f));
   }
   __syncthreads();
-  // per-lane tap offsets of one kernel row: k = lq*8+e -> plane ci, column offset kx (slots 27..31 read a valid address, weight 0)
-  int toff[8];
-#pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    const int k = lq * 8 + e, kc = k < 27 ? k : 26;
-    toff[e] = (kc / 9) * (C9_R + 8) * LDX + kc % 9;
-  }
   float s1[2][4], s2[2][4];
 #pragma unroll
   for (int cb = 0; cb < 2; ++cb)
@@ -1104,17 +1115,24 @@ __global__ __launch_bounds__(256) void conv9_rgb_kernel(const float* __restrict_
   for (int gi = wave; gi < rows * gpr; gi += 4) {
     const int ry = gi / gpr, ox = (gi % gpr) * 16 + li, oy = y0 + ry;
     f32x4_t acc[2] = {(f32x4_t){0.f, 0.f, 0.f, 0.f}, (f32x4_t){0.f, 0.f, 0.f, 0.f}};
+    const bf16_t* rp = xs + ((size_t)ry * LDX + ox) * 4;
 #pragma unroll
-    for (int ky = 0; ky < 9; ++ky) {
-      const bf16_t* rp = xs + (ry + ky) * LDX + ox;
-      unsigned h[8];
-#pragma unroll
-      for (int e = 0; e < 8; ++e) h[e] = rp[toff[e]];
-      const uint4 u = make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
-      const bf16x8_t bf = __builtin_bit_cast(bf16x8_t, u);
+    for (int st_ = 0; st_ < 11; ++st_) {
+      uint2 lo, hi;
+      if (st_ < 9) {            // kernel row st_, columns kx = 2 lq, 2 lq + 1
+        lo = *reinterpret_cast<const uint2*>(rp + ((size_t)st_ * LDX + lq * 2) * 4);
+        hi = *reinterpret_cast<const uint2*>(rp + ((size_t)st_ * LDX + lq * 2 + 1) * 4);
+      } else if (st_ == 9) {    // column kx = 8 of kernel rows 2 lq, 2 lq + 1
+        lo = *reinterpret_cast<const uint2*>(rp + ((size_t)(lq * 2) * LDX + 8) * 4);
+        hi = *reinterpret_cast<const uint2*>(rp + ((size_t)(lq * 2 + 1) * LDX + 8) * 4);
+      } else {                  // column 8 of kernel row 8 (quarter 0; the other quarters meet zero weights)
+        lo = *reinterpret_cast<const uint2*>(rp + ((size_t)8 * LDX + 8) * 4);
+        hi = lo;
+      }
+      const bf16x8_t bf = __builtin_bit_cast(bf16x8_t, make_uint4(lo.x, lo.y, hi.x, hi.y));
 #pragma unroll
       for (int cb = 0; cb < 2; ++cb)
-        acc[cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wfrag[(ky * 2 + cb) * 64 + lane]), bf, acc[cb], 0, 0, 0);
+        acc[cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wfrag[(st_ * 2 + cb) * 64 + lane]), bf, acc[cb], 0, 0, 0);
     }
 #pragma unroll
     for (int cb = 0; cb < 2; ++cb) {
@@ -1360,7 +1378,7 @@ extern "C" int spb_gconv_up2(int dtype, const spb_gconv_args_t* a, spb_stream_t 
 extern "C" int spb_conv9_rgb(const float* x, const float* w, const float* bias, void* y, float* stats, int B, int H, int W,
                              spb_stream_t stream) {
   if (!x || !w || !y || B <= 0 || H < 5 || W < 16 || (W & 15)) return SPB_E_ARG;
-  const size_t lds = (size_t)9 * 2 * 64 * 16 + ((size_t)3 * (C9_R + 8) * (W + 10) + 8) * sizeof(bf16_t) + 4 * 64 * sizeof(float) + 16;
+  const size_t lds = (size_t)11 * 2 * 64 * 16 + ((size_t)4 * (C9_R + 8) * (W + 9) + 8) * sizeof(bf16_t) + 4 * 64 * sizeof(float) + 16;
   if (lds > 160 * 1024) return SPB_E_SHAPE;
   static bool attr = false;
   if (!attr) { hipFuncSetAttribute(reinterpret_cast<const void*>(&conv9_rgb_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
