@@ -15,6 +15,7 @@ int main() {
   if (getenv("WPXG")) spb_debug_set_gconv_wlds_pxg(atoi(getenv("WPXG")));
   printf("GABL=%d PF=%s SLAB=%s WPXG=%s\n", GABL, getenv("PF") ? getenv("PF") : "-", getenv("SLAB") ? getenv("SLAB") : "-", getenv("WPXG") ? getenv("WPXG") : "-");
   for (auto sh : shapes) {
+    if (getenv("UB")) sh.B = atoi(getenv("UB"));
     const int Hout = sh.H * sh.up / sh.st;
     size_t nin = (size_t)sh.B * sh.H * sh.H * sh.Cin, nout = (size_t)sh.B * Hout * Hout * (sh.Cout < 4 ? 4 : sh.Cout);
     void *x, *w, *y; float *coef, *stats, *bias;
