@@ -533,6 +533,7 @@ int spb_debug_set_gemm_bk64_min_k(int k); /* small-M bf16 GEMMs with K >= k use 
 int spb_debug_set_gconv_slab(int mode); /* wide decoder convs: 0 per-wave weight streaming; 1 slab kernel with 4 tiles (1 workgroup per CU); 2 (default) 2 tiles, 2 per CU */
 int spb_debug_set_side_wgrad(int on); /* 0: pointwise weight gradients stay on the launch stream */
 int spb_debug_set_dw_rows(int rows); /* rows per row unit (0: automatic) */
+int spb_debug_set_im2col_rgb_band(int on); /* SPN conv1 column matrix: 1 = band kernel (image rows through LDS), 0 = per-element gather */
 int spb_debug_set_gconv_slab_pf(int n); /* wide decoder convs: weight slabs in flight per workgroup (3 | 6, default 6) */
 int spb_debug_set_gconv_halo_prefetch(int on); /* decoder convs with LDS-resident weights: prefetch the next tile's halo (1, default) */
 int spb_debug_set_gconv_wlds_pxg(int n); /* decoder convs with LDS-resident weights: 8x8 tiles per workgroup side by side (1 | 2) */

@@ -229,6 +229,7 @@ SYMBOLS = {
     "spb_debug_set_gemm_sk": (i32, [i32, i32, i32]),
     "spb_debug_set_gconv_wlds_pxg": (i32, [i32]),
     "spb_debug_set_gconv_halo_prefetch": (i32, [i32]),
+    "spb_debug_set_im2col_rgb_band": (i32, [i32]),
     "spb_debug_set_gconv_slab_pf": (i32, [i32]),
     "spb_version": (C.c_char_p, []),
 }

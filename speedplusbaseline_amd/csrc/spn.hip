@@ -77,6 +77,48 @@ __global__ void im2col_rgb_kernel(const float* __restrict__ x, T* __restrict__ d
   }
 }
 
+// The same column matrix (bf16), one workgroup per (image, output row): the KH input rows of the three colours are read with
+// coalesced loads, ALL in flight at once (<= RGB_NLD per thread), rounded to bf16 into LDS, and the output row's OW column-matrix
+// rows are then written as 16-byte vectors gathered from LDS.  The per-element kernel above issues 8 dependent-address scalar
+// loads per 16-byte store (67 us for the 71 MB of conv1 at bs=32, 85-95 us beside the parameter update).
+constexpr int RGB_NLD = 32;
+__global__ __launch_bounds__(256) void im2col_rgb_band_kernel(const float* __restrict__ x, bf16_t* __restrict__ dst, int H, int W, int KH,
+                                                              int KW, int st, int OH, int OW, int Kpad) {
+  extern __shared__ __attribute__((aligned(16))) char smem_rgb[];
+  bf16_t* band = reinterpret_cast<bf16_t*>(smem_rgb);          // [3][KH][W]
+  const int t = threadIdx.x;
+  const int b = blockIdx.x / OH, oy = blockIdx.x % OH;
+  const int total = 3 * KH * W;
+  const float* xb = x + (size_t)b * 3 * H * W;
+  float v[RGB_NLD];
+#pragma unroll
+  for (int u = 0; u < RGB_NLD; ++u) {
+    const int e = t + 256 * u, ec = e < total ? e : total - 1;
+    const int xx = ec % W, r = ec / W, ci = r / KH, ky = r - ci * KH;
+    v[u] = xb[((size_t)ci * H + oy * st + ky) * W + xx];
+  }
+#pragma unroll
+  for (int u = 0; u < RGB_NLD; ++u) {
+    const int e = t + 256 * u;
+    if (e < total) band[e] = f2bf(v[u]);
+  }
+  __syncthreads();
+  const int KV = Kpad >> 3, KK = 3 * KH * KW, taps = KH * KW;
+  bf16_t* out = dst + (size_t)(b * OH + oy) * OW * Kpad;
+  for (int i = t; i < OW * KV; i += 256) {
+    const int ox = i / KV, kv = i - ox * KV;
+    int k = kv * 8;
+    int ci = k / taps, rem = k - ci * taps, ky = rem / KW, kx = rem - ky * KW;
+    unsigned h[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      h[j] = (k + j < KK) ? band[(ci * KH + ky) * W + ox * st + kx] : 0u;
+      if (++kx == KW) { kx = 0; if (++ky == KH) { ky = 0; ++ci; } }
+    }
+    *reinterpret_cast<uint4*>(out + (size_t)i * 8) = make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
+  }
+}
+
 // dx[b,iy,ix,c] = sum over taps of dcol[(b, iy+pad-ky, ix+pad-kx)][(ky*KW+kx)*C + c]   (stride 1)
 template <typename T>
 __global__ void col2im_kernel(const T* __restrict__ dcol, T* __restrict__ dx, int B, int H, int W, int C, int KH, int KW, int pad,
@@ -380,12 +422,20 @@ extern "C" int spb_im2col(int dtype, const void* src, void* dst, int B, int H, i
   return 0;
 }
 
+static int g_rgb_band = 1;
+extern "C" int spb_debug_set_im2col_rgb_band(int on) { g_rgb_band = on; return 0; }
 extern "C" int spb_im2col_rgb(int dtype, const float* x, void* dst, int B, int H, int W, int KH, int KW, int stride, int Kpad,
                               spb_stream_t stream) {
   if (!x || !dst || B <= 0 || Kpad < KH * KW * 3 || (Kpad & 7)) return SPB_E_ARG;
   const int OH = (H - KH) / stride + 1, OW = (W - KW) / stride + 1;
   const long long total = (long long)B * OH * OW * (Kpad >> 3);
   hipStream_t s = (hipStream_t)stream;
+  if (dtype == SPB_BF16 && g_rgb_band && 3 * KH * W <= 256 * RGB_NLD && (size_t)3 * KH * W * 2 <= 64 * 1024) {
+    hipLaunchKernelGGL(im2col_rgb_band_kernel, dim3((unsigned)(B * OH)), dim3(256), (size_t)3 * KH * W * sizeof(bf16_t), s, x, (bf16_t*)dst, H, W,
+                       KH, KW, stride, OH, OW, Kpad);
+    SPB_CHECK_LAUNCH();
+    return 0;
+  }
   SPN_T(dtype, hipLaunchKernelGGL(im2col_rgb_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, s, x, (bf16_t*)dst, B, H, W, KH, KW, stride, OH, OW, Kpad),
         hipLaunchKernelGGL(im2col_rgb_kernel<float>, dim3(grid_for(total)), dim3(256), 0, s, x, (float*)dst, B, H, W, KH, KW, stride, OH, OW, Kpad))
   SPB_CHECK_LAUNCH();

@@ -413,3 +413,25 @@ def test_rgb_stem_convolution(device, B):
     L.check(lib.spb_spn_stem(_vp(x), _vp(wp), _vp(bias), _vp(y), B, 227, 227, 11, 11, 4, 96, 544, 1, st), "spb_spn_stem")
     ref = F.relu(F.conv2d(x.to(torch.bfloat16).float(), w.to(torch.bfloat16).float(), bias, stride=4))
     assert rel(y.float().view(B, 55, 55, 96).permute(0, 3, 1, 2), ref) < 8e-3
+
+
+@pytest.mark.parametrize("B", [1, 5])
+def test_im2col_rgb_band_equals_gather(device, B):
+    """the column matrix of conv1 from the band kernel (image rows through LDS) is bit-identical to the per-element gather"""
+    import ctypes as C
+    from speedplusbaseline_amd import _lib as L
+    lib, st = L.lib(), C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    x = torch.randn(B, 3, 227, 227, generator=torch.Generator().manual_seed(B)).to(device)
+    cols = []
+    try:
+        for band in (0, 1):
+            lib.spb_debug_set_im2col_rgb_band(band)
+            col = torch.full((B * 55 * 55, 368), 7.0, dtype=torch.bfloat16, device=device)
+            L.check(lib.spb_im2col_rgb(L.BF16, _vp(x), _vp(col), B, 227, 227, 11, 11, 4, 368, st), "spb_im2col_rgb")
+            cols.append(col)
+    finally:
+        lib.spb_debug_set_im2col_rgb_band(1)
+    torch.cuda.synchronize()
+    assert torch.equal(cols[0], cols[1])
+    ref = torch.nn.functional.unfold(x.to(torch.bfloat16).float(), 11, stride=4).transpose(1, 2).reshape(B * 55 * 55, 363)
+    assert torch.equal(cols[1][:, :363].float(), ref) and float(cols[1][:, 363:].abs().max()) == 0.0
