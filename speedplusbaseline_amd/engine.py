@@ -156,10 +156,21 @@ class KrnEngine:
             L.check(self.lib.spb_krn_update_running(self.context(batch, slot), _stream()), "spb_krn_update_running")
 
     def backward(self, batch, slot=0, grads=None, gscale=1.0, with_pose=True, dlogit=None, alpha=0.0):
+        if with_pose and int(batch) > self.max_train_batch():
+            raise RuntimeError("per-GPU training batch %d is above this build's limit of %d (%s): the head's weight-gradient "
+                               "kernel keeps one [B,7,7,8] slab of the feature map in LDS; split the batch over more GPUs or "
+                               "accumulate two half batches" % (batch, self.max_train_batch(),
+                                                                "bf16" if self.dtype_code == PRECISIONS["bf16"] else "fp32"))
         ctx = self.context(batch, slot)
         with torch.cuda.device(self.device):
             L.check(self.lib.spb_krn_backward(ctx, _p(grads), float(gscale), 1 if with_pose else 0, _p(dlogit), float(alpha),
                                               _stream()), "spb_krn_backward")
+
+    def max_train_batch(self):
+        """largest per-GPU batch spb_head_bwd accepts (csrc/stem_head.hip: B*32 floats of upstream gradient + a [B,49,8] slab of
+        z in 160 KB of LDS): 179 in bf16, 96 in fp32.  The reference's recipes use 48 (README.md:87) and 16 (DANN)."""
+        el = 2 if self.dtype_code == PRECISIONS["bf16"] else 4
+        return (160 * 1024) // (32 * 4 + 49 * 8 * el)
 
     # ------------------------------------------------------------------------------------------------ live timing
     def set_side_stream(self, batch, slot=0, on=True):

@@ -144,3 +144,18 @@ def test_dataset_import_paths_of_the_reference():
     assert list(inspect.signature(build_transforms).parameters)[:4] == ["model_name", "input_size", "p_aug", "is_train"]
     with pytest.raises(RuntimeError):
         build_transforms("krn", (224, 224), device="cpu")
+
+
+def test_training_batch_limit_is_reported_before_the_library_is_called():
+    """spb_head_bwd keeps a [B,7,7,8] slab of z + [B,32] floats in 160 KB of LDS (csrc/stem_head.hip); the engine names the
+    limit instead of surfacing SPB_E_SHAPE (-2) from spb_krn_backward.  The reference's recipes use 48 and 16 (README.md:87,105)."""
+    from speedplusbaseline_amd.engine import KrnEngine, PRECISIONS
+    eng = KrnEngine(11)
+    eng.dtype_code = PRECISIONS["bf16"]
+    assert eng.max_train_batch() == 179 and 179 * (128 + 49 * 8 * 2) <= 160 * 1024 < 180 * (128 + 49 * 8 * 2)
+    with pytest.raises(RuntimeError, match="limit of 179"):
+        eng.backward(192)
+    eng.dtype_code = PRECISIONS["fp32"]
+    assert eng.max_train_batch() == 96
+    with pytest.raises(RuntimeError, match="limit of 96"):
+        eng.backward(128)
