@@ -279,7 +279,7 @@ def main():
 
     # ---- CPU baseline: the oracle's train step (reference --no_cuda fp32 path) on this box's host cores, rank 0 only
     cpu = None
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:   # N=1 only: the other ranks would sit in the process group meanwhile
         # PyTorch's CPU conv/BN kernels stop scaling (and then collapse: 504 s for 3 steps on 256 threads, measured) well
         # before a 256-core host is full; 32 threads is the best of {8,16,32,64,256} on this class of box
         ncores = min(os.cpu_count() or 1, args.cpu_threads)
@@ -469,7 +469,7 @@ def bench_dann(args):
                         alg_bytes_per_launch=round(dv["bytes"] / dv["launches"]),
                         step_sum_of_kernels_ms=round(sum(v["ms"] for v in agg.values()) / n_prof, 3))
     cpu = None
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:   # N=1 only: the other ranks would sit in the process group meanwhile
         ncores = min(os.cpu_count() or 1, args.cpu_threads)
         torch.set_num_threads(ncores)
         tr = O.DannTrainer(O.init_state(11, dann=True), "adamw", lr=1e-3, momentum=0.9, weight_decay=0.01)
@@ -573,7 +573,7 @@ def bench_spn(args):
                         avg_launch_us=round(us, 1), alg_bytes_per_launch=by,
                         note="timed alone as one arena-wide launch; in the step it runs as two launches (convolution range, heads) and the "
                              "heads' part overlaps the trunk's backward and the next step's trunk forward")
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:   # N=1 only: the other ranks would sit in the process group meanwhile
         from oracle import spn_oracle as S
         ncores = min(os.cpu_count() or 1, args.cpu_threads)
         torch.set_num_threads(ncores)
