@@ -10,6 +10,7 @@
 #include <string>
 #include <vector>
 #include <cstring>
+#include <cstdlib>
 #include <cstdio>
 #include "common.h"
 
@@ -471,9 +472,89 @@ __global__ void domain_tail_fwd_kernel(const void* D1, int dtype, const float* w
   if (threadIdx.x == 0) logits[b] = red[0] + red[1] + red[2] + red[3] + b3[0];
 }
 
-__global__ void domain_tail_bwd_kernel(const void* D1, void* Gd, int dtype, const float* w3, const float* pooled,
+// Backward of AvgPool2d(7) + Conv2d(1280,1,1) behind the ReLU of domain_classifier.0 (revgrad.py:75-80):
+//   dD1[b,hw,c] = dlogit[b]*w3[c]/HW * (D1 > 0)      dbias0[c] += sum_{b,hw} dD1      dw3[c] += sum_b dlogit[b]*pooled[b,c]
+// grid (C/64, row ranges of 128): a workgroup owns 64 channels (8 lanes x 8-channel 16-byte vectors) x 32 row lanes with
+// DTB_U rows of each lane in flight, so a launch is ONE memory round trip on some hundred workgroups.  (Round 1..2: one
+// thread per channel on C/256 = 5 workgroups walking all B*49 rows -- 2352 dependent iterations, ~0.6-1.2 ms per launch on
+// the critical path of both DANN passes.)  The element values are computed exactly as before; only the order of the
+// per-channel bias sum changed (32-lane LDS reduction, then one f32 atomic per channel and row range).
+constexpr int DTB_U = 4, DTB_ROWS = 32 * DTB_U;
+template <typename T> __device__ __forceinline__ void dtb_store8(T* p, const float g[8]);
+template <> __device__ __forceinline__ void dtb_store8<bf16_t>(bf16_t* p, const float g[8]) {
+  uint4 u;
+  u.x = pack_bf16x2(g[0], g[1]); u.y = pack_bf16x2(g[2], g[3]); u.z = pack_bf16x2(g[4], g[5]); u.w = pack_bf16x2(g[6], g[7]);
+  *reinterpret_cast<uint4*>(p) = u;
+}
+template <> __device__ __forceinline__ void dtb_store8<float>(float* p, const float g[8]) {
+  *reinterpret_cast<float4*>(p) = make_float4(g[0], g[1], g[2], g[3]);
+  *reinterpret_cast<float4*>(p + 4) = make_float4(g[4], g[5], g[6], g[7]);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void domain_tail_bwd_kernel(const T* D1, T* Gd, const float* w3, const float* pooled,
+                                                              const float* dlogit, float* dw3, float* db3, float* dbias0,
+                                                              int B, int HW, int C) {
+  __shared__ float red[32][65];
+  const int t = threadIdx.x, v = t & 7, sub = t >> 3;
+  const int cb = blockIdx.x * 64, c0 = cb + v * 8;
+  const bool cok = c0 < C;                       // C % 8 == 0 (the 1x1 convolution above requires it)
+  const int cc = cok ? c0 : 0;
+  const int rows = B * HW;
+  const int r0 = blockIdx.y * DTB_ROWS, r1 = min(rows, r0 + DTB_ROWS);
+  const float hw = (float)HW;
+  float w[8], gb[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { w[j] = w3[cc + j]; gb[j] = 0.f; }
+  Raw8<T> raw[DTB_U];
+  float dl[DTB_U];
+#pragma unroll
+  for (int u = 0; u < DTB_U; ++u) {              // every load first, on clamped rows
+    const int ru = r0 + sub + 32 * u;
+    const int rc = ru < r1 ? ru : r1 - 1;
+    raw[u] = ldraw<T>(D1 + (size_t)rc * C + cc);
+    dl[u] = dlogit[rc / HW];
+  }
+#pragma unroll
+  for (int u = 0; u < DTB_U; ++u) {
+    const int ru = r0 + sub + 32 * u;
+    if (ru < r1 && cok) {
+      float d[8], g[8];
+      cvt8(raw[u], d);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) g[j] = d[j] > 0.f ? dl[u] * w[j] / hw : 0.f;
+      rnd8<T>(g);
+      dtb_store8<T>(Gd + (size_t)ru * C + c0, g);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) gb[j] += g[j];
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) red[sub][v * 8 + j] = gb[j];
+  __syncthreads();
+  if (t < 64 && cb + t < C) {
+    const int c = cb + t;
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) s += red[i][t];
+    atomicAdd(dbias0 + c, s);
+    if (blockIdx.y == 0) {                       // single writer per channel
+      float gw = 0.f;
+      for (int b = 0; b < B; ++b) gw += dlogit[b] * pooled[(size_t)b * C + c];
+      dw3[c] += gw;
+    }
+  }
+  if (blockIdx.x == 0 && blockIdx.y == 0 && t == 64) {
+    float s = 0.f;
+    for (int b = 0; b < B; ++b) s += dlogit[b];
+    db3[0] += s;
+  }
+}
+
+__global__ void domain_tail_bwd_ref_kernel(const void* D1, void* Gd, int dtype, const float* w3, const float* pooled,
                                        const float* dlogit, float* dw3, float* db3, float* dbias0, int B, int HW, int C) {
-  // one block per channel slab of 256: dD1[b,hw,c] = dlogit[b]*w3[c]/HW * (D1>0);  dw3[c] += sum_b dlogit[b]*pooled[b,c]
+  // REFERENCE for the row-parallel kernel above (SPB_DOMAIN_TAIL_REF=1; the rounds-1..2 kernel: serial over rows, exact same element
+  // arithmetic).  One block per channel slab of 256: dD1[b,hw,c] = dlogit[b]*w3[c]/HW * (D1>0);  dw3[c] += sum_b dlogit[b]*pooled[b,c]
   const int cidx = blockIdx.x * 256 + threadIdx.x;
   if (cidx < C) {
     float gw = 0.f, gb0 = 0.f;
@@ -506,6 +587,7 @@ __global__ void domain_tail_bwd_kernel(const void* D1, void* Gd, int dtype, cons
     db3[0] += s;
   }
 }
+
 
 __global__ void bce_logits_kernel(const float* logits, float label, int B, float* loss, float* dlogit, float gscale) {
   // binary_cross_entropy_with_logits(reduction='mean') against a constant label (dann.py:85-92)
@@ -819,10 +901,23 @@ extern "C" int spb_krn_backward(spb_krn_ctx_t* c, float* grads, float gscale, in
   void* ddom = nullptr;
   if (dlogit) {  // domain classifier backward, then the gradient-reversal layer (-alpha) into the feature
     r.tic(PC_DOMAIN, ((double)c->B * 49 * (3 * 1280 + 2 * 320) + 2 * 320.0 * 1280) * r.es(), 4.0 * c->B * 49 * 320 * 1280);
-    hipLaunchKernelGGL(domain_tail_bwd_kernel, dim3((1280 + 255) / 256), dim3(256), 0, st,
-                       (const void*)(c->ws + c->dom1_off), (void*)(c->ws + c->gdom_off), dt,
-                       (const float*)(m->P + m->dc3_w_off), (const float*)(c->ws + c->dompool_off), dlogit,
-                       m->G + m->dc3_w_off, m->G + m->dc3_b_off, m->G + m->dc0.bias_off, c->B, 49, 1280);
+    const dim3 tgrid((1280 + 63) / 64, (c->B * 49 + DTB_ROWS - 1) / DTB_ROWS);
+    const char* tail_ref = std::getenv("SPB_DOMAIN_TAIL_REF");      // test rig: the serial reference kernel
+    if (tail_ref && tail_ref[0] == '1')
+      hipLaunchKernelGGL(domain_tail_bwd_ref_kernel, dim3((1280 + 255) / 256), dim3(256), 0, st,
+                         (const void*)(c->ws + c->dom1_off), (void*)(c->ws + c->gdom_off), dt,
+                         (const float*)(m->P + m->dc3_w_off), (const float*)(c->ws + c->dompool_off), dlogit,
+                         m->G + m->dc3_w_off, m->G + m->dc3_b_off, m->G + m->dc0.bias_off, c->B, 49, 1280);
+    else if (dt == SPB_BF16)
+      hipLaunchKernelGGL(domain_tail_bwd_kernel<bf16_t>, tgrid, dim3(256), 0, st,
+                         (const bf16_t*)(c->ws + c->dom1_off), (bf16_t*)(c->ws + c->gdom_off),
+                         (const float*)(m->P + m->dc3_w_off), (const float*)(c->ws + c->dompool_off), dlogit,
+                         m->G + m->dc3_w_off, m->G + m->dc3_b_off, m->G + m->dc0.bias_off, c->B, 49, 1280);
+    else
+      hipLaunchKernelGGL(domain_tail_bwd_kernel<float>, tgrid, dim3(256), 0, st,
+                         (const float*)(c->ws + c->dom1_off), (float*)(c->ws + c->gdom_off),
+                         (const float*)(m->P + m->dc3_w_off), (const float*)(c->ws + c->dompool_off), dlogit,
+                         m->G + m->dc3_w_off, m->G + m->dc3_b_off, m->G + m->dc0.bias_off, c->B, 49, 1280);
     spb_gemm_args_t g; std::memset(&g, 0, sizeof(g));
     g.A = c->ws + c->gdom_off; g.Bw = r.wc(m->dc0.wct_off); g.Y = c->ws + c->ddom_off; g.pro = Runner::ident(1280);
     g.M = c->B * 49; g.K = 1280; g.N = 320; g.pro_mode = 2; g.epi_mode = 0; g.oR = 1; g.out_scale = -alpha;
