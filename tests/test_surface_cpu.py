@@ -159,3 +159,35 @@ def test_training_batch_limit_is_reported_before_the_library_is_called():
     assert eng.max_train_batch() == 96
     with pytest.raises(RuntimeError, match="limit of 96"):
         eng.backward(128)
+
+
+def test_product_never_touches_the_oracle_and_fails_loudly_without_the_library(monkeypatch):
+    """oracle/ is test infrastructure: nothing under the package, the reference-path aliases (src/) or the CLI scripts may import,
+    open or execute it; and a missing libspb_hip.so is an error, not a fallback."""
+    import ast
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    product = [os.path.join(root, f) for f in ("train.py", "adapt.py", "test.py", "config.py")]
+    for top in ("speedplusbaseline_amd", "src"):
+        for d, _dirs, files in os.walk(os.path.join(root, top)):
+            product += [os.path.join(d, f) for f in files if f.endswith(".py")]
+    assert len(product) > 30
+    for path in product:
+        text = open(path).read()
+        for node in ast.walk(ast.parse(text)):
+            mods = []
+            if isinstance(node, ast.Import):
+                mods = [a.name for a in node.names]
+            elif isinstance(node, ast.ImportFrom):
+                mods = [node.module or ""]
+            assert not any(m == "oracle" or m.startswith("oracle.") for m in mods), path
+        assert not re.search(r"""['"/]oracle['"/]""", text), path          # no path to oracle/ either
+    for path in (os.path.join(root, "speedplusbaseline_amd", "csrc"), os.path.join(root, "include")):
+        for f in os.listdir(path):
+            if f.endswith((".hip", ".h")):
+                assert "oracle" not in open(os.path.join(path, f)).read(), f
+
+    from speedplusbaseline_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", os.path.join(root, "speedplusbaseline_amd", "no_such_libspb_hip.so"))
+    with pytest.raises(RuntimeError, match="no CPU or PyTorch fallback"):
+        _lib.lib()
