@@ -11,9 +11,11 @@ What it restates (reference file:line):
     park2019.py:107-108): restated from the published architecture -- stem 3x3/s2 conv 3->32 + BN + ReLU6, then
     InvertedResidual (t,c,n,s) = (1,16,1,1),(6,24,2,2),(6,32,3,2),(6,64,4,2),(6,96,3,1),(6,160,3,2),(6,320,1,1),
     each [1x1 expand+BN+ReLU6 if t!=1] -> dw3x3(stride)+BN+ReLU6 -> 1x1 project+BN, skip iff stride 1 and Cin==Cout.
-    PARITY UNPINNED for this sub-graph: the reference holds no test or golden vector at the torchvision boundary and
-    torchvision is not installed here; what is pinned is the parameter count (5 643 862), the 350 state-dict keys /
-    shapes, the block-13 tap depth (96) and the [B,320,7,7] feature the reference's own code relies on.
+    PARITY UNPINNED against torchvision itself for this sub-graph: the reference holds no test or golden vector at the
+    torchvision boundary and torchvision is not installed here; what is pinned is the parameter count (5 643 862), the
+    350 state-dict keys / shapes, the block-13 tap depth (96), the [B,320,7,7] feature the reference's own code relies
+    on, and the arithmetic against an independent third-party implementation of the same published architecture
+    (Hugging Face transformers' MobileNetV2Model with these weights: tests/test_backbone_pin_cpu.py, 1e-9 in float64).
 Everything the reference itself wrote is pinned by tests/golden/*.npz (generated from the imported reference modules by
 tests/golden/make_golden.py).
 

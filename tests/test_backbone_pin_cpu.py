@@ -1,7 +1,8 @@
 """Known-answer checks for the MobileNetV2 backbone that do NOT pass through this repository's own
 builder or stand-in: the published torchvision==0.9 `mobilenet_v2` state-dict layout and parameter counts, written out
 here as literals.  torchvision is a third-party dependency absent from /root/reference and from this image, so the
-sub-graph's VALUES stay "parity unpinned"  until a torchvision-produced tensor is available; what these
+sub-graph's VALUES have no torchvision-produced vector; they are held to an independent third-party
+implementation of the published architecture instead (last test of this file).  What the other
 tests pin is everything the reference's own code relies on at that boundary (park2019.py:107-108,130-132; revgrad.py:71):
 key names, shapes, counts, and -- when SPB_MOBILENETV2_WEIGHTS points at a real `mobilenet_v2-*.pth` -- strict loading.
 """
@@ -113,3 +114,69 @@ def test_real_torchvision_checkpoint_loads_strictly():
     got = model.state_dict()
     for k, s in published_feature_keys():
         assert tuple(sd[k].shape) == s and torch.equal(got["base." + k[len("features."):]], sd[k]), k
+
+
+def _hf_backbone():
+    """Hugging Face transformers' MobileNetV2Model: an implementation of the published architecture written by a third party
+    (torch.nn modules wired from Sandler et al. 2018), configured like torchvision 0.9's mobilenet_v2: symmetric (k-1)//2
+    padding instead of TF 'SAME', BatchNorm eps 1e-5, ReLU6, width 1.0, expansion 6, output stride 32."""
+    transformers = pytest.importorskip("transformers")
+    cfg = transformers.MobileNetV2Config(tf_padding=False, layer_norm_eps=1e-5, depth_multiplier=1.0, expand_ratio=6.0,
+                                         output_stride=32, first_layer_is_expansion=True, finegrained_output=True,
+                                         hidden_act="relu6")
+    return transformers.MobileNetV2Model(cfg, add_pooling_layer=False)
+
+
+def _copy_oracle_state_into_hf(hf, sd, prefix="base."):
+    """torchvision layout -> HF layout.  features[0] / features[1] are HF's conv_stem (first_conv; conv_3x3 + reduce_1x1),
+    features[k], k = 2..17, is HF's layer[k-2] (expand_1x1, conv_3x3, reduce_1x1); HF's conv_1x1 is features[18], which the
+    reference drops (park2019.py:107-108) -- it keeps its own initialisation and its output is not looked at."""
+    pairs = [("conv_stem.first_conv", "0.0", "0.1"), ("conv_stem.conv_3x3", "1.conv.0.0", "1.conv.0.1"),
+             ("conv_stem.reduce_1x1", "1.conv.1", "1.conv.2")]
+    for k in range(2, 18):
+        p = "%d.conv." % k
+        pairs += [("layer.%d.expand_1x1" % (k - 2), p + "0.0", p + "0.1"), ("layer.%d.conv_3x3" % (k - 2), p + "1.0", p + "1.1"),
+                  ("layer.%d.reduce_1x1" % (k - 2), p + "2", p + "3")]
+    hsd, used = hf.state_dict(), set()
+    with torch.no_grad():
+        for h, conv, bn in pairs:
+            hsd[h + ".convolution.weight"].copy_(sd[prefix + conv + ".weight"]); used.add(prefix + conv + ".weight")
+            for f in ("weight", "bias", "running_mean", "running_var"):
+                hsd[h + ".normalization." + f].copy_(sd[prefix + bn + "." + f]); used.add(prefix + bn + "." + f)
+    return used
+
+
+@pytest.mark.parametrize("training", [False, True])
+def test_oracle_backbone_arithmetic_matches_an_independent_implementation(training):
+    """a2's VALUES against code this repository did not write: the oracle's functional restatement of torchvision-0.9
+    mobilenet_v2.features[:-1] (oracle/krn_oracle.py krn_features) and Hugging Face's MobileNetV2Model carry the same
+    weights and must agree on the block-13 tap the reference routes into RouterV2 (park2019.py:130-132), on the block-17
+    feature that feeds the extras and RevGrad's hook (park2019.py:134; revgrad.py:71), and on every block output in
+    between -- in evaluation (running statistics) and in training mode (batch statistics).  This is not torchvision itself
+    (absent from the image), so DESIGN.md keeps the row at 'pinned to an independent implementation of the published
+    architecture', one step short of a torchvision-produced tensor."""
+    from oracle import krn_oracle as O
+    hf = _hf_backbone().double()
+    sd = O.init_state(11, dtype=torch.float64)
+    g = torch.Generator().manual_seed(5)
+    for k in list(sd):      # non-trivial running statistics, so the evaluation leg does not run on (0, 1)
+        if k.endswith("running_mean"):
+            sd[k] = 0.1 * torch.randn(sd[k].shape, generator=g, dtype=torch.float64)
+        elif k.endswith("running_var"):
+            sd[k] = 0.5 + torch.rand(sd[k].shape, generator=g, dtype=torch.float64)
+    used = _copy_oracle_state_into_hf(hf, sd)
+    # every backbone tensor of the oracle went into the third-party model, nothing else did
+    mine = {k for k in sd if k.startswith("base.") and not k.endswith("num_batches_tracked")}
+    assert used == mine and len(used) == 51 * 5      # 51 convolutions (stem, 2 in block 1, 3 in each of blocks 2..17), each with its BatchNorm
+    x, _ = O.synth_batch(3, tag="hfpin")
+    x = x.double()
+    hf.train(training)
+    with torch.no_grad():
+        out = hf(x, output_hidden_states=True)
+        feat, tap = O.krn_features({k: v.clone() for k, v in sd.items()}, x, training)
+    hs = out.hidden_states          # hs[i] = output of layer[i] = torchvision features[i + 2]
+    assert len(hs) == 16
+    assert tuple(tap.shape) == (3, 96, 14, 14) and tuple(feat.shape) == (3, 320, 7, 7)
+    torch.testing.assert_close(hs[11], tap, rtol=1e-9, atol=1e-10)      # features[13]
+    torch.testing.assert_close(hs[15], feat, rtol=1e-9, atol=1e-10)     # features[17]
+    assert float(feat.abs().mean()) > 1e-3
