@@ -37,4 +37,8 @@ cp $(find /tmp/p_sf -name "*counter_collection.csv" | head -1) $OUT/spn_fetch.cs
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/p_sw -o w -- python $ROOT/bench.py --model spn --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2> $OUT/spn_write.err
 cp $(find /tmp/p_sw -name "*counter_collection.csv" | head -1) $OUT/spn_write.csv
 python $ROOT/scratch/pmc_spn_summary.py $OUT/spn_fetch.csv $OUT/spn_write.csv $OUT/spn_pmc_traffic.json > $OUT/spn_pmc_summary.txt 2>&1
+# DANN (bs=48 source + 48 target): kernel stats of the bench command -- the round-2 domain-tail finding (a 5-workgroup kernel of
+# ~1 ms on the critical path) was visible only in the per-family table of the bench line; this puts it under profiles/ too
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_dann -o dann -- python $ROOT/bench.py --model dann --steps 20 --warmup 5 --no-cpu-baseline > $OUT/dann_bench_under_rocprof.json 2> $OUT/dann.err
+cp $(find /tmp/p_dann -name "*kernel_stats.csv" | head -1) $OUT/dann_kernel_stats.csv
 ls -la $OUT
