@@ -124,7 +124,8 @@ def main():
                     ("SPB_PLAIN_DMA", "spb_debug_set_gemm_plain_dma"), ("SPB_DW_XCD", "spb_debug_set_dw_xcd"),
                     ("SPB_REPLICA_ROWS", "spb_debug_set_replica_rows"), ("SPB_BK64_DGRAD_MIN_K", "spb_debug_set_gemm_bk64_dgrad_min_k"),
                     ("SPB_WGRAD_BATCH", "spb_debug_set_wgrad_batch"), ("SPB_WGRAD_MIN_FLUSH", "spb_debug_set_wgrad_min_flush"),
-                    ("SPB_LAUNCH_EVENTS", "spb_debug_set_launch_events"), ("SPB_DW_SPLIT", "spb_debug_set_dw_split")):
+                    ("SPB_LAUNCH_EVENTS", "spb_debug_set_launch_events"), ("SPB_DW_SPLIT", "spb_debug_set_dw_split"),
+                    ("SPB_DW_PLANE_W", "spb_debug_set_dw_plane_max_w"), ("SPB_WGRAD_TARGET", "spb_debug_set_wgrad_target")):
         if os.environ.get(env) is not None:
             getattr(_L.lib(), fn)(int(os.environ[env]))
     if os.environ.get("SPB_STEM_GRID"):      # "fwd,wgrad" workgroup caps

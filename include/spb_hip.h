@@ -302,7 +302,9 @@ int spb_krn_ctx_set_side_stream(spb_krn_ctx_t* c, int on);
 /* refresh compute-dtype weight copies (W, W^T, permuted head) from the f32 parameters */
 int spb_krn_prepare_weights(spb_krn_t* m, spb_stream_t stream);
 /* forward.  training=1: batch statistics + running-stat update; training=2: batch statistics, the running-stat update is
- * left to a later spb_krn_update_running (two passes on two streams, see below).  target NULL => prediction only.
+ * left to a later spb_krn_update_running (two passes on two streams, see below).  training | 4: spb_krn_prepare_weights first,
+ * on the context's side stream beside the stem and the first depthwise layer (they read the f32 parameters), joined before the
+ * first 1x1 convolution.  target NULL => prediction only.
  * pred [B][2K] f32 (interleaved x,y as the head emits them), scalars [3] = loss, loss_x, loss_y.
  * alpha_valid=1 with a dann plan also runs the domain classifier: domain_logits [B].                           */
 int spb_krn_forward(spb_krn_ctx_t* c, const float* x_nchw, const float* target, int training, float* pred,
@@ -514,9 +516,9 @@ int spb_preproc_batch(const spb_preproc_args_t* a, spb_stream_t stream);
 /* debug / test helpers */
 int spb_debug_set_conv9_band(int on); /* decoder's last 9x9 layer: band-staged kernel (1, default) or the generic 8x8-tile kernel */
 int spb_debug_set_launch_events(int on); /* side-stream forks wait on the preceding GEMM launch's completion event (1) or on a recorded event (0) */
-int spb_debug_set_dw_split(int rows);      /* depthwise layers with fewer than `rows` input rows (B*H*W) run their weight gradient on
-                                              the side stream, apart from the input gradient (default 0 = always fused: the split measured slower) */
+int spb_debug_set_dw_split(int hw);        /* depthwise layers on maps up to `hw` columns wide run their weight gradient on the side stream (default 56: every depthwise layer below the 112x112 maps; 0: always fused) */
 int spb_debug_set_wgrad_min_flush(int n); /* fork at a depthwise backward kernel only when >= n weight gradients are queued */
+int spb_debug_set_wgrad_target(int wgs); /* pointwise weight gradient: row splits chosen for about this many workgroups per launch (every split adds N*K f32 atomics) */
 int spb_debug_set_wgrad_batch(int n); /* pointwise weight-gradient GEMMs handed to the side stream per fork event */
 int spb_debug_set_gemm_bk64_dgrad_min_k(int k); /* backward-type small-M GEMMs with K >= k: 64x32 tiles with 64-deep chunks */
 int spb_debug_set_replica_rows(long long rows); /* BatchNorm batch sums get 8 atomic replicas for tensors with at least this many rows (contexts created afterwards) */
@@ -526,17 +528,20 @@ int spb_debug_set_gemm_plain_dma(int on); /* pro_mode 0 bf16 GEMMs: LDS-DMA ring
 int spb_debug_set_optim(int vec, int per_thread, int nontemporal); /* optimizer launch shape A/B: lanes of 1|4 floats, 1|2|4 per thread, nt accesses */
 int spb_debug_trread(const unsigned short* in4096, unsigned short* out256, spb_stream_t stream);
 int spb_debug_set_gemm_dma(int on); /* 1: small-M bf16 pointwise GEMMs use the LDS-DMA ring kernel (default 0) */
-int spb_debug_set_dw_mode(int mode); /* depthwise fwd/dgrad: 1 row-unit kernels (default), 0 LDS-tiled kernels */
+int spb_debug_set_dw_mode(int mode); /* depthwise fwd/dgrad: 1 plane kernels on maps up to spb_debug_set_dw_plane_max_w columns wide (14x14 and 7x7 by default), row-unit kernels elsewhere (default); 0 row-unit kernels only */
 int spb_debug_set_fused_pw_bwd(int on); /* 0: the KRN plan never uses spb_pwconv_bwd_fused */
 int spb_debug_set_stem_mfma(int on); /* 0: bf16 stem uses the scalar kernels instead of the MFMA implicit GEMM */
 int spb_debug_set_gemm_bk64_min_k(int k); /* small-M bf16 GEMMs with K >= k use 64-wide reduction chunks (default 256) */
 int spb_debug_set_gconv_slab(int mode); /* wide decoder convs: 0 per-wave weight streaming; 1 slab kernel with 4 tiles (1 workgroup per CU); 2 (default) 2 tiles, 2 per CU */
 int spb_debug_set_side_wgrad(int on); /* 0: pointwise weight gradients stay on the launch stream */
 int spb_debug_set_dw_rows(int rows); /* rows per row unit (0: automatic) */
+int spb_debug_set_dw_plane_max_w(int w); /* depthwise plane kernels: widest feature map they take (default 14; at most 28) */
+int spb_debug_set_dw_plane_min_wgs(int n); /* depthwise plane kernels: fewer images per workgroup while the launch has fewer workgroups than n (default 384) */
 int spb_debug_set_im2col_rgb_band(int on); /* SPN conv1 column matrix: 1 = band kernel (image rows through LDS), 0 = per-element gather */
 int spb_debug_set_gconv_slab_pf(int n); /* wide decoder convs: weight slabs in flight per workgroup (3 | 6, default 6) */
 int spb_debug_set_gconv_halo_prefetch(int on); /* decoder convs with LDS-resident weights: prefetch the next tile's halo (1, default) */
 int spb_debug_set_gconv_wlds_pxg(int n); /* decoder convs with LDS-resident weights: 8x8 tiles per workgroup side by side (1 | 2) */
+int spb_debug_set_gemm_os(int on, int min_k, int max_n, int min_m); /* small-map bf16 GEMMs with min_k <= K <= 576, N <= max_n (<= 96), M >= min_m: one-shot kernel (on=1, default; 0 arguments keep the defaults 160 / 96 / 4096) */
 int spb_debug_set_gemm_sk(int on, int min_k, int rf); /* small-M bf16 GEMMs with K >= min_k (default 192): split-K-over-waves kernel (on=1, default); rf > 0 forces 16*rf-row tiles */
 const char* spb_version(void);
 

@@ -198,6 +198,7 @@ SYMBOLS = {
     "spb_debug_set_dw_split": (i32, [i32]),
     "spb_debug_set_wgrad_min_flush": (i32, [i32]),
     "spb_debug_set_wgrad_batch": (i32, [i32]),
+    "spb_debug_set_wgrad_target": (i32, [i32]),
     "spb_debug_set_gemm_bk64_dgrad_min_k": (i32, [i32]),
     "spb_debug_set_replica_rows": (i32, [i64]),
     "spb_debug_set_dw_xcd": (i32, [i32]),
@@ -226,7 +227,10 @@ SYMBOLS = {
     "spb_debug_set_stem_mfma": (i32, [i32]),
     "spb_debug_set_fused_pw_bwd": (i32, [i32]),
     "spb_debug_set_dw_rows": (i32, [i32]),
+    "spb_debug_set_dw_plane_min_wgs": (i32, [i32]),
+    "spb_debug_set_dw_plane_max_w": (i32, [i32]),
     "spb_debug_set_gemm_sk": (i32, [i32, i32, i32]),
+    "spb_debug_set_gemm_os": (i32, [i32, i32, i32, i32]),
     "spb_debug_set_gconv_wlds_pxg": (i32, [i32]),
     "spb_debug_set_gconv_halo_prefetch": (i32, [i32]),
     "spb_debug_set_im2col_rgb_band": (i32, [i32]),

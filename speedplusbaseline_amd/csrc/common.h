@@ -129,6 +129,10 @@ typedef spb_bnref_t BNRef;
 // kept the replica count of the small tensors at 1 and their atomics serialised on one address.
 #define SPB_MAX_REPLICAS 8
 __device__ __forceinline__ void bn_replica_sums(const float* base, int R, int C, int c, float& a, float& b) {
+  if (R == 1) {   // (uniform) most tensors -- every map below 56x56 at bs=48 -- have one replica: 2 loads instead of 16 clamped ones
+    a = base[c]; b = base[C + c];
+    return;
+  }
   float va[SPB_MAX_REPLICAS], vb[SPB_MAX_REPLICAS];
 #pragma unroll
   for (int i = 0; i < SPB_MAX_REPLICAS; ++i) {
@@ -213,6 +217,22 @@ template <int CTRL> __device__ __forceinline__ float spb_dpp_f(float v) {
 __device__ __forceinline__ float row16_sum(float v) {
   v += spb_dpp_f<0xB1>(v); v += spb_dpp_f<0x4E>(v); v += spb_dpp_f<0x141>(v); v += spb_dpp_f<0x140>(v);
   return v;
+}
+// v[lane] + v[lane ^ 32] and v[lane] + v[lane ^ 16] in every lane, on the vector ALU: gfx950's v_permlane32_swap / v_permlane16_swap
+// exchange the upper half (the odd 16-lane rows) of the first operand with the lower half (the even rows) of the second.
+// Inline asm on purpose: __builtin_amdgcn_permlane32_swap / 16_swap are miscompiled by this hipcc when both operands are the same
+// value (the second result register is dropped: scratch/probe_permlane.hip, checked on the GPU), and __shfl_xor is a
+// ds_bpermute_b32 -- an LDS round trip per step that serialises reductions inside loops (a 9-tap loop with 16 of them per tap:
+// 1.2 us per tap, measured in the depthwise plane kernel).
+__device__ __forceinline__ float xor32_sum(float v) {
+  float a = v, b = v;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+  return a + b;
+}
+__device__ __forceinline__ float xor16_sum(float v) {
+  float a = v, b = v;
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+  return a + b;
 }
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -1,7 +1,8 @@
 // Depthwise 3x3 convolution, "row unit" kernels: forward and fused backward (input gradient + weight gradient).
-// Same contract as dwconv.hip (reference park2019.py:47-49, torchvision MobileNetV2 inverted residual, park2019.py:107-108).
+// Replaces nn.Conv2d(groups=C, k=3) + BatchNorm2d + ReLU6/ReLU of reference park2019.py:47-49 and of the torchvision MobileNetV2
+// inverted residual (park2019.py:107-108); C-ABI: spb_dwconv_fwd / _dgrad / _wgrad (include/spb_hip.h), at the end of this file.
 //
-// Why a second formulation.  The tiled kernels in dwconv.hip stage an 8x8 window in LDS and read 9 taps x (32 B data +
+// Why this formulation.  The first, LDS-tiled kernels (retired: scratch/dwconv_tiled_retired.hip) staged an 8x8 window in LDS and read 9 taps x (32 B data +
 // 32 B weights) per pixel and 8 channels from it.  Ablation on MI355X (scratch/ubench_dwbwd.hip) showed that to be
 // LDS-bandwidth bound: half of the kernel time is the tap loop at ~2x the 128 B/clk/CU LDS floor, and another 40 % is
 // the staging + 3 barriers per tile.  Here the taps never touch LDS:
@@ -677,5 +678,62 @@ int spb_dwr_bwd(int dtype, const spb_dw_args_t* a, hipStream_t s) {
   else { if (st == 1) P_(float, 1) else P_(float, 2) }
 #undef P_
 #undef L_
+  return 0;
+}
+
+// ---- C-ABI of the depthwise convolution (include/spb_hip.h): shape checks and the choice between the two kernel
+// families.  Small maps (width <= 28: the 28x28 / 14x14 / 7x7 tensors of KRN) go to the one-round-trip plane kernels
+// (dwconv_plane.hip), everything else and the stand-alone weight gradient to the row-unit kernels above.
+int spb_dwp_fwd(int dtype, const spb_dw_args_t* a, hipStream_t s);   // dwconv_plane.hip; SPB_E_UNSUPPORTED: not covered
+int spb_dwp_bwd(int dtype, const spb_dw_args_t* a, hipStream_t s);
+static int g_dw_mode = 1;   // 1: plane kernels where they apply (default); 0: row-unit kernels only
+extern "C" int spb_debug_set_dw_mode(int mode) { g_dw_mode = mode; return 0; }
+
+static int dw_check(const spb_dw_args_t* a) {
+  if (!a || !a->X || !a->Wd) return SPB_E_ARG;
+  if (a->B <= 0 || a->H <= 0 || a->W <= 0 || a->C <= 0 || (a->C & 7)) return SPB_E_SHAPE;
+  if (a->stride != 1 && a->stride != 2) return SPB_E_SHAPE;
+  return 0;
+}
+
+extern "C" int spb_dwconv_fwd(int dtype, const spb_dw_args_t* a, spb_stream_t stream) {
+  int e = dw_check(a);
+  if (e) return e;
+  if (!a->Y || (a->epi_mode == 1 && (!a->osums || a->oR < 1))) return SPB_E_ARG;
+  if (dtype != SPB_BF16 && dtype != SPB_F32) return SPB_E_ARG;
+  if (g_dw_mode != 1 || spb_dwp_fwd(dtype, a, (hipStream_t)stream) == SPB_E_UNSUPPORTED)
+    spb_dwr_fwd(dtype, a, (hipStream_t)stream);
+  SPB_CHECK_LAUNCH();
+  return 0;
+}
+
+// dW != NULL fuses the weight gradient into the same pass: then Zout must be the input tensor of the convolution and
+// `epi` its BN/activation (what spb_dwconv_wgrad takes as Xin / pro_in), also when epi_mode == 0.
+extern "C" int spb_dwconv_dgrad(int dtype, const spb_dw_args_t* a, spb_stream_t stream) {
+  int e = dw_check(a);
+  if (e) return e;
+  if (!a->Y) return SPB_E_ARG;
+  if (a->epi_mode == 2 && (!a->osums || a->oR < 1 || !a->Zout)) return SPB_E_ARG;
+  if (a->dW != nullptr && !a->Zout) return SPB_E_ARG;
+  if (dtype != SPB_BF16 && dtype != SPB_F32) return SPB_E_ARG;
+  spb_dw_args_t k = *a;
+  if (!k.X2) k.X2 = k.X;  // no BN behind the convolution: p1 == 0, the kernel still reads a (finite) second operand
+  if (g_dw_mode != 1 || spb_dwp_bwd(dtype, &k, (hipStream_t)stream) == SPB_E_UNSUPPORTED)
+    spb_dwr_bwd(dtype, &k, (hipStream_t)stream);
+  SPB_CHECK_LAUNCH();
+  return 0;
+}
+
+// weight gradient alone (row-unit kernel, weight-gradient-only instance: the input tensor travels as Zout / epi there)
+extern "C" int spb_dwconv_wgrad(int dtype, const spb_dw_args_t* a, spb_stream_t stream) {
+  int e = dw_check(a);
+  if (e) return e;
+  if (!a->dW || !a->Xin) return SPB_E_ARG;
+  if (dtype != SPB_BF16 && dtype != SPB_F32) return SPB_E_ARG;
+  spb_dw_args_t k = *a;
+  k.Zout = a->Xin; k.epi = a->pro_in; k.Y = nullptr; k.epi_mode = 0; k.res = nullptr;
+  if (!k.X2) k.X2 = k.X;
+  spb_dwr_wgrad(dtype, &k, (hipStream_t)stream);
+  SPB_CHECK_LAUNCH();
   return 0;
 }

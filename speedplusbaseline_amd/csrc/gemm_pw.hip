@@ -20,6 +20,7 @@
 #include <hip/hip_ext.h>
 
 int spb_gemm_sk(const spb_gemm_args_t* a, hipStream_t stream);   // gemm_sk.hip
+int spb_gemm_os(const spb_gemm_args_t* a, hipStream_t stream);   // gemm_os.hip
 
 // phase timestamps for scratch/ubench_gemm.hip (compiled out in the product build)
 #ifndef SPB_TS
@@ -75,9 +76,6 @@ __global__ __launch_bounds__(256, (RF == 1 && sizeof(T) == 2) ? ((BK == 64 && PR
   const int l = t & 63, w = t >> 6;
   const int li = l & 15, lq = l >> 4;
 
-  // ---- prologue coefficients for every reduction channel (derived from the producer's raw batch sums)
-  bn_coef_table<PRO == 1 ? 1 : 2>(g.pro, K, Kp, coef, t);
-
   const int NT = (N + BN - 1) / BN;
   const int MT = (M + BM - 1) / BM;
   const int lid = xcd_remap(blockIdx.x, gridDim.x);
@@ -97,18 +95,6 @@ __global__ __launch_bounds__(256, (RF == 1 && sizeof(T) == 2) ? ((BK == 64 && PR
   // (With mean/invstd/scale/shift in registers this variant sat at 164 VGPRs = 2 workgroups per CU, and the
   // 882-workgroup layers ran in two rounds.)
   float e_bias[8];
-  if (EPI == 2) {
-    for (int c = t; c < BN; c += 256) {
-      float sc = 1.f, sh = 0.f;
-      if (n0 + c < N && g.epi.gamma != nullptr) {
-        float mu, is;
-        bn_moments(g.epi, n0 + c, mu, is);
-        sc = g.epi.gamma[n0 + c] * is;
-        sh = g.epi.beta[n0 + c] - mu * sc;
-      }
-      ecoef[c] = sc; ecoef[BN + c] = sh;
-    }
-  }
   if (EPI == 0) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) e_bias[j] = (colok && g.bias) ? g.bias[nE + j] : 0.f;
@@ -201,9 +187,25 @@ __global__ __launch_bounds__(256, (RF == 1 && sizeof(T) == 2) ? ((BK == 64 && PR
       }                                                                                                        \
     }
 
+  // the first two operand chunks go out BEFORE the coefficient table: the table's loads (the producer's batch sums) and
+  // the operand loads then share one memory round trip instead of following each other
   if (lid / NT < MT) {
     LOAD_TILE(0, (lid / NT) * BM, 0);
     if (KT > 1) LOAD_TILE(1, (lid / NT) * BM, 1);
+  }
+  // ---- prologue coefficients for every reduction channel (derived from the producer's raw batch sums)
+  bn_coef_table<PRO == 1 ? 1 : 2>(g.pro, K, Kp, coef, t);
+  if (EPI == 2) {
+    for (int c = t; c < BN; c += 256) {
+      float sc = 1.f, sh = 0.f;
+      if (n0 + c < N && g.epi.gamma != nullptr) {
+        float mu, is;
+        bn_moments(g.epi, n0 + c, mu, is);
+        sc = g.epi.gamma[n0 + c] * is;
+        sh = g.epi.beta[n0 + c] - mu * sc;
+      }
+      ecoef[c] = sc; ecoef[BN + c] = sh;
+    }
   }
   __syncthreads();  // coefficients visible
   SPB_TS(1);
@@ -814,10 +816,12 @@ __global__ __launch_bounds__(256) void pw_wgrad_kernel(const spb_wgrad_args_t g,
       }
 }
 
+int g_wgrad_target_wgs = 1024;   // row splits so that a launch has about this many workgroups (spb_debug_set_wgrad_target)
+
 template <typename T>
 int launch_wgrad(const spb_wgrad_args_t& g, hipStream_t stream) {
   const int NT = (g.N + WT - 1) / WT, KT = (g.K + WT - 1) / WT;
-  int S = spb_ceil_div(1024, NT * KT);
+  int S = spb_ceil_div(g_wgrad_target_wgs, NT * KT);
   const int maxS = spb_ceil_div(g.M, 2 * WM);
   if (S > maxS) S = maxS;
   if (S < 1) S = 1;
@@ -848,6 +852,9 @@ extern "C" int spb_pwconv_gemm(int dtype, const spb_gemm_args_t* a, spb_stream_t
   if (a->epi_mode != 0 && (!a->osums || a->oR < 1)) return SPB_E_ARG;
   if (a->epi_mode == 2 && !a->Zout) return SPB_E_ARG;
   if (dtype == SPB_BF16) {
+    // 28x28 / 14x14 maps, medium reduction, narrow output: the one-shot kernel (gemm_os.hip)
+    const int eo = spb_gemm_os(a, (hipStream_t)stream);
+    if (eo != SPB_E_UNSUPPORTED) return eo;
     // the 14x14 / 7x7 maps with a long reduction: split-K over the waves of a workgroup (gemm_sk.hip)
     const int e = spb_gemm_sk(a, (hipStream_t)stream);
     if (e != SPB_E_UNSUPPORTED) return e;
@@ -871,6 +878,7 @@ extern "C" int spb_debug_trread(const unsigned short* in4096, unsigned short* ou
   return 0;
 }
 
+extern "C" int spb_debug_set_wgrad_target(int wgs) { g_wgrad_target_wgs = wgs < 1 ? 1 : wgs; return 0; }
 extern "C" int spb_debug_set_gemm_dma(int on) { g_disable_dma = (on == 0); g_dma_min_k = on > 1 ? on : 64; return 0; }
 extern "C" int spb_debug_set_gemm_plain_dma(int on) { g_plain_dma = (on != 0); return 0; }
 extern "C" int spb_debug_set_gemm_bk64_min_k(int k) { g_bk64_min_k = k; return 0; }

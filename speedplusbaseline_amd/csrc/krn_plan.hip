@@ -119,6 +119,7 @@ struct spb_krn_ctx {
   bool side_on = true;
   std::vector<hipEvent_t> fork_ev;
   hipEvent_t join_ev = nullptr;
+  hipEvent_t prep_ev = nullptr;     // weight copies refreshed on the side stream (spb_krn_forward, training & 4)
   hipEvent_t bucket_ev = nullptr;   // recorded when the gradients of [split_off, n_params) are final
   bool bucket_recorded = false;
   bool bucket_on = false;           // spb_krn_ctx_set_bucket: single-GPU runs skip the mid-backward join
@@ -128,6 +129,7 @@ struct spb_krn_ctx {
     for (hipEvent_t e : prof_ev) hipEventDestroy(e);
     if (join_ev) hipEventDestroy(join_ev);
     if (bucket_ev) hipEventDestroy(bucket_ev);
+    if (prep_ev) hipEventDestroy(prep_ev);
     if (side) hipStreamDestroy(side);
   }
 };
@@ -227,14 +229,20 @@ static int g_side_wgrad = 1;
 // fork per inverted-residual block instead of two, and they then run beside a memory-bound kernel rather than beside the
 // input-gradient GEMMs); at most g_wgrad_batch are held back.  Measured: fork per GEMM 3.52 ms, per 3 GEMMs 3.43 ms, at the
 // depthwise kernels 3.37 ms per step.  spb_debug_set_wgrad_batch(n): n > 0 plain batches of n, n < 0 flush at depthwise, cap -n.
+static int g_skip_side = 0;            // TIMING EXPERIMENT ONLY (spb_debug_set_launch_events(2|4)): 2 drops the pointwise, 4 the depthwise side-stream weight gradients
 static int g_launch_events = 1;        // fork on the completion event of the preceding GEMM launch instead of an event record
-extern "C" int spb_debug_set_launch_events(int on) { g_launch_events = on; return 0; }
+extern "C" int spb_debug_set_launch_events(int on) { g_launch_events = on & 1; g_skip_side = on & 6; return 0; }
 static int g_wgrad_flush_at_dw = 1;
 static int g_wgrad_min_flush = 1;      // flush at a depthwise kernel only with at least this many queued
 extern "C" int spb_debug_set_wgrad_min_flush(int n) { g_wgrad_min_flush = n < 1 ? 1 : n; return 0; }
 static int g_wgrad_batch = 8;
-static long long g_dw_split_rows = 0;       // > 0: depthwise layers with fewer input rows (B*H*W) send their weight gradient to the side stream (measured slower: 3.33 vs 3.29 ms)
-extern "C" int spb_debug_set_dw_split(int rows) { g_dw_split_rows = rows; return 0; }
+// Depthwise layers on maps up to this many columns wide run their input gradient alone on the launch stream and send the weight
+// gradient to the side stream with the pointwise ones: in the plane kernels (dwconv_plane.hip, maps up to 14x14) the weight
+// gradient triples the instruction count (72 partials per lane, each reduced across lanes) on a path that is bound by VALU issue.
+// Measured in the step (round 3): 0 -> 3.32 ms, 14 -> 3.22, 28 -> 3.23, 56 -> 3.22 (3.20 vs 3.19 after the later changes).
+// (Round 2, row-unit kernels on every map: the split was slower, 3.33 vs 3.29 ms.)
+static int g_dw_split_hw = 56;
+extern "C" int spb_debug_set_dw_split(int hw) { g_dw_split_hw = hw; return 0; }
 extern "C" int spb_debug_set_wgrad_batch(int n) {
   g_wgrad_flush_at_dw = n < 0;
   if (n < 0) n = -n;
@@ -357,7 +365,7 @@ struct Runner {
     }
     // this launch's own completion event: what the queued weight gradients wait for (see flush_wgrads)
     launch_ev = nullptr;
-    if (g_launch_events && before_dw && (!pend.empty() || head_pending || g_dw_split_rows > 0) && side_usable()) {
+    if (g_launch_events && before_dw && (!pend.empty() || head_pending || g_dw_split_hw > 0) && side_usable()) {
       launch_ev = next_event(); g.stop_event = launch_ev;
     }
     ok(spb_pwconv_gemm(dt, &g, st));
@@ -408,9 +416,9 @@ struct Runner {
       launch_ev = nullptr; forked = true; s = c->side;
     } else s = side_stream();            // one event record for the whole batch
     if (head_pending) { ok(spb_head_bwd(dt, &head_args, s)); head_pending = false; }
-    for (const spb_dw_args_t& d : pend_dw) ok(spb_dwconv_wgrad(dt, &d, s));
+    if (!(g_skip_side & 4)) for (const spb_dw_args_t& d : pend_dw) ok(spb_dwconv_wgrad(dt, &d, s));
     pend_dw.clear();
-    for (const spb_wgrad_args_t& w : pend) ok(spb_pwconv_wgrad(dt, &w, s));
+    if (!(g_skip_side & 2)) for (const spb_wgrad_args_t& w : pend) ok(spb_pwconv_wgrad(dt, &w, s));
     pend.clear();
   }
   void join_side() {
@@ -426,12 +434,10 @@ struct Runner {
     d.X = this->g(aout); d.X2 = z(aout); d.Xin = in.ptr; d.Wd = m->P + L.w_off; d.dW = m->G + L.w_off;
     d.pro = ref(aout, true); d.pro_in = in.ref; d.B = c->B; d.H = Hin; d.W = Hin; d.C = L.C; d.stride = L.stride;
     d.Zout = in.ptr; d.epi = in.ref;  // the convolution's input and its BN/activation (== ref(atgt) when atgt >= 0)
-    // Experiment (spb_debug_set_dw_split, off by default): on small maps the weight gradient goes to the side stream with the
-    // pointwise ones (everything it reads -- g, z and the batch sums of this layer's output, the forward input -- is final and
-    // never rewritten during backward) and the launch stream runs the input gradient alone.  Measured 3.33 ms against 3.29 ms
-    // per step with the fused kernel: the input-gradient-only instance is barely shorter (its time is load latency, not the
-    // 9 extra FMAs) and the extra side-stream kernels take compute units from the chain.
-    const bool split = side_usable() && (long long)c->B * Hin * Hin < g_dw_split_rows;
+    // On the small maps the weight gradient goes to the side stream with the pointwise ones (everything it reads -- g, z and the
+    // batch sums of this layer's output, the forward input -- is final and never rewritten during backward) and the launch
+    // stream runs the input gradient alone (spb_debug_set_dw_split).
+    const bool split = side_usable() && Hin <= g_dw_split_hw;
     if (split) {
       pend_dw.push_back(d);
       d.dW = nullptr;
@@ -747,6 +753,7 @@ extern "C" int spb_krn_ctx_create(spb_krn_t* m, int batch, void* workspace, spb_
   if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess) c->side = nullptr;
   if (hipEventCreateWithFlags(&c->join_ev, hipEventDisableTiming) != hipSuccess) { delete c; return SPB_E_STATE; }
   if (hipEventCreateWithFlags(&c->bucket_ev, hipEventDisableTiming) != hipSuccess) { delete c; return SPB_E_STATE; }
+  if (hipEventCreateWithFlags(&c->prep_ev, hipEventDisableTiming) != hipSuccess) { delete c; return SPB_E_STATE; }
   for (int i = 0; i < 64; ++i) {
     hipEvent_t ev;
     if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) break;
@@ -772,6 +779,20 @@ extern "C" int spb_krn_forward(spb_krn_ctx_t* c, const float* x, const float* ta
   spb_krn* m = c->m;
   hipStream_t st = (hipStream_t)stream;
   Runner r(c, st);
+  // training & 4: refresh the compute-dtype weight copies first (what spb_krn_prepare_weights does) -- on the side stream,
+  // beside the stem and the first depthwise layer, which read the f32 parameters; joined before the first 1x1 convolution
+  const bool prep = (training & 4) != 0;
+  training &= 3;
+  bool prep_wait = false;
+  if (prep) {
+    if (r.side_usable() && c->fork_ev.size() > 0) {
+      hipEventRecord(c->fork_ev[0], st);
+      hipStreamWaitEvent(c->side, c->fork_ev[0], 0);
+      r.ok(spb_weight_prep(m->dtype, m->prep_d, m->n_prep, m->n_prep_tiles, m->P, m->wc, c->side));
+      hipEventRecord(c->prep_ev, c->side);
+      prep_wait = true;
+    } else r.ok(spb_weight_prep(m->dtype, m->prep_d, m->n_prep, m->n_prep_tiles, m->P, m->wc, stream));
+  }
   const bool tr = training != 0;
   const spb_bnupd_entry_t* tab = reinterpret_cast<const spb_bnupd_entry_t*>(c->ws + c->table_off);
   if (tr) {
@@ -797,6 +818,7 @@ extern "C" int spb_krn_forward(spb_krn_ctx_t* c, const float* x, const float* ta
     } else {
       r.dw_fwd(b.D, cur, b.Hin, b.aD, tr);
     }
+    if (prep_wait) { hipStreamWaitEvent(st, c->prep_ev, 0); prep_wait = false; }
     r.pw_fwd(b.P, r.src_act(b.aD, tr), b.aP, tr);
     if (b.res) {
       spb_bnapply_args_t a; std::memset(&a, 0, sizeof(a));

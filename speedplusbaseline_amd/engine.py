@@ -119,8 +119,6 @@ class KrnEngine:
         ctx = self.context(B, slot)
         with torch.cuda.device(self.device):
             st = _stream()
-            if prepare:
-                L.check(self.lib.spb_krn_prepare_weights(self.h, st), "spb_krn_prepare_weights")
             pred = torch.empty(B, 2 * self.num_keypoints, dtype=torch.float32, device=self.device)
             scalars = None
             if target is not None:
@@ -129,7 +127,8 @@ class KrnEngine:
                     raise RuntimeError("target must be [B,2,%d], got %s" % (self.num_keypoints, tuple(target.shape)))
                 scalars = torch.empty(3, dtype=torch.float32, device=self.device)
             dom = torch.empty(B, dtype=torch.float32, device=self.device) if (domain and self.dann) else None
-            L.check(self.lib.spb_krn_forward(ctx, _p(x), _p(target), (1 if update_running else 2) if training else 0, _p(pred),
+            mode = ((1 if update_running else 2) if training else 0) | (4 if prepare else 0)   # | 4: refresh the weight copies on the side stream
+            L.check(self.lib.spb_krn_forward(ctx, _p(x), _p(target), mode, _p(pred),
                                              _p(scalars), _p(dom), st), "spb_krn_forward")
         self._last_x = getattr(self, "_last_x", {})
         self._last_x[(B, slot)] = (x, target)

@@ -74,19 +74,21 @@ def test_trread_semantics(device):
 
 @pytest.fixture(params=["default", "lds_dma", "tiled"])
 def gemm_variant(request):
-    """the pointwise-GEMM kernels: the default dispatch (split-K-over-waves kernel for small M with a long reduction, the
-    register-prefetch tiled kernel otherwise), the LDS-DMA ring (small M, bf16, K >= 64) and the tiled kernel alone"""
+    """the pointwise-GEMM kernels: the default dispatch (one-shot kernel for medium reductions with a narrow output on the 28x28 /
+    14x14 maps, split-K-over-waves kernel for small M with a long reduction, the register-prefetch tiled kernel otherwise), the LDS-DMA ring (small M, bf16, K >= 64) and the tiled kernel alone"""
     L.lib().spb_debug_set_gemm_dma(1 if request.param == "lds_dma" else 0)
     L.lib().spb_debug_set_gemm_sk(0 if request.param != "default" else 1, 0, 0)
+    L.lib().spb_debug_set_gemm_os(0 if request.param != "default" else 1, 0, 0, 0)
     yield request.param
     L.lib().spb_debug_set_gemm_dma(0)
     L.lib().spb_debug_set_gemm_sk(1, 0, 0)
+    L.lib().spb_debug_set_gemm_os(1, 0, 0, 0)
 
 
-@pytest.fixture(params=["rows", "tiles"])
+@pytest.fixture(params=["auto", "rows"])
 def dw_variant(request):
-    """both depthwise kernel families: the default row-unit kernels and the LDS-tiled ones"""
-    L.lib().spb_debug_set_dw_mode(1 if request.param == "rows" else 0)
+    """both depthwise kernel families: the default choice (plane kernels on maps up to 28 columns wide) and the row-unit kernels everywhere"""
+    L.lib().spb_debug_set_dw_mode(1 if request.param == "auto" else 0)
     yield request.param
     L.lib().spb_debug_set_dw_mode(1)
 
@@ -97,7 +99,9 @@ def dw_variant(request):
                                           (129, 16, 96, L.ACT_NONE, 8),
                                           # project convolutions of the 14x14 / 7x7 maps at bs=48 and the ConvDw pointwise layers
                                           (9408, 384, 64, L.ACT_RELU6, 1), (9408, 576, 96, L.ACT_RELU6, 1), (2352, 960, 160, L.ACT_RELU6, 1),
-                                          (2352, 960, 320, L.ACT_RELU6, 1), (2352, 1280, 1024, L.ACT_RELU, 1), (2349, 200, 72, L.ACT_LEAKY, 2)])
+                                          (2352, 960, 320, L.ACT_RELU6, 1), (2352, 1280, 1024, L.ACT_RELU, 1), (2349, 200, 72, L.ACT_LEAKY, 2),
+                                          # one-shot kernel (gemm_os.hip): 28x28 project, ragged rows / reduction / columns
+                                          (37632, 192, 32, L.ACT_RELU6, 8), (4100, 200, 72, L.ACT_LEAKY, 2), (4099, 168, 40, L.ACT_RELU, 1)])
 def test_pw_gemm_fwd(device, gemm_variant, dt, M, K, N, act, R):
     torch.manual_seed(M + K + N)
     zin = rt(torch.randn(M, K, dtype=torch.float64) * 1.5 + 0.3, dt)
@@ -150,7 +154,9 @@ def _composite(M, K, N, act1, act2, dt, seed):
                                              # expand convolutions of the 14x14 / 7x7 maps at bs=48 (the input gradient reduces over N)
                                              (9408, 64, 384, L.ACT_NONE, L.ACT_RELU6), (9408, 96, 576, L.ACT_NONE, L.ACT_RELU6),
                                              (2352, 160, 960, L.ACT_NONE, L.ACT_RELU6), (2352, 320, 1024, L.ACT_NONE, L.ACT_RELU),
-                                             (2352, 1024, 1024, L.ACT_RELU, L.ACT_RELU), (2349, 72, 200, L.ACT_RELU6, L.ACT_LEAKY)])
+                                             (2352, 1024, 1024, L.ACT_RELU, L.ACT_RELU), (2349, 72, 200, L.ACT_RELU6, L.ACT_LEAKY),
+                                             # one-shot kernel (gemm_os.hip): 28x28 expand, ragged shapes
+                                             (37632, 32, 192, L.ACT_NONE, L.ACT_RELU6), (4100, 72, 200, L.ACT_RELU6, L.ACT_LEAKY), (4099, 40, 168, L.ACT_NONE, L.ACT_RELU)])
 def test_pw_gemm_bwd(device, gemm_variant, dt, M, K, N, act1, act2):
     c = _composite(M, K, N, act1, act2, dt, seed=M * 7 + N)
     dev = device
@@ -247,7 +253,11 @@ def test_pw_bwd_fused(device, M, K, N, act1, act2, with_res, mat):
 
 @pytest.mark.parametrize("dt", DTYPES)
 @pytest.mark.parametrize("B,H,C,stride,act", [(2, 14, 96, 1, L.ACT_RELU6), (3, 15, 32, 2, L.ACT_RELU6), (2, 7, 1280, 1, L.ACT_NONE),
-                                              (2, 28, 144, 2, L.ACT_RELU)])
+                                              (2, 28, 144, 2, L.ACT_RELU),
+                                              # the plane-kernel layers of KRN at bs=48 (dwconv_plane.hip), plus ragged image groups / segments
+                                              (48, 14, 384, 1, L.ACT_RELU6), (48, 7, 960, 1, L.ACT_RELU6), (48, 14, 576, 2, L.ACT_RELU6),
+                                              (12, 28, 192, 1, L.ACT_RELU6), (7, 28, 64, 2, L.ACT_RELU6), (5, 7, 320, 1, L.ACT_RELU),
+                                              (3, 9, 40, 1, L.ACT_RELU), (2, 27, 24, 2, L.ACT_RELU6)])
 def test_dwconv(device, dw_variant, dt, B, H, C, stride, act):
     torch.manual_seed(B * H + C)
     dev = device
