@@ -128,6 +128,9 @@ def main():
                     ("SPB_DW_PLANE_W", "spb_debug_set_dw_plane_max_w"), ("SPB_WGRAD_TARGET", "spb_debug_set_wgrad_target")):
         if os.environ.get(env) is not None:
             getattr(_L.lib(), fn)(int(os.environ[env]))
+    for kv in filter(None, os.environ.get("SPB_DBG", "").split(";")):   # generic: SPB_DBG="spb_debug_set_x=1,2;spb_debug_set_y=3"
+        fn, _, val = kv.partition("=")
+        getattr(_L.lib(), fn)(*[int(v) for v in val.split(",")])
     if os.environ.get("SPB_STEM_GRID"):      # "fwd,wgrad" workgroup caps
         _L.lib().spb_debug_set_stem_grid(*[int(v) for v in os.environ["SPB_STEM_GRID"].split(",")])
 

@@ -73,15 +73,27 @@ typedef struct spb_gemm_args {
 int spb_pwconv_gemm(int dtype, const spb_gemm_args_t* args, spb_stream_t stream);
 
 /* dW[N,K] += sum_m dz[m,n] * a[m,k];  dz = bn_backward(G, Zn) (pro_dz), a = act(bn(X)) (pro_a).  dW is f32. */
+/* Weight-gradient partials.  A kernel that splits its reduction (the rows of the batch) over workgroups either adds every
+ * workgroup's result into dW with f32 atomics (part == NULL), or -- the form the KRN plan uses -- stores it with plain stores
+ * into a scratch slab `part` ([nparts][n] f32, `part_cap` floats available) and reports the reduce job that finishes it:
+ * dst[i] += sum_p src[p*stride + i].  With job_out == NULL the entry launches that reduce itself on `stream`; otherwise the
+ * caller collects the jobs and runs them in one spb_partial_reduce launch.  (Measured on the KRN step: the ~2 M device-scope
+ * float atomics per pointwise weight-gradient launch cost the step ~0.2 ms; the partial sums are also order-deterministic.) */
+typedef struct spb_red_job { const float* src; float* dst; long long stride; int n; int nparts; } spb_red_job_t;
+int spb_partial_reduce(const spb_red_job_t* jobs, int njobs, spb_stream_t stream);
+
 typedef struct spb_wgrad_args {
   const void* G;  /* [M,N] */
   const void* Zn; /* [M,N] or NULL */
   const void* X;  /* [M,K] */
-  float* dW;      /* [N,K] f32, accumulated with atomics */
+  float* dW;      /* [N,K] f32, accumulated */
   spb_bnref_t pro_dz;
   spb_bnref_t pro_a;
   int M, K, N;
   int ldg, ldx;   /* row strides (elements) of G/Zn and X; 0 = dense (N and K) */
+  float* part;    /* optional scratch for partial sums (see spb_red_job_t); NULL: f32 atomics into dW */
+  long long part_cap;      /* floats available at `part` */
+  spb_red_job_t* job_out;  /* optional: receives the reduce job (nparts == 0: none needed) instead of launching it */
 } spb_wgrad_args_t;
 int spb_pwconv_wgrad(int dtype, const spb_wgrad_args_t* args, spb_stream_t stream);
 
@@ -104,6 +116,9 @@ typedef struct {
   spb_bnref_t pro_a;  /* BN + activation turning X into the conv input */
   spb_bnref_t epi;    /* BN + activation of the input-side tensor (mask and xhat) */
   int M, K, N, oR;
+  float* part;             /* as in spb_wgrad_args_t: scratch for the per-workgroup weight-gradient partials */
+  long long part_cap;
+  spb_red_job_t* job_out;
 } spb_pwbwd_args_t;
 int spb_pwconv_bwd_fused(int dtype, const spb_pwbwd_args_t* args, spb_stream_t stream);
 
@@ -125,6 +140,9 @@ typedef struct spb_dw_args {
   int B, H, W, C, stride;
   int epi_mode;      /* fwd: 1;  dgrad: 0 or 2 */
   int oR;
+  float* part;             /* dgrad with dW / wgrad: as in spb_wgrad_args_t */
+  long long part_cap;
+  spb_red_job_t* job_out;
 } spb_dw_args_t;
 int spb_dwconv_fwd(int dtype, const spb_dw_args_t* args, spb_stream_t stream);
 /* dgrad with args->dW != NULL also accumulates the weight gradient in the same pass (one read of g, z and the input
@@ -230,6 +248,10 @@ int spb_weight_prep(int dtype, const spb_prep_entry_t* table_dev, int n_entries,
 
 /* ---- optimiser: global-norm clip (trainer.py:90,97; dann.py:99) fused with the update (build.py:60-78) ----- */
 int spb_grad_sqnorm(const float* grads, long long n, float* sqnorm_out /*[1], zeroed by this call*/, spb_stream_t stream);
+/* the same sum of squares as SPB_SQ_PARTS per-workgroup partials (plain stores, no arrival counter: 512 same-address
+ * atomics cost the one-scalar form ~13 of its 20 us on the KRN arena); spb_optim_step(sq_partials) consumes them */
+#define SPB_SQ_PARTS 256
+int spb_grad_sqnorm_partials(const float* grads, long long n, float* partials_out /*[SPB_SQ_PARTS]*/, spb_stream_t stream);
 /* optimizer.zero_grad() on the flat f32 gradient arena (trainer.py:81, dann.py:74), and dst += src over two arenas (the two
  * backward passes of a DANN step accumulate into one gradient, dann.py:95); n elements, n % 4 == 0 for the add */
 int spb_arena_zero(float* arena, long long n, spb_stream_t stream);
@@ -254,6 +276,9 @@ typedef struct spb_optim_args {
                            element, so the next forward needs no separate conversion pass (SPN, 152 M parameters) */
   int max_blocks;       /* > 0: at most this many workgroups, each walking the arena with a grid stride -- a background
                            update that leaves the compute units to the kernels of another stream; 0: one block per run */
+  const float* sq_partials; /* optional, instead of sqnorm: n_sq_partials (<= 256) partial sums of squares from
+                               spb_grad_sqnorm_partials; every workgroup adds them up itself (no single-address ticket) */
+  int n_sq_partials;
 } spb_optim_args_t;
 int spb_optim_step(const spb_optim_args_t* a, spb_stream_t stream);
 /* Weight gradient of a fully connected layer (spb_fc_wgrad's operands: GT [N][MP], XT [K][MP], batch M <= 64) fused with that
@@ -304,7 +329,10 @@ int spb_krn_prepare_weights(spb_krn_t* m, spb_stream_t stream);
 /* forward.  training=1: batch statistics + running-stat update; training=2: batch statistics, the running-stat update is
  * left to a later spb_krn_update_running (two passes on two streams, see below).  training | 4: spb_krn_prepare_weights first,
  * on the context's side stream beside the stem and the first depthwise layer (they read the f32 parameters), joined before the
- * first 1x1 convolution.  target NULL => prediction only.
+ * first 1x1 convolution.  training | 8: the bound gradient arena is zeroed (optimizer.zero_grad()) on the same side-stream
+ * fork.  training | 16 (with training=1): the running-stat update is enqueued by the NEXT spb_krn_backward on this context,
+ * on its side stream (nothing in a train step reads the running statistics); a forward or spb_krn_update_running that
+ * comes first applies it.  target NULL => prediction only.
  * pred [B][2K] f32 (interleaved x,y as the head emits them), scalars [3] = loss, loss_x, loss_y.
  * alpha_valid=1 with a dann plan also runs the domain classifier: domain_logits [B].                           */
 int spb_krn_forward(spb_krn_ctx_t* c, const float* x_nchw, const float* target, int training, float* pred,
@@ -337,6 +365,9 @@ int spb_krn_prof_enable(spb_krn_ctx_t* c, int on);
 int spb_krn_prof_num_categories(void);
 const char* spb_krn_prof_category_name(int i);
 int spb_krn_prof_read(spb_krn_ctx_t* c, int* launches, float* ms, double* bytes, double* flops);
+/* per-launch records since the last spb_krn_prof_read, in launch order (category index, ms, algorithmic bytes); returns the
+ * number of records, writes at most `max`; does not reset */
+int spb_krn_prof_launches(spb_krn_ctx_t* c, int max, int* cat, float* ms, double* bytes);
 long long spb_krn_weight_prep_bytes(const spb_krn_t* m);
 
 /* ---- style-transfer decoder (Ghiasi), inference only: src/styleaug/ghiasi.py:6-135, called from
@@ -517,8 +548,9 @@ int spb_preproc_batch(const spb_preproc_args_t* a, spb_stream_t stream);
 int spb_debug_set_conv9_band(int on); /* decoder's last 9x9 layer: band-staged kernel (1, default) or the generic 8x8-tile kernel */
 int spb_debug_set_launch_events(int on); /* side-stream forks wait on the preceding GEMM launch's completion event (1) or on a recorded event (0) */
 int spb_debug_set_dw_split(int hw);        /* depthwise layers on maps up to `hw` columns wide run their weight gradient on the side stream (default 56: every depthwise layer below the 112x112 maps; 0: always fused) */
+int spb_debug_set_wgrad_parts(int on);     /* KRN plan: weight gradients as partial sums + spb_partial_reduce (1, default) or f32 atomics (0) */
 int spb_debug_set_wgrad_min_flush(int n); /* fork at a depthwise backward kernel only when >= n weight gradients are queued */
-int spb_debug_set_wgrad_target(int wgs); /* pointwise weight gradient: row splits chosen for about this many workgroups per launch (every split adds N*K f32 atomics) */
+int spb_debug_set_wgrad_target(int wgs); /* pointwise weight gradient: row splits chosen for about this many workgroups per launch (every split adds N*K f32 atomics); wgs < 0: the same for the partial-sum form (default 512; every split adds an N*K slab) */
 int spb_debug_set_wgrad_batch(int n); /* pointwise weight-gradient GEMMs handed to the side stream per fork event */
 int spb_debug_set_gemm_bk64_dgrad_min_k(int k); /* backward-type small-M GEMMs with K >= k: 64x32 tiles with 64-deep chunks */
 int spb_debug_set_replica_rows(long long rows); /* BatchNorm batch sums get 8 atomic replicas for tensors with at least this many rows (contexts created afterwards) */

@@ -7,6 +7,8 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libspb_hip.so")
+if os.environ.get("SPB_LIB_VARIANT"):   # kernel experiments only (scratch/build_variant.py): libspb_hip.<variant>.so, same C-ABI
+    LIB_PATH = os.path.join(_HERE, "libspb_hip.%s.so" % os.environ["SPB_LIB_VARIANT"])
 
 F32, BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_RELU6, ACT_LEAKY = 0, 1, 2, 3
@@ -29,15 +31,19 @@ class GemmArgs(C.Structure):
                 ("epi_mode", i32), ("out_act", i32), ("oR", i32), ("out_scale", f32), ("lda", i32), ("ldc", i32), ("stop_event", vp)]
 
 
+class RedJob(C.Structure):
+    _fields_ = [("src", vp), ("dst", vp), ("stride", i64), ("n", i32), ("nparts", i32)]
+
+
 class WgradArgs(C.Structure):
     _fields_ = [("G", vp), ("Zn", vp), ("X", vp), ("dW", vp), ("pro_dz", BNRef), ("pro_a", BNRef), ("M", i32),
-                ("K", i32), ("N", i32), ("ldg", i32), ("ldx", i32)]
+                ("K", i32), ("N", i32), ("ldg", i32), ("ldx", i32), ("part", vp), ("part_cap", i64), ("job_out", vp)]
 
 
 class PwBwdArgs(C.Structure):
     _fields_ = [("G", vp), ("Zn", vp), ("Wt", vp), ("X", vp), ("Zout", vp), ("res", vp), ("Y", vp), ("dW", vp),
                 ("osums", vp), ("pro_dz", BNRef), ("pro_a", BNRef), ("epi", BNRef), ("M", i32), ("K", i32), ("N", i32),
-                ("oR", i32)]
+                ("oR", i32), ("part", vp), ("part_cap", i64), ("job_out", vp)]
 
 
 class GconvArgs(C.Structure):
@@ -49,7 +55,7 @@ class GconvArgs(C.Structure):
 class DwArgs(C.Structure):
     _fields_ = [("X", vp), ("X2", vp), ("Xin", vp), ("Wd", vp), ("Y", vp), ("dW", vp), ("res", vp), ("Zout", vp),
                 ("osums", vp), ("pro", BNRef), ("pro_in", BNRef), ("epi", BNRef), ("B", i32), ("H", i32), ("W", i32),
-                ("C", i32), ("stride", i32), ("epi_mode", i32), ("oR", i32)]
+                ("C", i32), ("stride", i32), ("epi_mode", i32), ("oR", i32), ("part", vp), ("part_cap", i64), ("job_out", vp)]
 
 
 class BnApplyArgs(C.Structure):
@@ -88,7 +94,7 @@ class OptimArgs(C.Structure):
     _fields_ = [("params", vp), ("grads", vp), ("m", vp), ("v", vp), ("sqnorm", vp), ("gmul", vp), ("hyper", vp),
                 ("n", i64), ("kind", i32), ("lr", f32), ("beta1", f32), ("beta2", f32), ("eps", f32),
                 ("weight_decay", f32), ("max_norm", f32), ("clip_value", f32), ("bias_c1", f32), ("bias_c2", f32),
-                ("first_step", i32), ("shadow_bf16", vp), ("max_blocks", i32)]
+                ("first_step", i32), ("shadow_bf16", vp), ("max_blocks", i32), ("sq_partials", vp), ("n_sq_partials", i32)]
 
 
 class SpnConvArgs(C.Structure):
@@ -119,6 +125,7 @@ class TensorInfo(C.Structure):
 SYMBOLS = {
     "spb_pwconv_gemm": (i32, [i32, C.POINTER(GemmArgs), vp]),
     "spb_pwconv_wgrad": (i32, [i32, C.POINTER(WgradArgs), vp]),
+    "spb_partial_reduce": (i32, [C.POINTER(RedJob), i32, vp]),
     "spb_pwconv_bwd_fused": (i32, [i32, C.POINTER(PwBwdArgs), vp]),
     "spb_dwconv_fwd": (i32, [i32, C.POINTER(DwArgs), vp]),
     "spb_dwconv_dgrad": (i32, [i32, C.POINTER(DwArgs), vp]),
@@ -134,6 +141,7 @@ SYMBOLS = {
     "spb_bn_load_running": (i32, [vp, i32, vp, vp, vp]),
     "spb_weight_prep": (i32, [i32, vp, i32, i32, vp, vp, vp]),
     "spb_grad_sqnorm": (i32, [vp, i64, vp, vp]),
+    "spb_grad_sqnorm_partials": (i32, [vp, i64, vp, vp]),
     "spb_arena_zero": (i32, [vp, i64, vp]),
     "spb_arena_add": (i32, [vp, vp, i64, vp]),
     "spb_stream_create": (i32, [i32, C.POINTER(C.c_void_p)]),
@@ -169,6 +177,7 @@ SYMBOLS = {
     "spb_krn_prof_num_categories": (i32, []),
     "spb_krn_prof_category_name": (C.c_char_p, [i32]),
     "spb_krn_prof_read": (i32, [vp, vp, vp, vp, vp]),
+    "spb_krn_prof_launches": (i32, [vp, i32, vp, vp, vp]),
     "spb_krn_weight_prep_bytes": (i64, [vp]),
     "spb_gconv": (i32, [i32, C.POINTER(GconvArgs), vp]),
     "spb_gconv_up2": (i32, [i32, C.POINTER(GconvArgs), vp]),
@@ -196,6 +205,7 @@ SYMBOLS = {
     "spb_debug_set_conv9_band": (i32, [i32]),
     "spb_debug_set_launch_events": (i32, [i32]),
     "spb_debug_set_dw_split": (i32, [i32]),
+    "spb_debug_set_wgrad_parts": (i32, [i32]),
     "spb_debug_set_wgrad_min_flush": (i32, [i32]),
     "spb_debug_set_wgrad_batch": (i32, [i32]),
     "spb_debug_set_wgrad_target": (i32, [i32]),

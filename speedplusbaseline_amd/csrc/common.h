@@ -4,6 +4,17 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "../../include/spb_hip.h"
+// TIMING EXPERIMENTS ONLY (scratch/build_variant.py; results are wrong): -DSPB_NO_ATOMICS turns every statistics atomic of a
+// file into a no-op, -DSPB_NO_ATOMICS_W the weight-gradient atomics (sites marked SPB_ATOMIC_W)
+template <typename P, typename V> __device__ __forceinline__ void spb_no_atomic(P p, V v) { *p = v; }   // a plain store keeps the computation alive
+#ifdef SPB_NO_ATOMICS_W
+#define SPB_ATOMIC_W(p, v) spb_no_atomic(p, v)
+#else
+#define SPB_ATOMIC_W(p, v) (atomicAdd)(p, v)
+#endif
+#ifdef SPB_NO_ATOMICS
+#define atomicAdd(p, v) spb_no_atomic(p, v)
+#endif
 
 typedef unsigned short bf16_t;  // raw bfloat16 bits; activations in HBM are bf16 (or float in parity mode)
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;

@@ -33,9 +33,15 @@ namespace {
 constexpr int CFN = 128;  // floats of per-channel-group coefficients: w[9][8] | p0,p1,p2 (bwd) or sc,sh (fwd) | sc,sh,mu,is
 // ring depth: stream elements in flight per wave, sized so that a block's rings stay under ~48 KB (3 blocks per CU by
 // LDS; with 96 KB rings the stride-2 backward ran one block per CU)
+#ifndef SPB_DW_RING_BUDGET
+#define SPB_DW_RING_BUDGET 49152
+#endif
+#ifndef SPB_DW_RING_CAP
+#define SPB_DW_RING_CAP 4
+#endif
 template <typename T, int NS> struct RingDepth {
   static constexpr int bytes = NS * (sizeof(T) == 2 ? 1 : 2) * 4096;   // one element of all 4 waves
-  static constexpr int v = 49152 / bytes >= 4 ? 4 : (49152 / bytes >= 2 ? 49152 / bytes : 2);
+  static constexpr int v = SPB_DW_RING_BUDGET / bytes >= SPB_DW_RING_CAP ? SPB_DW_RING_CAP : (SPB_DW_RING_BUDGET / bytes >= 2 ? SPB_DW_RING_BUDGET / bytes : 2);
 };
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
@@ -428,7 +434,7 @@ __global__ __launch_bounds__(256, 2) void dwr_bwd_kernel(const spb_dw_args_t a, 
         if (ok) { s[0][j] += acc[j]; s[1][j] += acc[j] * zf[j]; }
       }
     }
-    if (ok) st8<T>(Y + off, acc);
+    if (ok && !(SPB_ABL & 1024)) st8<T>(Y + off, acc);
   };
 
   Cursor pc, cc;
@@ -440,9 +446,10 @@ __global__ __launch_bounds__(256, 2) void dwr_bwd_kernel(const spb_dw_args_t a, 
 #pragma unroll
   for (int j = 0; j < 8; ++j) { dm[j] = 0.f; d0[j] = 0.f; }
   for (int e = 0; e < N; ++e) {
-    if (pe < N) { issue(pc, pe % RD); advance(pc, g, nwq); ++pe; }
+    if (pe < N) { if (!(SPB_ABL & 512)) issue(pc, pe % RD); advance(pc, g, nwq); ++pe; }
     if (N - 1 - e >= RD - 1) wait_vmcnt<NS * (sizeof(T) == 2 ? 1 : 2) * (RD - 1)>();
     else wait_vmcnt<0>();
+    if (SPB_ABL & 256) { advance(cc, g, nwq); continue; }
     const char* slot = ring + (e % RD) * SLOT;
     const int q = cc.sx * NP + l16 - LH;
     const bool qok = q >= 0 && q < OW;
@@ -588,7 +595,7 @@ Geo make_geo(int B, int C, int lane_rows, int lane_cols, int NP, int halo, int t
 
 int ring_depth_host(int ns, int es) {   // == RingDepth<T, NS>::v
   const int bytes = ns * es * 4096;
-  return 49152 / bytes >= 4 ? 4 : (49152 / bytes >= 2 ? 49152 / bytes : 2);
+  return SPB_DW_RING_BUDGET / bytes >= SPB_DW_RING_CAP ? SPB_DW_RING_CAP : (SPB_DW_RING_BUDGET / bytes >= 2 ? SPB_DW_RING_BUDGET / bytes : 2);
 }
 
 template <typename K>

@@ -5,6 +5,7 @@
 //       copies (bf16 W, W^T, permuted head weight)
 //   * global-norm clip + optimiser update fused over the flat parameter arena
 //       (reference trainer.py:90,97  clip_grad_norm_; build.py:60-78 sgd/rmsprop/adam/adamw)
+#include <cstring>
 #include "common.h"
 #include "optim_math.h"
 
@@ -239,6 +240,33 @@ __global__ __launch_bounds__(256) void grad_sqnorm_kernel(const float* __restric
   if (threadIdx.x == 0) { *out = red[0] + red[1] + red[2] + red[3]; *counter = 0; }
 }
 
+// SPB_SQ_PARTS workgroups, block b owns a contiguous run; 8 independent 16-byte loads per thread in flight; partial[b] by a
+// plain store (the consumer adds the partials up)
+__global__ __launch_bounds__(256) void grad_sqnorm_partials_kernel(const float* __restrict__ g, long long n, float* partial) {
+  __shared__ float red[4];
+  const long long n4 = n >> 2;
+  const long long per = (n4 + gridDim.x - 1) / gridDim.x;
+  const long long lo = (long long)blockIdx.x * per, hi = lo + per < n4 ? lo + per : n4;
+  const float4* g4 = reinterpret_cast<const float4*>(g);
+  float s[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) s[u] = 0.f;
+  for (long long i = lo + threadIdx.x; i < hi; i += 2048) {
+    float4 a[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { const long long j = i + 256 * u; a[u] = g4[j < hi ? j : hi - 1]; }
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (i + 256 * u < hi) s[u] += a[u].x * a[u].x + a[u].y * a[u].y + a[u].z * a[u].z + a[u].w * a[u].w;
+  }
+  float t = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) { const float v = g[(n4 << 2) + threadIdx.x]; t += v * v; }
+  t = wave_sum(t);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = t;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
 // VEC = 4: 16-byte accesses (n % 4 == 0, 16-byte aligned arenas); VEC = 1: scalar.  NT: non-temporal accesses (a 150 M
 // element arena is a pure stream: nothing is reused from L2 / MALL)
 template <bool NT> __device__ __forceinline__ f32x4_t ldv(const float* p, long long i) {
@@ -256,7 +284,15 @@ template <int VEC, bool NT, int U>
 __global__ __launch_bounds__(256) void optim_step_kernel(const spb_optim_args_t a) {
   float gm = a.gmul ? *a.gmul : 1.f;
   float coef = 1.f;
-  if (a.max_norm > 0.f && a.sqnorm) {
+  if (a.max_norm > 0.f && a.sq_partials && a.n_sq_partials > 0) {   // every workgroup adds the partials up in the same fixed order
+    __shared__ float sqred[4];
+    float t = (int)threadIdx.x < a.n_sq_partials ? a.sq_partials[threadIdx.x] : 0.f;
+    t = wave_sum(t);
+    if ((threadIdx.x & 63) == 0) sqred[threadIdx.x >> 6] = t;
+    __syncthreads();
+    const float tn = sqrtf((sqred[0] + sqred[1]) + (sqred[2] + sqred[3])) * fabsf(gm);
+    coef = fminf(a.max_norm / (tn + 1e-6f), 1.f);
+  } else if (a.max_norm > 0.f && a.sqnorm) {
     const float tn = sqrtf(*a.sqnorm) * fabsf(gm);
     coef = fminf(a.max_norm / (tn + 1e-6f), 1.f);
   }
@@ -410,6 +446,13 @@ extern "C" int spb_grad_sqnorm(const float* grads, long long n, float* out, spb_
   return 0;
 }
 
+extern "C" int spb_grad_sqnorm_partials(const float* grads, long long n, float* partials_out, spb_stream_t stream) {
+  if (!grads || !partials_out || n <= 0) return SPB_E_ARG;
+  hipLaunchKernelGGL(grad_sqnorm_partials_kernel, dim3(SPB_SQ_PARTS), dim3(256), 0, (hipStream_t)stream, grads, n, partials_out);
+  SPB_CHECK_LAUNCH();
+  return 0;
+}
+
 // ---- flat gradient arena maintenance (optimizer.zero_grad(), and the sum of the two DANN passes' arenas, dann.py:95)
 __global__ __launch_bounds__(256) void arena_add_kernel(float* __restrict__ dst, const float* __restrict__ src, long long n4) {
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
@@ -438,6 +481,7 @@ extern "C" int spb_optim_step(const spb_optim_args_t* a, spb_stream_t stream) {
   if (a->kind < 0 || a->kind > 3) return SPB_E_ARG;
   if (a->kind >= 2 && (!a->m || !a->v)) return SPB_E_ARG;
   if (a->kind == 1 && !a->v) return SPB_E_ARG;
+  if (a->n_sq_partials < 0 || a->n_sq_partials > 256) return SPB_E_ARG;
   const bool vec = !(a->n & 3) && !(((uintptr_t)a->params | (uintptr_t)a->grads | (uintptr_t)a->m | (uintptr_t)a->v) & 15) &&
                    !((uintptr_t)a->shadow_bf16 & 7);
   const bool capped = a->max_blocks > 0;     // few workgroups: each thread keeps 4 x 16 bytes of every stream in flight
@@ -481,4 +525,63 @@ extern "C" int spb_stream_create(int level, spb_stream_t* out) {
 }
 extern "C" int spb_stream_destroy(spb_stream_t s) {
   return s && hipStreamDestroy((hipStream_t)s) == hipSuccess ? 0 : SPB_E_ARG;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Reduce pass of the weight-gradient partials (spb_red_job_t, include/spb_hip.h): dst[i] += sum_p src[p*stride + i].
+// One launch takes up to RED_MAX jobs (the table travels in the kernel arguments); a workgroup owns 1024 consecutive
+// elements of one job and RED_PC of its parts, all of a thread's loads in flight together; jobs with more than RED_PC parts
+// finish with one f32 atomic per element and part chunk (16-32x fewer than one per workgroup of the producing kernel).
+namespace {
+constexpr int RED_MAX = 16, RED_PC = 16;
+struct RedTab { spb_red_job_t j[RED_MAX]; int blk0[RED_MAX + 1]; int njobs; };
+
+__global__ __launch_bounds__(256) void partial_reduce_kernel(const RedTab tab) {
+  int ji = 0;
+  while (ji + 1 < tab.njobs && (int)blockIdx.x >= tab.blk0[ji + 1]) ++ji;
+  const spb_red_job_t jb = tab.j[ji];
+  const int eb = (jb.n + 1023) / 1024;
+  const int lb = (int)blockIdx.x - tab.blk0[ji];
+  const int chunk = lb / eb, i = ((lb - chunk * eb) * 256 + (int)threadIdx.x) * 4;
+  if (i >= jb.n) return;
+  const int p0 = chunk * RED_PC, p1 = min(jb.nparts, p0 + RED_PC);
+  const float* src = jb.src + (size_t)p0 * jb.stride + i;
+  float4 v[RED_PC];
+#pragma unroll
+  for (int p = 0; p < RED_PC; ++p) {   // clamped part index: every load issued before the first add
+    const int pc = p0 + p < p1 ? p : p1 - 1 - p0;
+    v[p] = *reinterpret_cast<const float4*>(src + (size_t)pc * jb.stride);
+  }
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int p = 0; p < RED_PC; ++p)
+    if (p0 + p < p1) { a.x += v[p].x; a.y += v[p].y; a.z += v[p].z; a.w += v[p].w; }
+  float* d = jb.dst + i;
+  if (jb.nparts <= RED_PC) {
+    float4 o = *reinterpret_cast<float4*>(d);
+    o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w;
+    *reinterpret_cast<float4*>(d) = o;
+  } else { atomicAdd(d, a.x); atomicAdd(d + 1, a.y); atomicAdd(d + 2, a.z); atomicAdd(d + 3, a.w); }
+}
+}  // namespace
+
+extern "C" int spb_partial_reduce(const spb_red_job_t* jobs, int njobs, spb_stream_t stream) {
+  if (njobs < 0 || (njobs > 0 && !jobs)) return SPB_E_ARG;
+  int done = 0;
+  while (done < njobs) {
+    RedTab tab; std::memset(&tab, 0, sizeof(tab));
+    int nb = 0, k = 0;
+    for (; k < RED_MAX && done + k < njobs; ++k) {
+      const spb_red_job_t& j = jobs[done + k];
+      if (!j.src || !j.dst || j.n <= 0 || (j.n & 3) || j.nparts <= 0 || (j.stride & 3) ||
+          (reinterpret_cast<uintptr_t>(j.src) & 15) || (reinterpret_cast<uintptr_t>(j.dst) & 15)) return SPB_E_ARG;
+      tab.j[k] = j; tab.blk0[k] = nb;
+      nb += ((j.n + 1023) / 1024) * ((j.nparts + RED_PC - 1) / RED_PC);
+    }
+    tab.blk0[k] = nb; tab.njobs = k;
+    hipLaunchKernelGGL(partial_reduce_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, tab);
+    SPB_CHECK_LAUNCH();
+    done += k;
+  }
+  return 0;
 }

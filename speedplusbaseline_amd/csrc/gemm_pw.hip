@@ -16,6 +16,7 @@
 //   * workgroups are persistent over M tiles (fixed N tile) so the per-channel sums stay in registers; one set of
 //     atomics per workgroup at the end, spread over `oR` replicas of the accumulator.
 //   * logical workgroup ids are remapped so the N tiles that share an A tile run on one XCD (one L2).
+#include <cstring>
 #include "common.h"
 #include <hip/hip_ext.h>
 
@@ -676,7 +677,9 @@ int dispatch_modes(const spb_gemm_args_t& g, hipStream_t stream) {
 constexpr int WT = 64;   // output tile (n and k)
 constexpr int WM = 64;   // m rows per LDS stage
 
-template <typename T>
+// PART: the tile of this row split is stored (plain stores) into slab `split` of g.part ([S][N*K] f32) for spb_partial_reduce
+// instead of being added into dW with f32 atomics
+template <typename T, bool PART>
 __global__ __launch_bounds__(256) void pw_wgrad_kernel(const spb_wgrad_args_t g, int rows_per_split) {
   constexpr int LD = WT + 8;
   __shared__ __attribute__((aligned(16))) T Ds[WM * LD];
@@ -812,22 +815,47 @@ __global__ __launch_bounds__(256) void pw_wgrad_kernel(const spb_wgrad_args_t g,
       for (int r = 0; r < 4; ++r) {
         const int n = n0 + (wn * 2 + a) * 16 + lq * 4 + r;
         const int k = k0 + (wk * 2 + b) * 16 + li;
-        if (n < N && k < K) atomicAdd(g.dW + (size_t)n * K + k, acc[a][b][r]);
+        if (n < N && k < K) {
+          if (PART) g.part[(size_t)split * N * K + (size_t)n * K + k] = acc[a][b][r];
+          else SPB_ATOMIC_W(g.dW + (size_t)n * K + k, acc[a][b][r]);
+        }
       }
 }
 
 int g_wgrad_target_wgs = 1024;   // row splits so that a launch has about this many workgroups (spb_debug_set_wgrad_target)
+int g_wgrad_part_target = 512;   // the same for the partial-store form (its splits cost slab traffic instead of atomics)
+
+// floats of partial-sum scratch launch_wgrad uses at most for this shape (the KRN plan sizes its workspace with it)
+long long wgrad_part_floats(int M, int K, int N) {
+  const int NT = (N + WT - 1) / WT, KT = (K + WT - 1) / WT;
+  int S = spb_ceil_div(g_wgrad_part_target, NT * KT);
+  const int maxS = spb_ceil_div(M, 2 * WM);
+  if (S > maxS) S = maxS;
+  if (S < 1) S = 1;
+  return S >= 2 ? (long long)S * N * K : 0;
+}
 
 template <typename T>
 int launch_wgrad(const spb_wgrad_args_t& g, hipStream_t stream) {
   const int NT = (g.N + WT - 1) / WT, KT = (g.K + WT - 1) / WT;
-  int S = spb_ceil_div(g_wgrad_target_wgs, NT * KT);
+  const long long NK = (long long)g.N * g.K;
+  const bool part = g.part != nullptr && g.part_cap >= 2 * NK && (reinterpret_cast<uintptr_t>(g.part) & 15) == 0;
+  int S = spb_ceil_div(part ? g_wgrad_part_target : g_wgrad_target_wgs, NT * KT);
   const int maxS = spb_ceil_div(g.M, 2 * WM);
   if (S > maxS) S = maxS;
+  if (part && S > g.part_cap / NK) S = (int)(g.part_cap / NK);
   if (S < 1) S = 1;
   int rps = spb_ceil_div(spb_ceil_div(g.M, S), WM) * WM;
   S = spb_ceil_div(g.M, rps);
-  hipLaunchKernelGGL((pw_wgrad_kernel<T>), dim3(NT * KT * S), dim3(256), 0, stream, g, rps);
+  if (g.job_out) std::memset(g.job_out, 0, sizeof(*g.job_out));
+  if (part && S >= 2) {
+    hipLaunchKernelGGL((pw_wgrad_kernel<T, true>), dim3(NT * KT * S), dim3(256), 0, stream, g, rps);
+    SPB_CHECK_LAUNCH();
+    spb_red_job_t job; job.src = g.part; job.dst = g.dW; job.stride = NK; job.n = (int)NK; job.nparts = S;
+    if (g.job_out) { *g.job_out = job; return 0; }
+    return spb_partial_reduce(&job, 1, stream);
+  }
+  hipLaunchKernelGGL((pw_wgrad_kernel<T, false>), dim3(NT * KT * S), dim3(256), 0, stream, g, rps);
   SPB_CHECK_LAUNCH();
   return 0;
 }
@@ -864,6 +892,8 @@ extern "C" int spb_pwconv_gemm(int dtype, const spb_gemm_args_t* a, spb_stream_t
   return SPB_E_ARG;
 }
 
+long long spb_wgrad_part_floats(int M, int K, int N) { return wgrad_part_floats(M, K, N); }   // for krn_plan.hip
+
 extern "C" int spb_pwconv_wgrad(int dtype, const spb_wgrad_args_t* a, spb_stream_t stream) {
   if (!a || !a->G || !a->X || !a->dW) return SPB_E_ARG;
   if (a->M <= 0 || a->K <= 0 || a->N <= 0 || (a->K & 7) || (a->N & 7)) return SPB_E_SHAPE;
@@ -878,7 +908,10 @@ extern "C" int spb_debug_trread(const unsigned short* in4096, unsigned short* ou
   return 0;
 }
 
-extern "C" int spb_debug_set_wgrad_target(int wgs) { g_wgrad_target_wgs = wgs < 1 ? 1 : wgs; return 0; }
+extern "C" int spb_debug_set_wgrad_target(int wgs) {   // wgs < 0: target of the partial-store form
+  if (wgs < 0) g_wgrad_part_target = -wgs; else g_wgrad_target_wgs = wgs < 1 ? 1 : wgs;
+  return 0;
+}
 extern "C" int spb_debug_set_gemm_dma(int on) { g_disable_dma = (on == 0); g_dma_min_k = on > 1 ? on : 64; return 0; }
 extern "C" int spb_debug_set_gemm_plain_dma(int on) { g_plain_dma = (on != 0); return 0; }
 extern "C" int spb_debug_set_gemm_bk64_min_k(int k) { g_bk64_min_k = k; return 0; }

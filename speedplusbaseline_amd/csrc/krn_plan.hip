@@ -14,6 +14,8 @@
 #include <cstdio>
 #include "common.h"
 
+long long spb_wgrad_part_floats(int M, int K, int N);   // gemm_pw.hip
+
 namespace {
 
 struct PInfo { std::string name; int ndim; int shape[4]; long long off; long long numel; };
@@ -104,8 +106,12 @@ struct spb_krn_ctx {
   size_t stats_off = 0, stats_floats = 0;
   size_t dcat_off = 0, dtap_off = 0, ddom_off = 0, dom1_off = 0, gdom_off = 0;
   size_t partial_off = 0, dout_off = 0, table_off = 0, dompool_off = 0;
+  // weight-gradient partial sums (spb_red_job_t): one scratch slab per layer, keyed by the layer's weight offset in the arena
+  struct PartSlab { long long key; size_t off; long long floats; };
+  std::vector<PartSlab> parts;
   int S = 0;
   int last_training = 0;
+  bool pending_running = false;   // forward ran with training & 16: the running-statistics update rides with the next backward's side stream
   const float* x = nullptr;  // image of the last forward (needed by the stem weight gradient)
   // live per-launch timing (HIP events on the launch stream) with the algorithmic bytes of each launch
   bool prof_on = false;
@@ -234,7 +240,7 @@ static int g_launch_events = 1;        // fork on the completion event of the pr
 extern "C" int spb_debug_set_launch_events(int on) { g_launch_events = on & 1; g_skip_side = on & 6; return 0; }
 static int g_wgrad_flush_at_dw = 1;
 static int g_wgrad_min_flush = 1;      // flush at a depthwise kernel only with at least this many queued
-extern "C" int spb_debug_set_wgrad_min_flush(int n) { g_wgrad_min_flush = n < 1 ? 1 : n; return 0; }
+extern "C" int spb_debug_set_wgrad_min_flush(int n);
 static int g_wgrad_batch = 8;
 // Depthwise layers on maps up to this many columns wide run their input gradient alone on the launch stream and send the weight
 // gradient to the side stream with the pointwise ones: in the plane kernels (dwconv_plane.hip, maps up to 14x14) the weight
@@ -258,7 +264,19 @@ extern "C" int spb_debug_set_replica_rows(long long rows) {
   g_replica_min_rows = rows;
   return 0;
 }
+static int g_flush_after_dw = 0;   // measured: 3.23 ms with the side-stream batch enqueued after the launch-stream kernel, 3.19 before it
+// (sign convention of spb_debug_set_wgrad_min_flush: -1 -> before (default), -2 -> after)
+extern "C" int spb_debug_set_wgrad_min_flush(int n) {
+  if (n < 0) { g_flush_after_dw = n == -2; return 0; }
+  g_wgrad_min_flush = n < 1 ? 1 : n;
+  return 0;
+}   // spb_debug_set_wgrad_min_flush(-1) restores flush-before-launch
+static int g_wgrad_parts = 0;     // 1: pointwise weight gradients as partial sums + one reduce launch per batch instead of f32 atomics
+                                  // (order-deterministic; measured 3.25 vs 3.18 ms per step: the slab traffic and the extra launches cost more
+                                  // than the atomics they replace) -- spb_debug_set_wgrad_parts
+extern "C" int spb_debug_set_wgrad_parts(int on) { g_wgrad_parts = on; return 0; }
 static int g_fused_pw_bwd = 1;
+static long long g_fused_pw_bwd_min_m = 32768;   // spb_debug_set_fused_pw_bwd(v > 1): fused kernel from v rows up
 struct Runner {
   spb_krn_ctx* c; spb_krn* m; hipStream_t st; int dt; int err = 0;
   Runner(spb_krn_ctx* c_, hipStream_t s) : c(c_), m(c_->m), st(s), dt(c_->m->dtype) {}
@@ -290,6 +308,13 @@ struct Runner {
   float* bsums(int a) const { return stats() + c->bsums_off[a]; }
   int M(int a) const { return c->B * m->acts[a].H * m->acts[a].W; }
   const void* wc(long long off) const { return m->wc + (size_t)off * c->es; }
+  // scratch slab of a layer's weight-gradient partial sums (keyed by its weight offset); floats = 0: none
+  float* part_slab(long long key, long long* floats) const {
+    for (const auto& p : c->parts)
+      if (p.key == key) { *floats = p.floats; return reinterpret_cast<float*>(c->ws + p.off); }
+    *floats = 0;
+    return nullptr;
+  }
 
   spb_bnref_t ref(int a, bool training) const {
     const ActDef& d = m->acts[a]; const BNDef& b = m->bns[d.bn];
@@ -331,7 +356,7 @@ struct Runner {
   void pw_bwd(const PWDef& L, const Src& in, int aout, int atgt, void* plain, const void* res, float plain_scale = 1.f,
               bool before_dw = false) {
     // wide, shallow layers (the 112x112 / 56x56 maps): one fused pass over g and z for both gradients
-    if (g_fused_pw_bwd && dt == SPB_BF16 && atgt >= 0 && M(aout) >= 32768) {
+    if (g_fused_pw_bwd && dt == SPB_BF16 && atgt >= 0 && M(aout) >= g_fused_pw_bwd_min_m) {
       spb_pwbwd_args_t f; std::memset(&f, 0, sizeof(f));
       f.G = this->g(aout); f.Zn = z(aout); f.Wt = wc(L.wct_off); f.X = in.ptr; f.Zout = z(atgt); f.res = res;
       f.Y = this->g(atgt); f.dW = m->G + L.w_off; f.osums = bsums(atgt); f.pro_dz = ref(aout, true); f.pro_a = in.ref;
@@ -349,6 +374,7 @@ struct Runner {
     spb_wgrad_args_t w; std::memset(&w, 0, sizeof(w));
     w.G = this->g(aout); w.Zn = z(aout); w.X = in.ptr; w.dW = m->G + L.w_off; w.pro_dz = ref(aout, true);
     w.pro_a = in.ref; w.M = M(aout); w.K = L.K; w.N = L.N;
+    if (g_wgrad_parts) w.part = part_slab(L.w_off, &w.part_cap);
     tic(PC_PW_WGRAD, ((double)w.M * (2 * L.N + L.K)) * es() + 4.0 * L.K * L.N, 2.0 * w.M * L.K * L.N);
     queue_wgrad(w);
     toc();
@@ -396,8 +422,19 @@ struct Runner {
   // Their inputs (g, z, batch sums of the output tensor, the forward activations) are not overwritten during backward, so a
   // weight gradient may start any time after its layer's pw_bwd was reached.
   std::vector<spb_wgrad_args_t> pend;
+  std::vector<spb_red_job_t> jobs;      // reduce jobs of the partial sums stored since the last run_jobs
+  void run_jobs(hipStream_t s) {
+    if (!jobs.empty()) ok(spb_partial_reduce(jobs.data(), (int)jobs.size(), s));
+    jobs.clear();
+  }
+  void launch_wgrad(spb_wgrad_args_t w, hipStream_t s) {
+    spb_red_job_t job; std::memset(&job, 0, sizeof(job));
+    w.job_out = &job;
+    ok(spb_pwconv_wgrad(dt, &w, s));
+    if (job.nparts > 0) jobs.push_back(job);
+  }
   void queue_wgrad(const spb_wgrad_args_t& w) {
-    if (c->prof_on || !c->side || !c->side_on || !g_side_wgrad) { ok(spb_pwconv_wgrad(dt, &w, st)); return; }
+    if (c->prof_on || !c->side || !c->side_on || !g_side_wgrad) { launch_wgrad(w, st); run_jobs(st); return; }
     pend.push_back(w);
     if ((int)pend.size() >= g_wgrad_batch) flush_wgrads();
   }
@@ -415,11 +452,17 @@ struct Runner {
       hipStreamWaitEvent(c->side, launch_ev, 0);
       launch_ev = nullptr; forked = true; s = c->side;
     } else s = side_stream();            // one event record for the whole batch
+    if (c->pending_running) {   // deferred BatchNorm running-statistics update of the forward pass (spb_krn_forward, training & 16)
+      ok(spb_bn_running_update(reinterpret_cast<const spb_bnupd_entry_t*>(c->ws + c->table_off), (int)m->bns.size(), stats(),
+                               m->Bf, m->nbt, kMomentum, s));
+      c->pending_running = false;
+    }
     if (head_pending) { ok(spb_head_bwd(dt, &head_args, s)); head_pending = false; }
     if (!(g_skip_side & 4)) for (const spb_dw_args_t& d : pend_dw) ok(spb_dwconv_wgrad(dt, &d, s));
     pend_dw.clear();
-    if (!(g_skip_side & 2)) for (const spb_wgrad_args_t& w : pend) ok(spb_pwconv_wgrad(dt, &w, s));
+    if (!(g_skip_side & 2)) for (const spb_wgrad_args_t& w : pend) launch_wgrad(w, s);
     pend.clear();
+    run_jobs(s);   // one reduce launch for the batch
   }
   void join_side() {
     flush_wgrads();
@@ -442,17 +485,20 @@ struct Runner {
       pend_dw.push_back(d);
       d.dW = nullptr;
     }
-    // the queued weight gradients run beside this memory-bound kernel
-    if (g_wgrad_flush_at_dw && (int)(pend.size() + pend_dw.size()) >= g_wgrad_min_flush) flush_wgrads();
-    launch_ev = nullptr;   // the event belongs to the launch before this one: nothing queued later may fork on it
     // one fused pass: input gradient (+ activation mask / BN sums of the input-side tensor) and weight gradient
     if (atgt >= 0) {
       d.Y = this->g(atgt); d.osums = bsums(atgt); d.oR = c->R[atgt]; d.res = res; d.epi_mode = 2;
     } else { d.Y = plain; d.epi_mode = 0; d.oR = 1; }
     const double nin = (double)c->B * Hin * Hin * L.C, nout = elems(aout);
+    if (!g_flush_after_dw && g_wgrad_flush_at_dw && (int)(pend.size() + pend_dw.size()) >= g_wgrad_min_flush) flush_wgrads();
     tic(PC_DW_DGRAD, (2 * nout + 2 * nin + (res ? nin : 0)) * es(), 36.0 * nout);
     ok(spb_dwconv_dgrad(dt, &d, st));
     toc();
+    // the queued weight gradients run beside this memory-bound kernel.  They are handed to the side stream AFTER the launch
+    // stream got its kernel: the host is only a bounded number of packets ahead of the GPU, and a burst of ~10 side-stream
+    // launches in front of the next launch-stream kernel showed up as 30-50 us holes in the launch queue (round-3 trace)
+    if (g_flush_after_dw && g_wgrad_flush_at_dw && (int)(pend.size() + pend_dw.size()) >= g_wgrad_min_flush) flush_wgrads();
+    launch_ev = nullptr;   // the event belongs to the launch before the depthwise kernel: nothing queued later may fork on it
   }
 };
 
@@ -714,10 +760,35 @@ static void layout_ctx(const spb_krn* m, int B, int dtype, spb_krn_ctx* c, size_
   size_t dompool = take((size_t)B * 1280 * sizeof(float));
   size_t partial = take((size_t)S * B * m->Jp * sizeof(float));
   size_t dout = take((size_t)B * m->J * sizeof(float));
+  // scratch slabs of the weight-gradient partial sums: pointwise (row splits, or one part per workgroup of the fused
+  // backward kernel on the 112x112 / 56x56 maps) and depthwise (one part per workgroup of a channel quad)
+  std::vector<spb_krn_ctx::PartSlab> slabs;
+  auto pw_slab = [&](const PWDef& d, int H) {
+    const long long Mr = (long long)B * H * H;
+    long long f = spb_wgrad_part_floats((int)Mr, d.K, d.N);
+    if (Mr >= 32768 && 512LL * d.N * d.K > f) f = 512LL * d.N * d.K;
+    if (f > 0) slabs.push_back(spb_krn_ctx::PartSlab{d.w_off, take((size_t)f * sizeof(float)), f});
+  };
+  auto dw_slab = [&](const DWDef& d) {
+    const long long f = 520LL * d.C * 9;
+    slabs.push_back(spb_krn_ctx::PartSlab{d.w_off, take((size_t)f * sizeof(float)), f});
+  };
+  for (int k = 1; k <= 17; ++k) {
+    const Block& b = m->blk[k];
+    if (b.t != 1) pw_slab(b.E, b.Hin);
+    dw_slab(b.D);
+    pw_slab(b.P, b.Hout);
+  }
+  for (int e = 0; e < 4; ++e) {
+    if (e == 2) { pw_slab(m->router, 14); continue; }
+    dw_slab(m->eD[e]); pw_slab(m->eP[e], 7);
+  }
+  if (m->dann) pw_slab(m->dc0, 7);
   if (c) {
     c->table_off = table; c->stats_off = stats; c->stats_floats = sf; c->dcat_off = dcat; c->dtap_off = dtap;
     c->ddom_off = ddom; c->dom1_off = dom1; c->gdom_off = gdom; c->dompool_off = dompool; c->partial_off = partial;
     c->dout_off = dout; c->S = S;
+    c->parts = slabs;
   }
   *total = off;
 }
@@ -764,7 +835,7 @@ extern "C" int spb_krn_ctx_create(spb_krn_t* m, int batch, void* workspace, spb_
 }
 extern "C" void spb_krn_ctx_destroy(spb_krn_ctx_t* c) { delete c; }
 extern "C" int spb_debug_set_side_wgrad(int on) { g_side_wgrad = on; return 0; }
-extern "C" int spb_debug_set_fused_pw_bwd(int on) { g_fused_pw_bwd = on; return 0; }
+extern "C" int spb_debug_set_fused_pw_bwd(int on) { g_fused_pw_bwd = on != 0; if (on > 1) g_fused_pw_bwd_min_m = on; return 0; }
 extern "C" int spb_krn_ctx_set_side_stream(spb_krn_ctx_t* c, int on) {
   if (!c) return SPB_E_ARG;
   c->side_on = on != 0;
@@ -781,17 +852,29 @@ extern "C" int spb_krn_forward(spb_krn_ctx_t* c, const float* x, const float* ta
   Runner r(c, st);
   // training & 4: refresh the compute-dtype weight copies first (what spb_krn_prepare_weights does) -- on the side stream,
   // beside the stem and the first depthwise layer, which read the f32 parameters; joined before the first 1x1 convolution
-  const bool prep = (training & 4) != 0;
+  // training & 8: zero the bound gradient arena (optimizer.zero_grad()) on the side stream too -- nothing touches it before the
+  // backward pass; training & 16: the BatchNorm running-statistics update is left to the next spb_krn_backward on this context,
+  // which runs it on its side stream (no kernel of the step reads the running statistics)
+  const bool prep = (training & 4) != 0, zero_g = (training & 8) != 0 && m->G != nullptr, defer_run = (training & 16) != 0;
   training &= 3;
+  if (c->pending_running) {   // a deferred update that no backward pass picked up: apply it before the sums are overwritten
+    r.ok(spb_bn_running_update(reinterpret_cast<const spb_bnupd_entry_t*>(c->ws + c->table_off), (int)m->bns.size(), r.stats(),
+                               m->Bf, m->nbt, kMomentum, stream));
+    c->pending_running = false;
+  }
   bool prep_wait = false;
-  if (prep) {
+  if (prep || zero_g) {
     if (r.side_usable() && c->fork_ev.size() > 0) {
       hipEventRecord(c->fork_ev[0], st);
       hipStreamWaitEvent(c->side, c->fork_ev[0], 0);
-      r.ok(spb_weight_prep(m->dtype, m->prep_d, m->n_prep, m->n_prep_tiles, m->P, m->wc, c->side));
+      if (prep) r.ok(spb_weight_prep(m->dtype, m->prep_d, m->n_prep, m->n_prep_tiles, m->P, m->wc, c->side));
+      if (zero_g && hipMemsetAsync(m->G, 0, (size_t)m->n_params * sizeof(float), c->side) != hipSuccess) r.ok(SPB_E_STATE);
       hipEventRecord(c->prep_ev, c->side);
       prep_wait = true;
-    } else r.ok(spb_weight_prep(m->dtype, m->prep_d, m->n_prep, m->n_prep_tiles, m->P, m->wc, stream));
+    } else {
+      if (prep) r.ok(spb_weight_prep(m->dtype, m->prep_d, m->n_prep, m->n_prep_tiles, m->P, m->wc, stream));
+      if (zero_g && hipMemsetAsync(m->G, 0, (size_t)m->n_params * sizeof(float), st) != hipSuccess) r.ok(SPB_E_STATE);
+    }
   }
   const bool tr = training != 0;
   const spb_bnupd_entry_t* tab = reinterpret_cast<const spb_bnupd_entry_t*>(c->ws + c->table_off);
@@ -874,7 +957,8 @@ extern "C" int spb_krn_forward(spb_krn_ctx_t* c, const float* x, const float* ta
                        reinterpret_cast<float*>(c->ws + c->dompool_off), domain_logits, 49, 1280);
     r.toc();
   }
-  if (tr && training != 2) {   // training == 2: the caller applies the running-statistics update later (spb_krn_update_running)
+  if (tr && defer_run && training != 2 && r.side_usable()) c->pending_running = true;
+  else if (tr && training != 2) {   // training == 2: the caller applies the running-statistics update later (spb_krn_update_running)
     r.tic(PC_BN_UPDATE, (double)c->stats_floats * 2 + (double)m->n_buffers * 8);
     r.ok(spb_bn_running_update(tab, (int)m->bns.size(), r.stats(), m->Bf, m->nbt, kMomentum, stream));
     r.toc();
@@ -890,6 +974,7 @@ extern "C" int spb_krn_forward(spb_krn_ctx_t* c, const float* x, const float* ta
 extern "C" int spb_krn_update_running(spb_krn_ctx_t* c, spb_stream_t stream) {
   if (!c || !c->last_training) return SPB_E_STATE;
   spb_krn* m = c->m;
+  c->pending_running = false;
   Runner r(c, (hipStream_t)stream);
   const spb_bnupd_entry_t* tab = reinterpret_cast<const spb_bnupd_entry_t*>(c->ws + c->table_off);
   return spb_bn_running_update(tab, (int)m->bns.size(), r.stats(), m->Bf, m->nbt, kMomentum, stream);
@@ -1033,6 +1118,11 @@ extern "C" int spb_krn_backward(spb_krn_ctx_t* c, float* grads, float gscale, in
     r.toc();
   }
   r.join_side();
+  if (c->pending_running) {
+    r.ok(spb_bn_running_update(reinterpret_cast<const spb_bnupd_entry_t*>(c->ws + c->table_off), (int)m->bns.size(), r.stats(),
+                               m->Bf, m->nbt, kMomentum, stream));
+    c->pending_running = false;
+  }
   r.tic(PC_BN_PARAM_GRADS, (double)c->stats_floats * 2);
   // BatchNorm affine gradients: dgamma += sum(g*xhat), dbeta += sum(g)
   r.ok(spb_bn_param_grads(reinterpret_cast<const spb_bnupd_entry_t*>(c->ws + c->table_off),
@@ -1068,6 +1158,18 @@ extern "C" int spb_krn_prof_enable(spb_krn_ctx_t* c, int on) {
 }
 extern "C" int spb_krn_prof_num_categories(void) { return PC_COUNT; }
 extern "C" const char* spb_krn_prof_category_name(int i) { return (i >= 0 && i < PC_COUNT) ? kProfNames[i] : ""; }
+// Per-launch records since the last spb_krn_prof_read, in launch order: category, milliseconds, algorithmic bytes.  Returns the
+// number of records (at most `max` are written); does not reset.
+extern "C" int spb_krn_prof_launches(spb_krn_ctx_t* c, int max, int* cat, float* ms, double* bytes) {
+  if (!c || !cat || !ms || !bytes) return SPB_E_ARG;
+  for (int i = 0; i < c->prof_n && i < max; ++i) {
+    if (hipEventSynchronize(c->prof_ev[2 * i + 1]) != hipSuccess) return SPB_E_STATE;
+    float t = 0.f;
+    if (hipEventElapsedTime(&t, c->prof_ev[2 * i], c->prof_ev[2 * i + 1]) != hipSuccess) return SPB_E_STATE;
+    cat[i] = c->prof_cat[i]; ms[i] = t; bytes[i] = c->prof_bytes[i];
+  }
+  return c->prof_n;
+}
 // Sums the launches recorded since the last call per category (synchronises on the recorded events) and resets.
 extern "C" int spb_krn_prof_read(spb_krn_ctx_t* c, int* launches, float* ms, double* bytes, double* flops) {
   if (!c || !launches || !ms || !bytes || !flops) return SPB_E_ARG;

@@ -295,7 +295,7 @@ __global__ __launch_bounds__(256, 1) void pwb_kernel(const spb_pwbwd_args_t g, l
     if (n < N && k < K) {
       float v = 0.f;
       for (int w = 0; w < nw; ++w) v += red[w * NB * KB * 256 + e];
-      atomicAdd(g.dW + (size_t)n * K + k, v);
+      SPB_ATOMIC_W(g.dW + (size_t)n * K + k, v);
     }
   }
   __syncthreads();

@@ -109,11 +109,14 @@ class KrnEngine:
                                % (tuple(x.shape),))
         return x.detach().to(torch.float32).contiguous()
 
-    def forward(self, x, target=None, training=True, slot=0, domain=False, prepare=True, update_running=True):
+    def forward(self, x, target=None, training=True, slot=0, domain=False, prepare=True, update_running=True,
+                zero_grads=False, defer_running=False):
         """Enqueue one forward.  Returns (pred [B,2K], scalars [3] or None, domain_logits [B] or None); x is kept
         alive by the caller/ctx until backward.  prepare=False: the compute-dtype weight copies are already current
         (second pass of a DANN step); update_running=False: training forward whose BatchNorm running-statistics update is
-        applied later by update_running(batch, slot)."""
+        applied later by update_running(batch, slot).  zero_grads=True: the gradient arena is zeroed on the context's side stream
+        (optimizer.zero_grad() off the launch stream); defer_running=True: the running-statistics update is enqueued by the next
+        backward() on this context, on its side stream (the fused train step: nothing in it reads the running statistics)."""
         x = self._check_input(x)
         B = x.shape[0]
         ctx = self.context(B, slot)
@@ -128,6 +131,10 @@ class KrnEngine:
                 scalars = torch.empty(3, dtype=torch.float32, device=self.device)
             dom = torch.empty(B, dtype=torch.float32, device=self.device) if (domain and self.dann) else None
             mode = ((1 if update_running else 2) if training else 0) | (4 if prepare else 0)   # | 4: refresh the weight copies on the side stream
+            if zero_grads:
+                mode |= 8
+            if defer_running and training and update_running:
+                mode |= 16
             L.check(self.lib.spb_krn_forward(ctx, _p(x), _p(target), mode, _p(pred),
                                              _p(scalars), _p(dom), st), "spb_krn_forward")
         self._last_x = getattr(self, "_last_x", {})
@@ -190,6 +197,14 @@ class KrnEngine:
                 out[self.lib.spb_krn_prof_category_name(i).decode()] = dict(launches=int(la[i]), ms=float(ms[i]),
                                                                             bytes=float(by[i]), flops=float(fl[i]))
         return out
+
+    def prof_launches(self, batch, slot=0, cap=512):
+        """[(kernel family, ms, algorithmic bytes)] of every launch since the last prof_read, in launch order"""
+        cat = (C.c_int * cap)(); ms = (C.c_float * cap)(); by = (C.c_double * cap)()
+        n = self.lib.spb_krn_prof_launches(self.context(batch, slot), cap, cat, ms, by)
+        if n < 0:
+            L.check(n, "spb_krn_prof_launches")
+        return [(self.lib.spb_krn_prof_category_name(cat[i]).decode(), float(ms[i]), float(by[i])) for i in range(min(n, cap))]
 
     def weight_prep_bytes(self):
         return int(self.lib.spb_krn_weight_prep_bytes(self.h))

@@ -210,6 +210,16 @@ def grad_sqnorm(grads, out):
     L.check(L.lib().spb_grad_sqnorm(_ptr(grads), grads.numel(), _ptr(out), _stream()), "spb_grad_sqnorm")
 
 
+SQ_PARTS = 256
+
+
+def grad_sqnorm_partials(grads, out):
+    """sum of squares of the arena as SQ_PARTS partial sums (no arrival counter); optim_step(sq_partials=out) adds them up"""
+    _need_cuda(grads, out)
+    assert out.numel() >= SQ_PARTS and out.dtype == torch.float32
+    L.check(L.lib().spb_grad_sqnorm_partials(_ptr(grads), grads.numel(), _ptr(out), _stream()), "spb_grad_sqnorm_partials")
+
+
 def arena_zero(arena):
     """optimizer.zero_grad() on a flat f32 arena (no ATen kernel on the hot path)"""
     _need_cuda(arena)
@@ -225,9 +235,13 @@ OPT_KIND = {"sgd": 0, "rmsprop": 1, "adam": 2, "adamw": 3}
 
 
 def optim_step(kind, params, grads, m=None, v=None, sqnorm=None, gmul=None, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8,
-               weight_decay=0.0, max_norm=0.0, clip_value=0.0, step=1, first_step=False, hyper=None, shadow=None, max_blocks=0):
+               weight_decay=0.0, max_norm=0.0, clip_value=0.0, step=1, first_step=False, hyper=None, shadow=None, max_blocks=0,
+               sq_partials=None):
     a = _optim_args(kind, params, grads, m, v, sqnorm, gmul, lr, beta1, beta2, eps, weight_decay, max_norm, clip_value, step, first_step,
                     hyper, shadow, max_blocks)
+    if sq_partials is not None:
+        _need_cuda(sq_partials)
+        a.sq_partials = _ptr(sq_partials); a.n_sq_partials = SQ_PARTS
     L.check(L.lib().spb_optim_step(C.byref(a), _stream()), "spb_optim_step")
 
 

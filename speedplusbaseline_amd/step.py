@@ -2,11 +2,16 @@
 global-norm clip -> optimizer update, in the reference's order (trainer.py:72-98; dann.py:68-100), enqueued as HIP
 kernels with no host synchronisation.  The whole forward+backward is two C calls that enqueue ~200 launches, which
 keeps the MI355X busy without a graph; weight-gradient GEMMs go to a side stream and overlap the input-gradient chain
-(measured 5.06 ms / step at B=48 bf16).  A captured hipGraph replay is available (use_graph=True, 5.29 ms: cross-stream
-edges inside a graph cost more than they hide, so the side stream is switched off there).
+(KRN: 3.2 ms / step at B=48 bf16 at the start of round 3; DANN 5.06 ms).  A captured hipGraph replay is available
+(use_graph=True, KRN 3.65 ms: cross-stream edges inside a graph cost more than they hide, so the side stream is switched off
+there).
 
-The per-step scalars that change between replays (lr, Adam bias corrections) live in a 3-float device buffer that is
-refreshed by an async H2D copy before each step, so the captured launch arguments stay valid.
+Eager mode passes the per-step scalars (lr, Adam bias corrections) by value in the optimizer launch; only the graph mode keeps
+them in a 3-float device buffer refreshed by an async H2D copy before each replay (that copy and the bubble behind it were
+17 us of every eager step).  Step-boundary work that nothing on the launch stream waits for rides on the plan's side stream:
+zero_grad with the weight-copy refresh at the start of forward, the BatchNorm running-statistics update with the first
+weight-gradient batch of backward.  The clip's sum of squares is 256 per-workgroup partials that every optimizer workgroup
+adds up itself (the one-scalar form spent 13 of its 20 us on 512 same-address ticket atomics).
 """
 import os
 
@@ -49,6 +54,7 @@ class FusedTrainStep:
         self.m = torch.zeros(n, dtype=torch.float32, device=dev)
         self.v = torch.zeros(n, dtype=torch.float32, device=dev)
         self.sq = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.sqp = torch.zeros(ops.SQ_PARTS, dtype=torch.float32, device=dev)
         ops.grad_sqnorm(engine.grads, self.sq)     # first call allocates the library's reduction scratch (never inside a graph capture)
         self.gmul = torch.full((1,), mean_scale(self.world), dtype=torch.float32, device=dev) if self.world > 1 else None
         self.hyper = torch.zeros(3, dtype=torch.float32, device=dev)
@@ -71,6 +77,8 @@ class FusedTrainStep:
         return self.momentum, 0.0
 
     def _refresh_hyper(self):
+        if not self.use_graph:
+            return                      # eager: lr / bias corrections travel by value in the optimizer launch
         b1, b2 = self._betas()
         i = self.t % self._hslots
         ev = self._hyper_ev[i]
@@ -89,8 +97,10 @@ class FusedTrainStep:
     def _fwd_bwd(self, x, y, xt=None, alpha=0.0):
         e = self.e
         if not self.dann:
-            _, scal, _ = e.forward(x, y, training=True, slot=0)
-            ops.arena_zero(e.grads)
+            side = not self.use_graph   # graph capture keeps every launch on one stream
+            _, scal, _ = e.forward(x, y, training=True, slot=0, zero_grads=side, defer_running=side)
+            if not side:
+                ops.arena_zero(e.grads)
             e.backward(self.B, slot=0)
             if self._overlap:   # early bucket: all-reduce on the communication stream beside the rest of the backward
                 e.wait_bucket(self.B, 0, self._comm)
@@ -146,11 +156,11 @@ class FusedTrainStep:
         e = self.e
         b1, b2 = self._betas()
         if self.max_norm > 0:
-            ops.grad_sqnorm(e.grads, self.sq)
-        ops.optim_step(self.kind, e.params, e.grads, m=self.m, v=self.v, sqnorm=self.sq if self.max_norm > 0 else None,
+            ops.grad_sqnorm_partials(e.grads, self.sqp)
+        ops.optim_step(self.kind, e.params, e.grads, m=self.m, v=self.v, sq_partials=self.sqp if self.max_norm > 0 else None,
                        gmul=self.gmul, lr=self.lr, beta1=b1, beta2=b2, eps=_KIND_DEFAULT_EPS,
                        weight_decay=self.weight_decay, max_norm=self.max_norm, clip_value=self.clip_value, step=max(self.t, 1),
-                       first_step=False, hyper=self.hyper)
+                       first_step=False, hyper=self.hyper if self.use_graph else None)
 
     def static_inputs(self):
         """the graph's input buffers (write a batch into them to skip the per-step device copy)"""
