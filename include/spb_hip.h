@@ -563,6 +563,8 @@ int spb_debug_set_gemm_dma(int on); /* 1: small-M bf16 pointwise GEMMs use the L
 int spb_debug_set_dw_mode(int mode); /* depthwise fwd/dgrad: 1 plane kernels on maps up to spb_debug_set_dw_plane_max_w columns wide (14x14 and 7x7 by default), row-unit kernels elsewhere (default); 0 row-unit kernels only */
 int spb_debug_set_fused_pw_bwd(int on); /* 0: the KRN plan never uses spb_pwconv_bwd_fused */
 int spb_debug_set_stem_mfma(int on); /* 0: bf16 stem uses the scalar kernels instead of the MFMA implicit GEMM */
+int spb_debug_set_gemm_big(int on, int min_n, int min_k); /* small-M bf16 GEMMs with N >= min_n (512), K >= min_k (256): 128 x 128 tile kernel (on=1, default) */
+int spb_debug_set_gemm_wide_min_n(int n); /* small-M forward-type bf16 GEMMs with N >= n and a long reduction: 64 x 128 tiles */
 int spb_debug_set_gemm_bk64_min_k(int k); /* small-M bf16 GEMMs with K >= k use 64-wide reduction chunks (default 256) */
 int spb_debug_set_gconv_slab(int mode); /* wide decoder convs: 0 per-wave weight streaming; 1 slab kernel with 4 tiles (1 workgroup per CU); 2 (default) 2 tiles, 2 per CU */
 int spb_debug_set_side_wgrad(int on); /* 0: pointwise weight gradients stay on the launch stream */

@@ -22,6 +22,7 @@
 
 int spb_gemm_sk(const spb_gemm_args_t* a, hipStream_t stream);   // gemm_sk.hip
 int spb_gemm_os(const spb_gemm_args_t* a, hipStream_t stream);   // gemm_os.hip
+int spb_gemm_big(const spb_gemm_args_t* a, hipStream_t stream);  // gemm_big.hip
 
 // phase timestamps for scratch/ubench_gemm.hip (compiled out in the product build)
 #ifndef SPB_TS
@@ -48,7 +49,7 @@ constexpr size_t gemm_region_bytes() {
 
 // RF = 16-row fragments per wave (workgroup tile = 64*RF rows x BN columns)
 template <typename T, int RF, int BN, int BK, int PRO, int EPI>
-__global__ __launch_bounds__(256, (RF == 1 && sizeof(T) == 2) ? ((BK == 64 && PRO == 2) ? 2 : 4) : 1) void pw_gemm_kernel(const spb_gemm_args_t g) {
+__global__ __launch_bounds__(256, (RF == 1 && sizeof(T) == 2) ? (((BK == 64 && PRO == 2) || BN == 128) ? 2 : 4) : 1) void pw_gemm_kernel(const spb_gemm_args_t g) {
   constexpr int BM = 64 * RF;
   constexpr int GBK = BK;
   constexpr int LDK = LdsPad<T, BK>::LDK;
@@ -622,6 +623,7 @@ bool g_disable_dma = true;
 int g_dma_min_k = 64;      // spb_debug_set_gemm_dma(v): v == 1 -> every K >= 64, v > 1 -> only reductions K >= v
 bool g_plain_dma = true;
 int g_bk64_min_k = 256;
+int g_wide_min_n = 1 << 30;    // spb_debug_set_gemm_wide_min_n
 int g_bk64_dgrad_min_k = 1 << 30;   // spb_debug_set_gemm_bk64_dgrad_min_k
 
 template <typename T, int PRO, int EPI>
@@ -638,6 +640,10 @@ int dispatch_bn(const spb_gemm_args_t& g, hipStream_t stream) {
   if (EPI == 2 && bn == 128) bn = 64;        // backward epilogue hoists 2 operand vectors per output row sweep
   // small M (the 14x14 and 7x7 maps): 64-row tiles and 64-column tiles so the launch has enough workgroups
   const bool small_m = g.M <= 40000;   // 28x28 and below: 64-row tiles at 4 waves/SIMD beat 128-row tiles at 2
+  // wide outputs behind a long reduction (the 7x7 ConvDw layers, N = 1024, K = 320..1280): 64 x 128 tiles with 64-deep chunks
+  if constexpr (sizeof(T) == 2 && PRO == 1 && EPI != 2) {
+    if (small_m && bn == 128 && g.N >= g_wide_min_n && g.K >= g_bk64_min_k) return launch_gemm<T, 1, 128, 64, PRO, EPI>(g, stream);
+  }
   if (small_m && bn == 128) bn = 64;
   if (small_m) {
     if (bn == 32) return launch_gemm<T, 1, 32, 32, PRO, EPI>(g, stream);
@@ -880,6 +886,9 @@ extern "C" int spb_pwconv_gemm(int dtype, const spb_gemm_args_t* a, spb_stream_t
   if (a->epi_mode != 0 && (!a->osums || a->oR < 1)) return SPB_E_ARG;
   if (a->epi_mode == 2 && !a->Zout) return SPB_E_ARG;
   if (dtype == SPB_BF16) {
+    // the 7x7 maps, wide output behind a long reduction (ConvDw extras, domain classifier): 128 x 128 tiles (gemm_big.hip)
+    const int eb = spb_gemm_big(a, (hipStream_t)stream);
+    if (eb != SPB_E_UNSUPPORTED) return eb;
     // 28x28 / 14x14 maps, medium reduction, narrow output: the one-shot kernel (gemm_os.hip)
     const int eo = spb_gemm_os(a, (hipStream_t)stream);
     if (eo != SPB_E_UNSUPPORTED) return eo;
@@ -915,6 +924,7 @@ extern "C" int spb_debug_set_wgrad_target(int wgs) {   // wgs < 0: target of the
 extern "C" int spb_debug_set_gemm_dma(int on) { g_disable_dma = (on == 0); g_dma_min_k = on > 1 ? on : 64; return 0; }
 extern "C" int spb_debug_set_gemm_plain_dma(int on) { g_plain_dma = (on != 0); return 0; }
 extern "C" int spb_debug_set_gemm_bk64_min_k(int k) { g_bk64_min_k = k; return 0; }
+extern "C" int spb_debug_set_gemm_wide_min_n(int n) { g_wide_min_n = n; return 0; }
 extern "C" int spb_debug_set_gemm_bk64_dgrad_min_k(int k) { g_bk64_dgrad_min_k = k; return 0; }
 
 extern "C" const char* spb_version(void) { return "speedplusbaseline_amd gfx950 r1"; }

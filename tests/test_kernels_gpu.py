@@ -75,14 +75,17 @@ def test_trread_semantics(device):
 @pytest.fixture(params=["default", "lds_dma", "tiled"])
 def gemm_variant(request):
     """the pointwise-GEMM kernels: the default dispatch (one-shot kernel for medium reductions with a narrow output on the 28x28 /
-    14x14 maps, split-K-over-waves kernel for small M with a long reduction, the register-prefetch tiled kernel otherwise), the LDS-DMA ring (small M, bf16, K >= 64) and the tiled kernel alone"""
+    14x14 maps, split-K-over-waves kernel for small M with a long reduction, the 128 x 128 tile kernel for a wide output behind a long
+    reduction on the 7x7 maps, the register-prefetch tiled kernel otherwise), the LDS-DMA ring (small M, bf16, K >= 64) and the tiled kernel alone"""
     L.lib().spb_debug_set_gemm_dma(1 if request.param == "lds_dma" else 0)
     L.lib().spb_debug_set_gemm_sk(0 if request.param != "default" else 1, 0, 0)
     L.lib().spb_debug_set_gemm_os(0 if request.param != "default" else 1, 0, 0, 0)
+    L.lib().spb_debug_set_gemm_big(0 if request.param != "default" else 1, 0, 0)
     yield request.param
     L.lib().spb_debug_set_gemm_dma(0)
     L.lib().spb_debug_set_gemm_sk(1, 0, 0)
     L.lib().spb_debug_set_gemm_os(1, 0, 0, 0)
+    L.lib().spb_debug_set_gemm_big(1, 0, 0)
 
 
 @pytest.fixture(params=["auto", "rows"])
