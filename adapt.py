@@ -3,6 +3,8 @@ import logging
 import os
 import os.path as osp
 
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")   # before the HIP runtime starts (speedplusbaseline_amd/__init__.py)
+
 import torch
 
 from config import cfg
@@ -23,6 +25,7 @@ def main():
     setup_logger('adapt')
     set_all_seeds(2021, cfg, True)  # the reference pins 2021 here (adapt.py:55)
     os.makedirs(cfg.savedir, exist_ok=True)
+    os.makedirs(cfg.logdir, exist_ok=True)   # valid_krn (--test_epoch) writes its result files there
     model = get_model(cfg)
     optimizer = get_optimizer(cfg, model)
     checkpoint_file = osp.join(cfg.savedir, 'checkpoint.pth.tar')

@@ -7,6 +7,7 @@ Differences from the reference, all invisible at its evaluation batch size of 1 
 batch is scored (the reference updates its meters and result lists with the LAST sample of a batch only, inference.py:95-106),
 and `speed_score(applyThresh=False)` returns a value instead of raising UnboundLocalError (metrics.py:62)."""
 import logging
+import os
 import os.path as osp
 import time
 
@@ -91,6 +92,7 @@ def valid_krn(epoch, cfg, model, data_loader, cameraMatrix, distCoeffs, corners3
     performances = tr.finish(epoch, writer)
     logdir = getattr(cfg, 'logdir', None)
     if logdir:                                    # inference.py:128-142
+        os.makedirs(logdir, exist_ok=True)
         for fn, key in (('err_q.txt', 'err_q'), ('err_t.txt', 'err_t'), ('speed_raw.txt', 'speed_raw'), ('speed_mod.txt', 'speed_mod')):
             with open(osp.join(logdir, fn), 'w') as f:
                 for v in tr.all[key]:

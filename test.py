@@ -5,6 +5,8 @@ import logging
 import os
 import os.path as osp
 
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")   # before the HIP runtime starts (speedplusbaseline_amd/__init__.py)
+
 import torch
 
 from config import cfg
@@ -38,7 +40,7 @@ def main():
     test_loader = SyntheticEvalLoader(1, cfg.synthetic_batches, corners3D, cameraMatrix, distCoeffs, hw, seed=cfg.seed)   # batch 1: datasets/build.py:51
     assert attClasses.shape[0] == cfg.num_classes, 'Number of classes not matching.'
     performances = eval('valid_' + cfg.model_name)(0, cfg, model, test_loader, cameraMatrix, distCoeffs, corners3D, None, device, attClasses)
-    writefn = osp.join(cfg.logdir, cfg.resultfn)
+    writefn = osp.join(cfg.logdir, cfg.resultfn or 'results.txt')   # the reference's default '' names the directory itself (IsADirectoryError)
     with open(writefn, 'w') as f:
         for metric in performances:
             msg = metric + ': {:.5f} [' + performances[metric].unit + ']\n'

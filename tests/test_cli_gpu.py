@@ -78,3 +78,30 @@ def test_train_single_epoch_spn_driver(device, capsys):
     assert set(w.s) == {"train/loss_c", "train/loss_r"} and all(v[0] == v[0] and v[0] > 0 for v in w.s.values())
     assert opt._t == 5 and float((model.flat_parameters() - before).abs().max()) > 0
     assert torch.isfinite(model.flat_parameters()).all()
+
+
+def test_train_with_per_epoch_validation_krn_and_spn(device, tmp_path):
+    """train.py --test_epoch 1 (reference train.py:135-138): valid_krn / valid_spn run after every epoch on the synthetic loader"""
+    out = run("train.py", "--model_name", "krn", "--batch_size", 4, "--synthetic_batches", 2, "--optimizer", "adamw", "--max_epochs", 1,
+              "--test_epoch", 1, "--savedir", tmp_path / "k_save", "--logdir", tmp_path / "k_log", "--precision", "bf16")
+    assert "Testing 001" in out or "Testing 000" in out, out[-2000:]
+    for fn in ('err_q.txt', 'err_t.txt', 'speed_raw.txt', 'speed_mod.txt'):
+        assert len(open(tmp_path / "k_log" / fn).read().split()) >= 1
+    out = run("train.py", "--model_name", "spn", "--num_classes", 64, "--batch_size", 4, "--synthetic_batches", 2, "--optimizer", "adamw",
+              "--max_epochs", 1, "--test_epoch", 1, "--savedir", tmp_path / "s_save", "--logdir", tmp_path / "s_log")
+    assert "Testing" in out and "eR" in out, out[-2000:]
+
+
+def test_adapt_with_per_epoch_validation(device, tmp_path):
+    """adapt.py --test_epoch 1 with a log directory that does not exist yet (FileNotFoundError at the first validation)"""
+    out = run("adapt.py", "--perform_dann", "--model_name", "krn", "--batch_size", 4, "--synthetic_batches", 2, "--max_epochs", 1, "--optimizer",
+              "adamw", "--test_epoch", 1, "--savedir", tmp_path / "save", "--logdir", tmp_path / "fresh" / "log", "--precision", "bf16")
+    assert "Testing" in out
+    assert os.path.exists(tmp_path / "fresh" / "log" / "err_q.txt") and os.path.exists(tmp_path / "save" / "checkpoint.pth.tar")
+
+
+def test_test_py_spn_with_the_default_result_name(device, tmp_path):
+    """test.py --model_name spn with the reference's default --resultfn '' (was IsADirectoryError after the whole evaluation)"""
+    run("test.py", "--model_name", "spn", "--num_classes", 64, "--synthetic_batches", 3, "--logdir", tmp_path / "log")
+    txt = open(tmp_path / "log" / "results.txt").read()
+    assert "eR" in txt and "speed (raw)" in txt

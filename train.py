@@ -4,6 +4,8 @@ import logging
 import os
 import os.path as osp
 
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")   # before the HIP runtime starts (speedplusbaseline_amd/__init__.py)
+
 import torch
 
 from config import cfg
