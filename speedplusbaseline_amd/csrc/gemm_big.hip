@@ -9,10 +9,11 @@
 // 64 x 64 tiles with a register prefetch two chunks deep and two barriers per 64-deep chunk: 25-43 us, 150-200 TFLOP/s, the
 // K loop bound by one memory round trip per chunk.  Here:
 //   * 128 x 128 tiles, eight waves as 2 x 4, a wave owns 64 x 32 = 4 x 2 MFMA tiles;
-//   * operands go global -> LDS by LDS-DMA (no VGPRs) into a ring of NST stages, counted s_waitcnt; the 16-byte slots of a
+//   * operands go global -> LDS by LDS-DMA (no VGPRs) into a ring of three stages, counted s_waitcnt; the 16-byte slots of a
 //     row are XOR-swizzled with (row & 7) on the SOURCE address, so the lane-linear DMA image is read back conflict-free;
-//   * the BatchNorm(+activation) / BatchNorm-backward transform runs ONCE per element, in place in the landed A tile (a
-//     workgroup-wide sweep, 32 bytes per thread), not per fragment read: the MFMAs stay fed by plain ds_read_b128;
+//   * the BatchNorm(+activation) / BatchNorm-backward transform runs ONCE per element, in place in the landed A tile (each
+//     wave the rows it fetched itself, so it waits for its own DMA only), not per fragment read: the MFMAs stay fed by plain
+//     ds_read_b128; the transform of stage kt+1 is issued behind the matrix steps of stage kt and one barrier closes the stage;
 //   * epilogue through LDS for 16-byte stores; batch sums per workgroup, one f32 atomic per channel and workgroup.
 // bf16 only (the f32 parity mode keeps the tiled kernel).
 #include "common.h"
@@ -37,7 +38,7 @@ __global__ __launch_bounds__(NTH) void pw_big_kernel(const spb_gemm_args_t g) {
   typedef bf16_t T;
   constexpr int NA = PRO == 2 ? 2 : 1;                 // A-side tensors (g and z for the BatchNorm-backward prologue)
   constexpr int STAGE = (NA + 1) * GB_TILE;
-  constexpr int NST = PRO == 2 ? 2 : 3;                // 96 KB of ring either way
+  constexpr int NST = 3;                               // 96 KB (forward) / 144 KB (BatchNorm-backward prologue: g and z tiles) of ring
   constexpr int DI = 16 / NW;                          // DMA instructions per tile and wave
   constexpr int IPS = (NA + 1) * DI;                   // DMA instructions per stage and wave
   constexpr int LDO = GB + 8, NV = GB / 8, VR = NTH / NV, VRI = GB / VR;
@@ -125,31 +126,16 @@ __global__ __launch_bounds__(NTH) void pw_big_kernel(const spb_gemm_args_t g) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) e_bias[j] = (colok && g.bias) ? g.bias[nE + j] : 0.f;
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  SPB_TSR(1);
-
-  f32x4_t acc[4][WJ];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < WJ; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
   const float act_h = act_hi(g.pro.act), act_n = act_ns(g.pro.act, g.pro.slope);
-
-  for (int kt = 0; kt < KT; ++kt) {
-    if (kt > 0) {
-      // stage kt has landed once at most min(NST-2, KT-1-kt) younger stages are in flight
-      if (NST > 2 && KT - 1 - kt >= NST - 2) wait_vmcnt<(NST - 2) * IPS>();
-      else wait_vmcnt<0>();
-      __builtin_amdgcn_s_barrier();    // everyone's share of stage kt is visible; everyone is done with the matrix steps of stage kt-1
-    }
-    if (kt + NST - 1 < KT) issue(kt + NST - 1);   // into the buffer stage kt-1 vacated
+  // In-place transform of the A tile of stage kt: a wave transforms exactly the rows it fetched itself (rows w*DI*8 .. +DI*8-1:
+  // lane l, instruction i -> row w*DI*8 + i*8 + (l >> 3), slot l & 7, the slot its own DMA lane wrote), so it only has to wait
+  // for its OWN DMA (vmcnt), not for a workgroup barrier, before it starts.
+  auto transform = [&](int kt) {
     char* sb = ring + (size_t)(kt % NST) * STAGE;
-    // ---- transform the A tile in place: thread t owns slots t, t + NTH, ... of the 128 x 8 slot grid
 #pragma unroll
-    for (int i = 0; i < 1024 / NTH; ++i) {
-      const int e = t + NTH * i, row = e >> 3, ps = e & 7;
-      const int kb = kt * GBK + ((ps ^ (row & 7)) << 3);
+    for (int i = 0; i < DI; ++i) {
+      const int row = w * (DI * 8) + i * 8 + (l >> 3), ps = l & 7;
+      const int kb = kt * GBK + (dkv << 3);
       char* p = sb + row * (GBK * 2) + (ps << 4);
       Raw8<T> ar; ar.u = *reinterpret_cast<const uint4*>(p);
       float a[8], x[8];
@@ -178,10 +164,26 @@ __global__ __launch_bounds__(NTH) void pw_big_kernel(const spb_gemm_args_t g) {
       if (kb >= K) pa = make_uint4(0, 0, 0, 0);    // reduction padding: explicit zeros against clamped (finite) weights
       *reinterpret_cast<uint4*>(p) = pa;
     }
-    __syncthreads();
-    // ---- matrix steps
-    const char* at = sb;
-    const char* bt = sb + NA * GB_TILE;
+  };
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // stages 0 .. NST-2, the tables and the epilogue operands have landed
+  __syncthreads();                                    // coefficient tables visible
+  transform(0);
+  __syncthreads();                                    // stage 0 transformed and visible
+  SPB_TSR(1);
+
+  f32x4_t acc[4][WJ];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < WJ; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+  // Software pipeline, ONE barrier per stage.  Entering iteration kt: stage kt is transformed and visible to everyone, stage
+  // kt+1 is in flight or landed (raw), buffer (kt+2) % 3 == (kt-1) % 3 is free (the barrier closing iteration kt-1).
+  for (int kt = 0; kt < KT; ++kt) {
+    const bool more = kt + NST - 1 < KT;
+    if (more) issue(kt + NST - 1);
+    const char* at = ring + (size_t)(kt % NST) * STAGE;
+    const char* bt = at + NA * GB_TILE;
 #pragma unroll
     for (int ks = 0; ks < GBK / 32; ++ks) {
       const int v = ks * 4 + lq;
@@ -201,6 +203,14 @@ __global__ __launch_bounds__(NTH) void pw_big_kernel(const spb_gemm_args_t g) {
 #pragma unroll
         for (int j = 0; j < WJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfv[j], acc[i][j], 0, 0, 0);
     }
+    if (kt + 1 < KT) {
+      // this wave's own share of stage kt+1 has landed once only the stage issued above is still in flight; its transform
+      // (LDS + vector ALU) runs while the matrix cores work through the steps issued above
+      if (more) wait_vmcnt<IPS>(); else wait_vmcnt<0>();
+      transform(kt + 1);
+    }
+    __builtin_amdgcn_s_barrier();   // stage kt+1 transformed and visible; everyone is done reading stage kt
+    asm volatile("" ::: "memory");
   }
   __syncthreads();   // the ring is idle (the last stages were waited with vmcnt(0)): reuse it
   SPB_TSR(2);
@@ -293,7 +303,7 @@ __global__ __launch_bounds__(NTH) void pw_big_kernel(const spb_gemm_args_t g) {
 
 template <int PRO, int EPI>
 int launch_big(const spb_gemm_args_t& g, hipStream_t stream) {
-  constexpr int NA = PRO == 2 ? 2 : 1, NST = PRO == 2 ? 2 : 3;
+  constexpr int NA = PRO == 2 ? 2 : 1, NST = 3;
   const int NT = (g.N + GB - 1) / GB, MT = (g.M + GB - 1) / GB;
   const int Kp = (g.K + GBK - 1) / GBK * GBK;
   const size_t lds = (size_t)(3 * Kp + 2 * GB) * sizeof(float) + (size_t)NST * (NA + 1) * GB_TILE;
