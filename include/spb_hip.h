@@ -60,7 +60,7 @@ typedef struct spb_gemm_args {
   spb_bnref_t pro;   /* BN/activation applied to A while loading (pro_mode 1) or BN-backward (pro_mode 2) */
   spb_bnref_t epi;   /* epi_mode 2: BN/activation of the output-side tensor */
   int M, K, N;
-  int pro_mode;      /* 0: a = A (plain operand; `pro` must still be a valid identity reference);  1: a = act(bn(A));  2: a = bn_backward(g=A, z=A2) */
+  int pro_mode;      /* 0: a = A (plain operand; `pro` must still be a valid identity reference);  1: a = act(bn(A));  2: a = bn_backward(g=A, z=A2);  3: a = bn(A) + bn2(A2), see pro2 / Ymat below */
   int epi_mode;      /* 0: y = out_act(acc*out_scale + bias);  1: y = acc, accumulate batch sums;  2: g = (acc+res)*act'(bn(Zout)) */
   int out_act;       /* epi_mode 0 */
   int oR;
@@ -69,6 +69,12 @@ typedef struct spb_gemm_args {
                         convolution run on a column slab of the im2col / output matrices (SPN conv2, conv4, conv5) */
   void* stop_event;  /* host side only: optional hipEvent_t completed by THIS launch (attached to its dispatch packet), so
                         another stream can wait for it without an event-record packet in the launch stream */
+  /* pro_mode 3, the residual join of an inverted-residual block folded into the next block's expand convolution
+   * (torchvision InvertedResidual `x + self.conv(x)`): a = bn(A) + bn2(A2), no activation on either side (pro.act and
+   * pro2.act must be SPB_ACT_NONE; pro2.gamma == NULL: A2 is a materialised tensor).  The workgroups of the first column
+   * tile also write a to Ymat [M,K] (row stride lda) -- the block output later consumers read. */
+  spb_bnref_t pro2;
+  void* Ymat;
 } spb_gemm_args_t;
 int spb_pwconv_gemm(int dtype, const spb_gemm_args_t* args, spb_stream_t stream);
 
@@ -548,6 +554,7 @@ int spb_preproc_batch(const spb_preproc_args_t* a, spb_stream_t stream);
 int spb_debug_set_conv9_band(int on); /* decoder's last 9x9 layer: band-staged kernel (1, default) or the generic 8x8-tile kernel */
 int spb_debug_set_launch_events(int on); /* side-stream forks wait on the preceding GEMM launch's completion event (1) or on a recorded event (0) */
 int spb_debug_set_dw_split(int hw);        /* depthwise layers on maps up to `hw` columns wide run their weight gradient on the side stream (default 56: every depthwise layer below the 112x112 maps; 0: always fused) */
+int spb_debug_set_join_fused(int on);      /* KRN plan: residual adds formed by the next expand convolution (1, default) or by bn_apply launches (0) */
 int spb_debug_set_wgrad_parts(int on);     /* KRN plan: weight gradients as partial sums + spb_partial_reduce (1, default) or f32 atomics (0) */
 int spb_debug_set_wgrad_min_flush(int n); /* fork at a depthwise backward kernel only when >= n weight gradients are queued */
 int spb_debug_set_wgrad_target(int wgs); /* pointwise weight gradient: row splits chosen for about this many workgroups per launch (every split adds N*K f32 atomics); wgs < 0: the same for the partial-sum form (default 512; every split adds an N*K slab) */

@@ -28,7 +28,8 @@ class BNRef(C.Structure):
 class GemmArgs(C.Structure):
     _fields_ = [("A", vp), ("A2", vp), ("Bw", vp), ("Y", vp), ("res", vp), ("Zout", vp), ("bias", vp), ("osums", vp),
                 ("pro", BNRef), ("epi", BNRef), ("M", i32), ("K", i32), ("N", i32), ("pro_mode", i32),
-                ("epi_mode", i32), ("out_act", i32), ("oR", i32), ("out_scale", f32), ("lda", i32), ("ldc", i32), ("stop_event", vp)]
+                ("epi_mode", i32), ("out_act", i32), ("oR", i32), ("out_scale", f32), ("lda", i32), ("ldc", i32), ("stop_event", vp),
+                ("pro2", BNRef), ("Ymat", vp)]
 
 
 class RedJob(C.Structure):
@@ -206,6 +207,7 @@ SYMBOLS = {
     "spb_debug_set_launch_events": (i32, [i32]),
     "spb_debug_set_dw_split": (i32, [i32]),
     "spb_debug_set_wgrad_parts": (i32, [i32]),
+    "spb_debug_set_join_fused": (i32, [i32]),
     "spb_debug_set_wgrad_min_flush": (i32, [i32]),
     "spb_debug_set_wgrad_batch": (i32, [i32]),
     "spb_debug_set_wgrad_target": (i32, [i32]),

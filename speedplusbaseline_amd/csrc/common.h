@@ -218,6 +218,33 @@ __device__ __forceinline__ void bn_coef_table(const BNRef& r, int K, int Kp, flo
   }
 }
 
+// Prologue table of the residual join a = bn(A) + bn2(A2) (spb_gemm_args_t pro_mode 3; neither side has an activation):
+// coef[0..Kp) = scale of A, coef[Kp..2Kp) = scale of A2, coef[2Kp..3Kp) = shift + shift2 -- the a*c0 + a2*c1 + c2 form the
+// BatchNorm-backward prologue already runs on.  Same launch shape as bn_coef_table (256 threads, clamped branch-free loads).
+__device__ __forceinline__ void bn_join_table(const BNRef& r, const BNRef& r2, int K, int Kp, float* coef, int t) {
+  constexpr int G = 2;
+  for (int cb = t; cb < Kp; cb += 256 * G) {
+    float c0[G], c1[G], c2[G];
+#pragma unroll
+    for (int j = 0; j < G; ++j) {
+      const int c = cb + 256 * j;
+      const int cc = c < K ? c : K - 1;
+      float sc, sh, sc2, sh2;
+      bn_fwd_coef(r, cc, sc, sh);
+      bn_fwd_coef(r2, cc, sc2, sh2);
+      c0[j] = sc; c1[j] = sc2; c2[j] = sh + sh2;
+    }
+#pragma unroll
+    for (int j = 0; j < G; ++j) {
+      const int c = cb + 256 * j;
+      if (c < Kp) {
+        const bool ok = c < K;
+        coef[c] = ok ? c0[j] : 0.f; coef[Kp + c] = ok ? c1[j] : 0.f; coef[2 * Kp + c] = ok ? c2[j] : 0.f;
+      }
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // wave64 reductions via DPP-lowered shuffles
 // sum over the 16 lanes of a DPP row, result in every lane: VALU-only butterflies (quad_perm [1,0,3,2], quad_perm [2,3,0,1],

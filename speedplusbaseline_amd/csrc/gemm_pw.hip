@@ -3,6 +3,8 @@
 //   forward   Y[M,N]  = act(bn(A))[M,K] * W[N,K]^T        + per-channel sum(y), sum(y^2) for the next BN
 //   dgrad     dA[M,K] = bn_bwd(G,Z)[M,N] * Wt[K,N]^T      + output-side activation mask and sum(g), sum(g*xhat)
 //   wgrad     dW[N,K] = bn_bwd(G,Z)[M,N]^T * act(bn(X))[M,K]
+//   join      Y[M,N]  = (bn(A) + bn2(A2))[M,K] * W[N,K]^T   + the same sums; the first column tile also writes the joined
+//             operand (PRO 3: the residual add of the previous inverted-residual block, folded into this block's expand conv)
 //
 // Replaces nn.Conv2d(k=1) + nn.BatchNorm2d + ReLU6/ReLU/LeakyReLU at reference park2019.py:51-53,64-66,
 // revgrad.py:76 and the torchvision MobileNetV2 expand/project convolutions (park2019.py:107-108).
@@ -49,7 +51,7 @@ constexpr size_t gemm_region_bytes() {
 
 // RF = 16-row fragments per wave (workgroup tile = 64*RF rows x BN columns)
 template <typename T, int RF, int BN, int BK, int PRO, int EPI>
-__global__ __launch_bounds__(256, (RF == 1 && sizeof(T) == 2) ? (((BK == 64 && PRO == 2) || BN == 128) ? 2 : 4) : 1) void pw_gemm_kernel(const spb_gemm_args_t g) {
+__global__ __launch_bounds__(256, (RF == 1 && sizeof(T) == 2) ? (((BK == 64 && PRO >= 2) || BN == 128) ? 2 : 4) : 1) void pw_gemm_kernel(const spb_gemm_args_t g) {
   constexpr int BM = 64 * RF;
   constexpr int GBK = BK;
   constexpr int LDK = LdsPad<T, BK>::LDK;
@@ -108,6 +110,7 @@ __global__ __launch_bounds__(256, (RF == 1 && sizeof(T) == 2) ? (((BK == 64 && P
   T* Yg = reinterpret_cast<T*>(g.Y);
   const T* Rg = reinterpret_cast<const T*>(g.res);
   const T* Zg = reinterpret_cast<const T*>(g.Zout);
+  T* Ymat = reinterpret_cast<T*>(g.Ymat);
 
   const int kvA = t % BKV, rowA = t / BKV;  // A tile: rows rowA + AROWS*i
   const int KT = Kp / GBK;
@@ -124,7 +127,7 @@ __global__ __launch_bounds__(256, (RF == 1 && sizeof(T) == 2) ? (((BK == 64 && P
         const int m = (m0_) + rowA + AROWS * i;                                               \
         const size_t o = (size_t)(m < M ? m : M - 1) * lda + kc;                                \
         ra[S][i] = ldraw<T>(Ag + o);                                                          \
-        if (PRO == 2) { if (A2g) ra2[S][i] = ldraw<T>(A2g + o); }                             \
+        if (PRO >= 2) { if (A2g) ra2[S][i] = ldraw<T>(A2g + o); }                             \
       }                                                                                       \
       _Pragma("unroll") for (int i = 0; i < NBV; ++i) {                                       \
         const int e = t + 256 * i;                                                            \
@@ -141,7 +144,7 @@ __global__ __launch_bounds__(256, (RF == 1 && sizeof(T) == 2) ? (((BK == 64 && P
         float v[8], a1[8], a2[8];                                                             \
         const bool ok = (m < M && k < K);                                                     \
         cvt8(ra[S][i], a1);                                                                   \
-        if (PRO == 2) {                                                                       \
+        if (PRO >= 2) {                                                                       \
           if (A2g) cvt8(ra2[S][i], a2);                                                       \
           else { _Pragma("unroll") for (int j = 0; j < 8; ++j) a2[j] = 0.f; }                 \
         }                                                                                     \
@@ -152,6 +155,7 @@ __global__ __launch_bounds__(256, (RF == 1 && sizeof(T) == 2) ? (((BK == 64 && P
           v[j] = ok ? x : 0.f;                                                                \
         }                                                                                     \
         st8<T>(As + (rowA + AROWS * i) * LDK + kvA * 8, v);                                   \
+        if (PRO == 3) { if (nt == 0 && ok) st8<T>(Ymat + (size_t)m * lda + k, v); }           \
       }                                                                                       \
       _Pragma("unroll") for (int i = 0; i < NBV; ++i) {                                       \
         const int e = t + 256 * i;                                                            \
@@ -196,7 +200,8 @@ __global__ __launch_bounds__(256, (RF == 1 && sizeof(T) == 2) ? (((BK == 64 && P
     if (KT > 1) LOAD_TILE(1, (lid / NT) * BM, 1);
   }
   // ---- prologue coefficients for every reduction channel (derived from the producer's raw batch sums)
-  bn_coef_table<PRO == 1 ? 1 : 2>(g.pro, K, Kp, coef, t);
+  if constexpr (PRO == 3) bn_join_table(g.pro, g.pro2, K, Kp, coef, t);
+  else bn_coef_table<PRO == 1 ? 1 : 2>(g.pro, K, Kp, coef, t);
   if (EPI == 2) {
     for (int c = t; c < BN; c += 256) {
       float sc = 1.f, sh = 0.f;
@@ -647,7 +652,7 @@ int dispatch_bn(const spb_gemm_args_t& g, hipStream_t stream) {
   if (small_m && bn == 128) bn = 64;
   if (small_m) {
     if (bn == 32) return launch_gemm<T, 1, 32, 32, PRO, EPI>(g, stream);
-    if (g.K >= g_dma_min_k && sizeof(T) == 2 && !g_disable_dma) return launch_gemm_dma<PRO, EPI>(g, stream);
+    if constexpr (PRO != 3) { if (g.K >= g_dma_min_k && sizeof(T) == 2 && !g_disable_dma) return launch_gemm_dma<PRO, EPI>(g, stream); }
     // long reductions (the 7x7 ConvDw layers, K up to 1280): 64-wide chunks halve the number of latency-bound steps
     // (forward-type only: the backward variant spills 87 dwords at 128 VGPRs with two 64-wide prefetch sets: 0.68 -> 0.75 ms)
     if (sizeof(T) == 2 && PRO == 1 && g.K >= g_bk64_min_k) return launch_gemm<T, 1, 64, 64, PRO, EPI>(g, stream);
@@ -673,6 +678,8 @@ int dispatch_modes(const spb_gemm_args_t& g, hipStream_t stream) {
   if (g.pro_mode == 1 && g.epi_mode == 0) return dispatch_bn<T, 1, 0>(g, stream);
   if (g.pro_mode == 2 && g.epi_mode == 0) return dispatch_bn<T, 2, 0>(g, stream);
   if (g.pro_mode == 2 && g.epi_mode == 2) return dispatch_bn<T, 2, 2>(g, stream);
+  if (g.pro_mode == 3 && g.epi_mode == 1) return dispatch_bn<T, 3, 1>(g, stream);
+  if (g.pro_mode == 3 && g.epi_mode == 0) return dispatch_bn<T, 3, 0>(g, stream);
   return SPB_E_UNSUPPORTED;
 }
 
@@ -885,6 +892,7 @@ extern "C" int spb_pwconv_gemm(int dtype, const spb_gemm_args_t* a, spb_stream_t
   if (a->M <= 0 || a->K <= 0 || a->N <= 0 || (a->K & 7) || (a->N & 7)) return SPB_E_SHAPE;
   if (a->epi_mode != 0 && (!a->osums || a->oR < 1)) return SPB_E_ARG;
   if (a->epi_mode == 2 && !a->Zout) return SPB_E_ARG;
+  if (a->pro_mode == 3 && (!a->A2 || !a->Ymat || a->pro.act != SPB_ACT_NONE || a->pro2.act != SPB_ACT_NONE)) return SPB_E_ARG;
   if (dtype == SPB_BF16) {
     // the 7x7 maps, wide output behind a long reduction (ConvDw extras, domain classifier): 128 x 128 tiles (gemm_big.hip)
     const int eb = spb_gemm_big(a, (hipStream_t)stream);

@@ -228,7 +228,9 @@ void build_model(spb_krn* m, int nK, bool dann) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-struct Src { const void* ptr; spb_bnref_t ref; };
+// An operand as a consumer sees it: tensor + its BatchNorm / activation.  join: the residual sum of an inverted-residual block that
+// has not been materialised yet -- bn(ptr) + bn2(ptr2) -- which the next expand convolution forms while loading and writes to `mat`
+struct Src { const void* ptr; spb_bnref_t ref; const void* ptr2 = nullptr; spb_bnref_t ref2 = spb_bnref_t(); void* mat = nullptr; };
 
 static int g_side_wgrad = 1;
 // Pointwise weight gradients are queued and handed to the side stream right before the next depthwise backward kernel (one
@@ -275,6 +277,8 @@ static int g_wgrad_parts = 0;     // 1: pointwise weight gradients as partial su
                                   // (order-deterministic; measured 3.25 vs 3.18 ms per step: the slab traffic and the extra launches cost more
                                   // than the atomics they replace) -- spb_debug_set_wgrad_parts
 extern "C" int spb_debug_set_wgrad_parts(int on) { g_wgrad_parts = on; return 0; }
+static int g_join_fused = 1;      // residual adds folded into the next expand convolution (spb_debug_set_join_fused)
+extern "C" int spb_debug_set_join_fused(int on) { g_join_fused = on; return 0; }
 static int g_fused_pw_bwd = 1;
 static long long g_fused_pw_bwd_min_m = 32768;   // spb_debug_set_fused_pw_bwd(v > 1): fused kernel from v rows up
 struct Runner {
@@ -338,8 +342,9 @@ struct Runner {
     spb_gemm_args_t g; std::memset(&g, 0, sizeof(g));
     g.A = in.ptr; g.Bw = wc(L.wc_off); g.Y = z(aout); g.pro = in.ref; g.M = M(aout); g.K = L.K; g.N = L.N;
     g.pro_mode = 1; g.out_scale = 1.f;
+    if (in.mat) { g.pro_mode = 3; g.A2 = in.ptr2; g.pro2 = in.ref2; g.Ymat = in.mat; }   // residual join of the previous block
     if (tr) { g.epi_mode = 1; g.osums = sums(aout); g.oR = c->R[aout]; } else { g.epi_mode = 0; g.oR = 1; }
-    tic(PC_PW_FWD, ((double)g.M * (L.K + L.N) + (double)L.K * L.N) * es(), 2.0 * g.M * L.K * L.N);
+    tic(PC_PW_FWD, ((double)g.M * ((in.mat ? 3 : 1) * L.K + L.N) + (double)L.K * L.N) * es(), 2.0 * g.M * L.K * L.N);
     ok(spb_pwconv_gemm(dt, &g, st));
     toc();
   }
@@ -897,12 +902,21 @@ extern "C" int spb_krn_forward(spb_krn_ctx_t* c, const float* x, const float* ta
     const Block& b = m->blk[k];
     if (b.t != 1) {
       r.pw_fwd(b.E, cur, b.aE, tr);
+      if (cur.mat) cur = r.block_out(k - 1, tr);   // the join is materialised now: later readers take the block's output tensor
       r.dw_fwd(b.D, r.src_act(b.aE, tr), b.Hin, b.aD, tr);
     } else {
       r.dw_fwd(b.D, cur, b.Hin, b.aD, tr);
     }
     if (prep_wait) { hipStreamWaitEvent(st, c->prep_ev, 0); prep_wait = false; }
     r.pw_fwd(b.P, r.src_act(b.aD, tr), b.aP, tr);
+    if (b.res && g_join_fused && k < 17) {
+      // y_k = bn(z_P) + y_{k-1}: formed by the next block's expand convolution while it loads its operand (pro_mode 3) and
+      // written to the block's output tensor by that launch -- no bn_apply launch (10 of them per forward pass)
+      Src j = r.src_act(b.aP, tr);
+      j.ptr2 = cur.ptr; j.ref2 = cur.ref; j.mat = r.y(b.matY);
+      cur = j;
+      continue;
+    }
     if (b.res) {
       spb_bnapply_args_t a; std::memset(&a, 0, sizeof(a));
       a.Z = r.z(b.aP); a.res = cur.ptr; a.Y = r.y(b.matY); a.bn = r.ref(b.aP, tr); a.bn_res = cur.ref;
