@@ -571,6 +571,8 @@ int spb_debug_set_dw_mode(int mode); /* depthwise fwd/dgrad: 1 plane kernels on 
 int spb_debug_set_fused_pw_bwd(int on); /* 0: the KRN plan never uses spb_pwconv_bwd_fused */
 int spb_debug_set_stem_mfma(int on); /* 0: bf16 stem uses the scalar kernels instead of the MFMA implicit GEMM */
 int spb_debug_set_gemm_big(int on, int min_n, int min_k); /* small-M bf16 GEMMs with N >= min_n (512), K >= min_k (256): 128 x 128 tile kernel (on=1, default) */
+int spb_debug_set_bn_bwd_prep_rows(int on); /* spb_bn_bwd_prep: row-parallel kernel (1, default) or the walking kernel (0) */
+int spb_debug_set_gemm_wg_cap(int n); /* tiled pointwise GEMM: most workgroups per launch (default 1024 = what is resident at once); beyond it workgroups loop over M tiles */
 int spb_debug_set_gemm_wide_min_n(int n); /* small-M forward-type bf16 GEMMs with N >= n and a long reduction: 64 x 128 tiles */
 int spb_debug_set_gemm_bk64_min_k(int k); /* small-M bf16 GEMMs with K >= k use 64-wide reduction chunks (default 256) */
 int spb_debug_set_gconv_slab(int mode); /* wide decoder convs: 0 per-wave weight streaming; 1 slab kernel with 4 tiles (1 workgroup per CU); 2 (default) 2 tiles, 2 per CU */

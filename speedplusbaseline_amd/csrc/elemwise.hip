@@ -113,6 +113,85 @@ __global__ __launch_bounds__(256) void bn_bwd_prep_kernel(const spb_bnbwd_args_t
   for (int i = threadIdx.x; i < 2 * C; i += 256) atomicAdd(a.osums + (size_t)rep * 2 * C + i, red[i]);
 }
 
+// Row-parallel form (round 3): grid (ceil(C/64), row ranges of BBP_ROWS).  A workgroup owns 64 channels (8 lanes x 8-channel
+// 16-byte vectors) x 32 row lanes with BBP_U rows of each lane in flight; every global load of a thread -- operands and the
+// BatchNorm sums / affine of its 8 channels -- is issued before anything is waited for: one memory round trip on a few hundred
+// workgroups.  The per-channel sums meet in LDS by plain stores (32 row lanes), then one f32 atomic per channel, sum and workgroup.
+// (The kernel above walks the tensor with 147 / 37 workgroups, reduces through 16 LDS float atomics per thread and ends with 2*C
+// global atomics per workgroup: 300 k of them on the 1024-channel concat branch, 22 + 19 us for two launches that move 18 MB.)
+constexpr int BBP_U = 4, BBP_ROWS = 32 * BBP_U;
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_prep_rows_kernel(const spb_bnbwd_args_t a) {
+  __shared__ float red[2][32][65];
+  const int t = threadIdx.x, v = t & 7, sub = t >> 3;
+  const int C = a.C, cb = blockIdx.x * 64, c0 = cb + v * 8;
+  const bool cok = c0 < C;
+  const int cc = cok ? c0 : 0;
+  const long long rows = (long long)a.B * a.H * a.W;
+  const long long r0 = (long long)blockIdx.y * BBP_ROWS, r1 = r0 + BBP_ROWS < rows ? r0 + BBP_ROWS : rows;
+  const T* dY = reinterpret_cast<const T*>(a.dY);
+  const T* Z = reinterpret_cast<const T*>(a.Z);
+  T* G = reinterpret_cast<T*>(a.G);
+  const int s = a.reorg;
+  Raw8<T> dr[BBP_U], zr[BBP_U];
+#pragma unroll
+  for (int u = 0; u < BBP_U; ++u) {
+    const long long ru = r0 + sub + 32 * u;
+    const long long p = ru < r1 ? ru : r1 - 1;
+    size_t o;
+    if (s > 0) {
+      const int w = (int)(p % a.W), h = (int)((p / a.W) % a.H), b = (int)(p / ((long long)a.W * a.H));
+      const int OH = a.H / s, OW = a.W / s;
+      o = ((size_t)(b * OH + h / s) * OW + w / s) * a.ldc + a.coff + ((h % s) * s + (w % s)) * C + cc;
+    } else {
+      o = (size_t)p * a.ldc + a.coff + cc;
+    }
+    dr[u] = ldraw<T>(dY + o);
+    zr[u] = ldraw<T>(Z + (size_t)p * C + cc);
+  }
+  float sc[8], sh[8], mu[8], is[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    sc[j] = 1.f; sh[j] = 0.f; mu[j] = 0.f; is[j] = 0.f;
+    if (a.bn.gamma) {
+      bn_moments(a.bn, cc + j, mu[j], is[j]);
+      sc[j] = a.bn.gamma[cc + j] * is[j];
+      sh[j] = a.bn.beta[cc + j] - mu[j] * sc[j];
+    }
+  }
+  float s1[8], s2[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
+#pragma unroll
+  for (int u = 0; u < BBP_U; ++u) {
+    const long long ru = r0 + sub + 32 * u;
+    if (ru < r1 && cok) {
+      float d[8], z[8];
+      cvt8(dr[u], d); cvt8(zr[u], z);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float uu = z[j] * sc[j] + sh[j];
+        d[j] = rnd<T>(d[j] * act_grad(uu, a.bn.act, a.bn.slope));
+        s1[j] += d[j];
+        s2[j] += d[j] * ((z[j] - mu[j]) * is[j]);
+      }
+      st8<T>(G + (size_t)ru * C + c0, d);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { red[0][sub][v * 8 + j] = s1[j]; red[1][sub][v * 8 + j] = s2[j]; }
+  __syncthreads();
+  if (t < 128) {
+    const int which = t >> 6, c = t & 63;
+    if (cb + c < C) {
+      float acc = 0.f;
+#pragma unroll
+      for (int i = 0; i < 32; ++i) acc += red[which][i][c];
+      atomicAdd(a.osums + (size_t)(blockIdx.y % a.oR) * 2 * C + (size_t)which * C + cb + c, acc);
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ BN tables
 __global__ __launch_bounds__(256) void bn_running_update_kernel(const spb_bnupd_entry_t* tab, const float* stats,
                                                                 float* buffers, long long* nbt, float momentum) {
@@ -377,10 +456,21 @@ extern "C" int spb_bn_apply(int dtype, const spb_bnapply_args_t* a, spb_stream_t
   return 0;
 }
 
+static int g_bbp_rows = 1;   // spb_debug_set_bn_bwd_prep_rows(0): the walking kernel (kept as the test reference)
+extern "C" int spb_debug_set_bn_bwd_prep_rows(int on) { g_bbp_rows = on; return 0; }
 extern "C" int spb_bn_bwd_prep(int dtype, const spb_bnbwd_args_t* a, spb_stream_t stream) {
   if (!a || !a->dY || !a->Z || !a->G || !a->osums || a->oR < 1) return SPB_E_ARG;
   if (a->C <= 0 || (a->C & 7) || (a->ldc & 7) || (a->coff & 7)) return SPB_E_SHAPE;
   if (a->reorg > 0 && ((a->H % a->reorg) || (a->W % a->reorg))) return SPB_E_SHAPE;
+  if (g_bbp_rows) {   // row-parallel kernel (default)
+    const long long rows = (long long)a->B * a->H * a->W;
+    const dim3 grid((unsigned)((a->C + 63) / 64), (unsigned)((rows + BBP_ROWS - 1) / BBP_ROWS));
+    if (dtype == SPB_BF16) hipLaunchKernelGGL(bn_bwd_prep_rows_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, *a);
+    else if (dtype == SPB_F32) hipLaunchKernelGGL(bn_bwd_prep_rows_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, *a);
+    else return SPB_E_ARG;
+    SPB_CHECK_LAUNCH();
+    return 0;
+  }
   const int CG = a->C >> 3;
   const long long items = (long long)a->B * a->H * a->W * CG;
   const int unit = CG / gcd_i(CG, 256);

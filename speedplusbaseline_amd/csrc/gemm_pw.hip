@@ -345,15 +345,21 @@ __global__ __launch_bounds__(256, (RF == 1 && sizeof(T) == 2) ? (((BK == 64 && P
   SPB_TS(4);
 }
 
+// Most workgroups of a tiled launch; beyond it the workgroups loop over M tiles.  The 64-row instances need 105-128 VGPRs, so
+// 4 workgroups (1024 on the chip) are resident at once (scratch/occ_probe.hip); the 1323- and 1764-workgroup launches of the
+// 14x14 / 28x28 layers ran a second, nearly empty round (phase timestamps: last workgroup started 7-11 us into a 12-19 us
+// launch).  Measured in the step: 2048 -> 3.144 ms, 1280 -> 3.111, 1024 -> 3.109, 900 -> 3.116.  spb_debug_set_gemm_wg_cap
+int g_gemm_wg_cap = 1024;
+
 template <typename T, int RF, int BN, int BK, int PRO, int EPI>
 int launch_gemm(const spb_gemm_args_t& g, hipStream_t stream) {
   constexpr int BM = 64 * RF;
   constexpr int GBK = BK;
   const int NT = (g.N + BN - 1) / BN;
   const int MT = (g.M + BM - 1) / BM;
-  // persistent over M tiles: at most ~2048 workgroups, and an even split of the tiles (19 tiles on 16 workgroup rows
+  // persistent over M tiles: at most g_gemm_wg_cap workgroups, and an even split of the tiles (19 tiles on 16 workgroup rows
   // made the slowest row take two tiles: 2x the layer time)
-  const int cap = 2048 / NT > 8 ? 2048 / NT : 8;
+  const int cap = g_gemm_wg_cap / NT > 8 ? g_gemm_wg_cap / NT : 8;
   int GM = MT;
   if (GM > cap) {
     const int rounds = (MT + cap - 1) / cap;
@@ -933,6 +939,7 @@ extern "C" int spb_debug_set_gemm_dma(int on) { g_disable_dma = (on == 0); g_dma
 extern "C" int spb_debug_set_gemm_plain_dma(int on) { g_plain_dma = (on != 0); return 0; }
 extern "C" int spb_debug_set_gemm_bk64_min_k(int k) { g_bk64_min_k = k; return 0; }
 extern "C" int spb_debug_set_gemm_wide_min_n(int n) { g_wide_min_n = n; return 0; }
+extern "C" int spb_debug_set_gemm_wg_cap(int n) { g_gemm_wg_cap = n < 64 ? 64 : n; return 0; }
 extern "C" int spb_debug_set_gemm_bk64_dgrad_min_k(int k) { g_bk64_dgrad_min_k = k; return 0; }
 
 extern "C" const char* spb_version(void) { return "speedplusbaseline_amd gfx950 r1"; }

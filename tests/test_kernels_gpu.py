@@ -484,6 +484,47 @@ def test_bn_apply_and_bwd_prep(device, dt):
     assert relerr(sm[0], gs.sum(0)) < 1e-3 and relerr(sm[1], (gs * xh).sum(0)) < 1e-3
 
 
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("B,H,C,coff,reorg", [(3, 7, 96, 32, 0), (48, 7, 1024, 256, 0), (5, 14, 64, 0, 2)])
+def test_bn_bwd_prep_row_parallel_kernel(device, dt, B, H, C, coff, reorg):
+    """spb_bn_bwd_prep's row-parallel kernel (the default) at the two KRN call sites (the 1024-channel slice of the concat gradient,
+    the un-reorg of the router slice) and a ragged channel count: against float64 and against the walking kernel it replaced"""
+    torch.manual_seed(B * 100 + C)
+    dev = device
+    z = rt(torch.randn(B, H, H, C, dtype=torch.float64), dt)
+    g1 = torch.rand(C, dtype=torch.float64) + 0.5; b1 = torch.randn(C, dtype=torch.float64) * 0.2
+    u, xh = bn_train(z.view(-1, C), g1, b1)
+    bn = ops.bnref(C, sums=sums_of(z.view(-1, C), 1, dev), gamma=g1.float().to(dev), beta=b1.float().to(dev), n=B * H * H, R=1, act=L.ACT_RELU)
+    s = max(reorg, 1)
+    ldc = coff + s * s * C + 16
+    dcat = rt(torch.randn(B, H // s, H // s, ldc, dtype=torch.float64), dt)
+    outs = []
+    for rows in (1, 0):
+        L.lib().spb_debug_set_bn_bwd_prep_rows(rows)
+        G = torch.empty(B, H, H, C, dtype=dt, device=dev)
+        osums = torch.zeros(2, 2, C, dtype=torch.float32, device=dev)
+        ops.bn_bwd_prep(dcat.to(dt).to(dev), z.to(dt).to(dev), G, osums, bn, ldc=ldc, coff=coff, reorg=reorg, oR=2)
+        torch.cuda.synchronize()
+        outs.append((G, osums.sum(0)))
+    L.lib().spb_debug_set_bn_bwd_prep_rows(1)
+    if reorg:
+        d_nchw = dcat[..., coff: coff + s * s * C].permute(0, 3, 1, 2)
+        dx = torch.zeros(B, C, H, H, dtype=torch.float64)
+        for i in range(s):
+            for j in range(s):
+                dx[:, :, i::s, j::s] = d_nchw[:, (i * s + j) * C:(i * s + j + 1) * C]
+        dx = dx.permute(0, 2, 3, 1)
+    else:
+        dx = dcat[..., coff: coff + C]
+    expg = dx * (u > 0).double().view(B, H, H, C)
+    G, sm = outs[0]
+    assert relerr(G, expg) < TOL[dt]
+    assert torch.equal(G, outs[1][0])                                     # same element arithmetic as the walking kernel
+    gs = G.double().cpu().view(-1, C); sm = sm.double().cpu()
+    assert relerr(sm[0], gs.sum(0)) < 1e-3 and relerr(sm[1], (gs * xh).sum(0)) < 1e-3
+    assert relerr(sm, outs[1][1].double().cpu()) < 1e-4
+
+
 @pytest.mark.parametrize("kind", ["adamw", "adam", "rmsprop", "sgd"])
 def test_optim_step_matches_torch(device, kind):
     """fused clip + update vs clip_grad_norm_ + torch.optim (reference build.py:60-78, trainer.py:97-98)"""
