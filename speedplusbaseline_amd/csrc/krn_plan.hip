@@ -249,7 +249,7 @@ static int g_wgrad_batch = 8;
 // gradient triples the instruction count (72 partials per lane, each reduced across lanes) on a path that is bound by VALU issue.
 // Measured in the step (round 3): 0 -> 3.32 ms, 14 -> 3.22, 28 -> 3.23, 56 -> 3.22 (3.20 vs 3.19 after the later changes).
 // (Round 2, row-unit kernels on every map: the split was slower, 3.33 vs 3.29 ms.)
-static int g_dw_split_hw = 56;
+static int g_dw_split_hw = 112;   // end of round 3 (with the resident-grid cap on the GEMMs): 56 -> 3.096 ms, 112 -> 3.084
 extern "C" int spb_debug_set_dw_split(int hw) { g_dw_split_hw = hw; return 0; }
 extern "C" int spb_debug_set_wgrad_batch(int n) {
   g_wgrad_flush_at_dw = n < 0;
@@ -280,7 +280,8 @@ extern "C" int spb_debug_set_wgrad_parts(int on) { g_wgrad_parts = on; return 0;
 static int g_join_fused = 1;      // residual adds folded into the next expand convolution (spb_debug_set_join_fused)
 extern "C" int spb_debug_set_join_fused(int on) { g_join_fused = on; return 0; }
 static int g_fused_pw_bwd = 1;
-static long long g_fused_pw_bwd_min_m = 32768;   // spb_debug_set_fused_pw_bwd(v > 1): fused kernel from v rows up
+static long long g_fused_pw_bwd_min_m = 100000;  // spb_debug_set_fused_pw_bwd(v > 1): fused kernel from v rows up.  The 28x28 layer
+                                                 // (M = 37632, 144 -> 32) took 45 us fused for 26 MB; as GEMM + side-stream weight gradient the step is 12 us shorter
 struct Runner {
   spb_krn_ctx* c; spb_krn* m; hipStream_t st; int dt; int err = 0;
   Runner(spb_krn_ctx* c_, hipStream_t s) : c(c_), m(c_->m), st(s), dt(c_->m->dtype) {}
