@@ -44,7 +44,7 @@ def _host():
     return dict(cpu_model=model, host_cores=os.cpu_count())
 
 
-def _pmc_traffic(family, files=("r2_pmc_traffic.json", "r1_pmc_traffic.json")):
+def _pmc_traffic(family, files=("r3_pmc_traffic.json", "r2_pmc_traffic.json", "r1_pmc_traffic.json")):
     """HBM bytes per launch of a kernel family from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE, separate runs,
     corrected as MI355X_MICROARCH.md prescribes; scratch/pmc_summary.py) -- rocprofv3 cannot run inside bench.py"""
     for name in files:
@@ -276,8 +276,16 @@ def main():
         dec_ms = e0.elapsed_time(e1) / n_dec
         dec_tf = 15.43e9 * B / (dec_ms * 1e-3) / 1e12
         krn_roofline = roofline
+        dec_traffic, dec_src = (None, None)
+        if B == 48:
+            try:   # HBM bytes of one restyle (all decoder launches), from the committed FETCH_SIZE / WRITE_SIZE passes of scratch/bench_ghiasi.py
+                with open(os.path.join(ROOT, "profiles", "r3_ghiasi_pmc_traffic.json")) as f:
+                    dec_traffic, dec_src = json.load(f)["restyle_hbm_bytes"], "r3_ghiasi_pmc_traffic.json"
+            except Exception:
+                pass
         roofline = dict(bound="mfma", kernel="Ghiasi decoder (all launches of one restyle, %d images)" % B, achieved=round(dec_tf, 1),
-                        peak=MFMA_PEAK_TFLOPS["bf16"], unit="TFLOP/s", frac=round(dec_tf / MFMA_PEAK_TFLOPS["bf16"], 4), traffic=None,
+                        peak=MFMA_PEAK_TFLOPS["bf16"], unit="TFLOP/s", frac=round(dec_tf / MFMA_PEAK_TFLOPS["bf16"], 4),
+                        traffic=dec_traffic, traffic_source=dec_src,
                         decoder_ms_per_batch=round(dec_ms, 3), alg_flops_per_batch=15.43e9 * B,
                         train_step_dominant_kernel=krn_roofline)
 
@@ -466,9 +474,9 @@ def bench_dann(args):
         eng.prof_enable(B, 0, False); eng.prof_enable(B, 1, False)
         dk, dv = max(agg.items(), key=lambda kv: kv[1]["ms"])
         ach = dv["bytes"] / (dv["ms"] * 1e-3) / 1e9
-        traffic, traffic_src = _pmc_traffic(dk)
+        traffic, traffic_src = _pmc_traffic(dk, ("r3_dann_pmc_traffic.json",)) if B == 48 else (None, None)   # passes taken at bs=48+48
         roofline = dict(bound="hbm", kernel=dk, achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4),
-                        traffic=None, traffic_note="PMC passes were taken at bs=48 (%s); this line runs bs=%d" % (traffic_src, B),
+                        traffic=traffic, traffic_source=traffic_src,
                         launches_per_step=dv["launches"] // n_prof, avg_launch_us=round(dv["ms"] / dv["launches"] * 1e3, 2),
                         alg_bytes_per_launch=round(dv["bytes"] / dv["launches"]),
                         step_sum_of_kernels_ms=round(sum(v["ms"] for v in agg.values()) / n_prof, 3))

@@ -9,16 +9,22 @@ def family(name):
     if m:
         pro, epi = int(m.group(1)), int(m.group(2))
         return "pw_gemm_dgrad" if pro == 2 else ("pw_gemm_fwd" if epi == 1 else "pw_gemm_plain")
-    m = re.search(r"pw_sk_kernel<(\d+), *(\d+)", name)               # split-K kernel: PRO, EPI lead the template list
+    m = re.search(r"pw_(?:sk|os|big)_kernel<(\d+), *(\d+)", name)    # split-K / one-shot / 128x128 kernels: PRO, EPI lead the template list
     if m:
         return "pw_gemm_dgrad" if int(m.group(1)) == 2 else "pw_gemm_fwd"
+    m = re.search(r"dw[rp]_bwd_kernel<[^,]*, *\d+, *(true|false), *(true|false)(?:, *(true|false))?", name)
+    if m:                                                             # row-unit: <T, ST, WG, EPI, DG>; plane: <T, ST, WG, EPI>
+        return "dw_wgrad" if (m.group(3) == "false") else "dw_dgrad"
+    if "dwp_fwd_kernel" in name:
+        return "dw_fwd"
     for pat, fam in (("pwb_kernel", "pw_bwd_fused"), ("dwr_fwd_kernel", "dw_fwd"), ("dwr_bwd_kernel", "dw_dgrad"),
                      ("stem_fwd_mfma", "stem_fwd"), ("stem_wgrad_mfma", "stem_wgrad"), ("pw_gemm_dma_kernel", "pw_gemm_dma")):
         if pat in name:
             return fam
     for k in ("pw_wgrad", "dw_fwd", "dw_dgrad", "dw_wgrad", "stem_fwd", "stem_wgrad", "head_fwd", "head_reduce", "head_bwd",
               "bn_apply", "bn_bwd_prep", "bn_running_update", "bn_param_grads", "bn_load_running", "weight_prep", "grad_sqnorm",
-              "optim_step", "domain_tail", "bce_logits"):
+              "optim_step", "domain_tail", "bce_logits", "partial_reduce", "gconv_slab", "gconv_up2", "gconv_kernel", "conv9", "in_coef",
+              "in_apply", "style_fc", "final_sigmoid"):
         if k in name:
             return k
     return "other:" + name[:40]

@@ -41,4 +41,16 @@ python $ROOT/scratch/pmc_spn_summary.py $OUT/spn_fetch.csv $OUT/spn_write.csv $O
 # ~1 ms on the critical path) was visible only in the per-family table of the bench line; this puts it under profiles/ too
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_dann -o dann -- python $ROOT/bench.py --model dann --steps 20 --warmup 5 --no-cpu-baseline > $OUT/dann_bench_under_rocprof.json 2> $OUT/dann.err
 cp $(find /tmp/p_dann -name "*kernel_stats.csv" | head -1) $OUT/dann_kernel_stats.csv
+# DANN HBM traffic (bs=48+48): two PMC passes of their own
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/p_df -o f -- python $ROOT/bench.py --model dann --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2> $OUT/dann_fetch.err
+cp $(find /tmp/p_df -name "*counter_collection.csv" | head -1) $OUT/dann_fetch.csv
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/p_dw -o w -- python $ROOT/bench.py --model dann --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2> $OUT/dann_write.err
+cp $(find /tmp/p_dw -name "*counter_collection.csv" | head -1) $OUT/dann_write.csv
+python $ROOT/scratch/pmc_summary.py $OUT/dann_kernel_stats.csv $OUT/dann_fetch.csv $OUT/dann_write.csv $OUT/dann_pmc_traffic.json 4 > $OUT/dann_pmc_summary.txt 2>&1
+# decoder HBM traffic
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/p_gf -o f -- python $ROOT/scratch/bench_ghiasi.py > /dev/null 2> $OUT/ghiasi_fetch.err
+cp $(find /tmp/p_gf -name "*counter_collection.csv" | head -1) $OUT/ghiasi_fetch.csv
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/p_gw -o w -- python $ROOT/scratch/bench_ghiasi.py > /dev/null 2> $OUT/ghiasi_write.err
+cp $(find /tmp/p_gw -name "*counter_collection.csv" | head -1) $OUT/ghiasi_write.csv
+python $ROOT/scratch/pmc_ghiasi_summary.py $OUT/ghiasi_fetch.csv $OUT/ghiasi_write.csv $OUT/ghiasi_pmc_traffic.json > $OUT/ghiasi_pmc_summary.txt 2>&1
 ls -la $OUT
