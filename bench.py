@@ -543,7 +543,8 @@ def bench_spn(args):
 
     def one():
         out = net.loss_and_grads(x, yc, yw, world_size=world, group=group, compress_bf16={"1": True, "0": False}.get(os.environ.get("SPB_SPN_BF16_GRADS")),   # default: the library's (on in bf16)
-                                 optimizer=None if os.environ.get("SPB_SPN_EARLY_UPDATE") == "0" else opt)
+                                 optimizer=None if os.environ.get("SPB_SPN_EARLY_UPDATE") == "0" else opt,
+                                 sharded=world > 1 and os.environ.get("SPB_SPN_SHARDED", "1") != "0")   # data parallel: rank-sharded fc update
         opt.step(world_size=world, group=group)
         return out
 
@@ -611,7 +612,9 @@ def bench_spn(args):
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
             "config": {"workload": "SPN (AlexNet trunk + two 5000-class attitude heads) train step, 227x227, bs=%d/GPU, AdamW + "
                                    "clip_grad_value 1.0, dropout 0.5" % B, "per_gpu_batch": B, "global_batch": B * world,
-                       "parallelism": "dp%d" % world, "weights": "random init", "loss_last_step": [float(v) for v in out.cpu()]},
+                       "parallelism": "dp%d" % world + (" (fc gradients reduce-scattered, optimizer state of the fully connected layers "
+                                                          "sharded by rank, bf16 shadows all-gathered)" if world > 1 and os.environ.get("SPB_SPN_SHARDED", "1") != "0" else ""),
+                       "weights": "random init", "loss_last_step": [float(v) for v in out.cpu()]},
             "roofline": roofline, "cpu_baseline": cpu}))
     if world > 1:
         torch.distributed.destroy_process_group()

@@ -183,16 +183,19 @@ class SpnOptimizer(torch.optim.Optimizer):
                        first_step=(t == 1), shadow=None if mdl._shadow is None else mdl._shadow[lo:hi], max_blocks=max_blocks)
 
     @torch.no_grad()
-    def update_range_early(self, lo, hi, world_size=1, max_blocks=0):
+    def update_range_early(self, lo, hi, world_size=1, max_blocks=0, covers=None):
         """Called by SpacecraftPoseNet.loss_and_grads(..., optimizer=self) from inside the backward pass, on the stream that
         produced (and, data parallel, exchanged) the gradients of arena elements [lo, hi): this step's update of that range,
-        issued while the rest of backward still runs.  step() then updates what is left.  Ranges must not overlap."""
+        issued while the rest of backward still runs.  step() then updates what is left.  Ranges must not overlap.
+        covers=(a, b): the sharded exchange -- this rank updates [lo, hi) of the bucket [a, b) and the other ranks the rest, so
+        step() must leave the whole bucket alone."""
         self._model._ensure_arena()
         self._state(self._model._flat)
         if not self._early:
             self._t += 1
-        self._early.append((lo, hi))
-        self._update(lo, hi, world_size, max_blocks)
+        self._early.append(tuple(covers) if covers is not None else (lo, hi))
+        if hi > lo:
+            self._update(lo, hi, world_size, max_blocks)
 
     @torch.no_grad()
     def fused_fc_update(self, name, gT, xT, M):

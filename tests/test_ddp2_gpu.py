@@ -42,7 +42,7 @@ def test_krn_two_ranks_replicas_identical_and_gradient_is_the_sum(device):
 def test_spn_two_ranks_replicas_identical_and_gradient_is_the_sum(device):
     r = run_two_ranks("spn")
     print(r)
-    for mode in ("plain", "overlap", "overlap_f32", "overlap_early"):
+    for mode in ("plain", "overlap", "overlap_f32", "overlap_early", "sharded_f32", "sharded"):
         assert r[mode]["replica_diff"] == 0.0, (mode, r[mode])
         assert r[mode]["moved"] > 0
         assert r[mode]["grad_rel_conv"] < 0.05, (mode, r[mode])
@@ -53,3 +53,10 @@ def test_spn_two_ranks_replicas_identical_and_gradient_is_the_sum(device):
     # (lr 0.05 x gradient noise: 1.5e-5 .. 3e-4 observed; a wrong or missing update would show as 0.05 = lr x clip)
     assert r["overlap_early"]["diff_fc"] < 2e-3 and r["overlap_early"]["diff_conv"] < 0.02, r["overlap_early"]
     assert r["overlap"]["grad_rel_fc"] < 2e-2          # bfloat16 on the wire (2^-9 per element), default in bf16 mode
+    # rank-sharded optimizer state (reduce-scatter of the fc buckets, each rank updates its half, all-gather of the bf16 shadows):
+    # float32 on the wire gives the unsharded path's parameters (same sums, same elementwise update: only the run-to-run gradient
+    # noise is left), bfloat16 on the wire moves an update by lr x 2^-9 x |g|; the gathered shadows are identical on both ranks and
+    # so are the f32 masters after sync_sharded_params (replica_diff above)
+    assert r["sharded_f32"]["diff_fc"] < 2e-3 and r["sharded_f32"]["diff_conv"] < 0.02, r["sharded_f32"]
+    assert r["sharded"]["diff_fc"] < 5e-3 and r["sharded"]["diff_conv"] < 0.02, r["sharded"]
+    assert r["sharded_f32"]["shadow_diff"] == 0.0 and r["sharded"]["shadow_diff"] == 0.0

@@ -88,7 +88,7 @@ def spn(rank, world, dev):
     net.loss_and_grads(x, yc, yw, masks=masks)
     torch.cuda.synchronize()
     want = sum(gather(net.flat_grads().clone()))
-    for mode in ("plain", "overlap", "overlap_f32", "overlap_early"):
+    for mode in ("plain", "overlap", "overlap_f32", "overlap_early", "sharded_f32", "sharded"):
         net = fresh()
         opt = SpnOptimizer(list(net.parameters()), kind="sgd", lr=0.05, momentum=0.9, weight_decay=1e-4, model=net)
         p0 = net.flat_parameters().clone()
@@ -99,6 +99,9 @@ def spn(rank, world, dev):
             elif mode == "overlap_early":      # the heads' buckets are updated on the communication stream as they arrive
                 net.loss_and_grads(x, yc, yw, masks=masks, world_size=world, group=dist.group.WORLD, compress_bf16=False,
                                    optimizer=opt)
+            elif mode in ("sharded_f32", "sharded"):   # reduce-scatter, rank-sharded update, all-gather of the shadows
+                net.loss_and_grads(x, yc, yw, masks=masks, world_size=world, group=dist.group.WORLD,
+                                   compress_bf16=(mode == "sharded"), optimizer=opt, sharded=True)
             else:
                 net.loss_and_grads(x, yc, yw, masks=masks, world_size=world, group=dist.group.WORLD,
                                    compress_bf16=None if mode == "overlap" else False)
@@ -106,6 +109,8 @@ def spn(rank, world, dev):
                 net.finish_gradient_exchange(dist.group.WORLD)
                 torch.cuda.synchronize()
                 got = net.flat_grads().clone()
+                if mode.startswith("sharded"):     # a rank holds the reduced fc gradient of its own slices only: compare those
+                    got[net._conv_end:] = want[net._conv_end:]
             opt.step(world_size=world, group=dist.group.WORLD)
             if it == 0:
                 torch.cuda.synchronize()
@@ -119,9 +124,12 @@ def spn(rank, world, dev):
                          grad_rel_conv=float((got[:ce] - want[:ce]).norm() / want[:ce].norm()),
                          grad_rel_fc=float((got[ce:] - want[ce:]).norm() / want[ce:].norm()),
                          moved=float((both[0] - p0).abs().max()))
-        if mode == "overlap_early":            # same float32 exchange, same update, compared after the first step (later
+        if mode in ("overlap_early", "sharded_f32", "sharded"):   # same exchange arithmetic, same update, compared after the first step (later
             d = (after1 - f32_params).abs()    # steps amplify the atomics noise of the convolution gradients, see test_spn_gpu)
             res[mode]["diff_conv"], res[mode]["diff_fc"] = float(d[:ce].max()), float(d[ce:].max())
+        if mode.startswith("sharded"):         # the bf16 shadows the next forward reads: identical on both ranks after the all-gather
+            sh = gather(net._shadow.float().clone())
+            res[mode]["shadow_diff"] = float((sh[0] - sh[1]).abs().max())
     return res
 
 
