@@ -491,10 +491,11 @@ class SpacecraftPoseNet(nn.Module):
         rank's slice, all-gather the updated shadows (bf16 mode) or parameters (f32 mode).  Slices are 8-element aligned; the
         staging buffers are padded to world equal pieces."""
         import torch.distributed as dist
+        from ..parallel import shard_slice
         rank = dist.get_rank(group)
         n = hi - lo
-        per = ((n + world_size - 1) // world_size + 7) // 8 * 8
-        my_lo = min(hi, lo + rank * per); my_hi = min(hi, my_lo + per); m = my_hi - my_lo
+        per, my_lo, my_hi = shard_slice(lo, hi, rank, world_size)
+        m = my_hi - my_lo
         part = self._gflat[lo:hi]
         wire = torch.bfloat16 if compress_bf16 else torch.float32
         stage = self._buf("shard_rs_%d" % lo, (per * world_size,), wire)
@@ -529,13 +530,14 @@ class SpacecraftPoseNet(nn.Module):
         if not stale:
             return
         import torch.distributed as dist
+        from ..parallel import shard_slice
         self.join_updates()
         if getattr(self, "_early_on_comm", False):
             torch.cuda.current_stream().wait_stream(self._comm)
         for lo, hi, per, group, world in stale.values():
             rank = dist.get_rank(group)
             n = hi - lo
-            my_lo = min(hi, lo + rank * per); my_hi = min(hi, my_lo + per); m = my_hi - my_lo
+            _, my_lo, my_hi = shard_slice(lo, hi, rank, world); m = my_hi - my_lo
             g_in = torch.zeros(per, dtype=torch.float32, device=self._flat.device)
             if m > 0:
                 g_in[:m].copy_(self._flat[my_lo:my_hi])

@@ -20,6 +20,16 @@ def shard_range(global_batch, rank, world):
     return rank * per, (rank + 1) * per
 
 
+def shard_slice(lo, hi, rank, world):
+    """The sharded exchange of an arena bucket [lo, hi) (SpacecraftPoseNet._shard_exchange): `world` equal pieces of `per`
+    elements (8-element aligned, the staging buffers are padded to world * per); returns (per, my_lo, my_hi) -- rank's slice
+    [my_lo, my_hi), empty for trailing ranks of a tiny bucket."""
+    n = hi - lo
+    per = ((n + world - 1) // world + 7) // 8 * 8
+    my_lo = min(hi, lo + rank * per)
+    return per, my_lo, min(hi, my_lo + per)
+
+
 def allreduce_sum_(flat, group=None):
     """in-place sum over ranks of a flat gradient arena; returns the tensor"""
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:

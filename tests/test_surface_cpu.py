@@ -191,3 +191,19 @@ def test_product_never_touches_the_oracle_and_fails_loudly_without_the_library(m
     monkeypatch.setattr(_lib, "LIB_PATH", os.path.join(root, "speedplusbaseline_amd", "no_such_libspb_hip.so"))
     with pytest.raises(RuntimeError, match="no CPU or PyTorch fallback"):
         _lib.lib()
+
+
+def test_shard_slices_tile_the_bucket():
+    """the rank slices of the sharded SPN exchange: 8-aligned, disjoint, in order, covering [lo, hi) exactly -- also for buckets
+    smaller than world * 8 and sizes that do not divide"""
+    from speedplusbaseline_amd.parallel import shard_slice
+    for lo, hi in ((0, 64), (24, 24 + 1), (1000, 1000 + 37_752_832), (8, 8 + 100), (16, 16 + 8 * 8)):
+        for world in (1, 2, 3, 8):
+            pos, pers = lo, set()
+            for r in range(world):
+                per, a, b = shard_slice(lo, hi, r, world)
+                pers.add(per)
+                assert per % 8 == 0 and per * world >= hi - lo
+                assert a == pos and a <= b <= hi and (b - a) <= per
+                pos = b
+            assert pos == hi and len(pers) == 1
