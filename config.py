@@ -30,7 +30,7 @@ parser.add_argument('--perform_dann', dest='dann', action='store_true', default=
 parser.add_argument('--texture_alpha', type=float, default=0.5)
 parser.add_argument('--texture_ratio', type=float, default=0.5)
 parser.add_argument('--use_fp16', dest='fp16', action='store_true', default=False,
-                    help='reference: fp16 autocast + GradScaler; here: bfloat16 compute, no loss scaling (a warning is logged)')
+                    help='reference: fp16 autocast + GradScaler; here: SPN runs float16 with device-side dynamic loss scaling, KRN / RevGrad run bfloat16 (logged)')
 parser.add_argument('--batch_size', type=int, default=32)
 parser.add_argument('--max_epochs', type=int, default=75)
 parser.add_argument('--num_workers', type=int, default=8)
@@ -53,8 +53,8 @@ parser.add_argument('--gpu_id', type=int, default=0)
 parser.add_argument('--no_cuda', dest='use_cuda', action='store_false', default=True)
 
 # ---- additions of this implementation (all optional)
-parser.add_argument('--precision', type=str, default=None, choices=[None, 'fp32', 'bf16'],
-                    help='compute type of the HIP kernels; default fp32 (the reference trains in fp32), --use_fp16 selects bf16')
+parser.add_argument('--precision', type=str, default=None, choices=[None, 'fp32', 'bf16', 'fp16'],
+                    help='compute type of the HIP kernels; default fp32 (the reference trains in fp32); --use_fp16 selects fp16 for SPN, bf16 for KRN; fp16 exists for SPN only')
 parser.add_argument('--synthetic_batches', type=int, default=0,
                     help='>0: train/evaluate on this many synthetic batches per epoch (U[0,1) images, U[0,1) keypoints); '
                          'the SPEED+ dataset pipeline is not part of this build')

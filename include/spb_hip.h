@@ -282,11 +282,34 @@ typedef struct spb_optim_args {
                            element, so the next forward needs no separate conversion pass (SPN, 152 M parameters) */
   int max_blocks;       /* > 0: at most this many workgroups, each walking the arena with a grid stride -- a background
                            update that leaves the compute units to the kernels of another stream; 0: one block per run */
+  const float* skip;        /* optional device scalar: != 0 -> the whole launch does nothing (AMP: non-finite gradients, see spb_amp_step) */
   const float* sq_partials; /* optional, instead of sqnorm: n_sq_partials (<= 256) partial sums of squares from
                                spb_grad_sqnorm_partials; every workgroup adds them up itself (no single-address ticket) */
   int n_sq_partials;
 } spb_optim_args_t;
 int spb_optim_step(const spb_optim_args_t* a, spb_stream_t stream);
+
+/* Dynamic loss scaling on the device: torch.cuda.amp.GradScaler's arithmetic (reference trainer.py:146-181, train.py:101-104)
+ * with no host read of found_inf.  `state` is SPB_AMP_STATE floats the caller initialises to {scale = 65536, 0, ...}:
+ *   spb_softce_scaled(..., state + SPB_AMP_SCALE)      the loss gradient carries the scale (the loss value does not)
+ *   spb_amp_check(grads, n, state)                      state[FOUND_INF] = 1 if any gradient element is inf / nan
+ *   spb_amp_step(state, lr, beta1, beta2, 2, 0.5, 2000) inv_scale of the step in flight, the skip flag, lr and the Adam bias
+ *                                                       corrections of the optimizer's OWN step count (it does not advance on a
+ *                                                       skipped step), then GradScaler.update(): scale *= backoff on overflow,
+ *                                                       *= growth after `interval` clean steps in a row
+ *   spb_optim_step(gmul = state + INV_SCALE, hyper = state + LR, skip = state + SKIP)                                        */
+#define SPB_AMP_STATE 12
+#define SPB_AMP_SCALE 0
+#define SPB_AMP_INV_SCALE 1
+#define SPB_AMP_TRACKER 2
+#define SPB_AMP_FOUND_INF 3
+#define SPB_AMP_STEPS 4
+#define SPB_AMP_LR 5      /* LR, BC1, BC2 are consecutive: spb_optim_args_t.hyper */
+#define SPB_AMP_BC1 6
+#define SPB_AMP_BC2 7
+#define SPB_AMP_SKIP 8
+int spb_amp_check(const float* grads, long long n, float* state, spb_stream_t stream);
+int spb_amp_step(float* state, float lr, float beta1, float beta2, float growth, float backoff, int interval, spb_stream_t stream);
 /* Weight gradient of a fully connected layer (spb_fc_wgrad's operands: GT [N][MP], XT [K][MP], batch M <= 64) fused with that
  * layer's share of the optimizer step: opt->params / m / v / shadow_bf16 point at the layer's [N][K] weight (opt->n == N*K),
  * opt->grads is NULL or receives the raw gradient.  Same arithmetic per element as spb_fc_wgrad followed by spb_optim_step;
@@ -446,6 +469,9 @@ int spb_dropout(int dtype, void* y, unsigned char* mask, long long n, float p, u
  * dlogits (may be NULL) = d(weight*loss)/dlogits */
 int spb_softce(int dtype, const void* logits, const float* target, void* dlogits, float* out, int slot, int B, int C, float weight,
                spb_stream_t stream);
+/* the same with dlogits multiplied by the device scalar *gscale (the AMP loss scale, spb_amp_* below); out is unscaled */
+int spb_softce_scaled(int dtype, const void* logits, const float* target, void* dlogits, float* out, int slot, int B, int C,
+                      float weight, const float* gscale, spb_stream_t stream);
 /* the same with reduction='none' (spn.py:43-44): rows[b] = -sum_c target[b][c] * log_softmax(logits[b])[c] */
 int spb_softce_rows(int dtype, const void* logits, const float* target, float* rows, int B, int C, spb_stream_t stream);
 /* out[n] += sum_m g[m][n] (bias gradients) */

@@ -11,6 +11,7 @@ if os.environ.get("SPB_LIB_VARIANT"):   # kernel experiments only (scratch/build
     LIB_PATH = os.path.join(_HERE, "libspb_hip.%s.so" % os.environ["SPB_LIB_VARIANT"])
 
 F32, BF16 = 0, 1
+AMP_STATE, AMP_SCALE, AMP_INV_SCALE, AMP_TRACKER, AMP_FOUND_INF, AMP_STEPS, AMP_LR, AMP_SKIP = 12, 0, 1, 2, 3, 4, 5, 8   # spb_hip.h SPB_AMP_*
 ACT_NONE, ACT_RELU, ACT_RELU6, ACT_LEAKY = 0, 1, 2, 3
 
 vp = C.c_void_p
@@ -95,7 +96,7 @@ class OptimArgs(C.Structure):
     _fields_ = [("params", vp), ("grads", vp), ("m", vp), ("v", vp), ("sqnorm", vp), ("gmul", vp), ("hyper", vp),
                 ("n", i64), ("kind", i32), ("lr", f32), ("beta1", f32), ("beta2", f32), ("eps", f32),
                 ("weight_decay", f32), ("max_norm", f32), ("clip_value", f32), ("bias_c1", f32), ("bias_c2", f32),
-                ("first_step", i32), ("shadow_bf16", vp), ("max_blocks", i32), ("sq_partials", vp), ("n_sq_partials", i32)]
+                ("first_step", i32), ("shadow_bf16", vp), ("max_blocks", i32), ("skip", vp), ("sq_partials", vp), ("n_sq_partials", i32)]
 
 
 class SpnConvArgs(C.Structure):
@@ -198,6 +199,9 @@ SYMBOLS = {
     "spb_relu_bwd": (i32, [i32, vp, vp, vp, vp, i64, f32, vp]),
     "spb_dropout": (i32, [i32, vp, vp, i64, f32, C.c_ulonglong, i32, vp]),
     "spb_softce": (i32, [i32, vp, vp, vp, vp, i32, i32, i32, f32, vp]),
+    "spb_softce_scaled": (i32, [i32, vp, vp, vp, vp, i32, i32, i32, f32, vp, vp]),
+    "spb_amp_check": (i32, [vp, i64, vp, vp]),
+    "spb_amp_step": (i32, [vp, f32, f32, f32, f32, f32, i32, vp]),
     "spb_softce_rows": (i32, [i32, vp, vp, vp, i32, i32, vp]),
     "spb_colsum": (i32, [i32, vp, vp, i64, i32, vp]),
     "spb_preproc_max_taps": (i32, []),
@@ -275,6 +279,33 @@ def lib():
             fn.argtypes = args
         _lib = l
     return _lib
+
+
+_lib_f16 = None
+LIB_F16_PATH = os.path.join(_HERE, "libspb_hip_f16.so")
+
+
+def lib_f16():
+    """The IEEE-half twin of the library (the SPN sources compiled with -DSPB_F16, csrc/common.h): same entry points and
+    argument structs, 16-bit tensors are float16 instead of bfloat16 and the matrix cores run v_mfma_f32_16x16x32_f16.  It
+    holds the SPN path only (spn*.hip, the pointwise GEMMs, the elementwise / optimizer kernels); no fallback exists."""
+    global _lib_f16
+    if _lib_f16 is None:
+        if not os.path.exists(LIB_F16_PATH):
+            raise RuntimeError("libspb_hip_f16.so is missing (%s). Build it with `python -m speedplusbaseline_amd.build`." % LIB_F16_PATH)
+        import torch  # noqa: F401
+        l = C.CDLL(LIB_F16_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(l, name, None)          # the twin exports the SPN subset of the C-ABI
+            if fn is not None:
+                fn.restype = res
+                fn.argtypes = args
+        _lib_f16 = l
+    return _lib_f16
+
+
+def lib_for(precision):
+    return lib_f16() if precision == "fp16" else lib()
 
 
 class SpbError(RuntimeError):

@@ -16,6 +16,10 @@ LIB = os.path.join(HERE, "libspb_hip.so")
 OBJDIR = os.path.join(HERE, "csrc", "_obj")
 SOURCES = ["gemm_pw.hip", "gemm_sk.hip", "gemm_os.hip", "gemm_big.hip", "pw_bwd_fused.hip", "dwconv_rows.hip", "dwconv_plane.hip", "stem_head.hip", "stem_mfma.hip", "elemwise.hip", "ghiasi.hip", "spn.hip", "spn_fc.hip", "spn_conv.hip", "preproc.hip", "krn_plan.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result", "-Wno-unused-value"]
+# IEEE-half twin for the SPN fp16 recipe (csrc/common.h, -DSPB_F16): the SPN kernels, the pointwise GEMMs they use and the
+# elementwise / optimizer kernels.  The KRN-only kernels keep bfloat16 bit tricks of their own and are not part of it.
+LIB_F16 = os.path.join(HERE, "libspb_hip_f16.so")
+SOURCES_F16 = ["gemm_pw.hip", "elemwise.hip", "spn.hip", "spn_fc.hip", "spn_conv.hip"]
 
 
 def _hipcc():
@@ -41,7 +45,7 @@ def build(force=False, verbose=True):
     srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
     stamp = os.path.join(OBJDIR, "stamp.txt")
     want = _digest(srcs + headers)
-    if not force and os.path.exists(LIB) and os.path.exists(stamp) and open(stamp).read().strip() == want:
+    if not force and os.path.exists(LIB) and os.path.exists(LIB_F16) and os.path.exists(stamp) and open(stamp).read().strip() == want:
         return LIB
     hipcc = _hipcc()
 
@@ -59,12 +63,29 @@ def build(force=False, verbose=True):
             f.write(d)
         return obj
 
+    def compile_f16(src):
+        obj = os.path.join(OBJDIR, os.path.basename(src) + ".f16.o")
+        dig = os.path.join(OBJDIR, os.path.basename(src) + ".f16.sha")
+        d = _digest([src] + headers)
+        if not force and os.path.exists(obj) and os.path.exists(dig) and open(dig).read().strip() == d:
+            return obj
+        cmd = [hipcc] + FLAGS + ["-DSPB_F16", "-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+        with open(dig, "w") as f:
+            f.write(d)
+        return obj
+
+    srcs16 = [os.path.join(CSRC, s) for s in SOURCES_F16]
     with ThreadPoolExecutor(max_workers=4) as ex:
         objs = list(ex.map(compile_one, srcs))
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
-    if verbose:
-        print(" ".join(cmd), flush=True)
-    subprocess.check_call(cmd)
+        objs16 = list(ex.map(compile_f16, srcs16))
+    for out, ob in ((LIB, objs), (LIB_F16, objs16)):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + ob
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
     with open(stamp, "w") as f:
         f.write(want)
     return LIB

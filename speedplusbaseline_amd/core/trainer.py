@@ -131,13 +131,17 @@ def train_single_epoch_krn(epoch, cfg, model, data_loader, optimizer, writer, de
 def train_single_epoch_spn(epoch, cfg, model, data_loader, optimizer, writer, device, styleAugmentor=None, scaler=None):
     """trainer.py:114-199.  One step = forward, loss = softCE(c, yClasses) + 10 softCE(r, yWeights), backward,
     clip_grad_value_(1.0), optimizer step -- all HIP launches (SpacecraftPoseNet.loss_and_grads + SpnOptimizer.step);
-    `scaler` is accepted for signature compatibility (bf16 needs no loss scaling)."""
+    `scaler`: in fp16 mode (--use_fp16) the GradScaler's arithmetic runs on the device inside loss_and_grads / optimizer.step
+    (SpnOptimizer._step_fp16); a torch GradScaler passed here only contributes its hyper-parameters.  bf16 / fp32 need none."""
     training_time_meter = AverageMeter('ms')
     loss_class_meter = AverageMeter('-')
     loss_weight_meter = AverageMeter('-')
     model.train()
     lr = optimizer.param_groups[-1]['lr']
     world, group = _world()
+    if scaler is not None and getattr(model, "precision", None) == "fp16" and hasattr(optimizer, "amp_interval"):
+        optimizer.amp_growth, optimizer.amp_backoff = float(scaler.get_growth_factor()), float(scaler.get_backoff_factor())
+        optimizer.amp_interval = int(scaler.get_growth_interval())
     n_iter = len(data_loader)
     for idx, (images, yClasses, yWeights) in enumerate(data_loader):
         start = time.time()

@@ -16,8 +16,19 @@ template <typename P, typename V> __device__ __forceinline__ void spb_no_atomic(
 #define atomicAdd(p, v) spb_no_atomic(p, v)
 #endif
 
-typedef unsigned short bf16_t;  // raw bfloat16 bits; activations in HBM are bf16 (or float in parity mode)
+typedef unsigned short bf16_t;  // raw 16-bit storage element: bfloat16 bits -- or IEEE half bits in the -DSPB_F16 twin library (below)
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+// The 16-bit storage format is a COMPILE-TIME property of the library: libspb_hip.so stores bfloat16, its twin libspb_hip_f16.so
+// (the same sources compiled with -DSPB_F16, speedplusbaseline_amd/build.py) stores IEEE half and runs v_mfma_f32_16x16x32_f16 --
+// the reference's fp16 autocast recipe for SPN (train.py:101-104, trainer.py:146-181; BASELINE configs[5]).  Everything that
+// touches the bits goes through the helpers of this header (bf2f / pack_bf16x2 / cvt8 / ld8 / rnd8) and SPB_MFMA16.
+#ifdef SPB_F16
+typedef _Float16 spb_h16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 spb_h16x8 __attribute__((ext_vector_type(8)));
+#define SPB_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(spb_h16x8, (a)), __builtin_bit_cast(spb_h16x8, (b)), (c), 0, 0, 0)
+#else
+#define SPB_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
+#endif
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 
@@ -31,14 +42,28 @@ typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 
 // ---------------------------------------------------------------------------------------------
 // scalar conversions
+#ifdef SPB_F16
+__device__ __forceinline__ float bf2f(bf16_t h) { return (float)__builtin_bit_cast(_Float16, h); }
+// the two halves of a packed 32-bit word as floats
+__device__ __forceinline__ void spb_unpack2(uint32_t u, float& lo, float& hi) {
+  const spb_h16x2 h = __builtin_bit_cast(spb_h16x2, u);
+  lo = (float)h[0]; hi = (float)h[1];
+}
+#else
 __device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+__device__ __forceinline__ void spb_unpack2(uint32_t u, float& lo, float& hi) { lo = __uint_as_float(u << 16); hi = __uint_as_float(u & 0xffff0000u); }
+#endif
 // float -> bf16, round-to-nearest-even: one v_cvt_pk_bf16_f32 per pair on gfx950 (the integer emulation cost 7 VALU
 // ops per value and was ~20 % of the instruction stream of the streaming kernels)
 typedef __bf16 spb_bf16x2_hw __attribute__((ext_vector_type(2)));
 typedef float spb_f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
   const spb_f32x2 v = {lo, hi};
+#ifdef SPB_F16
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, spb_h16x2));   // v_cvt_pk_f16_f32 (RNE; overflow -> inf, as autocast)
+#else
   return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, spb_bf16x2_hw));
+#endif
 }
 __device__ __forceinline__ bf16_t f2bf(float f) { return (bf16_t)(pack_bf16x2(f, 0.f) & 0xffffu); }
 template <typename T> __device__ __forceinline__ float to_f(T v);
@@ -60,10 +85,7 @@ template <> __device__ __forceinline__ void ld8<float>(const float* p, float v[8
 }
 template <> __device__ __forceinline__ void ld8<bf16_t>(const bf16_t* p, float v[8]) {
   const uint4 u = *reinterpret_cast<const uint4*>(p);
-  v[0] = __uint_as_float(u.x << 16); v[1] = __uint_as_float(u.x & 0xffff0000u);
-  v[2] = __uint_as_float(u.y << 16); v[3] = __uint_as_float(u.y & 0xffff0000u);
-  v[4] = __uint_as_float(u.z << 16); v[5] = __uint_as_float(u.z & 0xffff0000u);
-  v[6] = __uint_as_float(u.w << 16); v[7] = __uint_as_float(u.w & 0xffff0000u);
+  spb_unpack2(u.x, v[0], v[1]); spb_unpack2(u.y, v[2], v[3]); spb_unpack2(u.z, v[4], v[5]); spb_unpack2(u.w, v[6], v[7]);
 }
 template <typename T> __device__ __forceinline__ void st8(T* p, const float v[8]);
 template <> __device__ __forceinline__ void st8<float>(float* p, const float v[8]) {
@@ -92,10 +114,7 @@ template <> __device__ __forceinline__ Raw8<float> ldraw<float>(const float* p) 
   Raw8<float> r; r.a = *reinterpret_cast<const float4*>(p); r.b = *reinterpret_cast<const float4*>(p + 4); return r;
 }
 __device__ __forceinline__ void cvt8(const Raw8<bf16_t>& r, float v[8]) {
-  v[0] = __uint_as_float(r.u.x << 16); v[1] = __uint_as_float(r.u.x & 0xffff0000u);
-  v[2] = __uint_as_float(r.u.y << 16); v[3] = __uint_as_float(r.u.y & 0xffff0000u);
-  v[4] = __uint_as_float(r.u.z << 16); v[5] = __uint_as_float(r.u.z & 0xffff0000u);
-  v[6] = __uint_as_float(r.u.w << 16); v[7] = __uint_as_float(r.u.w & 0xffff0000u);
+  spb_unpack2(r.u.x, v[0], v[1]); spb_unpack2(r.u.y, v[2], v[3]); spb_unpack2(r.u.z, v[4], v[5]); spb_unpack2(r.u.w, v[6], v[7]);
 }
 __device__ __forceinline__ void cvt8(const Raw8<float>& r, float v[8]) {
   v[0] = r.a.x; v[1] = r.a.y; v[2] = r.a.z; v[3] = r.a.w; v[4] = r.b.x; v[5] = r.b.y; v[6] = r.b.z; v[7] = r.b.w;
@@ -107,7 +126,7 @@ template <> __device__ __forceinline__ void rnd8<bf16_t>(float v[8]) {
 #pragma unroll
   for (int i = 0; i < 8; i += 2) {
     const uint32_t p = pack_bf16x2(v[i], v[i + 1]);
-    v[i] = __uint_as_float(p << 16); v[i + 1] = __uint_as_float(p & 0xffff0000u);
+    spb_unpack2(p, v[i], v[i + 1]);
   }
 }
 

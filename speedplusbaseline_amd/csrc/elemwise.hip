@@ -361,6 +361,7 @@ template <bool NT> __device__ __forceinline__ void stv(float* p, long long i, f3
 // HBM pages open; measured 5.9 TB/s against 5.0 TB/s for a 2048-block grid-stride loop on the 152 M element SPN arena).
 template <int VEC, bool NT, int U>
 __global__ __launch_bounds__(256) void optim_step_kernel(const spb_optim_args_t a) {
+  if (a.skip && *a.skip != 0.f) return;   // AMP: a non-finite gradient was found -- GradScaler.step() skips optimizer.step()
   float gm = a.gmul ? *a.gmul : 1.f;
   float coef = 1.f;
   if (a.max_norm > 0.f && a.sq_partials && a.n_sq_partials > 0) {   // every workgroup adds the partials up in the same fixed order
@@ -673,5 +674,59 @@ extern "C" int spb_partial_reduce(const spb_red_job_t* jobs, int njobs, spb_stre
     SPB_CHECK_LAUNCH();
     done += k;
   }
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Dynamic loss scaling on the device (torch.cuda.amp.GradScaler as the reference's fp16 recipe uses it, trainer.py:146-181:
+// scaler.scale(loss).backward(); scaler.unscale_(optimizer); clip_grad_value_; scaler.step(optimizer); scaler.update()) --
+// without the host synchronisation GradScaler.step() makes to read found_inf.  State: SPB_AMP_STATE floats, see spb_hip.h.
+namespace {
+__global__ __launch_bounds__(256) void amp_check_kernel(const float* __restrict__ g, long long n, float* state) {
+  const long long n4 = n >> 2;
+  const float4* g4 = reinterpret_cast<const float4*>(g);
+  bool bad = false;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+    const float4 v = g4[i];
+    // finite <=> |x| <= FLT_MAX; a NaN compares false
+    bad |= !(fabsf(v.x) <= 3.4028234e38f) | !(fabsf(v.y) <= 3.4028234e38f) | !(fabsf(v.z) <= 3.4028234e38f) | !(fabsf(v.w) <= 3.4028234e38f);
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) bad |= !(fabsf(g[(n4 << 2) + threadIdx.x]) <= 3.4028234e38f);
+  if (bad) state[SPB_AMP_FOUND_INF] = 1.f;   // racing writers store the same value
+}
+__global__ void amp_step_kernel(float* st, float lr, float beta1, float beta2, float growth, float backoff, int interval) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const bool found = st[SPB_AMP_FOUND_INF] != 0.f;
+  st[SPB_AMP_INV_SCALE] = 1.f / st[SPB_AMP_SCALE];           // the unscale factor of the step in flight
+  st[SPB_AMP_SKIP] = found ? 1.f : 0.f;
+  st[SPB_AMP_LR] = lr;
+  if (!found) {                                               // the optimizer's own step count only advances on steps it takes
+    const float t = st[SPB_AMP_STEPS] + 1.f;
+    st[SPB_AMP_STEPS] = t;
+    st[SPB_AMP_BC1] = beta1 > 0.f ? 1.f - powf(beta1, t) : 1.f;
+    st[SPB_AMP_BC2] = beta2 > 0.f ? 1.f - powf(beta2, t) : 1.f;
+  }
+  // GradScaler.update(): back off at once, grow after `interval` clean steps in a row
+  if (found) { st[SPB_AMP_SCALE] *= backoff; st[SPB_AMP_TRACKER] = 0.f; }
+  else {
+    const float k = st[SPB_AMP_TRACKER] + 1.f;
+    if (k >= (float)interval) { st[SPB_AMP_SCALE] *= growth; st[SPB_AMP_TRACKER] = 0.f; } else st[SPB_AMP_TRACKER] = k;
+  }
+  st[SPB_AMP_FOUND_INF] = 0.f;
+}
+}  // namespace
+
+extern "C" int spb_amp_check(const float* grads, long long n, float* state, spb_stream_t stream) {
+  if (!grads || !state || n <= 0) return SPB_E_ARG;
+  const long long n4 = n >> 2;
+  const int nblk = (int)(n4 >= 2048LL * 256 * 4 ? 2048 : (n4 + 1023) / 1024 > 0 ? (n4 + 1023) / 1024 : 1);
+  hipLaunchKernelGGL(amp_check_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, grads, n, state);
+  SPB_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int spb_amp_step(float* state, float lr, float beta1, float beta2, float growth, float backoff, int interval, spb_stream_t stream) {
+  if (!state || interval < 1) return SPB_E_ARG;
+  hipLaunchKernelGGL(amp_step_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, state, lr, beta1, beta2, growth, backoff, interval);
+  SPB_CHECK_LAUNCH();
   return 0;
 }

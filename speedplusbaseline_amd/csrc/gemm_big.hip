@@ -201,7 +201,7 @@ __global__ __launch_bounds__(NTH) void pw_big_kernel(const spb_gemm_args_t g) {
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < WJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfv[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < WJ; ++j) acc[i][j] = SPB_MFMA16(af[i], bfv[j], acc[i][j]);
     }
     if (kt + 1 < KT) {
       // this wave's own share of stage kt+1 has landed once only the stage issued above is still in flight; its transform

@@ -168,7 +168,7 @@ __global__ __launch_bounds__(256) void pw_os_kernel(const spb_gemm_args_t g, int
 #pragma unroll
       for (int j = 0; j < NF; ++j) {
         const uint4 pb = *reinterpret_cast<const uint4*>(wl + ((size_t)(c * NF + j) << 10) + li * 64 + lq * 16);
-        acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, __builtin_bit_cast(bf16x8_t, pb), acc[j], 0, 0, 0);
+        acc[j] = SPB_MFMA16(af, __builtin_bit_cast(bf16x8_t, pb), acc[j]);
       }
     }
   }

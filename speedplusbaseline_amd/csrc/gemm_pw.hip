@@ -22,9 +22,15 @@
 #include "common.h"
 #include <hip/hip_ext.h>
 
+#ifdef SPB_F16   // the IEEE-half twin holds this file's kernels only (build.py SOURCES_F16)
+static int spb_gemm_sk(const spb_gemm_args_t*, hipStream_t) { return SPB_E_UNSUPPORTED; }
+static int spb_gemm_os(const spb_gemm_args_t*, hipStream_t) { return SPB_E_UNSUPPORTED; }
+static int spb_gemm_big(const spb_gemm_args_t*, hipStream_t) { return SPB_E_UNSUPPORTED; }
+#else
 int spb_gemm_sk(const spb_gemm_args_t* a, hipStream_t stream);   // gemm_sk.hip
 int spb_gemm_os(const spb_gemm_args_t* a, hipStream_t stream);   // gemm_os.hip
 int spb_gemm_big(const spb_gemm_args_t* a, hipStream_t stream);  // gemm_big.hip
+#endif
 
 // phase timestamps for scratch/ubench_gemm.hip (compiled out in the product build)
 #ifndef SPB_TS
@@ -178,7 +184,7 @@ __global__ __launch_bounds__(256, (RF == 1 && sizeof(T) == 2) ? (((BK == 64 && P
         _Pragma("unroll") for (int j = 0; j < NF; ++j) {                                                       \
           const bf16x8_t bfv = *reinterpret_cast<const bf16x8_t*>(Bs + (j * 16 + li) * LDK + ks * 32 + lq * 8); \
           _Pragma("unroll") for (int i = 0; i < RF; ++i)                                                       \
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfv, acc[i][j], 0, 0, 0);               \
+            acc[i][j] = SPB_MFMA16(af[i], bfv, acc[i][j]);               \
         }                                                                                                      \
       }                                                                                                        \
     } else {                                                                                                   \
@@ -541,7 +547,7 @@ __global__ __launch_bounds__(256) void pw_gemm_dma_kernel(const spb_gemm_args_t 
         const int brow_ = j * 16 + li;
         uint4 pb = *reinterpret_cast<const uint4*>(sb + (PRO == 2 ? 2 : 1) * DBM * DBK * 2 + brow_ * (DBK * 2) + ((v ^ (brow_ & 7)) << 4));
         if (kb >= K || n0 + brow_ >= N) pb = make_uint4(0, 0, 0, 0);
-        acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, __builtin_bit_cast(bf16x8_t, pb), acc[j], 0, 0, 0);
+        acc[j] = SPB_MFMA16(af, __builtin_bit_cast(bf16x8_t, pb), acc[j]);
       }
     }
   }
@@ -804,7 +810,7 @@ __global__ __launch_bounds__(256) void pw_wgrad_kernel(const spb_wgrad_args_t g,
         for (int a = 0; a < 2; ++a)
 #pragma unroll
           for (int b = 0; b < 2; ++b)
-            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf[a], qf[b], acc[a][b], 0, 0, 0);
+            acc[a][b] = SPB_MFMA16(pf[a], qf[b], acc[a][b]);
       }
     } else {
 #pragma unroll 4

@@ -197,7 +197,7 @@ __global__ __launch_bounds__(256) void pw_sk_kernel(const spb_gemm_args_t g) {
         for (int j = 0; j < NF; ++j) {
           const bf16x8_t bfv = __builtin_bit_cast(bf16x8_t, rb[d][j]);
 #pragma unroll
-          for (int i = 0; i < RF; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfv, acc[i][j], 0, 0, 0);
+          for (int i = 0; i < RF; ++i) acc[i][j] = SPB_MFMA16(af[i], bfv, acc[i][j]);
         }
         const int sn = s + 4 * D;
         SK_LOAD(d, sn < KT ? sn : KT - 1);              // clamped, unconditional: no load inside a branch of its own

@@ -253,7 +253,7 @@ __global__ __launch_bounds__(256) void gconv_kernel(const spb_gconv_args_t g, in
           const uint4 au = wok[nb] ? auv[nb] : make_uint4(0, 0, 0, 0);
 #pragma unroll
           for (int p = 0; p < PXG; ++p)
-            acc[p][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, au), bfv[p], acc[p][nb], 0, 0, 0);
+            acc[p][nb] = SPB_MFMA16(__builtin_bit_cast(bf16x8_t, au), bfv[p], acc[p][nb]);
         }
       };
       if (ns > 0) frag_load(bfc, auc);
@@ -301,7 +301,7 @@ __global__ __launch_bounds__(256) void gconv_kernel(const spb_gconv_args_t g, in
             for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
               for (int p = 0; p < PXG; ++p)
-                acc[p][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a[nb]), bf[p], acc[p][nb], 0, 0, 0);
+                acc[p][nb] = SPB_MFMA16(__builtin_bit_cast(bf16x8_t, a[nb]), bf[p], acc[p][nb]);
             if (++cc == nch) { cc = 0; if (++kx == KH) { kx = 0; ++ky; } }
           }
         }
@@ -505,7 +505,7 @@ __global__ __launch_bounds__(256) void gconv_up2_kernel(const spb_gconv_args_t g
           const uint4 au = wok[nb] ? auv[nb] : make_uint4(0, 0, 0, 0);
 #pragma unroll
           for (int p = 0; p < PXG; ++p)
-            acc[p][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, au), bfv[p], acc[p][nb], 0, 0, 0);
+            acc[p][nb] = SPB_MFMA16(__builtin_bit_cast(bf16x8_t, au), bfv[p], acc[p][nb]);
         }
       };
       frag_load(bfc, auc);
@@ -554,7 +554,7 @@ __global__ __launch_bounds__(256) void gconv_up2_kernel(const spb_gconv_args_t g
             for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
               for (int p = 0; p < PXG; ++p)
-                acc[p][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a[nb]), bf[p], acc[p][nb], 0, 0, 0);
+                acc[p][nb] = SPB_MFMA16(__builtin_bit_cast(bf16x8_t, a[nb]), bf[p], acc[p][nb]);
             if (++cc == nch) { cc = 0; if (++kx == 2) { kx = 0; ++ky; } }
           }
         }
@@ -736,7 +736,7 @@ __global__ __launch_bounds__(256, PXG >= 4 ? 1 : 2) void gconv_slab_kernel(const
 #pragma unroll
         for (int p = 0; p < PXG; ++p) {
           if (GABL & 8) acc[p][nb][0] += (float)af[0] * (float)bf[p][0];
-          else acc[p][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bf[p], acc[p][nb], 0, 0, 0);
+          else acc[p][nb] = SPB_MFMA16(af, bf[p], acc[p][nb]);
         }
       }
       // NO branch around these stores and loads (ROWS * 4 is a multiple of 256; the step index is clamped, the last steps
@@ -885,7 +885,7 @@ __global__ __launch_bounds__(256) void conv9_band_kernel(const spb_gconv_args_t 
 #pragma unroll
       for (int p = 0; p < 4; ++p) {
         const bf16x8_t bf = *reinterpret_cast<const bf16x8_t*>(hb[p] + (ky * HW_ + kx) * LDP);
-        acc[p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bf, acc[p], 0, 0, 0);
+        acc[p] = SPB_MFMA16(af, bf, acc[p]);
       }
     }
   // epilogue: lanes lq == 0 hold channels 0..3 of their pixel
@@ -1001,8 +1001,8 @@ __global__ __launch_bounds__(256) void conv9_kxrows_kernel(const spb_gconv_args_
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const bf16x8_t bf = *reinterpret_cast<const bf16x8_t*>(hb + ((r + ky) * HW_ + q * 16) * LDP);
-        acc[r][q][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, bf, acc[r][q][0], 0, 0, 0);
-        acc[r][q][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, bf, acc[r][q][1], 0, 0, 0);
+        acc[r][q][0] = SPB_MFMA16(a0, bf, acc[r][q][0]);
+        acc[r][q][1] = SPB_MFMA16(a1, bf, acc[r][q][1]);
       }
   }
   __syncthreads();                                                 // everyone is done with the halo: it becomes P
@@ -1132,7 +1132,7 @@ __global__ __launch_bounds__(256) void conv9_rgb_kernel(const float* __restrict_
       const bf16x8_t bf = __builtin_bit_cast(bf16x8_t, make_uint4(lo.x, lo.y, hi.x, hi.y));
 #pragma unroll
       for (int cb = 0; cb < 2; ++cb)
-        acc[cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wfrag[(st_ * 2 + cb) * 64 + lane]), bf, acc[cb], 0, 0, 0);
+        acc[cb] = SPB_MFMA16(__builtin_bit_cast(bf16x8_t, wfrag[(st_ * 2 + cb) * 64 + lane]), bf, acc[cb]);
     }
 #pragma unroll
     for (int cb = 0; cb < 2; ++cb) {

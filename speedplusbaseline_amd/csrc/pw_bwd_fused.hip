@@ -202,7 +202,7 @@ __global__ __launch_bounds__(256, 1) void pwb_kernel(const spb_pwbwd_args_t g, l
       for (int kb = 0; kb < KB; ++kb) {
         acc[kb] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int ns = 0; ns < NS; ++ns) acc[kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Wf[kb][ns], bz[h][ns], acc[kb], 0, 0, 0);
+        for (int ns = 0; ns < NS; ++ns) acc[kb] = SPB_MFMA16(Wf[kb][ns], bz[h][ns], acc[kb]);
       }
       const int row = h * 16 + li;
       const long long m = m0 + row;
@@ -273,7 +273,7 @@ __global__ __launch_bounds__(256, 1) void pwb_kernel(const spb_pwbwd_args_t g, l
     for (int nb = 0; nb < NB; ++nb) {
       const bf16x8_t af = tr_frag(dzt, LDZ, nb * 16, li, lq);
 #pragma unroll
-      for (int kb = 0; kb < KB; ++kb) dw[nb][kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bf[kb], dw[nb][kb], 0, 0, 0);
+      for (int kb = 0; kb < KB; ++kb) dw[nb][kb] = SPB_MFMA16(af, bf[kb], dw[nb][kb]);
     }
   }
   wait_vmcnt<0>();

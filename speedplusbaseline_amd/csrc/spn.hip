@@ -287,7 +287,8 @@ __global__ void dropout_kernel(T* __restrict__ y, unsigned char* __restrict__ ma
 // out[0] += weight * mean-over-rows contribution, out[slot] += unweighted mean (for the two reported losses)
 template <typename T>
 __global__ __launch_bounds__(256) void softce_kernel(const T* __restrict__ logits, const float* __restrict__ target, T* __restrict__ dlogits,
-                                                     float* out, int slot, int Bn, int Cn, float weight, float* rows) {
+                                                     float* out, int slot, int Bn, int Cn, float weight, float* rows,
+                                                     const float* gscale = nullptr) {
   __shared__ float red[256];
   const int b = blockIdx.x, t = threadIdx.x;
   const T* x = logits + (size_t)b * Cn;
@@ -318,7 +319,7 @@ __global__ __launch_bounds__(256) void softce_kernel(const T* __restrict__ logit
     if (rows) rows[b] = lse * st - sx;      // reduction='none' (spn.py:43-44): the per-sample loss
   }
   if (dlogits) {
-    const float gs = weight / (float)Bn;
+    const float gs = weight / (float)Bn * (gscale ? *gscale : 1.f);   // gscale: the AMP loss scale (device scalar; the loss value stays unscaled)
     for (int c = t; c < Cn; c += 256) stf<T>(dlogits + (size_t)b * Cn + c, (expf(ldf<T>(x + c) - lse) * st - tg[c]) * gs);
   }
 }
@@ -539,6 +540,17 @@ extern "C" int spb_softce(int dtype, const void* logits, const float* target, vo
   SPB_CHECK_LAUNCH();
   return 0;
 }
+// the same with the gradient multiplied by a device scalar: GradScaler's scale(loss).backward() (reference trainer.py:171-173)
+extern "C" int spb_softce_scaled(int dtype, const void* logits, const float* target, void* dlogits, float* out, int slot, int B, int C,
+                                 float weight, const float* gscale, spb_stream_t stream) {
+  if (!logits || !target || !out || B <= 0 || C <= 0 || slot < 1 || slot > 2) return SPB_E_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  SPN_T(dtype, hipLaunchKernelGGL(softce_kernel<bf16_t>, dim3(B), dim3(256), 0, s, (const bf16_t*)logits, target, (bf16_t*)dlogits, out, slot, B, C, weight, (float*)nullptr, gscale),
+        hipLaunchKernelGGL(softce_kernel<float>, dim3(B), dim3(256), 0, s, (const float*)logits, target, (float*)dlogits, out, slot, B, C, weight, (float*)nullptr, gscale))
+  SPB_CHECK_LAUNCH();
+  return 0;
+}
+
 extern "C" int spb_softce_rows(int dtype, const void* logits, const float* target, float* rows, int B, int C, spb_stream_t stream) {
   if (!logits || !target || !rows || B <= 0 || C <= 0) return SPB_E_ARG;
   hipStream_t s = (hipStream_t)stream;

@@ -131,7 +131,7 @@ __global__ __launch_bounds__(256) void spn_conv_kernel(const bf16_t* __restrict_
         const int br = j * 16 + li;
         const bf16x8_t bf = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(sb + A_BYTES + br * (CBK * 2) + ((v ^ (br & 7)) << 4)));
 #pragma unroll
-        for (int r = 0; r < RW; ++r) acc[r][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[r], bf, acc[r][j], 0, 0, 0);
+        for (int r = 0; r < RW; ++r) acc[r][j] = SPB_MFMA16(af[r], bf, acc[r][j]);
       }
     }
   }
@@ -266,7 +266,7 @@ __global__ __launch_bounds__(256) void spn_stem_kernel(const float* __restrict__
       const bf16x8_t bf = __builtin_bit_cast(bf16x8_t, make_uint4(lo.x, lo.y, hi.x, hi.y));
 #pragma unroll
       for (int nb = 0; nb < STEM_NB; ++nb)
-        acc[g][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a[nb]), bf, acc[g][nb], 0, 0, 0);
+        acc[g][nb] = SPB_MFMA16(__builtin_bit_cast(bf16x8_t, a[nb]), bf, acc[g][nb]);
     }
   }
   // ---- epilogue: lane (li = pixel, lq): channels lq*24 + nb*4 + e, 48 contiguous bytes
@@ -395,7 +395,7 @@ __global__ __launch_bounds__(256) void spn_conv_wgrad_kernel(const bf16_t* __res
 #pragma unroll
       for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf[a], qf[b], acc[a][b], 0, 0, 0);
+        for (int b = 0; b < 2; ++b) acc[a][b] = SPB_MFMA16(pf[a], qf[b], acc[a][b]);
     }
   }
 #undef WG_STAGE

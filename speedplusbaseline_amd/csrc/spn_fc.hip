@@ -31,7 +31,7 @@ __device__ __forceinline__ bf16x8_t zero_frag() {
   return x.v;
 }
 __device__ __forceinline__ f32x4_t mfma(bf16x8_t a, bf16x8_t b, f32x4_t c) {
-  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+  return SPB_MFMA16(a, b, c);
 }
 
 // cross-wave sum of per-lane accumulators through LDS, then atomics into accT[f0 + ...][MP]

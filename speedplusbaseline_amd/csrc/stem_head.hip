@@ -171,7 +171,7 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const spb_head_args_t a, 
           u.w = (uint32_t)f2bf(v[6]) | ((uint32_t)f2bf(v[7]) << 16);
           const bf16x8_t af = __builtin_bit_cast(bf16x8_t, u);
 #pragma unroll
-          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bf[j], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < 2; ++j) acc[i][j] = SPB_MFMA16(af, bf[j], acc[i][j]);
         }
       }
     } else {

@@ -87,7 +87,7 @@ __global__ __launch_bounds__(256) void stem_fwd_mfma_kernel(const float* __restr
 #pragma unroll
     for (int cb = 0; cb < 2; ++cb) {
       f32x4_t acc = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Wa[cb], bf, acc, 0, 0, 0);
+      acc = SPB_MFMA16(Wa[cb], bf, acc);
       // lane (li, lq): pixel p, channels cb*16 + lq*4 .. +3
       uint2 o;
       o.x = pack_bf16x2(acc[0], acc[1]); o.y = pack_bf16x2(acc[2], acc[3]);
@@ -215,7 +215,7 @@ __global__ __launch_bounds__(256) void stem_wgrad_mfma_kernel(const float* __res
     for (int cb = 0; cb < 2; ++cb) {
       const bf16x8_t af = tr_frag(dzt, LD, cb * 16, li, lq);
 #pragma unroll
-      for (int tb = 0; tb < 2; ++tb) acc[cb][tb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, pf[tb], acc[cb][tb], 0, 0, 0);
+      for (int tb = 0; tb < 2; ++tb) acc[cb][tb] = SPB_MFMA16(af, pf[tb], acc[cb][tb]);
     }
     asm volatile("" ::: "memory");
   }

@@ -14,13 +14,21 @@ def _precision(cfg):
     if p:
         return p
     if getattr(cfg, "fp16", False):
-        # reference: torch.cuda.amp autocast (float16) + GradScaler (train.py:101-104, trainer.py:73-94).  The MI355X kernels
-        # compute in bfloat16 with f32 accumulation / master weights / statistics instead: same 16-bit operand width and
-        # matrix-core rate, f32's exponent range, so no loss scaling (and no inf-check host sync) is needed.
+        # reference: torch.cuda.amp autocast (float16) + GradScaler (train.py:101-104, trainer.py:73-94, 146-181).
+        #   SPN: real float16 -- IEEE-half activations / weight shadows on v_mfma_f32_16x16x32_f16 (libspb_hip_f16.so), f32
+        #        master weights and accumulation, GradScaler's dynamic loss scale kept on the device (spb_amp_*).
+        #   KRN / RevGrad: bfloat16 compute instead (same operand width and matrix-core rate, f32's exponent range: no loss
+        #        scaling); their kernels have no float16 instances.
         global _warned_fp16
+        if cfg.model_name == 'spn' and not cfg.dann:
+            if not _warned_fp16:
+                logger.info("--use_fp16: SPN runs in float16 with device-side dynamic loss scaling (GradScaler defaults: "
+                            "init 65536, x2 after 2000 clean steps, x0.5 and a skipped step on overflow)")
+                _warned_fp16 = True
+            return "fp16"
         if not _warned_fp16:
-            logger.warning("--use_fp16: float16 autocast + GradScaler is replaced by bfloat16 compute (no loss scaling); "
-                           "pass --precision bf16 to select it explicitly")
+            logger.warning("--use_fp16: for KRN / RevGrad float16 autocast + GradScaler is replaced by bfloat16 compute (no loss "
+                           "scaling); pass --precision bf16 to select it explicitly")
             _warned_fp16 = True
         return "bf16"
     return None

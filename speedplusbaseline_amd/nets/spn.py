@@ -44,14 +44,14 @@ def softmax_cross_entropy_with_logits(logits, target, reduction="mean"):
         raise ValueError("reduction must be 'mean', 'sum' or 'none' (spn.py:45-48)")
     B, Cn = logits.shape
     lg = logits.detach().contiguous()
-    lg = lg if lg.dtype in (torch.float32, torch.bfloat16) else lg.float()
+    lg = lg if lg.dtype in (torch.float32, torch.bfloat16, torch.float16) else lg.float()
     tg = target.detach().float().contiguous()
     if reduction == "none":
         rows = torch.empty(B, dtype=torch.float32, device=logits.device)
-        L.check(L.lib().spb_softce_rows(ops.dtype_code(lg), _p(lg), _p(tg), _p(rows), B, Cn, _st()), "spb_softce_rows")
+        L.check(ops.lib_of(lg).spb_softce_rows(ops.dtype_code(lg), _p(lg), _p(tg), _p(rows), B, Cn, _st()), "spb_softce_rows")
         return rows
     out = torch.zeros(3, dtype=torch.float32, device=logits.device)
-    L.check(L.lib().spb_softce(ops.dtype_code(lg), _p(lg), _p(tg), None, _p(out), 1, B, Cn, 1.0, _st()), "spb_softce")
+    L.check(ops.lib_of(lg).spb_softce(ops.dtype_code(lg), _p(lg), _p(tg), None, _p(out), 1, B, Cn, 1.0, _st()), "spb_softce")
     return out[1] * (B if reduction == "sum" else 1)
 
 
@@ -98,7 +98,11 @@ class SpacecraftPoseNet(nn.Module):
         for name, o, i in (("fc6", 4096, 9216), ("fc7", 4096, 4096), ("fc8", num_classes, 4096), ("fc9", 4096, 9216),
                            ("fc10", 4096, 4096), ("fc11", num_classes, 4096)):
             setattr(self, name, _Layer((o, i)))
+        precision = precision or "fp32"       # None: the reference's default (train.py without --use_fp16)
+        if precision not in ("bf16", "fp16", "fp32"):
+            raise ValueError("precision must be bf16, fp16 or fp32, got %r" % (precision,))
         self.precision = precision
+        self._half = precision in ("bf16", "fp16")     # 16-bit activations / weight shadows, f32 accumulation and master weights
         self._flat = self._gflat = self._shadow = None
         self._version = 0          # bumped whenever parameters change: compute copies are rebuilt lazily
         self._copies = None
@@ -156,9 +160,28 @@ class SpacecraftPoseNet(nn.Module):
                 p_.data = flat[o:o + k].view(p_.shape)
                 p_.grad = gflat[o:o + k].view(p_.shape)
         self._flat, self._gflat, self._offs = flat, gflat, offs
-        self._shadow = torch.empty(off, dtype=torch.bfloat16, device=dev) if self.precision == "bf16" else None
+        self._shadow = torch.empty(off, dtype=self._dt(), device=dev) if self._half else None
         self._shadow_version = -1
         self._conv_end = offs["fc6.weight"][0]
+
+    # ---- fp16: dynamic loss scaling on the device (GradScaler's arithmetic: init 65536, x2 after 2000 clean steps, x0.5 on overflow)
+    def amp_state(self, init_scale=65536.0):
+        """float32 [SPB_AMP_STATE] device tensor (include/spb_hip.h): loss scale, unscale factor of the step in flight, growth
+        tracker, found_inf, the optimizer's own step count, lr / Adam bias corrections, skip flag.  Created on first use."""
+        if getattr(self, "_amp", None) is None:
+            self._ensure_arena()
+            st = torch.zeros(L.AMP_STATE, dtype=torch.float32, device=self._flat.device)
+            st[L.AMP_SCALE] = float(init_scale); st[L.AMP_INV_SCALE] = 1.0 / float(init_scale)
+            self._amp = st
+        return self._amp
+
+    def loss_scale(self):
+        """current loss scale (host float; synchronises) -- 1.0 outside fp16 mode"""
+        return float(self.amp_state()[L.AMP_SCALE]) if self.precision == "fp16" else 1.0
+
+    def _lib(self):
+        """libspb_hip.so, or its IEEE-half twin libspb_hip_f16.so in fp16 mode (same entry points, csrc/common.h SPB_F16)"""
+        return L.lib_for(self.precision)
 
     def flat_parameters(self):
         self._ensure_arena()
@@ -194,28 +217,28 @@ class SpacecraftPoseNet(nn.Module):
     # ---- compute-dtype copies: conv weights as [Cout][Kpad] in (ky,kx,c_full) order (block diagonal for groups),
     #      fc6/fc9 columns permuted from the reference's NCHW flatten to NHWC, plus the transposes the input gradients need
     def _dt(self):
-        return torch.bfloat16 if self.precision == "bf16" else torch.float32
+        return {"bf16": torch.bfloat16, "fp16": torch.float16}.get(self.precision, torch.float32)
 
     def _implicit(self):
         """bf16: conv2..conv5 run as implicit GEMMs (no column matrix); float32 keeps the im2col + GEMM path"""
-        return self.precision == "bf16" and self.implicit_conv
+        return self._half and self.implicit_conv
 
     def _conv(self, X, Wp, bias, mask, Y, B, H, W, Cx, k, stride, pad, groups, Cg, Ng, relu):
         a = L.SpnConvArgs()
         a.X, a.Wp, a.bias, a.mask, a.Y = _p(X).value, _p(Wp).value, _p(bias).value, _p(mask).value, _p(Y).value
         a.B, a.H, a.W, a.Cx, a.KH, a.KW, a.stride, a.pad = B, H, W, Cx, k, k, stride, pad
         a.groups, a.Cg, a.Ng, a.Kp, a.relu = groups, Cg, Ng, Wp.shape[1], 1 if relu else 0
-        L.check(L.lib().spb_spn_conv(C.byref(a), _st()), "spb_spn_conv")
+        L.check(self._lib().spb_spn_conv(C.byref(a), _st()), "spb_spn_conv")
 
     def _fast(self, B):
-        return self.precision == "bf16" and B <= 64 and self.num_classes % 8 == 0
+        return self._half and B <= 64 and self.num_classes % 8 == 0
 
     def _build_copies(self, need_t, fast):
         cpo = self._copies
         if cpo is not None and cpo["v"] == self._version and (cpo["t"] or not need_t) and (cpo["fc"] or fast):
             return cpo
-        lib, st = L.lib(), _st()
-        dt, dc = self._dt(), (L.BF16 if self.precision == "bf16" else L.F32)
+        lib, st = self._lib(), _st()
+        dt, dc = self._dt(), (L.BF16 if self._half else L.F32)
         cp = {"v": self._version, "t": need_t, "fc": not fast}
         jobs = (L.SpnPackJob * 12)()
         nj = 0
@@ -280,7 +303,7 @@ class SpacecraftPoseNet(nn.Module):
         a.accT, a.src, a.bias, a.H, a.Y, a.YT, a.mask, a.db = (_p(accT).value, _p(src).value, _p(bias).value, _p(H).value, _p(Y).value,
                                                                 _p(YT).value, _p(mask).value, _p(db).value)
         a.M, a.F, a.mode, a.relu, a.p, a.scale, a.seed, a.mask_given = B, F, mode, relu, p, scale, seed, given
-        L.check(L.lib().spb_fc_epilogue(C.byref(a), _st()), "spb_fc_epilogue")
+        L.check(self._lib().spb_fc_epilogue(C.byref(a), _st()), "spb_fc_epilogue")
 
     def _acc(self, key, F, MP):
         """zero-initialised feature-major f32 accumulator; the epilogue kernels hand it back zeroed"""
@@ -291,9 +314,9 @@ class SpacecraftPoseNet(nn.Module):
         return t
 
     def _trunk(self, x, cp, sv):
-        lib, st = L.lib(), _st()
+        lib, st = self._lib(), _st()
         B, _, H, W = x.shape
-        dt, dc = self._dt(), (L.BF16 if self.precision == "bf16" else L.F32)
+        dt, dc = self._dt(), (L.BF16 if self._half else L.F32)
         x = x.contiguous().float()
         cur, Hc, Wc, Cc = None, H, W, 3
         for li, (name, cout, cin, g, k, stride, pad) in enumerate(_CONVS):
@@ -342,13 +365,13 @@ class SpacecraftPoseNet(nn.Module):
         return self.dropout_seed * 1000003 + self._step * 16 + hi * 4 + (1 if second else 0)
 
     def _forward_impl(self, x, training, masks=None):
-        lib = L.lib()
+        lib = self._lib()
         if not x.is_cuda:
             raise RuntimeError("SpacecraftPoseNet runs on the MI355X only (no CPU path)")
         self._ensure_arena()
         B = x.shape[0]
         fast = self._fast(B)
-        dt, dc = self._dt(), (L.BF16 if self.precision == "bf16" else L.F32)
+        dt, dc = self._dt(), (L.BF16 if self._half else L.F32)
         cp = self._build_copies(need_t=training, fast=fast)
         st = _st()
         sv = {"B": B, "fast": fast}
@@ -652,17 +675,22 @@ class SpacecraftPoseNet(nn.Module):
         and the gather only has to land before the next forward reaches fc6.  The f32 master copy of a slice lives on its owner
         only; sync_sharded_params() (collective; state_dict() / flat_parameters() call it) gathers the masters.  The convolution
         parameters (2 % of the arena) stay replicated and all-reduced."""
+        if self.precision == "fp16":
+            # GradScaler.step() is all or nothing: every gradient must exist (and be checked for inf / nan) before any parameter
+            # moves, so the heads' early update and the sharded exchange are off; SpnOptimizer.step() does check + update
+            optimizer, sharded = None, False
+            compress_bf16 = False          # scaled float16-range gradients travel as float32
         if sharded and (world_size <= 1 or optimizer is None):
             sharded = False
         self._sharded = bool(sharded)
-        lib = L.lib()
-        dt, dc = self._dt(), (L.BF16 if self.precision == "bf16" else L.F32)
+        lib = self._lib()
+        dt, dc = self._dt(), (L.BF16 if self._half else L.F32)
         c, r = self._forward_impl(x, True, masks)
         self._step += 1
         self._ddp_finished = False       # SpnOptimizer.step(world_size > 1) exchanges whatever has not been exchanged yet
         self._ddp_works = []
         if compress_bf16 is None:
-            compress_bf16 = self.precision == "bf16"
+            compress_bf16 = self.precision == "bf16"     # (float16 gradients carry the loss scale: they travel as float32)
         head2_lo = self._offs["fc9.weight"][0]
         sv, cp = self._saved, self._copies
         B, fast = sv["B"], sv["fast"]
@@ -691,7 +719,11 @@ class SpacecraftPoseNet(nn.Module):
                 st = _st()
                 acc = self._acc("acc%d" % hi, max(4096, NC), MP)
                 pend = []
-                L.check(lib.spb_softce(dc, _p(lg), _p(tgt_), _p(g), _p(out), slot, B, NC, wgt, st), "spb_softce")
+                if self.precision == "fp16":   # scaler.scale(loss).backward(): the gradient carries the loss scale, the loss does not
+                    L.check(lib.spb_softce_scaled(dc, _p(lg), _p(tgt_), _p(g), _p(out), slot, B, NC, wgt,
+                                                  _p(self.amp_state()[L.AMP_SCALE:L.AMP_SCALE + 1]), st), "spb_softce_scaled")
+                else:
+                    L.check(lib.spb_softce(dc, _p(lg), _p(tgt_), _p(g), _p(out), slot, B, NC, wgt, st), "spb_softce")
                 a, b_, c_ = names
                 gT = self._buf("gT" + c_, (NC, MP), dt)
                 self._epi(B, NC, 1, src=g, YT=gT, db=getattr(self, c_).bias.grad)

@@ -7,7 +7,12 @@ import torch
 
 from . import _lib as L
 
-_DT = {torch.float32: L.F32, torch.bfloat16: L.BF16}
+_DT = {torch.float32: L.F32, torch.bfloat16: L.BF16, torch.float16: L.BF16}   # float16: the same 16-bit code, served by the IEEE-half twin library
+
+
+def lib_of(t):
+    """the library that understands tensor t's 16-bit format: libspb_hip_f16.so for float16, libspb_hip.so otherwise"""
+    return L.lib_f16() if (t is not None and t.dtype == torch.float16) else L.lib()
 
 
 def _ptr(t):
@@ -39,7 +44,7 @@ def dtype_code(t):
     try:
         return _DT[t.dtype]
     except KeyError:
-        raise RuntimeError("activation dtype must be float32 or bfloat16, got %s" % t.dtype)
+        raise RuntimeError("activation dtype must be float32, bfloat16 or float16, got %s" % t.dtype)
 
 
 def bnref(C_, sums=None, gamma=None, beta=None, bsums=None, n=1, R=1, act=L.ACT_NONE, slope=0.0, eps=1e-5, moments=0):
@@ -64,7 +69,7 @@ def pwconv_gemm(A, Bw, Y, pro, pro_mode, epi_mode, A2=None, res=None, Zout=None,
     g.lda = A.stride(0) if A.stride(0) != A.shape[1] else 0     # column slabs of wider matrices (grouped convolutions)
     g.ldc = Y.stride(0) if Y.stride(0) != Y.shape[1] else 0
     g.pro_mode = pro_mode; g.epi_mode = epi_mode; g.out_act = out_act; g.oR = oR; g.out_scale = out_scale
-    L.check(L.lib().spb_pwconv_gemm(dtype_code(A), C.byref(g), _stream()), "spb_pwconv_gemm")
+    L.check(lib_of(A).spb_pwconv_gemm(dtype_code(A), C.byref(g), _stream()), "spb_pwconv_gemm")
 
 
 def pwconv_wgrad(G, X, dW, pro_dz, pro_a, Zn=None):
@@ -75,7 +80,7 @@ def pwconv_wgrad(G, X, dW, pro_dz, pro_a, Zn=None):
     w.M = G.shape[0]; w.N = G.shape[1]; w.K = X.shape[1]
     w.ldg = G.stride(0) if G.stride(0) != G.shape[1] else 0
     w.ldx = X.stride(0) if X.stride(0) != X.shape[1] else 0
-    L.check(L.lib().spb_pwconv_wgrad(dtype_code(G), C.byref(w), _stream()), "spb_pwconv_wgrad")
+    L.check(lib_of(G).spb_pwconv_wgrad(dtype_code(G), C.byref(w), _stream()), "spb_pwconv_wgrad")
 
 
 def pwconv_bwd_fused(G, Zn, Wt, X, Zout, Y, dW, osums, pro_dz, pro_a, epi, res=None, oR=1):
@@ -236,13 +241,16 @@ OPT_KIND = {"sgd": 0, "rmsprop": 1, "adam": 2, "adamw": 3}
 
 def optim_step(kind, params, grads, m=None, v=None, sqnorm=None, gmul=None, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8,
                weight_decay=0.0, max_norm=0.0, clip_value=0.0, step=1, first_step=False, hyper=None, shadow=None, max_blocks=0,
-               sq_partials=None):
+               sq_partials=None, skip=None):
     a = _optim_args(kind, params, grads, m, v, sqnorm, gmul, lr, beta1, beta2, eps, weight_decay, max_norm, clip_value, step, first_step,
                     hyper, shadow, max_blocks)
     if sq_partials is not None:
         _need_cuda(sq_partials)
         a.sq_partials = _ptr(sq_partials); a.n_sq_partials = SQ_PARTS
-    L.check(L.lib().spb_optim_step(C.byref(a), _stream()), "spb_optim_step")
+    if skip is not None:
+        _need_cuda(skip)
+        a.skip = _ptr(skip)
+    L.check(lib_of(shadow).spb_optim_step(C.byref(a), _stream()), "spb_optim_step")   # a float16 shadow: the half twin writes it
 
 
 def _optim_args(kind, params, grads, m, v, sqnorm, gmul, lr, beta1, beta2, eps, weight_decay, max_norm, clip_value, step, first_step,
@@ -264,7 +272,7 @@ def fc_wgrad_update(gT, xT, M, kind, params, grads=None, m=None, v=None, gmul=No
     N, K = params.shape
     a = _optim_args(kind, params, grads, m, v, None, gmul, lr, beta1, beta2, eps, weight_decay, 0.0, clip_value, step, first_step, None,
                     shadow, 0)
-    L.check(L.lib().spb_fc_wgrad_update(_ptr(gT), _ptr(xT), M, N, K, C.byref(a), _stream()), "spb_fc_wgrad_update")
+    L.check(lib_of(gT).spb_fc_wgrad_update(_ptr(gT), _ptr(xT), M, N, K, C.byref(a), _stream()), "spb_fc_wgrad_update")
 
 
 def debug_trread(inp, out):

@@ -220,12 +220,46 @@ class SpnOptimizer(torch.optim.Optimizer):
         o, n = mdl._offs[name + ".bias"]
         self.update_range_early(o, o + (n + 7) // 8 * 8)
 
+    # GradScaler defaults (torch.cuda.amp.GradScaler(): init_scale 2**16 lives in the model's AMP state)
+    amp_growth, amp_backoff, amp_interval = 2.0, 0.5, 2000
+
+    def _step_fp16(self, world_size, group):
+        """fp16: unscale, inf / nan check, clip, update and GradScaler.update() of trainer.py:175-181, all on the device: the
+        optimizer pass multiplies every gradient by 1/scale before the clamp and does nothing at all when the check found a
+        non-finite value; the scale halves then, and doubles after amp_interval clean steps in a row."""
+        from . import ops
+        from . import _lib as L
+        import ctypes as C
+        mdl = self._model
+        flat, gflat = mdl._flat, mdl._gflat
+        self._t += 1                                  # host-side count of step() calls; the bias corrections use the device count
+        if world_size > 1:
+            mdl.finish_gradient_exchange(group)
+        mdl.finish_early_updates()
+        st = mdl.amp_state()
+        g = self.param_groups[0]
+        b1, b2 = self._betas(g["kind"], g["momentum"])
+        lib = L.lib_f16()
+        stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        L.check(lib.spb_amp_check(C.c_void_p(gflat.data_ptr()), gflat.numel(), C.c_void_p(st.data_ptr()), stream), "spb_amp_check")
+        L.check(lib.spb_amp_step(C.c_void_p(st.data_ptr()), float(g["lr"]), float(b1), float(b2), float(self.amp_growth),
+                                 float(self.amp_backoff), int(self.amp_interval), stream), "spb_amp_step")
+        gm = st[L.AMP_INV_SCALE:L.AMP_INV_SCALE + 1]
+        if world_size > 1:                            # data-parallel mean on top of the unscale factor
+            gm = gm / float(world_size)
+        ops.optim_step(g["kind"], flat, gflat, m=self._m, v=self._v, gmul=gm, lr=g["lr"], beta1=b1, beta2=b2, eps=1e-8,
+                       weight_decay=g["weight_decay"], max_norm=0.0, clip_value=self.clip_value, step=max(self._t, 1),
+                       first_step=False, hyper=st[L.AMP_LR:L.AMP_LR + 3], shadow=mdl._shadow, skip=st[L.AMP_SKIP:L.AMP_SKIP + 1])
+        mdl.optimizer_updated()
+
     @torch.no_grad()
     def step(self, closure=None, world_size=1, group=None):
         mdl = self._model
         mdl._ensure_arena()
         flat = mdl._flat          # not flat_parameters(): that would wait for the heads' update still in flight
         self._state(flat)
+        if getattr(mdl, "precision", None) == "fp16":
+            return self._step_fp16(world_size, group)
         early, self._early = sorted(self._early), []
         if not early:
             self._t += 1

@@ -40,7 +40,7 @@ def test_train_spn_with_use_fp16_flag_warns_and_resumes(device, tmp_path):
     common = ["--model_name", "spn", "--num_classes", 64, "--batch_size", 4, "--synthetic_batches", 2, "--optimizer", "adamw", "--savedir",
               tmp_path / "save", "--logdir", tmp_path / "log", "--use_fp16"]
     out = run("train.py", *common, "--max_epochs", 1)
-    assert "bfloat16" in out and "loss_c" in out                             # the documented substitution is announced
+    assert "float16 with device-side dynamic loss scaling" in out and "loss_c" in out   # --use_fp16: real fp16 + GradScaler arithmetic for SPN
     out = run("train.py", *common, "--max_epochs", 2)                        # resume with the model still on the CPU
     assert "Checkpoint loaded" in out
     ck = torch.load(tmp_path / "save" / "checkpoint.pth.tar", map_location="cpu")
