@@ -27,7 +27,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
-MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}
+MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp16": 2500.0, "fp32": 157.3}
 
 
 def _host():
@@ -75,7 +75,8 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=48, help="images per GPU (README recipe: 48)")
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32", "fp16"],
+                    help="fp16 (IEEE half + device-side dynamic loss scaling) exists for --model spn only: BASELINE configs[5]")
     ap.add_argument("--graph", action="store_true", help="replay a captured hipGraph instead of enqueuing the launches "
                     "eagerly (eager + side-stream weight gradients is the faster, default mode)")
     ap.add_argument("--no-graph", action="store_true", help=argparse.SUPPRESS)  # old spelling of the default
@@ -89,6 +90,8 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=32)
     args = ap.parse_args()
 
+    if args.precision == "fp16" and args.model != "spn":
+        raise SystemExit("--precision fp16 exists for --model spn only (KRN / RevGrad: bf16 with f32 accumulation, DESIGN.md a13)")
     if args.model == "spn":
         return bench_spn(args)
     if args.model == "dann":
@@ -578,10 +581,11 @@ def bench_spn(args):
             evs.append((e0, e1))
         torch.cuda.synchronize()
         us = sum(a.elapsed_time(b) for a, b in evs) / len(evs) * 1e3
-        by = n * (28 + (2 if args.precision == "bf16" else 0))
+        by = n * (28 + (2 if args.precision in ("bf16", "fp16") else 0)) + (4 * n if args.precision == "fp16" else 0)   # fp16: + the inf / nan check's read of g
         ach = by / (us * 1e-6) / 1e9
         traffic, traffic_src = _pmc_traffic("optim_step_full", ("r2_spn_pmc_traffic.json",)) if (B == 32 and NC == 5000) else (None, None)
-        roofline = dict(bound="hbm", kernel="optim_step (clip_grad_value + AdamW + bf16 shadow)", achieved=round(ach, 1), peak=HBM_PEAK_GBS,
+        roofline = dict(bound="hbm", kernel="optim_step (clip_grad_value + AdamW + bf16 shadow)" if args.precision != "fp16" else
+                        "amp_check + amp_step + optim_step (inf/nan check, unscale, clip_grad_value, AdamW, float16 shadow)", achieved=round(ach, 1), peak=HBM_PEAK_GBS,
                         unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4), traffic=traffic, traffic_source=traffic_src, launches_per_step=1,
                         avg_launch_us=round(us, 1), alg_bytes_per_launch=by,
                         note="timed alone as one arena-wide launch; in the step it runs as two launches (convolution range, heads) and the "
