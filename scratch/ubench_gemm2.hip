@@ -14,11 +14,13 @@ __device__ unsigned long long* g_ts;
 #include "../speedplusbaseline_amd/csrc/gemm_sk.hip"
 #include "../speedplusbaseline_amd/csrc/gemm_os.hip"
 #include "../speedplusbaseline_amd/csrc/gemm_big.hip"
+#include "../speedplusbaseline_amd/csrc/gemm_rs.hip"
 extern "C" int spb_partial_reduce(const spb_red_job_t*, int, spb_stream_t) { return 0; }   // not exercised here
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("err %s line %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
 int main() {
   if (getenv("OS")) spb_debug_set_gemm_os(atoi(getenv("OS")), 0, 0, 0);
   if (getenv("BIG")) spb_debug_set_gemm_big(atoi(getenv("BIG")), 0, 0);
+  if (getenv("RS")) spb_debug_set_gemm_rs(atoi(getenv("RS")), 0);
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   struct Sh { int M, K, N, n; } fwd[] = {
     {37632, 32, 192, 3}, {37632, 192, 32, 2}, {9408, 192, 64, 1}, {9408, 64, 384, 4}, {9408, 384, 64, 3}, {9408, 384, 96, 1},

@@ -242,6 +242,7 @@ SYMBOLS = {
     "spb_debug_set_gemm_bk64_min_k": (i32, [i32]),
     "spb_debug_set_gemm_wide_min_n": (i32, [i32]),
     "spb_debug_set_gemm_big": (i32, [i32, i32, i32]),
+    "spb_debug_set_gemm_rs": (i32, [i32, i32]),
     "spb_debug_set_gemm_wg_cap": (i32, [i32]),
     "spb_debug_set_bn_bwd_prep_rows": (i32, [i32]),
     "spb_debug_set_stem_mfma": (i32, [i32]),

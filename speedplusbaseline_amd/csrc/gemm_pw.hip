@@ -31,6 +31,11 @@ int spb_gemm_sk(const spb_gemm_args_t* a, hipStream_t stream);   // gemm_sk.hip
 int spb_gemm_os(const spb_gemm_args_t* a, hipStream_t stream);   // gemm_os.hip
 int spb_gemm_big(const spb_gemm_args_t* a, hipStream_t stream);  // gemm_big.hip
 #endif
+#ifdef SPB_F16
+static int spb_gemm_rs(const spb_gemm_args_t*, hipStream_t) { return SPB_E_UNSUPPORTED; }
+#else
+int spb_gemm_rs(const spb_gemm_args_t* a, hipStream_t stream);   // gemm_rs.hip
+#endif
 
 // phase timestamps for scratch/ubench_gemm.hip (compiled out in the product build)
 #ifndef SPB_TS
@@ -906,6 +911,9 @@ extern "C" int spb_pwconv_gemm(int dtype, const spb_gemm_args_t* a, spb_stream_t
   if (a->epi_mode == 2 && !a->Zout) return SPB_E_ARG;
   if (a->pro_mode == 3 && (!a->A2 || !a->Ymat || a->pro.act != SPB_ACT_NONE || a->pro2.act != SPB_ACT_NONE)) return SPB_E_ARG;
   if (dtype == SPB_BF16) {
+    // 28x28 / 14x14 maps, short reduction, wide output (expand forwards, project input gradients): the row-slab kernel (gemm_rs.hip)
+    const int er = spb_gemm_rs(a, (hipStream_t)stream);
+    if (er != SPB_E_UNSUPPORTED) return er;
     // the 7x7 maps, wide output behind a long reduction (ConvDw extras, domain classifier): 128 x 128 tiles (gemm_big.hip)
     const int eb = spb_gemm_big(a, (hipStream_t)stream);
     if (eb != SPB_E_UNSUPPORTED) return eb;

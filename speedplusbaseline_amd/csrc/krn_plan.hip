@@ -258,10 +258,14 @@ extern "C" int spb_debug_set_wgrad_batch(int n) {
   return 0;
 }
 static long long g_replica_min_rows = 32768;   // BN-sum replicas (8) from this many rows up; spb_debug_set_replica_rows
-static int g_replica_mid = 1;   // replicas for tensors with 4096 <= rows < g_replica_min_rows (the 14x14 maps at bs=48).  Measured with 8
-                                // (round 2, all replica loads of a channel in flight together): producers -1 us (their atomics
-                                // spread over 8 addresses), every consumer +2 us (16 instead of 2 loads per channel): stays 1
+static int g_replica_mid = 4;   // replicas for tensors with g_replica_mid_rows <= rows < g_replica_min_rows (the 14x14 maps at bs=48).  Round 2 (tiled
+                                // kernels only): 8 replicas = producers -1 us, consumers +2 us, net zero -> 1.  Round 3: the row-slab GEMM (gemm_rs.hip)
+                                // has 294 workgroups per channel address instead of 147 and same-address f32 atomics serialise at ~25 ns: with one
+                                // replica its launches end 6 us after their last store (3.100 ms per step); 2 -> 3.061, 3 -> 3.037, 4 -> 3.027,
+                                // 6 -> 3.029, 8 -> 3.033 (without the row-slab kernel the replica count changes nothing: 3.062)
+static long long g_replica_mid_rows = 4096;
 extern "C" int spb_debug_set_replica_rows(long long rows) {
+  if (rows < -100) { g_replica_mid_rows = -rows; return 0; }   // below -100: the row count from which the mid-size replica count applies
   if (rows < 0) { g_replica_mid = (int)(-rows > SPB_MAX_REPLICAS ? SPB_MAX_REPLICAS : -rows); return 0; }   // negative: set the mid-size replica count instead
   g_replica_min_rows = rows;
   return 0;
@@ -742,7 +746,7 @@ static void layout_ctx(const spb_krn* m, int B, int dtype, spb_krn_ctx* c, size_
   for (int a = 0; a < nA; ++a) {
     const ActDef& d = m->acts[a];
     const long long Mrows = (long long)B * d.H * d.W;
-    Rv[a] = Mrows >= g_replica_min_rows ? 8 : (Mrows >= 4096 ? g_replica_mid : 1);
+    Rv[a] = Mrows >= g_replica_min_rows ? 8 : (Mrows >= g_replica_mid_rows ? g_replica_mid : 1);
     so[a] = sf; sf += (size_t)Rv[a] * 2 * d.C;
     bo[a] = sf; sf += (size_t)Rv[a] * 2 * d.C;
   }

@@ -58,7 +58,7 @@ def bnref(C_, sums=None, gamma=None, beta=None, bsums=None, n=1, R=1, act=L.ACT_
 
 
 def pwconv_gemm(A, Bw, Y, pro, pro_mode, epi_mode, A2=None, res=None, Zout=None, bias=None, osums=None, epi=None,
-                out_act=L.ACT_NONE, oR=1, out_scale=1.0):
+                out_act=L.ACT_NONE, oR=1, out_scale=1.0, pro2=None, Ymat=None):
     _need_rows(A, Y)
     _need_cuda(Bw, A2, res, Zout, bias, osums)
     g = L.GemmArgs()
@@ -69,6 +69,9 @@ def pwconv_gemm(A, Bw, Y, pro, pro_mode, epi_mode, A2=None, res=None, Zout=None,
     g.lda = A.stride(0) if A.stride(0) != A.shape[1] else 0     # column slabs of wider matrices (grouped convolutions)
     g.ldc = Y.stride(0) if Y.stride(0) != Y.shape[1] else 0
     g.pro_mode = pro_mode; g.epi_mode = epi_mode; g.out_act = out_act; g.oR = oR; g.out_scale = out_scale
+    if pro_mode == 3:       # residual join: a = bn(A) + bn2(A2), written to Ymat by the launch
+        _need_cuda(Ymat)
+        g.pro2 = pro2 if pro2 is not None else bnref(A.shape[1]); g.Ymat = _ptr(Ymat)
     L.check(lib_of(A).spb_pwconv_gemm(dtype_code(A), C.byref(g), _stream()), "spb_pwconv_gemm")
 
 

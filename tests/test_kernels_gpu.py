@@ -81,11 +81,13 @@ def gemm_variant(request):
     L.lib().spb_debug_set_gemm_sk(0 if request.param != "default" else 1, 0, 0)
     L.lib().spb_debug_set_gemm_os(0 if request.param != "default" else 1, 0, 0, 0)
     L.lib().spb_debug_set_gemm_big(0 if request.param != "default" else 1, 0, 0)
+    L.lib().spb_debug_set_gemm_rs(0 if request.param != "default" else 1, 0)
     yield request.param
     L.lib().spb_debug_set_gemm_dma(0)
     L.lib().spb_debug_set_gemm_sk(1, 0, 0)
     L.lib().spb_debug_set_gemm_os(1, 0, 0, 0)
     L.lib().spb_debug_set_gemm_big(1, 0, 0)
+    L.lib().spb_debug_set_gemm_rs(1, 0)
 
 
 @pytest.fixture(params=["auto", "rows"])
@@ -252,6 +254,71 @@ def test_pw_bwd_fused(device, M, K, N, act1, act2, with_res, mat):
     s = osums.double().cpu().sum(0)
     assert relerr(s[0], gs.sum(0)) < 1e-3 and relerr(s[1], (gs * c["xh1"].detach()).sum(0)) < 2e-3
     assert relerr(dW, c["W"].grad) < tol * (4 if mat else 1)   # materialised a is itself rounded to bf16
+
+
+@pytest.mark.parametrize("rs", [1, 0])
+@pytest.mark.parametrize("M,K,N", [(9408, 64, 384), (9408, 96, 576), (37632, 32, 192), (4100, 96, 384), (4099, 64, 192), (300, 24, 144)])
+def test_pw_gemm_row_slab_forward_and_residual_join(device, rs, M, K, N):
+    """expand convolutions of the 28x28 / 14x14 maps (short reduction, wide output): the row-slab kernel (gemm_rs.hip) and the tiled kernel,
+    plain prologue and the residual join of pro_mode 3 (a = bn(A) + bn2(A2); the launch also writes the joined block output)"""
+    dt = torch.bfloat16
+    L.lib().spb_debug_set_gemm_rs(rs, 0)
+    try:
+        torch.manual_seed(M + N)
+        zin = rt(torch.randn(M, K, dtype=torch.float64) * 1.5 + 0.3, dt)
+        res = rt(torch.randn(M, K, dtype=torch.float64), dt)
+        gamma = torch.rand(K, dtype=torch.float64) + 0.5; beta = torch.randn(K, dtype=torch.float64) * 0.3
+        W = rt(torch.randn(N, K, dtype=torch.float64) / math.sqrt(K), dt)
+        u, _ = bn_train(zin, gamma, beta)
+        for join in (False, True):
+            act = L.ACT_NONE if join else L.ACT_RELU6
+            a = rt(u + res, dt) if join else act_fn(u, act)        # the joined operand is what the launch materialises (rounded)
+            y = a @ W.t()
+            pro = ops.bnref(K, sums=sums_of(zin, 2, device), gamma=gamma.float().to(device), beta=beta.float().to(device), n=M, R=2, act=act)
+            Y = torch.empty(M, N, dtype=dt, device=device)
+            osums = torch.zeros(4, 2, N, dtype=torch.float32, device=device)
+            if join:
+                Ym = torch.zeros(M, K, dtype=dt, device=device)
+                ops.pwconv_gemm(zin.to(dt).to(device), W.to(dt).to(device), Y, pro, 3, 1, A2=res.to(dt).to(device), osums=osums, oR=4, Ymat=Ym)
+            else:
+                ops.pwconv_gemm(zin.to(dt).to(device), W.to(dt).to(device), Y, pro, 1, 1, osums=osums, oR=4)
+            torch.cuda.synchronize()
+            assert relerr(Y, y) < TOL[dt], (join, relerr(Y, y))
+            ys = Y.double().cpu(); s = osums.double().cpu().sum(0)
+            assert relerr(s[0], ys.sum(0)) < 1e-4 and relerr(s[1], (ys * ys).sum(0)) < 1e-4
+            if join:
+                assert relerr(Ym, u + res) < TOL[dt]
+    finally:
+        L.lib().spb_debug_set_gemm_rs(1, 0)
+
+
+@pytest.mark.parametrize("M,K,N", [(9408, 384, 64), (9408, 576, 96), (37632, 192, 32), (4100, 384, 96), (9408, 192, 64)])
+def test_pw_gemm_row_slab_input_gradient(device, M, K, N):
+    """project convolutions of the 28x28 / 14x14 maps, input gradient without a residual (what the KRN plan launches): the row-slab
+    kernel against float64 autograd and against the tiled kernel (same element arithmetic up to the order of the MFMA reduction)"""
+    dt = torch.bfloat16
+    c = _composite(M, K, N, L.ACT_RELU6, L.ACT_NONE, dt, seed=M * 3 + N)
+    dev = device
+    g2 = rt(c["u2"].grad, dt)
+    bs = torch.stack([g2.sum(0), (g2 * c["xh2"].detach()).sum(0)]).float().unsqueeze(0).contiguous().to(dev)
+    pro = ops.bnref(N, sums=sums_of(c["z"], 1, dev), gamma=c["g2"].detach().float().to(dev), beta=c["b2"].detach().float().to(dev),
+                    bsums=bs, n=M, act=L.ACT_NONE)
+    epi = ops.bnref(K, sums=sums_of(c["zin"].detach(), 2, dev), gamma=c["g1"].float().to(dev), beta=c["b1"].float().to(dev), n=M, R=2, act=L.ACT_RELU6)
+    Wt = c["W"].detach().t().contiguous().to(dt).to(dev)
+    outs = []
+    for rs in (1, 0):
+        L.lib().spb_debug_set_gemm_rs(rs, 0)
+        G1 = torch.empty(M, K, dtype=dt, device=dev)
+        osums = torch.zeros(2, 2, K, dtype=torch.float32, device=dev)
+        ops.pwconv_gemm(g2.to(dt).to(dev), Wt, G1, pro, 2, 2, A2=c["z"].to(dt).to(dev), Zout=c["zin"].detach().to(dt).to(dev), osums=osums, epi=epi, oR=2)
+        torch.cuda.synchronize()
+        outs.append((G1, osums.sum(0)))
+    L.lib().spb_debug_set_gemm_rs(1, 0)
+    G1, sm = outs[0]
+    assert relerr(G1, c["u1"].grad) < TOL[dt] * 3
+    assert relerr(G1, outs[1][0]) < 2e-3                                   # vs the tiled kernel: reduction order only
+    gs = G1.double().cpu(); sm = sm.double().cpu()
+    assert relerr(sm[0], gs.sum(0)) < 1e-3 and relerr(sm[1], (gs * c["xh1"].detach()).sum(0)) < 1e-3
 
 
 @pytest.mark.parametrize("dt", DTYPES)
