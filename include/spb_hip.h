@@ -596,6 +596,7 @@ int spb_debug_set_gemm_dma(int on); /* 1: small-M bf16 pointwise GEMMs use the L
 int spb_debug_set_dw_mode(int mode); /* depthwise fwd/dgrad: 1 plane kernels on maps up to spb_debug_set_dw_plane_max_w columns wide (14x14 and 7x7 by default), row-unit kernels elsewhere (default); 0 row-unit kernels only */
 int spb_debug_set_fused_pw_bwd(int on); /* 0: the KRN plan never uses spb_pwconv_bwd_fused */
 int spb_debug_set_stem_mfma(int on); /* 0: bf16 stem uses the scalar kernels instead of the MFMA implicit GEMM */
+int spb_debug_set_softce_split(int min_classes); /* spb_softce / _scaled: rows of at least this many classes (default 2048) use the class-split pair of launches (8 workgroups per row) */
 int spb_debug_set_gemm_rs(int on, int min_m); /* bf16 GEMMs with K <= 96, N = 192 | 384 | 576, M >= min_m (4096): one-round-trip row-slab kernel (on=1, default) */
 int spb_debug_set_gemm_big(int on, int min_n, int min_k); /* small-M bf16 GEMMs with N >= min_n (512), K >= min_k (256): 128 x 128 tile kernel (on=1, default) */
 int spb_debug_set_bn_bwd_prep_rows(int on); /* spb_bn_bwd_prep: row-parallel kernel (1, default) or the walking kernel (0) */

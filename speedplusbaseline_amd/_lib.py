@@ -199,6 +199,7 @@ SYMBOLS = {
     "spb_relu_bwd": (i32, [i32, vp, vp, vp, vp, i64, f32, vp]),
     "spb_dropout": (i32, [i32, vp, vp, i64, f32, C.c_ulonglong, i32, vp]),
     "spb_softce": (i32, [i32, vp, vp, vp, vp, i32, i32, i32, f32, vp]),
+    "spb_debug_set_softce_split": (i32, [i32]),
     "spb_softce_scaled": (i32, [i32, vp, vp, vp, vp, i32, i32, i32, f32, vp, vp]),
     "spb_amp_check": (i32, [vp, i64, vp, vp]),
     "spb_amp_step": (i32, [vp, f32, f32, f32, f32, f32, i32, vp]),

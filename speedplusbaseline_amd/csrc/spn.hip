@@ -324,6 +324,81 @@ __global__ __launch_bounds__(256) void softce_kernel(const T* __restrict__ logit
   }
 }
 
+// Class-split form of softce_kernel for wide rows (5000 classes: one workgroup per row walked the row three times, 31 us on 32
+// workgroups).  Stage 1: grid (B, SCE_S), each workgroup reduces ITS class range of the row to (max, sum exp(x - max), sum t, sum t*x) in
+// `part` [B][SCE_S][4].  Stage 2: grid (B, SCE_S), every workgroup recombines the SCE_S partials of its row in the same fixed order (so all
+// of them get the identical log-sum-exp), workgroup (b, 0) adds the row's loss, and each writes the gradient of its class range.
+constexpr int SCE_S = 8;
+template <typename T>
+__device__ __forceinline__ float sce_block_reduce(float v, float* red, int t, bool is_max) {
+  red[t] = v; __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) { if (t < s) red[t] = is_max ? fmaxf(red[t], red[t + s]) : red[t] + red[t + s]; __syncthreads(); }
+  const float r = red[0]; __syncthreads();
+  return r;
+}
+template <typename T>
+__global__ __launch_bounds__(256) void softce_part_kernel(const T* __restrict__ logits, const float* __restrict__ target, float* __restrict__ part, int Cn) {
+  __shared__ float red[256];
+  const int b = blockIdx.x, sp = blockIdx.y, t = threadIdx.x;
+  const int per = (Cn + SCE_S - 1) / SCE_S, c0 = sp * per, c1 = min(Cn, c0 + per);
+  const T* x = logits + (size_t)b * Cn;
+  const float* tg = target + (size_t)b * Cn;
+  float m = -3.0e38f;
+  for (int c = c0 + t; c < c1; c += 256) m = fmaxf(m, ldf<T>(x + c));
+  m = sce_block_reduce<T>(m, red, t, true);
+  float se = 0.f, st = 0.f, sx = 0.f;
+  for (int c = c0 + t; c < c1; c += 256) { const float v = ldf<T>(x + c); se += expf(v - m); st += tg[c]; sx += tg[c] * v; }
+  se = sce_block_reduce<T>(se, red, t, false);
+  st = sce_block_reduce<T>(st, red, t, false);
+  sx = sce_block_reduce<T>(sx, red, t, false);
+  if (t == 0) {
+    float* p = part + ((size_t)b * SCE_S + sp) * 4;
+    p[0] = m; p[1] = se; p[2] = st; p[3] = sx;
+  }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void softce_fin_kernel(const T* __restrict__ logits, const float* __restrict__ target, T* __restrict__ dlogits,
+                                                         float* out, int slot, int Bn, int Cn, float weight, float* rows,
+                                                         const float* __restrict__ part, const float* gscale) {
+  const int b = blockIdx.x, sp = blockIdx.y, t = threadIdx.x;
+  const float* p = part + (size_t)b * SCE_S * 4;
+  float m = -3.0e38f;
+#pragma unroll
+  for (int i = 0; i < SCE_S; ++i) m = fmaxf(m, p[i * 4]);
+  float se = 0.f, st = 0.f, sx = 0.f;
+#pragma unroll
+  for (int i = 0; i < SCE_S; ++i) { se += p[i * 4 + 1] * expf(p[i * 4] - m); st += p[i * 4 + 2]; sx += p[i * 4 + 3]; }
+  const float lse = m + logf(se);
+  if (sp == 0 && t == 0) {
+    const float l = (lse * st - sx) / (float)Bn;
+    if (out) { atomicAdd(out, weight * l); atomicAdd(out + slot, l); }
+    if (rows) rows[b] = lse * st - sx;
+  }
+  if (dlogits) {
+    const int per = (Cn + SCE_S - 1) / SCE_S, c0 = sp * per, c1 = min(Cn, c0 + per);
+    const T* x = logits + (size_t)b * Cn;
+    const float* tg = target + (size_t)b * Cn;
+    const float gs = weight / (float)Bn * (gscale ? *gscale : 1.f);
+    for (int c = c0 + t; c < c1; c += 256) stf<T>(dlogits + (size_t)b * Cn + c, (expf(ldf<T>(x + c) - lse) * st - tg[c]) * gs);
+  }
+}
+// rows wider than this use the class-split pair of launches (library-owned scratch for the partials, one row set per stream slot)
+static int g_softce_split_min_c = 2048;
+extern "C" int spb_debug_set_softce_split(int min_classes) { g_softce_split_min_c = min_classes; return 0; }
+template <typename T>
+static int softce_split(const void* logits, const float* target, void* dlogits, float* out, int slot, int B, int C, float weight, float* rows,
+                        const float* gscale, hipStream_t s) {
+  // partials: [slot 0..2][B <= 4096][SCE_S][4] floats; the slots keep the two heads (concurrent streams) and the rows form apart
+  static float* part = nullptr;
+  if (!part && hipMalloc(&part, (size_t)3 * 4096 * SCE_S * 4 * sizeof(float)) != hipSuccess) return SPB_E_STATE;
+  if (B > 4096) return SPB_E_SHAPE;
+  float* pp = part + (size_t)(slot < 0 || slot > 2 ? 0 : slot) * 4096 * SCE_S * 4;
+  hipLaunchKernelGGL(softce_part_kernel<T>, dim3(B, SCE_S), dim3(256), 0, s, (const T*)logits, target, pp, C);
+  hipLaunchKernelGGL(softce_fin_kernel<T>, dim3(B, SCE_S), dim3(256), 0, s, (const T*)logits, target, (T*)dlogits, out, slot, B, C, weight, rows,
+                     (const float*)pp, gscale);
+  return 0;
+}
+
 // out[n] += sum_m g[m][n]
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ g, float* __restrict__ out, long long M, int N,
@@ -535,6 +610,13 @@ extern "C" int spb_softce(int dtype, const void* logits, const float* target, vo
                           float weight, spb_stream_t stream) {
   if (!logits || !target || !out || B <= 0 || C <= 0 || slot < 1) return SPB_E_ARG;
   hipStream_t s = (hipStream_t)stream;
+  if (C >= g_softce_split_min_c) {
+    const int e = dtype == SPB_BF16 ? softce_split<bf16_t>(logits, target, dlogits, out, slot, B, C, weight, nullptr, nullptr, s)
+                : dtype == SPB_F32 ? softce_split<float>(logits, target, dlogits, out, slot, B, C, weight, nullptr, nullptr, s) : SPB_E_ARG;
+    if (e) return e;
+    SPB_CHECK_LAUNCH();
+    return 0;
+  }
   SPN_T(dtype, hipLaunchKernelGGL(softce_kernel<bf16_t>, dim3(B), dim3(256), 0, s, (const bf16_t*)logits, target, (bf16_t*)dlogits, out, slot, B, C, weight, (float*)nullptr),
         hipLaunchKernelGGL(softce_kernel<float>, dim3(B), dim3(256), 0, s, (const float*)logits, target, (float*)dlogits, out, slot, B, C, weight, (float*)nullptr))
   SPB_CHECK_LAUNCH();
@@ -545,6 +627,13 @@ extern "C" int spb_softce_scaled(int dtype, const void* logits, const float* tar
                                  float weight, const float* gscale, spb_stream_t stream) {
   if (!logits || !target || !out || B <= 0 || C <= 0 || slot < 1 || slot > 2) return SPB_E_ARG;
   hipStream_t s = (hipStream_t)stream;
+  if (C >= g_softce_split_min_c) {
+    const int e = dtype == SPB_BF16 ? softce_split<bf16_t>(logits, target, dlogits, out, slot, B, C, weight, nullptr, gscale, s)
+                : dtype == SPB_F32 ? softce_split<float>(logits, target, dlogits, out, slot, B, C, weight, nullptr, gscale, s) : SPB_E_ARG;
+    if (e) return e;
+    SPB_CHECK_LAUNCH();
+    return 0;
+  }
   SPN_T(dtype, hipLaunchKernelGGL(softce_kernel<bf16_t>, dim3(B), dim3(256), 0, s, (const bf16_t*)logits, target, (bf16_t*)dlogits, out, slot, B, C, weight, (float*)nullptr, gscale),
         hipLaunchKernelGGL(softce_kernel<float>, dim3(B), dim3(256), 0, s, (const float*)logits, target, (float*)dlogits, out, slot, B, C, weight, (float*)nullptr, gscale))
   SPB_CHECK_LAUNCH();
