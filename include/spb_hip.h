@@ -580,6 +580,7 @@ int spb_preproc_batch(const spb_preproc_args_t* a, spb_stream_t stream);
 int spb_debug_set_conv9_band(int on); /* decoder's last 9x9 layer: band-staged kernel (1, default) or the generic 8x8-tile kernel */
 int spb_debug_set_launch_events(int on); /* side-stream forks wait on the preceding GEMM launch's completion event (1) or on a recorded event (0) */
 int spb_debug_set_dw_split(int hw);        /* depthwise layers on maps up to `hw` columns wide run their weight gradient on the side stream (default 112: every depthwise layer; 0: always fused) */
+int spb_debug_set_domain_tail_rows(int on); /* RevGrad forward: row-parallel AvgPool2d(7) + Conv2d(1280,1,1) tail (1, default) or the walking kernel (0) */
 int spb_debug_set_join_fused(int on);      /* KRN plan: residual adds formed by the next expand convolution (1, default) or by bn_apply launches (0) */
 int spb_debug_set_wgrad_parts(int on);     /* KRN plan: weight gradients as partial sums + spb_partial_reduce (1, default) or f32 atomics (0) */
 int spb_debug_set_wgrad_min_flush(int n); /* fork at a depthwise backward kernel only when >= n weight gradients are queued */

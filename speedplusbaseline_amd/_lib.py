@@ -213,6 +213,7 @@ SYMBOLS = {
     "spb_debug_set_dw_split": (i32, [i32]),
     "spb_debug_set_wgrad_parts": (i32, [i32]),
     "spb_debug_set_join_fused": (i32, [i32]),
+    "spb_debug_set_domain_tail_rows": (i32, [i32]),
     "spb_debug_set_wgrad_min_flush": (i32, [i32]),
     "spb_debug_set_wgrad_batch": (i32, [i32]),
     "spb_debug_set_wgrad_target": (i32, [i32]),

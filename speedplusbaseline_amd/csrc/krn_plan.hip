@@ -281,6 +281,8 @@ static int g_wgrad_parts = 0;     // 1: pointwise weight gradients as partial su
                                   // (order-deterministic; measured 3.25 vs 3.18 ms per step: the slab traffic and the extra launches cost more
                                   // than the atomics they replace) -- spb_debug_set_wgrad_parts
 extern "C" int spb_debug_set_wgrad_parts(int on) { g_wgrad_parts = on; return 0; }
+static int g_domain_tail_rows = 1;   // row-parallel forward of the domain classifier's pooled tail (spb_debug_set_domain_tail_rows(0): the walking kernel)
+extern "C" int spb_debug_set_domain_tail_rows(int on) { g_domain_tail_rows = on; return 0; }
 static int g_join_fused = 1;      // residual adds folded into the next expand convolution (spb_debug_set_join_fused)
 extern "C" int spb_debug_set_join_fused(int on) { g_join_fused = on; return 0; }
 static int g_fused_pw_bwd = 1;
@@ -532,6 +534,59 @@ __global__ void domain_tail_fwd_kernel(const void* D1, int dtype, const float* w
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
   __syncthreads();
   if (threadIdx.x == 0) logits[b] = red[0] + red[1] + red[2] + red[3] + b3[0];
+}
+
+// Row-parallel form (round 3): grid (B, C / 256).  A workgroup owns 256 channels (32 lanes x 8-channel vectors) of one image and 8
+// row lanes; the 7 rows of a lane are all in flight together, the row lanes meet in LDS, and the image's logit collects one f32 atomic
+// per channel slab (logits are zeroed by the caller's memset; slab 0 adds the bias).  The kernel above walks 5 channels x 49 rows per
+// thread in dependent steps on B workgroups (named in rounds 2 and 3 as the low-parallelism launch of the DANN forward).
+template <typename T>
+__global__ __launch_bounds__(256) void domain_tail_fwd_rows_kernel(const T* __restrict__ D1, const float* __restrict__ w3, const float* __restrict__ b3,
+                                                                   float* __restrict__ pooled, float* __restrict__ logits, int HW, int C) {
+  __shared__ float red[8][257];
+  __shared__ float wred[4];
+  const int b = blockIdx.x, cb = blockIdx.y * 256, t = threadIdx.x, v = t & 31, sub = t >> 5;
+  const int c0 = cb + v * 8;
+  const bool cok = c0 < C;
+  const int cc = cok ? c0 : 0;
+  constexpr int U = 7;                                   // rows per lane: 8 x 7 = 56 >= 49
+  Raw8<T> raw[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int r = sub + 8 * u;
+    raw[u] = ldraw<T>(D1 + ((size_t)b * HW + (r < HW ? r : HW - 1)) * C + cc);
+  }
+  float a[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) a[j] = 0.f;
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    if (sub + 8 * u < HW) {
+      float d[8];
+      cvt8(raw[u], d);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) a[j] += d[j];
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) red[sub][v * 8 + j] = a[j];
+  __syncthreads();
+  float s = 0.f;
+  {
+    const int c = cb + t;
+    if (c < C) {
+      float p = 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) p += red[i][t];
+      p /= (float)HW;
+      pooled[(size_t)b * C + c] = p;
+      s = p * w3[c];
+    }
+  }
+  s = wave_sum(s);
+  if ((t & 63) == 0) wred[t >> 6] = s;
+  __syncthreads();
+  if (t == 0) atomicAdd(logits + b, wred[0] + wred[1] + wred[2] + wred[3] + (blockIdx.y == 0 ? b3[0] : 0.f));
 }
 
 // Backward of AvgPool2d(7) + Conv2d(1280,1,1) behind the ReLU of domain_classifier.0 (revgrad.py:75-80):
@@ -971,6 +1026,18 @@ extern "C" int spb_krn_forward(spb_krn_ctx_t* c, const float* x, const float* ta
     g.pro = feat.ref; g.M = c->B * 49; g.K = 320; g.N = 1280; g.pro_mode = 1; g.epi_mode = 0; g.out_act = SPB_ACT_RELU;
     g.oR = 1; g.out_scale = 1.f;
     r.ok(spb_pwconv_gemm(m->dtype, &g, stream));
+    if (g_domain_tail_rows && (49 <= 56)) {
+      if (hipMemsetAsync(domain_logits, 0, (size_t)c->B * sizeof(float), st) != hipSuccess) r.ok(SPB_E_STATE);
+      const dim3 tg((unsigned)c->B, (1280 + 255) / 256);
+      if (m->dtype == SPB_BF16)
+        hipLaunchKernelGGL(domain_tail_fwd_rows_kernel<bf16_t>, tg, dim3(256), 0, st, (const bf16_t*)(c->ws + c->dom1_off),
+                           (const float*)(m->P + m->dc3_w_off), (const float*)(m->P + m->dc3_b_off),
+                           reinterpret_cast<float*>(c->ws + c->dompool_off), domain_logits, 49, 1280);
+      else
+        hipLaunchKernelGGL(domain_tail_fwd_rows_kernel<float>, tg, dim3(256), 0, st, (const float*)(c->ws + c->dom1_off),
+                           (const float*)(m->P + m->dc3_w_off), (const float*)(m->P + m->dc3_b_off),
+                           reinterpret_cast<float*>(c->ws + c->dompool_off), domain_logits, 49, 1280);
+    } else
     hipLaunchKernelGGL(domain_tail_fwd_kernel, dim3(c->B), dim3(256), 0, st, (const void*)(c->ws + c->dom1_off), m->dtype,
                        (const float*)(m->P + m->dc3_w_off), (const float*)(m->P + m->dc3_b_off),
                        reinterpret_cast<float*>(c->ws + c->dompool_off), domain_logits, 49, 1280);
