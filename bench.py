@@ -261,7 +261,14 @@ def main():
                         step_sum_of_kernels_ms=round(tot_ms / n_prof, 3),
                         step_alg_GBps=round(sum(v["bytes"] for v in agg.values()) / n_prof / (ms_per_step * 1e-3) / 1e9, 1),
                         step_alg_TFLOPs=round(sum(v["flops"] for v in agg.values()) / n_prof / (ms_per_step * 1e-3) / 1e12, 2),
-                        mfma_peak_TFLOPs=MFMA_PEAK_TFLOPS[args.precision])
+                        mfma_peak_TFLOPs=MFMA_PEAK_TFLOPS[args.precision],
+                        # the same figure for every family above 5 % of the step (the depthwise backward runs as two kernels since
+                        # round 3 -- input gradient on the launch stream, weight gradient on the side stream -- and is measured as such)
+                        families={k: dict(frac=round(v["bytes"] / (v["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                          achieved=round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1),
+                                          avg_launch_us=round(v["ms"] / v["launches"] * 1e3, 2),
+                                          traffic=_pmc_traffic(k)[0])
+                                  for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["ms"]) if v["ms"] > 0.05 * tot_ms})
 
     # ---- style augmentation: the decoder is the matrix-core-bound kernel family of this workload (15.43 GFLOP per
     # image, 0.74 TFLOP per restyled batch); its achieved rate, timed alone with HIP events on the launch stream

@@ -492,9 +492,11 @@ struct Runner {
     // On the small maps the weight gradient goes to the side stream with the pointwise ones (everything it reads -- g, z and the
     // batch sums of this layer's output, the forward input -- is final and never rewritten during backward) and the launch
     // stream runs the input gradient alone (spb_debug_set_dw_split).
-    const bool split = side_usable() && Hin <= g_dw_split_hw;
+    // (the instrumented pass measures the SAME two kernels, back to back on the one stream, not the fused one the product no longer runs)
+    const bool split = (side_usable() || c->prof_on) && Hin <= g_dw_split_hw;
+    spb_dw_args_t dwg = d;
     if (split) {
-      pend_dw.push_back(d);
+      if (!c->prof_on) pend_dw.push_back(d);
       d.dW = nullptr;
     }
     // one fused pass: input gradient (+ activation mask / BN sums of the input-side tensor) and weight gradient
@@ -506,6 +508,11 @@ struct Runner {
     tic(PC_DW_DGRAD, (2 * nout + 2 * nin + (res ? nin : 0)) * es(), 36.0 * nout);
     ok(spb_dwconv_dgrad(dt, &d, st));
     toc();
+    if (split && c->prof_on) {
+      tic(PC_DW_WGRAD, (2 * nout + nin) * es() + 36.0 * L.C, 18.0 * nout);
+      ok(spb_dwconv_wgrad(dt, &dwg, st));
+      toc();
+    }
     // the queued weight gradients run beside this memory-bound kernel.  They are handed to the side stream AFTER the launch
     // stream got its kernel: the host is only a bounded number of packets ahead of the GPU, and a burst of ~10 side-stream
     // launches in front of the next launch-stream kernel showed up as 30-50 us holes in the launch queue (round-3 trace)
