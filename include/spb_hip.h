@@ -420,6 +420,12 @@ int spb_gconv(int dtype, const spb_gconv_args_t* args, spb_stream_t stream);
  * low-resolution image equals the reflection padding of the upsampled one.  Same result as spb_gconv up to one bf16 rounding
  * of the summed weights, 2.25x fewer matrix-core steps. */
 int spb_gconv_up2(int dtype, const spb_gconv_args_t* args, spb_stream_t stream);
+/* The residual blocks' 128 -> 128 3x3 convolutions (ghiasi.py:92-104; Cin == Cout == 128, stride 1, no upsampling, Hin and Win
+ * multiples of 8, ldc % 8 == 0): same result as spb_gconv, args->W holds the weights as spb_gconv_wide_pack lays them out
+ * ([36 reduction steps][8 KB LDS image of the step's 128 x 32 slab]); csrc/ghiasi_wide.hip. */
+int spb_gconv_wide(int dtype, const spb_gconv_args_t* args, spb_stream_t stream);
+/* w [128][9][128] bf16 (the spb_gconv layout) -> packed, 294 912 bytes */
+int spb_gconv_wide_pack(const void* w, void* packed, spb_stream_t stream);
 /* first layer: Conv2d(3,32,9) with reflection padding on the fp32 NCHW image -> NHWC bf16 [B,H,W,32] + stats; W % 16 == 0 */
 int spb_conv9_rgb(const float* x, const float* w_oihw, const float* bias, void* y, float* stats, int B, int H, int W,
                   spb_stream_t stream);

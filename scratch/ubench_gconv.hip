@@ -5,6 +5,8 @@
 #include <cstring>
 #include <cstdlib>
 #include "../speedplusbaseline_amd/csrc/ghiasi.hip"
+#define GWABL GABL
+#include "../speedplusbaseline_amd/csrc/ghiasi_wide.hip"
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("err %s line %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
 int main() {
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -26,8 +28,9 @@ int main() {
     spb_gconv_args_t a; std::memset(&a, 0, sizeof(a));
     a.X = x; a.W = w; a.bias = bias; a.coef = coef; a.Y = y; a.stats = stats; a.B = sh.B; a.Hin = sh.H; a.Win = sh.H; a.Cin = sh.Cin;
     a.Cout = sh.Cout; a.KH = sh.K; a.stride = sh.st; a.upsample = sh.up; a.relu = 1; a.ldc = sh.Cout < 4 ? 4 : sh.Cout;
-    for (int k = 0; k < 3; ++k) if (spb_gconv(SPB_BF16, &a, 0)) { printf("launch failed\n"); return 1; }
-    CK(hipEventRecord(e0)); for (int k = 0; k < 10; ++k) spb_gconv(SPB_BF16, &a, 0);
+    const bool wide = getenv("WIDE") && sh.Cin == 128 && sh.Cout == 128 && sh.up == 1;
+    for (int k = 0; k < 3; ++k) if (wide ? spb_gconv_wide(SPB_BF16, &a, 0) : spb_gconv(SPB_BF16, &a, 0)) { printf("launch failed\n"); return 1; }
+    CK(hipEventRecord(e0)); for (int k = 0; k < 10; ++k) { if (wide) spb_gconv_wide(SPB_BF16, &a, 0); else spb_gconv(SPB_BF16, &a, 0); }
     CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); float ms; CK(hipEventElapsedTime(&ms, e0, e1));
     const double fl = 2.0 * sh.B * Hout * Hout * sh.Cout * sh.Cin * sh.K * sh.K;
     printf("gconv %dx%d %3d->%3d s%d u%d @%3d: %8.2f us  %7.1f TFLOP/s\n", sh.K, sh.K, sh.Cin, sh.Cout, sh.st, sh.up, Hout, ms * 100, fl / (ms / 10 * 1e-3) / 1e12);

@@ -183,6 +183,8 @@ SYMBOLS = {
     "spb_krn_weight_prep_bytes": (i64, [vp]),
     "spb_gconv": (i32, [i32, C.POINTER(GconvArgs), vp]),
     "spb_gconv_up2": (i32, [i32, C.POINTER(GconvArgs), vp]),
+    "spb_gconv_wide": (i32, [i32, C.POINTER(GconvArgs), vp]),
+    "spb_gconv_wide_pack": (i32, [vp, vp, vp]),
     "spb_conv9_rgb": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, vp]),
     "spb_in_coef": (i32, [vp, vp, vp, i32, vp, i32, i32, i64, f32, vp]),
     "spb_style_fc": (i32, [vp, vp, vp, vp, i32, i32, vp]),

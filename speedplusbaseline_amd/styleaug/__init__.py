@@ -28,6 +28,7 @@ def _stream():
 
 
 _UP2_BY_PHASE = os.environ.get("SPB_GCONV_UP2", "1") != "0"
+_WIDE = os.environ.get("SPB_GCONV_WIDE", "1") != "0"     # residual-block convolutions through csrc/ghiasi_wide.hip
 
 
 def _phase_weights(w):
@@ -126,6 +127,10 @@ class Ghiasi(nn.Module):
                         convs[(i, name)] = (w, c.bias.detach().float().contiguous())
                         if isinstance(layer, _UpsampleConvInRelu) and tuple(c.weight.shape[2:]) == (3, 3):
                             convs[(i, name, "up2")] = _phase_weights(c.weight.detach().float())
+                        if isinstance(layer, _ResidualBlock) and tuple(w.shape) == (128, 3, 3, 128):
+                            wp = torch.empty_like(w)      # one 8 KB LDS image per reduction step (spb_gconv_wide_pack)
+                            L.check(L.lib().spb_gconv_wide_pack(_p(w), _p(wp), _stream()), "spb_gconv_wide_pack")
+                            convs[(i, name, "wide")] = wp
             for name in ("fc_beta", "fc_gamma", "fc_beta1", "fc_gamma1", "fc_beta2", "fc_gamma2"):
                 if hasattr(layer, name):
                     fc = getattr(layer, name)
@@ -194,9 +199,13 @@ class Ghiasi(nn.Module):
             a.B = B; a.Hin = Hin; a.Win = Win; a.Cin = Cin; a.Cout = Cout; a.KH = k; a.stride = stride; a.upsample = up
             a.relu = relu; a.ldc = ldc
             wp = pk["convs"].get(key + ("up2",)) if (up == 2 and k == 3 and stride == 1 and _UP2_BY_PHASE) else None
+            ww = pk["convs"].get(key + ("wide",)) if (_WIDE and up == 1 and stride == 1 and not (Hin % 8 or Win % 8)) else None
             if wp is not None:        # Upsample(2) + ReflectionPad(1) + 3x3 as four 2x2 phase convolutions on the low-res input
                 a.W = _p(wp)
                 L.check(lib.spb_gconv_up2(L.BF16, C.byref(a), st), "spb_gconv_up2")
+            elif ww is not None:
+                a.W = _p(ww)
+                L.check(lib.spb_gconv_wide(L.BF16, C.byref(a), st), "spb_gconv_wide")
             else:
                 L.check(lib.spb_gconv(L.BF16, C.byref(a), st), "spb_gconv")
             self._mark("gconv %dx%d %d->%d s%d u%d @%d" % (k, k, Cin, Cout, stride, up, Hout))

@@ -65,6 +65,50 @@ def test_gconv_against_torch(device, cin, cout, k, stride, up, hw):
     assert float((s[..., 1] - (got * got).sum((2, 3))).abs().max() / (got * got).sum((2, 3)).abs().max()) < 1e-3
 
 
+@pytest.mark.parametrize("h,w_,with_coef", [(8, 8, True), (16, 24, True), (56, 56, False), (24, 8, False), (40, 56, True)])
+def test_wide_residual_conv_against_torch(device, h, w_, with_coef):
+    """spb_gconv_wide (csrc/ghiasi_wide.hip): the residual blocks' 128 -> 128 3x3 convolution from packed weights -- odd numbers of
+    8x8 tiles (a workgroup with one live tile), non-square maps, every border, with and without the input transform; output,
+    per-(image, channel) sums, and agreement with spb_gconv on the same operands"""
+    import ctypes as C
+    torch.manual_seed(h * 100 + w_)
+    B, cin, cout = 3, 128, 128
+    x = _bf(torch.randn(B, cin, h, w_))
+    w = _bf(torch.randn(cout, cin, 3, 3) / (cin * 9) ** 0.5)
+    bias = torch.randn(cout) * 0.1
+    coef = torch.stack([torch.rand(B, cin) + 0.5, torch.randn(B, cin) * 0.3], dim=2).contiguous()
+    a = _bf(F.relu(x * coef[:, :, 0, None, None] + coef[:, :, 1, None, None])) if with_coef else x
+    ref = F.conv2d(F.pad(a.double(), (1, 1, 1, 1), mode="reflect"), w.double(), bias.double())
+    xd = x.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).to(device)
+    wd = w.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).to(device)
+    wp = torch.empty_like(wd)
+    bd, cd = bias.to(device), coef.to(device)
+    p = lambda t: C.c_void_p(t.data_ptr())
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    L.check(L.lib().spb_gconv_wide_pack(p(wd), p(wp), st), "spb_gconv_wide_pack")
+    assert sorted(wp.view(torch.int16).flatten().tolist()) == sorted(wd.view(torch.int16).flatten().tolist())   # a permutation
+    outs = []
+    for wide in (1, 0):
+        Y = torch.zeros(B, h, w_, cout, dtype=torch.bfloat16, device=device)
+        stats = torch.zeros(B, cout, 2, dtype=torch.float32, device=device)
+        g = L.GconvArgs()
+        g.X = p(xd); g.W = p(wp if wide else wd); g.bias = p(bd); g.coef = p(cd) if with_coef else None; g.Y = p(Y); g.stats = p(stats)
+        g.B = B; g.Hin = h; g.Win = w_; g.Cin = cin; g.Cout = cout; g.KH = 3; g.stride = 1; g.upsample = 1
+        g.relu = 1 if with_coef else 0; g.ldc = cout
+        fn = L.lib().spb_gconv_wide if wide else L.lib().spb_gconv
+        L.check(fn(L.BF16, C.byref(g), st), "spb_gconv_wide" if wide else "spb_gconv")
+        torch.cuda.synchronize()
+        outs.append((Y.float().cpu(), stats.double().cpu()))
+    got = outs[0][0].permute(0, 3, 1, 2).double()
+    err = float((got - ref).abs().max() / ref.abs().max())
+    assert err < 1.5e-2, err                     # bf16 storage of the result
+    s = outs[0][1]
+    assert float((s[..., 0] - got.sum((2, 3))).abs().max() / got.sum((2, 3)).abs().max()) < 1e-3
+    assert float((s[..., 1] - (got * got).sum((2, 3))).abs().max() / (got * got).sum((2, 3)).abs().max()) < 1e-3
+    # same reduction order as the slab kernel; the bias enters first here, last there: at most one bf16 ulp apart
+    assert float((outs[0][0] - outs[1][0]).abs().max()) <= 2.0 ** -7 * float(outs[1][0].abs().max())
+
+
 @pytest.mark.parametrize("cin,cout,hw", [(128, 64, 8), (64, 32, 16), (128, 64, 56), (64, 32, 28)])
 def test_upsample_conv_by_phase_against_torch(device, cin, cout, hw):
     """spb_gconv_up2: Upsample(2, nearest) + ReflectionPad2d(1) + Conv2d 3x3 as four 2x2 phase convolutions on the low-resolution
