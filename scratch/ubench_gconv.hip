@@ -14,6 +14,8 @@ int main() {
   if (getenv("PF")) spb_debug_set_gconv_slab_pf(atoi(getenv("PF")));
   if (getenv("SLAB")) spb_debug_set_gconv_slab(atoi(getenv("SLAB")));
   if (getenv("HPRE")) spb_debug_set_gconv_halo_prefetch(atoi(getenv("HPRE")));
+  if (getenv("ROT")) spb_debug_set_gconv_wide_rotate(atoi(getenv("ROT")));
+  if (getenv("WGS")) spb_debug_set_gconv_wide_wgs(atoi(getenv("WGS")));
   if (getenv("WPXG")) spb_debug_set_gconv_wlds_pxg(atoi(getenv("WPXG")));
   printf("GABL=%d PF=%s SLAB=%s WPXG=%s\n", GABL, getenv("PF") ? getenv("PF") : "-", getenv("SLAB") ? getenv("SLAB") : "-", getenv("WPXG") ? getenv("WPXG") : "-");
   for (auto sh : shapes) {

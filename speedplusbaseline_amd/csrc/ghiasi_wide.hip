@@ -23,6 +23,9 @@
 // Two 8x8 tiles per workgroup, 67 KB of LDS, two workgroups per CU (one in its matrix-core loop while the other stages or stores).
 #include "common.h"
 
+#ifndef GW_BF2
+#define GW_BF2 0   // 1: pixel fragments double-buffered in registers (one reduction step ahead)
+#endif
 #ifndef GWABL
 #define GWABL 0   // ablation bits for scratch/ubench_gconv.hip: 1 no K loop, 2 no halo staging, 4 no slab traffic, 8 no MFMA, 64 no output
 #endif
@@ -32,60 +35,77 @@ namespace {
 constexpr int GW_PLANE = 1632;           // bytes per chunk plane: 100 pixels x 16 B + 32 (staggers the 8 planes of a parity over the store banks)
 constexpr int GW_ODD = 8 * GW_PLANE;     // 13056 = 51 x 256: where the odd chunks start
 constexpr int GW_TILE = 2 * GW_ODD;      // one 8x8 tile's 10x10 halo, 128 channels
-constexpr int GW_SLAB = 8192;            // one reduction step of weights: 128 rows x 32 k, bf16
 constexpr int GW_OPITCH = 272;           // output staging: 128 channels of a pixel + 16 B
-constexpr int GW_PF = 6;                 // weight slabs in flight per workgroup (global -> registers -> LDS)
+constexpr int GW_PF = 6;                 // reduction steps of weight fragments in flight per wave (global -> registers, 2 KB each)
 constexpr int GW_NSTEP = 36;             // 9 taps x 4 chunks of 32 input channels
 constexpr int GW_HV = 2 * 100 * 16;      // halo vectors (8 channels) per workgroup
 constexpr int GW_HU = (GW_HV + 255) / 256;
 
 __device__ __forceinline__ int gw_reflect(int i, int n) { i = i < 0 ? -i : i; return i >= n ? 2 * n - 2 - i : i; }
 
-__global__ __launch_bounds__(256, 2) void gconv_wide_kernel(const spb_gconv_args_t g) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* slab = smem;                   // [2][GW_SLAB]; after the loop: float red[4 waves][128][2]
-  char* halo = smem + 2 * GW_SLAB;     // [2 tiles][GW_TILE]; after the loop: output staging [128 pixels][GW_OPITCH]
-  const int t = threadIdx.x, lane = t & 63, li = lane & 15, lq = lane >> 4, wave = t >> 6;
-  const int H = g.Hin, W = g.Win;
-  const int tiles_x = W >> 3, tpi = tiles_x * (H >> 3), gpi = (tpi + 1) >> 1;
-  const int bid = xcd_remap(blockIdx.x, gridDim.x);     // neighbouring tiles (shared halo rows) on one XCD's L2
-  const int b = bid / gpi, grp = bid % gpi;
-  const bf16_t* Wg = reinterpret_cast<const bf16_t*>(g.W);
-  const bf16_t* X = reinterpret_cast<const bf16_t*>(g.X);
-  bf16_t* Y = reinterpret_cast<bf16_t*>(g.Y);
-  int oy0[2], ox0[2];
-  bool tvalid[2];
+struct GwGroup { int b, oy0[2], ox0[2]; bool tvalid[2]; };
+
+__device__ __forceinline__ GwGroup gw_group(int gid, int gpi, int tpi, int tiles_x) {
+  GwGroup q;
+  q.b = gid / gpi;
+  const int grp = gid - q.b * gpi;
 #pragma unroll
   for (int p = 0; p < 2; ++p) {
     int tr = grp * 2 + p;
-    tvalid[p] = tr < tpi;
-    tr = tvalid[p] ? tr : tpi - 1;
-    oy0[p] = (tr / tiles_x) * 8; ox0[p] = (tr % tiles_x) * 8;
+    q.tvalid[p] = tr < tpi;
+    tr = q.tvalid[p] ? tr : tpi - 1;
+    q.oy0[p] = (tr / tiles_x) * 8; q.ox0[p] = (tr % tiles_x) * 8;
   }
-  typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
-  u32x4_t sreg[GW_PF * 2];   // flat, constant indices only (stays in registers)
+  return q;
+}
+
+// Persistent: gridDim.x workgroups (two per CU) walk the tile groups of "their" XCD (workgroup k runs on XCD k % 8, which owns a
+// contiguous range of groups, so neighbouring tiles share one L2).  Per group: [halo commit] [36-step K loop] [next group's halo
+// and coefficient loads issued] [epilogue].  A one-shot workgroup per group (the first version: 54 us) kept its CU slot until its
+// output stores were acknowledged and restarted the weight stream from an empty pipe; here the stores drain under the next
+// group's work, the halo round trip hides behind the epilogue, and the weight ring never stops (36 steps per group, PF | 36: the
+// prefetch simply wraps to slab 0).
+__global__ __launch_bounds__(256, 2) void gconv_wide_kernel(const spb_gconv_args_t g, int ngroups, int rotate) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* halo = smem;                             // [2 tiles][GW_TILE]; in the epilogue: output staging [128 pixels][GW_OPITCH]
+  float* red = reinterpret_cast<float*>(smem + 2 * GW_TILE);   // [4 waves][128][2]
+  float* biasl = red + 4 * 128 * 2;              // [128]
+  const int t = threadIdx.x, lane = t & 63, li = lane & 15, lq = lane >> 4, wave = t >> 6;
+  const int H = g.Hin, W = g.Win;
+  const int tiles_x = W >> 3, tpi = tiles_x * (H >> 3), gpi = (tpi + 1) >> 1;
+  const int xcd = blockIdx.x & 7, nw8 = gridDim.x >> 3;
+  const int gq = ngroups >> 3, gr = ngroups & 7;
+  const int cnt = gq + (xcd < gr ? 1 : 0), base = xcd * gq + (xcd < gr ? xcd : gr);
+  int l = blockIdx.x >> 3;
+  if (l >= cnt) return;
+  const bf16_t* Wg = reinterpret_cast<const bf16_t*>(g.W);
+  const bf16_t* X = reinterpret_cast<const bf16_t*>(g.X);
+  bf16_t* Y = reinterpret_cast<bf16_t*>(g.Y);
+  // weight fragments of this wave (output channels 32 w .. 32 w + 31): straight from L2 into the registers the matrix cores
+  // read, GW_PF steps ahead; 1 KB contiguous per wave instruction
+  const bf16_t* Wl = Wg + ((size_t)wave * 128 + lane) * 8;
+  bf16x8_t areg[GW_PF * 2];   // flat, constant indices only (stays in registers)
+  // Every workgroup streams the SAME 295 KB of weights; started together they would all ask the same L2 channel for the same
+  // lines at the same time.  The 36 reduction steps are a cycle: workgroup k enters it at step 6 * (k' % 6) and never leaves
+  // it (the next group's steps follow on), so at any moment the workgroups of an XCD are spread over the whole tensor.
+  const int rot = rotate ? GW_PF * ((blockIdx.x >> 3) % (GW_NSTEP / GW_PF)) : 0;
 #pragma unroll
   for (int d = 0; d < GW_PF; ++d)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
-      sreg[d * 2 + j] = *reinterpret_cast<const u32x4_t*>(Wg + ((size_t)d * 512 + t + 256 * j) * 8);
+      areg[d * 2 + j] = *reinterpret_cast<const bf16x8_t*>(Wl + (size_t)(rot + d) * 4096 + j * 512);
+  int sbase = rot;                                   // first step of the next 6 (36 per group: back at `rot` after each group)
 
-  // ---- halo: thread t owns channel chunk cv = t % 16 of pixels (t / 16 + 16 u) of the two 10x10 halos
+  // halo: thread t owns channel chunk cv = t % 16 of pixels (t / 16 + 16 u) of the two 10x10 halos
   const int cv = t & 15;
-  if (!(GWABL & 2)) {
-    float sc[8], sh[8];
+  Raw8<bf16_t> r[GW_HU];
+  float4 cfr[4];
+  auto issue_halo = [&](const GwGroup& q) {
     if (g.coef) {
-      const float4* cp = reinterpret_cast<const float4*>(g.coef + ((size_t)b * 128 + cv * 8) * 2);
+      const float4* cp = reinterpret_cast<const float4*>(g.coef + ((size_t)q.b * 128 + cv * 8) * 2);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float4 v = cp[j];
-        sc[2 * j] = v.x; sh[2 * j] = v.y; sc[2 * j + 1] = v.z; sh[2 * j + 1] = v.w;
-      }
-    } else {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) { sc[j] = 1.f; sh[j] = 0.f; }
+      for (int j = 0; j < 4; ++j) cfr[j] = cp[j];
     }
-    Raw8<bf16_t> r[GW_HU];
 #pragma unroll
     for (int u = 0; u < GW_HU; ++u) {
       const int i = t + 256 * u;
@@ -93,138 +113,166 @@ __global__ __launch_bounds__(256, 2) void gconv_wide_kernel(const spb_gconv_args
       const int p = ic >= 1600 ? 1 : 0;
       const int hp = (ic - p * 1600) >> 4;
       const int hy = hp / 10, hx = hp - hy * 10;
-      const int sy = gw_reflect((p ? oy0[1] : oy0[0]) - 1 + hy, H), sx = gw_reflect((p ? ox0[1] : ox0[0]) - 1 + hx, W);
-      r[u] = ldraw<bf16_t>(X + ((size_t)(b * H + sy) * W + sx) * 128 + cv * 8);
+      const int sy = gw_reflect((p ? q.oy0[1] : q.oy0[0]) - 1 + hy, H), sx = gw_reflect((p ? q.ox0[1] : q.ox0[0]) - 1 + hx, W);
+      r[u] = ldraw<bf16_t>(X + ((size_t)(q.b * H + sy) * W + sx) * 128 + cv * 8);
     }
-    char* hdst = halo + (cv & 1) * GW_ODD + (cv >> 1) * GW_PLANE;
-#pragma unroll
-    for (int u = 0; u < GW_HU; ++u) {
-      const int i = t + 256 * u;
-      if (i >= GW_HV) continue;
-      const int p = i >= 1600 ? 1 : 0;
-      const int hp = (i - p * 1600) >> 4;
-      float v[8];
-      cvt8(r[u], v);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const float uu = v[j] * sc[j] + sh[j];
-        v[j] = g.relu ? fmaxf(uu, 0.f) : uu;
-      }
-      st8<bf16_t>(reinterpret_cast<bf16_t*>(hdst + p * GW_TILE + hp * 16), v);
-    }
-  }
-#pragma unroll
-  for (int j = 0; j < 2; ++j) *reinterpret_cast<u32x4_t*>(slab + (t + 256 * j) * 16) = sreg[j];
-  __syncthreads();
+  };
+  GwGroup cur = gw_group(base + l, gpi, tpi, tiles_x);
+  if (!(GWABL & 2)) issue_halo(cur);
 
-  // ---- K loop: wave w owns tile rows (w, w+4) of both tiles x all 128 output channels
-  const int prow = wave + 4 * (li >> 3), pcol = li & 7;
+  const int prow = 4 * (li >> 3), pcol = li & 7;      // fragment f = tile (f / 4), rows (f % 4, f % 4 + 4)
   const char* hb = halo + (lq & 1) * GW_ODD + (lq >> 1) * GW_PLANE + (prow * 10 + pcol) * 16;
-  const int arow = lq * 256 + li * 16;
-  f32x4_t acc[2][8];
-  {
-    const int co0 = lq * 32;
-#pragma unroll
-    for (int nb = 0; nb < 8; ++nb) {
-      float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (g.bias) bv = *reinterpret_cast<const float4*>(g.bias + co0 + nb * 4);
-#pragma unroll
-      for (int p = 0; p < 2; ++p) acc[p][nb] = (f32x4_t){bv.x, bv.y, bv.z, bv.w};
-    }
-  }
-  int tapo = 0, kx = 0, cc = 0;     // tapo = (ky * 10 + kx) * 16
-  const int nsteps = (GWABL & 1) ? 0 : GW_NSTEP;
-  for (int s0 = 0; s0 < nsteps; s0 += GW_PF) {
-#pragma unroll
-    for (int d = 0; d < GW_PF; ++d) {
-      const int s = s0 + d;
-      const char* sl = slab + (s & 1) * GW_SLAB + arow;
-      bf16x8_t bf[2];
-#pragma unroll
-      for (int p = 0; p < 2; ++p) bf[p] = *reinterpret_cast<const bf16x8_t*>(hb + p * GW_TILE + cc * (2 * GW_PLANE) + tapo);
-#pragma unroll
-      for (int nb = 0; nb < 8; ++nb) {
-        const bf16x8_t af = *reinterpret_cast<const bf16x8_t*>(sl + nb * 1024);
-#pragma unroll
-        for (int p = 0; p < 2; ++p) {
-          if (GWABL & 8) acc[p][nb][0] += (float)af[0] * (float)bf[p][0];
-          else acc[p][nb] = SPB_MFMA16(af, bf[p], acc[p][nb]);
-        }
-      }
-      // no branch around these (see gconv_slab_kernel): the step index is clamped, the last steps re-fetch the last slab and
-      // park it in the idle buffer
-      if (!(GWABL & 4)) {
-        char* sn = slab + ((s + 1) & 1) * GW_SLAB;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) *reinterpret_cast<u32x4_t*>(sn + (t + 256 * j) * 16) = sreg[((d + 1) % GW_PF) * 2 + j];
-        const int sf = s + GW_PF < GW_NSTEP ? s + GW_PF : GW_NSTEP - 1;
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-          sreg[d * 2 + j] = *reinterpret_cast<const u32x4_t*>(Wg + ((size_t)sf * 512 + t + 256 * j) * 8);
-      }
-      __syncthreads();
-      if (++cc == 4) { cc = 0; tapo += 16; if (++kx == 3) { kx = 0; tapo += 7 * 16; } }
-    }
-  }
-  if (GWABL & 1) __syncthreads();
+  if (t < 128) biasl[t] = g.bias ? g.bias[t] : 0.f;     // visible after the first barrier of the group loop
 
-  // ---- epilogue 1: accumulators -> LDS as whole pixels (the halo is dead: every wave passed the last barrier of the loop)
-  char* ost = halo;
-  if (!(GWABL & 64)) {
-#pragma unroll
-    for (int p = 0; p < 2; ++p) {
-      char* dst = ost + (p * 64 + prow * 8 + pcol) * GW_OPITCH + lq * 64;
-#pragma unroll
-      for (int nb = 0; nb < 8; nb += 2) {
-        uint4 o;
-        o.x = pack_bf16x2(acc[p][nb][0], acc[p][nb][1]); o.y = pack_bf16x2(acc[p][nb][2], acc[p][nb][3]);
-        o.z = pack_bf16x2(acc[p][nb + 1][0], acc[p][nb + 1][1]); o.w = pack_bf16x2(acc[p][nb + 1][2], acc[p][nb + 1][3]);
-        *reinterpret_cast<uint4*>(dst + nb * 8) = o;
-      }
-    }
-  }
-  __syncthreads();
-  // ---- epilogue 2: pixel (t/16 + 16 u), chunk cv: 16-byte stores, 1 KB contiguous per wave instruction; sums of the stored values
-  float s1[8], s2[8];
-#pragma unroll
-  for (int j = 0; j < 8; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
-  if (!(GWABL & 64)) {
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int p = u >> 2;                          // pixels 0..63 are tile 0
-      const int q = ((t >> 4) + 16 * u) & 63;
-      if (!tvalid[p]) continue;
-      const uint4 o = *reinterpret_cast<const uint4*>(ost + (p * 64 + q) * GW_OPITCH + cv * 16);
-      const int oy = oy0[p] + (q >> 3), ox = ox0[p] + (q & 7);
-      *reinterpret_cast<uint4*>(Y + ((size_t)(b * H + oy) * W + ox) * g.ldc + cv * 8) = o;
-      const unsigned w4[4] = {o.x, o.y, o.z, o.w};
+  for (;;) {
+    // ---- commit the halo of `cur` (loads issued one epilogue ago)
+    if (!(GWABL & 2)) {
+      float sc[8], sh[8];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const float lo = bf2f((bf16_t)(w4[j] & 0xffffu)), hi = bf2f((bf16_t)(w4[j] >> 16));
-        s1[2 * j] += lo; s2[2 * j] += lo * lo; s1[2 * j + 1] += hi; s2[2 * j + 1] += hi * hi;
+        sc[2 * j] = g.coef ? cfr[j].x : 1.f; sh[2 * j] = g.coef ? cfr[j].y : 0.f;
+        sc[2 * j + 1] = g.coef ? cfr[j].z : 1.f; sh[2 * j + 1] = g.coef ? cfr[j].w : 0.f;
+      }
+      char* hdst = halo + (cv & 1) * GW_ODD + (cv >> 1) * GW_PLANE;
+#pragma unroll
+      for (int u = 0; u < GW_HU; ++u) {
+        const int i = t + 256 * u;
+        if (i >= GW_HV) continue;
+        const int p = i >= 1600 ? 1 : 0;
+        const int hp = (i - p * 1600) >> 4;
+        float v[8];
+        cvt8(r[u], v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float uu = v[j] * sc[j] + sh[j];
+          v[j] = g.relu ? fmaxf(uu, 0.f) : uu;
+        }
+        st8<bf16_t>(reinterpret_cast<bf16_t*>(hdst + p * GW_TILE + hp * 16), v);
       }
     }
-  }
-  if (g.stats) {
-    float* red = reinterpret_cast<float*>(slab);     // the slab buffers are idle after the loop's last barrier
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const float a1 = xor32_sum(xor16_sum(s1[j])), a2 = xor32_sum(xor16_sum(s2[j]));   // over the 4 pixels of this wave instruction
-      if (lane < 16) { red[(wave * 128 + cv * 8 + j) * 2] = a1; red[(wave * 128 + cv * 8 + j) * 2 + 1] = a2; }
-    }
     __syncthreads();
-    atomicAdd(g.stats + (size_t)b * 256 + t, red[t] + red[256 + t] + red[512 + t] + red[768 + t]);
+
+    // ---- K loop, no barrier and no LDS store in it: wave w owns output channels 32 w .. 32 w + 31 of all 128 pixels (8 pixel
+    // fragments from LDS x 2 weight fragments from its registers = 16 MFMAs per 8 ds_read_b128)
+    f32x4_t acc[8][2];
+#pragma unroll
+    for (int cf = 0; cf < 2; ++cf) {
+      const float4 bv = *reinterpret_cast<const float4*>(biasl + wave * 32 + lq * 8 + cf * 4);
+#pragma unroll
+      for (int f = 0; f < 8; ++f) acc[f][cf] = (f32x4_t){bv.x, bv.y, bv.z, bv.w};
+    }
+    const int nsteps = (GWABL & 1) ? 0 : GW_NSTEP;
+    // LDS offset of reduction step s = tap * 4 + cc within a fragment's plane set: chunk pair 2 cc, pixel (ky, kx)
+    auto step_off = [](int s) { const int tap = s >> 2, ky = (tap * 11) >> 5; return (s & 3) * (2 * GW_PLANE) + (ky * 10 + tap - 3 * ky) * 16; };
+#if GW_BF2
+    // pixel fragments one step ahead, in their own registers (left alone the compiler fetched two at a time into the same
+    // registers: an LDS round trip per four MFMAs)
+    bf16x8_t bfr[2][8];
+    {
+      const char* hs = hb + step_off(sbase);
+#pragma unroll
+      for (int f = 0; f < 8; ++f) bfr[0][f] = *reinterpret_cast<const bf16x8_t*>(hs + (f >> 2) * GW_TILE + (f & 3) * 160);
+    }
+#else
+    bf16x8_t bfr[1][8];
+#endif
+    for (int i0 = 0; i0 < nsteps; i0 += GW_PF) {
+#pragma unroll
+      for (int d = 0; d < GW_PF; ++d) {
+        const int s = sbase + d;
+#if GW_BF2
+        const char* hs = hb + step_off(s + 1 == GW_NSTEP ? 0 : s + 1);     // after the group's last step: unused
+        const int cur = d & 1, nxt = (d + 1) & 1;
+#else
+        const char* hs = hb + step_off(s);
+        const int cur = 0, nxt = 0;
+#endif
+#pragma unroll
+        for (int f = 0; f < 8; ++f) bfr[nxt][f] = *reinterpret_cast<const bf16x8_t*>(hs + (f >> 2) * GW_TILE + (f & 3) * 160);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int f = 0; f < 8; ++f) {
+#pragma unroll
+          for (int cf = 0; cf < 2; ++cf) {
+            if (GWABL & 8) acc[f][cf][0] += (float)areg[d * 2 + cf][0] * (float)bfr[cur][f][0];
+            else acc[f][cf] = SPB_MFMA16(areg[d * 2 + cf], bfr[cur][f], acc[f][cf]);
+          }
+        }
+        // no branch around the refill: the step index wraps (the weight stream of the next group starts here)
+        if (!(GWABL & 4)) {
+          const int sf = s + GW_PF < GW_NSTEP ? s + GW_PF : s + GW_PF - GW_NSTEP;
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            areg[d * 2 + j] = *reinterpret_cast<const bf16x8_t*>(Wl + (size_t)sf * 4096 + j * 512);
+        }
+      }
+      sbase = sbase + GW_PF < GW_NSTEP ? sbase + GW_PF : 0;
+    }
+    __syncthreads();   // every wave is done with the halo
+
+    // ---- epilogue 1: accumulators -> LDS as whole pixels: a lane holds channels 32 w + 8 lq .. + 7 of its 8 pixels
+    char* ost = halo;
+    if (!(GWABL & 64)) {
+#pragma unroll
+      for (int f = 0; f < 8; ++f) {
+        uint4 o;
+        o.x = pack_bf16x2(acc[f][0][0], acc[f][0][1]); o.y = pack_bf16x2(acc[f][0][2], acc[f][0][3]);
+        o.z = pack_bf16x2(acc[f][1][0], acc[f][1][1]); o.w = pack_bf16x2(acc[f][1][2], acc[f][1][3]);
+        *reinterpret_cast<uint4*>(ost + ((f >> 2) * 64 + ((f & 3) + prow) * 8 + pcol) * GW_OPITCH + wave * 64 + lq * 16) = o;
+      }
+    }
+    // ---- the next group's halo: in flight during the rest of the epilogue (clamped, not branched: the last group re-reads its
+    // own).  After the accumulators have left their registers: 13 vectors + coefficients per thread.
+    const int ln = l + nw8;
+    const bool more = ln < cnt;
+    const GwGroup nxt = gw_group(base + (more ? ln : l), gpi, tpi, tiles_x);
+    if (!(GWABL & 2)) issue_halo(nxt);
+    __syncthreads();
+    // ---- epilogue 2: pixel (t/16 + 16 u), chunk cv: 16-byte stores, 1 KB contiguous per wave instruction; sums of the stored values
+    float s1[8], s2[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
+    if (!(GWABL & 64)) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int p = u >> 2;                          // pixels 0..63 are tile 0
+        const int q = ((t >> 4) + 16 * u) & 63;
+        if (!cur.tvalid[p]) continue;
+        const uint4 o = *reinterpret_cast<const uint4*>(ost + (p * 64 + q) * GW_OPITCH + cv * 16);
+        const int oy = cur.oy0[p] + (q >> 3), ox = cur.ox0[p] + (q & 7);
+        *reinterpret_cast<uint4*>(Y + ((size_t)(cur.b * H + oy) * W + ox) * g.ldc + cv * 8) = o;
+        const unsigned w4[4] = {o.x, o.y, o.z, o.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float lo = bf2f((bf16_t)(w4[j] & 0xffffu)), hi = bf2f((bf16_t)(w4[j] >> 16));
+          s1[2 * j] += lo; s2[2 * j] += lo * lo; s1[2 * j + 1] += hi; s2[2 * j + 1] += hi * hi;
+        }
+      }
+    }
+    if (g.stats) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float a1 = xor32_sum(xor16_sum(s1[j])), a2 = xor32_sum(xor16_sum(s2[j]));   // over the 4 pixels of a wave instruction
+        if (lane < 16) { red[(wave * 128 + cv * 8 + j) * 2] = a1; red[(wave * 128 + cv * 8 + j) * 2 + 1] = a2; }
+      }
+    }
+    __syncthreads();   // the staging area is read out (the next commit overwrites it); red is complete
+    if (g.stats) atomicAdd(g.stats + (size_t)cur.b * 256 + t, red[t] + red[256 + t] + red[512 + t] + red[768 + t]);
+    if (!more) break;
+    l = ln;
+    cur = nxt;
   }
 }
 
-// W [128][9][128] bf16 (the spb_gconv layout) -> packed[step = tap*4 + cc][nb][lq][li][8]: row (li, nb) is output channel
-// (li / 4) * 32 + nb * 4 + li % 4 (a lane of the transposed product then holds 32 consecutive channels), k = cc * 32 + lq * 8 + j
+// W [128][9][128] bf16 (the spb_gconv layout) -> packed[step = tap*4 + cc][wave w][cf][lane = lq*16 + li][8]: MFMA row li of
+// fragment (w, cf) is output channel 32 w + (li / 4) * 8 + cf * 4 + li % 4 (a lane of the transposed product then holds 8
+// consecutive channels over its two fragments), k = cc * 32 + lq * 8 + j
 __global__ void gconv_wide_pack_kernel(const bf16_t* __restrict__ w, bf16_t* __restrict__ out) {
   const int idx = blockIdx.x * 256 + threadIdx.x;
   if (idx >= GW_NSTEP * 512) return;
   const int s = idx >> 9, gr = idx & 511;
-  const int nb = gr >> 6, lq = (gr >> 4) & 3, li = gr & 15;
-  const int co = (li >> 2) * 32 + nb * 4 + (li & 3), tap = s >> 2, cc = s & 3;
+  const int wv = gr >> 7, cf = (gr >> 6) & 1, lq = (gr >> 4) & 3, li = gr & 15;
+  const int co = wv * 32 + (li >> 2) * 8 + cf * 4 + (li & 3), tap = s >> 2, cc = s & 3;
   *reinterpret_cast<uint4*>(out + (size_t)idx * 8) =
       *reinterpret_cast<const uint4*>(w + ((size_t)co * 9 + tap) * 128 + cc * 32 + lq * 8);
 }
@@ -239,19 +287,26 @@ extern "C" int spb_gconv_wide_pack(const void* w, void* packed, spb_stream_t str
   return 0;
 }
 
+static int g_gw_rot = 1;     // workgroups enter the weight cycle at staggered steps
+extern "C" int spb_debug_set_gconv_wide_rotate(int on) { g_gw_rot = on; return 0; }
+static int g_gw_wgs = 512;   // persistent workgroups: two per CU
+extern "C" int spb_debug_set_gconv_wide_wgs(int n) { g_gw_wgs = n < 8 ? 8 : (n & ~7); return 0; }
+
 extern "C" int spb_gconv_wide(int dtype, const spb_gconv_args_t* a, spb_stream_t stream) {
   if (!a || !a->X || !a->W || !a->Y) return SPB_E_ARG;
   if (dtype != SPB_BF16) return SPB_E_UNSUPPORTED;
   if (a->B <= 0 || a->Cin != 128 || a->Cout != 128 || a->KH != 3 || a->stride != 1 || a->upsample != 1) return SPB_E_SHAPE;
   if ((a->Hin & 7) || (a->Win & 7) || a->Hin < 8 || a->Win < 8 || a->ldc < 128 || (a->ldc & 7)) return SPB_E_SHAPE;
   const int tpi = (a->Hin >> 3) * (a->Win >> 3), gpi = (tpi + 1) >> 1;
-  const size_t lds = 2 * GW_SLAB + 2 * GW_TILE;
+  const int ngroups = a->B * gpi;
+  const size_t lds = 2 * GW_TILE + (4 * 128 * 2 + 128) * sizeof(float);
+  const int nwg = ngroups < g_gw_wgs ? ((ngroups + 7) & ~7) : g_gw_wgs;   // a multiple of 8: one share per XCD
   static bool once = false;
   if (!once) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gconv_wide_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     once = true;
   }
-  hipLaunchKernelGGL(gconv_wide_kernel, dim3((unsigned)(a->B * gpi)), dim3(256), lds, (hipStream_t)stream, *a);
+  hipLaunchKernelGGL(gconv_wide_kernel, dim3((unsigned)nwg), dim3(256), lds, (hipStream_t)stream, *a, ngroups, g_gw_rot);
   SPB_CHECK_LAUNCH();
   return 0;
 }
