@@ -6,6 +6,7 @@
 #include <cstdlib>
 #include "../speedplusbaseline_amd/csrc/ghiasi.hip"
 #define GWABL GABL
+#define GW_TS 1
 #include "../speedplusbaseline_amd/csrc/ghiasi_wide.hip"
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("err %s line %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
 int main() {
@@ -15,6 +16,7 @@ int main() {
   if (getenv("SLAB")) spb_debug_set_gconv_slab(atoi(getenv("SLAB")));
   if (getenv("HPRE")) spb_debug_set_gconv_halo_prefetch(atoi(getenv("HPRE")));
   if (getenv("ROT")) spb_debug_set_gconv_wide_rotate(atoi(getenv("ROT")));
+  if (getenv("DELAY")) spb_debug_set_gconv_wide_delay(atoi(getenv("DELAY")));
   if (getenv("WGS")) spb_debug_set_gconv_wide_wgs(atoi(getenv("WGS")));
   if (getenv("WPXG")) spb_debug_set_gconv_wlds_pxg(atoi(getenv("WPXG")));
   printf("GABL=%d PF=%s SLAB=%s WPXG=%s\n", GABL, getenv("PF") ? getenv("PF") : "-", getenv("SLAB") ? getenv("SLAB") : "-", getenv("WPXG") ? getenv("WPXG") : "-");
@@ -34,6 +36,22 @@ int main() {
     for (int k = 0; k < 3; ++k) if (wide ? spb_gconv_wide(SPB_BF16, &a, 0) : spb_gconv(SPB_BF16, &a, 0)) { printf("launch failed\n"); return 1; }
     CK(hipEventRecord(e0)); for (int k = 0; k < 10; ++k) { if (wide) spb_gconv_wide(SPB_BF16, &a, 0); else spb_gconv(SPB_BF16, &a, 0); }
     CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    if (wide) {
+      unsigned long long* ts; CK(hipMalloc(&ts, 1024 * 4 * 5 * 8)); CK(hipMemset(ts, 0, 1024 * 4 * 5 * 8));
+      CK(hipMemcpyToSymbol(HIP_SYMBOL(g_gw_ts), &ts, sizeof(ts)));
+      spb_gconv_wide(SPB_BF16, &a, 0); CK(hipDeviceSynchronize());
+      static unsigned long long h[1024 * 4 * 5]; CK(hipMemcpy(h, ts, sizeof(h), hipMemcpyDeviceToHost));
+      unsigned long long* nul = nullptr; CK(hipMemcpyToSymbol(HIP_SYMBOL(g_gw_ts), &nul, sizeof(nul)));
+      unsigned long long t0 = ~0ull;
+      for (int i = 0; i < 1024 * 20; ++i) if (h[i] && h[i] < t0) t0 = h[i];
+      for (int gi = 0; gi < 3; ++gi) {
+        double av[5] = {0, 0, 0, 0, 0}; int n = 0;
+        for (int w = 0; w < 1024; ++w) if (h[(w * 4 + gi) * 5]) { ++n; for (int i = 0; i < 5; ++i) av[i] += (double)(h[(w * 4 + gi) * 5 + i] - t0) / 100.0; }
+        if (n) printf("  group %d (%4d wgs): start %.2f  committed %.2f  loop done %.2f  all waves done %.2f  end %.2f us\n", gi, n, av[0] / n, av[1] / n, av[2] / n, av[3] / n, av[4] / n);
+      }
+      for (int w = 0; w < 3; ++w) { printf("  wg %d:", w * 8); for (int gi = 0; gi < 3; ++gi) for (int i = 0; i < 5; ++i) printf(" %.2f", h[(w * 32 + gi) * 5 + i] ? (double)(h[(w * 32 + gi) * 5 + i] - t0) / 100.0 : 0.0); printf("\n"); }
+      hipFree(ts);
+    }
     const double fl = 2.0 * sh.B * Hout * Hout * sh.Cout * sh.Cin * sh.K * sh.K;
     printf("gconv %dx%d %3d->%3d s%d u%d @%3d: %8.2f us  %7.1f TFLOP/s\n", sh.K, sh.K, sh.Cin, sh.Cout, sh.st, sh.up, Hout, ms * 100, fl / (ms / 10 * 1e-3) / 1e12);
     hipFree(x); hipFree(w); hipFree(y); hipFree(coef); hipFree(stats); hipFree(bias);

@@ -30,6 +30,13 @@
 #define GWABL 0   // ablation bits for scratch/ubench_gconv.hip: 1 no K loop, 2 no halo staging, 4 no slab traffic, 8 no MFMA, 64 no output
 #endif
 
+#ifdef GW_TS
+__device__ unsigned long long* g_gw_ts;     // scratch/ubench_gconv.hip: [workgroup][group 0..3][5] wall clock (100 MHz)
+#define GW_STAMP(i) do { if (t == 0 && g_gw_ts && gi < 4) g_gw_ts[(blockIdx.x * 4 + gi) * 5 + (i)] = wall_clock64(); } while (0)
+#else
+#define GW_STAMP(i) do { } while (0)
+#endif
+
 namespace {
 
 constexpr int GW_PLANE = 1632;           // bytes per chunk plane: 100 pixels x 16 B + 32 (staggers the 8 planes of a parity over the store banks)
@@ -40,6 +47,22 @@ constexpr int GW_PF = 6;                 // reduction steps of weight fragments 
 constexpr int GW_NSTEP = 36;             // 9 taps x 4 chunks of 32 input channels
 constexpr int GW_HV = 2 * 100 * 16;      // halo vectors (8 channels) per workgroup
 constexpr int GW_HU = (GW_HV + 255) / 256;
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt: in the epilogue that meant one full
+// round trip for the next group's halo loads and another for the output stores, 4.5 us per group (timestamps, round 3).
+__device__ __forceinline__ void gw_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// One swap serves two reductions: v_permlane16_swap exchanges the odd 16-lane rows of a with the even rows of b, so a' + b' holds
+// a's row-pair sums in the even rows and b's in the odd rows; v_permlane32_swap does the same with the wave's halves.  Sixteen
+// per-lane values reduced over the four rows cost 12 swaps (was 32), and the totals end up spread over the rows.
+__device__ __forceinline__ float gw_swap16_add(float a, float b) {
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+  return a + b;
+}
+__device__ __forceinline__ float gw_swap32_add(float a, float b) {
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+  return a + b;
+}
 
 __device__ __forceinline__ int gw_reflect(int i, int n) { i = i < 0 ? -i : i; return i >= n ? 2 * n - 2 - i : i; }
 
@@ -65,7 +88,7 @@ __device__ __forceinline__ GwGroup gw_group(int gid, int gpi, int tpi, int tiles
 // output stores were acknowledged and restarted the weight stream from an empty pipe; here the stores drain under the next
 // group's work, the halo round trip hides behind the epilogue, and the weight ring never stops (36 steps per group, PF | 36: the
 // prefetch simply wraps to slab 0).
-__global__ __launch_bounds__(256, 2) void gconv_wide_kernel(const spb_gconv_args_t g, int ngroups, int rotate) {
+__global__ __launch_bounds__(256, 2) void gconv_wide_kernel(const spb_gconv_args_t g, int ngroups, int rotate, int delay) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* halo = smem;                             // [2 tiles][GW_TILE]; in the epilogue: output staging [128 pixels][GW_OPITCH]
   float* red = reinterpret_cast<float*>(smem + 2 * GW_TILE);   // [4 waves][128][2]
@@ -106,6 +129,7 @@ __global__ __launch_bounds__(256, 2) void gconv_wide_kernel(const spb_gconv_args
 #pragma unroll
       for (int j = 0; j < 4; ++j) cfr[j] = cp[j];
     }
+    const char* Xb = reinterpret_cast<const char*>(X) + (size_t)q.b * H * W * 256;      // uniform base + 32-bit lane offsets
 #pragma unroll
     for (int u = 0; u < GW_HU; ++u) {
       const int i = t + 256 * u;
@@ -114,43 +138,67 @@ __global__ __launch_bounds__(256, 2) void gconv_wide_kernel(const spb_gconv_args
       const int hp = (ic - p * 1600) >> 4;
       const int hy = hp / 10, hx = hp - hy * 10;
       const int sy = gw_reflect((p ? q.oy0[1] : q.oy0[0]) - 1 + hy, H), sx = gw_reflect((p ? q.ox0[1] : q.ox0[0]) - 1 + hx, W);
-      r[u] = ldraw<bf16_t>(X + ((size_t)(q.b * H + sy) * W + sx) * 128 + cv * 8);
+      r[u] = ldraw<bf16_t>(reinterpret_cast<const bf16_t*>(Xb + (unsigned)((sy * W + sx) * 256 + cv * 16)));
     }
   };
   GwGroup cur = gw_group(base + l, gpi, tpi, tiles_x);
   if (!(GWABL & 2)) issue_halo(cur);
+  if (delay) {     // experiment: the second workgroup of a CU starts half a period late (its VALU phases under the first one's MFMA loop)
+    unsigned hwid;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+    const bool late = delay > 0 ? (hwid & 1) : ((blockIdx.x >> 3) >= (gridDim.x >> 4));
+    if (late) for (int i = 0; i < (delay > 0 ? delay : -delay); ++i) __builtin_amdgcn_s_sleep(16);   // 16 x 64 cycles = 0.43 us
+  }
 
   const int prow = 4 * (li >> 3), pcol = li & 7;      // fragment f = tile (f / 4), rows (f % 4, f % 4 + 4)
   const char* hb = halo + (lq & 1) * GW_ODD + (lq >> 1) * GW_PLANE + (prow * 10 + pcol) * 16;
   if (t < 128) biasl[t] = g.bias ? g.bias[t] : 0.f;     // visible after the first barrier of the group loop
 
-  for (;;) {
-    // ---- commit the halo of `cur` (loads issued one epilogue ago)
+  int gi = 0;
+  for (;; ++gi) {
+    GW_STAMP(0);
+    // ---- commit the halo of `cur` (loads issued one epilogue ago): x * scale + shift in packed f32 pairs, ReLU as a packed
+    // signed-16-bit max on the bf16 bits; the first convolution of a residual block reads a materialised tensor (no transform)
     if (!(GWABL & 2)) {
-      float sc[8], sh[8];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        sc[2 * j] = g.coef ? cfr[j].x : 1.f; sh[2 * j] = g.coef ? cfr[j].y : 0.f;
-        sc[2 * j + 1] = g.coef ? cfr[j].z : 1.f; sh[2 * j + 1] = g.coef ? cfr[j].w : 0.f;
-      }
       char* hdst = halo + (cv & 1) * GW_ODD + (cv >> 1) * GW_PLANE;
+      if (!g.coef && !g.relu) {
 #pragma unroll
-      for (int u = 0; u < GW_HU; ++u) {
-        const int i = t + 256 * u;
-        if (i >= GW_HV) continue;
-        const int p = i >= 1600 ? 1 : 0;
-        const int hp = (i - p * 1600) >> 4;
-        float v[8];
-        cvt8(r[u], v);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const float uu = v[j] * sc[j] + sh[j];
-          v[j] = g.relu ? fmaxf(uu, 0.f) : uu;
+        for (int u = 0; u < GW_HU; ++u) {
+          const int i = t + 256 * u;
+          if (i >= GW_HV) continue;
+          const int p = i >= 1600 ? 1 : 0;
+          *reinterpret_cast<uint4*>(hdst + p * GW_TILE + ((i - p * 1600) >> 4) * 16) = r[u].u;
         }
-        st8<bf16_t>(reinterpret_cast<bf16_t*>(hdst + p * GW_TILE + hp * 16), v);
+      } else {
+        spb_f32x2 scp[4], shp[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          scp[j] = g.coef ? (spb_f32x2){cfr[j].x, cfr[j].z} : (spb_f32x2){1.f, 1.f};
+          shp[j] = g.coef ? (spb_f32x2){cfr[j].y, cfr[j].w} : (spb_f32x2){0.f, 0.f};
+        }
+        typedef short gw_s16x2 __attribute__((ext_vector_type(2)));
+        const short lo = g.relu ? (short)0 : (short)-32768;
+        const gw_s16x2 floor2 = {lo, lo};
+#pragma unroll
+        for (int u = 0; u < GW_HU; ++u) {
+          const int i = t + 256 * u;
+          if (i >= GW_HV) continue;
+          const int p = i >= 1600 ? 1 : 0;
+          const unsigned w4[4] = {r[u].u.x, r[u].u.y, r[u].u.z, r[u].u.w};
+          unsigned o4[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const spb_f32x2 x = {bf2f((bf16_t)(w4[j] & 0xffffu)), bf2f((bf16_t)(w4[j] >> 16))};
+            const spb_f32x2 y = x * scp[j] + shp[j];
+            const unsigned pk = pack_bf16x2(y[0], y[1]);
+            o4[j] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(gw_s16x2, pk), floor2));
+          }
+          *reinterpret_cast<uint4*>(hdst + p * GW_TILE + ((i - p * 1600) >> 4) * 16) = make_uint4(o4[0], o4[1], o4[2], o4[3]);
+        }
       }
     }
-    __syncthreads();
+    gw_barrier();
+    GW_STAMP(1);
 
     // ---- K loop, no barrier and no LDS store in it: wave w owns output channels 32 w .. 32 w + 31 of all 128 pixels (8 pixel
     // fragments from LDS x 2 weight fragments from its registers = 16 MFMAs per 8 ds_read_b128)
@@ -208,7 +256,9 @@ __global__ __launch_bounds__(256, 2) void gconv_wide_kernel(const spb_gconv_args
       }
       sbase = sbase + GW_PF < GW_NSTEP ? sbase + GW_PF : 0;
     }
-    __syncthreads();   // every wave is done with the halo
+    GW_STAMP(2);
+    gw_barrier();   // every wave is done with the halo
+    GW_STAMP(3);
 
     // ---- epilogue 1: accumulators -> LDS as whole pixels: a lane holds channels 32 w + 8 lq .. + 7 of its 8 pixels
     char* ost = halo;
@@ -227,37 +277,52 @@ __global__ __launch_bounds__(256, 2) void gconv_wide_kernel(const spb_gconv_args
     const bool more = ln < cnt;
     const GwGroup nxt = gw_group(base + (more ? ln : l), gpi, tpi, tiles_x);
     if (!(GWABL & 2)) issue_halo(nxt);
-    __syncthreads();
-    // ---- epilogue 2: pixel (t/16 + 16 u), chunk cv: 16-byte stores, 1 KB contiguous per wave instruction; sums of the stored values
-    float s1[8], s2[8];
+    gw_barrier();
+    // ---- epilogue 2: pixel (t/16 + 16 u), chunk cv: 16-byte stores, 1 KB contiguous per wave instruction; sums of the stored
+    // values in packed f32 pairs.  Addresses are a uniform base + a 32-bit lane offset (no 64-bit vector arithmetic).
+    spb_f32x2 s1p[4], s2p[4];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
+    for (int j = 0; j < 4; ++j) { s1p[j] = (spb_f32x2){0.f, 0.f}; s2p[j] = (spb_f32x2){0.f, 0.f}; }
     if (!(GWABL & 64)) {
+      char* Yb = reinterpret_cast<char*>(Y) + (size_t)cur.b * H * W * g.ldc * 2;        // uniform
+      const unsigned rstride = (unsigned)(2 * W * g.ldc * 2);                          // two image rows per u
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int p = u >> 2;                          // pixels 0..63 are tile 0
-        const int q = ((t >> 4) + 16 * u) & 63;
+      for (int p = 0; p < 2; ++p) {
         if (!cur.tvalid[p]) continue;
-        const uint4 o = *reinterpret_cast<const uint4*>(ost + (p * 64 + q) * GW_OPITCH + cv * 16);
-        const int oy = cur.oy0[p] + (q >> 3), ox = cur.ox0[p] + (q & 7);
-        *reinterpret_cast<uint4*>(Y + ((size_t)(cur.b * H + oy) * W + ox) * g.ldc + cv * 8) = o;
-        const unsigned w4[4] = {o.x, o.y, o.z, o.w};
+        unsigned yoff = (unsigned)(((cur.oy0[p] + (t >> 7)) * W + cur.ox0[p] + ((t >> 4) & 7)) * g.ldc * 2 + cv * 16);
+        const char* src = ost + (p * 64 + (t >> 4)) * GW_OPITCH + cv * 16;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float lo = bf2f((bf16_t)(w4[j] & 0xffffu)), hi = bf2f((bf16_t)(w4[j] >> 16));
-          s1[2 * j] += lo; s2[2 * j] += lo * lo; s1[2 * j + 1] += hi; s2[2 * j + 1] += hi * hi;
+        for (int u = 0; u < 4; ++u) {
+          const uint4 o = *reinterpret_cast<const uint4*>(src + u * 16 * GW_OPITCH);
+          *reinterpret_cast<uint4*>(Yb + yoff) = o;
+          yoff += rstride;
+          const unsigned w4[4] = {o.x, o.y, o.z, o.w};
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const spb_f32x2 x = {__uint_as_float(w4[j] << 16), __uint_as_float(w4[j] & 0xffff0000u)};
+            s1p[j] += x;
+            s2p[j] += x * x;
+          }
         }
       }
     }
     if (g.stats) {
+      // V[0..7] = sums of channels cv*8 + 0..7, V[8..15] = sums of squares; after the two swap levels row k of Q[i] holds V[4 i + k]
+      float V[16];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const float a1 = xor32_sum(xor16_sum(s1[j])), a2 = xor32_sum(xor16_sum(s2[j]));   // over the 4 pixels of a wave instruction
-        if (lane < 16) { red[(wave * 128 + cv * 8 + j) * 2] = a1; red[(wave * 128 + cv * 8 + j) * 2 + 1] = a2; }
-      }
+      for (int j = 0; j < 4; ++j) { V[2 * j] = s1p[j][0]; V[2 * j + 1] = s1p[j][1]; V[8 + 2 * j] = s2p[j][0]; V[9 + 2 * j] = s2p[j][1]; }
+      float P[8], Q[4];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) P[i] = gw_swap16_add(V[2 * i], V[2 * i + 1]);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) Q[i] = gw_swap32_add(P[2 * i], P[2 * i + 1]);
+      float* rw = red + (wave * 128 + cv * 8 + lq) * 2;       // lane (row lq): channels cv*8 + lq and cv*8 + 4 + lq
+      *reinterpret_cast<float2*>(rw) = make_float2(Q[0], Q[2]);
+      *reinterpret_cast<float2*>(rw + 8) = make_float2(Q[1], Q[3]);
     }
-    __syncthreads();   // the staging area is read out (the next commit overwrites it); red is complete
+    gw_barrier();   // the staging area is read out (the next commit overwrites it); red is complete
     if (g.stats) atomicAdd(g.stats + (size_t)cur.b * 256 + t, red[t] + red[256 + t] + red[512 + t] + red[768 + t]);
+    GW_STAMP(4);
     if (!more) break;
     l = ln;
     cur = nxt;
@@ -287,6 +352,8 @@ extern "C" int spb_gconv_wide_pack(const void* w, void* packed, spb_stream_t str
   return 0;
 }
 
+static int g_gw_delay = 0;
+extern "C" int spb_debug_set_gconv_wide_delay(int n) { g_gw_delay = n; return 0; }
 static int g_gw_rot = 1;     // workgroups enter the weight cycle at staggered steps
 extern "C" int spb_debug_set_gconv_wide_rotate(int on) { g_gw_rot = on; return 0; }
 static int g_gw_wgs = 512;   // persistent workgroups: two per CU
@@ -306,7 +373,7 @@ extern "C" int spb_gconv_wide(int dtype, const spb_gconv_args_t* a, spb_stream_t
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gconv_wide_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     once = true;
   }
-  hipLaunchKernelGGL(gconv_wide_kernel, dim3((unsigned)nwg), dim3(256), lds, (hipStream_t)stream, *a, ngroups, g_gw_rot);
+  hipLaunchKernelGGL(gconv_wide_kernel, dim3((unsigned)nwg), dim3(256), lds, (hipStream_t)stream, *a, ngroups, g_gw_rot, g_gw_delay);
   SPB_CHECK_LAUNCH();
   return 0;
 }
