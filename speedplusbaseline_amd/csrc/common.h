@@ -320,4 +320,8 @@ __device__ __forceinline__ void dma16(const void* gsrc, unsigned lds_base) {
 __device__ __forceinline__ unsigned lds_addr(const void* p) {
   return (unsigned)(size_t)(const __attribute__((address_space(3))) char*)p;
 }
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt: every load prefetched across it and
+// every store issued before it costs its full round trip at the barrier.  For workgroups whose threads talk through LDS alone
+// (global data only ever reaches LDS through registers, i.e. behind its own data dependency).
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }

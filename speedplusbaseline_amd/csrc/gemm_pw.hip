@@ -225,7 +225,7 @@ __global__ __launch_bounds__(256, (RF == 1 && sizeof(T) == 2) ? (((BK == 64 && P
       ecoef[c] = sc; ecoef[BN + c] = sh;
     }
   }
-  __syncthreads();  // coefficients visible
+  lds_barrier();  // coefficients visible
   SPB_TS(1);
 
   for (int mt = lid / NT; mt < MT; mt += GM) {
@@ -238,16 +238,16 @@ __global__ __launch_bounds__(256, (RF == 1 && sizeof(T) == 2) ? (((BK == 64 && P
 
     for (int kt = 0; kt < KT; kt += 2) {
       STORE_TILE(0, m0, kt);
-      __syncthreads();
+      lds_barrier();
       if (kt + 2 < KT) LOAD_TILE(0, m0, kt + 2);
       MMA_TILE();
-      __syncthreads();
+      lds_barrier();
       if (kt + 1 < KT) {
         STORE_TILE(1, m0, kt + 1);
-        __syncthreads();
+        lds_barrier();
         if (kt + 3 < KT) LOAD_TILE(1, m0, kt + 3);
         MMA_TILE();
-        __syncthreads();
+        lds_barrier();
       }
     }
 
@@ -276,7 +276,7 @@ __global__ __launch_bounds__(256, (RF == 1 && sizeof(T) == 2) ? (((BK == 64 && P
 #pragma unroll
         for (int r = 0; r < 4; ++r)
           Os[(w * 16 * RF + i * 16 + lq * 4 + r) * LDO + j * 16 + li] = from_f<T>(acc[i][j][r]);
-    __syncthreads();
+    lds_barrier();
 
     // ---- coalesced epilogue: 16-byte vectors along the channel axis
     if (colok) {
@@ -321,7 +321,7 @@ __global__ __launch_bounds__(256, (RF == 1 && sizeof(T) == 2) ? (((BK == 64 && P
         }
       }
     }
-    __syncthreads();
+    lds_barrier();
     SPB_TS(3);
   }
 #undef LOAD_TILE
@@ -336,7 +336,7 @@ __global__ __launch_bounds__(256, (RF == 1 && sizeof(T) == 2) ? (((BK == 64 && P
       Rs[vrow0 * BN + vcol * 8 + j] = s1[j];
       Rs[VR * BN + vrow0 * BN + vcol * 8 + j] = s2[j];
     }
-    __syncthreads();
+    lds_barrier();
     if (t < 2 * BN) {
       const int which = t / BN, c = t % BN;
       float s = 0.f;
@@ -741,7 +741,7 @@ __global__ __launch_bounds__(256) void pw_wgrad_kernel(const spb_wgrad_args_t g,
     if (k0 + c < K) bn_fwd_coef(g.pro_a, k0 + c, sc, sh);
     ca[0][c] = sc; ca[1][c] = sh;
   }
-  __syncthreads();
+  lds_barrier();
 
   const T* Gg = reinterpret_cast<const T*>(g.G);
   const T* Zg = reinterpret_cast<const T*>(g.Zn);
@@ -791,7 +791,7 @@ __global__ __launch_bounds__(256) void pw_wgrad_kernel(const spb_wgrad_args_t g,
         v[j] = okk ? act_fwd(xx[j] * ca[0][cv * 8 + j] + ca[1][cv * 8 + j], g.pro_a.act, g.pro_a.slope) : 0.f;
       st8<T>(Xs + r * LD + cv * 8, v);
     }
-    __syncthreads();
+    lds_barrier();
     if (mb + WM < mend) WG_LOAD(mb + WM);
     if constexpr (sizeof(T) == 2) {
 #pragma unroll
@@ -833,7 +833,7 @@ __global__ __launch_bounds__(256) void pw_wgrad_kernel(const spb_wgrad_args_t g,
             acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(pf[a], qf[b], acc[a][b], 0, 0, 0);
       }
     }
-    __syncthreads();
+    lds_barrier();
   }
 #undef WG_LOAD
 

@@ -212,17 +212,17 @@ __global__ __launch_bounds__(256) void gconv_kernel(const spb_gconv_args_t g, in
     int oy0[PXG], ox0[PXG];
     bool tvalid[PXG];
     tile_origin(ti, oy0, ox0, tvalid);
-    __syncthreads();   // previous tile's taps are done with the halo (first pass: coefficient / weight tables written)
+    lds_barrier();   // previous tile's taps are done with the halo (first pass: coefficient / weight tables written)
     // ---- stage the input halo(s)
     if constexpr (PRE) {
       if (!(GABL & 2)) halo_commit<PSU>(g, hregs, halo, cf);
-      __syncthreads();
+      lds_barrier();
       int oyn[PXG], oxn[PXG]; bool tvn[PXG];                    // next tile's halo: in flight during this tile's taps and stores
       tile_origin(ti + 1 < tpw ? ti + 1 : ti, oyn, oxn, tvn);   // (clamped, no branch around the loads: the last one is redundant)
       halo_issue<PXG, PSU>(g, X, hregs, b, oyn, oxn, HT, LDP, Hu, Wu, st, up, pad, t);
     } else {
       stage_halo<PXG, 4>(g, X, halo, cf, b, oy0, ox0, HT, LDP, Hu, Wu, st, up, pad, t);
-      __syncthreads();
+      lds_barrier();
     }
     // ---- K loop: taps x 32-channel chunks.  lane (li, lq): pixel li of this wave's 2x8 strip, channels lq*8..+7
     f32x4_t acc[PXG][NB];
@@ -352,7 +352,7 @@ __global__ __launch_bounds__(256) void gconv_kernel(const spb_gconv_args_t g, in
       }
   }
   if (g.stats) {   // 4 waves -> one atomic per (image, channel, moment) and workgroup
-    __syncthreads();
+    lds_barrier();
     for (int i = t; i < NB * 16 * 2; i += 256) {
       const int co = i >> 1;
       if (co < Cout)
@@ -439,7 +439,7 @@ __global__ __launch_bounds__(256) void gconv_up2_kernel(const spb_gconv_args_t g
       tr = tvalid[p] ? tr : tpi - 1;
       oy0[p] = (tr / tiles_x) * 8; ox0[p] = (tr % tiles_x) * 8;
     }
-    __syncthreads();   // previous tile's taps are done with the halo (first pass: coefficient / weight tables written)
+    lds_barrier();   // previous tile's taps are done with the halo (first pass: coefficient / weight tables written)
     {                  // ---- low-resolution halo(s): 6x6 pixels per tile, index clamped, normalised + activated on the way in
       const int per = HT * HT * CV, total = PXG * per;
       for (int i0 = t; i0 < total; i0 += 256 * SU) {
@@ -479,7 +479,7 @@ __global__ __launch_bounds__(256) void gconv_up2_kernel(const spb_gconv_args_t g
         }
       }
     }
-    __syncthreads();
+    lds_barrier();
     f32x4_t acc[PXG][NB];
 #pragma unroll
     for (int p = 0; p < PXG; ++p)
@@ -603,7 +603,7 @@ __global__ __launch_bounds__(256) void gconv_up2_kernel(const spb_gconv_args_t g
           red[(wave * NB * 16 + co0 + nb * 4 + e) * 2 + 1] = a2;
         }
       }
-    __syncthreads();
+    lds_barrier();
     for (int i = t; i < NB * 16 * 2; i += 256) {
       const int co = i >> 1;
       if (co < Cout)
@@ -703,12 +703,12 @@ __global__ __launch_bounds__(256, PXG >= 4 ? 1 : 2) void gconv_slab_kernel(const
 #pragma unroll
     for (int j = 0; j < SPT; ++j)
       sreg[d * SPT + j] = *reinterpret_cast<const u32x4_t*>(Wg + SLAB_OFF(srow[j], d, spart[j]));
-  __syncthreads();
+  lds_barrier();
   // ---- stage the four input halos
   if (!(GABL & 2)) stage_halo<PXG, SLAB_SU>(g, X, halo, cf, b, oy0, ox0, HT, LDP, Hu, Wu, st, up, pad, t);
 #pragma unroll
   for (int j = 0; j < SPT; ++j) *reinterpret_cast<u32x4_t*>(slab + sslot[j]) = sreg[j];
-  __syncthreads();
+  lds_barrier();
 
   const int prow = wave * 2 + (li >> 3), pcol = li & 7;
   const bf16_t* hbase = halo + ((prow * st) * HT + pcol * st) * LDP + lq * 8;
@@ -753,7 +753,7 @@ __global__ __launch_bounds__(256, PXG >= 4 ? 1 : 2) void gconv_slab_kernel(const
         for (int j = 0; j < SPT; ++j)
           sreg[d * SPT + j] = *reinterpret_cast<const u32x4_t*>(Wg + SLAB_OFF(srow[j], sf, spart[j]));
       }
-      if (!(GABL & 16)) __syncthreads();
+      if (!(GABL & 16)) lds_barrier();
       if (++cc == nch) { cc = 0; if (++kx == KH) { kx = 0; ++ky; } }
     }
   }
@@ -800,7 +800,7 @@ __global__ __launch_bounds__(256, PXG >= 4 ? 1 : 2) void gconv_slab_kernel(const
       }
   }
   if (g.stats) {
-    __syncthreads();
+    lds_barrier();
     for (int i = t; i < ROWS * 2; i += 256)
       atomicAdd(g.stats + ((size_t)b * Cout + (i >> 1)) * 2 + (i & 1),
                 red[i] + red[ROWS * 2 + i] + red[2 * ROWS * 2 + i] + red[3 * ROWS * 2 + i]);
@@ -838,7 +838,7 @@ __global__ __launch_bounds__(256) void conv9_band_kernel(const spb_gconv_args_t 
     if (r < Cout) u = *reinterpret_cast<const uint4*>(Wg + (size_t)r * KK * 32 + v * 8);
     *reinterpret_cast<uint4*>(wl + r * LDW + v * 8) = u;
   }
-  __syncthreads();
+  lds_barrier();
   // halo: HR x HW_ pixels x 4 channel vectors, reflection + instance norm + style affine + ReLU on the way in, 5 loads in flight
   constexpr int total = HR * HW_ * 4;
   for (int i0 = t; i0 < total; i0 += 256 * 5) {
@@ -866,7 +866,7 @@ __global__ __launch_bounds__(256) void conv9_band_kernel(const spb_gconv_args_t 
       st8<bf16_t>(halo + dst[u], v);
     }
   }
-  __syncthreads();
+  lds_barrier();
   // wave w: rows 2w, 2w+1 x two 16-column groups
   f32x4_t acc[4];
 #pragma unroll
@@ -912,7 +912,7 @@ __global__ __launch_bounds__(256) void conv9_band_kernel(const spb_gconv_args_t 
       const float a1 = row16_sum(s1[e]), a2 = row16_sum(s2[e]);
       if (lane == 0) { red[(wave * 4 + e) * 2] = a1; red[(wave * 4 + e) * 2 + 1] = a2; }
     }
-    __syncthreads();
+    lds_barrier();
     if (t < Cout * 2)
       atomicAdd(g.stats + (size_t)b * Cout * 2 + t, red[t] + red[8 + t] + red[16 + t] + red[24 + t]);
   }
@@ -954,7 +954,7 @@ __global__ __launch_bounds__(256) void conv9_kxrows_kernel(const spb_gconv_args_
     if (r < 27 && co < Cout) u = *reinterpret_cast<const uint4*>(Wg + ((size_t)(co * 9 + ky) * 9 + kx) * 32 + v * 8);
     *reinterpret_cast<uint4*>(wl + (ky * 32 + r) * LDWK + v * 8) = u;
   }
-  __syncthreads();
+  lds_barrier();
   constexpr int total = HR * HW_ * 4;
   constexpr int SUK = (total + 255) / 256 <= 12 ? (total + 255) / 256 : 6;   // all of a thread's halo loads in ONE round trip when they fit
   for (int i0 = t; i0 < total; i0 += 256 * SUK) {
@@ -982,7 +982,7 @@ __global__ __launch_bounds__(256) void conv9_kxrows_kernel(const spb_gconv_args_
       st8<bf16_t>(halo + dst[u], v);
     }
   }
-  __syncthreads();
+  lds_barrier();
   // wave w: output rows w*C9K_RW ..; per row four 16-column groups of INPUT columns x two row fragments
   f32x4_t acc[C9K_RW][4][2];
 #pragma unroll
@@ -1005,7 +1005,7 @@ __global__ __launch_bounds__(256) void conv9_kxrows_kernel(const spb_gconv_args_
         acc[r][q][1] = SPB_MFMA16(a1, bf, acc[r][q][1]);
       }
   }
-  __syncthreads();                                                 // everyone is done with the halo: it becomes P
+  lds_barrier();                                                 // everyone is done with the halo: it becomes P
   float* P = reinterpret_cast<float*>(halo);                       // [8 rows][32 (kx, co)][64 input columns]
 #pragma unroll
   for (int r = 0; r < C9K_RW; ++r)
@@ -1015,7 +1015,7 @@ __global__ __launch_bounds__(256) void conv9_kxrows_kernel(const spb_gconv_args_
       for (int f = 0; f < 2; ++f)
 #pragma unroll
         for (int e = 0; e < 4; ++e) P[((wave * C9K_RW + r) * 32 + f * 16 + lq * 4 + e) * 64 + q * 16 + li] = acc[r][q][f][e];
-  __syncthreads();
+  lds_barrier();
   // lane = output column (56 of 64 lanes), every row of this wave: y[x][co] = sum_kx P[(kx, co)][x + kx]
   float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
   if (lane < C9K_W) {
@@ -1044,7 +1044,7 @@ __global__ __launch_bounds__(256) void conv9_kxrows_kernel(const spb_gconv_args_
       const float a1 = wave_sum(s1[e]), a2 = wave_sum(s2[e]);
       if (lane == 0) { red[(wave * 4 + e) * 2] = a1; red[(wave * 4 + e) * 2 + 1] = a2; }
     }
-    __syncthreads();
+    lds_barrier();
     if (t < Cout * 2)
       atomicAdd(g.stats + (size_t)b * Cout * 2 + t, red[t] + red[8 + t] + red[16 + t] + red[24 + t]);
   }
@@ -1105,7 +1105,7 @@ __global__ __launch_bounds__(256) void conv9_rgb_kernel(const float* __restrict_
     for (int u = 0; u < 6; ++u)
       if (dst[u] >= 0) *reinterpret_cast<uint2*>(xs + dst[u]) = make_uint2(pack_bf16x2(v[u][0], v[u][1]), pack_bf16x2(v[u][2], 0.f));
   }
-  __syncthreads();
+  lds_barrier();
   float s1[2][4], s2[2][4];
 #pragma unroll
   for (int cb = 0; cb < 2; ++cb)
@@ -1156,7 +1156,7 @@ __global__ __launch_bounds__(256) void conv9_rgb_kernel(const float* __restrict_
         const float a1 = row16_sum(s1[cb][e]), a2 = row16_sum(s2[cb][e]);
         if (li == 0) { red[wave * 64 + (cb * 16 + lq * 4 + e) * 2] = a1; red[wave * 64 + (cb * 16 + lq * 4 + e) * 2 + 1] = a2; }
       }
-    __syncthreads();
+    lds_barrier();
     if (threadIdx.x < 64)
       atomicAdd(stats + (size_t)b * 64 + threadIdx.x,
                 red[threadIdx.x] + red[64 + threadIdx.x] + red[128 + threadIdx.x] + red[192 + threadIdx.x]);
