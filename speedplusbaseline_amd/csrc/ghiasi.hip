@@ -30,6 +30,25 @@ namespace {
 
 __device__ __forceinline__ int reflecti(int i, int n) { i = i < 0 ? -i : i; return i >= n ? 2 * n - 2 - i : i; }
 
+// Halo vector index -> (tile p, halo pixel hp, row hy, column hx, channel chunk cv) without integer division by run-time values
+// (each one is ~35 instructions on this ISA; four of them per 16-byte vector were most of the staging cost of the narrow
+// layers): Cin / 8 is a power of two, p comes from <= 3 compares, the row from a float multiply (exact for hp < 2^20 / HT).
+struct HaloIdx { int p, hp, hy, hx, cv; };
+template <int PXG>
+__device__ __forceinline__ HaloIdx halo_split(int ic, int cvs, int HT) {
+  HaloIdx h;
+  const int hh = HT * HT;
+  const int hpp = ic >> cvs;
+  h.cv = ic & ((1 << cvs) - 1);
+  h.p = 0;
+#pragma unroll
+  for (int q = 1; q < PXG; ++q) h.p += hpp >= q * hh ? 1 : 0;
+  h.hp = hpp - h.p * hh;
+  h.hy = (int)(((float)h.hp + 0.5f) * (1.0f / (float)HT));
+  h.hx = h.hp - h.hy * HT;
+  return h;
+}
+
 // Stage `count` halo vectors (8 channels each) of PXG tiles: upsample (nearest), reflect, normalise + activate, bf16.
 // Loads are issued SU at a time before any of them is consumed (a load -> transform -> store loop exposed one L2 round
 // trip per iteration: 25 iterations x ~1.5 us per workgroup in the 128-channel layers).
@@ -37,7 +56,7 @@ template <int PXG, int SU>
 __device__ __forceinline__ void stage_halo(const spb_gconv_args_t& g, const bf16_t* X, bf16_t* halo, const float* cf, int b,
                                            const int* oy0, const int* ox0, int HT, int LDP, int Hu, int Wu, int st, int up,
                                            int pad, int t) {
-  const int Cin = g.Cin, CV = Cin >> 3;
+  const int Cin = g.Cin, CV = Cin >> 3, cvsh = __ffs(CV) - 1;
   const int per = HT * HT * CV, total = PXG * per;
   for (int i0 = t; i0 < total; i0 += 256 * SU) {
     Raw8<bf16_t> r[SU];
@@ -46,13 +65,12 @@ __device__ __forceinline__ void stage_halo(const spb_gconv_args_t& g, const bf16
     for (int u = 0; u < SU; ++u) {
       const int i = i0 + 256 * u;
       const int ic = i < total ? i : total - 1;
-      const int p = ic / per, ii = ic % per;
-      const int hp = ii / CV, cv = ii % CV;
-      const int hy = hp / HT, hx = hp % HT;
+      const HaloIdx hi = halo_split<PXG>(ic, cvsh, HT);
+      const int p = hi.p, hp = hi.hp, cv = hi.cv, hy = hi.hy, hx = hi.hx;
       int oyp = oy0[0], oxp = ox0[0];       // select, not oy0[p]: a dynamically indexed array lives in scratch memory
 #pragma unroll
       for (int q = 1; q < PXG; ++q) { oyp = p == q ? oy0[q] : oyp; oxp = p == q ? ox0[q] : oxp; }
-      const int sy = reflecti(oyp * st - pad + hy, Hu) / up, sx = reflecti(oxp * st - pad + hx, Wu) / up;
+      const int sy = reflecti(oyp * st - pad + hy, Hu) >> (up - 1), sx = reflecti(oxp * st - pad + hx, Wu) >> (up - 1);   // up = 1 | 2
       r[u] = ldraw<bf16_t>(X + ((size_t)(b * g.Hin + sy) * g.Win + sx) * Cin + cv * 8);
       dst[u] = i < total ? (p * HT * HT + hp) * LDP + cv * 8 : -1;
       cvs[u] = cv;
@@ -85,19 +103,18 @@ template <int SU> struct HaloRegs { Raw8<bf16_t> r[SU]; int dst[SU]; int cvs[SU]
 template <int PXG, int SU>
 __device__ __forceinline__ void halo_issue(const spb_gconv_args_t& g, const bf16_t* X, HaloRegs<SU>& h, int b, const int* oy0,
                                            const int* ox0, int HT, int LDP, int Hu, int Wu, int st, int up, int pad, int t) {
-  const int Cin = g.Cin, CV = Cin >> 3;
+  const int Cin = g.Cin, CV = Cin >> 3, cvsh = __ffs(CV) - 1;
   const int per = HT * HT * CV, total = PXG * per;
 #pragma unroll
   for (int u = 0; u < SU; ++u) {
     const int i = t + 256 * u;
     const int ic = i < total ? i : total - 1;
-    const int p = ic / per, ii = ic % per;
-    const int hp = ii / CV, cv = ii % CV;
-    const int hy = hp / HT, hx = hp % HT;
+    const HaloIdx hi = halo_split<PXG>(ic, cvsh, HT);
+    const int p = hi.p, hp = hi.hp, cv = hi.cv, hy = hi.hy, hx = hi.hx;
     int oyp = oy0[0], oxp = ox0[0];
 #pragma unroll
     for (int q = 1; q < PXG; ++q) { oyp = p == q ? oy0[q] : oyp; oxp = p == q ? ox0[q] : oxp; }
-    const int sy = reflecti(oyp * st - pad + hy, Hu) / up, sx = reflecti(oxp * st - pad + hx, Wu) / up;
+    const int sy = reflecti(oyp * st - pad + hy, Hu) >> (up - 1), sx = reflecti(oxp * st - pad + hx, Wu) >> (up - 1);   // up = 1 | 2
     h.r[u] = ldraw<bf16_t>(X + ((size_t)(b * g.Hin + sy) * g.Win + sx) * Cin + cv * 8);
     h.dst[u] = i < total ? (p * HT * HT + hp) * LDP + cv * 8 : -1;
     h.cvs[u] = cv;
@@ -371,7 +388,10 @@ __global__ __launch_bounds__(256) void gconv_kernel(const spb_gconv_args_t g, in
 // is 6x6 low-resolution pixels instead of 10x10 upsampled ones, and no pixel is staged twice.  A wave owns one phase: its 16
 // pixels are the 4x4 low-resolution positions of the tile, its A operand that phase's weights (packed by the host side:
 // [phase][Cout][tap 2x2][Cin], sums taken in float32).
-template <int NB, bool WLDS, int PXG>
+// NV > 0: the halo vectors of a tile group are exactly <= NV per thread and the NEXT group's are loaded into registers right
+// after this group's halo is committed (in flight during the matrix-core loop and the stores).  Without it every group exposed
+// one L2 / HBM round trip: 5.2 us per 128-pixel group of the 64 -> 32 layer for 0.43 us of matrix-core work (round 3).
+template <int NB, bool WLDS, int PXG, int NV = 0>
 __global__ __launch_bounds__(256) void gconv_up2_kernel(const spb_gconv_args_t g, int tpw) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int PD = 2, HT = 6, KT = 4, SU = 4;
@@ -409,7 +429,7 @@ __global__ __launch_bounds__(256) void gconv_up2_kernel(const spb_gconv_args_t g
   }
   const bf16_t* X = reinterpret_cast<const bf16_t*>(g.X);
   bf16_t* Y = reinterpret_cast<bf16_t*>(g.Y);
-  const int CV = Cin >> 3;
+  const int CV = Cin >> 3, cvsh = __ffs(CV) - 1;
   const int iy = li >> 2, ix = li & 3;                        // this lane's low-resolution position in the 4x4 block
   const bf16_t* hbase = halo + ((iy + py) * HT + (ix + px)) * LDP + lq * 8;
   const int nch = Cin >> 5;
@@ -429,18 +449,67 @@ __global__ __launch_bounds__(256) void gconv_up2_kernel(const spb_gconv_args_t g
 #pragma unroll
     for (int e = 0; e < 4; ++e) { s1[nb][e] = 0.f; s2[nb][e] = 0.f; }
 
+  auto tile_origin = [&](int ti_, int* oy0_, int* ox0_, bool* tv_) {
+#pragma unroll
+    for (int p = 0; p < PXG; ++p) {
+      int tr = (grp0 + ti_) * PXG + p;
+      tv_[p] = tr < tpi;
+      tr = tv_[p] ? tr : tpi - 1;
+      oy0_[p] = (tr / tiles_x) * 8; ox0_[p] = (tr % tiles_x) * 8;
+    }
+  };
+  Raw8<bf16_t> pre[NV > 0 ? NV : 1];
+  auto pre_issue = [&](int ti_) {
+    int oyq[PXG], oxq[PXG]; bool tvq[PXG];
+    tile_origin(ti_, oyq, oxq, tvq);
+    const int per = HT * HT * CV, total = PXG * per;
+#pragma unroll
+    for (int u = 0; u < (NV > 0 ? NV : 1); ++u) {
+      const int i = t + 256 * u;
+      const int ic = i < total ? i : total - 1;
+      const int hpp = ic >> cvsh, cv = ic & (CV - 1);
+      const int p = hpp / (HT * HT), hp = hpp - p * (HT * HT);      // HT is a compile-time 6 here
+      const int hy = hp / HT, hx = hp % HT;
+      int oyp = oyq[0], oxp = oxq[0];
+#pragma unroll
+      for (int q = 1; q < PXG; ++q) { oyp = p == q ? oyq[q] : oyp; oxp = p == q ? oxq[q] : oxp; }
+      const int sy = min(max((oyp >> 1) - 1 + hy, 0), g.Hin - 1), sx = min(max((oxp >> 1) - 1 + hx, 0), g.Win - 1);
+      pre[u] = ldraw<bf16_t>(X + ((size_t)(b * g.Hin + sy) * g.Win + sx) * Cin + cv * 8);
+    }
+  };
+  auto pre_commit = [&]() {
+    const int per = HT * HT * CV, total = PXG * per;
+#pragma unroll
+    for (int u = 0; u < (NV > 0 ? NV : 1); ++u) {
+      const int i = t + 256 * u;
+      if (i >= total) continue;
+      const int hpp = i >> cvsh, cv = i & (CV - 1);
+      const int p = hpp / (HT * HT), hp = hpp - p * (HT * HT);
+      float v[8], sc[8], sh[8];
+      cvt8(pre[u], v);
+#pragma unroll
+      for (int j = 0; j < 8; j += 4) {
+        *reinterpret_cast<float4*>(sc + j) = *reinterpret_cast<const float4*>(cf + cv * 8 + j);
+        *reinterpret_cast<float4*>(sh + j) = *reinterpret_cast<const float4*>(cf + Cin + cv * 8 + j);
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float uu = v[j] * sc[j] + sh[j];
+        v[j] = g.relu ? fmaxf(uu, 0.f) : uu;
+      }
+      st8<bf16_t>(halo + (p * HT * HT + hp) * LDP + cv * 8, v);
+    }
+  };
+  if constexpr (NV > 0) pre_issue(0);
+
   for (int ti = 0; ti < tpw; ++ti) {
     int oy0[PXG], ox0[PXG];
     bool tvalid[PXG];
-#pragma unroll
-    for (int p = 0; p < PXG; ++p) {
-      int tr = (grp0 + ti) * PXG + p;
-      tvalid[p] = tr < tpi;
-      tr = tvalid[p] ? tr : tpi - 1;
-      oy0[p] = (tr / tiles_x) * 8; ox0[p] = (tr % tiles_x) * 8;
-    }
+    tile_origin(ti, oy0, ox0, tvalid);
     lds_barrier();   // previous tile's taps are done with the halo (first pass: coefficient / weight tables written)
-    {                  // ---- low-resolution halo(s): 6x6 pixels per tile, index clamped, normalised + activated on the way in
+    if constexpr (NV > 0) {
+      pre_commit();
+    } else {           // ---- low-resolution halo(s): 6x6 pixels per tile, index clamped, normalised + activated on the way in
       const int per = HT * HT * CV, total = PXG * per;
       for (int i0 = t; i0 < total; i0 += 256 * SU) {
         Raw8<bf16_t> r[SU];
@@ -449,8 +518,8 @@ __global__ __launch_bounds__(256) void gconv_up2_kernel(const spb_gconv_args_t g
         for (int u = 0; u < SU; ++u) {
           const int i = i0 + 256 * u;
           const int ic = i < total ? i : total - 1;
-          const int p = ic / per, ii = ic % per;
-          const int hp = ii / CV, cv = ii % CV;
+          const int hpp = ic >> cvsh, cv = ic & (CV - 1);
+          const int p = hpp / (HT * HT), hp = hpp - p * (HT * HT);
           const int hy = hp / HT, hx = hp % HT;
           int oyp = oy0[0], oxp = ox0[0];
 #pragma unroll
@@ -480,6 +549,7 @@ __global__ __launch_bounds__(256) void gconv_up2_kernel(const spb_gconv_args_t g
       }
     }
     lds_barrier();
+    if constexpr (NV > 0) pre_issue(ti + 1 < tpw ? ti + 1 : ti);   // clamped, no branch around the loads: the last one is redundant
     f32x4_t acc[PXG][NB];
 #pragma unroll
     for (int p = 0; p < PXG; ++p)
@@ -1336,6 +1406,9 @@ extern "C" int spb_gconv(int dtype, const spb_gconv_args_t* a, spb_stream_t stre
   return 0;
 }
 
+static int g_up2_prefetch = 1;   // phase kernels: next tile group's halo loads in flight during the current group
+extern "C" int spb_debug_set_gconv_up2_prefetch(int on) { g_up2_prefetch = on; return 0; }
+
 // a->W: phase weights [4][Cout][4][Cin] (Ghiasi._pack builds them); a->upsample must be 2, a->stride 1, a->KH 3
 extern "C" int spb_gconv_up2(int dtype, const spb_gconv_args_t* a, spb_stream_t stream) {
   if (!a || !a->X || !a->W || !a->Y) return SPB_E_ARG;
@@ -1358,18 +1431,25 @@ extern "C" int spb_gconv_up2(int dtype, const spb_gconv_args_t* a, spb_stream_t 
     if (gpi % d == 0 && (long long)a->B * (gpi / d) >= 1024) tpw = d;
   const dim3 grid((unsigned)(a->B * (gpi / tpw)));
   hipStream_t s = (hipStream_t)stream;
-#define U_(NB_, WL_, PX_)                                                                                            \
+#define U_(NB_, WL_, PX_, NV_)                                                                                       \
   {                                                                                                                  \
     static bool once = false;                                                                                        \
     if (!once) {                                                                                                     \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gconv_up2_kernel<NB_, WL_, PX_>),                     \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gconv_up2_kernel<NB_, WL_, PX_, NV_>),                \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                             \
       once = true;                                                                                                   \
     }                                                                                                                \
-    hipLaunchKernelGGL((gconv_up2_kernel<NB_, WL_, PX_>), grid, dim3(256), lds, s, *a, tpw);                         \
+    hipLaunchKernelGGL((gconv_up2_kernel<NB_, WL_, PX_, NV_>), grid, dim3(256), lds, s, *a, tpw);                    \
   }
-  if (NB == 2) { if (wlds) U_(2, true, 2) else U_(2, false, 4) }
-  else { if (wlds) U_(4, true, 2) else U_(4, false, 4) }
+  const int hv = pxg * 36 * (a->Cin >> 3);          // halo vectors per tile group
+  const bool pre = g_up2_prefetch && tpw > 1;
+  if (NB == 2) {
+    if (wlds) { if (pre && hv <= 768) U_(2, true, 2, 3) else U_(2, true, 2, 0) }
+    else { if (pre && hv <= 2304) U_(2, false, 4, 9) else U_(2, false, 4, 0) }
+  } else {
+    if (wlds) { if (pre && hv <= 768) U_(4, true, 2, 3) else U_(4, true, 2, 0) }
+    else { if (pre && hv <= 2304) U_(4, false, 4, 9) else U_(4, false, 4, 0) }
+  }
 #undef U_
   SPB_CHECK_LAUNCH();
   return 0;
