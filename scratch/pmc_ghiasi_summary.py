@@ -1,9 +1,9 @@
 """Style decoder: HBM traffic from two rocprofv3 PMC passes over scratch/bench_ghiasi.py (FETCH_SIZE, WRITE_SIZE; separate runs,
 --kernel-trace only; corrections as scratch/pmc_summary.py: KB counters, FETCH_SIZE doubled on gfx950, WRITE_SIZE as reported).
-bench_ghiasi.py runs 3 + 10 + 1 = 14 restyles of 48 images: per-kernel bytes per launch and the HBM bytes of ONE restyle
-(every decoder launch of it) = total / 14."""
+bench_ghiasi.py runs 3 + 10 + 2 = 15 restyles of 48 images: per-kernel bytes per launch and the HBM bytes of ONE restyle
+(every decoder launch of it) = total / 15."""
 import csv, json, re, sys, collections
-RESTYLES = 14
+RESTYLES = 15
 
 
 def short(name):
