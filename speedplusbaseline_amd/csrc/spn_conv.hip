@@ -461,13 +461,19 @@ __global__ void pack_jobs_kernel(const PackJobs jobs, int bf16) {
   }
 }
 
-bf16_t* g_zero_page = nullptr;
+// One zeroed page per device (out-of-image taps read it).  Created on the first convolution call of a device with a blocking
+// allocation + fill: make that first call outside any stream capture (every caller here warms up before capturing).
+bf16_t* g_zero_page[64] = {};
 bf16_t* zero_page() {
-  if (!g_zero_page) {
-    if (hipMalloc(reinterpret_cast<void**>(&g_zero_page), 4096) != hipSuccess) return nullptr;
-    hipMemset(g_zero_page, 0, 4096);
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  if (!g_zero_page[dev]) {
+    bf16_t* p = nullptr;
+    if (hipMalloc(reinterpret_cast<void**>(&p), 4096) != hipSuccess) return nullptr;
+    if (hipMemset(p, 0, 4096) != hipSuccess || hipDeviceSynchronize() != hipSuccess) { (void)hipFree(p); return nullptr; }
+    g_zero_page[dev] = p;
   }
-  return g_zero_page;
+  return g_zero_page[dev];
 }
 
 }  // namespace

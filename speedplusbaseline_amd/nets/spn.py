@@ -445,9 +445,10 @@ class SpacecraftPoseNet(nn.Module):
     # ---- weight / bias gradients only feed the optimizer: they are queued and run on a side stream beside the input-gradient
     #      chain (forked at a few points only -- every fork costs the launch stream an event record), joined before returning
     def _on_side(self, fns, fc=False):
-        """fc=True: the fully connected layers' weight gradients (six HBM-bound 20-50 us kernels, queued when both heads are
-        through) go to the regression head's stream, idle by then, so that the convolution weight gradients of the trunk start
-        at once on the side stream.  Not a stream of their own: launch, head, side and update stream are four, and the HIP
+        """fc=True: the fully connected layers' weight gradients (six HBM-bound 20-50 us kernels) go to the regression head's
+        stream -- its own three behind its input-gradient chain, the class head's three after the launch stream has joined that
+        chain (loss_and_grads marks its end with an event: the launch stream does not wait for any of the six) -- so that the
+        convolution weight gradients of the trunk start at once on the side stream.  Not a stream of their own: launch, head, side and update stream are four, and the HIP
         runtime multiplexes streams onto four hardware queues by default -- a fifth shared a queue with the 1.2 ms update
         and the step went from 1.72 to 2.52 ms."""
         if not fns:
@@ -495,7 +496,11 @@ class SpacecraftPoseNet(nn.Module):
 
     def _join_heads(self):
         if getattr(self, "_heads_forked", False):
-            torch.cuda.current_stream().wait_stream(self._hs)
+            if getattr(self, "_heads_marked", False):    # backward: up to the end of the forked head's input-gradient chain
+                torch.cuda.current_stream().wait_event(self._hev)
+                self._heads_marked = False
+            else:
+                torch.cuda.current_stream().wait_stream(self._hs)
             self._heads_forked = False
 
     def _run_updates(self, optimizer, jobs, B):
@@ -741,8 +746,19 @@ class SpacecraftPoseNet(nn.Module):
                         g = self._buf("g" + prev, (B, 4096), dt)
                         gT = self._buf("gT" + prev, (4096, MP), dt)
                         self._epi(B, 4096, 1, accT=acc, H=sv["h" + prev], Y=g, YT=gT, db=getattr(self, prev).bias.grad, scale=scale)
-                self._on_side(pend, fc=True)     # this head's weight gradients: forked from its own stream, beside what follows
+                if hi == 1 and getattr(self, "_heads_forked", False):
+                    # the launch stream needs the forked head's INPUT-gradient chain only: mark its end before the three
+                    # HBM-bound weight-gradient kernels (20-50 us each) are queued behind it on the same stream
+                    if getattr(self, "_hev", None) is None:
+                        self._hev = torch.cuda.Event()
+                    self._hev.record(torch.cuda.current_stream())
+                    self._heads_marked = True
+                if hi == 1:
+                    self._on_side(pend, fc=True)     # this head's weight gradients: behind its own chain, beside what follows
+                else:
+                    pend0 = pend                     # the class head's: queued after the join (they would sit in front of it)
             self._join_heads()
+            self._on_side(pend0, fc=True)
             st = _st()
             if world_size > 1:               # the class head's bucket travels first, the regression head's follows below
                 self._ddp_works.append(self._start_exchange(group, compress_bf16, self._conv_end, head2_lo, optimizer, world_size, sharded))
