@@ -23,7 +23,9 @@
 // the kernel 25 % SLOWER -- a scratch reload is a vmcnt-counted load, and vmcnt retires in order, so each reload waited for the
 // whole weight prefetch in front of it.  Two 8x8 tiles per group, 57 KB of LDS, 220 VGPRs, no scratch.
 // Measured and dropped: tile-granular work split (5 | 4 tiles per workgroup instead of 6 | 4: single-tile units pay the whole
-// staging/epilogue cost, 46 us), staggered entry into the weight cycle and a delayed second workgroup per CU (no effect).
+// staging/epilogue cost, 46 us), staggered entry into the weight cycle and a delayed second workgroup per CU (no effect), pixel
+// fragments double-buffered in registers (GW_BF2: no effect once it fits without scratch), three workgroups per CU (168 registers:
+// the remaining 104 B of scratch sit between the halo loads and serialise them -- commit 12 us, 55 us per layer).
 #include "common.h"
 
 #ifndef GW_BF2
@@ -62,6 +64,11 @@ __device__ __forceinline__ float gw_swap32_add(float a, float b) {
   asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
   return a + b;
 }
+
+// A zero the compiler cannot see through: index arithmetic that depends on it is recomputed where it is used instead of being
+// hoisted out of the group loop -- hoisted, the per-vector halo offsets (13 per thread) were spilled to scratch in the three-per-CU
+// build, and a scratch reload between two halo loads waits (vmcnt retires in order) for every load issued before it.
+__device__ __forceinline__ int gw_opaque_zero() { int z; asm volatile("s_mov_b32 %0, 0" : "=s"(z)); return z; }
 
 __device__ __forceinline__ int gw_reflect(int i, int n) { i = i < 0 ? -i : i; return i >= n ? 2 * n - 2 - i : i; }
 
@@ -129,9 +136,10 @@ __global__ __launch_bounds__(256, 2) void gconv_wide_kernel(const spb_gconv_args
       for (int j = 0; j < 4; ++j) cfr[j] = cp[j];
     }
     const char* Xb = reinterpret_cast<const char*>(X) + (size_t)q.b * H * W * 256;      // uniform base + 32-bit lane offsets
+    const int tl = t + gw_opaque_zero();
 #pragma unroll
     for (int u = 0; u < GW_HU; ++u) {
-      const int i = t + 256 * u;
+      const int i = tl + 256 * u;
       const int ic = i < GW_HV ? i : GW_HV - 1;
       const int p = ic >= 1600 ? 1 : 0;
       const int hp = (ic - p * 1600) >> 4;
@@ -159,11 +167,12 @@ __global__ __launch_bounds__(256, 2) void gconv_wide_kernel(const spb_gconv_args
     // ---- commit the halo of `cur` (loads issued one epilogue ago): x * scale + shift in packed f32 pairs, ReLU as a packed
     // signed-16-bit max on the bf16 bits; the first convolution of a residual block reads a materialised tensor (no transform)
     if (!(GWABL & 2)) {
+      const int tl = t + gw_opaque_zero();
       char* hdst = halo + (cv & 1) * GW_ODD + (cv >> 1) * GW_PLANE;
       if (!g.coef && !g.relu) {
 #pragma unroll
         for (int u = 0; u < GW_HU; ++u) {
-          const int i = t + 256 * u;
+          const int i = tl + 256 * u;
           if (i >= GW_HV) continue;
           const int p = i >= 1600 ? 1 : 0;
           *reinterpret_cast<uint4*>(hdst + p * GW_TILE + ((i - p * 1600) >> 4) * 16) = r[u].u;
@@ -180,7 +189,7 @@ __global__ __launch_bounds__(256, 2) void gconv_wide_kernel(const spb_gconv_args
         const gw_s16x2 floor2 = {lo, lo};
 #pragma unroll
         for (int u = 0; u < GW_HU; ++u) {
-          const int i = t + 256 * u;
+          const int i = tl + 256 * u;
           if (i >= GW_HV) continue;
           const int p = i >= 1600 ? 1 : 0;
           const unsigned w4[4] = {r[u].u.x, r[u].u.y, r[u].u.z, r[u].u.w};
