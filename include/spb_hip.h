@@ -410,6 +410,15 @@ typedef struct {
   void* Y;            /* [B,Hout,Wout,ldc] NHWC bf16, raw conv output (+bias) */
   float* stats;       /* [B][Cout][2] f32 accumulated: sum and sum of squares of the stored output, or NULL */
   int B, Hin, Win, Cin, Cout, KH, stride, upsample, relu, ldc;
+  /* Input transform straight from the PRODUCER's sums (replaces `coef` and the spb_in_coef launch that would fill it) when
+   * in_stats != NULL: scale = gamma * rsqrt(max(s2/n - (s1/n)^2, 0) + eps), shift = beta - (s1/n) * scale, computed once per
+   * workgroup and channel.  in_stats [B][Cin][2]; in_gamma / in_beta rows [B][in_ld] (NULL: 1 / 0); in_inv_n = 1 / (H*W of X).
+   * spb_gconv and spb_gconv_up2 honour it; spb_gconv_wide reads `coef`. */
+  const float* in_stats;
+  const float* in_gamma;
+  const float* in_beta;
+  int in_ld;
+  float in_inv_n, in_eps;
 } spb_gconv_args_t;
 /* KxK conv (K = 3 | 9), nn.ReflectionPad2d(K/2), stride 1|2, optional nearest x2 upsampling of the input
  * (torch.nn.Upsample(scale_factor=2)); Hout = Hin*upsample/stride must be a multiple of 8.  bf16 only. */
@@ -439,6 +448,11 @@ int spb_in_apply(const void* X, const float* coef, const void* res, void* Y, int
                  spb_stream_t stream);
 /* out (fp32 NCHW, 3 channels) = sigmoid(Z*scale + shift), Z NHWC bf16 with channel stride ldc (ghiasi.py:135) */
 int spb_final_sigmoid(const void* Z, const float* coef, float* out, int B, long long hw, int ldc, spb_stream_t stream);
+/* the same two with the coefficients taken from the producer's sums (arguments as spb_in_coef; no coefficient launch in between) */
+int spb_in_apply_stats(const void* X, const float* stats, const float* gamma, const float* beta, int ld, float eps, const void* res,
+                       void* Y, int B, long long hw, int C, int relu, spb_stream_t stream);
+int spb_final_sigmoid_stats(const void* Z, const float* stats, const float* gamma, const float* beta, int ld, float eps, float* out,
+                            int B, long long hw, int ldc, spb_stream_t stream);
 
 /* ---- Spacecraft Pose Network building blocks (src/nets/spn.py:37-143; loss assembly src/core/trainer.py:160-165).
  * Convolutions and fully connected layers run through spb_pwconv_gemm / spb_pwconv_wgrad on im2col'd operands; all

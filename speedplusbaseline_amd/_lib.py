@@ -51,7 +51,8 @@ class PwBwdArgs(C.Structure):
 class GconvArgs(C.Structure):
     _fields_ = [("X", vp), ("W", vp), ("bias", vp), ("coef", vp), ("Y", vp), ("stats", vp), ("B", i32), ("Hin", i32),
                 ("Win", i32), ("Cin", i32), ("Cout", i32), ("KH", i32), ("stride", i32), ("upsample", i32), ("relu", i32),
-                ("ldc", i32)]
+                ("ldc", i32), ("in_stats", vp), ("in_gamma", vp), ("in_beta", vp), ("in_ld", i32), ("in_inv_n", C.c_float),
+                ("in_eps", C.c_float)]
 
 
 class DwArgs(C.Structure):
@@ -190,6 +191,8 @@ SYMBOLS = {
     "spb_style_fc": (i32, [vp, vp, vp, vp, i32, i32, vp]),
     "spb_in_apply": (i32, [vp, vp, vp, vp, i32, i64, i32, i32, vp]),
     "spb_final_sigmoid": (i32, [vp, vp, vp, i32, i64, i32, vp]),
+    "spb_in_apply_stats": (i32, [vp, vp, vp, vp, i32, f32, vp, vp, i32, i64, i32, i32, vp]),
+    "spb_final_sigmoid_stats": (i32, [vp, vp, vp, vp, i32, f32, vp, i32, i64, i32, vp]),
     "spb_im2col": (i32, [i32, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
     "spb_im2col_rgb": (i32, [i32, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
     "spb_col2im": (i32, [i32, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp]),

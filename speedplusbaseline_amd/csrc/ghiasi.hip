@@ -30,6 +30,24 @@ namespace {
 
 __device__ __forceinline__ int reflecti(int i, int n) { i = i < 0 ? -i : i; return i >= n ? 2 * n - 2 - i : i; }
 
+// scale / shift of input channel c of image b: from the producer's sums when the caller passes them (spb_gconv_args_t.in_stats:
+// what spb_in_coef would have written, without the launch), else from the coefficient table, else identity
+__device__ __forceinline__ void in_coef_of(const float* stats, const float* gamma, const float* beta, int ld, float inv_n, float eps,
+                                           int b, int C, int c, float& sc, float& sh) {
+  const size_t i = (size_t)b * C + c;
+  const float mean = stats[i * 2] * inv_n;
+  const float var = fmaxf(stats[i * 2 + 1] * inv_n - mean * mean, 0.f);
+  const float is = rsqrtf(var + eps);
+  const float ga = gamma ? gamma[(size_t)b * ld + c] : 1.f, be = beta ? beta[(size_t)b * ld + c] : 0.f;
+  sc = ga * is;
+  sh = be - mean * ga * is;
+}
+__device__ __forceinline__ void gconv_coef(const spb_gconv_args_t& g, int b, int Cin, int c, float& sc, float& sh) {
+  sc = 1.f; sh = 0.f;
+  if (g.in_stats) in_coef_of(g.in_stats, g.in_gamma, g.in_beta, g.in_ld, g.in_inv_n, g.in_eps, b, Cin, c, sc, sh);
+  else if (g.coef) { sc = g.coef[((size_t)b * Cin + c) * 2]; sh = g.coef[((size_t)b * Cin + c) * 2 + 1]; }
+}
+
 // Halo vector index -> (tile p, halo pixel hp, row hy, column hx, channel chunk cv) without integer division by run-time values
 // (each one is ~35 instructions on this ISA; four of them per 16-byte vector were most of the staging cost of the narrow
 // layers): Cin / 8 is a power of two, p comes from <= 3 compares, the row from a float multiply (exact for hp < 2^20 / HT).
@@ -176,8 +194,8 @@ __global__ __launch_bounds__(256) void gconv_kernel(const spb_gconv_args_t g, in
   const bf16_t* Wg = reinterpret_cast<const bf16_t*>(g.W);
 
   for (int c = t; c < Cin; c += 256) {
-    float sc = 1.f, sh = 0.f;
-    if (g.coef) { sc = g.coef[((size_t)b * Cin + c) * 2]; sh = g.coef[((size_t)b * Cin + c) * 2 + 1]; }
+    float sc, sh;
+    gconv_coef(g, b, Cin, c, sc, sh);
     cf[c] = sc; cf[Cin + c] = sh;
   }
   if (WLDS) {   // Cout rows; lanes whose (permuted) row is >= Cout use a zero fragment
@@ -414,8 +432,8 @@ __global__ __launch_bounds__(256) void gconv_up2_kernel(const spb_gconv_args_t g
   const int ph = wave, py = wave >> 1, px = wave & 1;
 
   for (int c = t; c < Cin; c += 256) {
-    float sc = 1.f, sh = 0.f;
-    if (g.coef) { sc = g.coef[((size_t)b * Cin + c) * 2]; sh = g.coef[((size_t)b * Cin + c) * 2 + 1]; }
+    float sc, sh;
+    gconv_coef(g, b, Cin, c, sc, sh);
     cf[c] = sc; cf[Cin + c] = sh;
   }
   if (WLDS) {
@@ -727,8 +745,8 @@ __global__ __launch_bounds__(256, PXG >= 4 ? 1 : 2) void gconv_slab_kernel(const
   bf16_t* Y = reinterpret_cast<bf16_t*>(g.Y);
 
   for (int c = t; c < Cin; c += 256) {
-    float sc = 1.f, sh = 0.f;
-    if (g.coef) { sc = g.coef[((size_t)b * Cin + c) * 2]; sh = g.coef[((size_t)b * Cin + c) * 2 + 1]; }
+    float sc, sh;
+    gconv_coef(g, b, Cin, c, sc, sh);
     cf[c] = sc; cf[Cin + c] = sh;
   }
   for (int i = t; i < 4 * ROWS * 2; i += 256) red[i] = 0.f;
@@ -898,8 +916,8 @@ __global__ __launch_bounds__(256) void conv9_band_kernel(const spb_gconv_args_t 
   const bf16_t* Wg = reinterpret_cast<const bf16_t*>(g.W);
   bf16_t* Y = reinterpret_cast<bf16_t*>(g.Y);
   if (t < 32) {
-    float sc = 1.f, sh = 0.f;
-    if (g.coef) { sc = g.coef[((size_t)b * 32 + t) * 2]; sh = g.coef[((size_t)b * 32 + t) * 2 + 1]; }
+    float sc, sh;
+    gconv_coef(g, b, 32, t, sc, sh);
     cf[t] = sc; cf[32 + t] = sh;
   }
   for (int i = t; i < 4 * (KK * 4); i += 256) {                    // weight rows (zero rows past Cout), 16-byte granules
@@ -1013,8 +1031,8 @@ __global__ __launch_bounds__(256) void conv9_kxrows_kernel(const spb_gconv_args_
   const bf16_t* Wg = reinterpret_cast<const bf16_t*>(g.W);       // [Cout][9][9][32]
   bf16_t* Y = reinterpret_cast<bf16_t*>(g.Y);
   if (t < 32) {
-    float sc = 1.f, sh = 0.f;
-    if (g.coef) { sc = g.coef[((size_t)b * 32 + t) * 2]; sh = g.coef[((size_t)b * 32 + t) * 2 + 1]; }
+    float sc, sh;
+    gconv_coef(g, b, 32, t, sc, sh);
     cf[t] = sc; cf[32 + t] = sh;
   }
   for (int i = t; i < 9 * 32 * 4; i += 256) {                      // 16-byte granules of [ky][row][32 channels]
@@ -1279,6 +1297,52 @@ __global__ void in_apply_kernel(const bf16_t* X, const float* coef, const bf16_t
   st8<bf16_t>(Y + i * 8, v);
 }
 
+// The same with the coefficients from the producer's sums: a thread keeps ONE channel chunk (8 scale / shift pairs, computed once)
+// and walks IAS_PX pixels of one image with it.  grid (ceil(hw / (rows-per-block)), B), block 256 = 256 / CV pixel lanes x CV chunks.
+constexpr int IAS_PX = 8;
+__global__ void in_apply_stats_kernel(const bf16_t* X, const float* stats, const float* gamma, const float* beta, int ld, float inv_n,
+                                      float eps, const bf16_t* res, bf16_t* Y, long long hw, int C, int relu) {
+  const int CV = C >> 3, cvs = __ffs(CV) - 1;
+  const int t = threadIdx.x, cv = t & (CV - 1), pl = t >> cvs, npl = 256 >> cvs;     // CV is a power of two <= 256
+  const int b = blockIdx.y;
+  float sc[8], sh[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) in_coef_of(stats, gamma, beta, ld, inv_n, eps, b, C, cv * 8 + j, sc[j], sh[j]);
+  const long long p0 = (long long)blockIdx.x * npl * IAS_PX + pl;
+  const bf16_t* Xb = X + (size_t)b * hw * C;
+  const bf16_t* Rb = res ? res + (size_t)b * hw * C : nullptr;
+  bf16_t* Yb = Y + (size_t)b * hw * C;
+#pragma unroll
+  for (int u = 0; u < IAS_PX; ++u) {
+    const long long p = p0 + (long long)u * npl;
+    if (p >= hw) continue;
+    float v[8], r[8];
+    ld8<bf16_t>(Xb + p * C + cv * 8, v);
+    if (Rb) ld8<bf16_t>(Rb + p * C + cv * 8, r);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float uu = v[j] * sc[j] + sh[j];
+      uu = relu ? fmaxf(uu, 0.f) : uu;
+      v[j] = Rb ? uu + r[j] : uu;
+    }
+    st8<bf16_t>(Yb + p * C + cv * 8, v);
+  }
+}
+__global__ void final_sigmoid_stats_kernel(const bf16_t* Z, const float* stats, const float* gamma, const float* beta, int ld, float inv_n,
+                                           float eps, float* out, long long hw, int ldc) {
+  const int b = blockIdx.y;
+  float sc[3], sh[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) in_coef_of(stats, gamma, beta, ld, inv_n, eps, b, 3, c, sc[c], sh[c]);
+  const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= hw) return;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const float u = bf2f(Z[((size_t)b * hw + p) * ldc + c]) * sc[c] + sh[c];
+    out[((size_t)b * 3 + c) * hw + p] = 1.f / (1.f + __expf(-u));
+  }
+}
+
 // out[b][c][y][x] = sigmoid(z[b][y][x][c] * scale + shift), z NHWC bf16 with channel stride ldc, out fp32 NCHW (3 channels)
 __global__ void final_sigmoid_kernel(const bf16_t* Z, const float* coef, float* out, int B, long long hw, int ldc) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1490,6 +1554,27 @@ extern "C" int spb_in_apply(const void* X, const float* coef, const void* res, v
   const long long n8 = (long long)B * hw * (C >> 3);
   hipLaunchKernelGGL(in_apply_kernel, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)X, coef,
                      (const bf16_t*)res, (bf16_t*)Y, hw, C, relu, n8);
+  SPB_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int spb_in_apply_stats(const void* X, const float* stats, const float* gamma, const float* beta, int ld, float eps,
+                                  const void* res, void* Y, int B, long long hw, int C, int relu, spb_stream_t stream) {
+  if (!X || !stats || !Y || B <= 0 || hw <= 0 || (C & 7) || C > 2048) return SPB_E_ARG;
+  const int CV = C >> 3;
+  if (CV & (CV - 1)) return SPB_E_SHAPE;                      // channel chunks per pixel: a power of two
+  const long long rows = (long long)(256 / CV) * IAS_PX;
+  hipLaunchKernelGGL(in_apply_stats_kernel, dim3((unsigned)((hw + rows - 1) / rows), (unsigned)B), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)X, stats, gamma, beta, ld, 1.f / (float)hw, eps, (const bf16_t*)res, (bf16_t*)Y, hw, C, relu);
+  SPB_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int spb_final_sigmoid_stats(const void* Z, const float* stats, const float* gamma, const float* beta, int ld, float eps,
+                                       float* out, int B, long long hw, int ldc, spb_stream_t stream) {
+  if (!Z || !stats || !out || B <= 0 || hw <= 0 || ldc < 3) return SPB_E_ARG;
+  hipLaunchKernelGGL(final_sigmoid_stats_kernel, dim3((unsigned)((hw + 255) / 256), (unsigned)B), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)Z, stats, gamma, beta, ld, 1.f / (float)hw, eps, out, hw, ldc);
   SPB_CHECK_LAUNCH();
   return 0;
 }

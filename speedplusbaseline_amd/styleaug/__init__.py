@@ -181,13 +181,18 @@ class Ghiasi(nn.Module):
         si = [0]
 
         def norm_of(C_, hw, gamma_key=None, beta_key=None):
-            """coefficients of the tensor whose sums were just accumulated in stats[si]"""
+            """the instance norm (+ style affine) of the tensor whose sums were just accumulated in stats[si]: its consumer builds the
+            per-(image, channel) scale / shift from the sums in its own prologue (spb_gconv_args_t.in_stats, spb_in_apply_stats,
+            spb_final_sigmoid_stats); only spb_gconv_wide reads a coefficient table (coef_table below)"""
             k = si[0]
-            g = fc[:, pk["off"][gamma_key]:] if gamma_key else None
-            b = fc[:, pk["off"][beta_key]:] if beta_key else None
-            L.check(lib.spb_in_coef(_p(stats[k]), _p(g), _p(b), pk["n"], _p(coef[k]), B, C_, hw, IN_EPS, st), "spb_in_coef")
             si[0] += 1
-            return coef[k]
+            return dict(k=k, C=C_, hw=hw, gamma=fc[:, pk["off"][gamma_key]:] if gamma_key else None,
+                        beta=fc[:, pk["off"][beta_key]:] if beta_key else None)
+
+        def coef_table(n):
+            L.check(lib.spb_in_coef(_p(stats[n["k"]]), _p(n["gamma"]), _p(n["beta"]), pk["n"], _p(coef[n["k"]]), B, n["C"], n["hw"],
+                                    IN_EPS, st), "spb_in_coef")
+            return coef[n["k"]]
 
         def gconv(key, X, Hin, Win, Cin, Cout, k, stride=1, up=1, cf=None, relu=0, ldc=None, name=None):
             w, bias = pk["convs"][key]
@@ -195,9 +200,12 @@ class Ghiasi(nn.Module):
             ldc = ldc or Cout
             Y = self._buf(name or ("z%d%s" % key), (B, Hout, Wout, ldc), bf, dev)
             a = L.GconvArgs()
-            a.X = _p(X); a.W = _p(w); a.bias = _p(bias); a.coef = _p(cf); a.Y = _p(Y); a.stats = _p(stats[si[0]])
+            a.X = _p(X); a.W = _p(w); a.bias = _p(bias); a.coef = None; a.Y = _p(Y); a.stats = _p(stats[si[0]])
             a.B = B; a.Hin = Hin; a.Win = Win; a.Cin = Cin; a.Cout = Cout; a.KH = k; a.stride = stride; a.upsample = up
             a.relu = relu; a.ldc = ldc
+            if cf is not None:            # the producer's sums: coefficients built in the consumer's prologue
+                a.in_stats = _p(stats[cf["k"]]); a.in_gamma = _p(cf["gamma"]); a.in_beta = _p(cf["beta"]); a.in_ld = pk["n"]
+                a.in_inv_n = 1.0 / cf["hw"]; a.in_eps = IN_EPS
             wp = pk["convs"].get(key + ("up2",)) if (up == 2 and k == 3 and stride == 1 and _UP2_BY_PHASE) else None
             ww = pk["convs"].get(key + ("wide",)) if (_WIDE and up == 1 and stride == 1 and not (Hin % 8 or Win % 8)) else None
             if wp is not None:        # Upsample(2) + ReflectionPad(1) + 3x3 as four 2x2 phase convolutions on the low-res input
@@ -205,6 +213,8 @@ class Ghiasi(nn.Module):
                 L.check(lib.spb_gconv_up2(L.BF16, C.byref(a), st), "spb_gconv_up2")
             elif ww is not None:
                 a.W = _p(ww)
+                if cf is not None:
+                    a.coef = _p(coef_table(cf))
                 L.check(lib.spb_gconv_wide(L.BF16, C.byref(a), st), "spb_gconv_wide")
             else:
                 L.check(lib.spb_gconv(L.BF16, C.byref(a), st), "spb_gconv")
@@ -224,7 +234,8 @@ class Ghiasi(nn.Module):
         c2 = norm_of(128, H2 * W2)
         hw2 = H2 * W2
         r = self._buf("r0", (B, H2, W2, 128), bf, dev)
-        L.check(lib.spb_in_apply(_p(z2), _p(c2), None, _p(r), B, hw2, 128, 1, st), "spb_in_apply")
+        L.check(lib.spb_in_apply_stats(_p(z2), _p(stats[c2["k"]]), _p(c2["gamma"]), _p(c2["beta"]), pk["n"], IN_EPS, None,
+                                       _p(r), B, hw2, 128, 1, st), "spb_in_apply_stats")
         # ResidualBlock x5 (ghiasi.py:92-104)
         for i in range(3, 8):
             za, _, _ = gconv((i, "conv1"), r, H2, W2, 128, 128, 3, name="za")
@@ -232,7 +243,8 @@ class Ghiasi(nn.Module):
             zb, _, _ = gconv((i, "conv2"), za, H2, W2, 128, 128, 3, cf=ca, relu=1, name="zb")
             cb = norm_of(128, hw2, (i, "fc_gamma2"), (i, "fc_beta2"))
             rn = self._buf("r1" if r is self._ws.get("r0") else "r0", (B, H2, W2, 128), bf, dev)
-            L.check(lib.spb_in_apply(_p(zb), _p(cb), _p(r), _p(rn), B, hw2, 128, 0, st), "spb_in_apply")
+            L.check(lib.spb_in_apply_stats(_p(zb), _p(stats[cb["k"]]), _p(cb["gamma"]), _p(cb["beta"]), pk["n"], IN_EPS, _p(r), _p(rn),
+                                           B, hw2, 128, 0, st), "spb_in_apply_stats")
             r = rn
         # UpsampleConvInRelu x3 (ghiasi.py:46-59)
         z8, H8, W8 = gconv((8, "conv"), r, H2, W2, 128, 64, 3, up=2)
@@ -242,7 +254,8 @@ class Ghiasi(nn.Module):
         z10, _, _ = gconv((10, "conv"), z9, H9, W9, 32, 3, 9, cf=c9, relu=1, ldc=4)
         c10 = norm_of(3, H9 * W9, (10, "fc_gamma"), (10, "fc_beta"))
         out = torch.empty(B, 3, H, W, dtype=torch.float32, device=dev)
-        L.check(lib.spb_final_sigmoid(_p(z10), _p(c10), _p(out), B, H * W, 4, st), "spb_final_sigmoid")
+        L.check(lib.spb_final_sigmoid_stats(_p(z10), _p(stats[c10["k"]]), _p(c10["gamma"]), _p(c10["beta"]), pk["n"], IN_EPS, _p(out), B,
+                                            H * W, 4, st), "spb_final_sigmoid_stats")
         self._mark("final")
         return out
 

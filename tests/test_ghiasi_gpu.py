@@ -109,6 +109,58 @@ def test_wide_residual_conv_against_torch(device, h, w_, with_coef):
     assert float((outs[0][0] - outs[1][0]).abs().max()) <= 2.0 ** -7 * float(outs[1][0].abs().max())
 
 
+def test_coefficients_from_producer_sums_match_the_coefficient_table(device):
+    """spb_gconv_args_t.in_stats / spb_in_apply_stats / spb_final_sigmoid_stats build the instance-norm + style coefficients in the
+    consumer's prologue; the result must equal the spb_in_coef table fed to the same consumer (same arithmetic, bit for bit)"""
+    import ctypes as C
+    torch.manual_seed(5)
+    lib = L.lib()
+    p = lambda t: C.c_void_p(0 if t is None else t.data_ptr())
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    B, cin, cout, hw, ld = 3, 64, 128, 16, 200
+    x = torch.randn(B, hw, hw, cin, device=device).to(torch.bfloat16)
+    xf = x.float()
+    stats = torch.stack([xf.sum((1, 2)), (xf * xf).sum((1, 2))], dim=2).contiguous()          # [B][cin][2]
+    fc = torch.randn(B, ld, device=device)
+    gamma, beta = fc[:, 7:], fc[:, 90:]
+    coef = torch.empty(B, cin, 2, device=device)
+    L.check(lib.spb_in_coef(p(stats), p(gamma), p(beta), ld, p(coef), B, cin, hw * hw, 1e-5, st), "spb_in_coef")
+    w = (torch.randn(cout, 3, 3, cin, device=device) / (cin * 9) ** 0.5).to(torch.bfloat16)
+    bias = torch.randn(cout, device=device) * 0.1
+    outs = []
+    for from_sums in (0, 1):
+        Y = torch.zeros(B, hw // 2, hw // 2, cout, dtype=torch.bfloat16, device=device)
+        so = torch.zeros(B, cout, 2, device=device)
+        g = L.GconvArgs()
+        g.X = p(x); g.W = p(w); g.bias = p(bias); g.Y = p(Y); g.stats = p(so)
+        g.B = B; g.Hin = hw; g.Win = hw; g.Cin = cin; g.Cout = cout; g.KH = 3; g.stride = 2; g.upsample = 1; g.relu = 1; g.ldc = cout
+        if from_sums:
+            g.in_stats = p(stats); g.in_gamma = p(gamma); g.in_beta = p(beta); g.in_ld = ld; g.in_inv_n = 1.0 / (hw * hw); g.in_eps = 1e-5
+        else:
+            g.coef = p(coef)
+        L.check(lib.spb_gconv(L.BF16, C.byref(g), st), "spb_gconv")
+        torch.cuda.synchronize()
+        outs.append(Y.float().cpu())
+    assert torch.equal(outs[0], outs[1])
+    res = torch.randn(B, hw, hw, cin, device=device).to(torch.bfloat16)
+    ya, yb = torch.empty_like(x), torch.empty_like(x)
+    for relu, r in ((1, None), (0, res)):
+        L.check(lib.spb_in_apply(p(x), p(coef), p(r), p(ya), B, hw * hw, cin, relu, st), "spb_in_apply")
+        L.check(lib.spb_in_apply_stats(p(x), p(stats), p(gamma), p(beta), ld, 1e-5, p(r), p(yb), B, hw * hw, cin, relu, st), "spb_in_apply_stats")
+        torch.cuda.synchronize()
+        assert torch.equal(ya, yb)
+    z = torch.randn(B, hw, hw, 4, device=device).to(torch.bfloat16)
+    zf = z.float()[..., :3]
+    s3 = torch.stack([zf.sum((1, 2)), (zf * zf).sum((1, 2))], dim=2).contiguous()
+    c3 = torch.empty(B, 3, 2, device=device)
+    L.check(lib.spb_in_coef(p(s3), p(gamma), p(beta), ld, p(c3), B, 3, hw * hw, 1e-5, st), "spb_in_coef")
+    oa, ob = torch.empty(B, 3, hw, hw, device=device), torch.empty(B, 3, hw, hw, device=device)
+    L.check(lib.spb_final_sigmoid(p(z), p(c3), p(oa), B, hw * hw, 4, st), "spb_final_sigmoid")
+    L.check(lib.spb_final_sigmoid_stats(p(z), p(s3), p(gamma), p(beta), ld, 1e-5, p(ob), B, hw * hw, 4, st), "spb_final_sigmoid_stats")
+    torch.cuda.synchronize()
+    assert torch.equal(oa, ob)
+
+
 @pytest.mark.parametrize("cin,cout,hw", [(128, 64, 8), (64, 32, 16), (128, 64, 56), (64, 32, 28)])
 def test_upsample_conv_by_phase_against_torch(device, cin, cout, hw):
     """spb_gconv_up2: Upsample(2, nearest) + ReflectionPad2d(1) + Conv2d 3x3 as four 2x2 phase convolutions on the low-resolution
