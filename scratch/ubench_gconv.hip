@@ -4,6 +4,7 @@
 #include <cstdio>
 #include <cstring>
 #include <cstdlib>
+#define GC_TS 1
 #include "../speedplusbaseline_amd/csrc/ghiasi.hip"
 #define GWABL GABL
 #define GW_TS 1
@@ -32,6 +33,26 @@ int main() {
     spb_gconv_args_t a; std::memset(&a, 0, sizeof(a));
     a.X = x; a.W = w; a.bias = bias; a.coef = coef; a.Y = y; a.stats = stats; a.B = sh.B; a.Hin = sh.H; a.Win = sh.H; a.Cin = sh.Cin;
     a.Cout = sh.Cout; a.KH = sh.K; a.stride = sh.st; a.upsample = sh.up; a.relu = 1; a.ldc = sh.Cout < 4 ? 4 : sh.Cout;
+    const bool up2 = getenv("UP2") && sh.up == 2 && sh.K == 3;
+    if (up2) {
+      for (int k = 0; k < 3; ++k) if (spb_gconv_up2(SPB_BF16, &a, 0)) { printf("up2 launch failed\n"); return 1; }
+      CK(hipEventRecord(e0)); for (int k = 0; k < 10; ++k) spb_gconv_up2(SPB_BF16, &a, 0);
+      CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); float ms2; CK(hipEventElapsedTime(&ms2, e0, e1));
+      printf("up2   %3d->%3d @%3d: %8.2f us\n", sh.Cin, sh.Cout, Hout, ms2 * 100);
+      unsigned long long* ts; CK(hipMalloc(&ts, 1024 * 16 * 8)); CK(hipMemset(ts, 0, 1024 * 16 * 8));
+      CK(hipMemcpyToSymbol(HIP_SYMBOL(g_gc_ts), &ts, sizeof(ts)));
+      spb_gconv_up2(SPB_BF16, &a, 0); CK(hipDeviceSynchronize());
+      static unsigned long long h[1024 * 16]; CK(hipMemcpy(h, ts, sizeof(h), hipMemcpyDeviceToHost));
+      unsigned long long* nul = nullptr; CK(hipMemcpyToSymbol(HIP_SYMBOL(g_gc_ts), &nul, sizeof(nul)));
+      unsigned long long t0 = ~0ull;
+      for (int i = 0; i < 1024 * 16; ++i) if (h[i] && h[i] < t0) t0 = h[i];
+      for (int ti = 0; ti < 4; ++ti) {
+        double av[3] = {0, 0, 0}; int n = 0;
+        for (int w = 0; w < 1024; ++w) if (h[(w * 4 + ti) * 4]) { ++n; for (int i = 0; i < 3; ++i) av[i] += (double)(h[(w * 4 + ti) * 4 + i] - t0) / 100.0; }
+        if (n) printf("  tile group %d (%4d wgs): top %.2f  committed %.2f  loop done %.2f us\n", ti, n, av[0] / n, av[1] / n, av[2] / n);
+      }
+      hipFree(ts);
+    }
     const bool wide = getenv("WIDE") && sh.Cin == 128 && sh.Cout == 128 && sh.up == 1;
     for (int k = 0; k < 3; ++k) if (wide ? spb_gconv_wide(SPB_BF16, &a, 0) : spb_gconv(SPB_BF16, &a, 0)) { printf("launch failed\n"); return 1; }
     CK(hipEventRecord(e0)); for (int k = 0; k < 10; ++k) { if (wide) spb_gconv_wide(SPB_BF16, &a, 0); else spb_gconv(SPB_BF16, &a, 0); }

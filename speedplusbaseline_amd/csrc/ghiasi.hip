@@ -26,6 +26,13 @@
 #define GABL 0
 #endif
 
+#ifdef GC_TS
+__device__ unsigned long long* g_gc_ts;     // scratch/ubench_gconv.hip: [workgroup][tile 0..3][4] wall clock (100 MHz)
+#define GC_STAMP(i) do { if (threadIdx.x == 0 && g_gc_ts && ti < 4 && blockIdx.x < 1024) g_gc_ts[(blockIdx.x * 4 + ti) * 4 + (i)] = wall_clock64(); } while (0)
+#else
+#define GC_STAMP(i) do { } while (0)
+#endif
+
 namespace {
 
 __device__ __forceinline__ int reflecti(int i, int n) { i = i < 0 ? -i : i; return i >= n ? 2 * n - 2 - i : i; }
@@ -199,11 +206,26 @@ __global__ __launch_bounds__(256) void gconv_kernel(const spb_gconv_args_t g, in
     cf[c] = sc; cf[Cin + c] = sh;
   }
   if (WLDS) {   // Cout rows; lanes whose (permuted) row is >= Cout use a zero fragment
-    const int RV = (KK * Cin) >> 3;
-    for (int i = t; i < Cout * RV; i += 256) {   // LDS rows in fragment order [nb][li]: conflict-free fragment reads
-      const int r = i / RV, v = i % RV;
-      const int slot = ((r % (4 * NB)) >> 2) * 16 + (r / (4 * NB)) * 4 + (r & 3);
-      *reinterpret_cast<uint4*>(wl + slot * LDW + v * 8) = *reinterpret_cast<const uint4*>(Wg + (size_t)r * KK * Cin + v * 8);
+    // LDS rows in fragment order [nb][li]: conflict-free fragment reads.  Eight loads in flight per thread and no integer division
+    // by run-time values (the one-granule-at-a-time loop with `i / RV, i % RV` was 27 us of every workgroup of the phase kernel:
+    // a third of the 64 -> 32 layer, round-3 timestamps)
+    const int RV = (KK * Cin) >> 3, total = Cout * RV;
+    const float inv_rv = 1.0f / (float)RV;
+    for (int i0 = t; i0 < total; i0 += 256 * 8) {
+      uint4 wv[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = i0 + 256 * u;
+        wv[u] = *reinterpret_cast<const uint4*>(Wg + (size_t)(i < total ? i : total - 1) * 8);     // rows are contiguous in memory
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = i0 + 256 * u;
+        if (i >= total) continue;
+        const int r = (int)(((float)i + 0.5f) * inv_rv), v = i - r * RV;                             // exact for i < 2^20
+        const int slot = ((r % (4 * NB)) >> 2) * 16 + (r / (4 * NB)) * 4 + (r & 3);
+        *reinterpret_cast<uint4*>(wl + slot * LDW + v * 8) = wv[u];
+      }
     }
   }
   const bf16_t* X = reinterpret_cast<const bf16_t*>(g.X);
@@ -436,13 +458,25 @@ __global__ __launch_bounds__(256) void gconv_up2_kernel(const spb_gconv_args_t g
     gconv_coef(g, b, Cin, c, sc, sh);
     cf[c] = sc; cf[Cin + c] = sh;
   }
-  if (WLDS) {
-    const int RV = (KT * Cin) >> 3;
-    for (int i = t; i < 4 * Cout * RV; i += 256) {   // rows in fragment order [nb][li] per phase: conflict-free fragment reads
-      const int v = i % RV, r = (i / RV) % Cout, p = i / (RV * Cout);
-      const int slot = ((r % (4 * NB)) >> 2) * 16 + (r / (4 * NB)) * 4 + (r & 3);
-      *reinterpret_cast<uint4*>(wl + (size_t)(p * NB * 16 + slot) * LDW + v * 8) =
-          *reinterpret_cast<const uint4*>(Wg + ((size_t)(p * Cout + r) * KT) * Cin + v * 8);
+  if (WLDS) {   // rows in fragment order [nb][li] per phase: conflict-free fragment reads; staged as in gconv_kernel
+    const int RV = (KT * Cin) >> 3, total = 4 * Cout * RV;
+    const float inv_rv = 1.0f / (float)RV, inv_co = 1.0f / (float)Cout;
+    for (int i0 = t; i0 < total; i0 += 256 * 8) {
+      uint4 wv[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = i0 + 256 * u;
+        wv[u] = *reinterpret_cast<const uint4*>(Wg + (size_t)(i < total ? i : total - 1) * 8);     // [phase][row][tap][Cin]: contiguous
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = i0 + 256 * u;
+        if (i >= total) continue;
+        const int ra = (int)(((float)i + 0.5f) * inv_rv), v = i - ra * RV;                           // row over all phases
+        const int p = (int)(((float)ra + 0.5f) * inv_co), r = ra - p * Cout;
+        const int slot = ((r % (4 * NB)) >> 2) * 16 + (r / (4 * NB)) * 4 + (r & 3);
+        *reinterpret_cast<uint4*>(wl + (size_t)(p * NB * 16 + slot) * LDW + v * 8) = wv[u];
+      }
     }
   }
   const bf16_t* X = reinterpret_cast<const bf16_t*>(g.X);
@@ -524,6 +558,7 @@ __global__ __launch_bounds__(256) void gconv_up2_kernel(const spb_gconv_args_t g
     int oy0[PXG], ox0[PXG];
     bool tvalid[PXG];
     tile_origin(ti, oy0, ox0, tvalid);
+    GC_STAMP(0);
     lds_barrier();   // previous tile's taps are done with the halo (first pass: coefficient / weight tables written)
     if constexpr (NV > 0) {
       pre_commit();
@@ -567,6 +602,7 @@ __global__ __launch_bounds__(256) void gconv_up2_kernel(const spb_gconv_args_t g
       }
     }
     lds_barrier();
+    GC_STAMP(1);
     if constexpr (NV > 0) pre_issue(ti + 1 < tpw ? ti + 1 : ti);   // clamped, no branch around the loads: the last one is redundant
     f32x4_t acc[PXG][NB];
 #pragma unroll
@@ -648,6 +684,7 @@ __global__ __launch_bounds__(256) void gconv_up2_kernel(const spb_gconv_args_t g
         }
       }
     }
+    GC_STAMP(2);
     // ---- epilogue: lane (li = low-resolution position, lq): channels lq*4*NB + nb*4 + e of output pixel (2 iy + py, 2 ix + px)
 #pragma unroll
     for (int p = 0; p < PXG; ++p) {
