@@ -431,8 +431,13 @@ __global__ __launch_bounds__(256) void gconv_kernel(const spb_gconv_args_t g, in
 // NV > 0: the halo vectors of a tile group are exactly <= NV per thread and the NEXT group's are loaded into registers right
 // after this group's halo is committed (in flight during the matrix-core loop and the stores).  Without it every group exposed
 // one L2 / HBM round trip: 5.2 us per 128-pixel group of the 64 -> 32 layer for 0.43 us of matrix-core work (round 3).
-template <int NB, bool WLDS, int PXG, int NV = 0>
-__global__ __launch_bounds__(256) void gconv_up2_kernel(const spb_gconv_args_t g, int tpw) {
+// WREG (Cin == 64, NB == 2: the 64 -> 32 layer, the largest launch of the decoder after the residual blocks): a wave's phase weights
+// are 8 reduction steps x 2 fragments = 64 registers, loaded ONCE per workgroup and kept for all its tile groups.  The tap loop
+// then has no weight traffic at all and is fully unrolled: 16 pixel-fragment reads in two batches, 32 MFMAs (timestamps, round 3:
+// the LDS-resident version spent 1.55 us per 128-pixel group in its 8-step loop for 0.43 us of matrix-core work -- one LDS round
+// trip per step -- and its 67 KB of weights per workgroup held the CU at two workgroups; without them LDS is 11 KB).
+template <int NB, bool WLDS, int PXG, int NV = 0, bool WREG = false>
+__global__ __launch_bounds__(256, WREG ? 3 : 1) void gconv_up2_kernel(const spb_gconv_args_t g, int tpw) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int PD = 2, HT = 6, KT = 4, SU = 4;
   const int Cin = g.Cin, Cout = g.Cout;
@@ -553,6 +558,18 @@ __global__ __launch_bounds__(256) void gconv_up2_kernel(const spb_gconv_args_t g
     }
   };
   if constexpr (NV > 0) pre_issue(0);
+  uint4 areg[WREG ? 8 : 1][NB];
+  if constexpr (WREG) {     // step s = (ky * 2 + kx) * 2 + cc, as the tap loops below walk it
+#pragma unroll
+    for (int s_ = 0; s_ < 8; ++s_) {
+      const int ko = (s_ >> 1) * Cin + (s_ & 1) * 32 + lq * 8;
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        const uint4 w = *reinterpret_cast<const uint4*>(Wg + ((size_t)(ph * Cout + wco[nb]) * KT) * Cin + ko);
+        areg[s_][nb] = wok[nb] ? w : make_uint4(0, 0, 0, 0);
+      }
+    }
+  }
 
   for (int ti = 0; ti < tpw; ++ti) {
     int oy0[PXG], ox0[PXG];
@@ -609,7 +626,26 @@ __global__ __launch_bounds__(256) void gconv_up2_kernel(const spb_gconv_args_t g
     for (int p = 0; p < PXG; ++p)
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) acc[p][nb] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-    if constexpr (WLDS) {
+    if constexpr (WREG) {
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        bf16x8_t bf[4][PXG];
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+          const int s_ = half * 4 + s4;       // ky = half, kx = s4 / 2, cc = s4 % 2
+#pragma unroll
+          for (int p = 0; p < PXG; ++p)
+            bf[s4][p] = *reinterpret_cast<const bf16x8_t*>(hbase + (p * HT * HT + (s_ >> 2) * HT + ((s_ >> 1) & 1)) * LDP + (s_ & 1) * 32);
+        }
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int p = 0; p < PXG; ++p)
+              acc[p][nb] = SPB_MFMA16(__builtin_bit_cast(bf16x8_t, areg[half * 4 + s4][nb]), bf[s4][p], acc[p][nb]);
+      }
+    } else if constexpr (WLDS) {
       int ky = 0, kx = 0, cc = 0;
       bf16x8_t bfc[PXG], bfn[PXG];
       uint4 auc[NB], aun[NB];
@@ -1507,6 +1543,8 @@ extern "C" int spb_gconv(int dtype, const spb_gconv_args_t* a, spb_stream_t stre
   return 0;
 }
 
+static int g_up2_wreg = 1;       // 64 -> 32 phase layer: weights in registers instead of LDS
+extern "C" int spb_debug_set_gconv_up2_wreg(int on) { g_up2_wreg = on; return 0; }
 static int g_up2_prefetch = 1;   // phase kernels: next tile group's halo loads in flight during the current group
 extern "C" int spb_debug_set_gconv_up2_prefetch(int on) { g_up2_prefetch = on; return 0; }
 
@@ -1519,10 +1557,11 @@ extern "C" int spb_gconv_up2(int dtype, const spb_gconv_args_t* a, spb_stream_t 
   if ((Hout & 7) || (Wout & 7) || a->ldc < a->Cout || (a->ldc & 3)) return SPB_E_SHAPE;
   const int NB = a->Cout <= 16 ? 1 : (a->Cout <= 32 ? 2 : (a->Cout <= 64 ? 4 : 8));
   const size_t wbytes = (size_t)4 * NB * 16 * (4 * a->Cin + 8) * 2;
-  const bool wlds = wbytes <= 72 * 1024;
+  const bool wreg = g_up2_wreg && NB == 2 && a->Cin == 64;          // phase weights in registers (gconv_up2_kernel, WREG)
+  const bool wlds = !wreg && wbytes <= 72 * 1024;
   if (!wlds && a->Cout != NB * 16) return SPB_E_SHAPE;
   if (NB != 2 && NB != 4) return SPB_E_UNSUPPORTED;
-  const int pxg = wlds ? 2 : 4;
+  const int pxg = (wlds || wreg) ? 2 : 4;
   const size_t lds = (size_t)a->Cin * 2 * sizeof(float) + (size_t)4 * NB * 16 * 2 * sizeof(float) +
                      (size_t)pxg * 36 * (a->Cin + 8) * 2 + (wlds ? wbytes : 0);
   const int tpi = (Hout >> 3) * (Wout >> 3);
@@ -1532,19 +1571,22 @@ extern "C" int spb_gconv_up2(int dtype, const spb_gconv_args_t* a, spb_stream_t 
     if (gpi % d == 0 && (long long)a->B * (gpi / d) >= 1024) tpw = d;
   const dim3 grid((unsigned)(a->B * (gpi / tpw)));
   hipStream_t s = (hipStream_t)stream;
-#define U_(NB_, WL_, PX_, NV_)                                                                                       \
+#define U_(NB_, WL_, PX_, NV_) U5_(NB_, WL_, PX_, NV_, false)
+#define U5_(NB_, WL_, PX_, NV_, WR_)                                                                                 \
   {                                                                                                                  \
     static bool once = false;                                                                                        \
     if (!once) {                                                                                                     \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gconv_up2_kernel<NB_, WL_, PX_, NV_>),                \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gconv_up2_kernel<NB_, WL_, PX_, NV_, WR_>),           \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                             \
       once = true;                                                                                                   \
     }                                                                                                                \
-    hipLaunchKernelGGL((gconv_up2_kernel<NB_, WL_, PX_, NV_>), grid, dim3(256), lds, s, *a, tpw);                    \
+    hipLaunchKernelGGL((gconv_up2_kernel<NB_, WL_, PX_, NV_, WR_>), grid, dim3(256), lds, s, *a, tpw);               \
   }
   const int hv = pxg * 36 * (a->Cin >> 3);          // halo vectors per tile group
   const bool pre = g_up2_prefetch && tpw > 1;
-  if (NB == 2) {
+  if (wreg) {
+    if (pre) U5_(2, false, 2, 3, true) else U5_(2, false, 2, 0, true)
+  } else if (NB == 2) {
     if (wlds) { if (pre && hv <= 768) U_(2, true, 2, 3) else U_(2, true, 2, 0) }
     else { if (pre && hv <= 2304) U_(2, false, 4, 9) else U_(2, false, 4, 0) }
   } else {
@@ -1552,6 +1594,7 @@ extern "C" int spb_gconv_up2(int dtype, const spb_gconv_args_t* a, spb_stream_t 
     else { if (pre && hv <= 2304) U_(4, false, 4, 9) else U_(4, false, 4, 0) }
   }
 #undef U_
+#undef U5_
   SPB_CHECK_LAUNCH();
   return 0;
 }
