@@ -1117,7 +1117,7 @@ __global__ __launch_bounds__(256) void conv9_kxrows_kernel(const spb_gconv_args_
   }
   lds_barrier();
   constexpr int total = HR * HW_ * 4;
-  constexpr int SUK = (total + 255) / 256 <= 12 ? (total + 255) / 256 : 6;   // all of a thread's halo loads in ONE round trip when they fit
+  constexpr int SUK = (total + 255) / 256 <= 16 ? (total + 255) / 256 : 8;   // all of a thread's halo loads in ONE round trip when they fit (16 here)
   for (int i0 = t; i0 < total; i0 += 256 * SUK) {
     Raw8<bf16_t> r[SUK];
     int dst[SUK], cvs[SUK];
