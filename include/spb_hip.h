@@ -630,6 +630,7 @@ int spb_debug_set_dw_rows(int rows); /* rows per row unit (0: automatic) */
 int spb_debug_set_dw_plane_max_w(int w); /* depthwise plane kernels: widest feature map they take (default 14; at most 28) */
 int spb_debug_set_dw_plane_min_wgs(int n); /* depthwise plane kernels: fewer images per workgroup while the launch has fewer workgroups than n (default 384) */
 int spb_debug_set_im2col_rgb_band(int on); /* SPN conv1 column matrix: 1 = band kernel (image rows through LDS), 0 = per-element gather */
+int spb_debug_set_conv9_wgs(int n); /* 9x9 32->3 conv: persistent workgroups (default 512) */
 int spb_debug_set_gconv_up2_wreg(int on); /* 64 -> 32 phase conv: a wave keeps its phase weights in registers for all its tile groups (1, default) */
 int spb_debug_set_gconv_up2_prefetch(int on); /* phase (upsampling) convs: prefetch the next tile group's halo into registers (1, default) */
 int spb_debug_set_gconv_wide_wgs(int n); /* residual-block convs (ghiasi_wide.hip): persistent workgroups (default 512 = two per CU) */

@@ -53,6 +53,17 @@ int main() {
       }
       hipFree(ts);
     }
+    if (getenv("K9") && sh.K == 9) {
+      unsigned long long* ts; CK(hipMalloc(&ts, 512 * 8 * 8)); CK(hipMemset(ts, 0, 512 * 8 * 8));
+      CK(hipMemcpyToSymbol(HIP_SYMBOL(g_gc_ts), &ts, sizeof(ts)));
+      spb_gconv(SPB_BF16, &a, 0); CK(hipDeviceSynchronize());
+      static unsigned long long h9[512 * 8]; CK(hipMemcpy(h9, ts, sizeof(h9), hipMemcpyDeviceToHost));
+      unsigned long long* nul = nullptr; CK(hipMemcpyToSymbol(HIP_SYMBOL(g_gc_ts), &nul, sizeof(nul)));
+      double av[7] = {0}; int n = 0;
+      for (int w = 0; w < 512; ++w) if (h9[w * 8]) { ++n; for (int i = 0; i < 7; ++i) av[i] += (double)(h9[w * 8 + i] - h9[w * 8]) / 100.0; }
+      if (n) printf("  9x9 band kernel (%d wgs): weights %.2f  halo %.2f  taps %.2f  barrier %.2f  P written %.2f  sums+stores %.2f  end %.2f us\n", n, av[1] / n, av[2] / n, av[3] / n, av[3] / n, av[4] / n, av[5] / n, av[6] / n);
+      hipFree(ts);
+    }
     const bool wide = getenv("WIDE") && sh.Cin == 128 && sh.Cout == 128 && sh.up == 1;
     for (int k = 0; k < 3; ++k) if (wide ? spb_gconv_wide(SPB_BF16, &a, 0) : spb_gconv(SPB_BF16, &a, 0)) { printf("launch failed\n"); return 1; }
     CK(hipEventRecord(e0)); for (int k = 0; k < 10; ++k) { if (wide) spb_gconv_wide(SPB_BF16, &a, 0); else spb_gconv(SPB_BF16, &a, 0); }

@@ -263,6 +263,7 @@ SYMBOLS = {
     "spb_debug_set_gconv_halo_prefetch": (i32, [i32]),
     "spb_debug_set_im2col_rgb_band": (i32, [i32]),
     "spb_debug_set_gconv_slab_pf": (i32, [i32]),
+    "spb_debug_set_conv9_wgs": (i32, [i32]),
     "spb_debug_set_gconv_up2_wreg": (i32, [i32]),
     "spb_debug_set_gconv_up2_prefetch": (i32, [i32]),
     "spb_debug_set_gconv_wide_wgs": (i32, [i32]),

@@ -29,8 +29,10 @@
 #ifdef GC_TS
 __device__ unsigned long long* g_gc_ts;     // scratch/ubench_gconv.hip: [workgroup][tile 0..3][4] wall clock (100 MHz)
 #define GC_STAMP(i) do { if (threadIdx.x == 0 && g_gc_ts && ti < 4 && blockIdx.x < 1024) g_gc_ts[(blockIdx.x * 4 + ti) * 4 + (i)] = wall_clock64(); } while (0)
+#define GC_STAMP2(i) do { if (threadIdx.x == 0 && g_gc_ts && blockIdx.y == 0 && blockIdx.x < 512) g_gc_ts[blockIdx.x * 8 + (i)] = wall_clock64(); } while (0)
 #else
 #define GC_STAMP(i) do { } while (0)
+#define GC_STAMP2(i) do { } while (0)
 #endif
 
 namespace {
@@ -1089,125 +1091,159 @@ __global__ __launch_bounds__(256) void conv9_band_kernel(const spb_gconv_args_t 
 #define C9K_ROWS 4     // 4: 80 KB of LDS, two workgroups per CU (188 us at 224x224, B=48); 8: one per CU (206 us)
 #endif
 constexpr int C9K_R = C9K_ROWS, C9K_W = 56, C9K_RW = C9K_ROWS / 4;   // rows per wave
-__global__ __launch_bounds__(256) void conv9_kxrows_kernel(const spb_gconv_args_t g) {
+// Persistent (round 3 timestamps of the one-band-per-workgroup version, 10.7 us per band: 2.2 us weight staging + 3.3 us exposed halo
+// round trip + 1.6 taps + 1.2 P / shifted sums + 2.4 statistics, 21 bands per CU slot): gridDim.x workgroups walk the bands
+// blockIdx.x, blockIdx.x + gridDim.x, ...; the weights are staged ONCE, the next band's halo is in registers (and its image's
+// coefficients in the other half of `cf`) before this band's taps start.
+__global__ __launch_bounds__(256) void conv9_kxrows_kernel(const spb_gconv_args_t g, int nbands) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int HW_ = C9K_W + 8, HR = C9K_R + 8, LDP = 40, LDWK = 32;   // weight rows unpadded: a fragment read is 1 KB contiguous
-  float* cf = reinterpret_cast<float*>(smem);                      // [32][2] scale | shift
-  float* red = cf + 64;                                            // [4 waves][4 ch][2]
+  float* cf = reinterpret_cast<float*>(smem);                      // [2 (band parity)][32][2] scale | shift
+  float* red = cf + 128;                                           // [4 waves][4 ch][2]
   bf16_t* halo = reinterpret_cast<bf16_t*>(red + 32);              // [HR][HW_][LDP]; after the reduction loop: P, float [8][32][64]
   bf16_t* wl = halo + HR * HW_ * LDP;                              // [9 ky][32 rows = kx*3 + co][LDWK]
   const int t = threadIdx.x, lane = t & 63, li = lane & 15, lq = lane >> 4, wave = t >> 6;
   const int H = g.Hin, W = g.Win, Cout = g.Cout;
-  const int bx = W / C9K_W;
-  const int b = blockIdx.y, y0 = (blockIdx.x / bx) * C9K_R, x0 = (blockIdx.x % bx) * C9K_W;
+  const int bx = W / C9K_W, bpi = bx * (H / C9K_R);                // bands per image
   const bf16_t* X = reinterpret_cast<const bf16_t*>(g.X);
   const bf16_t* Wg = reinterpret_cast<const bf16_t*>(g.W);       // [Cout][9][9][32]
   bf16_t* Y = reinterpret_cast<bf16_t*>(g.Y);
-  if (t < 32) {
-    float sc, sh;
-    gconv_coef(g, b, 32, t, sc, sh);
-    cf[t] = sc; cf[32 + t] = sh;
-  }
-  for (int i = t; i < 9 * 32 * 4; i += 256) {                      // 16-byte granules of [ky][row][32 channels]
-    const int v = i & 3, r = (i >> 2) & 31, ky = i >> 7;
-    const int kx = r / 3, co = r - kx * 3;
-    uint4 u = make_uint4(0, 0, 0, 0);
-    if (r < 27 && co < Cout) u = *reinterpret_cast<const uint4*>(Wg + ((size_t)(co * 9 + ky) * 9 + kx) * 32 + v * 8);
-    *reinterpret_cast<uint4*>(wl + (ky * 32 + r) * LDWK + v * 8) = u;
-  }
-  lds_barrier();
+  int band = blockIdx.x;
+  if (band >= nbands) return;
   constexpr int total = HR * HW_ * 4;
-  constexpr int SUK = (total + 255) / 256 <= 16 ? (total + 255) / 256 : 8;   // all of a thread's halo loads in ONE round trip when they fit (16 here)
-  for (int i0 = t; i0 < total; i0 += 256 * SUK) {
-    Raw8<bf16_t> r[SUK];
-    int dst[SUK], cvs[SUK];
+  constexpr int SUK = (total + 255) / 256;                         // halo vectors per thread (12 for 4-row bands)
+  static_assert(SUK <= 16, "band halo must fit the register prefetch");
+  Raw8<bf16_t> r[SUK];
+  auto band_coef = [&](int bnd, int par) {      // threads 0..31: the band's image coefficients into cf[par]
+    if (t < 32) {
+      float sc, sh;
+      gconv_coef(g, bnd / bpi, 32, t, sc, sh);
+      cf[par * 64 + t] = sc; cf[par * 64 + 32 + t] = sh;
+    }
+  };
+  auto halo_load = [&](int bnd) {
+    const int b = bnd / bpi, bi = bnd - b * bpi;
+    const int y0 = (bi / bx) * C9K_R, x0 = (bi % bx) * C9K_W;
 #pragma unroll
     for (int u = 0; u < SUK; ++u) {
-      const int i = i0 + 256 * u, ic = i < total ? i : total - 1;
+      const int i = t + 256 * u, ic = i < total ? i : total - 1;
       const int cv = ic & 3, hp = ic >> 2, hy = hp / HW_, hx = hp % HW_;
       const int sy = reflecti(y0 - 4 + hy, H), sx = reflecti(x0 - 4 + hx, W);
       r[u] = ldraw<bf16_t>(X + ((size_t)(b * H + sy) * W + sx) * 32 + cv * 8);
-      dst[u] = i < total ? hp * LDP + cv * 8 : -1;
-      cvs[u] = cv;
     }
-#pragma unroll
-    for (int u = 0; u < SUK; ++u) {
-      if (dst[u] < 0) continue;
-      float v[8];
-      cvt8(r[u], v);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const float uu = v[j] * cf[cvs[u] * 8 + j] + cf[32 + cvs[u] * 8 + j];
-        v[j] = g.relu ? fmaxf(uu, 0.f) : uu;
-      }
-      st8<bf16_t>(halo + dst[u], v);
-    }
+  };
+  GC_STAMP2(0);
+  band_coef(band, 0);
+  halo_load(band);
+  for (int i = t; i < 9 * 32 * 4; i += 256) {                      // 16-byte granules of [ky][row][32 channels]
+    const int v = i & 3, rr = (i >> 2) & 31, ky = i >> 7;
+    const int kx = rr / 3, co = rr - kx * 3;
+    uint4 u = make_uint4(0, 0, 0, 0);
+    if (rr < 27 && co < Cout) u = *reinterpret_cast<const uint4*>(Wg + ((size_t)(co * 9 + ky) * 9 + kx) * 32 + v * 8);
+    *reinterpret_cast<uint4*>(wl + (ky * 32 + rr) * LDWK + v * 8) = u;
   }
   lds_barrier();
-  // wave w: output rows w*C9K_RW ..; per row four 16-column groups of INPUT columns x two row fragments
-  f32x4_t acc[C9K_RW][4][2];
-#pragma unroll
-  for (int r = 0; r < C9K_RW; ++r)
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-#pragma unroll
-      for (int f = 0; f < 2; ++f) acc[r][q][f] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  GC_STAMP2(1);
   const bf16_t* hb = halo + ((wave * C9K_RW) * HW_ + li) * LDP + lq * 8;
   const bf16_t* wb = wl + li * LDWK + lq * 8;
-  for (int ky = 0; ky < 9; ++ky) {
-    const bf16x8_t a0 = *reinterpret_cast<const bf16x8_t*>(wb + (ky * 32) * LDWK);
-    const bf16x8_t a1 = *reinterpret_cast<const bf16x8_t*>(wb + (ky * 32 + 16) * LDWK);
+  for (int k = 0;; ++k) {
+    const int b = band / bpi, bi = band - b * bpi;
+    const int y0 = (bi / bx) * C9K_R, x0 = (bi % bx) * C9K_W;
+    // ---- commit this band's halo (loaded one band ago): a thread's channel chunk is fixed (256 % 4 == 0)
+    {
+      const float* cfk = cf + (k & 1) * 64;
+      float scr[8], shr[8];
 #pragma unroll
-    for (int r = 0; r < C9K_RW; ++r)
+      for (int j = 0; j < 8; ++j) { scr[j] = cfk[(t & 3) * 8 + j]; shr[j] = cfk[32 + (t & 3) * 8 + j]; }
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const bf16x8_t bf = *reinterpret_cast<const bf16x8_t*>(hb + ((r + ky) * HW_ + q * 16) * LDP);
-        acc[r][q][0] = SPB_MFMA16(a0, bf, acc[r][q][0]);
-        acc[r][q][1] = SPB_MFMA16(a1, bf, acc[r][q][1]);
+      for (int u = 0; u < SUK; ++u) {
+        const int i = t + 256 * u;
+        if (i >= total) continue;
+        float v[8];
+        cvt8(r[u], v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float uu = v[j] * scr[j] + shr[j];
+          v[j] = g.relu ? fmaxf(uu, 0.f) : uu;
+        }
+        st8<bf16_t>(halo + (i >> 2) * LDP + (i & 3) * 8, v);
       }
-  }
-  lds_barrier();                                                 // everyone is done with the halo: it becomes P
-  float* P = reinterpret_cast<float*>(halo);                       // [8 rows][32 (kx, co)][64 input columns]
-#pragma unroll
-  for (int r = 0; r < C9K_RW; ++r)
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-#pragma unroll
-      for (int f = 0; f < 2; ++f)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) P[((wave * C9K_RW + r) * 32 + f * 16 + lq * 4 + e) * 64 + q * 16 + li] = acc[r][q][f][e];
-  lds_barrier();
-  // lane = output column (56 of 64 lanes), every row of this wave: y[x][co] = sum_kx P[(kx, co)][x + kx]
-  float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
-  if (lane < C9K_W) {
-#pragma unroll
-    for (int r = 0; r < C9K_RW; ++r) {
-      const float* Pr = P + (size_t)(wave * C9K_RW + r) * 32 * 64 + lane;
-      float v[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int kx = 0; kx < 9; ++kx)
-#pragma unroll
-        for (int co = 0; co < 3; ++co) v[co] += Pr[(kx * 3 + co) * 64 + kx];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = (e < Cout ? v[e] : 0.f) + ((g.bias && e < Cout) ? g.bias[e] : 0.f);
-      uint2 o;
-      o.x = pack_bf16x2(v[0], v[1]); o.y = pack_bf16x2(v[2], v[3]);
-      *reinterpret_cast<uint2*>(Y + ((size_t)(b * H + y0 + wave * C9K_RW + r) * W + x0 + lane) * g.ldc) = o;
-      const float rr[4] = {__uint_as_float(o.x << 16), __uint_as_float(o.x & 0xffff0000u), __uint_as_float(o.y << 16),
-                           __uint_as_float(o.y & 0xffff0000u)};
-#pragma unroll
-      for (int e = 0; e < 4; ++e) { s1[e] += rr[e]; s2[e] += rr[e] * rr[e]; }
-    }
-  }
-  if (g.stats) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const float a1 = wave_sum(s1[e]), a2 = wave_sum(s2[e]);
-      if (lane == 0) { red[(wave * 4 + e) * 2] = a1; red[(wave * 4 + e) * 2 + 1] = a2; }
     }
     lds_barrier();
-    if (t < Cout * 2)
+    GC_STAMP2(2);
+    const int nband = band + (int)gridDim.x;
+    const bool more = nband < nbands;
+    band_coef(more ? nband : band, (k + 1) & 1);      // next band: coefficients and halo in flight during the taps
+    halo_load(more ? nband : band);                   // (clamped, not branched: the last band re-reads its own)
+    // wave w: output rows w*C9K_RW ..; per row four 16-column groups of INPUT columns x two row fragments
+    f32x4_t acc[C9K_RW][4][2];
+#pragma unroll
+    for (int rw = 0; rw < C9K_RW; ++rw)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int f = 0; f < 2; ++f) acc[rw][q][f] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    for (int ky = 0; ky < 9; ++ky) {
+      const bf16x8_t a0 = *reinterpret_cast<const bf16x8_t*>(wb + (ky * 32) * LDWK);
+      const bf16x8_t a1 = *reinterpret_cast<const bf16x8_t*>(wb + (ky * 32 + 16) * LDWK);
+#pragma unroll
+      for (int rw = 0; rw < C9K_RW; ++rw)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const bf16x8_t bf = *reinterpret_cast<const bf16x8_t*>(hb + ((rw + ky) * HW_ + q * 16) * LDP);
+          acc[rw][q][0] = SPB_MFMA16(a0, bf, acc[rw][q][0]);
+          acc[rw][q][1] = SPB_MFMA16(a1, bf, acc[rw][q][1]);
+        }
+    }
+    GC_STAMP2(3);
+    lds_barrier();                                                 // everyone is done with the halo: it becomes P
+    float* P = reinterpret_cast<float*>(halo);                       // [rows][32 (kx, co)][64 input columns]
+#pragma unroll
+    for (int rw = 0; rw < C9K_RW; ++rw)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int f = 0; f < 2; ++f)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) P[((wave * C9K_RW + rw) * 32 + f * 16 + lq * 4 + e) * 64 + q * 16 + li] = acc[rw][q][f][e];
+    lds_barrier();
+    GC_STAMP2(4);
+    // lane = output column (56 of 64 lanes), every row of this wave: y[x][co] = sum_kx P[(kx, co)][x + kx]
+    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+    if (lane < C9K_W) {
+#pragma unroll
+      for (int rw = 0; rw < C9K_RW; ++rw) {
+        const float* Pr = P + (size_t)(wave * C9K_RW + rw) * 32 * 64 + lane;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kx = 0; kx < 9; ++kx)
+#pragma unroll
+          for (int co = 0; co < 3; ++co) v[co] += Pr[(kx * 3 + co) * 64 + kx];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = (e < Cout ? v[e] : 0.f) + ((g.bias && e < Cout) ? g.bias[e] : 0.f);
+        uint2 o;
+        o.x = pack_bf16x2(v[0], v[1]); o.y = pack_bf16x2(v[2], v[3]);
+        *reinterpret_cast<uint2*>(Y + ((size_t)(b * H + y0 + wave * C9K_RW + rw) * W + x0 + lane) * g.ldc) = o;
+        const float rr[4] = {__uint_as_float(o.x << 16), __uint_as_float(o.x & 0xffff0000u), __uint_as_float(o.y << 16),
+                             __uint_as_float(o.y & 0xffff0000u)};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { s1[e] += rr[e]; s2[e] += rr[e] * rr[e]; }
+      }
+    }
+    GC_STAMP2(5);
+    if (g.stats) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float a1 = xor32_sum(xor16_sum(row16_sum(s1[e]))), a2 = xor32_sum(xor16_sum(row16_sum(s2[e])));   // VALU only (no ds_bpermute)
+        if (lane == 0) { red[(wave * 4 + e) * 2] = a1; red[(wave * 4 + e) * 2 + 1] = a2; }
+      }
+    }
+    lds_barrier();     // P is read out (the next commit overwrites it); red is complete
+    if (g.stats && t < Cout * 2)
       atomicAdd(g.stats + (size_t)b * Cout * 2 + t, red[t] + red[8 + t] + red[16 + t] + red[24 + t]);
+    GC_STAMP2(6);
+    if (!more) break;
+    band = nband;
   }
 }
 
@@ -1442,6 +1478,8 @@ extern "C" int spb_debug_set_gconv_halo_prefetch(int on) { g_halo_prefetch = on;
 static int g_wlds_pxg = 1;
 extern "C" int spb_debug_set_gconv_wlds_pxg(int n) { g_wlds_pxg = n; return 0; }
 
+static int g_conv9_wgs = 512;  // 9x9 32->3: persistent workgroups
+extern "C" int spb_debug_set_conv9_wgs(int n) { g_conv9_wgs = n < 1 ? 1 : n; return 0; }
 static int g_conv9_band = 2;   // 9x9 32->3: 0 generic tile kernel, 1 band kernel, 2 kernel columns folded into the matrix rows
 extern "C" int spb_debug_set_conv9_band(int on) { g_conv9_band = on; return 0; }
 
@@ -1458,10 +1496,12 @@ extern "C" int spb_gconv(int dtype, const spb_gconv_args_t* a, spb_stream_t stre
   if (g_conv9_band == 2 && a->KH == 9 && a->Cin == 32 && a->Cout <= 3 && a->stride == 1 && a->upsample == 1 && !(Wout % C9K_W) &&
       !(Hout % C9K_R) && a->ldc >= 4) {
     const size_t halo_b = (size_t)(C9K_R + 8) * (C9K_W + 8) * 40 * sizeof(bf16_t), p_b = (size_t)C9K_R * 32 * 64 * sizeof(float);
-    const size_t ldsk = (64 + 32) * sizeof(float) + (halo_b > p_b ? halo_b : p_b) + (size_t)9 * 32 * 32 * sizeof(bf16_t);
+    const size_t ldsk = (128 + 32) * sizeof(float) + (halo_b > p_b ? halo_b : p_b) + (size_t)9 * 32 * 32 * sizeof(bf16_t);
     static bool oncek = false;
     if (!oncek) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv9_kxrows_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); oncek = true; }
-    hipLaunchKernelGGL(conv9_kxrows_kernel, dim3((unsigned)((Hout / C9K_R) * (Wout / C9K_W)), (unsigned)a->B), dim3(256), ldsk, (hipStream_t)stream, *a);
+    const int nbands = (Hout / C9K_R) * (Wout / C9K_W) * a->B;
+    const int wgs9 = nbands < g_conv9_wgs ? nbands : g_conv9_wgs;      // persistent: two per CU
+    hipLaunchKernelGGL(conv9_kxrows_kernel, dim3((unsigned)wgs9), dim3(256), ldsk, (hipStream_t)stream, *a, nbands);
     SPB_CHECK_LAUNCH();
     return 0;
   }
