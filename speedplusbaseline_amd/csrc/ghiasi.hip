@@ -1270,7 +1270,9 @@ __global__ __launch_bounds__(256) void conv9_rgb_kernel(const float* __restrict_
   const int lane = threadIdx.x & 63, li = lane & 15, lq = lane >> 4, wave = threadIdx.x >> 6;
   const int b = blockIdx.y, y0 = blockIdx.x * C9_R;
   const int rows = min(C9_R, H - y0);
-  // A operand: W[co = cb*16 + li][8 reduction elements of quarter lq]
+  // A operand: W[co][8 reduction elements of quarter lq], row li of fragment cb = channel (li / 4) * 8 + cb * 4 + li % 4: a lane of
+  // the transposed product then holds 8 consecutive channels over its two fragments -- one 16-byte store per pixel and lane,
+  // 1 KB contiguous per wave instruction (it was two 8-byte stores 32 B apart)
   for (int f = wave; f < 22; f += 4) {
     const int st_ = f >> 1, cb = f & 1;
     float v[8];
@@ -1279,20 +1281,21 @@ __global__ __launch_bounds__(256) void conv9_rgb_kernel(const float* __restrict_
       const int k = lq * 8 + e, ci = k & 3, q = k >> 2;        // q: kx (steps 0..8) or ky (steps 9, 10)
       const int ky = st_ < 9 ? st_ : (st_ == 9 ? q : 8), kx = st_ < 9 ? q : 8;
       const bool ok = ci < 3 && (st_ < 10 || q == 0);
-      v[e] = ok ? w[((cb * 16 + li) * 3 + ci) * 81 + ky * 9 + kx] : 0.f;
+      v[e] = ok ? w[(((li >> 2) * 8 + cb * 4 + (li & 3)) * 3 + ci) * 81 + ky * 9 + kx] : 0.f;
     }
     wfrag[(st_ * 2 + cb) * 64 + lane] = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
   }
   // input band: rows y0-4 .. y0+rows+3, columns -4 .. W+3, reflected; one thread = one pixel (3 loads, one 8-byte store)
   const int nrow = rows + 8, ncol = W + 8;
   const int npix = nrow * ncol;
+  const float inv_ncol = 1.0f / (float)ncol;
   for (int i0 = threadIdx.x; i0 < npix; i0 += 256 * 6) {       // 18 loads in flight per thread
     float v[6][3];
     int dst[6];
 #pragma unroll
     for (int u = 0; u < 6; ++u) {
       const int i = i0 + 256 * u, ic = i < npix ? i : npix - 1;
-      const int cx = ic % ncol, r = ic / ncol;
+      const int r = (int)(((float)ic + 0.5f) * inv_ncol), cx = ic - r * ncol;     // exact for ic < 2^20
       const size_t o = (size_t)reflecti(y0 - 4 + r, H) * W + reflecti(cx - 4, W);
 #pragma unroll
       for (int ci = 0; ci < 3; ++ci) v[u][ci] = x[(size_t)(b * 3 + ci) * H * W + o];
@@ -1309,8 +1312,10 @@ __global__ __launch_bounds__(256) void conv9_rgb_kernel(const float* __restrict_
 #pragma unroll
     for (int e = 0; e < 4; ++e) { s1[cb][e] = 0.f; s2[cb][e] = 0.f; }
   const int gpr = W >> 4;
+  int ry = 0, gx = wave;                       // group gi = ry * gpr + gx, walked without dividing
+  while (gx >= gpr) { gx -= gpr; ++ry; }
   for (int gi = wave; gi < rows * gpr; gi += 4) {
-    const int ry = gi / gpr, ox = (gi % gpr) * 16 + li, oy = y0 + ry;
+    const int ox = gx * 16 + li, oy = y0 + ry;
     f32x4_t acc[2] = {(f32x4_t){0.f, 0.f, 0.f, 0.f}, (f32x4_t){0.f, 0.f, 0.f, 0.f}};
     const bf16_t* rp = xs + ((size_t)ry * LDX + ox) * 4;
 #pragma unroll
@@ -1331,19 +1336,23 @@ __global__ __launch_bounds__(256) void conv9_rgb_kernel(const float* __restrict_
       for (int cb = 0; cb < 2; ++cb)
         acc[cb] = SPB_MFMA16(__builtin_bit_cast(bf16x8_t, wfrag[(st_ * 2 + cb) * 64 + lane]), bf, acc[cb]);
     }
+    {
+      uint2 o[2];
 #pragma unroll
-    for (int cb = 0; cb < 2; ++cb) {
-      float v[4];
+      for (int cb = 0; cb < 2; ++cb) {
+        float v[4];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = acc[cb][e] + (bias ? bias[cb * 16 + lq * 4 + e] : 0.f);
-      uint2 o;
-      o.x = pack_bf16x2(v[0], v[1]); o.y = pack_bf16x2(v[2], v[3]);
-      *reinterpret_cast<uint2*>(y + ((size_t)(b * H + oy) * W + ox) * 32 + cb * 16 + lq * 4) = o;
-      const float r[4] = {__uint_as_float(o.x << 16), __uint_as_float(o.x & 0xffff0000u), __uint_as_float(o.y << 16),
-                          __uint_as_float(o.y & 0xffff0000u)};
+        for (int e = 0; e < 4; ++e) v[e] = acc[cb][e] + (bias ? bias[lq * 8 + cb * 4 + e] : 0.f);
+        o[cb].x = pack_bf16x2(v[0], v[1]); o[cb].y = pack_bf16x2(v[2], v[3]);
+        const float r[4] = {__uint_as_float(o[cb].x << 16), __uint_as_float(o[cb].x & 0xffff0000u), __uint_as_float(o[cb].y << 16),
+                            __uint_as_float(o[cb].y & 0xffff0000u)};
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { s1[cb][e] += r[e]; s2[cb][e] += r[e] * r[e]; }
+        for (int e = 0; e < 4; ++e) { s1[cb][e] += r[e]; s2[cb][e] += r[e] * r[e]; }
+      }
+      *reinterpret_cast<uint4*>(y + ((size_t)(b * H + oy) * W + ox) * 32 + lq * 8) = make_uint4(o[0].x, o[0].y, o[1].x, o[1].y);
     }
+    gx += 4;
+    while (gx >= gpr) { gx -= gpr; ++ry; }
   }
   if (stats) {
 #pragma unroll
@@ -1351,7 +1360,7 @@ __global__ __launch_bounds__(256) void conv9_rgb_kernel(const float* __restrict_
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const float a1 = row16_sum(s1[cb][e]), a2 = row16_sum(s2[cb][e]);
-        if (li == 0) { red[wave * 64 + (cb * 16 + lq * 4 + e) * 2] = a1; red[wave * 64 + (cb * 16 + lq * 4 + e) * 2 + 1] = a2; }
+        if (li == 0) { red[wave * 64 + (lq * 8 + cb * 4 + e) * 2] = a1; red[wave * 64 + (lq * 8 + cb * 4 + e) * 2 + 1] = a2; }
       }
     lds_barrier();
     if (threadIdx.x < 64)
