@@ -438,8 +438,11 @@ __global__ __launch_bounds__(256) void gconv_kernel(const spb_gconv_args_t g, in
 // then has no weight traffic at all and is fully unrolled: 16 pixel-fragment reads in two batches, 32 MFMAs (timestamps, round 3:
 // the LDS-resident version spent 1.55 us per 128-pixel group in its 8-step loop for 0.43 us of matrix-core work -- one LDS round
 // trip per step -- and its 67 KB of weights per workgroup held the CU at two workgroups; without them LDS is 11 KB).
-template <int NB, bool WLDS, int PXG, int NV = 0, bool WREG = false>
-__global__ __launch_bounds__(256, WREG ? 3 : 1) void gconv_up2_kernel(const spb_gconv_args_t g, int tpw) {
+// The same for the 128 -> 64 layer (NB == 4, Cin == 128): 16 steps x 4 fragments = 256 registers of weights per wave, one
+// workgroup per CU -- four waves that never wait for a weight: the streamed version spent 12.9 us per 256-pixel group in its tap
+// loop (two steps of weights in flight per wave) for 1.7 us of matrix-core work.
+template <int NB, bool WLDS, int PXG, int NV = 0, bool WREG = false, int WSTEPS = 8>
+__global__ __launch_bounds__(256, (WREG && NB == 2) ? 3 : 1) void gconv_up2_kernel(const spb_gconv_args_t g, int tpw) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int PD = 2, HT = 6, KT = 4, SU = 4;
   const int Cin = g.Cin, Cout = g.Cout;
@@ -560,11 +563,12 @@ __global__ __launch_bounds__(256, WREG ? 3 : 1) void gconv_up2_kernel(const spb_
     }
   };
   if constexpr (NV > 0) pre_issue(0);
-  uint4 areg[WREG ? 8 : 1][NB];
-  if constexpr (WREG) {     // step s = (ky * 2 + kx) * 2 + cc, as the tap loops below walk it
+  constexpr int WNCH = WSTEPS / 4;                    // 32-channel chunks per tap (Cin / 32)
+  uint4 areg[WREG ? WSTEPS : 1][NB];
+  if constexpr (WREG) {     // step s = (ky * 2 + kx) * WNCH + cc, as the tap loops below walk it
 #pragma unroll
-    for (int s_ = 0; s_ < 8; ++s_) {
-      const int ko = (s_ >> 1) * Cin + (s_ & 1) * 32 + lq * 8;
+    for (int s_ = 0; s_ < WSTEPS; ++s_) {
+      const int ko = (s_ / WNCH) * Cin + (s_ % WNCH) * 32 + lq * 8;
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) {
         const uint4 w = *reinterpret_cast<const uint4*>(Wg + ((size_t)(ph * Cout + wco[nb]) * KT) * Cin + ko);
@@ -629,23 +633,24 @@ __global__ __launch_bounds__(256, WREG ? 3 : 1) void gconv_up2_kernel(const spb_
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) acc[p][nb] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
     if constexpr (WREG) {
+      constexpr int BATCH = PXG >= 4 ? 2 : 4;         // steps whose pixel fragments are read together (8 fragments)
 #pragma unroll
-      for (int half = 0; half < 2; ++half) {
-        bf16x8_t bf[4][PXG];
+      for (int s0 = 0; s0 < WSTEPS; s0 += BATCH) {
+        bf16x8_t bf[BATCH][PXG];
 #pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4) {
-          const int s_ = half * 4 + s4;       // ky = half, kx = s4 / 2, cc = s4 % 2
+        for (int sb = 0; sb < BATCH; ++sb) {
+          const int s_ = s0 + sb, tap = s_ / WNCH;   // ky = tap / 2, kx = tap % 2
 #pragma unroll
           for (int p = 0; p < PXG; ++p)
-            bf[s4][p] = *reinterpret_cast<const bf16x8_t*>(hbase + (p * HT * HT + (s_ >> 2) * HT + ((s_ >> 1) & 1)) * LDP + (s_ & 1) * 32);
+            bf[sb][p] = *reinterpret_cast<const bf16x8_t*>(hbase + (p * HT * HT + (tap >> 1) * HT + (tap & 1)) * LDP + (s_ % WNCH) * 32);
         }
 #pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4)
+        for (int sb = 0; sb < BATCH; ++sb)
 #pragma unroll
           for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
             for (int p = 0; p < PXG; ++p)
-              acc[p][nb] = SPB_MFMA16(__builtin_bit_cast(bf16x8_t, areg[half * 4 + s4][nb]), bf[s4][p], acc[p][nb]);
+              acc[p][nb] = SPB_MFMA16(__builtin_bit_cast(bf16x8_t, areg[s0 + sb][nb]), bf[sb][p], acc[p][nb]);
       }
     } else if constexpr (WLDS) {
       int ky = 0, kx = 0, cc = 0;
@@ -1592,7 +1597,7 @@ extern "C" int spb_gconv(int dtype, const spb_gconv_args_t* a, spb_stream_t stre
   return 0;
 }
 
-static int g_up2_wreg = 1;       // 64 -> 32 phase layer: weights in registers instead of LDS
+static int g_up2_wreg = 2;       // phase layers: weights in registers (1: the 64 -> 32 layer; 2: the 128 -> 64 layer as well)
 extern "C" int spb_debug_set_gconv_up2_wreg(int on) { g_up2_wreg = on; return 0; }
 static int g_up2_prefetch = 1;   // phase kernels: next tile group's halo loads in flight during the current group
 extern "C" int spb_debug_set_gconv_up2_prefetch(int on) { g_up2_prefetch = on; return 0; }
@@ -1606,7 +1611,8 @@ extern "C" int spb_gconv_up2(int dtype, const spb_gconv_args_t* a, spb_stream_t 
   if ((Hout & 7) || (Wout & 7) || a->ldc < a->Cout || (a->ldc & 3)) return SPB_E_SHAPE;
   const int NB = a->Cout <= 16 ? 1 : (a->Cout <= 32 ? 2 : (a->Cout <= 64 ? 4 : 8));
   const size_t wbytes = (size_t)4 * NB * 16 * (4 * a->Cin + 8) * 2;
-  const bool wreg = g_up2_wreg && NB == 2 && a->Cin == 64;          // phase weights in registers (gconv_up2_kernel, WREG)
+  const bool wreg4 = g_up2_wreg >= 2 && NB == 4 && a->Cin == 128 && a->Cout == 64;                  // ... 256 registers of them, one workgroup per CU
+  const bool wreg = (g_up2_wreg && NB == 2 && a->Cin == 64) || wreg4;   // phase weights in registers (gconv_up2_kernel, WREG)
   const bool wlds = !wreg && wbytes <= 72 * 1024;
   if (!wlds && a->Cout != NB * 16) return SPB_E_SHAPE;
   if (NB != 2 && NB != 4) return SPB_E_UNSUPPORTED;
@@ -1617,7 +1623,7 @@ extern "C" int spb_gconv_up2(int dtype, const spb_gconv_args_t* a, spb_stream_t 
   const int gpi = (tpi + pxg - 1) / pxg;
   int tpw = 1;
   for (int d = 1; d <= gpi; ++d)
-    if (gpi % d == 0 && (long long)a->B * (gpi / d) >= 1024) tpw = d;
+    if (gpi % d == 0 && (long long)a->B * (gpi / d) >= (wreg4 ? 512 : 1024)) tpw = d;     // wreg4: one workgroup per CU, a few rounds
   const dim3 grid((unsigned)(a->B * (gpi / tpw)));
   hipStream_t s = (hipStream_t)stream;
 #define U_(NB_, WL_, PX_, NV_) U5_(NB_, WL_, PX_, NV_, false)
@@ -1633,7 +1639,20 @@ extern "C" int spb_gconv_up2(int dtype, const spb_gconv_args_t* a, spb_stream_t 
   }
   const int hv = pxg * 36 * (a->Cin >> 3);          // halo vectors per tile group
   const bool pre = g_up2_prefetch && tpw > 1;
-  if (wreg) {
+  if (wreg4) {
+#define U6_(NV_)                                                                                                     \
+  {                                                                                                                  \
+    static bool once = false;                                                                                        \
+    if (!once) {                                                                                                     \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gconv_up2_kernel<4, false, 2, NV_, true, 16>),        \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                             \
+      once = true;                                                                                                   \
+    }                                                                                                                \
+    hipLaunchKernelGGL((gconv_up2_kernel<4, false, 2, NV_, true, 16>), grid, dim3(256), lds, s, *a, tpw);            \
+  }
+    if (pre && hv <= 1280) U6_(5) else U6_(0)
+#undef U6_
+  } else if (wreg) {
     if (pre) U5_(2, false, 2, 3, true) else U5_(2, false, 2, 0, true)
   } else if (NB == 2) {
     if (wlds) { if (pre && hv <= 768) U_(2, true, 2, 3) else U_(2, true, 2, 0) }
