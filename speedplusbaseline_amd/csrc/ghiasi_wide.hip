@@ -151,10 +151,16 @@ __global__ __launch_bounds__(256, 2) void gconv_wide_kernel(const spb_gconv_args
   GwGroup cur = gw_group(base + l, gpi, tpi, tiles_x);
   if (!(GWABL & 2)) issue_halo(cur);
   if (delay) {     // experiment: the second workgroup of a CU starts half a period late (its VALU phases under the first one's MFMA loop)
+    // decided by wave 0 for the whole workgroup (each wave reading its own HW_ID made every workgroup "late" through the barrier):
+    // the wave-slot index of wave 0 on its SIMD differs between the two resident workgroups of a CU
     unsigned hwid;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
-    const bool late = delay > 0 ? (hwid & 1) : ((blockIdx.x >> 3) >= (gridDim.x >> 4));
+    if (t == 0) red[0] = (float)(hwid & 0xf);
+    __syncthreads();
+    const int slot = (int)red[0];
+    const bool late = delay > 0 ? (slot & 1) : ((blockIdx.x >> 3) & 1);
     if (late) for (int i = 0; i < (delay > 0 ? delay : -delay); ++i) __builtin_amdgcn_s_sleep(16);   // 16 x 64 cycles = 0.43 us
+    __syncthreads();
   }
 
   const int prow = 4 * (li >> 3), pcol = li & 7;      // fragment f = tile (f / 4), rows (f % 4, f % 4 + 4)
