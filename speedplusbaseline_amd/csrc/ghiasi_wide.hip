@@ -24,10 +24,14 @@
 // whole weight prefetch in front of it.  Two 8x8 tiles per group, 57 KB of LDS, 220 VGPRs, no scratch.
 // Measured and dropped: tile-granular work split (5 | 4 tiles per workgroup instead of 6 | 4: single-tile units pay the whole
 // staging/epilogue cost, 46 us), staggered entry into the weight cycle and a delayed second workgroup per CU (no effect), pixel
-// fragments double-buffered in registers (GW_BF2: no effect once it fits without scratch), three workgroups per CU (168 registers:
-// the remaining 104 B of scratch sit between the halo loads and serialise them -- commit 12 us, 55 us per layer).
+// fragments double-buffered in registers (GW_BF2: no effect once it fits without scratch), three workgroups per CU (GW_OCC3: a first
+// 168-register build kept 104 B of scratch between the halo loads -- commit 12 us, 55 us per layer; scratch-free with the weight
+// prefetch 3 steps deep it is 43.0 against 45.1 us in the microbenchmark and nothing in the decoder itself: kept as an option).
 #include "common.h"
 
+#ifndef GW_OCC3
+#define GW_OCC3 0   // 1: three workgroups per CU: 168 registers (weight prefetch 3 steps deep), 51.7 KB of LDS (unstaggered planes,
+#endif              //    the reduction scratch inside the staging area)
 #ifndef GW_BF2
 #define GW_BF2 0   // 1: pixel fragments double-buffered in registers (one reduction step ahead)
 #endif
@@ -44,11 +48,11 @@ __device__ unsigned long long* g_gw_ts;     // scratch/ubench_gconv.hip: [workgr
 
 namespace {
 
-constexpr int GW_PLANE = 1632;           // bytes per chunk plane: 100 pixels x 16 B + 32 (staggers the 8 planes of a parity over the store banks)
+constexpr int GW_PLANE = GW_OCC3 ? 1600 : 1632;   // bytes per chunk plane: 100 pixels x 16 B (+ 32: staggers the 8 planes of a parity over the store banks)
 constexpr int GW_ODD = 8 * GW_PLANE;     // 13056 = 51 x 256: where the odd chunks start
 constexpr int GW_TILE = 2 * GW_ODD;      // one 8x8 tile's 10x10 halo, 128 channels
 constexpr int GW_OPITCH = 272;           // output staging: 128 channels of a pixel + 16 B
-constexpr int GW_PF = 6;                 // reduction steps of weight fragments in flight per wave (global -> registers, 2 KB each)
+constexpr int GW_PF = GW_OCC3 ? 3 : 6;                 // reduction steps of weight fragments in flight per wave (global -> registers, 2 KB each)
 constexpr int GW_NSTEP = 36;             // 9 taps x 4 chunks of 32 input channels
 constexpr int GW_HV = 2 * 100 * 16;      // halo vectors (8 channels) per workgroup
 constexpr int GW_HU = (GW_HV + 255) / 256;
@@ -94,11 +98,12 @@ __device__ __forceinline__ GwGroup gw_group(int gid, int gpi, int tpi, int tiles
 // output stores were acknowledged and restarted the weight stream from an empty pipe; here the stores drain under the next
 // group's work, the halo round trip hides behind the epilogue, and the weight ring never stops (36 steps per group, PF | 36: the
 // prefetch simply wraps to slab 0).
-__global__ __launch_bounds__(256, 2) void gconv_wide_kernel(const spb_gconv_args_t g, int ngroups, int rotate, int delay) {
+__global__ __launch_bounds__(256, GW_OCC3 ? 3 : 2) void gconv_wide_kernel(const spb_gconv_args_t g, int ngroups, int rotate, int delay) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* halo = smem;                             // [2 tiles][GW_TILE]; in the epilogue: output staging [128 pixels][GW_OPITCH]
-  float* red = reinterpret_cast<float*>(smem + 2 * GW_TILE);   // [4 waves][128][2]
-  float* biasl = red + 4 * 128 * 2;              // [128]
+  // [4 waves][128][2]; GW_OCC3: behind the output staging inside the (then idle) halo area, fenced by one more barrier per group
+  float* red = reinterpret_cast<float*>(GW_OCC3 ? smem + 128 * GW_OPITCH : smem + 2 * GW_TILE);
+  float* biasl = reinterpret_cast<float*>(smem + 2 * GW_TILE) + (GW_OCC3 ? 0 : 4 * 128 * 2);   // [128]
   const int t = threadIdx.x, lane = t & 63, li = lane & 15, lq = lane >> 4, wave = t >> 6;
   const int H = g.Hin, W = g.Win;
   const int tiles_x = W >> 3, tpi = tiles_x * (H >> 3), gpi = (tpi + 1) >> 1;
@@ -336,6 +341,7 @@ __global__ __launch_bounds__(256, 2) void gconv_wide_kernel(const spb_gconv_args
     }
     lds_barrier();   // the staging area is read out (the next commit overwrites it); red is complete
     if (g.stats) atomicAdd(g.stats + (size_t)cur.b * 256 + t, red[t] + red[256 + t] + red[512 + t] + red[768 + t]);
+    if (GW_OCC3) lds_barrier();     // red sits where the next commit writes
     GW_STAMP(4);
     if (!more) break;
     l = ln;
@@ -370,7 +376,7 @@ static int g_gw_delay = 0;
 extern "C" int spb_debug_set_gconv_wide_delay(int n) { g_gw_delay = n; return 0; }
 static int g_gw_rot = 1;     // workgroups enter the weight cycle at staggered steps
 extern "C" int spb_debug_set_gconv_wide_rotate(int on) { g_gw_rot = on; return 0; }
-static int g_gw_wgs = 512;   // persistent workgroups: two per CU
+static int g_gw_wgs = GW_OCC3 ? 768 : 512;   // persistent workgroups: two (three) per CU
 extern "C" int spb_debug_set_gconv_wide_wgs(int n) { g_gw_wgs = n < 8 ? 8 : (n & ~7); return 0; }
 
 extern "C" int spb_gconv_wide(int dtype, const spb_gconv_args_t* a, spb_stream_t stream) {
@@ -380,7 +386,7 @@ extern "C" int spb_gconv_wide(int dtype, const spb_gconv_args_t* a, spb_stream_t
   if ((a->Hin & 7) || (a->Win & 7) || a->Hin < 8 || a->Win < 8 || a->ldc < 128 || (a->ldc & 7)) return SPB_E_SHAPE;
   const int tpi = (a->Hin >> 3) * (a->Win >> 3), gpi = (tpi + 1) >> 1;
   const int ngroups = a->B * gpi;
-  const size_t lds = 2 * GW_TILE + (4 * 128 * 2 + 128) * sizeof(float);
+  const size_t lds = 2 * GW_TILE + ((GW_OCC3 ? 0 : 4 * 128 * 2) + 128) * sizeof(float);
   const int nwg = ngroups < g_gw_wgs ? ((ngroups + 7) & ~7) : g_gw_wgs;   // a multiple of 8: one share per XCD
   static bool once = false;
   if (!once) {
