@@ -53,6 +53,19 @@ int main() {
       }
       hipFree(ts);
     }
+    if (getenv("GS") && sh.st == 2 && sh.Cin == 32) {
+      unsigned long long* ts; CK(hipMalloc(&ts, 1024 * 16 * 8)); CK(hipMemset(ts, 0, 1024 * 16 * 8));
+      CK(hipMemcpyToSymbol(HIP_SYMBOL(g_gc_ts), &ts, sizeof(ts)));
+      spb_gconv(SPB_BF16, &a, 0); CK(hipDeviceSynchronize());
+      static unsigned long long hs[1024 * 16]; CK(hipMemcpy(hs, ts, sizeof(hs), hipMemcpyDeviceToHost));
+      unsigned long long* nul = nullptr; CK(hipMemcpyToSymbol(HIP_SYMBOL(g_gc_ts), &nul, sizeof(nul)));
+      for (int ti = 0; ti < 4; ++ti) {
+        double av[3] = {0, 0, 0}; int n = 0;
+        for (int w = 0; w < 512; ++w) if (hs[(w * 4 + ti) * 4]) { ++n; for (int i = 0; i < 3; ++i) av[i] += (double)(hs[(w * 4 + ti) * 4 + i] - hs[(w * 4) * 4]) / 100.0; }
+        if (n) printf("  32->64 s2 tile %d (%4d wgs, us from the workgroup's first stamp): top %.2f  committed %.2f  loop done %.2f\n", ti, n, av[0] / n, av[1] / n, av[2] / n);
+      }
+      hipFree(ts);
+    }
     if (getenv("K9") && sh.K == 9) {
       unsigned long long* ts; CK(hipMalloc(&ts, 512 * 8 * 8)); CK(hipMemset(ts, 0, 512 * 8 * 8));
       CK(hipMemcpyToSymbol(HIP_SYMBOL(g_gc_ts), &ts, sizeof(ts)));

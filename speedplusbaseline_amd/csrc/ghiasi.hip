@@ -271,11 +271,13 @@ __global__ __launch_bounds__(256) void gconv_kernel(const spb_gconv_args_t g, in
     int oy0[PXG], ox0[PXG];
     bool tvalid[PXG];
     tile_origin(ti, oy0, ox0, tvalid);
+    GC_STAMP(0);
     lds_barrier();   // previous tile's taps are done with the halo (first pass: coefficient / weight tables written)
     // ---- stage the input halo(s)
     if constexpr (PRE) {
       if (!(GABL & 2)) halo_commit<PSU>(g, hregs, halo, cf);
       lds_barrier();
+      GC_STAMP(1);
       int oyn[PXG], oxn[PXG]; bool tvn[PXG];                    // next tile's halo: in flight during this tile's taps and stores
       tile_origin(ti + 1 < tpw ? ti + 1 : ti, oyn, oxn, tvn);   // (clamped, no branch around the loads: the last one is redundant)
       halo_issue<PXG, PSU>(g, X, hregs, b, oyn, oxn, HT, LDP, Hu, Wu, st, up, pad, t);
@@ -366,6 +368,7 @@ __global__ __launch_bounds__(256) void gconv_kernel(const spb_gconv_args_t g, in
         }
       }
     }
+    GC_STAMP(2);
     // ---- epilogue: lane (li = pixel, lq): channels lq*4*NB + nb*4 + e -- one contiguous run, 16-byte stores
 #pragma unroll
     for (int p = 0; p < PXG; ++p) {
