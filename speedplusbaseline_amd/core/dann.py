@@ -8,6 +8,7 @@ from torch.nn.utils import clip_grad_norm_
 
 from ..optim import FusedOptimizer
 from ..utils import AverageMeter, report_progress
+from .trainer import _world
 
 
 def dann_alpha(idx, epoch, n_batches, max_epochs):
@@ -25,6 +26,7 @@ def train_dann_single_epoch_krn(epoch, cfg, model, dataloader_source, dataloader
     lr = optimizer.param_groups[-1]['lr']
     n_batches = min(len(dataloader_source), len(dataloader_target))
     fused = isinstance(optimizer, FusedOptimizer)
+    world, group = _world()     # data parallel (one process per GPU): the summed gradient arena is averaged before the clip
     for idx, ((source, label), target) in enumerate(zip(dataloader_source, dataloader_target)):
         B = source.size(0)
         ts = time.time()
@@ -33,7 +35,7 @@ def train_dann_single_epoch_krn(epoch, cfg, model, dataloader_source, dataloader
         target = target.to(device, non_blocking=True)
         alpha = dann_alpha(idx, epoch, n_batches, cfg.max_epochs)
         if fused:
-            s = optimizer.train_step(source, label, target_images=target, alpha=alpha).tolist()
+            s = optimizer.train_step(source, label, target_images=target, alpha=alpha, world_size=world, group=group).tolist()
             l_pose, l_src, l_tgt = s[0], s[3], s[4]
         else:
             optimizer.zero_grad(set_to_none=True)

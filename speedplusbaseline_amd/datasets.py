@@ -72,12 +72,20 @@ class GpuTransformLoader:
                 yield images, boxes, torch.from_numpy(np.stack(qs)), torch.from_numpy(np.stack(ts))
 
 
-def make_dataloader(cfg, is_train=True, is_source=True, load_labels=True, device="cuda"):
-    """src/datasets/build.py:48-66 (batch size / shuffle / workers / drop_last as there), KRN datasets"""
+def make_dataloader(cfg, is_train=True, is_source=True, load_labels=True, device="cuda", rank=0, world=1):
+    """src/datasets/build.py:48-66 (batch size / shuffle / workers / drop_last as there), KRN datasets.  world > 1 (data parallel,
+    one process per GPU): every rank draws cfg.batch_size frames per step from its own 1/world shard of an epoch's permutation
+    (DistributedSampler seeded with cfg.seed; call loader.set_epoch(e) to reshuffle)."""
     if cfg.model_name != 'krn':
         raise NotImplementedError("the SPN dataset needs the attitude-class files of the reference checkout; only the KRN loader is built")
     dataset = Park2019KRNFrames(cfg, is_train, is_source, load_labels)
-    loader = DataLoader(dataset, batch_size=cfg.batch_size if is_train else 1, shuffle=is_train,
+    sampler = None
+    if world > 1 and is_train:
+        from torch.utils.data.distributed import DistributedSampler
+        sampler = DistributedSampler(dataset, num_replicas=world, rank=rank, shuffle=True, seed=int(getattr(cfg, "seed", 0)), drop_last=True)
+    loader = DataLoader(dataset, batch_size=cfg.batch_size if is_train else 1, shuffle=is_train and sampler is None, sampler=sampler,
                         num_workers=cfg.num_workers if is_train else 1, collate_fn=list, drop_last=True)
     transform = build_transforms(cfg.model_name, cfg.input_shape, is_train=is_train, device=device)
-    return GpuTransformLoader(loader, transform, is_train, load_labels)
+    out = GpuTransformLoader(loader, transform, is_train, load_labels)
+    out.set_epoch = sampler.set_epoch if sampler is not None else (lambda epoch: None)
+    return out

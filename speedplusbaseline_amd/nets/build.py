@@ -12,6 +12,9 @@ logger = logging.getLogger(__name__)
 def _precision(cfg):
     p = getattr(cfg, "precision", None)
     if p:
+        if p == "fp16" and (cfg.model_name != 'spn' or getattr(cfg, "dann", False)):
+            raise ValueError("--precision fp16 exists for SPN only (IEEE-half kernels + device-side loss scaling); KRN / RevGrad "
+                             "run --precision bf16 (what --use_fp16 selects for them) or fp32")
         return p
     if getattr(cfg, "fp16", False):
         # reference: torch.cuda.amp autocast (float16) + GradScaler (train.py:101-104, trainer.py:73-94, 146-181).

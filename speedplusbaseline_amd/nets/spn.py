@@ -173,7 +173,18 @@ class SpacecraftPoseNet(nn.Module):
             st = torch.zeros(L.AMP_STATE, dtype=torch.float32, device=self._flat.device)
             st[L.AMP_SCALE] = float(init_scale); st[L.AMP_INV_SCALE] = 1.0 / float(init_scale)
             self._amp = st
+        pending = getattr(self, "_amp_pending", None)
+        if pending is not None:           # SpnOptimizer.load_state_dict: the checkpointed scaler state (the model may have been on the CPU then)
+            self._amp.copy_(pending.to(self._amp.device))
+            self._amp_pending = None
         return self._amp
+
+    def restore_amp_state(self, state):
+        """float32 [SPB_AMP_STATE] host tensor from a checkpoint (SpnOptimizer.state_dict()['spn_fused']['amp']): written to the
+        device state on its next use, i.e. before the next forward scales a loss gradient"""
+        if state.numel() != L.AMP_STATE:
+            raise ValueError("AMP state has %d floats, expected %d" % (state.numel(), L.AMP_STATE))
+        self._amp_pending = state
 
     def loss_scale(self):
         """current loss scale (host float; synchronises) -- 1.0 outside fp16 mode"""
@@ -705,8 +716,13 @@ class SpacecraftPoseNet(nn.Module):
         dcg, drg = self._buf("dc", (B, NC), dt), self._buf("dr", (B, NC), dt)
         ycf, ywf = y_classes.float().contiguous(), y_weights.float().contiguous()
         if not fast:
-            L.check(lib.spb_softce(dc, _p(c), _p(ycf), _p(dcg), _p(out), 1, B, NC, 1.0, st), "spb_softce")
-            L.check(lib.spb_softce(dc, _p(r), _p(ywf), _p(drg), _p(out), 2, B, NC, 10.0, st), "spb_softce")
+            if self.precision == "fp16":   # scaler.scale(loss).backward(): SpnOptimizer._step_fp16 divides every gradient by the scale
+                sc = _p(self.amp_state()[L.AMP_SCALE:L.AMP_SCALE + 1])
+                L.check(lib.spb_softce_scaled(dc, _p(c), _p(ycf), _p(dcg), _p(out), 1, B, NC, 1.0, sc, st), "spb_softce_scaled")
+                L.check(lib.spb_softce_scaled(dc, _p(r), _p(ywf), _p(drg), _p(out), 2, B, NC, 10.0, sc, st), "spb_softce_scaled")
+            else:
+                L.check(lib.spb_softce(dc, _p(c), _p(ycf), _p(dcg), _p(out), 1, B, NC, 1.0, st), "spb_softce")
+                L.check(lib.spb_softce(dc, _p(r), _p(ywf), _p(drg), _p(out), 2, B, NC, 10.0, st), "spb_softce")
         ident = ops.bnref
         scale = 1.0 / (1.0 - self.keep_prob)
         self._gflat[:self._conv_end].zero_()          # conv bias gradients are accumulated with atomics
@@ -746,7 +762,9 @@ class SpacecraftPoseNet(nn.Module):
                         g = self._buf("g" + prev, (B, 4096), dt)
                         gT = self._buf("gT" + prev, (4096, MP), dt)
                         self._epi(B, 4096, 1, accT=acc, H=sv["h" + prev], Y=g, YT=gT, db=getattr(self, prev).bias.grad, scale=scale)
-                if hi == 1 and getattr(self, "_heads_forked", False):
+                if hi == 1 and getattr(self, "_heads_forked", False) and self.side_wgrad:
+                    # (side_wgrad off: the three weight gradients below run on this head's stream right here, and the launch
+                    # stream must wait for ALL of it -- _join_heads then waits for the stream, not for the event)
                     # the launch stream needs the forked head's INPUT-gradient chain only: mark its end before the three
                     # HBM-bound weight-gradient kernels (20-50 us each) are queued behind it on the same stream
                     if getattr(self, "_hev", None) is None:

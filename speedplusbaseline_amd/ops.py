@@ -40,7 +40,13 @@ def _need_rows(*ts):
             raise RuntimeError("speedplusbaseline_amd GEMM operands are row-major 2-D tensors or 8-aligned column slabs of one")
 
 
-def dtype_code(t):
+def dtype_code(t, twin=False):
+    """16-bit / 32-bit code of tensor t for the C-ABI.  float16 shares bfloat16's code and is only meaningful in the IEEE-half
+    twin library (lib_of): entry points that exist in libspb_hip.so alone (the KRN kernels) pass twin=False and refuse it
+    instead of reading half bits as bfloat16."""
+    if t.dtype == torch.float16 and not twin:
+        raise RuntimeError("this kernel has no float16 instance (bfloat16 / float32 only): float16 is built for the SPN path "
+                           "(libspb_hip_f16.so); KRN / RevGrad use --precision bf16")
     try:
         return _DT[t.dtype]
     except KeyError:
@@ -72,7 +78,7 @@ def pwconv_gemm(A, Bw, Y, pro, pro_mode, epi_mode, A2=None, res=None, Zout=None,
     if pro_mode == 3:       # residual join: a = bn(A) + bn2(A2), written to Ymat by the launch
         _need_cuda(Ymat)
         g.pro2 = pro2 if pro2 is not None else bnref(A.shape[1]); g.Ymat = _ptr(Ymat)
-    L.check(lib_of(A).spb_pwconv_gemm(dtype_code(A), C.byref(g), _stream()), "spb_pwconv_gemm")
+    L.check(lib_of(A).spb_pwconv_gemm(dtype_code(A, True), C.byref(g), _stream()), "spb_pwconv_gemm")
 
 
 def pwconv_wgrad(G, X, dW, pro_dz, pro_a, Zn=None):
@@ -83,7 +89,7 @@ def pwconv_wgrad(G, X, dW, pro_dz, pro_a, Zn=None):
     w.M = G.shape[0]; w.N = G.shape[1]; w.K = X.shape[1]
     w.ldg = G.stride(0) if G.stride(0) != G.shape[1] else 0
     w.ldx = X.stride(0) if X.stride(0) != X.shape[1] else 0
-    L.check(lib_of(G).spb_pwconv_wgrad(dtype_code(G), C.byref(w), _stream()), "spb_pwconv_wgrad")
+    L.check(lib_of(G).spb_pwconv_wgrad(dtype_code(G, True), C.byref(w), _stream()), "spb_pwconv_wgrad")
 
 
 def pwconv_bwd_fused(G, Zn, Wt, X, Zout, Y, dW, osums, pro_dz, pro_a, epi, res=None, oR=1):

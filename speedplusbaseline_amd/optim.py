@@ -149,6 +149,7 @@ class SpnOptimizer(torch.optim.Optimizer):
         self._t = 0
         self._m = self._v = self._gmul = None
         self._early = []       # arena ranges already updated for the step in flight (update_range_early)
+        self._shard_buckets = {}   # lo -> (lo, hi, world) of buckets whose moments are rank-sharded right now
 
     def _betas(self, kind, momentum):
         if kind == "rmsprop":
@@ -156,6 +157,41 @@ class SpnOptimizer(torch.optim.Optimizer):
         if kind in ("adam", "adamw"):
             return momentum, 0.999
         return momentum, 0.0
+
+    # ---- rank-sharded optimizer state (SpacecraftPoseNet.loss_and_grads(sharded=True)): after a sharded step the moments of a
+    #      fully connected bucket are current on their owner's slice only, like the f32 master parameters
+    def gather_sharded_state(self, group=None):
+        """COLLECTIVE (every rank, same order): all-gathers the moments of every bucket that was updated rank-sharded, and the
+        model's f32 master slices (sync_sharded_params), so that m / v / parameters are complete and identical on all ranks.
+        state_dict() calls it -- under a sharded run EVERY rank must therefore call optimizer.state_dict() / model.state_dict()
+        (train.py does; only rank 0 writes the file).  No-op when nothing is sharded."""
+        buckets, self._shard_buckets = self._shard_buckets, {}
+        mdl = self._model
+        mdl.sync_sharded_params()
+        if not buckets or self._m is None:
+            return
+        import torch.distributed as dist
+        from .parallel import shard_slice
+        mdl.join_updates()
+        if getattr(mdl, "_early_on_comm", False):
+            torch.cuda.current_stream().wait_stream(mdl._comm)
+        rank = dist.get_rank(group)
+        for lo, hi, world in buckets.values():
+            per, my_lo, my_hi = shard_slice(lo, hi, rank, world)
+            n, k = hi - lo, my_hi - my_lo
+            for arena in (self._m, self._v):
+                g_in = torch.zeros(per, dtype=torch.float32, device=arena.device)
+                if k > 0:
+                    g_in[:k].copy_(arena[my_lo:my_hi])
+                g_out = torch.empty(per * world, dtype=torch.float32, device=arena.device)
+                dist.all_gather_into_tensor(g_out, g_in, group=group)
+                arena[lo:hi].copy_(g_out[:n])
+
+    def _unshard_if_needed(self, lo, hi):
+        """a NON-sharded update of [lo, hi) after sharded steps (e.g. a ragged last batch that takes the generic path) must see
+        complete masters and moments there: gather first (collective -- every rank takes the same path, the batch shape decides it)"""
+        if any(a < hi and lo < b for a, b, _ in self._shard_buckets.values()):
+            self.gather_sharded_state()
 
     def _state(self, flat):
         if self._m is not None and self._m.numel() == flat.numel() and self._m.device != flat.device:
@@ -194,6 +230,10 @@ class SpnOptimizer(torch.optim.Optimizer):
         if not self._early:
             self._t += 1
         self._early.append(tuple(covers) if covers is not None else (lo, hi))
+        if covers is not None:      # rank-sharded bucket: this rank's moments are current on [lo, hi) only (gather_sharded_state)
+            self._shard_buckets[int(covers[0])] = (int(covers[0]), int(covers[1]), int(world_size))
+        else:
+            self._unshard_if_needed(lo, hi)
         if hi > lo:
             self._update(lo, hi, world_size, max_blocks)
 
@@ -269,16 +309,27 @@ class SpnOptimizer(torch.optim.Optimizer):
         pos = 0
         for lo, hi in early + [(flat.numel(), flat.numel())]:
             if lo > pos:
+                self._unshard_if_needed(pos, lo)
                 self._update(pos, lo, world_size)
             pos = max(pos, hi)
         mdl.optimizer_updated()
         return None
 
     def state_dict(self):
+        """COLLECTIVE after rank-sharded steps (gather_sharded_state): every rank calls it, rank 0 writes the file."""
         self._model.join_updates()      # the heads' moments may still be written on the update stream
+        self.gather_sharded_state()
         sd = super().state_dict()
         sd["spn_fused"] = {"t": self._t, "m": None if self._m is None else self._m.detach().cpu(),
                            "v": None if self._v is None else self._v.detach().cpu()}
+        # fp16: the GradScaler state lives on the device (loss scale, growth tracker, and the count of steps that were really
+        # taken -- the Adam bias corrections use it, skipped steps do not advance it): torch keeps these in scaler.state_dict()
+        # and in the optimizer's per-parameter `step`; here they travel with the optimizer
+        pending, amp = getattr(self._model, "_amp_pending", None), getattr(self._model, "_amp", None)
+        if pending is not None:
+            sd["spn_fused"]["amp"] = pending.clone()
+        elif amp is not None:
+            sd["spn_fused"]["amp"] = amp.detach().float().cpu()
         return sd
 
     def load_state_dict(self, sd):
@@ -291,3 +342,13 @@ class SpnOptimizer(torch.optim.Optimizer):
             self._t = int(st["t"])
             self._m = None if st["m"] is None else st["m"].detach().float().reshape(-1)
             self._v = None if st["v"] is None else st["v"].detach().float().reshape(-1)
+            amp = st.get("amp")
+            if amp is None and getattr(self._model, "precision", None) == "fp16" and self._t > 0:
+                # a checkpoint written before the scaler state was saved: at least seed the device step count (bias corrections)
+                from . import _lib as L
+                amp = torch.zeros(L.AMP_STATE, dtype=torch.float32)
+                amp[L.AMP_SCALE], amp[L.AMP_INV_SCALE], amp[L.AMP_STEPS] = 65536.0, 1.0 / 65536.0, float(self._t)
+            if amp is not None and hasattr(self._model, "restore_amp_state"):
+                # resume: loss scale, growth tracker and the count of steps actually taken go back to the device BEFORE the next
+                # forward scales its loss gradient with them
+                self._model.restore_amp_state(amp.detach().float().reshape(-1).clone())

@@ -52,27 +52,52 @@ def report_progress(epoch, lr, epoch_iter, epoch_size, time, is_train=True, **kw
     sys.stdout.flush()
 
 
+CHECKPOINT_KEYS = ('epoch', 'model', 'state_dict', 'best_score', 'optimizer')     # the file format of utils.py:109-119
+BEST_MODEL_FILE = 'model_best.pth.tar'
+
+
+def _write_atomically(obj, path):
+    """torch.save to a temporary name in the same directory, then rename: an interrupted run never leaves a truncated
+    checkpoint where auto-resume (train.py:86-94) would pick it up"""
+    tmp = '%s.tmp%d' % (path, os.getpid())
+    torch.save(obj, tmp)
+    os.replace(tmp, path)
+    return path
+
+
 def save_checkpoint(states, is_best, output_dir, filename='checkpoint.pth.tar'):
-    """savedir/checkpoint.pth.tar = {epoch, model, state_dict, best_score, optimizer}; bare state_dict to
-    model_best.pth.tar when is_best (same files and keys as the reference, utils.py:109-119)"""
-    torch.save(states, os.path.join(output_dir, filename))
-    logger.info('Checkpoint saved to {}'.format(os.path.join(output_dir, filename)))
-    if is_best and 'state_dict' in states:
-        torch.save(states['state_dict'], os.path.join(output_dir, 'model_best.pth.tar'))
-        logger.info('Best model saved to {}'.format(os.path.join(output_dir, 'model_best.pth.tar')))
+    """Reference contract (utils.py:109-119): `output_dir/filename` holds the whole `states` dict
+    ({epoch, model, state_dict, best_score, optimizer}); when `is_best`, the bare model state_dict additionally goes to
+    `output_dir/model_best.pth.tar`, which is what test.py --pretrained and adapt.py --pretrained read."""
+    written = [_write_atomically(states, os.path.join(output_dir, filename))]
+    weights = states.get('state_dict') if is_best else None
+    if weights is not None:
+        written.append(_write_atomically(weights, os.path.join(output_dir, BEST_MODEL_FILE)))
+    for path, what in zip(written, ('Checkpoint', 'Best model')):
+        logger.info('%s saved to %s', what, path)
+
+
+def _optimizer_state_to(optimizer, device):
+    for per_param in optimizer.state.values():
+        moved = {k: v.to(device) for k, v in per_param.items() if torch.is_tensor(v)}
+        per_param.update(moved)
 
 
 def load_checkpoint(checkpoint_file, model, optimizer, device):
-    load_dict = torch.load(checkpoint_file, map_location='cpu')
-    model.load_state_dict(load_dict['state_dict'], strict=True)
+    """Reference contract (utils.py:121-135): strict load of the model weights from a checkpoint read onto the CPU, optimizer
+    state restored and placed on `device`; returns (epoch, best_score).  The fused optimizers of this build keep their moments in
+    flat arenas of their own (FusedOptimizer / SpnOptimizer.load_state_dict), so the per-parameter move only concerns plain torch
+    optimizers."""
+    ckpt = torch.load(checkpoint_file, map_location='cpu')
+    missing = [k for k in ('state_dict', 'epoch', 'best_score') if k not in ckpt]
+    if missing:
+        raise KeyError('%s is not a training checkpoint (no %s)' % (checkpoint_file, ', '.join(missing)))
+    model.load_state_dict(ckpt['state_dict'], strict=True)
     if optimizer is not None:
-        optimizer.load_state_dict(load_dict['optimizer'])
-        for state in optimizer.state.values():
-            for k, v in state.items():
-                if isinstance(v, torch.Tensor):
-                    state[k] = v.to(device)
-    logger.info('Checkpoint loaded from {} at epoch {}'.format(checkpoint_file, load_dict['epoch']))
-    return load_dict['epoch'], load_dict['best_score']
+        optimizer.load_state_dict(ckpt['optimizer'])
+        _optimizer_state_to(optimizer, device)
+    logger.info('Checkpoint loaded from %s at epoch %s', checkpoint_file, ckpt['epoch'])
+    return ckpt['epoch'], ckpt['best_score']
 
 
 def set_all_seeds(seed, cfg, use_cuda):

@@ -134,3 +134,78 @@ def test_scale_grows_after_the_growth_interval(device):
         scales.append(float(st[L.AMP_SCALE]))
     assert scales == [256.0, 512.0, 512.0, 1024.0, 1024.0], scales
     assert float(st[L.AMP_STEPS]) == 5.0
+
+
+def test_generic_path_batch_above_64_carries_the_loss_scale(device):
+    """with B > 64 (or num_classes % 8 != 0) loss_and_grads takes its generic branch; in float16 the loss
+    gradient must carry the scale there too, because SpnOptimizer._step_fp16 divides EVERY gradient by it.  Unscaled, the
+    float16 gradients must equal the float32 path's on the same batch; the update must have the float32 update's size."""
+    Bbig, NCs = 72, 64
+    sd = S.init_state(NCs)
+    x, yc, yw = (t.to(device) for t in S.synth_batch(Bbig, NCs, seed=31))
+    grads, upd = {}, {}
+    for prec in ("fp16", "fp32"):
+        net = SpacecraftPoseNet(NCs, keep_prob=0.0, pretrain=False, precision=prec)
+        net.load_state_dict(sd, strict=True)
+        net = net.to(device).train()
+        opt = SpnOptimizer(list(net.parameters()), kind="sgd", lr=0.05, momentum=0.0, weight_decay=0.0, model=net)
+        if prec == "fp16":
+            net.amp_state(init_scale=1024.0)
+        assert not net._fast(Bbig)
+        p0 = net.flat_parameters().clone()
+        out = net.loss_and_grads(x, yc, yw, optimizer=opt)
+        torch.cuda.synchronize()
+        grads[prec] = net.flat_grads().clone() / (1024.0 if prec == "fp16" else 1.0)
+        opt.step()
+        torch.cuda.synchronize()
+        upd[prec] = net.flat_parameters() - p0
+        assert torch.isfinite(out).all()
+    ce = net._conv_end
+    for name, sl in (("fc", slice(ce, None)), ("conv", slice(0, ce))):
+        g16, g32 = grads["fp16"][sl], grads["fp32"][sl]
+        ratio = float(g16.norm() / g32.norm())
+        cos = float((g16 * g32).sum() / (g16.norm() * g32.norm()))
+        print("B=72 generic path, %s gradients: |g16|/|g32| = %.4f, cosine %.4f" % (name, ratio, cos))
+        assert abs(ratio - 1.0) < 0.05 and cos > 0.97, (name, ratio, cos)          # a missing scale shows as a ratio of 1/1024
+    r = float(upd["fp16"].norm() / upd["fp32"].norm())
+    assert abs(r - 1.0) < 0.05, r
+
+
+def test_scaler_state_travels_with_the_optimizer_checkpoint(device):
+    """loss scale, growth tracker and the count of steps really taken (Adam's bias corrections use it)
+    live on the device; they are saved in SpnOptimizer.state_dict() and restored before the next forward scales a gradient."""
+    net, x, yc, yw, masks = _small(device, "fp16")
+    opt = SpnOptimizer(list(net.parameters()), kind="adamw", lr=1e-3, momentum=0.9, weight_decay=0.01, model=net)
+    opt.amp_interval = 2
+    st = net.amp_state(init_scale=512.0)
+    for _ in range(3):
+        net.loss_and_grads(x, yc, yw, masks=masks)
+        opt.step()
+    torch.cuda.synchronize()
+    want = st.clone().cpu()
+    assert float(want[L.AMP_STEPS]) == 3.0 and float(want[L.AMP_SCALE]) == 1024.0 and float(want[L.AMP_TRACKER]) == 1.0
+    model_sd = {k: v.clone().cpu() for k, v in net.state_dict().items()}
+    opt_sd = opt.state_dict()
+    assert torch.equal(opt_sd["spn_fused"]["amp"], want)
+    # resume in the reference's order: optimizer state restored while the model is still on the CPU (train.py:86-97)
+    net2 = SpacecraftPoseNet(64, keep_prob=0.5, pretrain=False, precision="fp16")
+    net2.load_state_dict(model_sd, strict=True)
+    opt2 = SpnOptimizer(list(net2.parameters()), kind="adamw", lr=1e-3, momentum=0.9, weight_decay=0.01, model=net2)
+    opt2.amp_interval = 2
+    opt2.load_state_dict(opt_sd)
+    assert torch.equal(opt2.state_dict()["spn_fused"]["amp"], want)              # saved again before any step: still there
+    net2 = net2.to(device).train()
+    st2 = net2.amp_state()
+    assert torch.equal(st2.cpu(), want)
+    # the 4th step of both runs: same scale on the loss gradient, same bias corrections -> same update
+    p_a, p_b = net.flat_parameters().clone(), net2.flat_parameters().clone()
+    assert torch.equal(p_a, p_b)
+    for n_, o_ in ((net, opt), (net2, opt2)):
+        n_.loss_and_grads(x, yc, yw, masks=masks)
+        o_.step()
+    torch.cuda.synchronize()
+    assert float(st2[L.AMP_STEPS]) == 4.0 and float(st2[L.AMP_SCALE]) == 2048.0 and torch.equal(st2.cpu(), st.cpu())
+    d_a, d_b = net.flat_parameters() - p_a, net2.flat_parameters() - p_b
+    rel = float((d_a - d_b).norm() / d_a.norm())
+    print("4th AdamW step, original vs resumed run: relative update difference %.2e" % rel)
+    assert rel < 2e-2                                                             # float atomics in the gradients; a step count reset to 0 changes the update by tens of percent

@@ -130,6 +130,16 @@ def spn(rank, world, dev):
         if mode.startswith("sharded"):         # the bf16 shadows the next forward reads: identical on both ranks after the all-gather
             sh = gather(net._shadow.float().clone())
             res[mode]["shadow_diff"] = float((sh[0] - sh[1]).abs().max())
+        if mode in ("overlap_early", "sharded_f32", "sharded"):
+            # optimizer.state_dict() is a collective after sharded steps: the momentum buffers it returns must be complete
+            # and identical on both ranks, and equal the unsharded run's
+            mom = opt.state_dict()["spn_fused"]["m"].to(dev)
+            moms = gather(mom)
+            if mode == "overlap_early":
+                mom_ref = mom
+            res[mode]["mom_replica_diff"] = float((moms[0] - moms[1]).abs().max())
+            res[mode]["mom_rel"] = float((mom[ce:] - mom_ref[ce:]).norm() / mom_ref[ce:].norm())
+            res[mode]["mom_zero_frac"] = float((mom[ce:] == 0).float().mean())
     return res
 
 
