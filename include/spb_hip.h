@@ -618,6 +618,8 @@ int spb_debug_set_dw_mode(int mode); /* depthwise fwd/dgrad: 1 plane kernels on 
 int spb_debug_set_fused_pw_bwd(int on); /* 0: the KRN plan never uses spb_pwconv_bwd_fused */
 int spb_debug_set_stem_mfma(int on); /* 0: bf16 stem uses the scalar kernels instead of the MFMA implicit GEMM */
 int spb_debug_set_softce_split(int min_classes); /* spb_softce / _scaled: rows of at least this many classes (default 2048) use the class-split pair of launches (8 workgroups per row) */
+int spb_debug_set_dw_tile(int min_width, int workgroups); /* bf16 depthwise forward on maps at least min_width wide: LDS-tile kernels (dwconv_tile.hip; default 28, 0 = never); workgroups per launch in the low 16 bits (0 = resident estimate); bit 16: the stride-1 input gradient too (off: measured slower) */
+int spb_debug_set_pwb(int chunk_rows, int recompute_z, int max_waves); /* fused pointwise backward: rows per chunk (16 default | 32), z of the expand layers recomputed on the matrix cores instead of read (1 default; -1 keeps), waves per workgroup (8) */
 int spb_debug_set_gemm_rs(int on, int min_m); /* bf16 GEMMs with K <= 96, N = 192 | 384 | 576, M >= min_m (4096): one-round-trip row-slab kernel (on=1, default) */
 int spb_debug_set_gemm_big(int on, int min_n, int min_k); /* small-M bf16 GEMMs with N >= min_n (512), K >= min_k (256): 128 x 128 tile kernel (on=1, default) */
 int spb_debug_set_bn_bwd_prep_rows(int on); /* spb_bn_bwd_prep: row-parallel kernel (1, default) or the walking kernel (0) */

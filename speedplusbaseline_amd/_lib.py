@@ -249,6 +249,8 @@ SYMBOLS = {
     "spb_debug_set_gemm_bk64_min_k": (i32, [i32]),
     "spb_debug_set_gemm_wide_min_n": (i32, [i32]),
     "spb_debug_set_gemm_big": (i32, [i32, i32, i32]),
+    "spb_debug_set_pwb": (i32, [i32, i32, i32]),
+    "spb_debug_set_dw_tile": (i32, [i32, i32]),
     "spb_debug_set_gemm_rs": (i32, [i32, i32]),
     "spb_debug_set_gemm_wg_cap": (i32, [i32]),
     "spb_debug_set_bn_bwd_prep_rows": (i32, [i32]),
@@ -292,7 +294,20 @@ def lib():
             fn.restype = res
             fn.argtypes = args
         _lib = l
+        _apply_debug_env(l)
     return _lib
+
+
+def _apply_debug_env(l):
+    """A/B switch for measurement runs: SPB_DEBUG="spb_debug_set_pwb:32,0,4;spb_debug_set_dw_split:56" calls the named
+    spb_debug_* knobs (integer arguments) once, right after the library is loaded.  Unset in production."""
+    spec = os.environ.get("SPB_DEBUG", "")
+    for item in filter(None, (x.strip() for x in spec.split(";"))):
+        name, _, args = item.partition(":")
+        if not name.startswith("spb_debug_") or name not in SYMBOLS:
+            raise RuntimeError("SPB_DEBUG: %r is not a debug knob of libspb_hip.so" % name)
+        vals = [int(v) for v in args.split(",") if v.strip()]
+        getattr(l, name)(*vals)
 
 
 _lib_f16 = None

@@ -692,6 +692,8 @@ int spb_dwr_bwd(int dtype, const spb_dw_args_t* a, hipStream_t s) {
 // families.  Small maps (width <= 28: the 28x28 / 14x14 / 7x7 tensors of KRN) go to the one-round-trip plane kernels
 // (dwconv_plane.hip), everything else and the stand-alone weight gradient to the row-unit kernels above.
 int spb_dwp_fwd(int dtype, const spb_dw_args_t* a, hipStream_t s);   // dwconv_plane.hip; SPB_E_UNSUPPORTED: not covered
+int spb_dwt_fwd(int dtype, const spb_dw_args_t* a, hipStream_t s);   // dwconv_tile.hip (bf16, large maps); SPB_E_UNSUPPORTED: not covered
+int spb_dwt_dgrad(int dtype, const spb_dw_args_t* a, hipStream_t s);
 int spb_dwp_bwd(int dtype, const spb_dw_args_t* a, hipStream_t s);
 static int g_dw_mode = 1;   // 1: plane kernels where they apply (default); 0: row-unit kernels only
 extern "C" int spb_debug_set_dw_mode(int mode) { g_dw_mode = mode; return 0; }
@@ -708,8 +710,10 @@ extern "C" int spb_dwconv_fwd(int dtype, const spb_dw_args_t* a, spb_stream_t st
   if (e) return e;
   if (!a->Y || (a->epi_mode == 1 && (!a->osums || a->oR < 1))) return SPB_E_ARG;
   if (dtype != SPB_BF16 && dtype != SPB_F32) return SPB_E_ARG;
-  if (g_dw_mode != 1 || spb_dwp_fwd(dtype, a, (hipStream_t)stream) == SPB_E_UNSUPPORTED)
-    spb_dwr_fwd(dtype, a, (hipStream_t)stream);
+  if (spb_dwt_fwd(dtype, a, (hipStream_t)stream) == SPB_E_UNSUPPORTED) {
+    if (g_dw_mode != 1 || spb_dwp_fwd(dtype, a, (hipStream_t)stream) == SPB_E_UNSUPPORTED)
+      spb_dwr_fwd(dtype, a, (hipStream_t)stream);
+  }
   SPB_CHECK_LAUNCH();
   return 0;
 }
@@ -725,8 +729,10 @@ extern "C" int spb_dwconv_dgrad(int dtype, const spb_dw_args_t* a, spb_stream_t 
   if (dtype != SPB_BF16 && dtype != SPB_F32) return SPB_E_ARG;
   spb_dw_args_t k = *a;
   if (!k.X2) k.X2 = k.X;  // no BN behind the convolution: p1 == 0, the kernel still reads a (finite) second operand
-  if (g_dw_mode != 1 || spb_dwp_bwd(dtype, &k, (hipStream_t)stream) == SPB_E_UNSUPPORTED)
-    spb_dwr_bwd(dtype, &k, (hipStream_t)stream);
+  if (spb_dwt_dgrad(dtype, &k, (hipStream_t)stream) == SPB_E_UNSUPPORTED) {
+    if (g_dw_mode != 1 || spb_dwp_bwd(dtype, &k, (hipStream_t)stream) == SPB_E_UNSUPPORTED)
+      spb_dwr_bwd(dtype, &k, (hipStream_t)stream);
+  }
   SPB_CHECK_LAUNCH();
   return 0;
 }

@@ -19,21 +19,30 @@
 //     wave-private LDS tiles and read back with the gfx950 transpose load (ds_read_b64_tr_b16);
 //   * wide K (144) is split over blockIdx.y so that accumulators fit; g,z are then read once per split.
 // bf16 only (the f32 parity mode keeps the two-kernel path).
+//
+// Round 4: the kernel was bound by how few waves a CU could hold, not by memory: 32-row double-buffered stages cost a wave
+// 34-55 KB of LDS, so the 56x56 layers ran 3-4 waves per CU -- one per SIMD, every dependent instruction at its full latency
+// (9 us per 32-row chunk of the 24 -> 144 layer; 1.4-2.0 TB/s).  Now:
+//   * CHR = 16-row chunks (template): half the LDS per wave; workgroups of up to 8 waves share the coefficient tables;
+//   * RZ (expand layers, K <= 32): the raw conv output z is NOT read -- it is recomputed on the matrix cores from the conv input
+//     rows the kernel stages anyway (z = W a: two 16x16x32 MFMAs per 16 rows x 32 columns, W rows permuted so that the result
+//     lands in the lane layout the dz fragment needs).  That removes ~45 % of the launch's bytes (115 MB of 270 MB for 16 -> 96
+//     at 112x112) and the largest piece of every stage;
+//   * the block-level weight-gradient reduction goes wave by wave through ONE [NB][KB][256] tile instead of nw of them.
 #include "common.h"
 
 namespace {
 
-constexpr int CH = 32;  // rows per chunk
 
 // dz tile: when N is a multiple of 16 the transformed dz overwrites the raw g rows it came from (same lane, same
 // 16 bytes; leading dimension N); otherwise (N = 24) the 16-column blocks overrun a row and a padded tile is used.
 struct PwbLay { int gB, kB, stage, oZ, oZo, oX, oR, oDzt, oAt, ldz, wave_bytes; };
-__host__ __device__ inline PwbLay pwb_lay(int N, int KW, int NPAD, int KPAD, bool hasx, bool hasr) {
+__host__ __device__ inline PwbLay pwb_lay(int CH, int N, int KW, int NPAD, int KPAD, bool hasx, bool hasr, bool hasz) {
   PwbLay L;
   const bool inplace = (N & 15) == 0;
   L.gB = (CH * N * 2 + 1023) & ~1023;     // raw g (and z) rows of a chunk, whole 1 KB DMA instructions
   L.kB = (CH * KW * 2 + 1023) & ~1023;    // one K-side tile
-  L.oZ = L.gB; L.oZo = 2 * L.gB; L.oX = L.oZo + L.kB; L.oR = L.oX + (hasx ? L.kB : 0);
+  L.oZ = L.gB; L.oZo = (hasz ? 2 : 1) * L.gB; L.oX = L.oZo + L.kB; L.oR = L.oX + (hasx ? L.kB : 0);
   L.stage = L.oR + (hasr ? L.kB : 0);
   L.oDzt = inplace ? -1 : 2 * L.stage;
   L.ldz = inplace ? N : NPAD;
@@ -49,33 +58,41 @@ __device__ __forceinline__ void unpack4(uint2 r, float v[4]) {
 
 // transpose-load fragment: 32 rows x 16 columns (c0..c0+15) of a row-major bf16 LDS tile with leading dimension LD
 // -> lane (li, lq) gets column c0+li, rows lq*8 .. lq*8+7  (same addressing as pw_wgrad_kernel in gemm_pw.hip)
+// ROWS = 16: the tile has 16 rows only; the upper half of the 32-deep reduction (lanes lq >= 2) is zero
+template <int ROWS>
 __device__ __forceinline__ bf16x8_t tr_frag(const bf16_t* tile, int LD, int c0, int li, int lq) {
   typedef s16x4_t __attribute__((address_space(3))) * lds_v4;
-  const bf16_t* p = tile + (lq * 8 + (li >> 2)) * LD + c0 + (li & 3) * 4;
-  union { struct { s16x4_t lo, hi; } s; bf16x8_t v; } u;
+  const int lqc = ROWS == 32 ? lq : (lq & 1);            // (clamped: the read stays inside the tile, the value is dropped)
+  const bf16_t* p = tile + (lqc * 8 + (li >> 2)) * LD + c0 + (li & 3) * 4;
+  union { struct { s16x4_t lo, hi; } s; bf16x8_t v; uint4 q; } u;
   u.s.lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(p));
   u.s.hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(p + 4 * LD));
+  if (ROWS != 32 && lq >= 2) u.q = make_uint4(0, 0, 0, 0);
   return u.v;
 }
 
-template <int NB, int KB>
-__global__ __launch_bounds__(256, 1) void pwb_kernel(const spb_pwbwd_args_t g, long long nchunks) {
+template <int NB, int KB, int CH, bool RZ>
+__global__ __launch_bounds__(512, 2) void pwb_kernel(const spb_pwbwd_args_t g, long long nchunks) {
   constexpr int NS = (NB + 1) / 2;               // 32-wide reduction steps of the input-gradient GEMM
   constexpr int NP = NS * 32, NPAD = NP + 8;
   constexpr int KW = KB * 16, KPAD = KW + 8;
   constexpr int GPR = KW / 8;                    // 16-byte granules per K-side tile row
+  constexpr int NH = CH / 16;                    // 16-row halves of a chunk
+  static_assert(!RZ || KW <= 32, "z is recomputed in one 32-deep MFMA step: expand layers only (K <= 32)");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int M = g.M, N = g.N, K = g.K;
   const int lane = threadIdx.x & 63, li = lane & 15, lq = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int nw = (int)(blockDim.x >> 6), nthr = (int)blockDim.x;   // 2..4 waves per block, whatever fits the LDS
+  const int nw = (int)(blockDim.x >> 6), nthr = (int)blockDim.x;   // 2..8 waves per block, whatever fits the LDS
   const int k0 = blockIdx.y * KW;                // first input channel of this split
   const bool hasx = g.X != g.Zout, hasr = g.res != nullptr;
-  const PwbLay L = pwb_lay(N, KW, NPAD, KPAD, hasx, hasr);
+  const PwbLay L = pwb_lay(CH, N, KW, NPAD, KPAD, hasx, hasr, !RZ);
   float* pdz = reinterpret_cast<float*>(smem);   // [3][NP]  p0, p1, p2 of the conv output's BN backward
   float* pep = pdz + 3 * NP;                     // [4][KW]  scale, shift, mean, invstd of the input-side BN
   float* pa = pep + 4 * KW;                      // [2][KW]  scale, shift that turn X into the conv input
-  char* wreg = reinterpret_cast<char*>(pa + 2 * KW) + (size_t)wave * L.wave_bytes;
+  // RZ: W fragments of the z recomputation (A operand; [NS][2][64 lanes] x 16 B), shared by the workgroup's waves
+  uint4* wz = reinterpret_cast<uint4*>(pa + 2 * KW);
+  char* wreg = reinterpret_cast<char*>(wz + (RZ ? NS * 2 * 64 : 0)) + (size_t)wave * L.wave_bytes;
   for (int i = threadIdx.x; i < NP; i += nthr) {
     float p0 = 0.f, p1 = 0.f, p2 = 0.f;
     if (i < N) bn_bwd_coef(g.pro_dz, i, p0, p1, p2);
@@ -94,10 +111,29 @@ __global__ __launch_bounds__(256, 1) void pwb_kernel(const spb_pwbwd_args_t g, l
     pep[i] = sc; pep[KW + i] = sh; pep[2 * KW + i] = mu; pep[3 * KW + i] = is;
     pa[i] = asc; pa[KW + i] = ash;
   }
+  const bf16_t* Wt = reinterpret_cast<const bf16_t*>(g.Wt);
+  if constexpr (RZ) {
+    // z^T tile (32 columns n of 16 rows m) = two MFMAs whose A rows are PERMUTED weight rows: fragment t, row r  <->  output
+    // channel n = ns*32 + (r>>2)*8 + t*4 + (r&3).  The C layout then gives lane (li = m, lq) the channels ns*32 + lq*8 + t*4 + i:
+    // with t = 0, 1 exactly the 8 consecutive channels of the dz fragment below.  A fragment element: W[n][8*lq + j] = Wt[k][n].
+    for (int e = threadIdx.x; e < NS * 2 * 64; e += nthr) {
+      const int f = e >> 6, l = e & 63, r = l & 15, q = l >> 4;
+      const int n = (f >> 1) * 32 + (r >> 2) * 8 + (f & 1) * 4 + (r & 3);
+      bf16_t v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int k = q * 8 + j;
+        v[j] = (n < N && k < K) ? Wt[(size_t)k * N + n] : (bf16_t)0;
+      }
+      uint4 u;
+      u.x = (uint32_t)v[0] | ((uint32_t)v[1] << 16); u.y = (uint32_t)v[2] | ((uint32_t)v[3] << 16);
+      u.z = (uint32_t)v[4] | ((uint32_t)v[5] << 16); u.w = (uint32_t)v[6] | ((uint32_t)v[7] << 16);
+      wz[e] = u;
+    }
+  }
   // W^T fragments (A operand of the input-gradient MFMA), rows permuted: fragment kb, lane row li  <->  input channel
   // k0 + (li>>2)*4*KB + kb*4 + (li&3).  The KB accumulators of a lane then cover 4*KB CONSECUTIVE channels of its row:
   // 16-byte output stores instead of one scattered 8-byte store per accumulator (64 pieces per instruction).
-  const bf16_t* Wt = reinterpret_cast<const bf16_t*>(g.Wt);
   bf16x8_t Wf[KB][NS];
 #pragma unroll
   for (int kb = 0; kb < KB; ++kb)
@@ -128,7 +164,7 @@ __global__ __launch_bounds__(256, 1) void pwb_kernel(const spb_pwbwd_args_t g, l
       long long off = m0 * N * 2 + (long long)(i * 64 + lane) * 16;
       off = off > gtot - 16 ? gtot - 16 : off;       // past the tensor: any valid address, the rows are masked
       dma16(Gp + off, sb + (unsigned)(i << 10));
-      dma16(Zp + off, sb + (unsigned)(L.oZ + (i << 10)));
+      if constexpr (!RZ) dma16(Zp + off, sb + (unsigned)(L.oZ + (i << 10)));
     }
     for (int i = 0; i < (L.kB >> 10); ++i) {
       const int q = i * 64 + lane;
@@ -166,20 +202,56 @@ __global__ __launch_bounds__(256, 1) void pwb_kernel(const spb_pwbwd_args_t g, l
     char* st = wreg + s * L.stage;
     bf16_t* dzt = reinterpret_cast<bf16_t*>(L.oDzt < 0 ? st : wreg + L.oDzt);
     const long long m0 = c * CH;
-    // ---- dz: MFMA B fragments (row m = h*16+li, 8 consecutive n) and the row-major copy for the transpose loads
-    bf16x8_t bz[2][NS];
+    // ---- a = the conv input (act(bn(X)) or the materialised tensor as stored), row-major bf16 tile: operand of the weight
+    //      gradient's transpose loads and (RZ) of the z recomputation
 #pragma unroll
-    for (int h = 0; h < 2; ++h)
+    for (int h = 0; h < NH; ++h) {
+      const int row = h * 16 + li;
+      const long long m = m0 + row;
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb) {
+        const int kl = lq * 4 * KB + kb * 4, k = k0 + kl;
+        const bool ok = m < M && k < K;
+        float xf[4], asc[4], ash[4], a[4];
+        unpack4(*reinterpret_cast<const uint2*>(st + (hasx ? L.oX : L.oZo) + (row * KW + kl) * 2), xf);
+        *reinterpret_cast<float4*>(asc) = *reinterpret_cast<const float4*>(pa + kl);
+        *reinterpret_cast<float4*>(ash) = *reinterpret_cast<const float4*>(pa + KW + kl);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a[i] = ok ? act_fwd(xf[i] * asc[i] + ash[i], aact, aslope) : 0.f;
+        uint2 ap;
+        ap.x = pack_bf16x2(a[0], a[1]); ap.y = pack_bf16x2(a[2], a[3]);
+        *reinterpret_cast<uint2*>(at + row * KPAD + kl) = ap;
+      }
+    }
+    // ---- dz: MFMA B fragments (row m = h*16+li, 8 consecutive n) and the row-major copy for the transpose loads
+    bf16x8_t bz[NH][NS];
+#pragma unroll
+    for (int h = 0; h < NH; ++h) {
+      bf16x8_t afr;
+      if constexpr (RZ) {   // this lane's 8 input channels of row m: B operand of z^T = W a^T (zero beyond the KW columns)
+        uint4 u = make_uint4(0, 0, 0, 0);
+        if (lq * 8 < KW) u = *reinterpret_cast<const uint4*>(at + (h * 16 + li) * KPAD + lq * 8);
+        afr = __builtin_bit_cast(bf16x8_t, u);
+      }
 #pragma unroll
       for (int ns = 0; ns < NS; ++ns) {
         const int row = h * 16 + li, n = ns * 32 + lq * 8;
         const bool ok = n < N && m0 + row < M;
         const int nc = n < N ? n : N - 8;
         float gf[8], zf[8], p0[8], p1[8], p2[8], v[8];
-        Raw8<bf16_t> gr, zr;
+        Raw8<bf16_t> gr;
         gr.u = *reinterpret_cast<const uint4*>(st + (row * N + nc) * 2);
-        zr.u = *reinterpret_cast<const uint4*>(st + L.oZ + (row * N + nc) * 2);
-        cvt8(gr, gf); cvt8(zr, zf);
+        cvt8(gr, gf);
+        if constexpr (RZ) {
+          const f32x4_t z0 = SPB_MFMA16(__builtin_bit_cast(bf16x8_t, wz[(ns * 2 + 0) * 64 + lane]), afr, ((f32x4_t){0.f, 0.f, 0.f, 0.f}));
+          const f32x4_t z1 = SPB_MFMA16(__builtin_bit_cast(bf16x8_t, wz[(ns * 2 + 1) * 64 + lane]), afr, ((f32x4_t){0.f, 0.f, 0.f, 0.f}));
+#pragma unroll
+          for (int i = 0; i < 4; ++i) { zf[i] = z0[i]; zf[4 + i] = z1[i]; }
+        } else {
+          Raw8<bf16_t> zr;
+          zr.u = *reinterpret_cast<const uint4*>(st + L.oZ + (row * N + nc) * 2);
+          cvt8(zr, zf);
+        }
 #pragma unroll
         for (int j = 0; j < 8; j += 4) {
           *reinterpret_cast<float4*>(p0 + j) = *reinterpret_cast<const float4*>(pdz + n + j);
@@ -194,9 +266,10 @@ __global__ __launch_bounds__(256, 1) void pwb_kernel(const spb_pwbwd_args_t g, l
         bz[h][ns] = __builtin_bit_cast(bf16x8_t, u);
         if (L.oDzt >= 0 || n < N) *reinterpret_cast<uint4*>(dzt + row * LDZ + n) = u;
       }
+    }
     // ---- input gradient, one 16-row half at a time
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
+    for (int h = 0; h < NH; ++h) {
       f32x4_t acc[KB];
 #pragma unroll
       for (int kb = 0; kb < KB; ++kb) {
@@ -211,26 +284,13 @@ __global__ __launch_bounds__(256, 1) void pwb_kernel(const spb_pwbwd_args_t g, l
       for (int kb = 0; kb < KB; ++kb) {
         const int kl = lq * 4 * KB + kb * 4, k = k0 + kl;    // lane (li = row, lq): channels lq*4*KB + kb*4 + i
         const bool ok = m < M && k < K;
-        float zf[4], xf[4], sc[4], sh[4], asc[4], ash[4], v[4], a[4];
+        float zf[4], sc[4], sh[4], v[4];
         const uint2 zraw = *reinterpret_cast<const uint2*>(st + L.oZo + (row * KW + kl) * 2);
         unpack4(zraw, zf);
-        if (hasx) unpack4(*reinterpret_cast<const uint2*>(st + L.oX + (row * KW + kl) * 2), xf);
-        else {
-#pragma unroll
-          for (int i = 0; i < 4; ++i) xf[i] = zf[i];
-        }
         *reinterpret_cast<float4*>(sc) = *reinterpret_cast<const float4*>(pep + kl);
         *reinterpret_cast<float4*>(sh) = *reinterpret_cast<const float4*>(pep + KW + kl);
-        *reinterpret_cast<float4*>(asc) = *reinterpret_cast<const float4*>(pa + kl);
-        *reinterpret_cast<float4*>(ash) = *reinterpret_cast<const float4*>(pa + KW + kl);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          a[i] = ok ? act_fwd(xf[i] * asc[i] + ash[i], aact, aslope) : 0.f;
-          v[i] = acc[kb][i];
-        }
-        uint2 ap;
-        ap.x = pack_bf16x2(a[0], a[1]); ap.y = pack_bf16x2(a[2], a[3]);
-        *reinterpret_cast<uint2*>(at + row * KPAD + kl) = ap;
+        for (int i = 0; i < 4; ++i) v[i] = acc[kb][i];
         if (hasr) {
           float rf[4];
           unpack4(*reinterpret_cast<const uint2*>(st + L.oR + (row * KW + kl) * 2), rf);
@@ -264,39 +324,43 @@ __global__ __launch_bounds__(256, 1) void pwb_kernel(const spb_pwbwd_args_t g, l
         }
       }
     }
-    // ---- weight gradient: dW[n,k] += sum over the 32 rows
+    // ---- weight gradient: dW[n,k] += sum over the chunk's rows
     asm volatile("" ::: "memory");   // the dz / a tile stores above stay ahead of the transpose loads
     bf16x8_t bf[KB];
 #pragma unroll
-    for (int kb = 0; kb < KB; ++kb) bf[kb] = tr_frag(at, KPAD, kb * 16, li, lq);
+    for (int kb = 0; kb < KB; ++kb) bf[kb] = tr_frag<CH>(at, KPAD, kb * 16, li, lq);
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
-      const bf16x8_t af = tr_frag(dzt, LDZ, nb * 16, li, lq);
+      const bf16x8_t af = tr_frag<CH>(dzt, LDZ, nb * 16, li, lq);
 #pragma unroll
       for (int kb = 0; kb < KB; ++kb) dw[nb][kb] = SPB_MFMA16(af, bf[kb], dw[nb][kb]);
     }
   }
   wait_vmcnt<0>();
 
-  // ---- reductions over the block: weight gradient (C layout: column k = li, rows n = lq*4+i) and the BN sums
+  // ---- reductions over the block: weight gradient (C layout: column k = li, rows n = lq*4+i) and the BN sums.
+  //      ONE [NB][KB][256] tile: the waves add themselves in turn (nw barriers) -- nw tiles would be 147 KB for 8 waves
   __syncthreads();
-  float* red = reinterpret_cast<float*>(pa + 2 * KW);          // the wave regions are idle now
+  float* red = reinterpret_cast<float*>(wz + (RZ ? NS * 2 * 64 : 0));          // the wave regions are idle now
+  for (int w = 0; w < nw; ++w) {
+    if (wave == w) {
 #pragma unroll
-  for (int nb = 0; nb < NB; ++nb)
+      for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-    for (int kb = 0; kb < KB; ++kb)
+        for (int kb = 0; kb < KB; ++kb)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) red[((wave * NB + nb) * KB + kb) * 256 + (lq * 4 + i) * 16 + li] = dw[nb][kb][i];
-  __syncthreads();
+          for (int i = 0; i < 4; ++i) {
+            float* q = red + (nb * KB + kb) * 256 + (lq * 4 + i) * 16 + li;
+            *q = w == 0 ? dw[nb][kb][i] : *q + dw[nb][kb][i];
+          }
+    }
+    __syncthreads();
+  }
   for (int e = threadIdx.x; e < NB * KB * 256; e += nthr) {
     const int blk = e >> 8, r = (e >> 4) & 15, cidx = e & 15;
     const int nb = blk / KB, kb = blk % KB;
     const int n = nb * 16 + r, k = k0 + kb * 16 + cidx;
-    if (n < N && k < K) {
-      float v = 0.f;
-      for (int w = 0; w < nw; ++w) v += red[w * NB * KB * 256 + e];
-      SPB_ATOMIC_W(g.dW + (size_t)n * K + k, v);
-    }
+    if (n < N && k < K) SPB_ATOMIC_W(g.dW + (size_t)n * K + k, red[e]);
   }
   __syncthreads();
   // BN-backward sums of gin: lanes of a 16-lane row hold different m for the same 4 k -> butterfly, then waves in LDS
@@ -324,37 +388,69 @@ __global__ __launch_bounds__(256, 1) void pwb_kernel(const spb_pwbwd_args_t g, l
   }
 }
 
-template <int NB, int KB>
-int pwb_launch(const spb_pwbwd_args_t& g, hipStream_t stream) {
+static int g_pwb_ch = 16;      // rows per chunk (16 | 32) -- spb_debug_set_pwb(ch, rz, max_waves)
+static int g_pwb_rz = 1;       // expand layers (K <= 32): recompute z instead of reading it
+static int g_pwb_maxw = 8;     // waves per workgroup
+
+template <int NB, int KB, int CH, bool RZ>
+int pwb_launch2(const spb_pwbwd_args_t& g, hipStream_t stream) {
   constexpr int NS = (NB + 1) / 2, NP = NS * 32, NPAD = NP + 8, KW = KB * 16, KPAD = KW + 8;
   const bool hasx = g.X != g.Zout, hasr = g.res != nullptr;
-  const PwbLay L = pwb_lay(g.N, KW, NPAD, KPAD, hasx, hasr);
-  const size_t tables = (size_t)(3 * NP + 6 * KW) * sizeof(float);
-  int nw = 4;
-  size_t lds = 0;
-  for (; nw >= 2; --nw) {
-    lds = tables + (size_t)nw * L.wave_bytes;
-    const size_t red = tables + (size_t)nw * NB * KB * 256 * sizeof(float);
-    if (red > lds) lds = red;
-    if (lds <= 160 * 1024) break;
+  const PwbLay L = pwb_lay(CH, g.N, KW, NPAD, KPAD, hasx, hasr, !RZ);
+  const size_t tables = (size_t)(3 * NP + 6 * KW) * sizeof(float) + (RZ ? (size_t)NS * 2 * 64 * 16 : 0);
+  const size_t red = (size_t)NB * KB * 256 * sizeof(float);
+  // waves per workgroup x workgroups per CU: whatever holds the most waves on a CU (LDS, and the register file: 8 waves per CU
+  // at up to 256 registers, 12 at up to 168, 16 at up to 128)
+  static int reg_waves = 0;
+  if (!reg_waves) {
+    hipFuncAttributes fa;
+    reg_waves = 8;
+    if (hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&pwb_kernel<NB, KB, CH, RZ>)) == hipSuccess)
+      reg_waves = fa.numRegs <= 128 ? 16 : (fa.numRegs <= 168 ? 12 : 8);
   }
-  if (nw < 2) return SPB_E_UNSUPPORTED;
+  int nw = g_pwb_maxw < 2 ? 2 : (g_pwb_maxw > 8 ? 8 : g_pwb_maxw), per_cu = 1;
+  size_t lds = 0;
+  int best = 0;
+  for (int cand = nw; cand >= 2; --cand) {
+    size_t l = tables + (size_t)cand * L.wave_bytes;
+    if (tables + red > l) l = tables + red;     // the final reductions reuse the wave regions
+    if (l > 160 * 1024) continue;
+    int pc = (int)((160 * 1024) / l);
+    if (pc * cand > reg_waves) pc = reg_waves / cand;
+    if (pc < 1) pc = 1;
+    if (pc * cand > best) { best = pc * cand; nw = cand; per_cu = pc; lds = l; }
+  }
+  if (best == 0) return SPB_E_UNSUPPORTED;
   static bool once = false;
   if (!once) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pwb_kernel<NB, KB>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pwb_kernel<NB, KB, CH, RZ>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     once = true;
   }
   const long long nchunks = ((long long)g.M + CH - 1) / CH;
-  const int per_cu = (int)((160 * 1024) / lds) < 1 ? 1 : (int)((160 * 1024) / lds);
   long long blocks = (nchunks + nw - 1) / nw;
-  const long long cap = 256LL * (per_cu > 2 ? 2 : per_cu);
+  const long long cap = 256LL * per_cu;
   if (blocks > cap) blocks = cap;
   const int nsplit = (g.K + KW - 1) / KW;
-  hipLaunchKernelGGL((pwb_kernel<NB, KB>), dim3((unsigned)blocks, (unsigned)nsplit), dim3(64 * nw), lds, stream, g, nchunks);
+  hipLaunchKernelGGL((pwb_kernel<NB, KB, CH, RZ>), dim3((unsigned)blocks, (unsigned)nsplit), dim3(64 * nw), lds, stream, g, nchunks);
   return 0;
+}
+template <int NB, int KB>
+int pwb_launch(const spb_pwbwd_args_t& g, hipStream_t stream) {
+  constexpr bool can_rz = KB * 16 <= 32;
+  if constexpr (can_rz) {
+    if (g_pwb_rz && g.K <= KB * 16) return g_pwb_ch == 32 ? pwb_launch2<NB, KB, 32, true>(g, stream) : pwb_launch2<NB, KB, 16, true>(g, stream);
+  }
+  return g_pwb_ch == 32 ? pwb_launch2<NB, KB, 32, false>(g, stream) : pwb_launch2<NB, KB, 16, false>(g, stream);
 }
 
 }  // namespace
+
+extern "C" int spb_debug_set_pwb(int chunk_rows, int recompute_z, int max_waves) {
+  if (chunk_rows == 16 || chunk_rows == 32) g_pwb_ch = chunk_rows;
+  if (recompute_z >= 0) g_pwb_rz = recompute_z != 0;
+  if (max_waves >= 2) g_pwb_maxw = max_waves;
+  return 0;
+}
 
 // 0 on launch, SPB_E_UNSUPPORTED when this shape / dtype has no fused instance (the caller then uses
 // spb_pwconv_gemm + spb_pwconv_wgrad)

@@ -63,6 +63,6 @@ def test_spn_two_ranks_replicas_identical_and_gradient_is_the_sum(device):
     # SpnOptimizer.state_dict() after sharded steps gathers the momentum slices of the other rank (a collective both ranks made):
     # complete (a rank's un-gathered half would be zeros: half the fc elements), identical on both ranks, the unsharded run's values
     for mode in ("sharded_f32", "sharded"):
-        assert r[mode]["mom_replica_diff"] == 0.0, r[mode]
+        assert r[mode]["mom_replica_diff"] == 0.0 and r[mode]["mom2_replica_diff"] == 0.0, r[mode]
         assert r[mode]["mom_zero_frac"] < r["overlap_early"]["mom_zero_frac"] + 0.01, (r[mode], r["overlap_early"])
     assert r["sharded_f32"]["mom_rel"] < 5e-3 and r["sharded"]["mom_rel"] < 2e-2, (r["sharded_f32"], r["sharded"])

@@ -327,7 +327,10 @@ def test_pw_gemm_row_slab_input_gradient(device, M, K, N):
                                               # the plane-kernel layers of KRN at bs=48 (dwconv_plane.hip), plus ragged image groups / segments
                                               (48, 14, 384, 1, L.ACT_RELU6), (48, 7, 960, 1, L.ACT_RELU6), (48, 14, 576, 2, L.ACT_RELU6),
                                               (12, 28, 192, 1, L.ACT_RELU6), (7, 28, 64, 2, L.ACT_RELU6), (5, 7, 320, 1, L.ACT_RELU),
-                                              (3, 9, 40, 1, L.ACT_RELU), (2, 27, 24, 2, L.ACT_RELU6)])
+                                              (3, 9, 40, 1, L.ACT_RELU), (2, 27, 24, 2, L.ACT_RELU6),
+                                              # the large maps (bf16: LDS-tile kernels of dwconv_tile.hip): full and ragged 16 x 8 tiles, half channel chunks
+                                              (2, 56, 144, 1, L.ACT_RELU6), (2, 112, 32, 1, L.ACT_RELU6), (1, 112, 96, 2, L.ACT_RELU6),
+                                              (3, 56, 40, 2, L.ACT_RELU6), (1, 60, 24, 1, L.ACT_RELU), (2, 35, 16, 2, L.ACT_NONE)])
 def test_dwconv(device, dw_variant, dt, B, H, C, stride, act):
     torch.manual_seed(B * H + C)
     dev = device
@@ -402,7 +405,60 @@ def test_dwconv(device, dw_variant, dt, B, H, C, stride, act):
         assert relerr(dWf, Wd.grad) < tol
         assert relerr(Gf, nhwc(u1.grad) if with_epi else da) < tol
         if with_epi:
-            assert relerr(Gf, G1) < tol and relerr(osf.sum(0), os2.sum(0)) < 1e-3
+            # (the fused instance is the row-unit kernel with f32 tap weights, G1 may come from the tile kernel with bf16 taps: the
+            # tensors agree to the bf16 tolerance; each kernel's sums are held to ITS OWN output)
+            gf = Gf.double().cpu().view(-1, C); sf = osf.double().cpu().sum(0)
+            assert relerr(Gf, G1) < tol
+            assert relerr(sf[0], gf.sum(0)) < 1e-3 and relerr(sf[1], (gf * nhwc(xh1).view(-1, C)).sum(0)) < 1e-3
+
+
+@pytest.fixture(params=["rows", "tile"])
+def dw_tile_dgrad(request):
+    """stride-1 input gradient on the LDS-tile kernel (off by default: spb_debug_set_dw_tile bit 16) and on the default kernels"""
+    L.lib().spb_debug_set_dw_tile(28, (1 << 16) if request.param == "tile" else 0)
+    yield request.param
+    L.lib().spb_debug_set_dw_tile(28, 0)
+
+
+@pytest.mark.parametrize("B,H,C,act", [(3, 28, 192, L.ACT_RELU6), (2, 56, 144, L.ACT_RELU6), (1, 60, 24, L.ACT_RELU), (2, 35, 40, L.ACT_NONE)])
+def test_dwconv_input_gradient_tile_instance(device, dw_tile_dgrad, B, H, C, act):
+    """dz rebuilt from (g, z), flipped taps, ReLU-type mask of the input side and its two BatchNorm-backward sums, against float64"""
+    dt, dev, stride = torch.bfloat16, device, 1
+    torch.manual_seed(B * H + C)
+    zin = rt(torch.randn(B, C, H, H, dtype=torch.float64) + 0.1, dt).requires_grad_(True)
+    g1 = torch.rand(C, dtype=torch.float64) + 0.5; b1 = torch.randn(C, dtype=torch.float64) * 0.2
+    g2 = torch.rand(C, dtype=torch.float64) + 0.5; b2 = torch.randn(C, dtype=torch.float64) * 0.2
+    Wd = rt(torch.randn(C, 1, 3, 3, dtype=torch.float64) * 0.3, dt).requires_grad_(True)      # bf16-representable taps: both kernels see the same weights
+
+    def bn4(z, g, b):
+        mean = z.mean((0, 2, 3), keepdim=True); var = z.var((0, 2, 3), unbiased=False, keepdim=True)
+        xh = (z - mean) / torch.sqrt(var + EPS)
+        return xh * g.view(1, -1, 1, 1) + b.view(1, -1, 1, 1), xh
+
+    u1, xh1 = bn4(zin, g1, b1); u1.retain_grad()
+    a = act_fn(u1, act)
+    z = F.conv2d(a, Wd, stride=stride, padding=1, groups=C)
+    zq = rt(z.detach(), dt); z = z + (zq - z).detach()
+    u2, xh2 = bn4(z, g2, b2); u2.retain_grad()
+    (F.relu6(u2) * torch.randn_like(u2)).sum().backward()
+    nhwc = lambda t: t.detach().permute(0, 2, 3, 1).contiguous()
+    n = B * H * H
+    pro_in = ops.bnref(C, sums=sums_of(nhwc(zin).view(-1, C), 2, dev), gamma=g1.float().to(dev), beta=b1.float().to(dev), n=n, R=2, act=act)
+    g2s = rt(nhwc(u2.grad), dt)
+    bs = torch.stack([g2s.view(-1, C).sum(0), (g2s.view(-1, C) * nhwc(xh2).view(-1, C)).sum(0)]).float().unsqueeze(0).contiguous().to(dev)
+    pro = ops.bnref(C, sums=sums_of(nhwc(zq).view(-1, C), 1, dev), gamma=g2.float().to(dev), beta=b2.float().to(dev), bsums=bs, n=n, act=L.ACT_RELU6)
+    X = nhwc(zin).to(dt).to(dev); Wdev = Wd.detach().float().to(dev).contiguous()
+    G1 = torch.empty(B, H, H, C, dtype=dt, device=dev)
+    os2 = torch.zeros(2, 2, C, dtype=torch.float32, device=dev)
+    ops.dwconv_dgrad(g2s.to(dt).to(dev), nhwc(zq).to(dt).to(dev), Wdev, G1, pro, stride, (H, H), epi=pro_in, Zout=X, osums=os2, oR=2)
+    torch.cuda.synchronize()
+    assert relerr(G1, nhwc(u1.grad)) < TOL[dt] * 3
+    gs = G1.double().cpu().view(-1, C); s = os2.double().cpu().sum(0)
+    assert relerr(s[0], gs.sum(0)) < 1e-3 and relerr(s[1], (gs * nhwc(xh1).view(-1, C)).sum(0)) < 1e-3
+    P = torch.empty(B, H, H, C, dtype=dt, device=dev)
+    ops.dwconv_dgrad(g2s.to(dt).to(dev), nhwc(zq).to(dt).to(dev), Wdev, P, pro, stride, (H, H))
+    torch.cuda.synchronize()
+    assert relerr(P, nhwc(_dw_da(a, Wd, z, g2, g2s, xh2, C, stride))) < TOL[dt] * 3
 
 
 def _dw_da(a, Wd, z, g2, g2s_nhwc, xh2, C, stride):

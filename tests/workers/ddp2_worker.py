@@ -115,6 +115,11 @@ def spn(rank, world, dev):
             if it == 0:
                 torch.cuda.synchronize()
                 after1 = net.flat_parameters().clone()
+                if mode in ("overlap_early", "sharded_f32", "sharded"):
+                    # optimizer.state_dict() is a collective after sharded steps: the momentum buffers it returns must be
+                    # complete and identical on both ranks, and equal the unsharded run's (compared after the FIRST step, like the
+                    # parameters: later steps amplify the atomics noise of the convolution gradients)
+                    mom1 = opt.state_dict()["spn_fused"]["m"].to(dev)
         torch.cuda.synchronize()
         both = gather(net.flat_parameters().clone())
         ce = net._conv_end
@@ -131,15 +136,14 @@ def spn(rank, world, dev):
             sh = gather(net._shadow.float().clone())
             res[mode]["shadow_diff"] = float((sh[0] - sh[1]).abs().max())
         if mode in ("overlap_early", "sharded_f32", "sharded"):
-            # optimizer.state_dict() is a collective after sharded steps: the momentum buffers it returns must be complete
-            # and identical on both ranks, and equal the unsharded run's
-            mom = opt.state_dict()["spn_fused"]["m"].to(dev)
-            moms = gather(mom)
+            moms = gather(mom1)
             if mode == "overlap_early":
-                mom_ref = mom
+                mom_ref = mom1
             res[mode]["mom_replica_diff"] = float((moms[0] - moms[1]).abs().max())
-            res[mode]["mom_rel"] = float((mom[ce:] - mom_ref[ce:]).norm() / mom_ref[ce:].norm())
-            res[mode]["mom_zero_frac"] = float((mom[ce:] == 0).float().mean())
+            res[mode]["mom_rel"] = float((mom1[ce:] - mom_ref[ce:]).norm() / mom_ref[ce:].norm())
+            res[mode]["mom_zero_frac"] = float((mom1[ce:] == 0).float().mean())
+            mom2 = gather(opt.state_dict()["spn_fused"]["m"].to(dev))       # and again after a sharded step that followed a gather
+            res[mode]["mom2_replica_diff"] = float((mom2[0] - mom2[1]).abs().max())
     return res
 
 
