@@ -44,7 +44,7 @@ def _host():
     return dict(cpu_model=model, host_cores=os.cpu_count())
 
 
-def _pmc_traffic(family, files=("r3_pmc_traffic.json", "r2_pmc_traffic.json", "r1_pmc_traffic.json")):
+def _pmc_traffic(family, files=("r4_pmc_traffic.json", "r3_pmc_traffic.json", "r2_pmc_traffic.json", "r1_pmc_traffic.json")):
     """HBM bytes per launch of a kernel family from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE, separate runs,
     corrected as MI355X_MICROARCH.md prescribes; scratch/pmc_summary.py) -- rocprofv3 cannot run inside bench.py"""
     for name in files:
@@ -68,6 +68,146 @@ def _init_dist(dev):
     else:
         torch.distributed.init_process_group(backend)
 
+# ---- step-level algorithmic bytes: what `roofline` of the non-headline workloads is computed from
+KRN_BYTES_PER_IMAGE = 83.9e6        # bf16 activations, each conv reads its input once and writes its output once, x3 (fwd, dgrad, wgrad)
+GHIASI_FLOPS_PER_IMAGE = 15.43e9    # decoder forward at 224x224
+GHIASI_BYTES_PER_IMAGE = 45.95e6
+
+
+def _timed(fn, steps, warmup):
+    """ms per call of fn(): HIP-synchronised wall clock around `steps` calls after `warmup` untimed ones"""
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps * 1e3
+
+
+def _hbm_roof(alg_bytes, ms):
+    ach = alg_bytes / (ms * 1e-3) / 1e9
+    return dict(bound="hbm", achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4),
+                alg_bytes_per_step=round(alg_bytes))
+
+
+def spn_step_bytes(net, B, precision):
+    """algorithmic HBM bytes of one SPN train step: the optimizer's pass over the f32 arenas (p, g, m, v read; p, m, v written:
+    28 B per parameter, + the 16-bit shadow written, + fp16's inf / nan check reading g once more), the fully connected weights
+    streamed as 16-bit shadows by forward and input gradient (2 x 2 B) and their f32 gradient written once (4 B), and the
+    convolution trunk's activations (2.2 MB per image and pass)"""
+    n = net.flat_parameters().numel()
+    n_fc = n - net._conv_end
+    half = precision in ("bf16", "fp16")
+    opt = n * (28 + (2 if half else 0) + (4 if precision == "fp16" else 0))
+    fc = n_fc * ((2 + 2 if half else 4 + 4) + 4)
+    return opt + fc + 3 * 2.2e6 * B * (1 if half else 2)
+
+
+def bench_others(dev, budget_s=20.0):
+    """The other BASELINE.json workloads on this GPU, each for a short, fixed number of steps AFTER the headline region, so that they
+    sit under the driver's clock too: DANN (configs[3]) at the README's bs=16 and at bs=48, SPN (configs[5]) in bf16 and fp16,
+    KRN + style augmentation (configs[4]) and the style decoder alone.  ms per step + a step-level roofline each."""
+    from speedplusbaseline_amd.engine import KrnEngine
+    from speedplusbaseline_amd.step import FusedTrainStep
+    from oracle import krn_oracle as O  # weight init only (outside every timed region)
+    out = {}
+    t_start = time.perf_counter()
+    gen = torch.Generator(device="cpu"); gen.manual_seed(2021)
+
+    def left():
+        return budget_s - (time.perf_counter() - t_start)
+    # ---- DANN: one step = B source + B target images, two forwards, one backward through both, clip, AdamW
+    for B in (16, 48):
+        eng = KrnEngine(11, dann=True).attach(dev, "bf16")
+        sd = O.init_state(11, dann=True)
+        for info in eng.param_infos:
+            eng.param_view(info).copy_(sd[info[0]].to(dev))
+        for name, shape, off, numel in eng.buffer_infos:
+            eng.buffers[off: off + numel].copy_(sd[name].flatten().to(dev))
+        xs = torch.rand(B, 3, 224, 224, generator=gen).to(dev); ys = torch.rand(B, 2, 11, generator=gen).to(dev)
+        xt = torch.rand(B, 3, 224, 224, generator=gen).to(dev)
+        st = FusedTrainStep(eng, B, kind="adamw", lr=1e-3, momentum=0.9, weight_decay=0.01, max_norm=1.0, dann=True)
+        alpha = O.dann_alpha(5, 1, 100, 10)
+        ms = _timed(lambda: st(xs, ys, xt, alpha), 30, 8)
+        out["dann_bs%d" % B] = dict(ms_per_step=round(ms, 4), value=round(B / (ms * 1e-3), 1), unit="source images/sec", dtype="bf16",
+                                    roofline=_hbm_roof(2 * KRN_BYTES_PER_IMAGE * B, ms),
+                                    workload="RevGrad step, %d source + %d target images, AdamW + clip 1.0" % (B, B))
+        del st, eng
+    # ---- SPN, bf16 and fp16 (IEEE half + device-side dynamic loss scaling)
+    from speedplusbaseline_amd.nets.spn import SpacecraftPoseNet
+    from speedplusbaseline_amd.optim import SpnOptimizer
+    from speedplusbaseline_amd.data import SyntheticSpnLoader
+    x, yc, yw = (t.to(dev) for t in next(iter(SyntheticSpnLoader(32, 1, 5000, 5, seed=2021))))
+    for prec in ("bf16", "fp16"):
+        if left() < 4.0:
+            break
+        torch.manual_seed(2021)
+        net = SpacecraftPoseNet(5000, keep_prob=0.5, pretrain=False, precision=prec).to(dev).train()
+        opt = SpnOptimizer(list(net.parameters()), kind="adamw", lr=1e-4, momentum=0.9, weight_decay=0.0, model=net)
+
+        def one():
+            net.loss_and_grads(x, yc, yw, optimizer=opt)
+            opt.step()
+        ms = _timed(one, 30, 8)
+        out["spn_" + prec] = dict(ms_per_step=round(ms, 4), value=round(32 / (ms * 1e-3), 1), unit="images/sec", dtype=prec,
+                                  roofline=_hbm_roof(spn_step_bytes(net, 32, prec), ms),
+                                  workload="SPN train step, 227x227, bs=32, 5000 classes, AdamW + clip_grad_value 1.0")
+        del opt, net
+    # ---- style augmentation: the decoder alone, and the KRN step with the rank-synchronous coin (p = 0.5) one batch ahead
+    if left() > 3.0:
+        from speedplusbaseline_amd.styleaug import Ghiasi, StyleAugmentor
+        from speedplusbaseline_amd.parallel import shared_coin
+        torch.manual_seed(2021)
+        aug = StyleAugmentor.synthetic(0.5, dev, Ghiasi().state_dict(), seed=2021)
+        B = 48
+        xk = torch.rand(B, 3, 224, 224, generator=gen).to(dev); yk = torch.rand(B, 2, 11, generator=gen).to(dev)
+        ms = _timed(lambda: aug(xk), 12, 4)
+        tf = GHIASI_FLOPS_PER_IMAGE * B / (ms * 1e-3) / 1e12
+        out["decoder"] = dict(ms_per_step=round(ms, 4), value=round(B / (ms * 1e-3), 1), unit="images/sec", dtype="bf16",
+                              roofline=dict(bound="mfma", achieved=round(tf, 1), peak=MFMA_PEAK_TFLOPS["bf16"], unit="TFLOP/s",
+                                            frac=round(tf / MFMA_PEAK_TFLOPS["bf16"], 4), alg_flops_per_step=GHIASI_FLOPS_PER_IMAGE * B),
+                              workload="Ghiasi style decoder forward, %d images 224x224" % B)
+        eng = KrnEngine(11).attach(dev, "bf16")
+        sd = O.init_state(11)
+        for info in eng.param_infos:
+            eng.param_view(info).copy_(sd[info[0]].to(dev))
+        for name, shape, off, numel in eng.buffer_infos:
+            eng.buffers[off: off + numel].copy_(sd[name].flatten().to(dev))
+        st = FusedTrainStep(eng, B, kind="adamw", lr=1e-3, momentum=0.9, weight_decay=0.01, max_norm=1.0)
+        side = torch.cuda.Stream(device=dev)
+        state = {"i": 0, "next": None}
+
+        def stage(i):
+            if not shared_coin(i, 2021, 0.5):
+                return xk, None
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                o = aug(xk)
+                ev = torch.cuda.Event(); ev.record(side)
+            return o, ev
+
+        def one():
+            i = state["i"]
+            cur = state["next"] or stage(i)
+            state["next"] = stage(i + 1)          # the restyle of batch i+1 is enqueued before train step i (core/trainer.py AugLookahead)
+            xin, ev = cur
+            if ev is not None:
+                torch.cuda.current_stream().wait_event(ev)
+                xin.record_stream(torch.cuda.current_stream())
+            st(xin, yk)
+            state["i"] = i + 1
+        ms = _timed(one, 40, 10)
+        # algorithmic work of the average step: the KRN step's bytes + half a restyle's
+        out["styleaug"] = dict(ms_per_step=round(ms, 4), value=round(B / (ms * 1e-3), 1), unit="images/sec", dtype="bf16",
+                               roofline=_hbm_roof(KRN_BYTES_PER_IMAGE * B + 0.5 * GHIASI_BYTES_PER_IMAGE * B, ms),
+                               workload="KRN train step bs=48 with the style decoder on a p=0.5 coin, one batch ahead on a side stream")
+        del st, eng, aug
+    out["_note"] = ("each entry: 30-40 steps after 8-10 warm-up steps in this process, after the headline region; roofline = SURVEY 8d algorithmic "
+                    "bytes (or decoder flops) per step / step time; %.1f s in total" % (time.perf_counter() - t_start))
+    return out
+
 
 def main():
     ap = argparse.ArgumentParser()
@@ -86,10 +226,16 @@ def main():
     ap.add_argument("--styleaug", action="store_true", help="BASELINE configs[4] flavour: restyle the batch with the Ghiasi "
                     "decoder on a rank-synchronous coin (p=0.5, alpha=0.5) before the train step (trainer.py:68-69)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-others", action="store_true", help="skip the `others` block of the KRN line (the other BASELINE workloads, "
+                    "timed briefly in the same process after the headline region)")
+    ap.add_argument("--bare", action="store_true", help="timed region only (no instrumented pass, no others, no CPU baseline): what the "
+                    "rocprofv3 PMC passes run, so that a pass holds exactly warmup + steps steps")
     ap.add_argument("--cpu-steps", type=int, default=3)
     ap.add_argument("--cpu-threads", type=int, default=32)
     args = ap.parse_args()
 
+    if args.bare:
+        args.no_cpu_baseline = args.no_others = True
     if args.precision == "fp16" and args.model != "spn":
         raise SystemExit("--precision fp16 exists for --model spn only (KRN / RevGrad: bf16 with f32 accumulation, DESIGN.md a13)")
     if args.model == "spn":
@@ -211,7 +357,7 @@ def main():
     # ---- instrumented pass: per-kernel-family time (HIP events on the launch stream) and algorithmic bytes
     kernels = {}
     roofline = None
-    if rank == 0:
+    if rank == 0 and not args.bare:
         es = 2 if args.precision == "bf16" else 4
         n_prof = 5
         eng.prof_enable(B, 0, True)
@@ -289,8 +435,11 @@ def main():
         dec_traffic, dec_src = (None, None)
         if B == 48:
             try:   # HBM bytes of one restyle (all decoder launches), from the committed FETCH_SIZE / WRITE_SIZE passes of scratch/bench_ghiasi.py
-                with open(os.path.join(ROOT, "profiles", "r3_ghiasi_pmc_traffic.json")) as f:
-                    dec_traffic, dec_src = json.load(f)["restyle_hbm_bytes"], "r3_ghiasi_pmc_traffic.json"
+                for nm in ("r4_ghiasi_pmc_traffic.json", "r3_ghiasi_pmc_traffic.json"):
+                    if os.path.exists(os.path.join(ROOT, "profiles", nm)):
+                        with open(os.path.join(ROOT, "profiles", nm)) as f:
+                            dec_traffic, dec_src = json.load(f)["restyle_hbm_bytes"], nm
+                        break
             except Exception:
                 pass
         roofline = dict(bound="mfma", kernel="Ghiasi decoder (all launches of one restyle, %d images)" % B, achieved=round(dec_tf, 1),
@@ -320,6 +469,13 @@ def main():
         cpu = dict(value=round(B * args.cpu_steps / cdt, 2), unit="images/sec", cores=torch.get_num_threads(), kind="port", **_host(),
                    sample="%d train steps of the same bs=%d 224x224 batch, fp32, PyTorch CPU oracle (%.1f s)" % (args.cpu_steps, B, cdt))
 
+    others = None
+    if rank == 0 and world == 1 and not args.no_others and aug is None:
+        del step
+        try:
+            others = bench_others(dev)
+        except Exception as e:      # never lose the headline line to a side measurement
+            others = {"error": "%s: %s" % (type(e).__name__, e)}
     if rank == 0:
         out = {
             "metric": "images/sec KRN 224x224 bs=48/GPU train step",
@@ -333,7 +489,7 @@ def main():
                        "launch": "hipGraph replay (fwd+bwd | all-reduce | clip+AdamW)" if args.graph else
                                  "eager enqueue, weight-gradient GEMMs on a side stream",
                        "weights": "random init (no checkpoints offline)", "loss_last_step": loss_last},
-            "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels,
+            "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels, "others": others,
         }
         print(json.dumps(out))
     if world > 1:
@@ -462,7 +618,7 @@ def bench_dann(args):
     # ---- instrumented pass (both passes back to back on the launch stream, HIP events around every launch): the dominant
     # kernel family of the step and its achieved HBM rate, as for the KRN line
     roofline = None
-    if rank == 0:
+    if rank == 0 and not args.bare:
         n_prof = 3
         eng.prof_enable(B, 0, True); eng.prof_enable(B, 1, True)
         agg = {}
@@ -484,7 +640,7 @@ def bench_dann(args):
         eng.prof_enable(B, 0, False); eng.prof_enable(B, 1, False)
         dk, dv = max(agg.items(), key=lambda kv: kv[1]["ms"])
         ach = dv["bytes"] / (dv["ms"] * 1e-3) / 1e9
-        traffic, traffic_src = _pmc_traffic(dk, ("r3_dann_pmc_traffic.json",)) if B == 48 else (None, None)   # passes taken at bs=48+48
+        traffic, traffic_src = _pmc_traffic(dk, ("r4_dann_pmc_traffic.json", "r3_dann_pmc_traffic.json")) if B == 48 else (None, None)   # passes taken at bs=48+48
         roofline = dict(bound="hbm", kernel=dk, achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4),
                         traffic=traffic, traffic_source=traffic_src,
                         launches_per_step=dv["launches"] // n_prof, avg_launch_us=round(dv["ms"] / dv["launches"] * 1e3, 2),
@@ -576,27 +732,43 @@ def bench_spn(args):
     dt = float(t.item())
 
     roofline = cpu = None
+    ms_step = dt / args.steps * 1e3
     if rank == 0:
-        # dominant kernel: the fused clip + AdamW pass over the 152 M element arenas (reads p, g, m, v; writes p, m, v and the
-        # bf16 shadow = 30 B per parameter), timed with events on the launch stream
-        n = net.flat_parameters().numel()
-        evs = []
-        for _ in range(5):
-            net.loss_and_grads(x, yc, yw)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record(); opt.step(); e1.record()
-            evs.append((e0, e1))
-        torch.cuda.synchronize()
-        us = sum(a.elapsed_time(b) for a, b in evs) / len(evs) * 1e3
-        by = n * (28 + (2 if args.precision in ("bf16", "fp16") else 0)) + (4 * n if args.precision == "fp16" else 0)   # fp16: + the inf / nan check's read of g
-        ach = by / (us * 1e-6) / 1e9
-        traffic, traffic_src = _pmc_traffic("optim_step_full", ("r2_spn_pmc_traffic.json",)) if (B == 32 and NC == 5000) else (None, None)
-        roofline = dict(bound="hbm", kernel="optim_step (clip_grad_value + AdamW + bf16 shadow)" if args.precision != "fp16" else
-                        "amp_check + amp_step + optim_step (inf/nan check, unscale, clip_grad_value, AdamW, float16 shadow)", achieved=round(ach, 1), peak=HBM_PEAK_GBS,
-                        unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4), traffic=traffic, traffic_source=traffic_src, launches_per_step=1,
-                        avg_launch_us=round(us, 1), alg_bytes_per_launch=by,
-                        note="timed alone as one arena-wide launch; in the step it runs as two launches (convolution range, heads) and the "
-                             "heads' part overlaps the trunk's backward and the next step's trunk forward")
+        # STEP-level roofline: the step is HBM-bound by the optimizer's pass over the 152 M-element f32 arenas (28 B per parameter + the
+        # 16-bit shadow; fp16 adds the inf / nan check's read of g), the fully connected weights streamed by forward and input gradient
+        # and their f32 gradient written once: algorithmic bytes per step / step time (spn_step_bytes)
+        by_step = spn_step_bytes(net, B, args.precision)
+        roofline = _hbm_roof(by_step, ms_step)
+        roofline["kernel"] = "whole step (optimizer pass over the arenas + fully connected weight streams + trunk activations)"
+        traffic = traffic_src = None
+        if B == 32 and NC == 5000:
+            for nm in ("r4_spn_%s_pmc_traffic.json" % args.precision, "r3_spn_pmc_traffic.json"):
+                try:
+                    with open(os.path.join(ROOT, "profiles", nm)) as f:
+                        j = json.load(f)
+                    if "step_hbm_bytes" in j:
+                        traffic, traffic_src = j["step_hbm_bytes"], nm
+                        break
+                except Exception:
+                    continue
+        roofline["traffic"], roofline["traffic_source"] = traffic, traffic_src
+        if not args.bare:
+            # the dominant kernel alone: the fused clip + AdamW pass as ONE arena-wide launch, HIP events on the launch stream
+            n = net.flat_parameters().numel()
+            evs = []
+            for _ in range(5):
+                net.loss_and_grads(x, yc, yw)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(); opt.step(); e1.record()
+                evs.append((e0, e1))
+            torch.cuda.synchronize()
+            us = sum(a.elapsed_time(b) for a, b in evs) / len(evs) * 1e3
+            by = n * (28 + (2 if args.precision in ("bf16", "fp16") else 0)) + (4 * n if args.precision == "fp16" else 0)
+            ach = by / (us * 1e-6) / 1e9
+            roofline["optimizer_alone"] = dict(kernel="optim_step (clip_grad_value + AdamW + 16-bit shadow)" if args.precision != "fp16" else
+                                               "amp_check + amp_step + optim_step", achieved=round(ach, 1), frac=round(ach / HBM_PEAK_GBS, 4),
+                                               avg_launch_us=round(us, 1), alg_bytes_per_launch=by,
+                                               traffic=_pmc_traffic("optim_step_full", ("r3_spn_pmc_traffic.json", "r2_spn_pmc_traffic.json"))[0])
     if rank == 0 and world == 1 and not args.no_cpu_baseline:   # N=1 only: the other ranks would sit in the process group meanwhile
         from oracle import spn_oracle as S
         ncores = min(os.cpu_count() or 1, args.cpu_threads)
@@ -605,17 +777,29 @@ def bench_spn(args):
         sd = S.init_state(NC)
         xc, ycc, ywc = S.synth_batch(Bc, NC, seed=11)
         masks = S.synth_masks(Bc, seed=5)
+        # one reference step (trainer.py:146-185): forward, the two soft cross-entropies, backward, clip_grad_value_(1.0), AdamW
+        leaves = [v.clone().requires_grad_(True) for v in sd.values()]
+        names = list(sd.keys())
+        cpu_opt = torch.optim.AdamW(leaves, lr=1e-4, betas=(0.9, 0.999), weight_decay=0.0)
+
+        def cpu_step():
+            cpu_opt.zero_grad(set_to_none=True)
+            c_, r_ = S.forward(dict(zip(names, leaves)), xc, masks, 0.5)
+            loss_, _, _ = S.loss_fn(c_, r_, ycc, ywc)
+            loss_.backward()
+            torch.nn.utils.clip_grad_value_(leaves, 1.0)
+            cpu_opt.step()
         t1 = time.perf_counter()
-        S.train_grads(sd, xc, ycc, ywc, masks)      # warm-up
+        cpu_step()      # warm-up
         warm = time.perf_counter() - t1
         nst = max(1, min(40, int(12.0 / max(warm, 1e-3))))     # ~10-15 s of CPU work
         t1 = time.perf_counter()
         for _ in range(nst):
-            S.train_grads(sd, xc, ycc, ywc, masks)
+            cpu_step()
         cdt = time.perf_counter() - t1
         cpu = dict(value=round(Bc * nst / cdt, 2), unit="images/sec", cores=torch.get_num_threads(), kind="port", **_host(),
-                   sample="%d forward+backward passes of a bs=%d 227x227 batch, fp32, PyTorch CPU oracle, optimizer not included (%.1f s)"
-                          % (nst, Bc, cdt))
+                   sample="%d train steps (forward, backward, clip_grad_value_, AdamW over all 152 M parameters) of a bs=%d 227x227 batch, "
+                          "fp32, PyTorch CPU oracle (%.1f s)" % (nst, Bc, cdt))
     if rank == 0:
         print(json.dumps({
             "metric": "images/sec SPN 227x227 bs=32/GPU train step", "value": round(world * B * args.steps / dt, 1), "unit": "images/sec",

@@ -124,9 +124,11 @@ class _Net:
     momentum = BN_MOM  # class-level knob: tests set 1.0 to make running stats equal the batch statistics
     # class-level knob: emulate the bf16 storage/operand rounding points of the HIP path (straight-through in backward):
     #   every convolution output is stored as bf16; matrix-core operands (input and weight of the stem, the 1x1 convs,
-    #   the head and the domain conv) are rounded to bf16; depthwise arithmetic stays f32; materialised tensors (skip
-    #   outputs, concat) bf16.
+    #   the head and the domain conv) are rounded to bf16; depthwise arithmetic stays f32 on the small maps, and on the maps
+    #   at least DW_TILE_MIN wide (round 4: csrc/dwconv_tile.hip, forward) the activated operand is staged as bf16 and the
+    #   taps are bf16 (v_dot2c_f32_bf16, f32 accumulation); materialised tensors (skip outputs, concat) bf16.
     quant = False
+    DW_TILE_MIN = 28
 
     def __init__(self, sd, training, prefix=""):
         self.sd, self.training, self.p = sd, training, prefix
@@ -141,6 +143,8 @@ class _Net:
         w = self.sd[self.p + name + ".weight"]
         b = self.sd.get(self.p + name + ".bias")
         if groups == 1:  # matrix-core layers (stem, pointwise, head, domain conv): operands rounded
+            x, w = self.q(x), self.q(w)
+        elif x.shape[-1] >= self.DW_TILE_MIN:  # depthwise layers of the large maps: bf16 operand tile and bf16 taps
             x, w = self.q(x), self.q(w)
         z = F.conv2d(x, w, None, stride, padding, 1, groups)
         if b is not None:  # head / domain conv: f32 bias after the (rounded, for the domain conv) product

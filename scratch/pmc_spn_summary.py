@@ -21,7 +21,7 @@ def read(path, counter):
     return agg
 
 
-def main(fetch_csv, write_csv, out_json):
+def main(fetch_csv, write_csv, out_json, steps=0):
     fetch, write = read(fetch_csv, "FETCH_SIZE"), read(write_csv, "WRITE_SIZE")
     fam = {}
     for key in sorted(set(fetch) | set(write)):
@@ -34,6 +34,12 @@ def main(fetch_csv, write_csv, out_json):
         fam["optim_step_full"] = dict(fam[full], grid=int(full.split("@")[1]))
     out = {"_note": "bytes per launch = (2*FETCH_SIZE + WRITE_SIZE)*1024, averaged over the launches with that grid; scratch/pmc_spn_summary.py",
            "families": fam}
+    if int(steps) > 0:   # the passes ran `bench.py --model spn --bare --steps S --warmup W`: every launch belongs to one of the S + W steps
+        tot = sum((2 * kbf + kbw) * 1024 for (kbf, kbw) in
+                  ((fetch.get(k, [0, 0.0])[1], write.get(k, [0, 0.0])[1]) for k in set(fetch) | set(write)))
+        out["steps"] = int(steps)
+        out["step_hbm_bytes"] = round(tot / int(steps))
+        print("whole step: %.1f MB of HBM traffic (all launches of %d steps / %d)" % (tot / int(steps) / 1e6, int(steps), int(steps)))
     with open(out_json, "w") as f:
         json.dump(out, f, indent=1)
     for k, v in fam.items():
@@ -42,4 +48,4 @@ def main(fetch_csv, write_csv, out_json):
 
 
 if __name__ == "__main__":
-    main(*sys.argv[1:4])
+    main(*sys.argv[1:5])
