@@ -1,4 +1,4 @@
-"""One conditioned state, the bf16 gradient against float64 under different kernel selections (A/B of numerics, not of speed)."""
+"""One conditioned state: the bf16 gradient against float64 for several target shifts and kernel selections (numerics A/B, not speed)."""
 import os, sys, math
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch
@@ -10,28 +10,27 @@ dev = torch.device("cuda:0")
 sdc = T._condition(dev)
 B = T.B
 x, y = T.structured_batch(B, 8)
-ys = (y + T.TARGET_SHIFT)
+shifts = (0.0, 0.05, 0.1, 0.2)
 sd = {k: v.clone() for k, v in sdc.items()}
 names = O._leafify(sd)
 out, _ = O.krn_predict(sd, x.double(), True, "")
-loss = O.krn_loss(out, y.double())[0]; loss_s = O.krn_loss(out, ys.double())[0]
-gmin = torch.cat([g.flatten() for g in torch.autograd.grad(loss, [sd[k] for k in names], retain_graph=True)])
-loss_s.backward()
-gref = torch.cat([sd[k].grad.flatten() for k in names])
-print("float64: loss %.6f shifted %.6f |g| %.3e |g_shift| %.3e" % (float(loss), float(loss_s), float(gmin.norm()), float(gref.norm())))
+refs = []
+for sh in shifts:
+    l = O.krn_loss(out, (y + sh).double())[0]
+    g = torch.autograd.grad(l, [sd[k] for k in names], retain_graph=True)
+    refs.append((float(l), [t.flatten() for t in g]))
 lib = L.lib()
-def run(tag, prec="bf16"):
-    eng = KrnEngine(T.K).attach(dev, prec)
-    res = []
-    for tgt, gr in ((y, gmin), (ys, gref)):
+def run(tag):
+    eng = KrnEngine(T.K).attach(dev, "bf16")
+    row = []
+    for sh, (l, gr) in zip(shifts, refs):
         T.load_state(eng, sdc); eng.grads.zero_()
-        _, scal, _ = eng.forward(x.to(dev), tgt.to(dev), training=True); eng.backward(B); torch.cuda.synchronize()
-        g = torch.cat([eng.param_view(i, eng.grads).double().cpu().flatten() for i in eng.param_infos])
-        res.append((float(scal[0]), T._cos(g, gr), float(g.norm() / gr.norm())))
-    print("%-28s loss %.6f cos %.4f ratio %.3f | shifted: loss %.6f cos %.4f ratio %.3f" % ((tag,) + res[0] + res[1]))
-run("fp32", "fp32")
-run("default"); run("default (again)")
-lib.spb_debug_set_dw_tile(0, 0); run("dw tile off")
-lib.spb_debug_set_pwb(32, 0, 4); run("+ pwb old config")
-lib.spb_debug_set_fused_pw_bwd(0); run("+ fused pw bwd off")
-lib.spb_debug_set_fused_pw_bwd(1); lib.spb_debug_set_pwb(16, 1, 8); lib.spb_debug_set_dw_tile(28, 0); run("default (end)")
+        _, scal, _ = eng.forward(x.to(dev), (y + sh).to(dev), training=True); eng.backward(B); torch.cuda.synchronize()
+        gh = [eng.param_view(i, eng.grads).double().cpu().flatten() for i in eng.param_infos]
+        G, R = torch.cat(gh), torch.cat(gr)
+        worst = min((T._cos(a, b), i[0]) for a, b, i in zip(gh, gr, eng.param_infos) if i[0].endswith(".weight") and a.numel() > 64)
+        row.append("shift %.2f: cos %.4f ratio %.3f |g| %.2e worst %.2f %s" % (sh, T._cos(G, R), float(G.norm() / R.norm()), float(R.norm()), worst[0], worst[1]))
+    print(tag + "\n   " + "\n   ".join(row))
+run("default")
+lib.spb_debug_set_pwb(32, 0, 4); run("pwb old config (z read, 32-row chunks)")
+lib.spb_debug_set_pwb(16, 1, 8); lib.spb_debug_set_dw_tile(0, 0); run("dw tile off")
