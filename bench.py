@@ -105,108 +105,74 @@ def spn_step_bytes(net, B, precision):
     return opt + fc + 3 * 2.2e6 * B * (1 if half else 2)
 
 
-def bench_others(dev, budget_s=20.0):
+def bench_others(steps=40, warmup=10):
     """The other BASELINE.json workloads on this GPU, each for a short, fixed number of steps AFTER the headline region, so that they
     sit under the driver's clock too: DANN (configs[3]) at the README's bs=16 and at bs=48, SPN (configs[5]) in bf16 and fp16,
-    KRN + style augmentation (configs[4]) and the style decoder alone.  ms per step + a step-level roofline each."""
-    from speedplusbaseline_amd.engine import KrnEngine
-    from speedplusbaseline_amd.step import FusedTrainStep
-    from oracle import krn_oracle as O  # weight init only (outside every timed region)
+    KRN + style augmentation (configs[4]) and the style decoder alone.  Each runs `bench.py --bare` of its own in a fresh process --
+    exactly the command a reader would run by hand: measured in THIS process after the headline region they were 1.5-3x slower
+    (DANN bs=16 7.4 instead of 2.6 ms), because the HIP runtime hands hardware queues to streams round robin and the streams of the
+    finished workloads keep theirs: two concurrently active streams of a later workload end up sharing a queue."""
+    import subprocess
+    runs = (("dann_bs16", ["--model", "dann", "--batch", "16"]), ("dann_bs48", ["--model", "dann", "--batch", "48"]),
+            ("spn_bf16", ["--model", "spn", "--precision", "bf16"]), ("spn_fp16", ["--model", "spn", "--precision", "fp16"]),
+            ("styleaug", ["--styleaug"]), ("decoder", ["--model", "decoder"]))
     out = {}
     t_start = time.perf_counter()
-    gen = torch.Generator(device="cpu"); gen.manual_seed(2021)
-
-    def left():
-        return budget_s - (time.perf_counter() - t_start)
-    # ---- DANN: one step = B source + B target images, two forwards, one backward through both, clip, AdamW
-    for B in (16, 48):
-        eng = KrnEngine(11, dann=True).attach(dev, "bf16")
-        sd = O.init_state(11, dann=True)
-        for info in eng.param_infos:
-            eng.param_view(info).copy_(sd[info[0]].to(dev))
-        for name, shape, off, numel in eng.buffer_infos:
-            eng.buffers[off: off + numel].copy_(sd[name].flatten().to(dev))
-        xs = torch.rand(B, 3, 224, 224, generator=gen).to(dev); ys = torch.rand(B, 2, 11, generator=gen).to(dev)
-        xt = torch.rand(B, 3, 224, 224, generator=gen).to(dev)
-        st = FusedTrainStep(eng, B, kind="adamw", lr=1e-3, momentum=0.9, weight_decay=0.01, max_norm=1.0, dann=True)
-        alpha = O.dann_alpha(5, 1, 100, 10)
-        ms = _timed(lambda: st(xs, ys, xt, alpha), 30, 8)
-        out["dann_bs%d" % B] = dict(ms_per_step=round(ms, 4), value=round(B / (ms * 1e-3), 1), unit="source images/sec", dtype="bf16",
-                                    roofline=_hbm_roof(2 * KRN_BYTES_PER_IMAGE * B, ms),
-                                    workload="RevGrad step, %d source + %d target images, AdamW + clip 1.0" % (B, B))
-        del st, eng
-    # ---- SPN, bf16 and fp16 (IEEE half + device-side dynamic loss scaling)
-    from speedplusbaseline_amd.nets.spn import SpacecraftPoseNet
-    from speedplusbaseline_amd.optim import SpnOptimizer
-    from speedplusbaseline_amd.data import SyntheticSpnLoader
-    x, yc, yw = (t.to(dev) for t in next(iter(SyntheticSpnLoader(32, 1, 5000, 5, seed=2021))))
-    for prec in ("bf16", "fp16"):
-        if left() < 4.0:
-            break
-        torch.manual_seed(2021)
-        net = SpacecraftPoseNet(5000, keep_prob=0.5, pretrain=False, precision=prec).to(dev).train()
-        opt = SpnOptimizer(list(net.parameters()), kind="adamw", lr=1e-4, momentum=0.9, weight_decay=0.0, model=net)
-
-        def one():
-            net.loss_and_grads(x, yc, yw, optimizer=opt)
-            opt.step()
-        ms = _timed(one, 30, 8)
-        out["spn_" + prec] = dict(ms_per_step=round(ms, 4), value=round(32 / (ms * 1e-3), 1), unit="images/sec", dtype=prec,
-                                  roofline=_hbm_roof(spn_step_bytes(net, 32, prec), ms),
-                                  workload="SPN train step, 227x227, bs=32, 5000 classes, AdamW + clip_grad_value 1.0")
-        del opt, net
-    # ---- style augmentation: the decoder alone, and the KRN step with the rank-synchronous coin (p = 0.5) one batch ahead
-    if left() > 3.0:
-        from speedplusbaseline_amd.styleaug import Ghiasi, StyleAugmentor
-        from speedplusbaseline_amd.parallel import shared_coin
-        torch.manual_seed(2021)
-        aug = StyleAugmentor.synthetic(0.5, dev, Ghiasi().state_dict(), seed=2021)
-        B = 48
-        xk = torch.rand(B, 3, 224, 224, generator=gen).to(dev); yk = torch.rand(B, 2, 11, generator=gen).to(dev)
-        ms = _timed(lambda: aug(xk), 12, 4)
-        tf = GHIASI_FLOPS_PER_IMAGE * B / (ms * 1e-3) / 1e12
-        out["decoder"] = dict(ms_per_step=round(ms, 4), value=round(B / (ms * 1e-3), 1), unit="images/sec", dtype="bf16",
-                              roofline=dict(bound="mfma", achieved=round(tf, 1), peak=MFMA_PEAK_TFLOPS["bf16"], unit="TFLOP/s",
-                                            frac=round(tf / MFMA_PEAK_TFLOPS["bf16"], 4), alg_flops_per_step=GHIASI_FLOPS_PER_IMAGE * B),
-                              workload="Ghiasi style decoder forward, %d images 224x224" % B)
-        eng = KrnEngine(11).attach(dev, "bf16")
-        sd = O.init_state(11)
-        for info in eng.param_infos:
-            eng.param_view(info).copy_(sd[info[0]].to(dev))
-        for name, shape, off, numel in eng.buffer_infos:
-            eng.buffers[off: off + numel].copy_(sd[name].flatten().to(dev))
-        st = FusedTrainStep(eng, B, kind="adamw", lr=1e-3, momentum=0.9, weight_decay=0.01, max_norm=1.0)
-        side = torch.cuda.Stream(device=dev)
-        state = {"i": 0, "next": None}
-
-        def stage(i):
-            if not shared_coin(i, 2021, 0.5):
-                return xk, None
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                o = aug(xk)
-                ev = torch.cuda.Event(); ev.record(side)
-            return o, ev
-
-        def one():
-            i = state["i"]
-            cur = state["next"] or stage(i)
-            state["next"] = stage(i + 1)          # the restyle of batch i+1 is enqueued before train step i (core/trainer.py AugLookahead)
-            xin, ev = cur
-            if ev is not None:
-                torch.cuda.current_stream().wait_event(ev)
-                xin.record_stream(torch.cuda.current_stream())
-            st(xin, yk)
-            state["i"] = i + 1
-        ms = _timed(one, 40, 10)
-        # algorithmic work of the average step: the KRN step's bytes + half a restyle's
-        out["styleaug"] = dict(ms_per_step=round(ms, 4), value=round(B / (ms * 1e-3), 1), unit="images/sec", dtype="bf16",
-                               roofline=_hbm_roof(KRN_BYTES_PER_IMAGE * B + 0.5 * GHIASI_BYTES_PER_IMAGE * B, ms),
-                               workload="KRN train step bs=48 with the style decoder on a p=0.5 coin, one batch ahead on a side stream")
-        del st, eng, aug
-    out["_note"] = ("each entry: 30-40 steps after 8-10 warm-up steps in this process, after the headline region; roofline = SURVEY 8d algorithmic "
-                    "bytes (or decoder flops) per step / step time; %.1f s in total" % (time.perf_counter() - t_start))
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    for name, extra in runs:
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--bare", "--steps", str(steps), "--warmup", str(warmup)] + extra
+        try:
+            p = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+            line = [l for l in p.stdout.splitlines() if l.startswith("{")][-1]
+            d = json.loads(line)
+        except Exception as e:      # never lose the headline line to a side measurement
+            out[name] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
+            continue
+        ms, bsz = d["ms_per_step"], d["config"].get("per_gpu_batch", 48)
+        roof = d.get("roofline")
+        if name.startswith("dann"):
+            roof = _hbm_roof(2 * KRN_BYTES_PER_IMAGE * bsz, ms)          # two passes (source, target) of the KRN traffic
+        elif name == "styleaug":
+            roof = _hbm_roof(KRN_BYTES_PER_IMAGE * bsz + 0.5 * GHIASI_BYTES_PER_IMAGE * bsz, ms)   # the KRN step + half a restyle (coin p = 0.5)
+        out[name] = dict(ms_per_step=ms, value=d["value"], unit=d["unit"], dtype=d["dtype"], steps=d["steps"], roofline=roof,
+                         workload=d["config"]["workload"], command="python bench.py " + " ".join(cmd[2:]))
+    out["_note"] = ("each entry: its own `python bench.py --bare ...` process started by this one after the headline region (%d steps after %d "
+                    "warm-up steps); roofline = SURVEY 8d algorithmic bytes (decoder: flops) per step / step time; %.0f s in total"
+                    % (steps, warmup, time.perf_counter() - t_start))
     return out
+
+
+def bench_decoder(args):
+    """the Ghiasi style decoder alone (15.43 GFLOP per image at 224x224): one restyle of a resident batch per step"""
+    from speedplusbaseline_amd.styleaug import Ghiasi, StyleAugmentor
+    dev = torch.device("cuda", 0)
+    B = args.batch
+    torch.manual_seed(2021)
+    aug = StyleAugmentor.synthetic(0.5, dev, Ghiasi().state_dict(), seed=2021)   # random decoder weights (none offline)
+    gen = torch.Generator(device="cpu"); gen.manual_seed(2021)
+    x = torch.rand(B, 3, 224, 224, generator=gen).to(dev)
+    ms = _timed(lambda: aug(x), args.steps, args.warmup)
+    tf = GHIASI_FLOPS_PER_IMAGE * B / (ms * 1e-3) / 1e12
+    traffic = src = None
+    if B == 48:
+        for nm in ("r4_ghiasi_pmc_traffic.json", "r3_ghiasi_pmc_traffic.json"):
+            try:
+                with open(os.path.join(ROOT, "profiles", nm)) as f:
+                    traffic, src = json.load(f)["restyle_hbm_bytes"], nm
+                break
+            except Exception:
+                continue
+    print(json.dumps({
+        "metric": "images/sec Ghiasi style decoder 224x224 forward", "value": round(B / (ms * 1e-3), 1), "unit": "images/sec", "n_gpus": 1,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": "Ghiasi style decoder forward (StyleAugmentor, alpha 0.5), %d images 224x224" % B, "per_gpu_batch": B, "weights": "random init"},
+        "roofline": dict(bound="mfma", kernel="all launches of one restyle", achieved=round(tf, 1), peak=MFMA_PEAK_TFLOPS["bf16"], unit="TFLOP/s",
+                         frac=round(tf / MFMA_PEAK_TFLOPS["bf16"], 4), traffic=traffic, traffic_source=src,
+                         alg_flops_per_step=GHIASI_FLOPS_PER_IMAGE * B, alg_bytes_per_step=GHIASI_BYTES_PER_IMAGE * B),
+        "cpu_baseline": None}))
 
 
 def main():
@@ -220,7 +186,7 @@ def main():
     ap.add_argument("--graph", action="store_true", help="replay a captured hipGraph instead of enqueuing the launches "
                     "eagerly (eager + side-stream weight gradients is the faster, default mode)")
     ap.add_argument("--no-graph", action="store_true", help=argparse.SUPPRESS)  # old spelling of the default
-    ap.add_argument("--model", default="krn", choices=["krn", "spn", "dann", "preproc"], help="krn: the headline benchmark (BASELINE configs[1]); "
+    ap.add_argument("--model", default="krn", choices=["krn", "spn", "dann", "preproc", "decoder"], help="krn: the headline benchmark (BASELINE configs[1]); "
                     "spn: Spacecraft Pose Network train step, 227x227, bs=32, 5000 classes (configs[5] flavour); "
                     "dann: RevGrad domain-adversarial step, source + target batch (configs[3] flavour; --batch 16 is the README recipe)")
     ap.add_argument("--styleaug", action="store_true", help="BASELINE configs[4] flavour: restyle the batch with the Ghiasi "
@@ -244,6 +210,8 @@ def main():
         return bench_dann(args)
     if args.model == "preproc":
         return bench_preproc(args)
+    if args.model == "decoder":
+        return bench_decoder(args)
     from speedplusbaseline_amd.engine import KrnEngine
     from speedplusbaseline_amd.step import FusedTrainStep
     from oracle import krn_oracle as O  # checker / cpu_baseline leg only
@@ -418,7 +386,7 @@ def main():
 
     # ---- style augmentation: the decoder is the matrix-core-bound kernel family of this workload (15.43 GFLOP per
     # image, 0.74 TFLOP per restyled batch); its achieved rate, timed alone with HIP events on the launch stream
-    if rank == 0 and aug is not None:
+    if rank == 0 and aug is not None and not args.bare:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         for _ in range(3):
             aug(x)
@@ -471,9 +439,8 @@ def main():
 
     others = None
     if rank == 0 and world == 1 and not args.no_others and aug is None:
-        del step
         try:
-            others = bench_others(dev)
+            others = bench_others()
         except Exception as e:      # never lose the headline line to a side measurement
             others = {"error": "%s: %s" % (type(e).__name__, e)}
     if rank == 0:

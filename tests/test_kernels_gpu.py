@@ -329,7 +329,7 @@ def test_pw_gemm_row_slab_input_gradient(device, M, K, N):
                                               (12, 28, 192, 1, L.ACT_RELU6), (7, 28, 64, 2, L.ACT_RELU6), (5, 7, 320, 1, L.ACT_RELU),
                                               (3, 9, 40, 1, L.ACT_RELU), (2, 27, 24, 2, L.ACT_RELU6),
                                               # the large maps (bf16: LDS-tile kernels of dwconv_tile.hip): full and ragged 16 x 8 tiles, half channel chunks
-                                              (2, 56, 144, 1, L.ACT_RELU6), (2, 112, 32, 1, L.ACT_RELU6), (1, 112, 96, 2, L.ACT_RELU6),
+                                              (2, 56, 144, 1, L.ACT_RELU6), (1, 112, 96, 2, L.ACT_RELU6),
                                               (3, 56, 40, 2, L.ACT_RELU6), (1, 60, 24, 1, L.ACT_RELU), (2, 35, 16, 2, L.ACT_NONE)])
 def test_dwconv(device, dw_variant, dt, B, H, C, stride, act):
     torch.manual_seed(B * H + C)
