@@ -308,8 +308,16 @@ int spb_optim_step(const spb_optim_args_t* a, spb_stream_t stream);
 #define SPB_AMP_BC1 6
 #define SPB_AMP_BC2 7
 #define SPB_AMP_SKIP 8
+#define SPB_AMP_TICKET 9   /* spb_amp_decide: workgroup ticket (an unsigned integer in the float slot; zero between launches) */
+#define SPB_AMP_SEGS 8
+typedef struct spb_amp_segs { const void* ptr[SPB_AMP_SEGS]; long long n[SPB_AMP_SEGS]; int is16[SPB_AMP_SEGS]; int nseg; } spb_amp_segs_t;
 int spb_amp_check(const float* grads, long long n, float* state, spb_stream_t stream);
+int spb_amp_check16(const void* x, long long n, float* state, spb_stream_t stream);   /* the same on a 16-bit tensor (the library's storage format); n % 8 == 0 */
 int spb_amp_step(float* state, float lr, float beta1, float beta2, float growth, float backoff, int interval, spb_stream_t stream);
+/* spb_amp_check / spb_amp_check16 over up to SPB_AMP_SEGS segments (f32: n % 4 == 0; 16-bit: n % 8 == 0; 16-byte aligned) and spb_amp_step
+ * in ONE launch: the last workgroup to finish takes the decision */
+int spb_amp_decide(const spb_amp_segs_t* segs, float* state, float lr, float beta1, float beta2, float growth, float backoff, int interval,
+                   spb_stream_t stream);
 /* Weight gradient of a fully connected layer (spb_fc_wgrad's operands: GT [N][MP], XT [K][MP], batch M <= 64) fused with that
  * layer's share of the optimizer step: opt->params / m / v / shadow_bf16 point at the layer's [N][K] weight (opt->n == N*K),
  * opt->grads is NULL or receives the raw gradient.  Same arithmetic per element as spb_fc_wgrad followed by spb_optim_step;

@@ -48,6 +48,13 @@ class PwBwdArgs(C.Structure):
                 ("oR", i32), ("part", vp), ("part_cap", i64), ("job_out", vp)]
 
 
+AMP_SEGS = 8
+
+
+class AmpSegs(C.Structure):
+    _fields_ = [("ptr", vp * AMP_SEGS), ("n", i64 * AMP_SEGS), ("is16", i32 * AMP_SEGS), ("nseg", i32)]
+
+
 class GconvArgs(C.Structure):
     _fields_ = [("X", vp), ("W", vp), ("bias", vp), ("coef", vp), ("Y", vp), ("stats", vp), ("B", i32), ("Hin", i32),
                 ("Win", i32), ("Cin", i32), ("Cout", i32), ("KH", i32), ("stride", i32), ("upsample", i32), ("relu", i32),
@@ -207,6 +214,8 @@ SYMBOLS = {
     "spb_debug_set_softce_split": (i32, [i32]),
     "spb_softce_scaled": (i32, [i32, vp, vp, vp, vp, i32, i32, i32, f32, vp, vp]),
     "spb_amp_check": (i32, [vp, i64, vp, vp]),
+    "spb_amp_check16": (i32, [vp, i64, vp, vp]),
+    "spb_amp_decide": (i32, [vp, vp, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, i32, vp]),
     "spb_amp_step": (i32, [vp, f32, f32, f32, f32, f32, i32, vp]),
     "spb_softce_rows": (i32, [i32, vp, vp, vp, i32, i32, vp]),
     "spb_colsum": (i32, [i32, vp, vp, i64, i32, vp]),

@@ -724,6 +724,94 @@ extern "C" int spb_amp_check(const float* grads, long long n, float* state, spb_
   SPB_CHECK_LAUNCH();
   return 0;
 }
+// the same check on a 16-bit tensor (n % 8 == 0, 16-byte aligned).  A fully connected layer's weight gradient dW = g^T x (f32 accumulation
+// of at most 64 products of 16-bit values: no overflow of its own) is finite exactly when its operands are, so SpnOptimizer checks the six
+// [F][MP] gradient operands (a few hundred KB) instead of the 600 MB of f32 weight gradients they produce
+namespace {
+__global__ __launch_bounds__(256) void amp_check16_kernel(const bf16_t* __restrict__ x, long long n8, float* state) {
+  bool bad = false;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long long)gridDim.x * 256) {
+    float v[8];
+    ld8<bf16_t>(x + i * 8, v);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) bad |= !(fabsf(v[j]) <= 3.4028234e38f);
+  }
+  if (bad) state[SPB_AMP_FOUND_INF] = 1.f;
+}
+}  // namespace
+extern "C" int spb_amp_check16(const void* x, long long n, float* state, spb_stream_t stream) {
+  if (!x || !state || n <= 0 || (n & 7)) return SPB_E_ARG;
+  const long long n8 = n >> 3;
+  const int nblk = (int)((n8 + 255) / 256 > 1024 ? 1024 : (n8 + 255) / 256);
+  hipLaunchKernelGGL(amp_check16_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const bf16_t*>(x), n8, state);
+  SPB_CHECK_LAUNCH();
+  return 0;
+}
+// One launch for the whole decision: up to SPB_AMP_SEGS segments (f32 or 16-bit) are checked, and the LAST workgroup to finish (a ticket in
+// state[SPB_AMP_TICKET]) runs spb_amp_step's arithmetic -- nine launches (check x 7, step, ...) on the optimizer's critical path become one.
+namespace {
+__global__ __launch_bounds__(256) void amp_decide_kernel(const spb_amp_segs_t sg, float* state, float lr, float beta1, float beta2, float growth,
+                                                         float backoff, int interval) {
+  bool bad = false;
+  for (int s = 0; s < sg.nseg; ++s) {
+    const long long nv = sg.n[s] >> (sg.is16[s] ? 3 : 2);
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nv; i += (long long)gridDim.x * 256) {
+      if (sg.is16[s]) {
+        float v[8];
+        ld8<bf16_t>(reinterpret_cast<const bf16_t*>(sg.ptr[s]) + i * 8, v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) bad |= !(fabsf(v[j]) <= 3.4028234e38f);
+      } else {
+        const float4 v = reinterpret_cast<const float4*>(sg.ptr[s])[i];
+        bad |= !(fabsf(v.x) <= 3.4028234e38f) | !(fabsf(v.y) <= 3.4028234e38f) | !(fabsf(v.z) <= 3.4028234e38f) | !(fabsf(v.w) <= 3.4028234e38f);
+      }
+    }
+  }
+  const int any_bad = __syncthreads_or(bad ? 1 : 0);      // one lane publishes the workgroup's finding, then takes the ticket (its own release covers it)
+  if (threadIdx.x == 0) {
+    if (any_bad) __hip_atomic_store(state + SPB_AMP_FOUND_INF, 1.f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    bool last;
+    const unsigned prev = atomicAdd(reinterpret_cast<unsigned*>(state + SPB_AMP_TICKET), 1u);
+    last = prev == gridDim.x - 1;
+    if (last) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      *reinterpret_cast<unsigned*>(state + SPB_AMP_TICKET) = 0u;
+      float* st = state;
+      const bool found = __hip_atomic_load(st + SPB_AMP_FOUND_INF, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0.f;
+      st[SPB_AMP_INV_SCALE] = 1.f / st[SPB_AMP_SCALE];
+      st[SPB_AMP_SKIP] = found ? 1.f : 0.f;
+      st[SPB_AMP_LR] = lr;
+      if (!found) {
+        const float t = st[SPB_AMP_STEPS] + 1.f;
+        st[SPB_AMP_STEPS] = t;
+        st[SPB_AMP_BC1] = beta1 > 0.f ? 1.f - powf(beta1, t) : 1.f;
+        st[SPB_AMP_BC2] = beta2 > 0.f ? 1.f - powf(beta2, t) : 1.f;
+      }
+      if (found) { st[SPB_AMP_SCALE] *= backoff; st[SPB_AMP_TRACKER] = 0.f; }
+      else {
+        const float k = st[SPB_AMP_TRACKER] + 1.f;
+        if (k >= (float)interval) { st[SPB_AMP_SCALE] *= growth; st[SPB_AMP_TRACKER] = 0.f; } else st[SPB_AMP_TRACKER] = k;
+      }
+      st[SPB_AMP_FOUND_INF] = 0.f;
+    }
+  }
+}
+}  // namespace
+extern "C" int spb_amp_decide(const spb_amp_segs_t* segs, float* state, float lr, float beta1, float beta2, float growth, float backoff,
+                              int interval, spb_stream_t stream) {
+  if (!segs || !state || interval < 1 || segs->nseg < 1 || segs->nseg > SPB_AMP_SEGS) return SPB_E_ARG;
+  long long work = 0;
+  for (int s = 0; s < segs->nseg; ++s) {
+    if (!segs->ptr[s] || segs->n[s] <= 0 || (segs->n[s] & (segs->is16[s] ? 7 : 3))) return SPB_E_ARG;
+    work += segs->n[s] >> (segs->is16[s] ? 3 : 2);
+  }
+  const int nblk = (int)((work + 1023) / 1024 > 512 ? 512 : ((work + 1023) / 1024 < 1 ? 1 : (work + 1023) / 1024));
+  hipLaunchKernelGGL(amp_decide_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, *segs, state, lr, beta1, beta2, growth, backoff, interval);
+  SPB_CHECK_LAUNCH();
+  return 0;
+}
 extern "C" int spb_amp_step(float* state, float lr, float beta1, float beta2, float growth, float backoff, int interval, spb_stream_t stream) {
   if (!state || interval < 1) return SPB_E_ARG;
   hipLaunchKernelGGL(amp_step_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, state, lr, beta1, beta2, growth, backoff, interval);

@@ -631,6 +631,25 @@ class SpacecraftPoseNet(nn.Module):
             self._early_on_comm = False
         self._join_side()
 
+    def fp16_check_operands(self):
+        """the 16-bit [F][MP] gradient operands of the six fully connected weight gradients of the backward pass just run (fast path), or
+        None when that pass took the generic path: what SpnOptimizer's inf / nan check reads instead of the f32 gradients they produce"""
+        sv = self._saved
+        if not sv or not sv.get("fast") or not getattr(self, "_bwd_fast", False):
+            return None
+        out = [self._ws.get("gT" + n) for n in ("fc6", "fc7", "fc8", "fc9", "fc10", "fc11")]
+        return None if any(t is None for t in out) else out
+
+    def update_heads_on_side_stream(self, fn):
+        """runs fn() (the heads' share of the optimizer step) on the update stream, ordered after everything enqueued so far; the next
+        forward waits for it before fc6 (join_updates), state_dict() / flat_parameters() / invalidate() too"""
+        if getattr(self, "_upd", None) is None:
+            self._upd = _low_priority_stream(self._gflat.device)
+        self._upd.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self._upd):
+            fn()
+        self._early_on_upd = True
+
     def join_updates(self):
         """The heads' parameter update started by loss_and_grads(optimizer=...) may still be in flight on its own stream after
         optimizer.step() returned: the next forward only needs the convolution parameters until pool5, so that stretch of
@@ -725,6 +744,7 @@ class SpacecraftPoseNet(nn.Module):
                 L.check(lib.spb_softce(dc, _p(r), _p(ywf), _p(drg), _p(out), 2, B, NC, 10.0, st), "spb_softce")
         ident = ops.bnref
         scale = 1.0 / (1.0 - self.keep_prob)
+        self._bwd_fast = bool(fast)
         self._gflat[:self._conv_end].zero_()          # conv bias gradients are accumulated with atomics
         if fast:
             MP = sv["MP"]

@@ -281,16 +281,46 @@ class SpnOptimizer(torch.optim.Optimizer):
         b1, b2 = self._betas(g["kind"], g["momentum"])
         lib = L.lib_f16()
         stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-        L.check(lib.spb_amp_check(C.c_void_p(gflat.data_ptr()), gflat.numel(), C.c_void_p(st.data_ptr()), stream), "spb_amp_check")
-        L.check(lib.spb_amp_step(C.c_void_p(st.data_ptr()), float(g["lr"]), float(b1), float(b2), float(self.amp_growth),
-                                 float(self.amp_backoff), int(self.amp_interval), stream), "spb_amp_step")
+        # inf / nan check.  Fast path (what loss_and_grads ran for this batch): the convolution range of the f32 gradient arena (9 MB) and
+        # the six 16-bit [F][MP] gradient operands of the fully connected weight gradients -- dW = g^T x accumulates at most 64 products
+        # in f32, so it is finite exactly when its operands are (the bias gradients are column sums of the same g) -- instead of reading
+        # the 600 MB those layers' gradients occupy.  Exchanged gradients (world_size > 1) and the generic path: the whole arena.
+        ops16 = mdl.fp16_check_operands() if world_size == 1 else None
+        sg = L.AmpSegs()
+        segs = [(gflat[:mdl._conv_end], 0)] + [(t_, 1) for t_ in ops16] if ops16 else [(gflat, 0)]
+        if gflat.numel() & 3:
+            segs = None
+        if segs is not None and len(segs) <= L.AMP_SEGS:      # one launch: the checks and GradScaler's decision (last workgroup)
+            for i, (t_, h) in enumerate(segs):
+                sg.ptr[i], sg.n[i], sg.is16[i] = t_.data_ptr(), t_.numel(), h
+            sg.nseg = len(segs)
+            L.check(lib.spb_amp_decide(C.byref(sg), C.c_void_p(st.data_ptr()), float(g["lr"]), float(b1), float(b2), float(self.amp_growth),
+                                       float(self.amp_backoff), int(self.amp_interval), stream), "spb_amp_decide")
+        else:
+            L.check(lib.spb_amp_check(C.c_void_p(gflat.data_ptr()), gflat.numel(), C.c_void_p(st.data_ptr()), stream), "spb_amp_check")
+            L.check(lib.spb_amp_step(C.c_void_p(st.data_ptr()), float(g["lr"]), float(b1), float(b2), float(self.amp_growth),
+                                     float(self.amp_backoff), int(self.amp_interval), stream), "spb_amp_step")
         gm = st[L.AMP_INV_SCALE:L.AMP_INV_SCALE + 1]
         if world_size > 1:                            # data-parallel mean on top of the unscale factor
             gm = gm / float(world_size)
-        ops.optim_step(g["kind"], flat, gflat, m=self._m, v=self._v, gmul=gm, lr=g["lr"], beta1=b1, beta2=b2, eps=1e-8,
-                       weight_decay=g["weight_decay"], max_norm=0.0, clip_value=self.clip_value, step=max(self._t, 1),
-                       first_step=False, hyper=st[L.AMP_LR:L.AMP_LR + 3], shadow=mdl._shadow, skip=st[L.AMP_SKIP:L.AMP_SKIP + 1])
+        hyper, skip = st[L.AMP_LR:L.AMP_LR + 3], st[L.AMP_SKIP:L.AMP_SKIP + 1]
+
+        def upd(lo, hi):
+            ops.optim_step(g["kind"], flat[lo:hi], gflat[lo:hi], m=self._m[lo:hi], v=self._v[lo:hi], gmul=gm, lr=g["lr"], beta1=b1, beta2=b2,
+                           eps=1e-8, weight_decay=g["weight_decay"], max_norm=0.0, clip_value=self.clip_value, step=max(self._t, 1),
+                           first_step=False, hyper=hyper, shadow=mdl._shadow[lo:hi], skip=skip)
+        # GradScaler.step() is all or nothing, so nothing can be updated before the check above.  But the 98 % of the arena that belongs to
+        # the two heads (an 0.8 ms HBM-bound pass) need not hold up the launch stream: the next forward reads only convolution parameters
+        # until pool5 and waits for the heads' update before fc6 (join_updates), exactly as in bf16 mode.
+        ce = mdl._conv_end
+        upd(0, ce)
+        if world_size == 1 and self.overlap_heads_update:
+            mdl.update_heads_on_side_stream(lambda: upd(ce, flat.numel()))
+        else:
+            upd(ce, flat.numel())
         mdl.optimizer_updated()
+
+    overlap_heads_update = True
 
     @torch.no_grad()
     def step(self, closure=None, world_size=1, group=None):
