@@ -15,8 +15,13 @@ def family(name):
     m = re.search(r"dw[rp]_bwd_kernel<[^,]*, *\d+, *(true|false), *(true|false)(?:, *(true|false))?", name)
     if m:                                                             # row-unit: <T, ST, WG, EPI, DG>; plane: <T, ST, WG, EPI>
         return "dw_wgrad" if (m.group(3) == "false") else "dw_dgrad"
-    if "dwp_fwd_kernel" in name:
+    if "dwp_fwd_kernel" in name or "dwt_fwd_kernel" in name:
         return "dw_fwd"
+    if "dwt_dgrad" in name:
+        return "dw_dgrad"
+    m = re.search(r"pw_rs_kernel<(\d+)", name)                        # row-slab kernel: PRO leads the template list (1 / 3 forward, 2 input gradient)
+    if m:
+        return "pw_gemm_dgrad" if int(m.group(1)) == 2 else "pw_gemm_fwd"
     for pat, fam in (("pwb_kernel", "pw_bwd_fused"), ("dwr_fwd_kernel", "dw_fwd"), ("dwr_bwd_kernel", "dw_dgrad"),
                      ("stem_fwd_mfma", "stem_fwd"), ("stem_wgrad_mfma", "stem_wgrad"), ("pw_gemm_dma_kernel", "pw_gemm_dma")):
         if pat in name:
