@@ -236,6 +236,9 @@ int spb_bn_running_update(const spb_bnupd_entry_t* table_dev, int n_bn, const fl
 /* dgamma += sum(g*xhat), dbeta += sum(g) */
 int spb_bn_param_grads(const spb_bnupd_entry_t* table_dev, int n_bn, const float* stats, float* grads,
                        spb_stream_t stream);
+/* the same, and every BatchNorm's batch-sum slots ([sums | backward sums], 4 R C floats from sums_off: they must be laid out back to back)
+ * are zeroed afterwards: the last reader of a training step leaves clean accumulators for the next forward */
+int spb_bn_param_grads_zero(const spb_bnupd_entry_t* table_dev, int n_bn, float* stats, float* grads, spb_stream_t stream);
 /* eval mode: fill the stats arena slots with running mean/var so consumers see (mean,var) moments */
 int spb_bn_load_running(const spb_bnupd_entry_t* table_dev, int n_bn, float* stats, const float* buffers,
                         spb_stream_t stream);

@@ -148,6 +148,7 @@ SYMBOLS = {
     "spb_head_bwd": (i32, [i32, C.POINTER(HeadBwdArgs), vp]),
     "spb_bn_running_update": (i32, [vp, i32, vp, vp, vp, f32, vp]),
     "spb_bn_param_grads": (i32, [vp, i32, vp, vp, vp]),
+    "spb_bn_param_grads_zero": (i32, [vp, i32, vp, vp, vp]),
     "spb_bn_load_running": (i32, [vp, i32, vp, vp, vp]),
     "spb_weight_prep": (i32, [i32, vp, i32, i32, vp, vp, vp]),
     "spb_grad_sqnorm": (i32, [vp, i64, vp, vp]),

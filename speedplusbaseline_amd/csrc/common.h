@@ -237,6 +237,26 @@ __device__ __forceinline__ void bn_coef_table(const BNRef& r, int K, int Kp, flo
   }
 }
 
+// scale / shift of every channel into two arrays (LDS), G channels of a thread per pass with all of their loads in flight before
+// anything is stored: `for (c = t; c < C; c += 256) bn_fwd_coef(...)` makes one memory round trip per iteration (four for the 1024
+// channels of the head and of the concat's bn_apply: ~1.5 us each on the launch stream).
+template <int G>
+__device__ __forceinline__ void bn_fwd_table(const BNRef& r, int C, float* sc, float* sh, int t, int nthr) {
+  for (int cb = t; cb < C; cb += nthr * G) {
+    float a[G], b[G];
+#pragma unroll
+    for (int j = 0; j < G; ++j) {
+      const int c = cb + nthr * j;
+      bn_fwd_coef(r, c < C ? c : C - 1, a[j], b[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < G; ++j) {
+      const int c = cb + nthr * j;
+      if (c < C) { sc[c] = a[j]; sh[c] = b[j]; }
+    }
+  }
+}
+
 // Prologue table of the residual join a = bn(A) + bn2(A2) (spb_gemm_args_t pro_mode 3; neither side has an activation):
 // coef[0..Kp) = scale of A, coef[Kp..2Kp) = scale of A2, coef[2Kp..3Kp) = shift + shift2 -- the a*c0 + a2*c1 + c2 form the
 // BatchNorm-backward prologue already runs on.  Same launch shape as bn_coef_table (256 threads, clamped branch-free loads).

@@ -16,10 +16,8 @@ template <typename T>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const spb_bnapply_args_t a) {
   extern __shared__ float cf[];  // [4][C]: scale, shift, res scale, res shift
   const int C = a.C, CG = C >> 3;
-  for (int c = threadIdx.x; c < C; c += 256) {
-    bn_fwd_coef(a.bn, c, cf[c], cf[C + c]);
-    if (a.res) bn_fwd_coef(a.bn_res, c, cf[2 * C + c], cf[3 * C + c]);
-  }
+  bn_fwd_table<4>(a.bn, C, cf, cf + C, threadIdx.x, 256);
+  if (a.res) bn_fwd_table<4>(a.bn_res, C, cf + 2 * C, cf + 3 * C, threadIdx.x, 256);
   __syncthreads();
   const T* Z = reinterpret_cast<const T*>(a.Z);
   const T* R = reinterpret_cast<const T*>(a.res);
@@ -218,6 +216,28 @@ __global__ __launch_bounds__(256) void bn_param_grads_kernel(const spb_bnupd_ent
     grads[e.gamma_off + c] += s2;
     grads[e.beta_off + c] += s1;
   }
+}
+
+// the same, and afterwards the block zeroes the batch-sum slots of its own BatchNorm (sums and backward sums, all replicas: one
+// contiguous run of 4 R C floats from sums_off): nothing reads them after this kernel, and the next training forward then starts on
+// clean accumulators without a memset launch at the head of its launch stream (5.7 us per step)
+__global__ __launch_bounds__(256) void bn_param_grads_zero_kernel(const spb_bnupd_entry_t* tab, float* stats, float* grads) {
+  const spb_bnupd_entry_t e = tab[blockIdx.x];
+  if (e.bsums_off >= 0) {
+    for (int cb = threadIdx.x; cb < e.C; cb += 1024) {
+      float s1[4], s2[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { const int c = cb + 256 * j; bn_replica_sums(stats + e.bsums_off, e.R, e.C, c < e.C ? c : e.C - 1, s1[j], s2[j]); }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int c = cb + 256 * j;
+        if (c < e.C) { grads[e.gamma_off + c] += s2[j]; grads[e.beta_off + c] += s1[j]; }
+      }
+    }
+  }
+  __syncthreads();
+  const long long n = (e.bsums_off >= 0 ? 4LL : 2LL) * e.R * e.C;
+  for (long long i = threadIdx.x; i < n; i += 256) stats[e.sums_off + i] = 0.f;
 }
 
 __global__ __launch_bounds__(256) void bn_load_running_kernel(const spb_bnupd_entry_t* tab, float* stats,
@@ -499,6 +519,13 @@ extern "C" int spb_bn_param_grads(const spb_bnupd_entry_t* tab, int n_bn, const 
                                   spb_stream_t stream) {
   if (!tab || !stats || !grads || n_bn <= 0) return SPB_E_ARG;
   hipLaunchKernelGGL(bn_param_grads_kernel, dim3(n_bn), dim3(256), 0, (hipStream_t)stream, tab, stats, grads);
+  SPB_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int spb_bn_param_grads_zero(const spb_bnupd_entry_t* tab, int n_bn, float* stats, float* grads, spb_stream_t stream) {
+  if (!tab || !stats || !grads || n_bn <= 0) return SPB_E_ARG;
+  hipLaunchKernelGGL(bn_param_grads_zero_kernel, dim3(n_bn), dim3(256), 0, (hipStream_t)stream, tab, stats, grads);
   SPB_CHECK_LAUNCH();
   return 0;
 }

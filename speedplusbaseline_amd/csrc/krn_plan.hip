@@ -111,6 +111,9 @@ struct spb_krn_ctx {
   std::vector<PartSlab> parts;
   int S = 0;
   int last_training = 0;
+  bool one_backward = false;      // the last forward was a fused-train-step forward (training & 16): exactly one backward follows it
+  bool stats_clean = false;       // the batch-sum arena is all zeros (the last backward's bn_param_grads pass zeroed what it read): the next
+                                  // training forward skips its memset
   bool pending_running = false;   // forward ran with training & 16: the running-statistics update rides with the next backward's side stream
   const float* x = nullptr;  // image of the last forward (needed by the stem weight gradient)
   // live per-launch timing (HIP events on the launch stream) with the algorithmic bytes of each launch
@@ -823,7 +826,7 @@ static void layout_ctx(const spb_krn* m, int B, int dtype, spb_krn_ctx* c, size_
     size_t yo = take((size_t)B * m->mats[i].H * m->mats[i].W * m->mats[i].C * es);
     if (c) c->y_off[i] = yo;
   }
-  const int S = 256;  // split-K waves of the head GEMM
+  const int S = 512;  // split-K waves of the head GEMM (128 workgroups; 256: 64 workgroups on 256 CUs)
   size_t dcat = take((size_t)B * 49 * 1280 * es);
   size_t dtap = take((size_t)B * 14 * 14 * 96 * es);
   size_t ddom = take((size_t)B * 49 * 320 * es);
@@ -951,12 +954,16 @@ extern "C" int spb_krn_forward(spb_krn_ctx_t* c, const float* x, const float* ta
   const bool tr = training != 0;
   const spb_bnupd_entry_t* tab = reinterpret_cast<const spb_bnupd_entry_t*>(c->ws + c->table_off);
   if (tr) {
-    hipError_t e = hipMemsetAsync(r.stats(), 0, c->stats_floats * sizeof(float), st);
-    if (e != hipSuccess) return (int)e;
+    if (!c->stats_clean) {
+      hipError_t e = hipMemsetAsync(r.stats(), 0, c->stats_floats * sizeof(float), st);
+      if (e != hipSuccess) return (int)e;
+    }
   } else {
     r.ok(spb_bn_load_running(tab, (int)m->bns.size(), r.stats(), m->Bf, stream));
   }
   c->last_training = training;
+  c->one_backward = defer_run && tr;
+  c->stats_clean = false;
   c->x = x;
   // stem
   r.tic(PC_STEM_FWD, (double)c->B * 3 * kIn * kIn * 4 + r.elems(m->aStem) * r.es(), 54.0 * r.elems(m->aStem));
@@ -1090,6 +1097,11 @@ extern "C" int spb_krn_backward(spb_krn_ctx_t* c, float* grads, float gscale, in
   if (grads) m->G = grads;
   struct Restore { spb_krn* m; float* g; ~Restore() { m->G = g; } } restore{m, bound_G};
   if (!m->G || !c->last_training) return SPB_E_STATE;
+  if (c->stats_clean) return SPB_E_STATE;      // a second backward after a fused-train-step forward: the batch sums it needs were zeroed by the first
+  // Fused train step (forward flag 16: exactly one backward follows): the last reader of the batch sums zeroes them for the next
+  // forward.  Other callers may run several backward passes from one forward state (tests do), and a training == 2 context still owes
+  // its running-statistics update (spb_krn_update_running reads the sums after both DANN passes): those keep the memset in forward.
+  const bool zero_stats = c->one_backward && c->last_training == 1;
   if (!with_pose && !dlogit) return SPB_E_ARG;
   if (dlogit && !m->dann) return SPB_E_ARG;
   hipStream_t st = (hipStream_t)stream;
@@ -1197,7 +1209,8 @@ extern "C" int spb_krn_backward(spb_krn_ctx_t* c, float* grads, float gscale, in
       r.join_side();
       const spb_bnupd_entry_t* tab = reinterpret_cast<const spb_bnupd_entry_t*>(c->ws + c->table_off);
       r.tic(PC_BN_PARAM_GRADS, (double)c->stats_floats);
-      r.ok(spb_bn_param_grads(tab + m->split_bn, (int)m->bns.size() - m->split_bn, r.stats(), m->G, stream));
+      if (zero_stats) r.ok(spb_bn_param_grads_zero(tab + m->split_bn, (int)m->bns.size() - m->split_bn, r.stats(), m->G, stream));
+      else r.ok(spb_bn_param_grads(tab + m->split_bn, (int)m->bns.size() - m->split_bn, r.stats(), m->G, stream));
       r.toc();
       hipEventRecord(c->bucket_ev, st);
       c->bucket_recorded = true;
@@ -1218,9 +1231,14 @@ extern "C" int spb_krn_backward(spb_krn_ctx_t* c, float* grads, float gscale, in
   }
   r.tic(PC_BN_PARAM_GRADS, (double)c->stats_floats * 2);
   // BatchNorm affine gradients: dgamma += sum(g*xhat), dbeta += sum(g)
-  r.ok(spb_bn_param_grads(reinterpret_cast<const spb_bnupd_entry_t*>(c->ws + c->table_off),
-                          c->bucket_on ? m->split_bn : (int)m->bns.size(), r.stats(), m->G, stream));
+  if (zero_stats)
+    r.ok(spb_bn_param_grads_zero(reinterpret_cast<const spb_bnupd_entry_t*>(c->ws + c->table_off),
+                                 c->bucket_on ? m->split_bn : (int)m->bns.size(), r.stats(), m->G, stream));
+  else
+    r.ok(spb_bn_param_grads(reinterpret_cast<const spb_bnupd_entry_t*>(c->ws + c->table_off),
+                            c->bucket_on ? m->split_bn : (int)m->bns.size(), r.stats(), m->G, stream));
   r.toc();
+  c->stats_clean = zero_stats && r.err == 0;    // every BatchNorm's slots were zeroed by the pass(es) above
   hipError_t le = hipGetLastError();
   if (le != hipSuccess && r.err == 0) r.err = (int)le;
   return r.err;

@@ -127,7 +127,10 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const spb_head_args_t a, 
   float* sc = reinterpret_cast<float*>(smem);  // [C]
   float* sh = sc + a.C;
   const int t = threadIdx.x, l = t & 63, w = t >> 6, li = l & 15, lq = l >> 4;
-  for (int c = t; c < a.C; c += 256) bn_fwd_coef(a.pro, c, sc[c], sh[c]);
+  bn_fwd_table<4>(a.pro, a.C, sc, sh, t, 256);
+  // the loss scalars head_reduce_kernel accumulates into: zeroed here (that kernel starts after this one has finished) instead of by a
+  // memset launch between the two (7 us on the launch stream for 12 bytes)
+  if (blockIdx.x == 0 && t < 3 && a.target && a.scalars) a.scalars[t] = 0.f;
   __syncthreads();
   const int KH = a.HW * a.C;
   const int wave = blockIdx.x * 4 + w;
@@ -479,10 +482,6 @@ extern "C" int spb_head_fwd(int dtype, const spb_head_args_t* a, spb_stream_t st
     hipLaunchKernelGGL(head_fwd_kernel<float>, dim3(a->S / 4), dim3(256), lds, (hipStream_t)stream, *a, kchunk);
   else return SPB_E_ARG;
   SPB_CHECK_LAUNCH();
-  if (a->target) {
-    hipError_t me = hipMemsetAsync(a->scalars, 0, 3 * sizeof(float), (hipStream_t)stream);
-    if (me != hipSuccess) return (int)me;
-  }
   hipLaunchKernelGGL(head_reduce_kernel, dim3(spb_ceil_div(a->B * a->J, 64)), dim3(256), 0, (hipStream_t)stream, *a);
   SPB_CHECK_LAUNCH();
   return 0;
