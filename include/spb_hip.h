@@ -432,7 +432,9 @@ typedef struct {
   float in_inv_n, in_eps;
 } spb_gconv_args_t;
 /* KxK conv (K = 3 | 9), nn.ReflectionPad2d(K/2), stride 1|2, optional nearest x2 upsampling of the input
- * (torch.nn.Upsample(scale_factor=2)); Hout = Hin*upsample/stride must be a multiple of 8.  bf16 only. */
+ * (torch.nn.Upsample(scale_factor=2)); Hout = Hin*upsample/stride must be a multiple of 8.  SPB_BF16: the matrix-core kernels.
+ * SPB_F32: the reference-precision mode (the reference runs the decoder in fp32, trainer.py:68-69): X / Y float32 NHWC, W float32
+ * [Cout][KH*KH][Cin], any Cin / Cout / odd KH, Hout*Wout % 64 == 0, the `coef` table only (no in_stats) -- a direct convolution for parity. */
 int spb_gconv(int dtype, const spb_gconv_args_t* args, spb_stream_t stream);
 /* UpsampleConvInRelu's Upsample(2, nearest) + ReflectionPad2d(1) + Conv2d 3x3 (ghiasi.py:46-59) as four 2x2 convolutions on the
  * LOW-RESOLUTION input, one per output phase (upsample == 2, stride == 1, KH == 3): args->W holds the phase weights
@@ -459,6 +461,9 @@ int spb_in_apply(const void* X, const float* coef, const void* res, void* Y, int
                  spb_stream_t stream);
 /* out (fp32 NCHW, 3 channels) = sigmoid(Z*scale + shift), Z NHWC bf16 with channel stride ldc (ghiasi.py:135) */
 int spb_final_sigmoid(const void* Z, const float* coef, float* out, int B, long long hw, int ldc, spb_stream_t stream);
+/* float32 instances of the two for the reference-precision mode */
+int spb_in_apply_f32(const float* X, const float* coef, const float* res, float* Y, int B, long long hw, int C, int relu, spb_stream_t stream);
+int spb_final_sigmoid_f32(const float* Z, const float* coef, float* out, int B, long long hw, int ldc, spb_stream_t stream);
 /* the same two with the coefficients taken from the producer's sums (arguments as spb_in_coef; no coefficient launch in between) */
 int spb_in_apply_stats(const void* X, const float* stats, const float* gamma, const float* beta, int ld, float eps, const void* res,
                        void* Y, int B, long long hw, int C, int relu, spb_stream_t stream);

@@ -198,6 +198,8 @@ SYMBOLS = {
     "spb_in_coef": (i32, [vp, vp, vp, i32, vp, i32, i32, i64, f32, vp]),
     "spb_style_fc": (i32, [vp, vp, vp, vp, i32, i32, vp]),
     "spb_in_apply": (i32, [vp, vp, vp, vp, i32, i64, i32, i32, vp]),
+    "spb_in_apply_f32": (i32, [vp, vp, vp, vp, i32, i64, i32, i32, vp]),
+    "spb_final_sigmoid_f32": (i32, [vp, vp, vp, i32, i64, i32, vp]),
     "spb_final_sigmoid": (i32, [vp, vp, vp, i32, i64, i32, vp]),
     "spb_in_apply_stats": (i32, [vp, vp, vp, vp, i32, f32, vp, vp, i32, i64, i32, i32, vp]),
     "spb_final_sigmoid_stats": (i32, [vp, vp, vp, vp, i32, f32, vp, i32, i64, i32, vp]),

@@ -14,7 +14,7 @@ CSRC = os.path.join(HERE, "csrc")
 ROOT = os.path.dirname(HERE)
 LIB = os.path.join(HERE, "libspb_hip.so")
 OBJDIR = os.path.join(HERE, "csrc", "_obj")
-SOURCES = ["gemm_pw.hip", "gemm_sk.hip", "gemm_os.hip", "gemm_big.hip", "gemm_rs.hip", "pw_bwd_fused.hip", "dwconv_rows.hip", "dwconv_plane.hip", "dwconv_tile.hip", "stem_head.hip", "stem_mfma.hip", "elemwise.hip", "ghiasi.hip", "ghiasi_wide.hip", "spn.hip", "spn_fc.hip", "spn_conv.hip", "preproc.hip", "krn_plan.hip"]
+SOURCES = ["gemm_pw.hip", "gemm_sk.hip", "gemm_os.hip", "gemm_big.hip", "gemm_rs.hip", "pw_bwd_fused.hip", "dwconv_rows.hip", "dwconv_plane.hip", "dwconv_tile.hip", "stem_head.hip", "stem_mfma.hip", "elemwise.hip", "ghiasi.hip", "ghiasi_wide.hip", "ghiasi_f32.hip", "spn.hip", "spn_fc.hip", "spn_conv.hip", "preproc.hip", "krn_plan.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result", "-Wno-unused-value"]
 # IEEE-half twin for the SPN fp16 recipe (csrc/common.h, -DSPB_F16): the SPN kernels, the pointwise GEMMs they use and the
 # elementwise / optimizer kernels.  The KRN-only kernels keep bfloat16 bit tricks of their own and are not part of it.

@@ -1500,8 +1500,19 @@ extern "C" int spb_debug_set_conv9_wgs(int n) { g_conv9_wgs = n < 1 ? 1 : n; ret
 static int g_conv9_band = 2;   // 9x9 32->3: 0 generic tile kernel, 1 band kernel, 2 kernel columns folded into the matrix rows
 extern "C" int spb_debug_set_conv9_band(int on) { g_conv9_band = on; return 0; }
 
+int spb_gconv_f32(const spb_gconv_args_t* a, hipStream_t stream);   // ghiasi_f32.hip
 extern "C" int spb_gconv(int dtype, const spb_gconv_args_t* a, spb_stream_t stream) {
   if (!a || !a->X || !a->W || !a->Y) return SPB_E_ARG;
+  if (dtype == SPB_F32) {      // reference-precision mode (csrc/ghiasi_f32.hip): any Cin / Cout, direct convolution on the vector units
+    if (a->B <= 0 || a->Cin <= 0 || a->Cout <= 0 || (a->KH & 1) == 0 || a->ldc < a->Cout) return SPB_E_SHAPE;
+    if ((a->stride != 1 && a->stride != 2) || (a->upsample != 1 && a->upsample != 2)) return SPB_E_SHAPE;
+    if ((a->Hin * a->upsample) % a->stride || (a->Win * a->upsample) % a->stride) return SPB_E_SHAPE;
+    if (a->KH / 2 >= a->Hin * a->upsample || a->KH / 2 >= a->Win * a->upsample) return SPB_E_SHAPE;
+    const int e = spb_gconv_f32(a, (hipStream_t)stream);
+    if (e) return e;
+    SPB_CHECK_LAUNCH();
+    return 0;
+  }
   if (dtype != SPB_BF16) return SPB_E_UNSUPPORTED;
   if (a->B <= 0 || (a->Cin & 31) || a->Cout <= 0 || a->Cout > 128 || (a->KH != 3 && a->KH != 9)) return SPB_E_SHAPE;
   if ((a->stride != 1 && a->stride != 2) || (a->upsample != 1 && a->upsample != 2)) return SPB_E_SHAPE;

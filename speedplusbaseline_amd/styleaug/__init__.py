@@ -92,8 +92,13 @@ class Ghiasi(nn.Module):
     """Ghiasi(): same constructor, attributes (`layers`, `n_params`) and state_dict as ghiasi.py:107-123; forward(x, styles)
     returns the sigmoid image like ghiasi.py:125-135, computed by the HIP kernels."""
 
-    def __init__(self):
+    def __init__(self, precision="bf16"):
+        """precision "bf16" (default): the matrix-core kernels; "fp32": the reference-precision mode -- the reference runs the decoder outside
+        autocast in float32 (trainer.py:68-69) -- float32 tensors and arithmetic through csrc/ghiasi_f32.hip, ~30x slower, for parity work"""
         super().__init__()
+        if precision not in ("bf16", "fp32"):
+            raise ValueError("precision must be bf16 or fp32, got %r" % (precision,))
+        self.precision = precision
         self.layers = nn.ModuleList([
             _ConvInRelu(3, 32, 9), _ConvInRelu(32, 64, 3), _ConvInRelu(64, 128, 3),
             _ResidualBlock(128), _ResidualBlock(128), _ResidualBlock(128), _ResidualBlock(128), _ResidualBlock(128),
@@ -120,7 +125,9 @@ class Ghiasi(nn.Module):
             for name in ("conv", "conv1", "conv2"):
                 if hasattr(layer, name):
                     c = getattr(layer, name)
-                    if i == 0:
+                    if self.precision == "fp32":    # [Cout][K*K][Cin] float32 for every layer
+                        convs[(i, name)] = (c.weight.detach().float().permute(0, 2, 3, 1).contiguous(), c.bias.detach().float().contiguous())
+                    elif i == 0:
                         convs[(i, name)] = (c.weight.detach().float().contiguous(), c.bias.detach().float().contiguous())
                     else:
                         w = c.weight.detach().permute(0, 2, 3, 1).contiguous().to(torch.bfloat16)
@@ -175,6 +182,8 @@ class Ghiasi(nn.Module):
         st = _stream()
         fc = self._buf("fc", (B, pk["n"]), torch.float32, dev)
         L.check(lib.spb_style_fc(_p(styles), _p(pk["fcw"]), _p(pk["fcb"]), _p(fc), B, pk["n"], st), "spb_style_fc")
+        if self.precision == "fp32":
+            return self._forward_f32(x, fc, pk, st)
         stats = self._buf("stats", (16, B, 128, 2), torch.float32, dev)
         stats.zero_()
         coef = self._buf("coef", (16, B, 128, 2), torch.float32, dev)
@@ -259,6 +268,66 @@ class Ghiasi(nn.Module):
         self._mark("final")
         return out
 
+    def _forward_f32(self, x, fc, pk, st):
+        """ghiasi.py:125-135 in float32: the layer sequence of forward() through the direct-convolution kernel (spb_gconv with SPB_F32), the
+        coefficient table of every instance norm from spb_in_coef, float32 residual stream"""
+        lib = L.lib()
+        B, _, H, W = x.shape
+        dev = x.device
+        f32 = torch.float32
+        stats = self._buf("stats32", (16, B, 128, 2), f32, dev)
+        stats.zero_()
+        coef = self._buf("coef32", (16, B, 128, 2), f32, dev)
+        k = [0]
+
+        def conv(key, X, Hin, Win, Cin, Cout, ks, stride=1, up=1, cf=None, relu=0, ldc=None, name=None):
+            w, bias = pk["convs"][key]
+            Hout, Wout = Hin * up // stride, Win * up // stride
+            ldc = ldc or Cout
+            Y = self._buf(name or ("y32_%d%s" % key), (B, Hout, Wout, ldc), f32, dev)
+            a = L.GconvArgs()
+            a.X = _p(X); a.W = _p(w); a.bias = _p(bias); a.coef = _p(cf) if cf is not None else None; a.Y = _p(Y); a.stats = _p(stats[k[0]])
+            a.B = B; a.Hin = Hin; a.Win = Win; a.Cin = Cin; a.Cout = Cout; a.KH = ks; a.stride = stride; a.upsample = up
+            a.relu = relu; a.ldc = ldc
+            L.check(lib.spb_gconv(L.F32, C.byref(a), st), "spb_gconv (fp32)")
+            return Y, Hout, Wout
+
+        def norm(C_, hw, gk=None, bk=None):
+            """coefficient table of the tensor whose sums were just accumulated"""
+            i = k[0]; k[0] += 1
+            ga = fc[:, pk["off"][gk]:] if gk else None
+            be = fc[:, pk["off"][bk]:] if bk else None
+            L.check(lib.spb_in_coef(_p(stats[i]), _p(ga), _p(be), pk["n"], _p(coef[i]), B, C_, hw, IN_EPS, st), "spb_in_coef")
+            return coef[i]
+
+        x_nhwc = x.permute(0, 2, 3, 1).contiguous()
+        z0, _, _ = conv((0, "conv"), x_nhwc, H, W, 3, 32, 9)
+        c0 = norm(32, H * W)
+        z1, H1, W1 = conv((1, "conv"), z0, H, W, 32, 64, 3, stride=2, cf=c0, relu=1)
+        c1 = norm(64, H1 * W1)
+        z2, H2, W2 = conv((2, "conv"), z1, H1, W1, 64, 128, 3, stride=2, cf=c1, relu=1)
+        c2 = norm(128, H2 * W2)
+        hw2 = H2 * W2
+        r = self._buf("r32_0", (B, H2, W2, 128), f32, dev)
+        L.check(lib.spb_in_apply_f32(_p(z2), _p(c2), None, _p(r), B, hw2, 128, 1, st), "spb_in_apply_f32")
+        for i in range(3, 8):
+            za, _, _ = conv((i, "conv1"), r, H2, W2, 128, 128, 3, name="za32")
+            ca = norm(128, hw2, (i, "fc_gamma1"), (i, "fc_beta1"))
+            zb, _, _ = conv((i, "conv2"), za, H2, W2, 128, 128, 3, cf=ca, relu=1, name="zb32")
+            cb = norm(128, hw2, (i, "fc_gamma2"), (i, "fc_beta2"))
+            rn = self._buf("r32_1" if r is self._ws.get("r32_0") else "r32_0", (B, H2, W2, 128), f32, dev)
+            L.check(lib.spb_in_apply_f32(_p(zb), _p(cb), _p(r), _p(rn), B, hw2, 128, 0, st), "spb_in_apply_f32")
+            r = rn
+        z8, H8, W8 = conv((8, "conv"), r, H2, W2, 128, 64, 3, up=2)
+        c8 = norm(64, H8 * W8, (8, "fc_gamma"), (8, "fc_beta"))
+        z9, H9, W9 = conv((9, "conv"), z8, H8, W8, 64, 32, 3, up=2, cf=c8, relu=1)
+        c9 = norm(32, H9 * W9, (9, "fc_gamma"), (9, "fc_beta"))
+        z10, _, _ = conv((10, "conv"), z9, H9, W9, 32, 3, 9, cf=c9, relu=1, ldc=4)
+        c10 = norm(3, H9 * W9, (10, "fc_gamma"), (10, "fc_beta"))
+        out = torch.empty(B, 3, H, W, dtype=f32, device=dev)
+        L.check(lib.spb_final_sigmoid_f32(_p(z10), _p(c10), _p(out), B, H * W, 4, st), "spb_final_sigmoid_f32")
+        return out
+
 
 class StyleAugmentor(nn.Module):
     """StyleAugmentor(alpha, device) as styleAugmentor.py:12-68.  The reference's checkpoints (transformer weights,
@@ -267,11 +336,11 @@ class StyleAugmentor(nn.Module):
     synthetic benchmarks `StyleAugmentor.synthetic(alpha, device, seed)` builds one with random weights and a synthetic
     SPD covariance."""
 
-    def __init__(self, alpha, device, checkpoint_dir=None, _parts=None):
+    def __init__(self, alpha, device, checkpoint_dir=None, _parts=None, precision="bf16"):
         super().__init__()
         self.alpha = alpha
         self.device = device
-        self.ghiasi = Ghiasi()
+        self.ghiasi = Ghiasi(precision)     # "fp32": the reference's own precision for this module (trainer.py:68-69), ~30x slower
         if _parts is None:
             d = checkpoint_dir or os.path.join(os.path.dirname(__file__), "checkpoints")
             need = [os.path.join(d, f) for f in ("checkpoint_transformer.pth", "checkpoint_embeddings.pth", "embedding_mean_speedplus.npy")]
@@ -295,13 +364,13 @@ class StyleAugmentor(nn.Module):
         self.A = torch.tensor(np.matmul(u, np.diag(s ** 0.5))).float().to(device)   # 100 x 100
 
     @classmethod
-    def synthetic(cls, alpha, device, state_dict, seed=0):
+    def synthetic(cls, alpha, device, state_dict, seed=0, precision="bf16"):
         g = torch.Generator().manual_seed(seed)
         q = torch.randn(100, 100, generator=g, dtype=torch.float64)
         cov = (q @ q.t() / 100.0 + 0.05 * torch.eye(100, dtype=torch.float64)).numpy()
         mean = torch.randn(1, 100, generator=g) * 0.3
         base = torch.randn(100, generator=g) * 0.3
-        return cls(alpha, device, _parts=(state_dict, base, mean, cov))
+        return cls(alpha, device, _parts=(state_dict, base, mean, cov), precision=precision)
 
     def sample_embedding(self, n):
         embedding = torch.randn(n, 100).to(self.device)

@@ -55,13 +55,13 @@ def main():
     if cfg.randomize_texture:
         from speedplusbaseline_amd.styleaug import StyleAugmentor
         try:
-            styleAugmentor = StyleAugmentor(cfg.texture_alpha, device)
+            styleAugmentor = StyleAugmentor(cfg.texture_alpha, device, precision=cfg.styleaug_precision)
         except FileNotFoundError:
             if not getattr(cfg, 'synthetic_batches', 0):
                 raise
             # synthetic run: random decoder weights and a synthetic embedding distribution (no checkpoints offline)
             from speedplusbaseline_amd.styleaug import Ghiasi
-            styleAugmentor = StyleAugmentor.synthetic(cfg.texture_alpha, device, Ghiasi().state_dict())
+            styleAugmentor = StyleAugmentor.synthetic(cfg.texture_alpha, device, Ghiasi().state_dict(), precision=cfg.styleaug_precision)
     optimizer = get_optimizer(cfg, model)
     checkpoint_file = osp.join(cfg.savedir, 'checkpoint.pth.tar')
     if cfg.auto_resume and osp.exists(checkpoint_file):
