@@ -3,7 +3,7 @@
 // build is bf16 on the matrix cores (csrc/ghiasi.hip, ghiasi_wide.hip; mean |d| 3e-3 on a [0,1] image).  Ghiasi(precision="fp32") runs the
 // same layer sequence through the three kernels below instead: direct convolution on the vector units, every tensor float32, the same
 // "raw conv output + per-(image, channel) sums" representation of instance-normalised tensors.  It exists for parity (tests hold it to the
-// float32 oracle at 2e-4), not for speed: ~40 ms per 48 images against 1.3 ms.
+// float32 CPU restatement of ghiasi.py at 1e-4), not for speed: ~40 ms per 48 images against 1.3 ms.
 // C-ABI: spb_gconv(SPB_F32, ...) (same argument struct: X / Y float32 NHWC, W float32 [Cout][KH*KH][Cin], `coef` table only),
 // spb_in_apply_f32, spb_final_sigmoid_f32 (include/spb_hip.h).
 #include "common.h"
