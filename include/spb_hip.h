@@ -196,7 +196,8 @@ typedef struct spb_head_args {
   const void* Wp;      /* [Jp, HW*C] weights permuted to (h,w,c) order in the compute dtype; rows >= J are zero */
   const float* bias;   /* [J] */
   const float* target; /* [B,2,J/2] or NULL */
-  float* partial;      /* [S][B][Jp] split-K partials (workspace) */
+  float* partial;      /* S*B*Jp floats of workspace: the [B][Jp] 64-bit fixed-point accumulator of the split-K sums, then the ticket
+                          word of the last-arriver epilogue -- the workspace must be ZERO before the first call; every call leaves it zero */
   float* pred;         /* [B][J] */
   float* dout;         /* [B][J] = d loss / d pred (unit upstream gradient) */
   float* scalars;      /* [3] = loss, loss_x, loss_y */

@@ -895,6 +895,9 @@ extern "C" int spb_krn_ctx_create(spb_krn_t* m, int batch, void* workspace, spb_
   }
   hipError_t e = hipMemcpy(c->ws + c->table_off, tab.data(), tab.size() * sizeof(spb_bnupd_entry_t), hipMemcpyHostToDevice);
   if (e != hipSuccess) { delete c; return (int)e; }
+  // the head's split-K partial workspace ends in the ticket word of its last-arriver reduction (spb_head_fwd): zero once, every call restores it
+  e = hipMemset(c->ws + c->partial_off, 0, (size_t)c->S * batch * m->Jp * sizeof(float));
+  if (e != hipSuccess) { delete c; return (int)e; }
   // side stream + events are created here, outside any stream capture
   if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess) c->side = nullptr;
   if (hipEventCreateWithFlags(&c->join_ev, hipEventDisableTiming) != hipSuccess) { delete c; return SPB_E_STATE; }

@@ -4,6 +4,13 @@
 //   head  Conv2d(1024,2K,kernel 7) on the 7x7 map, i.e. one fully-connected layer over (h,w,c), followed by the
 //         (x,y) de-interleave and the summed per-keypoint MSE (park2019.py:121,139-162).
 #include "common.h"
+#include <type_traits>
+
+#ifndef SPB_TS_DECL       // register-held phase timestamps (scratch/ubench_head.hip); compiled out in the product build
+#define SPB_TS_DECL
+#define SPB_TSR(i)
+#define SPB_TS_FLUSH
+#endif
 
 namespace {
 
@@ -118,26 +125,60 @@ __global__ __launch_bounds__(192) void stem_wgrad_kernel(const float* __restrict
 }
 
 // ------------------------------------------------------------------------------------------------ head forward
-// out[b,j] = sum_k relu(bn(z))[b,k] * Wp[j,k],  K = HW*C = 50 176.  Skinny GEMM (M = batch, N = 2K keypoints):
-// split K over all waves of the grid, fragments straight from HBM (each operand element is used by one wave),
-// partial [wave][B][Jp] tiles reduced by the loss kernel.
+// out[b,j] = sum_k relu(bn(z))[b,k] * Wp[j,k],  K = HW*C = 50 176.  Skinny GEMM (M = batch, N = 2K keypoints): split K over all waves
+// of the grid, fragments straight from HBM (each operand element is used by one wave).  ONE launch: a wave issues every load of
+// its K slice before the first matrix step (U steps of 32: one memory round trip; the loop with its loads under `if (b < B)` made one per
+// step), the four waves of a workgroup add their tiles in LDS, and the workgroup adds its tile to the [B][Jp] accumulator in FIXED POINT
+// (64-bit integer atomics, 2^-36 resolution: integer addition is associative, so the result does not depend on the order in which the
+// workgroups arrive -- run-to-run identical, unlike float atomics) and takes a ticket; the workgroup that draws the last ticket reads the
+// accumulator, adds the bias and writes predictions, loss scalars and d loss / d pred (park2019.py:142-156).  Round 3 ran this as two
+// launches (19.6 + 8 us and a launch boundary); a last-arriver that re-reads per-workgroup partial tiles instead is bound by what one CU
+// can pull (0.5 MB: 50 us, measured).  `partial` (S*B*Jp floats) holds the accumulator and, behind it, the ticket word: zero before the
+// first call, restored to zero by every call.
+constexpr int HEAD_U = 4;
+constexpr float HEAD_FIX = 68719476736.f;   // 2^36: |partial| < 2^26 keeps the 64-bit sum of 2^16 terms exact
 template <typename T>
 __global__ __launch_bounds__(256) void head_fwd_kernel(const spb_head_args_t a, int kchunk) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* sc = reinterpret_cast<float*>(smem);  // [C]
   float* sh = sc + a.C;
+  float* tile = sh + a.C;                      // [4][64][32] per-wave accumulator tiles
+  __shared__ int last_flag;
+  __shared__ float lred[2][4];
   const int t = threadIdx.x, l = t & 63, w = t >> 6, li = l & 15, lq = l >> 4;
-  bn_fwd_table<4>(a.pro, a.C, sc, sh, t, 256);
-  // the loss scalars head_reduce_kernel accumulates into: zeroed here (that kernel starts after this one has finished) instead of by a
-  // memset launch between the two (7 us on the launch stream for 12 bytes)
-  if (blockIdx.x == 0 && t < 3 && a.target && a.scalars) a.scalars[t] = 0.f;
-  __syncthreads();
+  SPB_TS_DECL;
+  SPB_TSR(0);
   const int KH = a.HW * a.C;
   const int wave = blockIdx.x * 4 + w;
   const int kbeg = wave * kchunk, kend = min(KH, kbeg + kchunk);
   const T* Z = reinterpret_cast<const T*>(a.Z);
   const T* Wp = reinterpret_cast<const T*>(a.Wp);
   const int NJ = a.Jp / 16;  // <= 2
+  unsigned long long* acc64 = reinterpret_cast<unsigned long long*>(a.partial);              // [B][Jp]
+  unsigned* ticket = reinterpret_cast<unsigned*>(acc64 + (size_t)a.B * a.Jp);
+  // every load of a K slice first, on clamped indices (HEAD_U steps of 32)
+  uint4 wr[HEAD_U][2], zr[HEAD_U][4];
+  auto fetch = [&](int bb, int k0) {
+    if constexpr (sizeof(T) == 2) {
+#pragma unroll
+      for (int u = 0; u < HEAD_U; ++u) {
+        const int kk = k0 + u * 32 + lq * 8;
+        const int kc = kk < KH ? kk : KH - 8;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) wr[u][j] = *reinterpret_cast<const uint4*>(Wp + (size_t)((j < NJ ? j : 0) * 16 + li) * KH + kc);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int b = bb + i * 16 + li;
+          zr[u][i] = *reinterpret_cast<const uint4*>(Z + (size_t)(b < a.B ? b : a.B - 1) * KH + kc);
+        }
+      }
+    }
+  };
+  // the first slice is requested BEFORE the coefficient table: loads return in order, so the table's own loads ride the same round trip
+  fetch(0, kbeg);
+  bn_fwd_table<4>(a.pro, a.C, sc, sh, t, 256);
+  __syncthreads();
+  SPB_TSR(1);
   for (int bb = 0; bb < a.B; bb += 64) {
     f32x4_t acc[4][2];
 #pragma unroll
@@ -145,36 +186,34 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const spb_head_args_t a, 
 #pragma unroll
       for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
     if constexpr (sizeof(T) == 2) {
-      for (int k = kbeg; k < kend; k += 32) {
-        const int kk = k + lq * 8;
-        const int c0 = kk % a.C;
-        bf16x8_t bf[2];
+      for (int k0 = kbeg; k0 < kend; k0 += 32 * HEAD_U) {
+        if (bb != 0 || k0 != kbeg) fetch(bb, k0);
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          uint4 u = make_uint4(0, 0, 0, 0);
-          if (j < NJ) u = *reinterpret_cast<const uint4*>(Wp + (size_t)(j * 16 + li) * KH + kk);
-          bf[j] = __builtin_bit_cast(bf16x8_t, u);
-        }
+        for (int u = 0; u < HEAD_U; ++u) {
+          const int kk = k0 + u * 32 + lq * 8;
+          const bool kok = kk < kend;             // beyond the slice: zero weights (the activations stay finite)
+          const int c0 = (kk < KH ? kk : KH - 8) % a.C;
+          bf16x8_t bf[2];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int b = bb + i * 16 + li;
-          float v[8];
-          if (b < a.B) {
-            ld8<T>(Z + (size_t)b * KH + kk, v);
+          for (int j = 0; j < 2; ++j) bf[j] = __builtin_bit_cast(bf16x8_t, (kok && j < NJ) ? wr[u][j] : make_uint4(0, 0, 0, 0));
+          const float4 s0 = *reinterpret_cast<const float4*>(sc + c0), s1 = *reinterpret_cast<const float4*>(sc + c0 + 4);
+          const float4 h0 = *reinterpret_cast<const float4*>(sh + c0), h1 = *reinterpret_cast<const float4*>(sh + c0 + 4);
+          const float scv[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+          const float shv[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = act_fwd(v[e] * sc[c0 + e] + sh[c0 + e], a.pro.act, a.pro.slope);
-          } else {
+          for (int i = 0; i < 4; ++i) {
+            if (bb + i * 16 >= a.B) continue;     // (uniform) tile rows beyond the batch
+            Raw8<T> zq; zq.u = zr[u][i];
+            float v[8];
+            cvt8(zq, v);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = 0.f;
+            for (int e = 0; e < 8; ++e) v[e] = act_fwd(v[e] * scv[e] + shv[e], a.pro.act, a.pro.slope);
+            uint4 q;
+            q.x = pack_bf16x2(v[0], v[1]); q.y = pack_bf16x2(v[2], v[3]); q.z = pack_bf16x2(v[4], v[5]); q.w = pack_bf16x2(v[6], v[7]);
+            const bf16x8_t af = __builtin_bit_cast(bf16x8_t, q);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j] = SPB_MFMA16(af, bf[j], acc[i][j]);
           }
-          uint4 u;
-          u.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
-          u.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
-          u.z = (uint32_t)f2bf(v[4]) | ((uint32_t)f2bf(v[5]) << 16);
-          u.w = (uint32_t)f2bf(v[6]) | ((uint32_t)f2bf(v[7]) << 16);
-          const bf16x8_t af = __builtin_bit_cast(bf16x8_t, u);
-#pragma unroll
-          for (int j = 0; j < 2; ++j) acc[i][j] = SPB_MFMA16(af, bf[j], acc[i][j]);
         }
       }
     } else {
@@ -207,58 +246,72 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const spb_head_args_t a, 
         }
       }
     }
+    SPB_TSR(2);
+    // the four waves' tiles -> one partial tile of the workgroup (C layout: col = lane & 15, rows (lane >> 4) * 4 + r)
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int b = bb + i * 16 + lq * 4 + r, col = j * 16 + li;
-          if (b < a.B && col < a.Jp) a.partial[((size_t)wave * a.B + b) * a.Jp + col] = acc[i][j][r];
-        }
+        for (int r = 0; r < 4; ++r) tile[(w * 64 + i * 16 + lq * 4 + r) * 32 + j * 16 + li] = acc[i][j][r];
+    __syncthreads();
+    for (int i = t; i < 64 * 32; i += 256) {
+      const int b = bb + (i >> 5), col = i & 31;
+      if (b < a.B && col < a.J) {
+        const float v = (tile[i] + tile[2048 + i]) + (tile[4096 + i] + tile[6144 + i]);
+        atomicAdd(acc64 + (size_t)b * a.Jp + col, (unsigned long long)__float2ll_rn(v * HEAD_FIX));
+      }
+    }
+    __syncthreads();
   }
-}
-
-// pred = sum of split-K partials + bias; loss = sum_k mean_b (x-tx)^2 + (y-ty)^2 (park2019.py:142-156).
-// 64 outputs per workgroup, 4 lane groups each summing a quarter of the partials with independent (pipelined) loads.
-__global__ __launch_bounds__(256) void head_reduce_kernel(const spb_head_args_t a) {
-  __shared__ float red[4][64];
-  __shared__ float rl[2][64];
-  const int t = threadIdx.x, i = t & 63, q = t >> 6;
-  const int idx = blockIdx.x * 64 + i;
-  const bool ok = idx < a.B * a.J;
-  const int b = ok ? idx / a.J : 0, j = ok ? idx % a.J : 0;
-  const int per = a.S / 4;
-  const size_t stride = (size_t)a.B * a.Jp;
-  const float* p = a.partial + ((size_t)q * per * a.B + b) * a.Jp + j;
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  int w = 0;
-  for (; w + 4 <= per; w += 4) {
-    s0 += p[(size_t)w * stride]; s1 += p[(size_t)(w + 1) * stride];
-    s2 += p[(size_t)(w + 2) * stride]; s3 += p[(size_t)(w + 3) * stride];
-  }
-  for (; w < per; ++w) s0 += p[(size_t)w * stride];
-  red[q][i] = (s0 + s1) + (s2 + s3);
+  // ---- ticket: the workgroup that arrives last finishes the job
+  SPB_TSR(3);
+  __threadfence();
   __syncthreads();
-  if (q == 0) {
-    float lx = 0.f, ly = 0.f;
-    if (ok) {
-      const float s = red[0][i] + red[1][i] + red[2][i] + red[3][i] + (a.bias ? a.bias[j] : 0.f);
+  SPB_TSR(4);
+  if (t == 0) last_flag = atomicAdd(ticket, 1u) == gridDim.x - 1 ? 1 : 0;
+  __syncthreads();
+  SPB_TSR(5);
+  if (!last_flag) { SPB_TS_FLUSH; return; }
+  __threadfence();
+  float lx = 0.f, ly = 0.f;
+  const int nout = a.B * a.J;
+  for (int i0 = t; i0 < nout; i0 += 256 * 8) {
+    unsigned long long fx[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {          // all loads in flight (agent scope: the sums were made at the memory side by other XCDs' atomics)
+      const int idx = i0 + 256 * u, ic = idx < nout ? idx : nout - 1;
+      fx[u] = __hip_atomic_load(acc64 + (size_t)(ic / a.J) * a.Jp + ic % a.J, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int idx = i0 + 256 * u;
+      if (idx >= nout) continue;
+      const int b = idx / a.J, j = idx % a.J;
+      __hip_atomic_store(acc64 + (size_t)b * a.Jp + j, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // left zero for the next call
+      const float s = (float)((double)(long long)fx[u] * (1.0 / (double)HEAD_FIX)) + (a.bias ? a.bias[j] : 0.f);
       a.pred[idx] = s;
       if (a.target) {
         const int nK = a.J / 2;
         const float d = s - a.target[(size_t)b * a.J + (j & 1) * nK + (j >> 1)];
-        if (j & 1) ly = d * d; else lx = d * d;
+        if (j & 1) ly += d * d; else lx += d * d;
         a.dout[idx] = 2.f * d / (float)a.B;
       }
     }
-    lx = wave_sum(lx); ly = wave_sum(ly);
-    if (i == 0 && a.target && a.scalars) {
-      lx /= (float)a.B; ly /= (float)a.B;
-      atomicAdd(a.scalars + 0, lx + ly); atomicAdd(a.scalars + 1, lx); atomicAdd(a.scalars + 2, ly);
-    }
   }
-  (void)rl;
+  lx = wave_sum(lx); ly = wave_sum(ly);
+  if (l == 0) { lred[0][w] = lx; lred[1][w] = ly; }
+  lds_barrier();
+  if (t == 0) {
+    if (a.target && a.scalars) {
+      const float tx = ((lred[0][0] + lred[0][1]) + (lred[0][2] + lred[0][3])) / (float)a.B;
+      const float ty = ((lred[1][0] + lred[1][1]) + (lred[1][2] + lred[1][3])) / (float)a.B;
+      a.scalars[0] = tx + ty; a.scalars[1] = tx; a.scalars[2] = ty;
+    }
+    __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  SPB_TSR(6);
+  SPB_TS_FLUSH;
 }
 
 // ------------------------------------------------------------------------------------------------ head backward
@@ -271,16 +324,26 @@ template <typename T>
 __global__ __launch_bounds__(256) void head_bwd_kernel(const spb_head_bwd_args_t a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int KV = HBK / 8, NSUB = 256 / KV, WLD = 4;   // k vectors, batch subsets, weight vectors per thread (J * KV <= 1024: J <= 32)
-  float* ds = reinterpret_cast<float*>(smem);     // [B][J] upstream gradient * gscale
-  float* wl = ds + ((a.B * a.J + 3) & ~3);        // [J][HBK] weight slab
-  float* red = wl + (size_t)a.J * HBK;            // [2][HBK]
+  float* ds = reinterpret_cast<float*>(smem);     // [J][NSUB][MB] upstream gradient * gscale of the current 64 images, slot-major (below)
+  float* wl = ds + (size_t)a.J * 64;              // [J][HBK] weight slab
+  float* red = wl + (size_t)a.J * HBK;            // [4 waves][2][HBK]
+  float* tab = red + 8 * HBK;                     // [4][HBK] scale, shift, mean, inverse std of the workgroup's entries
+  static_assert(HBK == 256, "one table entry per thread");
   const int t = threadIdx.x;
+  SPB_TS_DECL;
+  SPB_TSR(0);
   const int KH = a.HW * a.C;
   const int kbase = blockIdx.x * HBK;
   const T* Z = reinterpret_cast<const T*>(a.Z);
   const T* Wp = reinterpret_cast<const T*>(a.Wp);
-  // weight slab: every load of this thread first (clamped indices), then the LDS stores
-  Raw8<T> wr[WLD];
+  // weight slab and this thread's z vectors: every load first (clamped indices), then the LDS stores.  The z loads used to sit in the batch
+  // loop below, one memory round trip per image of the thread's subset (six at bs=48: 23.6 us for 15 MB).
+  constexpr int MB = 8;                     // images per thread and pass: NSUB * MB = 64
+  const int k8 = t % KV, sub = t / KV;
+  const int k = kbase + k8 * 8;
+  const bool kok = k < KH;
+  const int kc = kok ? k : KH - 8;
+  Raw8<T> wr[WLD], zq[MB];
 #pragma unroll
   for (int u = 0; u < WLD; ++u) {
     const int i = t + 256 * u;
@@ -289,17 +352,20 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const spb_head_bwd_args_t
     const int kk = kbase + v8 * 8;
     wr[u] = ldraw<T>(Wp + (size_t)j * KH + (kk < KH ? kk : KH - 8));
   }
-  for (int i = t; i < a.B * a.J; i += 256) ds[i] = a.dout[i] * a.gscale;
-  const int k8 = t % KV, sub = t / KV;
-  const int k = kbase + k8 * 8;
-  const bool kok = k < KH;
-  const int c0 = (kok ? k : 0) % a.C;
-  float sc[8], sh[8], mu[8], is[8];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    bn_moments(a.pro, c0 + j, mu[j], is[j]);
-    sc[j] = a.pro.gamma[c0 + j] * is[j];
-    sh[j] = a.pro.beta[c0 + j] - mu[j] * sc[j];
+  for (int i = 0; i < MB; ++i) {
+    const int b = sub + i * NSUB;
+    zq[i] = ldraw<T>(Z + (size_t)(b < a.B ? b : a.B - 1) * KH + kc);
+  }
+  // BatchNorm coefficients of this workgroup's HBK consecutive (position, channel) entries: ONE channel per thread, so the moment loads of
+  // all of them are one memory round trip (eight bn_moments calls per thread, each with its uniform branches, were eight: 5 us of prologue)
+  {
+    const int kk = kbase + t < KH ? kbase + t : KH - 1;
+    const int c = kk % a.C;
+    float m, v;
+    bn_moments(a.pro, c, m, v);
+    const float g = a.pro.gamma[c] * v;
+    tab[t] = g; tab[HBK + t] = a.pro.beta[c] - m * g; tab[2 * HBK + t] = m; tab[3 * HBK + t] = v;
   }
 #pragma unroll
   for (int u = 0; u < WLD; ++u) {
@@ -313,49 +379,124 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const spb_head_bwd_args_t
       for (int e = 0; e < 8; ++e) wl[j * HBK + v8 * 8 + e] = ok ? v[e] : 0.f;
     }
   }
-  for (int i = t; i < 2 * HBK; i += 256) red[i] = 0.f;
-  __syncthreads();
   T* G = reinterpret_cast<T*>(a.G);
   float s1[8], s2[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
-  if (kok) {
-    for (int b = sub; b < a.B; b += NSUB) {
-      float da[8];
+  // dA[b][k] = sum_j d[b][j] * w[j][k] for this thread's 8 k and its MB images (b = b0 + sub + i * NSUB): j outermost, so the two weight
+  // vectors and the MB upstream gradients of a j are four 16-byte LDS reads feeding 8 * MB independent FMAs (the image-major loop read
+  // three LDS values per 8 FMAs behind one another with one wave per SIMD to hide it: 12.8 of the kernel's 18 us).
+  for (int b0 = 0; b0 < a.B; b0 += NSUB * MB) {
+    if (b0 > 0) {          // batches beyond 64 images: the next images' z vectors, landed by the barrier below (nothing is pending inside
+      __syncthreads();     // the per-image blocks then, so their stores are not waited for one by one)
 #pragma unroll
-      for (int e = 0; e < 8; ++e) da[e] = 0.f;
-      for (int j = 0; j < a.J; ++j) {
-        const float d = ds[b * a.J + j];
-        const float4 w0 = *reinterpret_cast<const float4*>(wl + j * HBK + k8 * 8);
-        const float4 w1 = *reinterpret_cast<const float4*>(wl + j * HBK + k8 * 8 + 4);
-        da[0] += d * w0.x; da[1] += d * w0.y; da[2] += d * w0.z; da[3] += d * w0.w;
-        da[4] += d * w1.x; da[5] += d * w1.y; da[6] += d * w1.z; da[7] += d * w1.w;
+      for (int i = 0; i < MB; ++i) {
+        const int b = b0 + sub + i * NSUB;
+        zq[i] = ldraw<T>(Z + (size_t)(b < a.B ? b : a.B - 1) * KH + kc);
       }
-      float z[8];
-      ld8<T>(Z + (size_t)b * KH + k, z);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const float u = z[e] * sc[e] + sh[e];
-        da[e] = rnd<T>(da[e] * act_grad(u, a.pro.act, a.pro.slope));
-        s1[e] += da[e];
-        s2[e] += da[e] * ((z[e] - mu[e]) * is[e]);
-      }
-      st8<T>(G + (size_t)b * KH + k, da);
     }
+    {   // upstream gradients of these 64 images, slot-major; all of a thread's loads first (J <= 32: at most 8)
+      float dl[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      atomicAdd(&red[k8 * 8 + e], s1[e]);
-      atomicAdd(&red[HBK + k8 * 8 + e], s2[e]);
+      for (int u = 0; u < 8; ++u) {
+        const int i = t + 256 * u, ic = i < a.J * 64 ? i : a.J * 64 - 1;
+        const int b = b0 + ((ic >> 3) & 7) + (ic & 7) * NSUB;
+        dl[u] = a.dout[(b < a.B ? b : a.B - 1) * a.J + (ic >> 6)];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = t + 256 * u;
+        const int b = b0 + ((i >> 3) & 7) + (i & 7) * NSUB;
+        if (i < a.J * 64) ds[i] = b < a.B ? dl[u] * a.gscale : 0.f;
+      }
+    }
+    __syncthreads();
+    if (b0 == 0) { SPB_TSR(1); }
+    if (kok) {
+      float sc[8], sh[8], mu[8], is[8];
+#pragma unroll
+      for (int e = 0; e < 8; e += 4) {
+        *reinterpret_cast<float4*>(sc + e) = *reinterpret_cast<const float4*>(tab + k8 * 8 + e);
+        *reinterpret_cast<float4*>(sh + e) = *reinterpret_cast<const float4*>(tab + HBK + k8 * 8 + e);
+        *reinterpret_cast<float4*>(mu + e) = *reinterpret_cast<const float4*>(tab + 2 * HBK + k8 * 8 + e);
+        *reinterpret_cast<float4*>(is + e) = *reinterpret_cast<const float4*>(tab + 3 * HBK + k8 * 8 + e);
+      }
+      // straight-line per slot count (a `continue` per slot inside the j loop made eight scalar branches per j and an LDS wait at every one)
+      auto images = [&](auto ns) {
+        constexpr int NS = decltype(ns)::value;
+        float da[NS][8];
+#pragma unroll
+        for (int i = 0; i < NS; ++i)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) da[i][e] = 0.f;
+#pragma unroll 2
+        for (int j = 0; j < a.J; ++j) {
+          const float4 w0 = *reinterpret_cast<const float4*>(wl + j * HBK + k8 * 8);
+          const float4 w1 = *reinterpret_cast<const float4*>(wl + j * HBK + k8 * 8 + 4);
+          const float4 d0 = *reinterpret_cast<const float4*>(ds + (j * NSUB + sub) * MB);
+          const float4 d1 = *reinterpret_cast<const float4*>(ds + (j * NSUB + sub) * MB + 4);
+          const float wv[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+          const float dv[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+#pragma unroll
+          for (int i = 0; i < NS; ++i)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) da[i][e] += dv[i] * wv[e];
+        }
+        if (b0 == 0) { SPB_TSR(4); }
+#pragma unroll
+        for (int i = 0; i < NS; ++i) {
+          const int b = b0 + sub + i * NSUB;
+          const bool live = b < a.B;            // per lane only when the batch is not a multiple of NSUB
+          const float lv = live ? 1.f : 0.f;
+          float z[8];
+          cvt8(zq[i], z);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float u = z[e] * sc[e] + sh[e];
+            da[i][e] = rnd<T>(da[i][e] * (lv * act_grad(u, a.pro.act, a.pro.slope)));
+            s1[e] += da[i][e];
+            s2[e] += da[i][e] * ((z[e] - mu[e]) * is[e]);
+          }
+          if (live) st8<T>(G + (size_t)b * KH + k, da[i]);
+        }
+      };
+      switch (min(MB, (a.B - b0 + NSUB - 1) / NSUB)) {
+        case 1: images(std::integral_constant<int, 1>()); break;
+        case 2: images(std::integral_constant<int, 2>()); break;
+        case 3: images(std::integral_constant<int, 3>()); break;
+        case 4: images(std::integral_constant<int, 4>()); break;
+        case 5: images(std::integral_constant<int, 5>()); break;
+        case 6: images(std::integral_constant<int, 6>()); break;
+        case 7: images(std::integral_constant<int, 7>()); break;
+        default: images(std::integral_constant<int, 8>()); break;
+      }
     }
   }
-  __syncthreads();
+  SPB_TSR(5);
+  // the two batch subsets of a wave (lanes l, l ^ 32) on the vector ALU, the four waves through LDS with plain stores: word e * KV + k8, so
+  // consecutive lanes hit consecutive banks (float LDS atomics on red[k8 * 8 + e] were 16-way bank conflicts: 3.5 us)
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const float v1 = xor32_sum(kok ? s1[e] : 0.f), v2 = xor32_sum(kok ? s2[e] : 0.f);
+    if ((t & 63) < 32) {
+      red[((t >> 6) * 2 + 0) * HBK + e * KV + k8] = v1;
+      red[((t >> 6) * 2 + 1) * HBK + e * KV + k8] = v2;
+    }
+  }
+  SPB_TSR(6);
+  lds_barrier();      // LDS only: the stores of G above need not have landed before the sums go out
+  SPB_TSR(2);
   for (int i = t; i < 2 * HBK; i += 256) {
-    const int which = i / HBK, kk = kbase + (i % HBK);
+    const int which = i / HBK, r = i % HBK;
+    const int kk = kbase + (r % KV) * 8 + r / KV;
     if (kk < KH) {
       const int rep = blockIdx.x % a.oR;
-      atomicAdd(a.osums + (size_t)rep * 2 * a.C + (size_t)which * a.C + (kk % a.C), red[i]);
+      const float v = (red[which * HBK + r] + red[(2 + which) * HBK + r]) + (red[(4 + which) * HBK + r] + red[(6 + which) * HBK + r]);
+      atomicAdd(a.osums + (size_t)rep * 2 * a.C + (size_t)which * a.C + (kk % a.C), v);
     }
   }
+  SPB_TSR(3);
+  SPB_TS_FLUSH;
 }
 
 // Weight gradient of the 7x7 head convolution: dW[j][c][hw] += sum_b dout[b][j] * relu(bn(z))[b][hw][c], dbias[j] += sum_b dout.
@@ -475,14 +616,12 @@ extern "C" int spb_head_fwd(int dtype, const spb_head_args_t* a, spb_stream_t st
   if (a->target && (!a->dout || !a->scalars)) return SPB_E_ARG;
   const int KH = a->HW * a->C;
   const int kchunk = spb_ceil_div(spb_ceil_div(KH, a->S), 32) * 32;
-  const size_t lds = (size_t)2 * a->C * sizeof(float);
+  const size_t lds = (size_t)2 * a->C * sizeof(float) + (size_t)4 * 64 * 32 * sizeof(float);
   if (dtype == SPB_BF16)
     hipLaunchKernelGGL(head_fwd_kernel<bf16_t>, dim3(a->S / 4), dim3(256), lds, (hipStream_t)stream, *a, kchunk);
   else if (dtype == SPB_F32)
     hipLaunchKernelGGL(head_fwd_kernel<float>, dim3(a->S / 4), dim3(256), lds, (hipStream_t)stream, *a, kchunk);
   else return SPB_E_ARG;
-  SPB_CHECK_LAUNCH();
-  hipLaunchKernelGGL(head_reduce_kernel, dim3(spb_ceil_div(a->B * a->J, 64)), dim3(256), 0, (hipStream_t)stream, *a);
   SPB_CHECK_LAUNCH();
   return 0;
 }
@@ -492,7 +631,7 @@ extern "C" int spb_head_bwd(int dtype, const spb_head_bwd_args_t* a, spb_stream_
   if (a->B <= 0 || a->J <= 0 || a->J > 32 || (a->C & 7) || a->oR < 1) return SPB_E_SHAPE;
   const int KH = a->HW * a->C;
   const int gx = spb_ceil_div(KH, HBK);
-  const size_t lds = ((size_t)((a->B * a->J + 3) & ~3) + (size_t)a->J * HBK + 2 * HBK) * sizeof(float);
+  const size_t lds = ((size_t)a->J * 64 + (size_t)a->J * HBK + 12 * HBK) * sizeof(float);
   if (a->J * (HBK / 8) > 1024) return SPB_E_SHAPE;
   if (lds > 160 * 1024) return SPB_E_SHAPE;
   static bool attr_done = false;

@@ -198,7 +198,7 @@ def head_fwd(Z, Wp, bias, pro, J, HW, C_, target=None, S=256):
     B = Z.shape[0]
     Jp = Wp.shape[0]
     dev = Z.device
-    partial = torch.empty(S * B * Jp, dtype=torch.float32, device=dev)
+    partial = torch.zeros(S * B * Jp, dtype=torch.float32, device=dev)   # ends in the reduction's ticket word: zero before the first call
     pred = torch.empty(B, J, dtype=torch.float32, device=dev)
     dout = torch.zeros(B, J, dtype=torch.float32, device=dev)
     scalars = torch.zeros(3, dtype=torch.float32, device=dev)
