@@ -117,6 +117,132 @@ __global__ __launch_bounds__(256) void stem_fwd_mfma_kernel(const float* __restr
   }
 }
 
+// ------------------------------------------------------------------------------------------------------ forward, LDS tile
+// The gather kernel above spends 327 vector instructions per 16 pixels on index arithmetic (64-bit pixel -> (image, row, column)
+// divisions, clamps and masks of eight scattered 4-byte loads per lane): 46 us for 67 MB (profiles/r4_sq_stall_breakdown.txt).  Here a
+// workgroup owns SR output rows of one image: the 2*SR+1 input rows of the three planes are fetched with 16-byte loads (one round trip),
+// rounded to bf16 and laid out in LDS as [row][column + 1][4] -- three channels and a zero per column, a zero column on each side, zero
+// rows outside the image -- so the taps of a pixel are contiguous: K is ordered (ky, column 0..3, channel 0..3) = 3 x 16 (+ 16 of zero
+// weights), and the 8 values a lane feeds to one MFMA are ONE aligned ds_read_b128 (columns 2*ow, 2*ow+1 or 2*ow+2, 2*ow+3 of row
+// 2*oh + ky).  Four MFMAs per 16 pixels (K = 64) instead of two, no masks, no packing.  The weight rows are permuted so that a lane ends
+// up with 8 consecutive channels of its pixel: one 16-byte NHWC store, 1 KB contiguous per wave.
+constexpr int SR = 8;
+__global__ __launch_bounds__(256) void stem_fwd_tile_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                            bf16_t* __restrict__ y, float* osums, int oR, int B, int H, int W,
+                                                            int OH, int OW, int NG, int TW) {
+  extern __shared__ __attribute__((aligned(16))) char tile[];    // [2*SR+1][TW] x 8 bytes
+  __shared__ float red[4][2][32];
+  const int t = threadIdx.x, lane = t & 63, li = lane & 15, lq = lane >> 4, wave = t >> 6;
+  const int nbands = (OH + SR - 1) / SR;
+  const int b = blockIdx.x / nbands, oh0 = (blockIdx.x % nbands) * SR;
+  const int RI = 2 * SR + 1, ih0 = 2 * oh0 - 1;
+  // ---- staging: task = (input row, 4-column group); the three planes' float4 of a task become four 8-byte LDS entries
+  const int ncg = W >> 2, ntask = RI * ncg;
+  for (int t0 = 0; t0 < ntask; t0 += 256 * 4) {
+    float4 v[4][3];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int task = t0 + u * 256 + t, tc = task < ntask ? task : ntask - 1;
+      const int r = tc / ncg, c4 = tc % ncg;
+      const int ih = clampi(ih0 + r, 0, H - 1);
+#pragma unroll
+      for (int ci = 0; ci < 3; ++ci) v[u][ci] = *reinterpret_cast<const float4*>(x + ((size_t)(b * 3 + ci) * H + ih) * W + c4 * 4);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int task = t0 + u * 256 + t;
+      if (task < ntask) {
+        const int r = task / ncg, c4 = task % ncg;
+        const bool rowok = ih0 + r >= 0 && ih0 + r < H;
+        const float a0[4] = {v[u][0].x, v[u][0].y, v[u][0].z, v[u][0].w};
+        const float a1[4] = {v[u][1].x, v[u][1].y, v[u][1].z, v[u][1].w};
+        const float a2[4] = {v[u][2].x, v[u][2].y, v[u][2].z, v[u][2].w};
+        uint2* dst = reinterpret_cast<uint2*>(tile) + (size_t)r * TW + c4 * 4 + 1;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          uint2 q;
+          q.x = rowok ? pack_bf16x2(a0[c], a1[c]) : 0u;
+          q.y = rowok ? pack_bf16x2(a2[c], 0.f) : 0u;
+          dst[c] = q;
+        }
+      }
+    }
+  }
+  for (int i = t; i < RI * (TW - W); i += 256) {        // the zero columns: column 0 (iw = -1) and W+1 .. TW-1
+    const int r = i / (TW - W), cc = i % (TW - W);
+    reinterpret_cast<uint2*>(tile)[(size_t)r * TW + (cc == 0 ? 0 : W + cc)] = make_uint2(0u, 0u);
+  }
+  // ---- A operand: Wa[cb][chunk], row li of block cb = output channel (li / 4) * 8 + cb * 4 + li % 4; k group gi = chunk * 4 + lq holds
+  // (ky = gi / 2, columns 2 * (gi % 2) + {0, 1}, channel 0..3); ky == 3, column 3 and channel 3 are zero weights
+  bf16x8_t Wa[2][2];
+#pragma unroll
+  for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+    for (int ch = 0; ch < 2; ++ch) {
+      const int co = (li >> 2) * 8 + cb * 4 + (li & 3);
+      const int gi = ch * 4 + lq, ky = gi >> 1;
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int kx = 2 * (gi & 1) + (e >> 2), ci = e & 3;
+        const bool ok = ky < 3 && kx < 3 && ci < 3;
+        v[e] = ok ? w[co * 27 + ci * 9 + ky * 3 + kx] : 0.f;
+      }
+      Wa[cb][ch] = pack8(v);
+    }
+  unsigned loff[2];
+#pragma unroll
+  for (int ch = 0; ch < 2; ++ch) {
+    const int gi = ch * 4 + lq, ky = gi >> 1 < 3 ? gi >> 1 : 2;
+    loff[ch] = (unsigned)((ky * TW + 2 * li + 2 * (gi & 1)) * 8);
+  }
+  float s1[8], s2[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
+  __syncthreads();
+  for (int g = wave; g < SR * NG; g += 4) {
+    const int ohl = g / NG, owg = g % NG;
+    const unsigned base = (unsigned)((2 * ohl * TW + 32 * owg) * 8);
+    bf16x8_t pf[2];
+#pragma unroll
+    for (int ch = 0; ch < 2; ++ch) pf[ch] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(tile + base + loff[ch]));
+    f32x4_t acc[2];
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+      acc[cb] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+      acc[cb] = SPB_MFMA16(Wa[cb][0], pf[0], acc[cb]);
+      acc[cb] = SPB_MFMA16(Wa[cb][1], pf[1], acc[cb]);
+    }
+    // lane (li, lq): pixel ow = owg * 16 + li, channels lq * 8 + cb * 4 + i
+    uint4 o;
+    o.x = pack_bf16x2(acc[0][0], acc[0][1]); o.y = pack_bf16x2(acc[0][2], acc[0][3]);
+    o.z = pack_bf16x2(acc[1][0], acc[1][1]); o.w = pack_bf16x2(acc[1][2], acc[1][3]);
+    const int oh = oh0 + ohl, ow = owg * 16 + li;
+    const bool ok = oh < OH && ow < OW;
+    if (ok) *reinterpret_cast<uint4*>(y + (((size_t)b * OH + oh) * OW + ow) * 32 + lq * 8) = o;
+    const unsigned q[4] = {o.x, o.y, o.z, o.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float r0 = ok ? __uint_as_float(q[e] << 16) : 0.f, r1 = ok ? __uint_as_float(q[e] & 0xffff0000u) : 0.f;
+      s1[2 * e] += r0; s1[2 * e + 1] += r1;
+      s2[2 * e] += r0 * r0; s2[2 * e + 1] += r1 * r1;
+    }
+  }
+  if (osums) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float a = row16_sum(s1[e]), b2 = row16_sum(s2[e]);
+      if (li == 0) { red[wave][0][lq * 8 + e] = a; red[wave][1][lq * 8 + e] = b2; }
+    }
+    __syncthreads();
+    if (t < 64) {
+      const int which = t >> 5, c = t & 31;
+      const float v = (red[0][which][c] + red[1][which][c]) + (red[2][which][c] + red[3][which][c]);
+      atomicAdd(osums + (size_t)(blockIdx.x % oR) * 64 + which * 32 + c, v);
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ weight gradient
 // requires OW % 8 == 0 (8 consecutive pixels of a lane lie in one output row)
 __global__ __launch_bounds__(256) void stem_wgrad_mfma_kernel(const float* __restrict__ x, const bf16_t* __restrict__ G,
@@ -233,6 +359,139 @@ __global__ __launch_bounds__(256) void stem_wgrad_mfma_kernel(const float* __res
   }
 }
 
+// ------------------------------------------------------------------------------------------------ weight gradient, LDS tile
+// Same idea as stem_fwd_tile_kernel for dW[co, tap] += dz^T[co, p] * patch[p, tap] (K = pixels): the patch operand of a lane is one tap at 8
+// consecutive pixels of a row, i.e. input columns 2*ow + kx - 1 at stride 2.  The workgroup's input rows are therefore staged as NINE bf16
+// planes [channel][kx][row][ow] = x[channel][row][2*ow + kx - 1] (zero outside the image), which makes that operand one aligned
+// ds_read_b128 -- the gather kernel spends 8 masked, clamped 4-byte global loads and their index arithmetic on it (8e6 vector instructions
+// per launch, 63 us for 106 MB, and it is the LAST kernel of the backward pass: nothing runs beside it).  dz comes from the wave-private
+// transposed tile exactly as in the gather kernel.  Requires OW % 8 == 0, W % 4 == 0, H and W even.
+template <int WSR>
+__global__ __launch_bounds__(256) void stem_wgrad_tile_kernel(const float* __restrict__ x, const bf16_t* __restrict__ G,
+                                                              const bf16_t* __restrict__ Z, const spb_bnref_t pro, float* dW,
+                                                              int B, int H, int W, int OH, int OW, int PW) {
+  constexpr int LD = 40, RI = 2 * WSR + 1;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  bf16_t* planes = reinterpret_cast<bf16_t*>(smem);                       // [3][3][RI][PW]
+  bf16_t* dzt_all = planes + (size_t)9 * RI * PW;                         // [4][32 * LD]
+  float* cf = reinterpret_cast<float*>(dzt_all + 4 * 32 * LD);            // [3][32]
+  float* red = cf + 96;                                                   // [4][32 * 32]
+  const int t = threadIdx.x, lane = t & 63, li = lane & 15, lq = lane >> 4, wave = t >> 6;
+  const int nbands = (OH + WSR - 1) / WSR;
+  const int b = blockIdx.x / nbands, oh0 = (blockIdx.x % nbands) * WSR;
+  const int ih0 = 2 * oh0 - 1;
+  const int rows = min(WSR, OH - oh0);                                     // output rows of this band
+  const size_t plane = (size_t)RI * PW;
+  // ---- staging (one round trip: all loads of a thread first)
+  const int ncg = W >> 2, ntask = RI * ncg;
+  for (int t0 = 0; t0 < ntask; t0 += 256 * 4) {
+    float4 v[4][3];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int task = t0 + u * 256 + t, tc = task < ntask ? task : ntask - 1;
+      const int r = tc / ncg, c4 = tc % ncg;
+      const int ih = clampi(ih0 + r, 0, H - 1);
+#pragma unroll
+      for (int ci = 0; ci < 3; ++ci) v[u][ci] = *reinterpret_cast<const float4*>(x + ((size_t)(b * 3 + ci) * H + ih) * W + c4 * 4);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int task = t0 + u * 256 + t;
+      if (task < ntask) {
+        const int r = task / ncg, c4 = task % ncg;
+        const bool rowok = ih0 + r >= 0 && ih0 + r < H;
+#pragma unroll
+        for (int ci = 0; ci < 3; ++ci) {
+          const float4 q = v[u][ci];
+          bf16_t* p0 = planes + (size_t)(ci * 3) * plane + (size_t)r * PW + c4 * 2;      // kx = 0: ow = c4*2 + 1, c4*2 + 2
+          const unsigned even = rowok ? pack_bf16x2(q.x, q.z) : 0u, odd = rowok ? pack_bf16x2(q.y, q.w) : 0u;
+          *reinterpret_cast<unsigned*>(p0 + plane) = even;                               // kx = 1: ow = c4*2, c4*2 + 1
+          *reinterpret_cast<unsigned*>(p0 + 2 * plane) = odd;                            // kx = 2: ow = c4*2, c4*2 + 1
+          p0[1] = (bf16_t)(odd & 0xffffu); p0[2] = (bf16_t)(odd >> 16);
+        }
+      }
+    }
+  }
+  for (int i = t; i < 3 * RI; i += 256) planes[(size_t)((i / RI) * 3) * plane + (size_t)(i % RI) * PW] = 0;   // iw = -1
+  if (t < 32) {
+    float p0, p1, p2;
+    bn_bwd_coef(pro, t, p0, p1, p2);
+    cf[t] = p0; cf[32 + t] = p1; cf[64 + t] = p2;
+  }
+  __syncthreads();
+  bf16_t* dzt = dzt_all + wave * 32 * LD;
+  // patch operand: lane column = tap tb*16+li, rows = the 8 pixels of run lq
+  unsigned toff[2];
+#pragma unroll
+  for (int tb = 0; tb < 2; ++tb) {
+    const int tp = tb * 16 + li, tt = tp < 27 ? tp : 26;
+    const int ci = tt / 9, ky = (tt % 9) / 3, kx = tt % 3;
+    toff[tb] = (unsigned)(((size_t)(ci * 3 + kx) * plane + (size_t)ky * PW) * 2);
+  }
+  const int px = lane >> 2, part = lane & 3;   // dz tile load: pixels px and px+16, channels part*8..+7
+  float c0[8], c1[8], c2[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { c0[j] = cf[part * 8 + j]; c1[j] = cf[32 + part * 8 + j]; c2[j] = cf[64 + part * 8 + j]; }
+  f32x4_t acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int bb = 0; bb < 2; ++bb) acc[a][bb] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  const int npix = rows * OW, ngroups = (npix + 31) / 32;       // pixels of the band in row-major order; a run of 8 lies in one row
+  const size_t pbase = ((size_t)b * OH + oh0) * OW;
+  Raw8<bf16_t> gr[2], zr[2];
+  auto load = [&](int g) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      int p = g * 32 + px + 16 * i;
+      p = p < npix ? p : npix - 1;
+      gr[i] = ldraw<bf16_t>(G + (pbase + p) * 32 + part * 8);
+      zr[i] = ldraw<bf16_t>(Z + (pbase + p) * 32 + part * 8);
+    }
+  };
+  int g = wave;
+  if (g < ngroups) load(g);
+  for (; g < ngroups; g += 4) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      float gf[8], zf[8], v[8];
+      cvt8(gr[i], gf); cvt8(zr[i], zf);
+      const bool ok = g * 32 + px + 16 * i < npix;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = ok ? gf[j] * c0[j] + zf[j] * c1[j] + c2[j] : 0.f;
+      *reinterpret_cast<bf16x8_t*>(dzt + (px + 16 * i) * LD + part * 8) = pack8(v);
+    }
+    if (g + 4 < ngroups) load(g + 4);
+    int run = g * 4 + lq;                                        // this lane's run of 8 pixels
+    run = run * 8 < npix ? run : 0;                              // beyond the band: dz is zero there, any finite patch will do
+    const int ohl = run / (OW >> 3), ow0 = (run % (OW >> 3)) * 8;
+    const unsigned poff = (unsigned)(((size_t)(2 * ohl) * PW + ow0) * 2);
+    bf16x8_t pf[2];
+#pragma unroll
+    for (int tb = 0; tb < 2; ++tb) pf[tb] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(smem + toff[tb] + poff));
+    asm volatile("" ::: "memory");   // the tile stores above must stay ahead of the transpose loads
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+      const bf16x8_t af = tr_frag(dzt, LD, cb * 16, li, lq);
+#pragma unroll
+      for (int tb = 0; tb < 2; ++tb) acc[cb][tb] = SPB_MFMA16(af, pf[tb], acc[cb][tb]);
+    }
+    asm volatile("" ::: "memory");
+  }
+  // C layout: column = tap tb*16+li, rows = co cb*16 + lq*4 + e
+#pragma unroll
+  for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+    for (int tb = 0; tb < 2; ++tb)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) red[wave * 1024 + (cb * 16 + lq * 4 + e) * 32 + tb * 16 + li] = acc[cb][tb][e];
+  __syncthreads();
+  for (int i = t; i < 32 * 32; i += 256) {
+    const int co = i >> 5, tp = i & 31;
+    if (tp < 27) atomicAdd(dW + co * 27 + tp, (red[i] + red[1024 + i]) + (red[2048 + i] + red[3072 + i]));
+  }
+}
+
 }  // namespace
 
 static int g_stem_grid_fwd = 1024, g_stem_grid_wgrad = 512;   // measured: fwd 70 / 44 / 47 / 50 us at 512 / 1024 / 2048 / 4096
@@ -242,8 +501,20 @@ extern "C" int spb_debug_set_stem_grid(int fwd, int wgrad) {
   return 0;
 }
 
+static int g_stem_tile = 1;
+extern "C" int spb_debug_set_stem_tile(int on) { g_stem_tile = on; return 0; }
+
 int spb_stem_fwd_mfma(const float* x, const float* w, void* y, float* osums, int oR, int B, int H, int W, hipStream_t s) {
   const int OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1;
+  {   // LDS-tile kernel: 16-byte input loads (W % 4 == 0), the band's tile within the default LDS limit
+    const int NG = (OW + 15) / 16, TW = (32 * NG + 4 > W + 2 ? 32 * NG + 4 : W + 2);
+    const size_t lds = (size_t)(2 * SR + 1) * TW * 8;
+    if (g_stem_tile && (W & 3) == 0 && lds <= 60 * 1024) {
+      const int nbands = (OH + SR - 1) / SR;
+      hipLaunchKernelGGL(stem_fwd_tile_kernel, dim3((unsigned)(B * nbands)), dim3(256), lds, s, x, w, (bf16_t*)y, osums, oR, B, H, W, OH, OW, NG, TW);
+      return 0;
+    }
+  }
   const long long groups = ((long long)B * OH * OW + 15) / 16;
   long long grid = (groups + 3) / 4;
   // the gather keeps only 8 scalar loads per lane in flight: 4 workgroups per CU instead of 2 hide more of the latency
@@ -252,8 +523,31 @@ int spb_stem_fwd_mfma(const float* x, const float* w, void* y, float* osums, int
   return 0;
 }
 
+template <int WSR>
+static int launch_wgrad_tile(const float* x, const void* G, const void* Z, const spb_bnref_t* pro, float* dW, int B, int H, int W, hipStream_t s) {
+  const int OH = H / 2, OW = W / 2, PW = OW + 8;
+  const size_t lds = (size_t)9 * (2 * WSR + 1) * PW * 2 + 4 * 32 * 40 * 2 + 96 * 4 + 4 * 1024 * 4;
+  if (lds > 160 * 1024) return SPB_E_UNSUPPORTED;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_wgrad_tile_kernel<WSR>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_done = true;
+  }
+  const int nbands = (OH + WSR - 1) / WSR;
+  hipLaunchKernelGGL(stem_wgrad_tile_kernel<WSR>, dim3((unsigned)(B * nbands)), dim3(256), lds, s, x, (const bf16_t*)G, (const bf16_t*)Z, *pro,
+                     dW, B, H, W, OH, OW, PW);
+  return 0;
+}
+
+static int g_stem_wtile_rows = 8;
+extern "C" int spb_debug_set_stem_wgrad_tile(int rows) { g_stem_wtile_rows = rows; return 0; }
+
 int spb_stem_wgrad_mfma(const float* x, const void* G, const void* Z, const spb_bnref_t* pro, float* dW, int B, int H, int W,
                         hipStream_t s) {
+  if (g_stem_tile && g_stem_wtile_rows > 0 && (W & 15) == 0 && (H & 1) == 0) {
+    const int e = g_stem_wtile_rows >= 16 ? launch_wgrad_tile<16>(x, G, Z, pro, dW, B, H, W, s) : launch_wgrad_tile<8>(x, G, Z, pro, dW, B, H, W, s);
+    if (e == 0) return 0;
+  }
   const int OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1;
   const long long groups = ((long long)B * OH * OW + 31) / 32;
   long long grid = (groups + 3) / 4;

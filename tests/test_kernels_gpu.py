@@ -475,19 +475,25 @@ def _dw_da(a, Wd, z, g2, g2s_nhwc, xh2, C, stride):
     return ad.grad
 
 
-@pytest.fixture(params=["mfma", "scalar"])
+@pytest.fixture(params=["tile", "tile16", "mfma", "scalar"])
 def stem_variant(request):
-    """bf16 stem: implicit GEMM on the matrix cores (default) and the scalar kernels (the f32 mode always uses those)"""
-    L.lib().spb_debug_set_stem_mfma(1 if request.param == "mfma" else 0)
+    """bf16 stem: implicit GEMM on the matrix cores from an LDS tile (default), the same with its taps gathered from global memory, and the
+    scalar kernels (the f32 mode always uses those)"""
+    L.lib().spb_debug_set_stem_mfma(0 if request.param == "scalar" else 1)
+    L.lib().spb_debug_set_stem_tile(1 if request.param.startswith("tile") else 0)
+    L.lib().spb_debug_set_stem_wgrad_tile(16 if request.param == "tile16" else 8)   # 16 rows per workgroup: a ragged last band at 48 x 48
     yield request.param
     L.lib().spb_debug_set_stem_mfma(1)
+    L.lib().spb_debug_set_stem_tile(1)
+    L.lib().spb_debug_set_stem_wgrad_tile(8)
 
 
 @pytest.mark.parametrize("dt", DTYPES)
-def test_stem(device, stem_variant, dt):
+@pytest.mark.parametrize("B,H", [(3, 32), (2, 44), (2, 48), (1, 224)])   # 44: ragged 16-pixel groups and a ragged last band of rows
+def test_stem(device, stem_variant, dt, B, H):
     torch.manual_seed(5)
     dev = device
-    B, H = 3, 32
+    O = (H - 1) // 2 + 1
     x = torch.rand(B, 3, H, H, dtype=torch.float32).double()
     W = (torch.randn(32, 3, 3, 3) * 0.2).double().requires_grad_(True)
     g2 = torch.rand(32, dtype=torch.float64) + 0.5; b2 = torch.randn(32, dtype=torch.float64) * 0.2
@@ -497,7 +503,7 @@ def test_stem(device, stem_variant, dt):
     xh = (z - mean) / torch.sqrt(var + EPS)
     u = xh * g2.view(1, -1, 1, 1) + b2.view(1, -1, 1, 1); u.retain_grad()
     (F.relu6(u) * torch.randn_like(u)).sum().backward()
-    Y = torch.empty(B, 16, 16, 32, dtype=dt, device=dev)
+    Y = torch.empty(B, O, O, 32, dtype=dt, device=dev)
     osums = torch.zeros(2, 2, 32, dtype=torch.float32, device=dev)
     ops.stem_fwd(x.float().to(dev), W.detach().float().to(dev), Y, osums=osums, oR=2)
     torch.cuda.synchronize()
@@ -508,9 +514,9 @@ def test_stem(device, stem_variant, dt):
     gs = rt(nhwc(u.grad), dt).view(-1, 32)
     bs = torch.stack([gs.sum(0), (gs * nhwc(xh).view(-1, 32)).sum(0)]).float().unsqueeze(0).contiguous().to(dev)
     pro = ops.bnref(32, sums=sums_of(nhwc(zq).view(-1, 32), 1, dev), gamma=g2.float().to(dev), beta=b2.float().to(dev), bsums=bs,
-                    n=B * 256, act=L.ACT_RELU6)
+                    n=B * O * O, act=L.ACT_RELU6)
     dW = torch.zeros(32, 3, 3, 3, dtype=torch.float32, device=dev)
-    ops.stem_wgrad(x.float().to(dev), gs.view(B, 16, 16, 32).to(dt).to(dev), nhwc(zq).to(dt).to(dev), pro, dW)
+    ops.stem_wgrad(x.float().to(dev), gs.view(B, O, O, 32).to(dt).to(dev), nhwc(zq).to(dt).to(dev), pro, dW)
     torch.cuda.synchronize()
     assert relerr(dW, W.grad) < TOL[dt] * 3
 
