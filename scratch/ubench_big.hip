@@ -9,6 +9,10 @@ __device__ unsigned long long* g_ts;
 #define SPB_TS_DECL unsigned long long ts_r[8] = {0, 0, 0, 0, 0, 0, 0, 0}
 #define SPB_TSR(i) ts_r[i] = wall_clock64()
 #define SPB_TS_FLUSH do { if (threadIdx.x == 0 && g_ts && blockIdx.x < 4096) for (int i_ = 0; i_ < 8; ++i_) g_ts[blockIdx.x * 8 + i_] = ts_r[i_]; } while (0)
+#define SPB_STAT_BEGIN unsigned long long st_b = __builtin_readcyclecounter()
+#define SPB_STAT_END(i) ts_r[i] += __builtin_readcyclecounter() - st_b
+#define SPB_STAT_BEGIN2 unsigned long long st_c = __builtin_readcyclecounter()
+#define SPB_STAT_END2(i) ts_r[i] += __builtin_readcyclecounter() - st_c
 #include "../speedplusbaseline_amd/csrc/gemm_big.hip"
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("err %s line %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
 int main(int argc, char** argv) {
@@ -51,6 +55,8 @@ int main(int argc, char** argv) {
       double avg[6] = {0}, mx[6] = {0};
       for (int b = 0; b < 4096; ++b) if (h[b * 8]) for (int i = 0; i < 6; ++i) { double v = h[b * 8 + i] ? (double)(h[b * 8 + i] - t0) / 100.0 : 0.0; avg[i] += v / nb; if (v > mx[i]) mx[i] = v; }
       printf(" | %4d wgs: start %.1f/%.1f  prologue %.1f/%.1f  kloop %.1f/%.1f  epi %.1f/%.1f  end %.1f/%.1f", nb, avg[0], mx[0], avg[1], mx[1], avg[2], mx[2], avg[3], mx[3], avg[4], mx[4]);
+      double w5 = 0, w6 = 0, w7 = 0; for (int b = 0; b < 4096; ++b) if (h[b * 8]) { w5 += (double)h[b * 8 + 5] / nb; w6 += (double)h[b * 8 + 6] / nb; w7 += (double)h[b * 8 + 7] / nb; }
+      printf("  [wave 0 cycles waiting: dma %.0f  lds %.0f  barrier %.0f]", w5, w6, w7);
     }
     printf("\n");
     hipFree(A); hipFree(A2); hipFree(W); hipFree(Y); hipFree(Zo); hipFree(sums); hipFree(gam); hipFree(bet); hipFree(osums); hipFree(esums);

@@ -337,6 +337,13 @@ __device__ __forceinline__ void dma16(const void* gsrc, unsigned lds_base) {
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                : "=&s"(keep) : "v"(gsrc), "s"(lds_base) : "memory");
 }
+// same with a wave-uniform 64-bit base in SGPRs and a 32-bit byte offset per lane: a ring whose source advances by a constant per stage
+// then needs no vector arithmetic at all for its addresses (the base moves on the scalar unit)
+__device__ __forceinline__ void dma16s(const void* sbase, unsigned voff, unsigned lds_base) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_base) : "memory");
+}
 __device__ __forceinline__ unsigned lds_addr(const void* p) {
   return (unsigned)(size_t)(const __attribute__((address_space(3))) char*)p;
 }

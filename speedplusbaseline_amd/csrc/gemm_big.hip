@@ -18,6 +18,7 @@
 // bf16 only (the f32 parity mode keeps the tiled kernel).
 #include "common.h"
 #include <hip/hip_ext.h>
+#include <type_traits>
 
 #ifndef SPB_TS_DECL       // register-held phase timestamps (scratch/ubench_gemm2.hip); compiled out in the product build
 #define SPB_TS_DECL
@@ -33,7 +34,8 @@ constexpr int GB_TILE = GB * GBK * 2;   // bytes of one 128 x 64 bf16 operand ti
 // NW = 8 waves (512 threads, 2 x 4, a wave owns 64 x 32): two waves per SIMD, so one wave's DMA issue / transform / barrier
 // wait overlaps the other's matrix steps (with 4 waves every phase of a stage is serial on its SIMD)
 constexpr int NW = 8, NTH = NW * 64, WCOLS = 4, WJ = GB / WCOLS / 16;   // waves across the columns, MFMA column tiles per wave
-template <int PRO, int EPI>
+// ACTK: prologue activation of the forward transform -- 0 none (affine only), 1 clamp (ReLU / ReLU6), 2 generic (leaky)
+template <int PRO, int EPI, int ACTK>
 __global__ __launch_bounds__(NTH) void pw_big_kernel(const spb_gemm_args_t g) {
   typedef bf16_t T;
   constexpr int NA = PRO == 2 ? 2 : 1;                 // A-side tensors (g and z for the BatchNorm-backward prologue)
@@ -71,43 +73,35 @@ __global__ __launch_bounds__(NTH) void pw_big_kernel(const spb_gemm_args_t g) {
   // DMA lane roles: instruction i of wave w fills rows w*32 + i*8 .. +7 of a tile (8 lanes = the 8 slots of a 128-byte row);
   // slot (l & 7) holds k-vector (l & 7) ^ (row & 7), and row & 7 == l >> 3
   const int dkv = (l & 7) ^ (l >> 3);
-  size_t arow[DI], brow[DI];
+  unsigned aoff[DI], boff[DI];          // byte offsets of this lane's 16 bytes inside stage 0 (K % 64 == 0: no clamp along k)
 #pragma unroll
   for (int i = 0; i < DI; ++i) {
     const int r = w * (DI * 8) + i * 8 + (l >> 3);
     const int m = m0 + r, n = n0 + r;
-    arow[i] = (size_t)(m < M ? m : M - 1) * lda;
-    brow[i] = (size_t)(n < N ? n : N - 1) * K;
+    aoff[i] = (unsigned)(((size_t)(m < M ? m : M - 1) * lda + dkv * 8) * 2);
+    boff[i] = (unsigned)(((size_t)(n < N ? n : N - 1) * K + dkv * 8) * 2);
   }
   const unsigned ring_lds = lds_addr(ring);
   const unsigned wave_ro = __builtin_amdgcn_readfirstlane((unsigned)(w * DI * 1024));
-  auto issue = [&](int kt) {
-    const unsigned sb = ring_lds + (unsigned)((kt % NST) * STAGE) + wave_ro;
-    const int k = kt * GBK + dkv * 8;
-    const int kc = k < K ? k : K - 8;
+  // stage kt -> ring buffer `buf` (compile-time in the main loop).  The sources advance by 128 bytes per stage on the SCALAR unit.
+  auto issue = [&](int kt, int buf) {
+    const unsigned sb = ring_lds + (unsigned)(buf * STAGE) + wave_ro;
+    const char* sa = reinterpret_cast<const char*>(Ag) + (size_t)kt * (GBK * 2);
+    const char* sa2 = reinterpret_cast<const char*>(A2g) + (size_t)kt * (GBK * 2);
+    const char* sw = reinterpret_cast<const char*>(Bg) + (size_t)kt * (GBK * 2);
 #pragma unroll
     for (int i = 0; i < DI; ++i) {
-      dma16(Ag + arow[i] + kc, sb + (unsigned)(i << 10));
-      if (PRO == 2) dma16(A2g + arow[i] + kc, sb + (unsigned)(GB_TILE + (i << 10)));
-      dma16(Bg + brow[i] + kc, sb + (unsigned)(NA * GB_TILE + (i << 10)));
+      dma16s(sa, aoff[i], sb + (unsigned)(i << 10));
+      if (PRO == 2) dma16s(sa2, aoff[i], sb + (unsigned)(GB_TILE + (i << 10)));
+      dma16s(sw, boff[i], sb + (unsigned)(NA * GB_TILE + (i << 10)));
     }
   };
-  for (int s = 0; s < NST - 1 && s < KT; ++s) issue(s);
+  for (int s = 0; s < NST && s < KT; ++s) issue(s, s);
 
   // ---- coefficient tables and the output-side operands of the dgrad epilogue share the round trip of the first stages
   const int vcol = t % NV, vrow0 = t / NV;
   const int nE = n0 + vcol * 8;
   const bool colok = nE < N;
-  uint4 zr[EPI == 2 ? VRI : 1], rr[EPI == 2 ? VRI : 1];
-  if (EPI == 2) {
-#pragma unroll
-    for (int s = 0; s < VRI; ++s) {
-      const int m = m0 + vrow0 + s * VR;
-      const size_t o = (size_t)(m < M ? m : M - 1) * ldc + (colok ? nE : 0);
-      zr[EPI == 2 ? s : 0] = *reinterpret_cast<const uint4*>(Zg + o);
-      if (Rg) rr[EPI == 2 ? s : 0] = *reinterpret_cast<const uint4*>(Rg + o);
-    }
-  }
   if (t < 256) bn_coef_table<PRO == 1 ? 1 : 2>(g.pro, K, Kp, coef, t);   // the table routine is written for 256 threads
   if (EPI == 2) {
     if (t < GB) {
@@ -127,48 +121,64 @@ __global__ __launch_bounds__(NTH) void pw_big_kernel(const spb_gemm_args_t g) {
     for (int j = 0; j < 8; ++j) e_bias[j] = (colok && g.bias) ? g.bias[nE + j] : 0.f;
   }
   const float act_h = act_hi(g.pro.act), act_n = act_ns(g.pro.act, g.pro.slope);
-  // In-place transform of the A tile of stage kt: a wave transforms exactly the rows it fetched itself (rows w*DI*8 .. +DI*8-1:
-  // lane l, instruction i -> row w*DI*8 + i*8 + (l >> 3), slot l & 7, the slot its own DMA lane wrote), so it only has to wait
-  // for its OWN DMA (vmcnt), not for a workgroup barrier, before it starts.
-  auto transform = [&](int kt) {
-    char* sb = ring + (size_t)(kt % NST) * STAGE;
+  // In-place transform of the A tile of a stage: a wave transforms exactly the rows it fetched itself (rows w*DI*8 .. +DI*8-1: lane l,
+  // instruction i -> row w*DI*8 + i*8 + (l >> 3), slot l & 7, the slot its own DMA lane wrote), so it only has to wait for its OWN DMA
+  // (vmcnt), not for a workgroup barrier, before it starts.  Split in two: every LDS read first (raw operands + coefficients), arithmetic
+  // and stores later -- the row-by-row form finishes row 0's store before row 1's loads (they may alias).
+  const unsigned xrow = (unsigned)((w * (DI * 8) + (l >> 3)) * (GBK * 2) + ((l & 7) << 4));      // byte offset of this lane's slot, row i = 0
+  struct XfRegs { uint4 raw[DI], raw2[DI]; float4 cf[6]; };
+  auto xf_load = [&](int kt, int buf, XfRegs& x) {
+    const char* sb = ring + (size_t)buf * STAGE + xrow;
+    const float* cp = coef + kt * GBK + (dkv << 3);
 #pragma unroll
     for (int i = 0; i < DI; ++i) {
-      const int row = w * (DI * 8) + i * 8 + (l >> 3), ps = l & 7;
-      const int kb = kt * GBK + (dkv << 3);
-      char* p = sb + row * (GBK * 2) + (ps << 4);
-      Raw8<T> ar; ar.u = *reinterpret_cast<const uint4*>(p);
-      float a[8], x[8];
+      x.raw[i] = *reinterpret_cast<const uint4*>(sb + i * 8 * (GBK * 2));
+      if (PRO == 2) x.raw2[i] = *reinterpret_cast<const uint4*>(sb + GB_TILE + i * 8 * (GBK * 2));
+    }
+#pragma unroll
+    for (int c = 0; c < (PRO == 2 ? 3 : 2); ++c) {
+      x.cf[2 * c] = *reinterpret_cast<const float4*>(cp + c * Kp);
+      x.cf[2 * c + 1] = *reinterpret_cast<const float4*>(cp + c * Kp + 4);
+    }
+  };
+  auto xf_store = [&](int buf, const XfRegs& x) {
+    char* sb = ring + (size_t)buf * STAGE + xrow;
+    const float c0[8] = {x.cf[0].x, x.cf[0].y, x.cf[0].z, x.cf[0].w, x.cf[1].x, x.cf[1].y, x.cf[1].z, x.cf[1].w};
+    const float c1[8] = {x.cf[2].x, x.cf[2].y, x.cf[2].z, x.cf[2].w, x.cf[3].x, x.cf[3].y, x.cf[3].z, x.cf[3].w};
+#pragma unroll
+    for (int i = 0; i < DI; ++i) {
+      Raw8<T> ar; ar.u = x.raw[i];
+      float a[8], v[8];
       cvt8(ar, a);
-      const float4 c0a = *reinterpret_cast<const float4*>(coef + kb), c0b = *reinterpret_cast<const float4*>(coef + kb + 4);
-      const float4 c1a = *reinterpret_cast<const float4*>(coef + Kp + kb), c1b = *reinterpret_cast<const float4*>(coef + Kp + kb + 4);
-      const float c0[8] = {c0a.x, c0a.y, c0a.z, c0a.w, c0b.x, c0b.y, c0b.z, c0b.w};
-      const float c1[8] = {c1a.x, c1a.y, c1a.z, c1a.w, c1b.x, c1b.y, c1b.z, c1b.w};
       if (PRO == 1) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           const float u = a[j] * c0[j] + c1[j];
-          x[j] = __builtin_amdgcn_fmed3f(u, 0.f, act_h) + act_n * fminf(u, 0.f);
+          v[j] = ACTK == 0 ? u : (ACTK == 1 ? __builtin_amdgcn_fmed3f(u, 0.f, act_h) : __builtin_amdgcn_fmed3f(u, 0.f, act_h) + act_n * fminf(u, 0.f));
         }
       } else {
-        Raw8<T> a2r; a2r.u = *reinterpret_cast<const uint4*>(p + GB_TILE);
+        Raw8<T> a2r; a2r.u = x.raw2[i];
         float a2[8];
         cvt8(a2r, a2);
-        const float4 c2a = *reinterpret_cast<const float4*>(coef + 2 * Kp + kb), c2b = *reinterpret_cast<const float4*>(coef + 2 * Kp + kb + 4);
-        const float c2[8] = {c2a.x, c2a.y, c2a.z, c2a.w, c2b.x, c2b.y, c2b.z, c2b.w};
+        const float c2[8] = {x.cf[4].x, x.cf[4].y, x.cf[4].z, x.cf[4].w, x.cf[5].x, x.cf[5].y, x.cf[5].z, x.cf[5].w};
 #pragma unroll
-        for (int j = 0; j < 8; ++j) x[j] = a[j] * c0[j] + a2[j] * c1[j] + c2[j];
+        for (int j = 0; j < 8; ++j) v[j] = a[j] * c0[j] + a2[j] * c1[j] + c2[j];
       }
       uint4 pa;
-      pa.x = pack_bf16x2(x[0], x[1]); pa.y = pack_bf16x2(x[2], x[3]); pa.z = pack_bf16x2(x[4], x[5]); pa.w = pack_bf16x2(x[6], x[7]);
-      if (kb >= K) pa = make_uint4(0, 0, 0, 0);    // reduction padding: explicit zeros against clamped (finite) weights
-      *reinterpret_cast<uint4*>(p) = pa;
+      pa.x = pack_bf16x2(v[0], v[1]); pa.y = pack_bf16x2(v[2], v[3]); pa.z = pack_bf16x2(v[4], v[5]); pa.w = pack_bf16x2(v[6], v[7]);
+      *reinterpret_cast<uint4*>(sb + i * 8 * (GBK * 2)) = pa;
     }
   };
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // stages 0 .. NST-2, the tables and the epilogue operands have landed
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // stages 0 .. NST-1, the tables and the epilogue operands have landed
   __syncthreads();                                    // coefficient tables visible
-  transform(0);
-  __syncthreads();                                    // stage 0 transformed and visible
+  {
+    XfRegs x0, x1;
+    xf_load(0, 0, x0);
+    if (KT > 1) xf_load(1, 1, x1);
+    xf_store(0, x0);
+    if (KT > 1) xf_store(1, x1);
+  }
+  __syncthreads();                                    // stages 0 and 1 transformed and visible
   SPB_TSR(1);
 
   f32x4_t acc[4][WJ];
@@ -177,42 +187,95 @@ __global__ __launch_bounds__(NTH) void pw_big_kernel(const spb_gemm_args_t g) {
 #pragma unroll
     for (int j = 0; j < WJ; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
-  // Software pipeline, ONE barrier per stage.  Entering iteration kt: stage kt is transformed and visible to everyone, stage
-  // kt+1 is in flight or landed (raw), buffer (kt+2) % 3 == (kt-1) % 3 is free (the barrier closing iteration kt-1).
-  for (int kt = 0; kt < KT; ++kt) {
-    const bool more = kt + NST - 1 < KT;
-    if (more) issue(kt + NST - 1);
-    const char* at = ring + (size_t)(kt % NST) * STAGE;
-    const char* bt = at + NA * GB_TILE;
+  // MFMA operands of a stage: 2 reduction steps x (4 row tiles + WJ column tiles), held in registers for a whole iteration
+  struct Frags { bf16x8_t a[2][4], b[2][WJ]; };
+  unsigned fa[2][4], fb[2][WJ];        // byte offsets of this lane's operand vectors inside a stage
 #pragma unroll
-    for (int ks = 0; ks < GBK / 32; ++ks) {
-      const int v = ks * 4 + lq;
-      bf16x8_t af[4], bfv[WJ];
+  for (int ks = 0; ks < 2; ++ks) {
+    const int v = ks * 4 + lq;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int r = wm * 64 + i * 16 + li;
-        af[i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(at + r * (GBK * 2) + ((v ^ (r & 7)) << 4)));
-      }
+    for (int i = 0; i < 4; ++i) { const int r = wm * 64 + i * 16 + li; fa[ks][i] = (unsigned)(r * (GBK * 2) + ((v ^ (r & 7)) << 4)); }
 #pragma unroll
-      for (int j = 0; j < WJ; ++j) {
-        const int r = wn * (WJ * 16) + j * 16 + li;
-        bfv[j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(bt + r * (GBK * 2) + ((v ^ (r & 7)) << 4)));
-      }
+    for (int j = 0; j < WJ; ++j) { const int r = wn * (WJ * 16) + j * 16 + li; fb[ks][j] = (unsigned)(NA * GB_TILE + r * (GBK * 2) + ((v ^ (r & 7)) << 4)); }
+  }
+  auto fetch = [&](int buf, Frags& f) {
+    const char* sb = ring + (size_t)buf * STAGE;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) f.a[ks][i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(sb + fa[ks][i]));
+#pragma unroll
+      for (int j = 0; j < WJ; ++j) f.b[ks][j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(sb + fb[ks][j]));
+    }
+  };
+  // Software pipeline over THREE stages, one barrier per iteration.  Entering iteration kt: the operands of stage kt sit in registers (fetched
+  // during iteration kt-1), stage kt+1 is transformed and visible, stage kt+2 is raw (landed or in flight), and the buffer of stage kt is
+  // free -- every wave finished reading it before the barrier that closed iteration kt-1 -- so the DMA of stage kt+3 goes there.
+  // What bounds the loop is the VECTOR-INSTRUCTION COUNT of an iteration, not its order (round 4: 240 instructions per wave and 64-deep
+  // stage, 150 of them vector ALU, at 2 waves per SIMD and ~4 cycles each = the 0.93 us per stage measured whatever the order: transform
+  // before / after / between the matrix steps, waves of a SIMD in opposite phase, operands prefetched into registers -- all within 5 %).
+  // Hence: ring buffers are compile-time (the loop is unrolled by three: no address arithmetic for 20 LDS accesses), DMA sources advance
+  // on the scalar unit, the activation is a template parameter, K % 64 == 0 (no padding test).
+  Frags cur, nxt;
+  fetch(0, cur);
+  lds_barrier();                                      // every wave holds the operands of stage 0: its buffer is free
+  auto iteration = [&](int kt, auto b_, auto f_dma, auto f_fetch, auto f_xf) {
+    constexpr int BUF = decltype(b_)::value;          // == kt % 3
+    constexpr bool DMA = decltype(f_dma)::value, FETCH = decltype(f_fetch)::value, XF = decltype(f_xf)::value;
+    XfRegs xr;
+    if (DMA) issue(kt + NST, BUF);
+    if (XF) {
+      // this wave's own share of stage kt+2 (requested one iteration ago) has landed once only the stage issued above is still in flight
+      if (DMA) wait_vmcnt<IPS>(); else wait_vmcnt<0>();
+      xf_load(kt + 2, (BUF + 2) % NST, xr);
+    }
+    if (FETCH) fetch((BUF + 1) % NST, nxt);
+#pragma unroll
+    for (int ks = 0; ks < GBK / 32; ++ks)
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < WJ; ++j) acc[i][j] = SPB_MFMA16(af[i], bfv[j], acc[i][j]);
-    }
-    if (kt + 1 < KT) {
-      // this wave's own share of stage kt+1 has landed once only the stage issued above is still in flight; its transform
-      // (LDS + vector ALU) runs while the matrix cores work through the steps issued above
-      if (more) wait_vmcnt<IPS>(); else wait_vmcnt<0>();
-      transform(kt + 1);
-    }
-    __builtin_amdgcn_s_barrier();   // stage kt+1 transformed and visible; everyone is done reading stage kt
-    asm volatile("" ::: "memory");
+        for (int j = 0; j < WJ; ++j) acc[i][j] = SPB_MFMA16(cur.a[ks][i], cur.b[ks][j], acc[i][j]);
+    if (XF) xf_store((BUF + 2) % NST, xr);
+    lds_barrier();   // stage kt+2 transformed and visible; every wave holds the operands of stage kt+1
+    if (FETCH) cur = nxt;
+  };
+  typedef std::true_type Y_;
+  typedef std::false_type N_;
+  typedef std::integral_constant<int, 0> B0;
+  typedef std::integral_constant<int, 1> B1;
+  typedef std::integral_constant<int, 2> B2;
+  // the last three iterations (no DMA; no fetch / transform beyond the last stage), starting at ring phase P
+  auto tail = [&](int kt, auto p_) {
+    constexpr int P = decltype(p_)::value;
+    iteration(kt, std::integral_constant<int, P>(), N_(), Y_(), Y_());
+    iteration(kt + 1, std::integral_constant<int, (P + 1) % 3>(), N_(), Y_(), N_());
+    iteration(kt + 2, std::integral_constant<int, (P + 2) % 3>(), N_(), N_(), N_());
+  };
+  int kt = 0;
+  for (; kt + 3 <= KT - NST; kt += 3) {               // KT >= 4 (K >= 256)
+    iteration(kt, B0(), Y_(), Y_(), Y_());
+    iteration(kt + 1, B1(), Y_(), Y_(), Y_());
+    iteration(kt + 2, B2(), Y_(), Y_(), Y_());
   }
-  __syncthreads();   // the ring is idle (the last stages were waited with vmcnt(0)): reuse it
+  const int left = KT - NST - kt;                     // 0..2 steady iterations left; kt is a multiple of 3
+  if (left >= 1) iteration(kt, B0(), Y_(), Y_(), Y_());
+  if (left == 2) iteration(kt + 1, B1(), Y_(), Y_(), Y_());
+  kt += left;
+  if (left == 0) tail(kt, B0()); else if (left == 1) tail(kt, B1()); else tail(kt, B2());
+  // the output-side operands of the dgrad epilogue: requested here, used after the accumulators went through LDS (held across the K loop
+  // they were 32 registers of a kernel that has none to spare: the loop spilled)
+  uint4 zr[EPI == 2 ? VRI : 1], rr[EPI == 2 ? VRI : 1];
+  if (EPI == 2) {
+#pragma unroll
+    for (int s = 0; s < VRI; ++s) {
+      const int m = m0 + vrow0 + s * VR;
+      const size_t o = (size_t)(m < M ? m : M - 1) * ldc + (colok ? nE : 0);
+      zr[EPI == 2 ? s : 0] = *reinterpret_cast<const uint4*>(Zg + o);
+      if (Rg) rr[EPI == 2 ? s : 0] = *reinterpret_cast<const uint4*>(Rg + o);
+    }
+  }
+  lds_barrier();   // the ring is idle (every DMA was waited for inside the loop): reuse it
   SPB_TSR(2);
 
   // ---- accumulators -> LDS (C layout: col = lane & 15, row = (lane >> 4) * 4 + r), then the coalesced 16-byte epilogue
@@ -301,7 +364,7 @@ __global__ __launch_bounds__(NTH) void pw_big_kernel(const spb_gemm_args_t g) {
   SPB_TS_FLUSH;
 }
 
-template <int PRO, int EPI>
+template <int PRO, int EPI, int ACTK>
 int launch_big(const spb_gemm_args_t& g, hipStream_t stream) {
   constexpr int NA = PRO == 2 ? 2 : 1, NST = 3;
   const int NT = (g.N + GB - 1) / GB, MT = (g.M + GB - 1) / GB;
@@ -310,15 +373,15 @@ int launch_big(const spb_gemm_args_t& g, hipStream_t stream) {
   if (lds > 160 * 1024) return SPB_E_UNSUPPORTED;
   static bool attr_done = false;
   if (!attr_done) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&pw_big_kernel<PRO, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&pw_big_kernel<PRO, EPI, ACTK>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done = true;
   }
   int grid = NT * MT;
   if (grid >= 8 && (grid & 7)) grid = (grid + 7) & ~7;     // keeps the XCD remap a bijection; the extra workgroups own no rows
   if (g.stop_event)
-    hipExtLaunchKernelGGL((pw_big_kernel<PRO, EPI>), dim3(grid), dim3(NTH), (unsigned)lds, stream, nullptr, (hipEvent_t)g.stop_event, 0, g);
+    hipExtLaunchKernelGGL((pw_big_kernel<PRO, EPI, ACTK>), dim3(grid), dim3(NTH), (unsigned)lds, stream, nullptr, (hipEvent_t)g.stop_event, 0, g);
   else
-    hipLaunchKernelGGL((pw_big_kernel<PRO, EPI>), dim3(grid), dim3(NTH), lds, stream, g);
+    hipLaunchKernelGGL((pw_big_kernel<PRO, EPI, ACTK>), dim3(grid), dim3(NTH), lds, stream, g);
   SPB_CHECK_LAUNCH();
   return 0;
 }
@@ -330,9 +393,13 @@ int g_big_on = 1, g_big_min_n = 512, g_big_min_k = 256, g_big_max_m = 16384;
 // bf16 only; SPB_E_UNSUPPORTED tells spb_pwconv_gemm to use the other kernels
 int spb_gemm_big(const spb_gemm_args_t* a, hipStream_t stream) {
   if (!g_big_on || a->N < g_big_min_n || a->K < g_big_min_k || a->M > g_big_max_m || (a->K & 7) || (a->N & 7)) return SPB_E_UNSUPPORTED;
-  if (a->pro_mode == 1 && a->epi_mode == 1) return launch_big<1, 1>(*a, stream);
-  if (a->pro_mode == 1 && a->epi_mode == 0) return launch_big<1, 0>(*a, stream);
-  if (a->pro_mode == 2 && a->epi_mode == 2) return launch_big<2, 2>(*a, stream);
+  if ((a->K & 63) || a->K < 256) return SPB_E_UNSUPPORTED;         // whole 64-deep stages, at least four of them
+  const int actk = (a->pro.act == SPB_ACT_RELU || a->pro.act == SPB_ACT_RELU6) ? 1 : (a->pro.act == SPB_ACT_NONE ? 0 : 2);
+  if (a->pro_mode == 1 && a->epi_mode == 1)
+    return actk == 1 ? launch_big<1, 1, 1>(*a, stream) : (actk == 0 ? launch_big<1, 1, 0>(*a, stream) : launch_big<1, 1, 2>(*a, stream));
+  if (a->pro_mode == 1 && a->epi_mode == 0)
+    return actk == 1 ? launch_big<1, 0, 1>(*a, stream) : (actk == 0 ? launch_big<1, 0, 0>(*a, stream) : launch_big<1, 0, 2>(*a, stream));
+  if (a->pro_mode == 2 && a->epi_mode == 2) return launch_big<2, 2, 0>(*a, stream);
   return SPB_E_UNSUPPORTED;
 }
 
