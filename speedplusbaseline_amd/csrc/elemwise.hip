@@ -147,16 +147,24 @@ __global__ __launch_bounds__(256) void bn_bwd_prep_rows_kernel(const spb_bnbwd_a
     dr[u] = ldraw<T>(dY + o);
     zr[u] = ldraw<T>(Z + (size_t)p * C + cc);
   }
+  // BatchNorm coefficients of the workgroup's 64 channels: ONE channel per thread, so all of their loads are one memory round trip
+  // (eight bn_moments calls per thread, each behind its uniform branches, were eight: the 7x7 launches took 13-18 us for 4-14 MB)
+  float* tab = &red[0][0][0];      // [4][64], before `red` is needed
+  if (t < 64) {
+    const int c = cb + t < C ? cb + t : C - 1;
+    float m = 0.f, iv = 0.f, g1 = 1.f, h1 = 0.f;
+    if (a.bn.gamma) {   // (uniform)
+      bn_moments(a.bn, c, m, iv);
+      g1 = a.bn.gamma[c] * iv;
+      h1 = a.bn.beta[c] - m * g1;
+    }
+    tab[t] = g1; tab[64 + t] = h1; tab[128 + t] = m; tab[192 + t] = iv;
+  }
+  __syncthreads();
   float sc[8], sh[8], mu[8], is[8];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    sc[j] = 1.f; sh[j] = 0.f; mu[j] = 0.f; is[j] = 0.f;
-    if (a.bn.gamma) {
-      bn_moments(a.bn, cc + j, mu[j], is[j]);
-      sc[j] = a.bn.gamma[cc + j] * is[j];
-      sh[j] = a.bn.beta[cc + j] - mu[j] * sc[j];
-    }
-  }
+  for (int j = 0; j < 8; ++j) { sc[j] = tab[v * 8 + j]; sh[j] = tab[64 + v * 8 + j]; mu[j] = tab[128 + v * 8 + j]; is[j] = tab[192 + v * 8 + j]; }
+  __syncthreads();                 // `red` is written below
   float s1[8], s2[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
