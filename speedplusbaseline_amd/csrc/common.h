@@ -187,25 +187,80 @@ __device__ __forceinline__ void bn_moments(const BNRef& r, int c, float& mean, f
   float var = fmaxf(q * r.inv_n - mean * mean, 0.f);
   invstd = rsqrtf(var + r.eps);
 }
+// The coefficient helpers below request EVERYTHING a channel needs before the first value is used.  Every `if` on the way (eval moments,
+// replica count, missing affine) is uniform, but a load behind a branch is only issued once the branch is decided and everything before
+// its merge point has been waited for: gamma / beta after the sums cost a second memory round trip in the prologue of every launch, the
+// BatchNorm-backward coefficients (sums, backward sums, gamma) a third -- ~0.7 us each, ~175 launches per step.
 // forward affine: a = act(z*scale + shift)
 __device__ __forceinline__ void bn_fwd_coef(const BNRef& r, int c, float& scale, float& shift) {
   if (r.gamma == nullptr) { scale = 1.f; shift = 0.f; return; }
+  const float gm = r.gamma[c], bt = r.beta[c];      // in flight together with the sums
   float mean, is;
   bn_moments(r, c, mean, is);
-  scale = r.gamma[c] * is;
-  shift = r.beta[c] - mean * scale;
+  scale = gm * is;
+  shift = bt - mean * scale;
 }
 // backward: dz = g*p0 + z*p1 + p2   (training-mode BN input gradient; g = dL/d(BN output))
 __device__ __forceinline__ void bn_bwd_coef(const BNRef& r, int c, float& p0, float& p1, float& p2) {
   if (r.gamma == nullptr) { p0 = 1.f; p1 = 0.f; p2 = 0.f; return; }
-  float mean, is;
-  bn_moments(r, c, mean, is);
-  float s1, s2;
-  bn_replica_sums(r.bsums, r.R, r.C, c, s1, s2);
+  const float gm = r.gamma[c];
+  float mean, is, s1, s2;
+  if (r.R == 1 && !r.moments) {   // (uniform) the common case -- every map below 28x28 at bs=48: five loads, one round trip
+    const float s = r.sums[c], q = r.sums[r.C + c];
+    s1 = r.bsums[c]; s2 = r.bsums[r.C + c];
+    mean = s * r.inv_n;
+    is = rsqrtf(fmaxf(q * r.inv_n - mean * mean, 0.f) + r.eps);
+  } else if (!r.moments) {        // replicas: the 4 x SPB_MAX_REPLICAS clamped loads of both pairs of sums first
+    float va[SPB_MAX_REPLICAS], vb[SPB_MAX_REPLICAS], vc[SPB_MAX_REPLICAS], vd[SPB_MAX_REPLICAS];
+#pragma unroll
+    for (int i = 0; i < SPB_MAX_REPLICAS; ++i) {
+      const size_t o = (size_t)(i < r.R ? i : 0) * 2 * r.C + c;
+      va[i] = r.sums[o]; vb[i] = r.sums[o + r.C]; vc[i] = r.bsums[o]; vd[i] = r.bsums[o + r.C];
+    }
+    float s = 0.f, q = 0.f;
+    s1 = 0.f; s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < SPB_MAX_REPLICAS; ++i) {
+      s += i < r.R ? va[i] : 0.f; q += i < r.R ? vb[i] : 0.f; s1 += i < r.R ? vc[i] : 0.f; s2 += i < r.R ? vd[i] : 0.f;
+    }
+    mean = s * r.inv_n;
+    is = rsqrtf(fmaxf(q * r.inv_n - mean * mean, 0.f) + r.eps);
+  } else {
+    bn_moments(r, c, mean, is);
+    bn_replica_sums(r.bsums, r.R, r.C, c, s1, s2);
+  }
   s1 *= r.inv_n; s2 *= r.inv_n;
-  p0 = r.gamma[c] * is;
+  p0 = gm * is;
   p1 = -p0 * is * s2;
   p2 = p0 * (mean * is * s2 - s1);
+}
+
+// BatchNorm-backward coefficients of channel c of `r` and, if `has_epi`, the forward affine + moments of the same channel of `e` (the
+// depthwise backward kernels need both: dz of their output's BatchNorm and the activation mask / xhat of their input's).  Common case
+// (one replica each, training statistics): the nine loads of both are requested together.
+__device__ __forceinline__ void bn_bwd_epi_coef(const BNRef& r, const BNRef& e, bool has_epi, int c, float& p0, float& p1, float& p2,
+                                                float& sc, float& sh, float& mu, float& is) {
+  sc = 1.f; sh = 0.f; mu = 0.f; is = 0.f;
+  if (has_epi && r.gamma != nullptr && r.R == 1 && !r.moments && e.R == 1 && !e.moments) {   // (uniform)
+    const float gm = r.gamma[c], s = r.sums[c], q = r.sums[r.C + c], s1 = r.bsums[c] * r.inv_n, s2 = r.bsums[r.C + c] * r.inv_n;
+    const float eg = e.gamma[c], eb = e.beta[c], es = e.sums[c], eq = e.sums[e.C + c];
+    const float mean = s * r.inv_n;
+    const float ris = rsqrtf(fmaxf(q * r.inv_n - mean * mean, 0.f) + r.eps);
+    p0 = gm * ris;
+    p1 = -p0 * ris * s2;
+    p2 = p0 * (mean * ris * s2 - s1);
+    mu = es * e.inv_n;
+    is = rsqrtf(fmaxf(eq * e.inv_n - mu * mu, 0.f) + e.eps);
+    sc = eg * is;
+    sh = eb - mu * sc;
+    return;
+  }
+  bn_bwd_coef(r, c, p0, p1, p2);
+  if (has_epi) {
+    bn_moments(e, c, mu, is);
+    sc = e.gamma[c] * is;
+    sh = e.beta[c] - mu * sc;
+  }
 }
 
 // Per-channel prologue table of a 256-thread workgroup: coef[0..Kp) = c0, coef[Kp..2Kp) = c1, coef[2Kp..3Kp) = c2 for

@@ -280,13 +280,8 @@ __global__ __launch_bounds__(256) void dwp_bwd_kernel(const spb_dw_args_t a, con
   {
     const int ch = t & (PCS - 1), c = c0 + ch, cc = c < C ? c : C - 1;
     const WPair wp = load_wpair(a.Wd, c0, C, t);
-    float p0, p1, p2, sc = 1.f, sh = 0.f, mu = 0.f, is = 0.f;
-    bn_bwd_coef(a.pro, cc, p0, p1, p2);
-    if (IN && a.epi.gamma != nullptr) {   // uniform
-      bn_moments(a.epi, cc, mu, is);
-      sc = a.epi.gamma[cc] * is;
-      sh = a.epi.beta[cc] - mu * sc;
-    }
+    float p0, p1, p2, sc, sh, mu, is;
+    bn_bwd_epi_coef(a.pro, a.epi, IN && a.epi.gamma != nullptr, cc, p0, p1, p2, sc, sh, mu, is);
     if (t < PCS) {
       cf[t] = p0; cf[PCS + t] = p1; cf[2 * PCS + t] = p2;
       cf[3 * PCS + t] = sc; cf[4 * PCS + t] = sh; cf[5 * PCS + t] = mu; cf[6 * PCS + t] = is;

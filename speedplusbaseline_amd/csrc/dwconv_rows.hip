@@ -344,13 +344,8 @@ __global__ __launch_bounds__(256, 2) void dwr_bwd_kernel(const spb_dw_args_t a, 
   float* cf = cfs + row * CFN;
   if (!(SPB_ABL & 128) && wave == 0 && l16 < 8) {
     const int c = c0 + l16;
-    float p0, p1, p2, sc = 1.f, sh = 0.f, mu = 0.f, is = 0.f;
-    bn_bwd_coef(a.pro, c, p0, p1, p2);
-    if (IN && a.epi.gamma != nullptr) {
-      bn_moments(a.epi, c, mu, is);
-      sc = a.epi.gamma[c] * is;
-      sh = a.epi.beta[c] - mu * sc;
-    }
+    float p0, p1, p2, sc, sh, mu, is;
+    bn_bwd_epi_coef(a.pro, a.epi, IN && a.epi.gamma != nullptr, c, p0, p1, p2, sc, sh, mu, is);
 #pragma unroll
     for (int k = 0; k < 9; ++k) cf[k * 8 + l16] = a.Wd[(size_t)c * 9 + k];
     cf[72 + l16] = p0; cf[80 + l16] = p1; cf[88 + l16] = p2;
