@@ -270,7 +270,83 @@ __device__ __forceinline__ void bn_bwd_epi_coef(const BNRef& r, const BNRef& e, 
 // channel's are issued: measured ~1.5 us per iteration on the 7x7 layers).
 template <int MODE>
 __device__ __forceinline__ void bn_coef_table(const BNRef& r, int K, int Kp, float* coef, int t) {
+  // Common case (affine present, one replica, training statistics): the uniform tests are taken ONCE, outside the channel loop, and the 4-5
+  // loads of up to GF channels per thread are requested together -- with the tests inside bn_fwd_coef / bn_bwd_coef every channel of the
+  // unrolled loop is its own basic-block chain and its loads are waited for before the next channel's are issued (three memory round trips
+  // per pass of a 768-channel table, measured in the prologue of the 7x7 GEMMs).
+  if (r.gamma != nullptr && r.R == 1 && !r.moments) {   // (uniform)
+    constexpr int GF = 5;                               // 1280 channels in one pass
+    for (int cb = t; cb < Kp; cb += 256 * GF) {
+      float gm[GF], bt[GF], s[GF], q[GF], s1[GF], s2[GF];
+#pragma unroll
+      for (int j = 0; j < GF; ++j) {
+        const int c = cb + 256 * j;
+        const int cc = c < K ? c : K - 1;
+        gm[j] = r.gamma[cc]; s[j] = r.sums[cc]; q[j] = r.sums[r.C + cc];
+        if (MODE == 1) { bt[j] = r.beta[cc]; s1[j] = 0.f; s2[j] = 0.f; }
+        else { bt[j] = 0.f; s1[j] = r.bsums[cc]; s2[j] = r.bsums[r.C + cc]; }
+      }
+#pragma unroll
+      for (int j = 0; j < GF; ++j) {
+        const int c = cb + 256 * j;
+        if (c < Kp) {
+          const bool ok = c < K;
+          const float mean = s[j] * r.inv_n;
+          const float is = rsqrtf(fmaxf(q[j] * r.inv_n - mean * mean, 0.f) + r.eps);
+          float v0, v1, v2;
+          if (MODE == 1) { v0 = gm[j] * is; v1 = bt[j] - mean * v0; v2 = 0.f; }
+          else {
+            const float m1 = s1[j] * r.inv_n, m2 = s2[j] * r.inv_n;
+            v0 = gm[j] * is; v1 = -v0 * is * m2; v2 = v0 * (mean * is * m2 - m1);
+          }
+          coef[c] = ok ? v0 : 0.f; coef[Kp + c] = ok ? v1 : 0.f; coef[2 * Kp + c] = ok ? v2 : 0.f;
+        }
+      }
+    }
+    return;
+  }
   constexpr int G = MODE == 1 ? 3 : 2;
+  if (r.gamma != nullptr && !r.moments) {               // (uniform) replicas (the 14x14 maps and larger): the same, 2-4 x 8 clamped loads per channel
+    for (int cb = t; cb < Kp; cb += 256 * G) {
+      float gm[G], bt[G], va[G][SPB_MAX_REPLICAS], vb[G][SPB_MAX_REPLICAS], vc[MODE == 1 ? 1 : G][SPB_MAX_REPLICAS], vd[MODE == 1 ? 1 : G][SPB_MAX_REPLICAS];
+#pragma unroll
+      for (int j = 0; j < G; ++j) {
+        const int c = cb + 256 * j;
+        const int cc = c < K ? c : K - 1;
+        gm[j] = r.gamma[cc];
+        bt[j] = MODE == 1 ? r.beta[cc] : 0.f;
+#pragma unroll
+        for (int i = 0; i < SPB_MAX_REPLICAS; ++i) {
+          const size_t o = (size_t)(i < r.R ? i : 0) * 2 * r.C + cc;
+          va[j][i] = r.sums[o]; vb[j][i] = r.sums[o + r.C];
+          if (MODE != 1) { vc[MODE == 1 ? 0 : j][i] = r.bsums[o]; vd[MODE == 1 ? 0 : j][i] = r.bsums[o + r.C]; }
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < G; ++j) {
+        const int c = cb + 256 * j;
+        float sv = 0.f, qv = 0.f, m1 = 0.f, m2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < SPB_MAX_REPLICAS; ++i) {
+          sv += i < r.R ? va[j][i] : 0.f; qv += i < r.R ? vb[j][i] : 0.f;
+          if (MODE != 1) { m1 += i < r.R ? vc[MODE == 1 ? 0 : j][i] : 0.f; m2 += i < r.R ? vd[MODE == 1 ? 0 : j][i] : 0.f; }
+        }
+        if (c < Kp) {
+          const bool ok = c < K;
+          const float mean = sv * r.inv_n;
+          const float is = rsqrtf(fmaxf(qv * r.inv_n - mean * mean, 0.f) + r.eps);
+          float v0, v1, v2;
+          if (MODE == 1) { v0 = gm[j] * is; v1 = bt[j] - mean * v0; v2 = 0.f; }
+          else {
+            m1 *= r.inv_n; m2 *= r.inv_n;
+            v0 = gm[j] * is; v1 = -v0 * is * m2; v2 = v0 * (mean * is * m2 - m1);
+          }
+          coef[c] = ok ? v0 : 0.f; coef[Kp + c] = ok ? v1 : 0.f; coef[2 * Kp + c] = ok ? v2 : 0.f;
+        }
+      }
+    }
+    return;
+  }
   for (int cb = t; cb < Kp; cb += 256 * G) {
     float c0[G], c1[G], c2[G];
 #pragma unroll
@@ -297,6 +373,24 @@ __device__ __forceinline__ void bn_coef_table(const BNRef& r, int K, int Kp, flo
 // channels of the head and of the concat's bn_apply: ~1.5 us each on the launch stream).
 template <int G>
 __device__ __forceinline__ void bn_fwd_table(const BNRef& r, int C, float* sc, float* sh, int t, int nthr) {
+  if (r.gamma != nullptr && r.R == 1 && !r.moments) {   // (uniform) as in bn_coef_table: the tests once, the loads of G channels together
+    for (int cb = t; cb < C; cb += nthr * G) {
+      float gm[G], bt[G], s[G], q[G];
+#pragma unroll
+      for (int j = 0; j < G; ++j) {
+        const int c = cb + nthr * j, cc = c < C ? c : C - 1;
+        gm[j] = r.gamma[cc]; bt[j] = r.beta[cc]; s[j] = r.sums[cc]; q[j] = r.sums[r.C + cc];
+      }
+#pragma unroll
+      for (int j = 0; j < G; ++j) {
+        const int c = cb + nthr * j;
+        const float mean = s[j] * r.inv_n;
+        const float a = gm[j] * rsqrtf(fmaxf(q[j] * r.inv_n - mean * mean, 0.f) + r.eps);
+        if (c < C) { sc[c] = a; sh[c] = bt[j] - mean * a; }
+      }
+    }
+    return;
+  }
   for (int cb = t; cb < C; cb += nthr * G) {
     float a[G], b[G];
 #pragma unroll
