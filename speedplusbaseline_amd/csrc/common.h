@@ -235,6 +235,44 @@ __device__ __forceinline__ void bn_bwd_coef(const BNRef& r, int c, float& p0, fl
   p2 = p0 * (mean * is * s2 - s1);
 }
 
+// Split form for prologues that need several BatchNorms at once: bn_issue requests gamma, beta and the replica sums of a channel (clamped
+// replica indices: no branch), bn_issue_bwd the backward sums, bn_finish turns them into mean / inverse std.  Training statistics only
+// (r.moments == 0) and r.gamma != nullptr: the caller tests that once, uniformly, and otherwise uses bn_fwd_coef / bn_bwd_coef.
+struct BNLoad { float gm, bt, a[SPB_MAX_REPLICAS], b[SPB_MAX_REPLICAS]; };
+struct BNLoadB { float c[SPB_MAX_REPLICAS], d[SPB_MAX_REPLICAS]; };
+__device__ __forceinline__ void bn_issue(const BNRef& r, int c, BNLoad& L) {
+  L.gm = r.gamma[c]; L.bt = r.beta[c];
+#pragma unroll
+  for (int i = 0; i < SPB_MAX_REPLICAS; ++i) {
+    const size_t o = (size_t)(i < r.R ? i : 0) * 2 * r.C + c;
+    L.a[i] = r.sums[o]; L.b[i] = r.sums[o + r.C];
+  }
+}
+__device__ __forceinline__ void bn_issue_bwd(const BNRef& r, int c, BNLoadB& L) {
+#pragma unroll
+  for (int i = 0; i < SPB_MAX_REPLICAS; ++i) {
+    const size_t o = (size_t)(i < r.R ? i : 0) * 2 * r.C + c;
+    L.c[i] = r.bsums[o]; L.d[i] = r.bsums[o + r.C];
+  }
+}
+__device__ __forceinline__ void bn_finish(const BNRef& r, const BNLoad& L, float& mean, float& is) {
+  float s = 0.f, q = 0.f;
+#pragma unroll
+  for (int i = 0; i < SPB_MAX_REPLICAS; ++i) { s += i < r.R ? L.a[i] : 0.f; q += i < r.R ? L.b[i] : 0.f; }
+  mean = s * r.inv_n;
+  is = rsqrtf(fmaxf(q * r.inv_n - mean * mean, 0.f) + r.eps);
+}
+__device__ __forceinline__ void bn_finish_bwd(const BNRef& r, const BNLoad& L, const BNLoadB& B, float& p0, float& p1, float& p2) {
+  float mean, is, s1 = 0.f, s2 = 0.f;
+  bn_finish(r, L, mean, is);
+#pragma unroll
+  for (int i = 0; i < SPB_MAX_REPLICAS; ++i) { s1 += i < r.R ? B.c[i] : 0.f; s2 += i < r.R ? B.d[i] : 0.f; }
+  s1 *= r.inv_n; s2 *= r.inv_n;
+  p0 = L.gm * is;
+  p1 = -p0 * is * s2;
+  p2 = p0 * (mean * is * s2 - s1);
+}
+
 // BatchNorm-backward coefficients of channel c of `r` and, if `has_epi`, the forward affine + moments of the same channel of `e` (the
 // depthwise backward kernels need both: dz of their output's BatchNorm and the activation mask / xhat of their input's).  Common case
 // (one replica each, training statistics): the nine loads of both are requested together.
@@ -403,6 +441,50 @@ __device__ __forceinline__ void bn_fwd_table(const BNRef& r, int C, float* sc, f
       const int c = cb + nthr * j;
       if (c < C) { sc[c] = a[j]; sh[c] = b[j]; }
     }
+  }
+}
+
+// Output-side coefficients of the input-gradient epilogue (activation mask / xhat of the W columns n0 .. n0+W-1 of `epi`): ecoef[0..W) scale,
+// [ld..ld+W) shift and, with FULL, [2ld..) mean, [3ld..) inverse std.  Split in two so that a prologue can request these sums BEFORE it
+// builds its reduction-side table (bn_coef_table) and finish them after: everything rides one memory round trip (as two plain calls the
+// second one's loads were issued only after the first table's had been waited for).  W <= 512, 256 threads.
+struct BNEpiPre { BNLoad l[2]; bool fast; };
+__device__ __forceinline__ void bn_epi_issue(const BNRef& epi, int n0, int N, int W, int t, BNEpiPre& P) {
+  P.fast = epi.gamma != nullptr && !epi.moments && W <= 512;   // (uniform)
+  if (P.fast) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int n = n0 + t + 256 * u;
+      bn_issue(epi, n < N ? n : N - 1, P.l[u]);
+    }
+  }
+}
+template <bool FULL>
+__device__ __forceinline__ void bn_epi_finish(const BNRef& epi, int n0, int N, int W, int ld, float* ecoef, int t, const BNEpiPre& P) {
+  if (P.fast) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int c = t + 256 * u;
+      float mu, is;
+      bn_finish(epi, P.l[u], mu, is);
+      if (c < W) {
+        const bool ok = n0 + c < N;
+        const float sc = P.l[u].gm * is;
+        ecoef[c] = ok ? sc : 1.f; ecoef[ld + c] = ok ? P.l[u].bt - mu * sc : 0.f;
+        if (FULL) { ecoef[2 * ld + c] = ok ? mu : 0.f; ecoef[3 * ld + c] = ok ? is : 0.f; }
+      }
+    }
+    return;
+  }
+  for (int c = t; c < W; c += 256) {
+    float sc = 1.f, sh = 0.f, mu = 0.f, is = 0.f;
+    if (n0 + c < N && epi.gamma != nullptr) {
+      bn_moments(epi, n0 + c, mu, is);
+      sc = epi.gamma[n0 + c] * is;
+      sh = epi.beta[n0 + c] - mu * sc;
+    }
+    ecoef[c] = sc; ecoef[ld + c] = sh;
+    if (FULL) { ecoef[2 * ld + c] = mu; ecoef[3 * ld + c] = is; }
   }
 }
 

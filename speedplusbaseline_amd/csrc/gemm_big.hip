@@ -104,15 +104,17 @@ __global__ __launch_bounds__(NTH) void pw_big_kernel(const spb_gemm_args_t g) {
   const bool colok = nE < N;
   if (t < 256) bn_coef_table<PRO == 1 ? 1 : 2>(g.pro, K, Kp, coef, t);   // the table routine is written for 256 threads
   if (EPI == 2) {
-    if (t < GB) {
+    if (t >= 256 && t < 256 + GB) {      // waves 4-5: in parallel with the table of waves 0-3 (the same threads did one after the other)
+      const int c = t - 256;
       float sc = 1.f, sh = 0.f;
-      if (n0 + t < N && g.epi.gamma != nullptr) {
+      if (n0 + c < N && g.epi.gamma != nullptr) {
         float mu, is;
-        bn_moments(g.epi, n0 + t, mu, is);
-        sc = g.epi.gamma[n0 + t] * is;
-        sh = g.epi.beta[n0 + t] - mu * sc;
+        const float gm = g.epi.gamma[n0 + c], bt = g.epi.beta[n0 + c];
+        bn_moments(g.epi, n0 + c, mu, is);
+        sc = gm * is;
+        sh = bt - mu * sc;
       }
-      ecoef[t] = sc; ecoef[GB + t] = sh;
+      ecoef[c] = sc; ecoef[GB + c] = sh;
     }
   }
   float e_bias[8];

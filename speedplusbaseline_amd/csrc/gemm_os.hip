@@ -111,20 +111,11 @@ __global__ __launch_bounds__(256) void pw_os_kernel(const spb_gemm_args_t g, int
     }
   }
   // ---- coefficient tables (their loads share the round trip of everything above)
+  BNEpiPre epre;
+  if (EPI == 2) bn_epi_issue(g.epi, n0, N, BN, t, epre);
   if (OS_ABL & 1) { for (int i = t; i < 3 * Kp; i += 256) coef[i] = 1.f; } else
   bn_coef_table<PRO == 1 ? 1 : 2>(g.pro, K, Kp, coef, t);
-  if (EPI == 2) {
-    for (int c = t; c < BN; c += 256) {
-      float sc = 1.f, sh = 0.f;
-      if (!(OS_ABL & 1) && n0 + c < N && g.epi.gamma != nullptr) {
-        float mu, is;
-        bn_moments(g.epi, n0 + c, mu, is);
-        sc = g.epi.gamma[n0 + c] * is;
-        sh = g.epi.beta[n0 + c] - mu * sc;
-      }
-      ecoef[c] = sc; ecoef[BN + c] = sh;
-    }
-  }
+  if (EPI == 2) bn_epi_finish<false>(g.epi, n0, N, BN, BN, ecoef, t, epre);
 
   f32x4_t acc[NF];
 #pragma unroll

@@ -211,20 +211,11 @@ __global__ __launch_bounds__(256, (RF == 1 && sizeof(T) == 2) ? (((BK == 64 && P
     if (KT > 1) LOAD_TILE(1, (lid / NT) * BM, 1);
   }
   // ---- prologue coefficients for every reduction channel (derived from the producer's raw batch sums)
+  BNEpiPre epre;
+  if (EPI == 2) bn_epi_issue(g.epi, n0, N, BN, t, epre);
   if constexpr (PRO == 3) bn_join_table(g.pro, g.pro2, K, Kp, coef, t);
   else bn_coef_table<PRO == 1 ? 1 : 2>(g.pro, K, Kp, coef, t);
-  if (EPI == 2) {
-    for (int c = t; c < BN; c += 256) {
-      float sc = 1.f, sh = 0.f;
-      if (n0 + c < N && g.epi.gamma != nullptr) {
-        float mu, is;
-        bn_moments(g.epi, n0 + c, mu, is);
-        sc = g.epi.gamma[n0 + c] * is;
-        sh = g.epi.beta[n0 + c] - mu * sc;
-      }
-      ecoef[c] = sc; ecoef[BN + c] = sh;
-    }
-  }
+  if (EPI == 2) bn_epi_finish<false>(g.epi, n0, N, BN, BN, ecoef, t, epre);
   lds_barrier();  // coefficients visible
   SPB_TS(1);
 

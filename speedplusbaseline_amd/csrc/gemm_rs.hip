@@ -102,16 +102,10 @@ __global__ __launch_bounds__(256, NJ >= 9 ? 2 : (NJ >= 6 ? 2 : 4)) void pw_rs_ke
   // (4) coefficient tables
   if constexpr (PRO == 3) bn_join_table(g.pro, g.pro2, K, KP, coef, t);
   else bn_coef_table<PRO == 1 ? 1 : 2>(g.pro, K, KP, coef, t);
-  if (EPI == 2) {
-    for (int c = t; c < N; c += 256) {
-      float sc = 1.f, sh = 0.f, mu = 0.f, is = 0.f;
-      if (g.epi.gamma != nullptr) {
-        bn_moments(g.epi, c, mu, is);
-        sc = g.epi.gamma[c] * is;
-        sh = g.epi.beta[c] - mu * sc;
-      }
-      ecoef[c] = sc; ecoef[N + c] = sh; ecoef[2 * N + c] = mu; ecoef[3 * N + c] = is;
-    }
+  if (EPI == 2) {     // (its own round trip: the table above is built by all 256 threads; EPI == 2 instances of this kernel are not in the KRN plan)
+    BNEpiPre epre;
+    bn_epi_issue(g.epi, 0, N, N, t, epre);
+    bn_epi_finish<true>(g.epi, 0, N, N, N, ecoef, t, epre);
   }
   __syncthreads();
   SPB_TSR(1);

@@ -93,6 +93,29 @@ __global__ __launch_bounds__(512, 2) void pwb_kernel(const spb_pwbwd_args_t g, l
   // RZ: W fragments of the z recomputation (A operand; [NS][2][64 lanes] x 16 B), shared by the workgroup's waves
   uint4* wz = reinterpret_cast<uint4*>(pa + 2 * KW);
   char* wreg = reinterpret_cast<char*>(wz + (RZ ? NS * 2 * 64 : 0)) + (size_t)wave * L.wave_bytes;
+  if (g.pro_dz.gamma != nullptr && !g.pro_dz.moments && g.pro_a.gamma != nullptr && !g.pro_a.moments && g.epi.gamma != nullptr && !g.epi.moments) {
+    // (uniform, the training step) the sums of all three BatchNorms are requested before any of them is used: one memory round trip
+    // instead of three (output-side backward coefficients, then the input side's moments, then its affine)
+    const int top = NP > KW ? NP : KW;
+    for (int i = threadIdx.x; i < top; i += nthr) {
+      BNLoad ldz, lep, lpa; BNLoadB bdz;
+      const int in = i < N ? i : N - 1, k = k0 + i < K ? k0 + i : K - 1;
+      bn_issue(g.pro_dz, in, ldz); bn_issue_bwd(g.pro_dz, in, bdz);
+      bn_issue(g.epi, k, lep);
+      bn_issue(g.pro_a, k, lpa);
+      float p0, p1, p2, mu, is, amu, ais;
+      bn_finish_bwd(g.pro_dz, ldz, bdz, p0, p1, p2);
+      bn_finish(g.epi, lep, mu, is);
+      bn_finish(g.pro_a, lpa, amu, ais);
+      if (i < NP) { const bool ok = i < N; pdz[i] = ok ? p0 : 0.f; pdz[NP + i] = ok ? p1 : 0.f; pdz[2 * NP + i] = ok ? p2 : 0.f; }
+      if (i < KW) {
+        const bool ok = k0 + i < K;
+        const float sc = lep.gm * is, asc = lpa.gm * ais;
+        pep[i] = ok ? sc : 1.f; pep[KW + i] = ok ? lep.bt - mu * sc : 0.f; pep[2 * KW + i] = ok ? mu : 0.f; pep[3 * KW + i] = ok ? is : 0.f;
+        pa[i] = ok ? asc : 0.f; pa[KW + i] = ok ? lpa.bt - amu * asc : 0.f;
+      }
+    }
+  } else {
   for (int i = threadIdx.x; i < NP; i += nthr) {
     float p0 = 0.f, p1 = 0.f, p2 = 0.f;
     if (i < N) bn_bwd_coef(g.pro_dz, i, p0, p1, p2);
@@ -110,6 +133,7 @@ __global__ __launch_bounds__(512, 2) void pwb_kernel(const spb_pwbwd_args_t g, l
     }
     pep[i] = sc; pep[KW + i] = sh; pep[2 * KW + i] = mu; pep[3 * KW + i] = is;
     pa[i] = asc; pa[KW + i] = ash;
+  }
   }
   const bf16_t* Wt = reinterpret_cast<const bf16_t*>(g.Wt);
   if constexpr (RZ) {
