@@ -51,8 +51,8 @@ __global__ __launch_bounds__(NTH) void pw_big_kernel(const spb_gemm_args_t g) {
   const int lda = g.lda > 0 ? g.lda : K, ldc = g.ldc > 0 ? g.ldc : N;
   const int Kp = (K + GBK - 1) / GBK * GBK, KT = Kp / GBK;
   float* coef = reinterpret_cast<float*>(smem);                       // [3][Kp]
-  float* ecoef = coef + 3 * Kp;                                        // [2][128]
-  char* ring = reinterpret_cast<char*>(ecoef + 2 * GB);
+  float* ecoef = coef + 3 * Kp;                                        // [4][128] scale, shift, mean, inverse std of the output columns
+  char* ring = reinterpret_cast<char*>(ecoef + 4 * GB);
   T* Os = reinterpret_cast<T*>(ring);                                  // [128][LDO], after the K loop
   float* Rs = reinterpret_cast<float*>(ring + 36864);                  // [2][VR][128] statistics scratch (32 KB)
 
@@ -106,15 +106,14 @@ __global__ __launch_bounds__(NTH) void pw_big_kernel(const spb_gemm_args_t g) {
   if (EPI == 2) {
     if (t >= 256 && t < 256 + GB) {      // waves 4-5: in parallel with the table of waves 0-3 (the same threads did one after the other)
       const int c = t - 256;
-      float sc = 1.f, sh = 0.f;
+      float sc = 1.f, sh = 0.f, mu = 0.f, is = 0.f;
       if (n0 + c < N && g.epi.gamma != nullptr) {
-        float mu, is;
         const float gm = g.epi.gamma[n0 + c], bt = g.epi.beta[n0 + c];
         bn_moments(g.epi, n0 + c, mu, is);
         sc = gm * is;
         sh = bt - mu * sc;
       }
-      ecoef[c] = sc; ecoef[GB + c] = sh;
+      ecoef[c] = sc; ecoef[GB + c] = sh; ecoef[2 * GB + c] = mu; ecoef[3 * GB + c] = is;   // mean / inverse std: for the sums at the very end
     }
   }
   float e_bias[8];
@@ -355,9 +354,8 @@ __global__ __launch_bounds__(NTH) void pw_big_kernel(const spb_gemm_args_t g) {
     }
     if (t < 2 * GB && n0 + c < N) {
       if (EPI == 2 && which == 1) {   // sum g*z -> sum g*xhat = invstd * (sum g*z - mean * sum g)
-        float mu = 0.f, is = 0.f;
-        if (g.epi.gamma != nullptr) bn_moments(g.epi, n0 + c, mu, is);
-        s = is * (s - mu * sg);
+        const float mu = ecoef[2 * GB + c], is = ecoef[3 * GB + c];   // kept from the prologue (loading the sums again here put a memory
+        s = is * (s - mu * sg);                                       // round trip between the last store and the end of the kernel)
       }
       atomicAdd(g.osums + (size_t)(blockIdx.x % g.oR) * 2 * N + (size_t)which * N + n0 + c, s);
     }
@@ -371,7 +369,7 @@ int launch_big(const spb_gemm_args_t& g, hipStream_t stream) {
   constexpr int NA = PRO == 2 ? 2 : 1, NST = 3;
   const int NT = (g.N + GB - 1) / GB, MT = (g.M + GB - 1) / GB;
   const int Kp = (g.K + GBK - 1) / GBK * GBK;
-  const size_t lds = (size_t)(3 * Kp + 2 * GB) * sizeof(float) + (size_t)NST * (NA + 1) * GB_TILE;
+  const size_t lds = (size_t)(3 * Kp + 4 * GB) * sizeof(float) + (size_t)NST * (NA + 1) * GB_TILE;
   if (lds > 160 * 1024) return SPB_E_UNSUPPORTED;
   static bool attr_done = false;
   if (!attr_done) {

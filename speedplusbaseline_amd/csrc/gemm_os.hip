@@ -57,8 +57,8 @@ __global__ __launch_bounds__(256) void pw_os_kernel(const spb_gemm_args_t g, int
   const int lda = g.lda > 0 ? g.lda : K, ldc = g.ldc > 0 ? g.ldc : N;
   const int KC = (K + 31) >> 5, Kp = KC * 32;
   float* coef = reinterpret_cast<float*>(smem);                       // [3][Kp]
-  float* ecoef = coef + 3 * Kp;                                        // [2][BN]
-  float* red = ecoef + 2 * BN;                                         // [4 waves][2][BN]
+  float* ecoef = coef + 3 * Kp;                                        // [4][BN] scale, shift, mean, inverse std
+  float* red = ecoef + 4 * BN;                                         // [4 waves][2][BN]
   bf16_t* Os = reinterpret_cast<bf16_t*>(red + 8 * BN);                // [64][LDO] (NV = 12: also the statistics scratch)
   constexpr int OSB = (OBM * LDO * 2 > 2 * 21 * BN * 4 ? OBM * LDO * 2 : 2 * 21 * BN * 4);
   char* al = reinterpret_cast<char*>(Os) + ((OSB + 1023) & ~1023);     // [NA][KS][4 row groups][1 KB]
@@ -115,7 +115,7 @@ __global__ __launch_bounds__(256) void pw_os_kernel(const spb_gemm_args_t g, int
   if (EPI == 2) bn_epi_issue(g.epi, n0, N, BN, t, epre);
   if (OS_ABL & 1) { for (int i = t; i < 3 * Kp; i += 256) coef[i] = 1.f; } else
   bn_coef_table<PRO == 1 ? 1 : 2>(g.pro, K, Kp, coef, t);
-  if (EPI == 2) bn_epi_finish<false>(g.epi, n0, N, BN, BN, ecoef, t, epre);
+  if (EPI == 2) bn_epi_finish<true>(g.epi, n0, N, BN, BN, ecoef, t, epre);
 
   f32x4_t acc[NF];
 #pragma unroll
@@ -265,8 +265,7 @@ __global__ __launch_bounds__(256) void pw_os_kernel(const spb_gemm_args_t g, int
     }
     if (n0 + c < N) {
       if (EPI == 2 && which == 1) {   // sum g*z -> sum g*xhat = invstd * (sum g*z - mean * sum g)
-        float mu = 0.f, is = 0.f;
-        if (g.epi.gamma != nullptr) bn_moments(g.epi, n0 + c, mu, is);
+        const float mu = ecoef[2 * BN + c], is = ecoef[3 * BN + c];   // kept from the prologue
         s = is * (s - mu * sg);
       }
       atomicAdd(g.osums + (size_t)(blockIdx.x % g.oR) * 2 * N + (size_t)which * N + n0 + c, s);
@@ -292,7 +291,7 @@ int launch_os(const spb_gemm_args_t& g, hipStream_t stream) {
   constexpr int OSB = (OBM * LDO * 2 > 2 * 21 * BN * 4 ? OBM * LDO * 2 : 2 * 21 * BN * 4);
   const int KC = (g.K + 31) / 32, Kp = KC * 32;
   const int NT = (g.N + BN - 1) / BN, MT = (g.M + OBM - 1) / OBM;
-  const size_t fixed = (size_t)(3 * Kp + 2 * BN + 8 * BN) * sizeof(float) + ((OSB + 1023) & ~1023);
+  const size_t fixed = (size_t)(3 * Kp + 4 * BN + 8 * BN) * sizeof(float) + ((OSB + 1023) & ~1023);
   const size_t per_chunk = (size_t)NA * 4096 + (size_t)NF * 1024;
   const size_t cap = 160 * 1024;
   if (fixed + per_chunk > cap) return SPB_E_UNSUPPORTED;

@@ -82,8 +82,8 @@ __global__ __launch_bounds__(256, (RF == 1 && sizeof(T) == 2) ? (((BK == 64 && P
   const int lda = g.lda > 0 ? g.lda : K, ldc = g.ldc > 0 ? g.ldc : N;   // row strides of A (and A2) / Y (and res, Zout)
   const int Kp = (K + GBK - 1) / GBK * GBK;
   float* coef = reinterpret_cast<float*>(smem);  // [3][Kp]
-  float* ecoef = coef + 3 * Kp;                   // [2][BN] (EPI 2): scale, shift of the input-side BN
-  T* As = reinterpret_cast<T*>(smem + (size_t)(3 * Kp + (EPI == 2 ? 2 * BN : 0)) * sizeof(float));
+  float* ecoef = coef + 3 * Kp;                   // [4][BN] (EPI 2): scale, shift, mean, inverse std of the input-side BN
+  T* As = reinterpret_cast<T*>(smem + (size_t)(3 * Kp + (EPI == 2 ? 4 * BN : 0)) * sizeof(float));
   T* Bs = As + BM * LDK;
   T* Os = As;
 
@@ -215,7 +215,7 @@ __global__ __launch_bounds__(256, (RF == 1 && sizeof(T) == 2) ? (((BK == 64 && P
   if (EPI == 2) bn_epi_issue(g.epi, n0, N, BN, t, epre);
   if constexpr (PRO == 3) bn_join_table(g.pro, g.pro2, K, Kp, coef, t);
   else bn_coef_table<PRO == 1 ? 1 : 2>(g.pro, K, Kp, coef, t);
-  if (EPI == 2) bn_epi_finish<false>(g.epi, n0, N, BN, BN, ecoef, t, epre);
+  if (EPI == 2) bn_epi_finish<true>(g.epi, n0, N, BN, BN, ecoef, t, epre);
   lds_barrier();  // coefficients visible
   SPB_TS(1);
 
@@ -334,9 +334,9 @@ __global__ __launch_bounds__(256, (RF == 1 && sizeof(T) == 2) ? (((BK == 64 && P
       for (int r = 0; r < VR; ++r) s += Rs[which * VR * BN + r * BN + c];
       if (n0 + c < N) {
         if (EPI == 2 && which == 1) {   // sum g*z -> sum g*xhat
-          float sg = 0.f, mu = 0.f, is = 0.f;
+          float sg = 0.f;
           for (int r = 0; r < VR; ++r) sg += Rs[r * BN + c];
-          if (g.epi.gamma != nullptr) bn_moments(g.epi, n0 + c, mu, is);
+          const float mu = ecoef[2 * BN + c], is = ecoef[3 * BN + c];   // kept from the prologue
           s = is * (s - mu * sg);
         }
         const int rep = blockIdx.x % g.oR;
@@ -369,7 +369,7 @@ int launch_gemm(const spb_gemm_args_t& g, hipStream_t stream) {
     if (GM >= 8 && (GM & 7)) GM = (GM + 7) / 8 * 8;  // multiple of 8 keeps the XCD remap bijective
   }
   const int Kp = (g.K + GBK - 1) / GBK * GBK;
-  const size_t lds = (size_t)(3 * Kp + (EPI == 2 ? 2 * BN : 0)) * sizeof(float) + gemm_region_bytes<T, RF, BN, BK>();
+  const size_t lds = (size_t)(3 * Kp + (EPI == 2 ? 4 * BN : 0)) * sizeof(float) + gemm_region_bytes<T, RF, BN, BK>();
   static bool attr_done = false;
   if (!attr_done) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(&pw_gemm_kernel<T, RF, BN, BK, PRO, EPI>),

@@ -76,8 +76,8 @@ __global__ __launch_bounds__(256) void pw_sk_kernel(const spb_gemm_args_t g) {
   const int lda = g.lda > 0 ? g.lda : K, ldc = g.ldc > 0 ? g.ldc : N;
   const int Kp = (K + SKK - 1) / SKK * SKK, KT = Kp / SKK;
   float* coef = reinterpret_cast<float*>(smem);                 // [3][Kp]
-  float* ecoef = coef + 3 * Kp;                                  // [2][BN]
-  float* red = ecoef + 2 * BN;                                   // [4][BM][LDR] partial tiles, then the statistics scratch
+  float* ecoef = coef + 3 * Kp;                                  // [4][BN] scale, shift, mean, inverse std
+  float* red = ecoef + 4 * BN;                                   // [4][BM][LDR] partial tiles, then the statistics scratch
 
   const int t = threadIdx.x, l = t & 63, w = t >> 6, li = l & 15, lq = l >> 4;
   const int NT = (N + BN - 1) / BN;
@@ -134,7 +134,7 @@ __global__ __launch_bounds__(256) void pw_sk_kernel(const spb_gemm_args_t g) {
   BNEpiPre epre;
   if (EPI == 2) bn_epi_issue(g.epi, n0, N, BN, t, epre);
   bn_coef_table<PRO == 1 ? 1 : 2>(g.pro, K, Kp, coef, t);
-  if (EPI == 2) bn_epi_finish<false>(g.epi, n0, N, BN, BN, ecoef, t, epre);
+  if (EPI == 2) bn_epi_finish<true>(g.epi, n0, N, BN, BN, ecoef, t, epre);
   __syncthreads();
 
   f32x4_t acc[RF][NF];
@@ -271,9 +271,9 @@ __global__ __launch_bounds__(256) void pw_sk_kernel(const spb_gemm_args_t g) {
       for (int r = 0; r < ROWS; ++r) s += Rs[which * ROWS * BN + r * BN + c];
       if (n0 + c < N) {
         if (EPI == 2 && which == 1) {          // sum g*z -> sum g*xhat = invstd * (sum g*z - mean * sum g)
-          float sg = 0.f, mu = 0.f, is = 0.f;
+          float sg = 0.f;
           for (int r = 0; r < ROWS; ++r) sg += Rs[r * BN + c];
-          if (g.epi.gamma != nullptr) bn_moments(g.epi, n0 + c, mu, is);
+          const float mu = ecoef[2 * BN + c], is = ecoef[3 * BN + c];   // kept from the prologue
           s = is * (s - mu * sg);
         }
         atomicAdd(g.osums + (size_t)(blockIdx.x % g.oR) * 2 * N + (size_t)which * N + n0 + c, s);
@@ -287,7 +287,7 @@ int launch_sk(const spb_gemm_args_t& g, hipStream_t stream) {
   typedef SkShape<RF, NF> S;
   const int NT = (g.N + S::BN - 1) / S::BN, MT = (g.M + S::BM - 1) / S::BM;
   const int Kp = (g.K + SKK - 1) / SKK * SKK;
-  const size_t lds = (size_t)(3 * Kp + 2 * S::BN) * sizeof(float) + sk_tile_bytes<RF, NF>();
+  const size_t lds = (size_t)(3 * Kp + 4 * S::BN) * sizeof(float) + sk_tile_bytes<RF, NF>();
   if (lds > 160 * 1024) return SPB_E_SHAPE;
   static bool attr_done = false;
   if (!attr_done) {
