@@ -493,6 +493,30 @@ __device__ __forceinline__ void bn_epi_finish(const BNRef& epi, int n0, int N, i
 // BatchNorm-backward prologue already runs on.  Same launch shape as bn_coef_table (256 threads, clamped branch-free loads).
 __device__ __forceinline__ void bn_join_table(const BNRef& r, const BNRef& r2, int K, int Kp, float* coef, int t) {
   constexpr int G = 2;
+  if (r.gamma != nullptr && !r.moments && r2.gamma != nullptr && !r2.moments) {   // (uniform) the sums of both sides requested together
+    for (int cb = t; cb < Kp; cb += 256 * G) {
+      BNLoad la[G], lb[G];
+#pragma unroll
+      for (int j = 0; j < G; ++j) {
+        const int c = cb + 256 * j;
+        const int cc = c < K ? c : K - 1;
+        bn_issue(r, cc, la[j]); bn_issue(r2, cc, lb[j]);
+      }
+#pragma unroll
+      for (int j = 0; j < G; ++j) {
+        const int c = cb + 256 * j;
+        float m1, i1, m2, i2;
+        bn_finish(r, la[j], m1, i1); bn_finish(r2, lb[j], m2, i2);
+        if (c < Kp) {
+          const bool ok = c < K;
+          const float sc = la[j].gm * i1, sc2 = lb[j].gm * i2;
+          coef[c] = ok ? sc : 0.f; coef[Kp + c] = ok ? sc2 : 0.f;
+          coef[2 * Kp + c] = ok ? (la[j].bt - m1 * sc) + (lb[j].bt - m2 * sc2) : 0.f;
+        }
+      }
+    }
+    return;
+  }
   for (int cb = t; cb < Kp; cb += 256 * G) {
     float c0[G], c1[G], c2[G];
 #pragma unroll

@@ -74,10 +74,22 @@ __global__ __launch_bounds__(256, ST == 1 ? 4 : 2) void dwt_fwd_kernel(const spb
   // ---- per-lane constants
   const bf16x8_t sel0 = selector(lane, 0), sel1 = selector(lane, 1);
   float sc[2], sh[2];      // staging: this lane's channels c0 + r and c0 + 16 + r
+  if (a.pro.gamma != nullptr && !a.pro.moments) {   // (uniform) the sums of both channels requested together: one round trip, not two
+    BNLoad bl[2];
 #pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    const int c = c0 + 16 * h + r;
-    bn_fwd_coef(a.pro, c < C ? c : C - 1, sc[h], sh[h]);     // (clamped, masked below: a load inside a conditional is waited for inside it)
+    for (int h = 0; h < 2; ++h) { const int c = c0 + 16 * h + r; bn_issue(a.pro, c < C ? c : C - 1, bl[h]); }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      float mu, is;
+      bn_finish(a.pro, bl[h], mu, is);
+      sc[h] = bl[h].gm * is; sh[h] = bl[h].bt - mu * sc[h];
+    }
+  } else {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int c = c0 + 16 * h + r;
+      bn_fwd_coef(a.pro, c < C ? c : C - 1, sc[h], sh[h]);     // (clamped, masked below: a load inside a conditional is waited for inside it)
+    }
   }
 #pragma unroll
   for (int h = 0; h < 2; ++h)

@@ -154,9 +154,10 @@ __global__ __launch_bounds__(256) void bn_bwd_prep_rows_kernel(const spb_bnbwd_a
     const int c = cb + t < C ? cb + t : C - 1;
     float m = 0.f, iv = 0.f, g1 = 1.f, h1 = 0.f;
     if (a.bn.gamma) {   // (uniform)
+      const float gm = a.bn.gamma[c], bt = a.bn.beta[c];      // requested with the sums, not after them
       bn_moments(a.bn, c, m, iv);
-      g1 = a.bn.gamma[c] * iv;
-      h1 = a.bn.beta[c] - m * g1;
+      g1 = gm * iv;
+      h1 = bt - m * g1;
     }
     tab[t] = g1; tab[64 + t] = h1; tab[128 + t] = m; tab[192 + t] = iv;
   }

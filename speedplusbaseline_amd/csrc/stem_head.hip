@@ -363,9 +363,10 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const spb_head_bwd_args_t
     const int kk = kbase + t < KH ? kbase + t : KH - 1;
     const int c = kk % a.C;
     float m, v;
+    const float gm = a.pro.gamma[c], bt = a.pro.beta[c];      // requested with the sums, not after them
     bn_moments(a.pro, c, m, v);
-    const float g = a.pro.gamma[c] * v;
-    tab[t] = g; tab[HBK + t] = a.pro.beta[c] - m * g; tab[2 * HBK + t] = m; tab[3 * HBK + t] = v;
+    const float g = gm * v;
+    tab[t] = g; tab[HBK + t] = bt - m * g; tab[2 * HBK + t] = m; tab[3 * HBK + t] = v;
   }
 #pragma unroll
   for (int u = 0; u < WLD; ++u) {
@@ -523,8 +524,9 @@ __global__ __launch_bounds__(256) void head_wgrad_kernel(const spb_head_bwd_args
   for (int i = t; i < a.B * 32; i += 256) ds[i] = (i & 31) < a.J ? a.dout[(i >> 5) * a.J + (i & 31)] * a.gscale : 0.f;
   const int ci = t & 7;
   float mu, is;
+  const float gm = a.pro.gamma[c0 + ci], bt = a.pro.beta[c0 + ci];
   bn_moments(a.pro, c0 + ci, mu, is);
-  const float sc = a.pro.gamma[c0 + ci] * is, sh = a.pro.beta[c0 + ci] - mu * sc;
+  const float sc = gm * is, sh = bt - mu * sc;
   __syncthreads();
   if (blockIdx.x == 0 && t < a.J) {
     float s = 0.f;
