@@ -760,6 +760,14 @@ __global__ __launch_bounds__(256) void pw_wgrad_kernel(const spb_wgrad_args_t g,
     xr[i] = ldraw<T>(Xg + mc_ * ldx + klc);                                   \
   }
   if (mbeg < mend) WG_LOAD(mbeg);
+  // this thread's 8 + 8 coefficient columns in registers: read from LDS inside the loop they cost 20 ds_read_b128 per 64-row stage (the
+  // barriers are opaque to the compiler, so nothing loop-invariant is hoisted across them) in a kernel with ~40 registers to its name
+  float z0[8], z1[8], z2[8], a0[8], a1[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    z0[j] = cz[0][cv * 8 + j]; z1[j] = cz[1][cv * 8 + j]; z2[j] = cz[2][cv * 8 + j];
+    a0[j] = ca[0][cv * 8 + j]; a1[j] = ca[1][cv * 8 + j];
+  }
   for (int mb = mbeg; mb < mend; mb += WM) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -775,11 +783,11 @@ __global__ __launch_bounds__(256) void pw_wgrad_kernel(const spb_wgrad_args_t g,
       const bool okn = (m < mend) && (nl < N), okk = (m < mend) && (kl < K);
 #pragma unroll
       for (int j = 0; j < 8; ++j)
-        v[j] = okn ? (gg[j] * cz[0][cv * 8 + j] + zz[j] * cz[1][cv * 8 + j] + cz[2][cv * 8 + j]) : 0.f;
+        v[j] = okn ? (gg[j] * z0[j] + zz[j] * z1[j] + z2[j]) : 0.f;
       st8<T>(Ds + r * LD + cv * 8, v);
 #pragma unroll
       for (int j = 0; j < 8; ++j)
-        v[j] = okk ? act_fwd(xx[j] * ca[0][cv * 8 + j] + ca[1][cv * 8 + j], g.pro_a.act, g.pro_a.slope) : 0.f;
+        v[j] = okk ? act_fwd(xx[j] * a0[j] + a1[j], g.pro_a.act, g.pro_a.slope) : 0.f;
       st8<T>(Xs + r * LD + cv * 8, v);
     }
     lds_barrier();
