@@ -700,7 +700,9 @@ constexpr int WM = 64;   // m rows per LDS stage
 
 // PART: the tile of this row split is stored (plain stores) into slab `split` of g.part ([S][N*K] f32) for spb_partial_reduce
 // instead of being added into dW with f32 atomics
-template <typename T, bool PART>
+// ACTK: activation of the input-side transform -- 0 none, 1 clamp (ReLU / ReLU6), 2 generic (the runtime form costs three vector
+// instructions per element where none or one is needed, in a loop that is bound by its vector instruction count)
+template <typename T, bool PART, int ACTK = 2>
 __global__ __launch_bounds__(256) void pw_wgrad_kernel(const spb_wgrad_args_t g, int rows_per_split) {
   constexpr int LD = WT + 8;
   __shared__ __attribute__((aligned(16))) T Ds[WM * LD];
@@ -762,6 +764,7 @@ __global__ __launch_bounds__(256) void pw_wgrad_kernel(const spb_wgrad_args_t g,
   if (mbeg < mend) WG_LOAD(mbeg);
   // this thread's 8 + 8 coefficient columns in registers: read from LDS inside the loop they cost 20 ds_read_b128 per 64-row stage (the
   // barriers are opaque to the compiler, so nothing loop-invariant is hoisted across them) in a kernel with ~40 registers to its name
+  const float a_hi = act_hi(g.pro_a.act);
   float z0[8], z1[8], z2[8], a0[8], a1[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
@@ -786,8 +789,10 @@ __global__ __launch_bounds__(256) void pw_wgrad_kernel(const spb_wgrad_args_t g,
         v[j] = okn ? (gg[j] * z0[j] + zz[j] * z1[j] + z2[j]) : 0.f;
       st8<T>(Ds + r * LD + cv * 8, v);
 #pragma unroll
-      for (int j = 0; j < 8; ++j)
-        v[j] = okk ? act_fwd(xx[j] * a0[j] + a1[j], g.pro_a.act, g.pro_a.slope) : 0.f;
+      for (int j = 0; j < 8; ++j) {
+        const float u = xx[j] * a0[j] + a1[j];
+        v[j] = okk ? (ACTK == 0 ? u : (ACTK == 1 ? __builtin_amdgcn_fmed3f(u, 0.f, a_hi) : act_fwd(u, g.pro_a.act, g.pro_a.slope))) : 0.f;
+      }
       st8<T>(Xs + r * LD + cv * 8, v);
     }
     lds_barrier();
@@ -884,7 +889,10 @@ int launch_wgrad(const spb_wgrad_args_t& g, hipStream_t stream) {
     if (g.job_out) { *g.job_out = job; return 0; }
     return spb_partial_reduce(&job, 1, stream);
   }
-  hipLaunchKernelGGL((pw_wgrad_kernel<T, false>), dim3(NT * KT * S), dim3(256), 0, stream, g, rps);
+  const int act = g.pro_a.act;
+  if (act == SPB_ACT_NONE) hipLaunchKernelGGL((pw_wgrad_kernel<T, false, 0>), dim3(NT * KT * S), dim3(256), 0, stream, g, rps);
+  else if (act == SPB_ACT_RELU || act == SPB_ACT_RELU6) hipLaunchKernelGGL((pw_wgrad_kernel<T, false, 1>), dim3(NT * KT * S), dim3(256), 0, stream, g, rps);
+  else hipLaunchKernelGGL((pw_wgrad_kernel<T, false, 2>), dim3(NT * KT * S), dim3(256), 0, stream, g, rps);
   SPB_CHECK_LAUNCH();
   return 0;
 }
