@@ -784,16 +784,34 @@ __global__ __launch_bounds__(256) void pw_wgrad_kernel(const spb_wgrad_args_t g,
       }
       cvt8(xr[i], xx);
       const bool okn = (m < mend) && (nl < N), okk = (m < mend) && (kl < K);
+      // rows past the split / columns past the matrix contribute zeros: masked on the PACKED vector (4 selects instead of 8 per operand)
 #pragma unroll
-      for (int j = 0; j < 8; ++j)
-        v[j] = okn ? (gg[j] * z0[j] + zz[j] * z1[j] + z2[j]) : 0.f;
-      st8<T>(Ds + r * LD + cv * 8, v);
+      for (int j = 0; j < 8; ++j) v[j] = gg[j] * z0[j] + zz[j] * z1[j] + z2[j];
+      if constexpr (sizeof(T) == 2) {
+        uint4 q;
+        q.x = pack_bf16x2(v[0], v[1]); q.y = pack_bf16x2(v[2], v[3]); q.z = pack_bf16x2(v[4], v[5]); q.w = pack_bf16x2(v[6], v[7]);
+        if (!okn) q = make_uint4(0, 0, 0, 0);
+        *reinterpret_cast<uint4*>(Ds + r * LD + cv * 8) = q;
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = okn ? v[j] : 0.f;
+        st8<T>(Ds + r * LD + cv * 8, v);
+      }
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const float u = xx[j] * a0[j] + a1[j];
-        v[j] = okk ? (ACTK == 0 ? u : (ACTK == 1 ? __builtin_amdgcn_fmed3f(u, 0.f, a_hi) : act_fwd(u, g.pro_a.act, g.pro_a.slope))) : 0.f;
+        v[j] = ACTK == 0 ? u : (ACTK == 1 ? __builtin_amdgcn_fmed3f(u, 0.f, a_hi) : act_fwd(u, g.pro_a.act, g.pro_a.slope));
       }
-      st8<T>(Xs + r * LD + cv * 8, v);
+      if constexpr (sizeof(T) == 2) {
+        uint4 q;
+        q.x = pack_bf16x2(v[0], v[1]); q.y = pack_bf16x2(v[2], v[3]); q.z = pack_bf16x2(v[4], v[5]); q.w = pack_bf16x2(v[6], v[7]);
+        if (!okk) q = make_uint4(0, 0, 0, 0);
+        *reinterpret_cast<uint4*>(Xs + r * LD + cv * 8) = q;
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = okk ? v[j] : 0.f;
+        st8<T>(Xs + r * LD + cv * 8, v);
+      }
     }
     lds_barrier();
     if (mb + WM < mend) WG_LOAD(mb + WM);
