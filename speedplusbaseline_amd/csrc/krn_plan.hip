@@ -243,6 +243,8 @@ static int g_side_wgrad = 1;
 static int g_skip_side = 0;            // TIMING EXPERIMENT ONLY (spb_debug_set_launch_events(2|4)): 2 drops the pointwise, 4 the depthwise side-stream weight gradients
 static int g_launch_events = 1;        // fork on the completion event of the preceding GEMM launch instead of an event record
 extern "C" int spb_debug_set_launch_events(int on) { g_launch_events = on & 1; g_skip_side = on & 6; return 0; }
+static int g_side_priority = 0;
+extern "C" int spb_debug_set_side_priority(int on) { g_side_priority = on; return 0; }
 static int g_wgrad_flush_at_dw = 1;
 static int g_wgrad_min_flush = 1;      // flush at a depthwise kernel only with at least this many queued
 extern "C" int spb_debug_set_wgrad_min_flush(int n);
@@ -899,7 +901,15 @@ extern "C" int spb_krn_ctx_create(spb_krn_t* m, int batch, void* workspace, spb_
   e = hipMemset(c->ws + c->partial_off, 0, (size_t)c->S * batch * m->Jp * sizeof(float));
   if (e != hipSuccess) { delete c; return (int)e; }
   // side stream + events are created here, outside any stream capture
-  if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess) c->side = nullptr;
+  {
+    // side stream of the weight gradients.  g_side_priority (spb_debug_set_side_priority, A/B): 0 default priority, 1 the lowest the device
+    // offers -- the launch stream's short, latency-bound kernels then get their workgroups placed ahead of the side stream's
+    int least = 0, greatest = 0;
+    hipError_t se = hipErrorUnknown;
+    if (g_side_priority && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess)
+      se = hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, least);
+    if (se != hipSuccess && hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess) c->side = nullptr;
+  }
   if (hipEventCreateWithFlags(&c->join_ev, hipEventDisableTiming) != hipSuccess) { delete c; return SPB_E_STATE; }
   if (hipEventCreateWithFlags(&c->bucket_ev, hipEventDisableTiming) != hipSuccess) { delete c; return SPB_E_STATE; }
   if (hipEventCreateWithFlags(&c->prep_ev, hipEventDisableTiming) != hipSuccess) { delete c; return SPB_E_STATE; }
