@@ -233,14 +233,42 @@ __global__ __launch_bounds__(256) void bn_param_grads_kernel(const spb_bnupd_ent
 __global__ __launch_bounds__(256) void bn_param_grads_zero_kernel(const spb_bnupd_entry_t* tab, float* stats, float* grads) {
   const spb_bnupd_entry_t e = tab[blockIdx.x];
   if (e.bsums_off >= 0) {
+    // the old gradient values and every replica sum of the pass are requested together (the replica-count test is taken once, outside:
+    // inside bn_replica_sums each of the four channels waited for its own loads, then the read-modify-write made a further round trip --
+    // this launch sits between the last weight gradient and the optimizer, with nothing beside it)
+    const float* bs = stats + e.bsums_off;
     for (int cb = threadIdx.x; cb < e.C; cb += 1024) {
-      float s1[4], s2[4];
+      float s1[4], s2[4], og[4], ob[4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) { const int c = cb + 256 * j; bn_replica_sums(stats + e.bsums_off, e.R, e.C, c < e.C ? c : e.C - 1, s1[j], s2[j]); }
+      for (int j = 0; j < 4; ++j) {
+        const int c = cb + 256 * j, cc = c < e.C ? c : e.C - 1;
+        og[j] = grads[e.gamma_off + cc]; ob[j] = grads[e.beta_off + cc];
+      }
+      if (e.R == 1) {   // (uniform)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const int c = cb + 256 * j, cc = c < e.C ? c : e.C - 1; s1[j] = bs[cc]; s2[j] = bs[e.C + cc]; }
+      } else {
+        float va[4][SPB_MAX_REPLICAS], vb[4][SPB_MAX_REPLICAS];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int c = cb + 256 * j, cc = c < e.C ? c : e.C - 1;
+#pragma unroll
+          for (int i = 0; i < SPB_MAX_REPLICAS; ++i) {
+            const size_t o = (size_t)(i < e.R ? i : 0) * 2 * e.C + cc;
+            va[j][i] = bs[o]; vb[j][i] = bs[o + e.C];
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          s1[j] = 0.f; s2[j] = 0.f;
+#pragma unroll
+          for (int i = 0; i < SPB_MAX_REPLICAS; ++i) { s1[j] += i < e.R ? va[j][i] : 0.f; s2[j] += i < e.R ? vb[j][i] : 0.f; }
+        }
+      }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int c = cb + 256 * j;
-        if (c < e.C) { grads[e.gamma_off + c] += s2[j]; grads[e.beta_off + c] += s1[j]; }
+        if (c < e.C) { grads[e.gamma_off + c] = og[j] + s2[j]; grads[e.beta_off + c] = ob[j] + s1[j]; }
       }
     }
   }
