@@ -289,8 +289,8 @@ def test_bf16_train_pass_tracks_float64_oracle_at_bs48(device, conditioned):
     # the next, so the bars below are the envelope of settled states, not a property of one lucky run.)
     # What the eight passes show (round 4, some forty states): within ONE state they agree to the third digit -- the deviation from float64 is
     # a property of the state, not run-to-run noise: 0.990 .. 0.991 on one state, 0.861 .. 0.901 at norm ratio 1.22 .. 1.31 on another
-    # (BatchNorm channels whose mean is hundreds of standard deviations make E[z^2] - E[z]^2 of bf16-ROUNDED z carry the rounding variance:
-    # a consistent scale error of those layers, the same for torch.autocast).  Settled states (shifted-target gradient norm below
+    # (suspected: BatchNorm channels whose mean is many standard deviations, where the bf16 rounding of the stored pre-activation is a large
+    # fraction of the deviation the consumer normalises by; scratch/grad_probe.py: identical on the kernels of round 3).  Settled states (shifted-target gradient norm below
     # G_SETTLED) gave cosine 0.882 .. 0.995, norm ratio 0.97 .. 1.26; unsettled ones down to 0.42.  The bars are for settled states; a run
     # whose conditioning never got there within its rounds reports that and skips them (its loss / statistics checks above still count).
     if CONDITIONED_GNORM is None or CONDITIONED_GNORM >= G_SETTLED:
