@@ -351,7 +351,7 @@ __global__ __launch_bounds__(256, (RF == 1 && sizeof(T) == 2) ? (((BK == 64 && P
 // 4 workgroups (1024 on the chip) are resident at once (scratch/occ_probe.hip); the 1323- and 1764-workgroup launches of the
 // 14x14 / 28x28 layers ran a second, nearly empty round (phase timestamps: last workgroup started 7-11 us into a 12-19 us
 // launch).  Measured in the step: 2048 -> 3.144 ms, 1280 -> 3.111, 1024 -> 3.109, 900 -> 3.116.  spb_debug_set_gemm_wg_cap
-int g_gemm_wg_cap = 1024;
+int g_gemm_wg_cap = 768;    // end of round 4 (with the 384-workgroup weight gradients beside it): 512 -> 2.669 ms, 640 -> 2.677, 768 -> 2.663, 896 -> 2.675, 1024 -> 2.685
 
 template <typename T, int RF, int BN, int BK, int PRO, int EPI>
 int launch_gemm(const spb_gemm_args_t& g, hipStream_t stream) {
@@ -874,7 +874,9 @@ __global__ __launch_bounds__(256) void pw_wgrad_kernel(const spb_wgrad_args_t g,
       }
 }
 
-int g_wgrad_target_wgs = 1024;   // row splits so that a launch has about this many workgroups (spb_debug_set_wgrad_target)
+int g_wgrad_target_wgs = 384;    // row splits so that a launch has about this many workgroups (spb_debug_set_wgrad_target).  End of round 4, in the step:
+                                 // 256 -> 2.693 ms, 384 -> 2.670, 512 -> 2.685, 768 -> 2.702, 1024 -> 2.727, 2048 -> 2.760 (fewer, longer workgroups on the side
+                                 // stream take less from the launch stream's kernels and issue fewer atomics)
 int g_wgrad_part_target = 512;   // the same for the partial-store form (its splits cost slab traffic instead of atomics)
 
 // floats of partial-sum scratch launch_wgrad uses at most for this shape (the KRN plan sizes its workspace with it)
