@@ -634,6 +634,7 @@ int spb_debug_set_gemm_dma(int on); /* 1: small-M bf16 pointwise GEMMs use the L
 int spb_debug_set_dw_mode(int mode); /* depthwise fwd/dgrad: 1 plane kernels on maps up to spb_debug_set_dw_plane_max_w columns wide (14x14 and 7x7 by default), row-unit kernels elsewhere (default); 0 row-unit kernels only */
 int spb_debug_set_fused_pw_bwd(int on); /* 0: the KRN plan never uses spb_pwconv_bwd_fused */
 int spb_debug_set_stem_mfma(int on); /* 0: bf16 stem uses the scalar kernels instead of the MFMA implicit GEMM */
+int spb_debug_set_dw_wgrad_blocks(int n); /* workgroups of the depthwise weight-gradient-only launches (A/B) */
 int spb_debug_set_side_priority(int on); /* 1: contexts created afterwards put their weight-gradient side stream at the lowest stream priority (A/B) */
 int spb_debug_set_stem_tile(int on); /* 0: the bf16 stem kernels gather their taps from global memory instead of an LDS tile (A/B) */
 int spb_debug_set_stem_wgrad_tile(int rows); /* output rows per workgroup of the LDS-tile stem weight gradient (8 | 16; 0: gather kernel) */

@@ -269,6 +269,7 @@ SYMBOLS = {
     "spb_debug_set_stem_mfma": (i32, [i32]),
     "spb_debug_set_stem_tile": (i32, [i32]),
     "spb_debug_set_side_priority": (i32, [i32]),
+    "spb_debug_set_dw_wgrad_blocks": (i32, [i32]),
     "spb_debug_set_stem_wgrad_tile": (i32, [i32]),
     "spb_debug_set_fused_pw_bwd": (i32, [i32]),
     "spb_debug_set_dw_rows": (i32, [i32]),

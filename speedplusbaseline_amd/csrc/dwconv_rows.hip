@@ -601,6 +601,8 @@ void allow_lds(K kernel, size_t bytes) {
 }  // namespace
 
 // rows > 0: rows per task; rows < 0: -rows = target block count (experiments)
+static int g_dw_wgrad_blocks = 512;   // workgroups of the weight-gradient-only instance (side stream); spb_debug_set_dw_wgrad_blocks
+extern "C" int spb_debug_set_dw_wgrad_blocks(int n) { if (n > 0) g_dw_wgrad_blocks = n; return 0; }
 extern "C" int spb_debug_set_dw_xcd(int on) { g_xcd_pair = on; return 0; }
 extern "C" int spb_debug_set_dw_rows(int rows) { if (rows >= 0) g_rows_override = rows; else g_blocks_override = -rows; return 0; }
 
@@ -631,7 +633,7 @@ int spb_dwr_fwd(int dtype, const spb_dw_args_t* a, hipStream_t s) {
 int spb_dwr_wgrad(int dtype, const spb_dw_args_t* a, hipStream_t s) {
   const int st = a->stride;
   const int OH = (a->H - 1) / st + 1, OW = (a->W - 1) / st + 1;
-  const Geo g = make_geo(a->B, a->C, OH, OW, st == 1 ? 14 : 15, st == 1 ? 2 : 1, 512);
+  const Geo g = make_geo(a->B, a->C, OH, OW, st == 1 ? 14 : 15, st == 1 ? 2 : 1, g_dw_wgrad_blocks);
   const int nquads = ((a->C >> 3) + 3) / 4;
   const dim3 grid((unsigned)(nquads * g.nb));
   const int es = dtype == SPB_BF16 ? 1 : 2;
