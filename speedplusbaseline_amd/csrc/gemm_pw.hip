@@ -705,8 +705,10 @@ constexpr int WM = 64;   // m rows per LDS stage
 template <typename T, bool PART, int ACTK = 2>
 __global__ __launch_bounds__(256) void pw_wgrad_kernel(const spb_wgrad_args_t g, int rows_per_split) {
   constexpr int LD = WT + 8;
-  __shared__ __attribute__((aligned(16))) T Ds[WM * LD];
-  __shared__ __attribute__((aligned(16))) T Xs[WM * LD];
+  // two copies of each operand tile: the transform of stage s+1 writes the other copy while slower waves still read stage s, so ONE
+  // barrier per stage is enough (with one copy a second barrier had to close every stage)
+  __shared__ __attribute__((aligned(16))) T Ds2[2][WM * LD];
+  __shared__ __attribute__((aligned(16))) T Xs2[2][WM * LD];
   __shared__ float cz[3][WT];
   __shared__ float ca[2][WT];
 
@@ -771,7 +773,10 @@ __global__ __launch_bounds__(256) void pw_wgrad_kernel(const spb_wgrad_args_t g,
     z0[j] = cz[0][cv * 8 + j]; z1[j] = cz[1][cv * 8 + j]; z2[j] = cz[2][cv * 8 + j];
     a0[j] = ca[0][cv * 8 + j]; a1[j] = ca[1][cv * 8 + j];
   }
-  for (int mb = mbeg; mb < mend; mb += WM) {
+  int par = 0;
+  for (int mb = mbeg; mb < mend; mb += WM, par ^= 1) {
+    T* Ds = Ds2[par];
+    T* Xs = Xs2[par];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int r = rw + 32 * i, m = mb + r;
@@ -855,7 +860,6 @@ __global__ __launch_bounds__(256) void pw_wgrad_kernel(const spb_wgrad_args_t g,
             acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(pf[a], qf[b], acc[a][b], 0, 0, 0);
       }
     }
-    lds_barrier();
   }
 #undef WG_LOAD
 
