@@ -365,6 +365,26 @@ void spb_krn_ctx_destroy(spb_krn_ctx_t* c);
  * chain.  on = 0 keeps every launch on `stream` (use this when capturing into a hipGraph: measured slower there). */
 int spb_krn_ctx_set_side_stream(spb_krn_ctx_t* c, int on);
 
+/* ---- reproducible mode (libspb_hip_det.so: the KRN sources compiled with -DSPB_DET, csrc/common.h) --------------------------
+ * The reference leaves training non-deterministic (utils.py:297-298: cudnn.benchmark = True, cudnn.deterministic = False); so does
+ * libspb_hip.so (float atomics in the batch-sum and weight-gradient kernels).  The twin library accumulates every such sum EXACTLY
+ * (four 64-bit fixed-point windows per float slot, integer atomics: order-independent), so a training run is a pure function of its
+ * inputs: bit-identical in every process, whatever ran on the device before.  Used by tests/test_parity_conditioned_gpu.py to
+ * condition ONE reproducible state, and available to users as KrnEngine(..., deterministic=True).
+ *   spb_det_register(lo, n, shadow): float range [lo, lo+n) accumulates into shadow[4*n] (int64, zero-initialised, caller-owned);
+ *   spb_det_flush(lo, stream): fold the windows of that region into the floats and clear them;
+ *   spb_det_misses(): float atomics that hit no region since the last call (0 = the run was fully exact);
+ *   spb_krn_set_det / spb_krn_ctx_set_det: the plan keeps every launch on the caller's stream and flushes after each launch.
+ * libspb_hip.so exports the same symbols; there spb_det_available() is 0 and the others return SPB_E_UNSUPPORTED.            */
+int spb_det_available(void);
+int spb_det_register(const float* lo, long long n_floats, long long* shadow);
+int spb_det_unregister(const float* lo);
+int spb_det_flush(const float* lo, spb_stream_t stream);
+long long spb_det_misses(void);
+int spb_krn_set_det(spb_krn_t* m, int on);
+int spb_krn_ctx_set_det(spb_krn_ctx_t* c, int on);
+int spb_krn_ctx_stats(spb_krn_ctx_t* c, float** ptr, long long* n_floats);
+
 /* refresh compute-dtype weight copies (W, W^T, permuted head) from the f32 parameters */
 int spb_krn_prepare_weights(spb_krn_t* m, spb_stream_t stream);
 /* forward.  training=1: batch statistics + running-stat update; training=2: batch statistics, the running-stat update is

@@ -288,6 +288,14 @@ SYMBOLS = {
     "spb_debug_set_gconv_wide_rotate": (i32, [i32]),
     "spb_debug_set_gconv_wide_delay": (i32, [i32]),
     "spb_version": (C.c_char_p, []),
+    "spb_det_available": (i32, []),
+    "spb_det_register": (i32, [vp, i64, vp]),
+    "spb_det_unregister": (i32, [vp]),
+    "spb_det_flush": (i32, [vp, vp]),
+    "spb_det_misses": (i64, []),
+    "spb_krn_set_det": (i32, [vp, i32]),
+    "spb_krn_ctx_set_det": (i32, [vp, i32]),
+    "spb_krn_ctx_stats": (i32, [vp, C.POINTER(vp), C.POINTER(i64)]),
 }
 
 _lib = None
@@ -347,6 +355,30 @@ def lib_f16():
                 fn.argtypes = args
         _lib_f16 = l
     return _lib_f16
+
+
+_lib_det = None
+LIB_DET_PATH = os.path.join(_HERE, "libspb_hip_det.so")
+
+
+def lib_det():
+    """The reproducible twin (the KRN sources compiled with -DSPB_DET, csrc/common.h): same entry points; float atomics are exact
+    fixed-point accumulations, so results do not depend on workgroup arrival order.  KrnEngine(..., deterministic=True) uses it."""
+    global _lib_det
+    if _lib_det is None:
+        if not os.path.exists(LIB_DET_PATH):
+            raise RuntimeError("libspb_hip_det.so is missing (%s). Build it with `python -m speedplusbaseline_amd.build`." % LIB_DET_PATH)
+        import torch  # noqa: F401
+        l = C.CDLL(LIB_DET_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(l, name, None)          # the twin exports the KRN subset of the C-ABI
+            if fn is not None:
+                fn.restype = res
+                fn.argtypes = args
+        if l.spb_det_available() != 1:
+            raise RuntimeError("libspb_hip_det.so was not built with -DSPB_DET")
+        _lib_det = l
+    return _lib_det
 
 
 def lib_for(precision):

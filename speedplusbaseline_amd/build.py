@@ -20,6 +20,10 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-res
 # elementwise / optimizer kernels.  The KRN-only kernels keep bfloat16 bit tricks of their own and are not part of it.
 LIB_F16 = os.path.join(HERE, "libspb_hip_f16.so")
 SOURCES_F16 = ["gemm_pw.hip", "elemwise.hip", "spn.hip", "spn_fc.hip", "spn_conv.hip"]
+# Reproducible twin (csrc/common.h, -DSPB_DET): the KRN / DANN kernels and the plan with exact (order-independent) accumulation in
+# place of float atomics.  KrnEngine(..., deterministic=True) and tests/test_parity_conditioned_gpu.py use it.
+LIB_DET = os.path.join(HERE, "libspb_hip_det.so")
+SOURCES_DET = ["gemm_pw.hip", "gemm_sk.hip", "gemm_os.hip", "gemm_big.hip", "gemm_rs.hip", "pw_bwd_fused.hip", "dwconv_rows.hip", "dwconv_plane.hip", "dwconv_tile.hip", "stem_head.hip", "stem_mfma.hip", "elemwise.hip", "krn_plan.hip"]
 
 
 def _hipcc():
@@ -45,7 +49,7 @@ def build(force=False, verbose=True):
     srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
     stamp = os.path.join(OBJDIR, "stamp.txt")
     want = _digest(srcs + headers)
-    if not force and os.path.exists(LIB) and os.path.exists(LIB_F16) and os.path.exists(stamp) and open(stamp).read().strip() == want:
+    if not force and os.path.exists(LIB) and os.path.exists(LIB_F16) and os.path.exists(LIB_DET) and os.path.exists(stamp) and open(stamp).read().strip() == want:
         return LIB
     hipcc = _hipcc()
 
@@ -63,13 +67,13 @@ def build(force=False, verbose=True):
             f.write(d)
         return obj
 
-    def compile_f16(src):
-        obj = os.path.join(OBJDIR, os.path.basename(src) + ".f16.o")
-        dig = os.path.join(OBJDIR, os.path.basename(src) + ".f16.sha")
+    def compile_twin(src, tag, define):
+        obj = os.path.join(OBJDIR, os.path.basename(src) + ".%s.o" % tag)
+        dig = os.path.join(OBJDIR, os.path.basename(src) + ".%s.sha" % tag)
         d = _digest([src] + headers)
         if not force and os.path.exists(obj) and os.path.exists(dig) and open(dig).read().strip() == d:
             return obj
-        cmd = [hipcc] + FLAGS + ["-DSPB_F16", "-c", src, "-o", obj]
+        cmd = [hipcc] + FLAGS + [define, "-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
@@ -78,10 +82,12 @@ def build(force=False, verbose=True):
         return obj
 
     srcs16 = [os.path.join(CSRC, s) for s in SOURCES_F16]
+    srcsdet = [os.path.join(CSRC, s) for s in SOURCES_DET]
     with ThreadPoolExecutor(max_workers=4) as ex:
         objs = list(ex.map(compile_one, srcs))
-        objs16 = list(ex.map(compile_f16, srcs16))
-    for out, ob in ((LIB, objs), (LIB_F16, objs16)):
+        objs16 = list(ex.map(lambda s_: compile_twin(s_, "f16", "-DSPB_F16"), srcs16))
+        objsdet = list(ex.map(lambda s_: compile_twin(s_, "det", "-DSPB_DET"), srcsdet))
+    for out, ob in ((LIB, objs), (LIB_F16, objs16), (LIB_DET, objsdet)):
         cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + ob
         if verbose:
             print(" ".join(cmd), flush=True)

@@ -16,6 +16,68 @@ template <typename P, typename V> __device__ __forceinline__ void spb_no_atomic(
 #define atomicAdd(p, v) spb_no_atomic(p, v)
 #endif
 
+// ---------------------------------------------------------------------------------------------
+// -DSPB_DET: the REPRODUCIBLE twin of the library (libspb_hip_det.so, speedplusbaseline_amd/build.py).  Every float atomicAdd of
+// the KRN kernels -- BatchNorm batch sums, backward sums, split-M weight gradients -- becomes an EXACT accumulation: the target
+// float slot has a shadow of four 64-bit integer windows (fixed point with least significant bits 2^0, 2^-40, 2^-80, 2^-120);
+// a contribution is split exactly over the windows (a float's 24-bit mantissa straddles at most two) and added with integer
+// atomics.  Integer addition is associative, so the accumulated value does not depend on the order in which workgroups arrive:
+// the same inputs give the same bits in every run, whatever else ran on the device before.  spb_det_flush (krn_plan.hip) folds
+// the windows into the float slot after each launch (plan: Runner::ok) -- kernels and their consumers are unchanged.
+// The regions (float range -> shadow) are registered per engine / context (spb_det_register); an atomic outside every region
+// falls back to the float atomic and is COUNTED (spb_det_misses), so a test can assert that a run was fully covered.
+// Cost: 1-2 integer atomics per float atomic + one flush launch per kernel launch: a test / reproducibility mode, not the bench path.
+#ifdef SPB_DET
+struct spb_det_region_t { const float* lo; const float* hi; long long* shadow; };
+#define SPB_DET_MAX_REGIONS 16
+struct spb_det_table_t { spb_det_region_t r[SPB_DET_MAX_REGIONS]; int n; int pad; };
+static __device__ spb_det_table_t g_spb_det_table;          // one copy per translation unit (no relocatable device code)
+static __device__ unsigned long long g_spb_det_misses;
+typedef int (*spb_det_tu_fn)(const spb_det_table_t*, unsigned long long*);
+extern "C" void spb_det_register_tu(spb_det_tu_fn f);       // krn_plan.hip: the list of per-file setters
+// (t != null: upload the table; misses != null: add and clear this file's miss counter)
+static int spb_det_tu_sync(const spb_det_table_t* t, unsigned long long* misses) {
+  if (t && hipMemcpyToSymbol(HIP_SYMBOL(g_spb_det_table), t, sizeof(*t)) != hipSuccess) { (void)hipGetLastError(); return 1; }
+  if (misses) {
+    unsigned long long m = 0, z = 0;
+    if (hipMemcpyFromSymbol(&m, HIP_SYMBOL(g_spb_det_misses), sizeof(m)) != hipSuccess) { (void)hipGetLastError(); return 1; }
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_spb_det_misses), &z, sizeof(z));
+    *misses += m;
+  }
+  return 0;
+}
+namespace { struct spb_det_tu_init { spb_det_tu_init() { spb_det_register_tu(&spb_det_tu_sync); } }; static spb_det_tu_init spb_det_tu_init_; }
+
+__device__ __forceinline__ void spb_det_add_exact(long long* sh, float v) {
+  double r = (double)v;
+  const double q0 = trunc(r);           r -= q0;
+  const double q1 = trunc(r * 0x1p40);  r -= q1 * 0x1p-40;
+  const double q2 = trunc(r * 0x1p80);  r -= q2 * 0x1p-80;
+  const double q3 = trunc(r * 0x1p120);
+  unsigned long long* u = reinterpret_cast<unsigned long long*>(sh);
+  if (q0 != 0.0) (atomicAdd)(u + 0, (unsigned long long)(long long)q0);
+  if (q1 != 0.0) (atomicAdd)(u + 1, (unsigned long long)(long long)q1);
+  if (q2 != 0.0) (atomicAdd)(u + 2, (unsigned long long)(long long)q2);
+  if (q3 != 0.0) (atomicAdd)(u + 3, (unsigned long long)(long long)q3);
+}
+template <typename P, typename V> __device__ __forceinline__ auto spb_det_atomic(P* p, V v) -> decltype((atomicAdd)(p, v)) { return (atomicAdd)(p, v); }
+__device__ __forceinline__ float spb_det_atomic(float* p, float v) {
+  if (v == 0.f) return 0.f;
+  if (fabsf(v) < 0x1p39f) {            // (non-finite or huge: the float slot takes it directly and stays non-finite through the flush)
+    const int n = g_spb_det_table.n;
+    for (int i = 0; i < n; ++i) {
+      const spb_det_region_t& R = g_spb_det_table.r[i];
+      if (p >= R.lo && p < R.hi) { spb_det_add_exact(R.shadow + 4 * (p - R.lo), v); return 0.f; }
+    }
+    (atomicAdd)(&g_spb_det_misses, 1ull);
+  }
+  return (atomicAdd)(p, v);
+}
+#undef SPB_ATOMIC_W
+#define SPB_ATOMIC_W(p, v) spb_det_atomic(p, v)
+#define atomicAdd(p, v) spb_det_atomic(p, v)
+#endif
+
 typedef unsigned short bf16_t;  // raw 16-bit storage element: bfloat16 bits -- or IEEE half bits in the -DSPB_F16 twin library (below)
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 // The 16-bit storage format is a COMPILE-TIME property of the library: libspb_hip.so stores bfloat16, its twin libspb_hip_f16.so

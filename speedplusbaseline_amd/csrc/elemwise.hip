@@ -101,6 +101,16 @@ __global__ __launch_bounds__(256) void bn_bwd_prep_kernel(const spb_bnbwd_args_t
     }
     st8<T>(G + (size_t)p * C + c0, d);
   }
+#ifdef SPB_DET   // reproducible twin (common.h): no LDS float atomics (their order is not fixed); every thread adds exactly
+  {
+    const int rep = blockIdx.x % a.oR;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      atomicAdd(a.osums + (size_t)rep * 2 * C + c0 + j, s1[j]);
+      atomicAdd(a.osums + (size_t)rep * 2 * C + C + c0 + j, s2[j]);
+    }
+  }
+#else
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     atomicAdd(&red[c0 + j], s1[j]);
@@ -109,6 +119,7 @@ __global__ __launch_bounds__(256) void bn_bwd_prep_kernel(const spb_bnbwd_args_t
   __syncthreads();
   const int rep = blockIdx.x % a.oR;
   for (int i = threadIdx.x; i < 2 * C; i += 256) atomicAdd(a.osums + (size_t)rep * 2 * C + i, red[i]);
+#endif
 }
 
 // Row-parallel form (round 3): grid (ceil(C/64), row ranges of BBP_ROWS).  A workgroup owns 64 channels (8 lanes x 8-channel

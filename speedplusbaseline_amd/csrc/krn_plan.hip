@@ -58,6 +58,7 @@ struct spb_krn {
   std::vector<spb_prep_entry_t> prep;
   int dtype = -1;
   std::string prefix;
+  bool det = false;   // reproducible mode (libspb_hip_det.so, spb_krn_set_det): exact accumulation + flush after every launch, one stream
 
   long long add_param(const std::string& name, std::vector<int> shape) {
     PInfo p; p.name = prefix + name; p.ndim = (int)shape.size(); p.numel = 1;
@@ -133,6 +134,7 @@ struct spb_krn_ctx {
   bool bucket_recorded = false;
   bool bucket_on = false;           // spb_krn_ctx_set_bucket: single-GPU runs skip the mid-backward join
   int n_fork = 0;
+  bool det = false;                 // spb_krn_ctx_set_det: this context's batch-sum arena has an exact-accumulation shadow
   ~spb_krn_ctx() {
     for (hipEvent_t e : fork_ev) hipEventDestroy(e);
     for (hipEvent_t e : prof_ev) hipEventDestroy(e);
@@ -233,6 +235,99 @@ void build_model(spb_krn* m, int nK, bool dann) {
 // ---------------------------------------------------------------------------------------------------------------
 // An operand as a consumer sees it: tensor + its BatchNorm / activation.  join: the residual sum of an inverted-residual block that
 // has not been materialised yet -- bn(ptr) + bn2(ptr2) -- which the next expand convolution forms while loading and writes to `mat`
+
+// ---- reproducible mode (common.h, -DSPB_DET) --------------------------------------------------------------------------
+// Host registry of the (float range -> shadow windows) regions; every translation unit of the twin library holds its own device copy
+// of the table (no relocatable device code), uploaded through the setters the files registered at load time.
+#ifdef SPB_DET
+namespace {
+std::vector<spb_det_tu_fn>& det_tus() { static std::vector<spb_det_tu_fn> v; return v; }
+spb_det_table_t& det_table() { static spb_det_table_t t; return t; }
+int det_upload() {
+  if (hipDeviceSynchronize() != hipSuccess) return SPB_E_STATE;   // no kernel may be reading the old table
+  for (spb_det_tu_fn f : det_tus()) (void)f(&det_table(), nullptr);   // (a file without float atomics has no table symbol: ignored)
+  return 0;
+}
+__global__ void det_flush_kernel(float* __restrict__ f, long long* __restrict__ sh, long long n) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const longlong2 a = *reinterpret_cast<const longlong2*>(sh + 4 * i), b = *reinterpret_cast<const longlong2*>(sh + 4 * i + 2);
+    if ((a.x | a.y | b.x | b.y) != 0) {
+      const double v = (((double)b.y * 0x1p-120 + (double)b.x * 0x1p-80) + (double)a.y * 0x1p-40) + (double)a.x;
+      f[i] += (float)v;
+      *reinterpret_cast<longlong2*>(sh + 4 * i) = longlong2{0, 0};
+      *reinterpret_cast<longlong2*>(sh + 4 * i + 2) = longlong2{0, 0};
+    }
+  }
+}
+// fold the shadow windows of the region that starts at `lo` into its float slots (and clear them), on `st`
+int det_flush(const float* lo, hipStream_t st) {
+  const spb_det_table_t& t = det_table();
+  for (int i = 0; i < t.n; ++i)
+    if (t.r[i].lo == lo) {
+      const long long n = t.r[i].hi - t.r[i].lo;
+      const int blocks = (int)std::min<long long>((n + 255) / 256, 2048);
+      hipLaunchKernelGGL(det_flush_kernel, dim3(blocks), dim3(256), 0, st, const_cast<float*>(lo), t.r[i].shadow, n);
+      return hipGetLastError() == hipSuccess ? 0 : SPB_E_STATE;
+    }
+  return SPB_E_STATE;
+}
+}  // namespace
+extern "C" void spb_det_register_tu(spb_det_tu_fn f) { det_tus().push_back(f); }
+extern "C" int spb_det_available(void) { return 1; }
+extern "C" int spb_det_register(const float* lo, long long n_floats, long long* shadow) {
+  if (!lo || n_floats <= 0 || !shadow) return SPB_E_ARG;
+  spb_det_table_t& t = det_table();
+  for (int i = 0; i < t.n; ++i) if (t.r[i].lo == lo) { t.r[i].hi = lo + n_floats; t.r[i].shadow = shadow; return det_upload(); }
+  if (t.n >= SPB_DET_MAX_REGIONS) return SPB_E_STATE;
+  t.r[t.n].lo = lo; t.r[t.n].hi = lo + n_floats; t.r[t.n].shadow = shadow; t.n++;
+  return det_upload();
+}
+extern "C" int spb_det_unregister(const float* lo) {
+  spb_det_table_t& t = det_table();
+  for (int i = 0; i < t.n; ++i)
+    if (t.r[i].lo == lo) { for (int j = i + 1; j < t.n; ++j) t.r[j - 1] = t.r[j]; t.n--; return det_upload(); }
+  return SPB_E_ARG;
+}
+extern "C" int spb_det_flush(const float* lo, spb_stream_t stream) { return det_flush(lo, (hipStream_t)stream); }
+extern "C" long long spb_det_misses(void) {   // float atomics that found no region since the last call (synchronises the device)
+  if (hipDeviceSynchronize() != hipSuccess) return SPB_E_STATE;
+  unsigned long long m = 0;
+  for (spb_det_tu_fn f : det_tus()) (void)f(nullptr, &m);
+  return (long long)m;
+}
+#else
+extern "C" int spb_det_available(void) { return 0; }
+extern "C" int spb_det_register(const float*, long long, long long*) { return SPB_E_UNSUPPORTED; }
+extern "C" int spb_det_unregister(const float*) { return SPB_E_UNSUPPORTED; }
+extern "C" int spb_det_flush(const float*, spb_stream_t) { return SPB_E_UNSUPPORTED; }
+extern "C" long long spb_det_misses(void) { return SPB_E_UNSUPPORTED; }
+#endif
+// Switch a bound engine / a context to the reproducible mode.  The caller has registered the gradient arena (spb_krn_bind's grads) and
+// the context's batch-sum arena (spb_krn_ctx_stats) with spb_det_register; the plan then keeps every launch on the one stream and folds
+// the shadows after each launch.  Only libspb_hip_det.so accepts it.
+extern "C" int spb_krn_set_det(spb_krn_t* m, int on) {
+  if (!m) return SPB_E_ARG;
+#ifdef SPB_DET
+  m->det = on != 0; return 0;
+#else
+  return on ? SPB_E_UNSUPPORTED : 0;
+#endif
+}
+extern "C" int spb_krn_ctx_set_det(spb_krn_ctx_t* c, int on) {
+  if (!c) return SPB_E_ARG;
+#ifdef SPB_DET
+  c->det = on != 0; return 0;
+#else
+  return on ? SPB_E_UNSUPPORTED : 0;
+#endif
+}
+// the context's batch-sum arena (what spb_det_register shadows): pointer and length in floats
+extern "C" int spb_krn_ctx_stats(spb_krn_ctx_t* c, float** ptr, long long* n_floats) {
+  if (!c || !ptr || !n_floats) return SPB_E_ARG;
+  *ptr = reinterpret_cast<float*>(c->ws + c->stats_off); *n_floats = (long long)c->stats_floats;
+  return 0;
+}
+
 struct Src { const void* ptr; spb_bnref_t ref; const void* ptr2 = nullptr; spb_bnref_t ref2 = spb_bnref_t(); void* mat = nullptr; };
 
 static int g_side_wgrad = 1;
@@ -296,7 +391,17 @@ static long long g_fused_pw_bwd_min_m = 100000;  // spb_debug_set_fused_pw_bwd(v
 struct Runner {
   spb_krn_ctx* c; spb_krn* m; hipStream_t st; int dt; int err = 0;
   Runner(spb_krn_ctx* c_, hipStream_t s) : c(c_), m(c_->m), st(s), dt(c_->m->dtype) {}
-  void ok(int e) { if (e != 0 && err == 0) err = e; }
+  void ok(int e) {
+    if (e != 0 && err == 0) err = e;
+#ifdef SPB_DET   // reproducible mode: fold the exact batch-sum shadows into the float slots the next launch reads
+    if (c->det) { const int f = det_flush(stats(), st); if (f != 0 && err == 0) err = f; }
+#endif
+  }
+  void det_flush_grads() {
+#ifdef SPB_DET
+    if (m->det && m->G) { const int f = det_flush(m->G, st); if (f != 0 && err == 0) err = f; }
+#endif
+  }
   // ---- live timing: tic(category, algorithmic bytes, flops) ... toc() around one launch
   void tic(int cat, double bytes, double flops = 0.0) {
     if (!c->prof_on) return;
@@ -425,7 +530,7 @@ struct Runner {
     }
     return c->fork_ev[c->n_fork++];
   }
-  bool side_usable() const { return !(c->prof_on || !c->side || !c->side_on || !g_side_wgrad); }
+  bool side_usable() const { return !(c->prof_on || !c->side || !c->side_on || !g_side_wgrad || c->det || m->det); }
   hipStream_t side_stream() {
     if (!side_usable()) return st;
     hipEvent_t e = next_event();
@@ -451,14 +556,14 @@ struct Runner {
     if (job.nparts > 0) jobs.push_back(job);
   }
   void queue_wgrad(const spb_wgrad_args_t& w) {
-    if (c->prof_on || !c->side || !c->side_on || !g_side_wgrad) { launch_wgrad(w, st); run_jobs(st); return; }
+    if (!side_usable()) { launch_wgrad(w, st); run_jobs(st); return; }
     pend.push_back(w);
     if ((int)pend.size() >= g_wgrad_batch) flush_wgrads();
   }
   bool head_pending = false;
   spb_head_bwd_args_t head_args;
   void queue_head_wgrad(const spb_head_bwd_args_t& h) {
-    if (c->prof_on || !c->side || !c->side_on || !g_side_wgrad) { ok(spb_head_bwd(dt, &h, st)); return; }
+    if (!side_usable()) { ok(spb_head_bwd(dt, &h, st)); return; }
     head_args = h; head_pending = true;
   }
   std::vector<spb_dw_args_t> pend_dw;   // depthwise weight gradients of the small maps (see dw_bwd)
@@ -483,6 +588,7 @@ struct Runner {
   }
   void join_side() {
     flush_wgrads();
+    det_flush_grads();
     if (!forked) return;
     hipEventRecord(c->join_ev, c->side);
     hipStreamWaitEvent(st, c->join_ev, 0);

@@ -65,6 +65,13 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__
     for (int j = 0; j < 8; ++j) { s1[j] += acc[j]; s2[j] += acc[j] * acc[j]; }
   }
   if (osums) {
+#ifdef SPB_DET   // reproducible twin (common.h): no LDS float atomics; every thread adds exactly
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      atomicAdd(osums + (size_t)(blockIdx.x % oR) * 64 + cg * 8 + j, s1[j]);
+      atomicAdd(osums + (size_t)(blockIdx.x % oR) * 64 + 32 + cg * 8 + j, s2[j]);
+    }
+#else
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       atomicAdd(&red[cg * 8 + j], s1[j]);
@@ -72,6 +79,7 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__
     }
     __syncthreads();
     if (t < 64) atomicAdd(osums + (size_t)(blockIdx.x % oR) * 64 + t, red[t]);
+#endif
   }
 }
 
@@ -116,12 +124,19 @@ __global__ __launch_bounds__(192) void stem_wgrad_kernel(const float* __restrict
       }
     }
   }
+#ifdef SPB_DET   // reproducible twin (common.h): no LDS float atomics; every thread adds exactly
+#pragma unroll
+  for (int k = 0; k < 9; ++k)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) atomicAdd(dW + (cg * 8 + j) * 27 + ci * 9 + k, aw[k][j]);
+#else
 #pragma unroll
   for (int k = 0; k < 9; ++k)
 #pragma unroll
     for (int j = 0; j < 8; ++j) atomicAdd(&red[(cg * 8 + j) * 27 + ci * 9 + k], aw[k][j]);
   __syncthreads();
   for (int i = t; i < 32 * 27; i += 192) atomicAdd(dW + i, red[i]);
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------ head forward

@@ -24,8 +24,14 @@ def _stream():
 class KrnEngine:
     """One KeypointRegressionNet (optionally with RevGrad's domain classifier) bound to device arenas."""
 
-    def __init__(self, num_keypoints, dann=False):
-        self.lib = L.lib()
+    def __init__(self, num_keypoints, dann=False, deterministic=False):
+        """deterministic=True: the reproducible twin library (libspb_hip_det.so; include/spb_hip.h "reproducible mode") -- batch sums and
+        weight gradients are accumulated exactly (order-independent), every launch stays on the caller's stream: a training run is
+        bit-identical in every process.  Slower (one flush launch per kernel launch); the reference offers no such mode
+        (utils.py:297-298 sets cudnn.deterministic = False)."""
+        self.deterministic = bool(deterministic)
+        self.lib = L.lib_det() if self.deterministic else L.lib()
+        self._det_regions = {}          # float pointer -> shadow tensor (kept alive while registered)
         self.h = C.c_void_p()
         L.check(self.lib.spb_krn_create(int(num_keypoints), 1 if dann else 0, C.byref(self.h)), "spb_krn_create")
         self.num_keypoints = int(num_keypoints)
@@ -50,6 +56,7 @@ class KrnEngine:
 
     def __del__(self):
         try:
+            self._det_release()
             for h, _ws in self._ctx.values():
                 self.lib.spb_krn_ctx_destroy(h)
             if self.h:
@@ -57,12 +64,31 @@ class KrnEngine:
         except Exception:
             pass
 
+    # ------------------------------------------------------------------------------------------------ reproducible mode
+    def _det_register(self, ptr, n_floats):
+        shadow = torch.zeros(4 * int(n_floats), dtype=torch.int64, device=self.device)
+        torch.cuda.synchronize(self.device)
+        L.check(self.lib.spb_det_register(C.c_void_p(ptr), int(n_floats), _p(shadow)), "spb_det_register")
+        self._det_regions[ptr] = shadow
+
+    def _det_release(self):
+        for ptr in list(getattr(self, "_det_regions", {})):
+            self.lib.spb_det_unregister(C.c_void_p(ptr))
+        self._det_regions = {}
+
+    def det_misses(self):
+        """float atomics of the reproducible library that hit no registered region since the last call (0: the run was exact)"""
+        if not self.deterministic:
+            raise RuntimeError("not a deterministic engine")
+        return int(self.lib.spb_det_misses())
+
     # ------------------------------------------------------------------------------------------------ arenas
     def attach(self, device, precision):
         device = torch.device(device)
         if device.type != "cuda":
             raise RuntimeError("the KRN engine runs on the MI355X only; there is no CPU path (got device %s)" % device)
         code = PRECISIONS[precision] if isinstance(precision, str) else int(precision)
+        self._det_release()
         for h, _ws in self._ctx.values():
             self.lib.spb_krn_ctx_destroy(h)
         self._ctx = {}
@@ -77,6 +103,9 @@ class KrnEngine:
             torch.cuda.synchronize(device)
             L.check(self.lib.spb_krn_bind(self.h, _p(self.params), _p(self.grads), _p(self.buffers), _p(self.nbt),
                                           _p(self.wc), _p(self.tables), code), "spb_krn_bind")
+            if self.deterministic:
+                self._det_register(self.grads.data_ptr(), self.n_params)
+                L.check(self.lib.spb_krn_set_det(self.h, 1), "spb_krn_set_det")
         return self
 
     def param_view(self, info, arena=None):
@@ -95,6 +124,11 @@ class KrnEngine:
                 h = C.c_void_p()
                 torch.cuda.synchronize(self.device)
                 L.check(self.lib.spb_krn_ctx_create(self.h, key[0], _p(ws), C.byref(h)), "spb_krn_ctx_create")
+                if self.deterministic:
+                    sp, sn = C.c_void_p(), C.c_longlong()
+                    L.check(self.lib.spb_krn_ctx_stats(h, C.byref(sp), C.byref(sn)), "spb_krn_ctx_stats")
+                    self._det_register(sp.value, sn.value)
+                    L.check(self.lib.spb_krn_ctx_set_det(h, 1), "spb_krn_ctx_set_det")
             self._ctx[key] = (h, ws)
         return self._ctx[key][0]
 
