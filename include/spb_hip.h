@@ -385,6 +385,12 @@ int spb_krn_set_det(spb_krn_t* m, int on);
 int spb_krn_ctx_set_det(spb_krn_ctx_t* c, int on);
 int spb_krn_ctx_stats(spb_krn_ctx_t* c, float** ptr, long long* n_floats);
 
+/* Introspection (parity tests): BatchNorm'd tensor a of the plan = raw convolution output z [B,H,W,C] (NHWC, compute dtype) at byte
+ * offset z_off of the context's workspace, its backward companion g at g_off, normalised by BatchNorm bn_index (spb_krn_bn_name). */
+typedef struct { long long z_off, g_off; int H, W, C, bn_index; } spb_act_info_t;
+int spb_krn_num_acts(const spb_krn_t* m);
+int spb_krn_ctx_act_info(const spb_krn_ctx_t* c, int a, spb_act_info_t* out);
+
 /* refresh compute-dtype weight copies (W, W^T, permuted head) from the f32 parameters */
 int spb_krn_prepare_weights(spb_krn_t* m, spb_stream_t stream);
 /* forward.  training=1: batch statistics + running-stat update; training=2: batch statistics, the running-stat update is

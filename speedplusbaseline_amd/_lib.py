@@ -127,6 +127,10 @@ class FcEpiArgs(C.Structure):
                 ("mask_given", i32)]
 
 
+class ActInfo(C.Structure):
+    _fields_ = [("z_off", i64), ("g_off", i64), ("H", i32), ("W", i32), ("C", i32), ("bn_index", i32)]
+
+
 class TensorInfo(C.Structure):
     _fields_ = [("name", C.c_char * 96), ("offset", i64), ("numel", i64), ("ndim", i32), ("shape", i32 * 4)]
 
@@ -288,6 +292,8 @@ SYMBOLS = {
     "spb_debug_set_gconv_wide_rotate": (i32, [i32]),
     "spb_debug_set_gconv_wide_delay": (i32, [i32]),
     "spb_version": (C.c_char_p, []),
+    "spb_krn_num_acts": (i32, [vp]),
+    "spb_krn_ctx_act_info": (i32, [vp, i32, C.POINTER(ActInfo)]),
     "spb_det_available": (i32, []),
     "spb_det_register": (i32, [vp, i64, vp]),
     "spb_det_unregister": (i32, [vp]),

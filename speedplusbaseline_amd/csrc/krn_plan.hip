@@ -321,6 +321,16 @@ extern "C" int spb_krn_ctx_set_det(spb_krn_ctx_t* c, int on) {
   return on ? SPB_E_UNSUPPORTED : 0;
 #endif
 }
+// Introspection for the parity tests: where BatchNorm'd tensor `a` (raw convolution output z, NHWC, compute dtype) and its backward
+// companion g live in the context's workspace, and which BatchNorm (index into spb_krn_bn_name) normalises it.
+extern "C" int spb_krn_num_acts(const spb_krn_t* m) { return m ? (int)m->acts.size() : SPB_E_ARG; }
+extern "C" int spb_krn_ctx_act_info(const spb_krn_ctx_t* c, int a, spb_act_info_t* out) {
+  if (!c || !out || a < 0 || a >= (int)c->m->acts.size()) return SPB_E_ARG;
+  const ActDef& d = c->m->acts[a];
+  out->z_off = (long long)c->z_off[a]; out->g_off = (long long)c->g_off[a];
+  out->H = d.H; out->W = d.W; out->C = d.C; out->bn_index = d.bn;
+  return 0;
+}
 // the context's batch-sum arena (what spb_det_register shadows): pointer and length in floats
 extern "C" int spb_krn_ctx_stats(spb_krn_ctx_t* c, float** ptr, long long* n_floats) {
   if (!c || !ptr || !n_floats) return SPB_E_ARG;

@@ -206,6 +206,20 @@ class KrnEngine:
             L.check(self.lib.spb_krn_backward(ctx, _p(grads), float(gscale), 1 if with_pose else 0, _p(dlogit), float(alpha),
                                               _stream()), "spb_krn_backward")
 
+    def activations(self, batch, slot=0):
+        """{BatchNorm name: raw convolution output z of the last forward as an NCHW VIEW of the context workspace} -- what the parity
+        tests hand to the oracle to take its backward pass through this forward state (tests/test_parity_conditioned_gpu.py)"""
+        h, ws = self._ctx[(int(batch), int(slot))]
+        dt = torch.bfloat16 if self.dtype_code == L.BF16 else torch.float32
+        es = 2 if self.dtype_code == L.BF16 else 4
+        out, ai = {}, L.ActInfo()
+        for a in range(self.lib.spb_krn_num_acts(self.h)):
+            L.check(self.lib.spb_krn_ctx_act_info(h, a, C.byref(ai)), "spb_krn_ctx_act_info")
+            n = int(batch) * ai.H * ai.W * ai.C
+            z = ws[ai.z_off: ai.z_off + n * es].view(dt).view(int(batch), ai.H, ai.W, ai.C).permute(0, 3, 1, 2)
+            out[self.bn_names[ai.bn_index][: -len(".num_batches_tracked")]] = z
+        return out
+
     def max_train_batch(self):
         """largest per-GPU batch spb_head_bwd accepts (csrc/stem_head.hip: B*32 floats of upstream gradient + a [B,49,8] slab of
         z in 160 KB of LDS): 179 in bf16, 96 in fp32.  The reference's recipes use 48 (README.md:87) and 16 (DANN)."""

@@ -1,31 +1,41 @@
-"""bf16 -- the benchmarked compute type -- against the float64 oracle at the north-star tolerance, on a CONDITIONED state.
+"""bf16 -- the benchmarked compute type -- against the float64 oracle at the north-star tolerance, on a CONDITIONED state, at the
+BASELINE batch size (48).  Round 5: ONE REPRODUCIBLE state, fixed hard bars, no skip paths, no warning tier.
 
-At random init this BatchNorm/ReLU6 stack amplifies any perturbation ~350x (tests/test_krn_gpu.py), which says nothing
-about a network someone would deploy.  Here the network is trained ONCE per test session on the MI355X (f32 HIP path, AdamW on
-structured synthetic frames whose keypoints are a function of the picture) until its BatchNorm statistics, weights and outputs
-are trained-like; that one state is frozen and shared by the three tests below, which compare the bf16 HIP path with the float64
-CPU oracle ON THE SAME WEIGHTS at the BASELINE batch size (48):
+What rounds 2-4 got wrong, and what was found (scratch/bf16_state_analysis.py; DESIGN.md section 4 "Round 5"):
 
+  * The conditioning run (f32 HIP training on structured synthetic frames) used the float-atomic library, so every run ended on a
+    different state -- after 40 steps two f32 runs already differ by 6 % in the parameters (scratch/det_probe.py) -- and the bars were
+    then fitted to whatever states turned up.  Now the run uses the REPRODUCIBLE twin library (libspb_hip_det.so: exact,
+    order-independent accumulation in place of float atomics; include/spb_hip.h "reproducible mode"): the conditioned state is
+    bit-identical in every process and on every box (its sha256 is printed; the first steps are run twice here and compared).
+  * The frames carried per-pixel clutter of amplitude 0.25 under the blob.  A network trained on them is CHAOTIC: on the float64 CPU
+    oracle a 2^-9 relative perturbation at the 112x112 layers grows to 15-22 % in the 7x7 activations, loss spikes of several hundred
+    appear in the (deterministic, f32) training run, and the gradient of ANY bfloat16 evaluation is unrelated to the float64 one --
+    the oracle with bf16 rounding at the storage / operand points: cosine 0.58, norm ratio 0.46; PyTorch's own CPU bf16 autocast of the
+    oracle: 0.84 / 0.68; float16 rounding instead (3 more mantissa bits): 0.98 / 1.00.  The suspected |mean| >> sigma channels do not
+    exist (max |mean| / sigma over all 58 BatchNorm layers: 2.4).  With clutter 0.05 the same recipe gives a well-conditioned network
+    (no loss spike, bf16 cosine 0.99), which is the state the end-to-end bars are put on; the cluttered recipe is kept as a second
+    state for the test that does not depend on conditioning (next point).
+  * A backward-kernel defect and forward chaos were indistinguishable in an end-to-end cosine.  They are separated now: the oracle
+    takes its backward pass THROUGH THE HIP FORWARD STATE (oracle._Net.forced: the stored bf16 convolution outputs and predictions of
+    the HIP pass replace its own), so the comparison holds exactly the backward kernels to float64 -- on the well-conditioned AND on the
+    chaotic state.
+
+Tests (all bars hard):
+  * reproducibility of the conditioning run (two short runs bit-identical, no float atomic outside the exact regions);
   * eval forward: keypoint MSE <= 1e-4 (BASELINE.json north_star: "keypoint MSE within 1e-4 of reference");
-  * train forward + backward: loss, per-layer BatchNorm batch statistics (error growth with depth bounded), and the GRADIENT
-    against float64, on the mean of 8 identical bf16 passes: expected cosine >= 0.93 / norm ratio 0.9 .. 1.1 (a warning when a state misses it),
-    hard tier: finite and positive cosine (second half of round 4: the deviation turned out to be a property of the conditioned STATE) (observed over some forty settled states: 0.919 .. 0.995 / 0.92 .. 1.19);
-  * the DANN step FusedTrainStep(dann=True) runs for bench.py --model dann (source and target passes on two streams,
-    step.py) against oracle.DannTrainer (dann.py:68-100), from the same backbone + the domain classifier's initial state.
-
-Round 4 (judge's review of round 3): no retry on a second state, no bar derived from the oracle's own emulated-bf16 run.  What made
-the old bars state-dependent was WHERE the gradient was taken: at an unseen batch of a converged state the true gradient is the
-small residual of 48 nearly cancelling per-sample gradients, while the bf16 rounding noise of the backward pass scales with the
-per-sample magnitudes -- the cosine then measures how close to its minimum that run's training happened to stop (0.80 .. 0.96 over
-a dozen runs; the conditioning trajectory differs per run because weight-gradient and statistics kernels use float atomics).  The
-gradient is now taken against targets shifted by a constant 0.05 -- a coherent upstream gradient like that of a network still in
-training -- where it no longer depends on how close to a minimum the run stopped (and not on the size of the shift: 0.05, 0.1, 0.2 give the same cosine).  The converged-batch cosine is
-still printed for information.
+  * train forward: loss within the keypoint budget; per-layer BatchNorm batch means (bounded error growth with depth);
+  * backward through the HIP forward state vs float64: cosine >= 0.999, norm ratio 0.99 .. 1.01, every tensor >= 0.99, on both states;
+  * end to end (identical inputs, targets shifted by 0.05 -- a coherent upstream gradient like that of a network still in training):
+    cosine >= 0.97 (mean of 8 float-atomic passes; 0.95 for every single pass and for the exact-accumulation pass), norm ratio 0.9 .. 1.1;
+  * the DANN step FusedTrainStep(dann=True) as bench.py --model dann runs it (two streams) and back to back, against oracle.DannTrainer
+    (dann.py:68-100): pose loss within budget, domain terms 2e-2, clipped SGD update cosine >= 0.93, ratio 0.9 .. 1.1.
 Reference: park2019.py:126-165, trainer.py:72-98, dann.py:68-100.
 """
+import hashlib
 import math
+import os
 
-import numpy as np
 import pytest
 import torch
 
@@ -37,20 +47,16 @@ from speedplusbaseline_amd.step import FusedTrainStep  # noqa: E402
 
 B = 48
 K = 11
-STEPS = 1000
-LR_AT = {300: 3e-4, 600: 1e-4}
-SETTLED = 0.004            # mean train loss (summed keypoint MSE) of the last 20 settling steps
+SCHEDULE = {0: 1e-3, 300: 3e-4, 600: 1e-4, 1000: 3e-5, 1600: 1e-5}   # AdamW learning rate from step ...
+STEPS = 2000
 TARGET_SHIFT = 0.05        # the gradient bars are taken against targets shifted by this constant (module docstring)
-import os as _os
-COND_PRECISION = _os.environ.get("SPB_COND_PRECISION", "fp32")
-CONDITIONED_GNORM = None   # shifted-target gradient norm of the state _condition froze
-OUTLIER_POSE_LOSS = 0.12   # float64 pose loss of a held-out batch above which the state has not generalised to it (typical: 0.056)
-N_RUNS = 8                 # identical bf16 passes whose mean gradient is held to the bars (test_bf16_train_pass...)
-G_SETTLED = 3.6           # float64 gradient norm against the shifted targets of a settled state: 2.7 .. 3.3 (module docstring, _condition)
+N_RUNS = 8                 # identical float-atomic bf16 passes (mean and every single one are held to the bars)
+CLEAN, CLUTTERED = 0.05, 0.25     # amplitude of the per-pixel clutter under the blob (module docstring)
+NOISE_AMP = float(os.environ.get("SPB_COND_NOISE", CLEAN))    # scratch/cond_explore.py sweeps it
 
 
-def structured_batch(n, seed, device=None):
-    """frames with a soft blob at (cx, cy) of size s over low-amplitude noise; the 11 keypoints sit on a fixed constellation
+def structured_batch(n, seed, device=None, noise=None):
+    """frames with a soft blob at (cx, cy) of size s over per-pixel clutter; the 11 keypoints sit on a fixed constellation
     around the blob, so the targets are a learnable function of the image (as real keypoints are).  device=None: CPU
     generator (the batches both sides are compared on); a cuda device: generated there (conditioning stream only)"""
     dev = torch.device("cpu") if device is None else torch.device(device)
@@ -61,7 +67,8 @@ def structured_batch(n, seed, device=None):
     yy, xx = torch.meshgrid(torch.linspace(0, 1, 224, device=dev), torch.linspace(0, 1, 224, device=dev), indexing="ij")
     d2 = (xx[None] - cx[:, None, None]) ** 2 + (yy[None] - cy[:, None, None]) ** 2
     blob = torch.exp(-d2 / (2 * s[:, None, None] ** 2))
-    img = 0.25 * r(n, 3, 224, 224) + 0.7 * blob[:, None] * torch.tensor([1.0, 0.8, 0.6], device=dev)[None, :, None, None]
+    amp = NOISE_AMP if noise is None else noise
+    img = amp * r(n, 3, 224, 224) + 0.7 * blob[:, None] * torch.tensor([1.0, 0.8, 0.6], device=dev)[None, :, None, None]
     ang = torch.arange(K, device=dev) * (2 * math.pi / K)
     kx = cx[:, None] + 1.5 * s[:, None] * torch.cos(ang)[None]
     ky = cy[:, None] + 1.5 * s[:, None] * torch.sin(ang)[None]
@@ -91,85 +98,52 @@ def dump_state(eng, dtype=torch.float64):
     return {k: sd[k] for k in order}
 
 
-def _condition(device):
-    """train the f32 HIP path: AdamW (wd 0.01, clip 1.0), lr 1e-3 -> 3e-4 -> 1e-4, a fresh structured batch every step, then settle
-    (below)"""
-    eng = KrnEngine(K).attach(device, COND_PRECISION)
+def digest(eng):
+    h = hashlib.sha256()
+    for t in (eng.params, eng.buffers, eng.nbt):
+        h.update(t.detach().cpu().numpy().tobytes())
+    return h.hexdigest()[:16]
+
+
+def _train(device, steps, noise):
+    """the conditioning run: f32 HIP path on the reproducible library, AdamW (wd 0.01, clip 1.0) on SCHEDULE, a fresh structured batch
+    every step (seed 100 + step).  Returns (engine, losses [steps] on the host)"""
+    eng = KrnEngine(K, deterministic=True).attach(device, "fp32")
     load_state(eng, O.init_state(K))
     ts = FusedTrainStep(eng, B, kind="adamw", lr=1e-3, momentum=0.9, weight_decay=0.01, max_norm=1.0)
-    hist = []
-    for it in range(STEPS):
-        if it in LR_AT:
-            ts.lr = LR_AT[it]
-        x, y = structured_batch(B, 100 + it, device)        # a fresh batch every step: the network has to generalise
-        s = ts(x, y)
-        if it % 100 == 0 or it == STEPS - 1:
-            hist.append(round(float(s[0]), 4))
-    # settle: rounds of 200 steps at 3e-5 until the mean loss of a round's last 50 steps is below SETTLED, then rounds at 1e-5 until
-    # the tail is also QUIET (no step of the last 50 above 4 x SETTLED).  A state caught right after a loss spike has a gradient several
-    # times larger and noisier than a settled one (round 4: |g| 12 against 2.8), and the bars below are about settled states.
-    it0 = STEPS
-
-    def round_(lr):
-        nonlocal it0
-        ts.lr = lr
-        tail = []
-        for it in range(it0, it0 + 200):
-            x, y = structured_batch(B, 100 + it, device)
-            s = ts(x, y)
-            if it >= it0 + 150:
-                tail.append(s[0:1].clone())
-        it0 += 200
-        tail = torch.cat(tail).cpu()
-        hist.append((round(float(tail.median()), 4), round(float(tail.max()), 4)))
-        return float(tail.median()), float(tail.max())       # the median: outlier batches are data, not a property of the state
-
-    for k in range(8):
-        if round_(3e-5)[0] < SETTLED and k >= 2:             # at least three rounds
-            break
-    # ... and settled AT THE BATCH THE GRADIENT TEST USES (seed 8, which the training stream never draws).  The training distribution has
-    # outlier batches (loss spikes the float64 oracle reproduces, scratch/spike_check.py) and a run whose last rounds were quiet can still sit
-    # in the aftermath of one: such a state is several times more SENSITIVE than a settled one -- against the shifted targets the float64
-    # gradient norm is 5 .. 50 instead of the 2.7 .. 3.3 the shift itself explains, float64 and bf16 losses differ by 10-35 %, and the bf16
-    # rounding noise of the backward pass is amplified with it (round 4: the same kernels gave cosine 0.99 on one run's final state and 0.48
-    # on another's).  The f32 HIP gradient (equal to float64 to 1e-4) is cheap, so the stopping rule measures that norm directly and keeps
-    # settling (same learning rate, up to 16 rounds) until it is below G_SETTLED.
-    xg, yg = structured_batch(B, 8)
-    yg = (yg + TARGET_SHIFT).clamp(0, 1.2)
-    probe = KrnEngine(K).attach(device, "fp32")
-
-    def shifted_gradient_norm():
-        load_state(probe, dump_state(eng))
-        probe.grads.zero_()
-        probe.forward(xg.to(device), yg.to(device), training=True)
-        probe.backward(B)
-        torch.cuda.synchronize()
-        return float(probe.grads.double().norm())
-
-    best = None
-    for k in range(12):
-        mean, worst = round_(1e-5)
-        if mean < SETTLED and k >= 1:                          # at least two rounds
-            gn = shifted_gradient_norm()
-            hist.append(("|g|", round(gn, 2)))
-            if best is None or gn < best[0]:
-                best = (gn, eng.params.clone(), eng.buffers.clone(), eng.nbt.clone())
-            if gn < G_SETTLED:
-                break
-    if best is None:
-        pytest.fail("the conditioning run did not settle (tail median %.4f, max %.4f): %s" % (mean, worst, hist))
-    eng.params.copy_(best[1]); eng.buffers.copy_(best[2]); eng.nbt.copy_(best[3])   # the most settled state of the run (usually the last)
-    global CONDITIONED_GNORM
-    CONDITIONED_GNORM = best[0]
+    losses = []
+    for it in range(steps):
+        if it in SCHEDULE:
+            ts.lr = SCHEDULE[it]
+        x, y = structured_batch(B, 100 + it, device, noise)        # a fresh batch every step: the network has to generalise
+        losses.append(ts(x, y)[0:1].clone())
     torch.cuda.synchronize()
-    print("conditioning loss every 100 steps, then (mean, max) of each settling round's last 50 steps: %s" % (hist,))
+    return eng, torch.cat(losses).cpu()
+
+
+def _condition(device, noise):
+    eng, losses = _train(device, STEPS, noise)
+    misses = eng.det_misses()
+    tail = losses[-50:]
+    print("conditioned state (clutter %.2f): sha256 %s after %d reproducible f32 steps; loss every 200 steps %s; last 50: median %.5f max %.5f; "
+          "largest loss of the run %.3f; float atomics outside the exact regions: %d"
+          % (noise, digest(eng), STEPS, [round(float(v), 4) for v in losses[::200]], float(tail.median()), float(tail.max()), float(losses.max()), misses))
+    assert misses == 0
+    assert torch.isfinite(losses).all()
     return dump_state(eng)
 
 
 @pytest.fixture(scope="module")
 def conditioned(device):
-    """ONE conditioned state per session, shared by every test of this module"""
-    return _condition(device)
+    """the well-conditioned state (clutter 0.05): ONE reproducible state per session, shared by the tests of this module"""
+    sd = _condition(device, CLEAN)
+    return sd
+
+
+@pytest.fixture(scope="module")
+def conditioned_cluttered(device):
+    """the chaotic state (clutter 0.25; module docstring): only the backward-through-the-HIP-forward-state test uses it"""
+    return _condition(device, CLUTTERED)
 
 
 @pytest.fixture(scope="module")
@@ -188,8 +162,25 @@ def _rel(a, b):
     return float((a - b).norm() / (b.norm() + 1e-30))
 
 
+def _cos(a, b):
+    return float(torch.dot(a, b) / (a.norm() * b.norm()))
+
+
+def test_conditioning_run_is_reproducible(device):
+    """two runs of the first 25 conditioning steps from scratch: parameters, BatchNorm buffers and every loss bit-identical; no float
+    atomic escaped the exact accumulation.  (Across processes and boxes: the printed sha256 of the conditioned states, profiles/r5_*.)"""
+    a, la = _train(device, 25, CLEAN)
+    da, ma = digest(a), a.det_misses()
+    del a
+    b, lb = _train(device, 25, CLEAN)
+    assert da == digest(b) and torch.equal(la, lb), (da, digest(b))
+    assert ma == 0 and b.det_misses() == 0
+    # ... while the float-atomic library (what bench.py times) is NOT reproducible run to run: that is what the twin is for
+    print("25-step digest %s (twice); losses %.6f .. %.6f" % (da, float(la[0]), float(la[-1])))
+
+
 def test_bf16_eval_keypoints_within_1e4_of_float64_oracle_at_bs48(device, conditioned):
-    x, y = structured_batch(B, 7)                      # a batch the network has not seen
+    x, y = structured_batch(B, 7, noise=CLEAN)         # a batch the network has not seen
     sd = {k: v.clone() for k, v in conditioned.items()}
     with torch.no_grad():
         xc, yc = O.krn_forward(sd, x.double(), None, training=False)
@@ -205,16 +196,74 @@ def test_bf16_eval_keypoints_within_1e4_of_float64_oracle_at_bs48(device, condit
     fit = float(((ref - y.double()) ** 2).mean())
     print("conditioned eval, B=48: keypoint MSE vs float64 oracle  fp32 %.3e (max |d| %.2e)   bf16 %.3e (max |d| %.2e);  "
           "oracle-vs-target MSE %.3e, reference mean square %.3e" % (out["fp32"] + out["bf16"] + (fit, float((ref ** 2).mean()))))
+    assert fit < 1e-3                               # the state is a trained one: it predicts the keypoints of an unseen batch
     assert out["fp32"][0] <= 1e-8
     assert out["bf16"][0] <= 1e-4, out             # the north-star bar, in the benchmarked dtype
 
 
-def _cos(a, b):
-    return float(torch.dot(a, b) / (a.norm() * b.norm()))
+def _oracle_grad(state, x, y, forced=None, forced_out=None):
+    """float64 loss and gradient (flat, state-dict order) of the oracle; forced / forced_out: through another forward state (module docstring)"""
+    sd = {k: v.clone() for k, v in state.items()}
+    names = O._leafify(sd)
+    O._Net.forced = forced
+    try:
+        out, _ = O.krn_predict(sd, x.double(), True, "")
+    finally:
+        O._Net.forced = None
+    if forced_out is not None:
+        out = out + (forced_out.double() - out).detach()
+    loss = O.krn_loss(out, y.double())[0]
+    loss.backward()
+    return float(loss), torch.cat([sd[k].grad.flatten() for k in names]), sd, names
+
+
+def _hip_grad(eng, state, x, y, device):
+    load_state(eng, state)                         # (the forward moves the running statistics)
+    eng.grads.zero_()
+    pred, scal, _ = eng.forward(x.to(device), y.to(device), training=True)
+    eng.backward(B)
+    torch.cuda.synchronize()
+    return scal.cpu().double(), torch.cat([eng.param_view(i, eng.grads).double().cpu().flatten() for i in eng.param_infos]), pred
+
+
+@pytest.mark.parametrize("which", ["clean", "cluttered"])
+def test_bf16_backward_through_its_own_forward_state_vs_float64(device, conditioned, conditioned_cluttered, which):
+    """the bf16 backward kernels alone: the float64 oracle takes its backward pass through the forward state the HIP pass stored (raw
+    convolution outputs of all 58 BatchNorm'd tensors + the predictions), so forward rounding -- which the chaotic state amplifies
+    beyond any bar -- is common to both sides.  Holds on every state; bars fixed."""
+    state, noise = (conditioned, CLEAN) if which == "clean" else (conditioned_cluttered, CLUTTERED)
+    x, y = structured_batch(B, 8, noise=noise)
+    y = (y + TARGET_SHIFT).clamp(0, 1.2)
+    eng = KrnEngine(K).attach(device, "bf16")
+    s, g_hip, pred = _hip_grad(eng, state, x, y, device)
+    forced = {k: v.detach().double().cpu() for k, v in eng.activations(B).items()}
+    assert len(forced) == 58
+    loss_f, g_forced, sd, names = _oracle_grad(state, x, y, forced, pred.cpu())
+    loss_0, g_free, _, _ = _oracle_grad(state, x, y)
+    cos, ratio = _cos(g_hip, g_forced), float(g_hip.norm() / g_forced.norm())
+    print("%s state: bf16 loss %.5f, float64 through the HIP forward state %.5f, float64 on its own %.5f" % (which, float(s[0]), loss_f, loss_0))
+    print("%s state: HIP bf16 gradient vs float64 THROUGH THE SAME FORWARD STATE: cosine %.4f, norm ratio %.4f   (end to end, for information: "
+          "cosine %.4f, norm ratio %.4f; the two float64 gradients: cosine %.4f)"
+          % (which, cos, ratio, _cos(g_hip, g_free), float(g_hip.norm() / g_free.norm()), _cos(g_forced, g_free)))
+    gn = float(g_forced.norm())
+    off, per = 0, []
+    for k in names:
+        n = sd[k].numel()
+        a, b = g_hip[off: off + n], g_forced[off: off + n]
+        off += n
+        if float(b.norm()) > 1e-3 * gn:
+            per.append((_cos(a, b), float(a.norm() / b.norm()), k))
+    per.sort()
+    print("   eight lowest per-tensor cosines among tensors above 1e-3 of |g| (cosine, norm ratio, tensor): " + "; ".join("%.3f %.2f %s" % t for t in per[:8]))
+    assert abs(float(s[0]) - loss_f) <= 1e-3 * loss_f + 1e-6          # same predictions -> same loss
+    # measured (round 5): cosine 1.0000 / ratio 1.0000 on the well-conditioned state, 1.0000 / 0.9992 on the chaotic one, where the end-to-end
+    # cosine of the same pass is 0.15; lowest per-tensor cosine 0.999
+    assert cos >= 0.999 and 0.99 <= ratio <= 1.01, (cos, ratio)
+    assert per[0][0] >= 0.99, per[0]
 
 
 def test_bf16_train_pass_tracks_float64_oracle_at_bs48(device, conditioned):
-    x, y = structured_batch(B, 8)                      # a batch the network has not seen
+    x, y = structured_batch(B, 8, noise=CLEAN)         # a batch the network has not seen
     y_shift = (y + TARGET_SHIFT).clamp(0, 1.2)
     sd = {k: v.clone() for k, v in conditioned.items()}
     names = O._leafify(sd)
@@ -225,26 +274,12 @@ def test_bf16_train_pass_tracks_float64_oracle_at_bs48(device, conditioned):
         O._Net.momentum = O.BN_MOM
     loss = O.krn_loss(out, y.double())[0]
     loss_shift = O.krn_loss(out, y_shift.double())[0]
-    g_at_min = torch.autograd.grad(loss, [sd[k] for k in names], retain_graph=True)
-    g_at_min = torch.cat([g.flatten() for g in g_at_min])
     loss_shift.backward()
     g_ref = torch.cat([sd[k].grad.flatten() for k in names])
     eng = KrnEngine(K).attach(device, "bf16")
-    load_state(eng, conditioned)
-
-    def hip_grad(target):
-        load_state(eng, conditioned)                   # (the forward moves the running statistics)
-        eng.grads.zero_()
-        _, scal, _ = eng.forward(x.to(device), target.to(device), training=True)
-        eng.backward(B)
-        torch.cuda.synchronize()
-        return scal.cpu().double(), torch.cat([eng.param_view(i, eng.grads).double().cpu().flatten() for i in eng.param_infos])
-
-    s, g_hip_min = hip_grad(y)
+    s, _, _ = _hip_grad(eng, conditioned, x, y, device)
     print("conditioned train pass, B=48: loss bf16 %.6f float64 %.6f" % (float(s[0]), float(loss)))
     # a per-coordinate keypoint budget of 1e-4 (mean square) moves the summed loss by at most 2 sqrt(L * 2K * 1e-4) + 2K * 1e-4
-    if float(loss) > 4 * SETTLED:      # (as in the DANN test: the bars are for batches the state has generalised to; typical 0.002 .. 0.005)
-        pytest.skip("the conditioned state treats the held-out batch as an outlier (float64 loss %.4f > %.4f)" % (float(loss), 4 * SETTLED))
     budget = 2 * math.sqrt(float(loss) * 2 * K * 1e-4) + 2 * K * 1e-4
     assert abs(float(s[0]) - float(loss)) <= budget, (float(s[0]), float(loss), budget)
     # per-layer batch means (running_mean after a momentum-0.1 update from the same start): error growth with depth
@@ -258,68 +293,40 @@ def test_bf16_train_pass_tracks_float64_oracle_at_bs48(device, conditioned):
           % (errs[0], sorted(errs)[len(errs) // 2], max(errs), errs[-1]))
     # bf16 operand rounding (2^-9) at the stem, bounded growth after; the largest per-layer error sits in the last, near-zero-mean layers
     assert errs[0] < 5e-3 and max(errs) < 0.15 and errs[-1] < 0.15 and sorted(errs)[len(errs) // 2] < 5e-3
-    # ---- the gradient, FIXED bars, against targets shifted by TARGET_SHIFT (module docstring)
-    # The bf16 gradient of one state on one batch is not a fixed vector: scratch/repeat_probe.py repeats the identical fused step 400 times --
-    # f32: loss identical, gradient within 4e-3 of the first run; bf16: loss 0.00256 .. 0.00307 and gradient up to 26 % away from the first
-    # run, on the kernels of round 3 as on today's (the f32 atomics of the statistics kernels decide bf16 roundings that this network
-    # amplifies ~350x).  Training integrates that run-to-run component away over its steps; what must not exist is a BIAS.  So the bars
-    # are put on the MEAN of N_RUNS identical bf16 passes, and the single-run spread is printed beside it.
-    runs = [hip_grad(y_shift) for _ in range(N_RUNS)]
-    s2 = runs[0][0]
+    # ---- the gradient end to end, FIXED bars, against targets shifted by TARGET_SHIFT (module docstring)
+    runs = [_hip_grad(eng, conditioned, x, y_shift, device) for _ in range(N_RUNS)]
     g_hip = torch.stack([r_[1] for r_ in runs]).mean(0)
     single = [(_cos(r_[1], g_ref), float(r_[1].norm() / g_ref.norm())) for r_ in runs]
-    print("single bf16 passes vs float64 (cosine, norm ratio): " + "  ".join("%.4f %.3f" % t for t in single))
+    print("single float-atomic bf16 passes vs float64 (cosine, norm ratio): " + "  ".join("%.4f %.3f" % t for t in single))
     cos, ratio = _cos(g_hip, g_ref), float(g_hip.norm() / g_ref.norm())
-    print("gradient vs float64 (targets + %.2f): cosine %.4f, norm ratio %.4f   (|g| %.3e; loss bf16 %.5f float64 %.5f)"
-          % (TARGET_SHIFT, cos, ratio, float(g_ref.norm()), float(s2[0]), float(loss_shift)))
-    print("for information, at the converged batch itself: cosine %.4f, norm ratio %.4f, |g| float64 %.3e"
-          % (_cos(g_hip_min, g_at_min), float(g_hip_min.norm() / g_at_min.norm()), float(g_at_min.norm())))
-    worst = min((_cos(eng.param_view(i, eng.grads).double().cpu().flatten(), sd[i[0]].grad.flatten()), i[0]) for i in eng.param_infos
-                if i[0].endswith(".weight") and sd[i[0]].grad.dim() == 4)
-    print("lowest per-tensor cosine among the convolution weights: %.4f (%s)" % worst)
+    print("gradient vs float64 (targets + %.2f), mean of %d passes: cosine %.4f, norm ratio %.4f   (|g| %.3e; loss bf16 %.5f float64 %.5f)"
+          % (TARGET_SHIFT, N_RUNS, cos, ratio, float(g_ref.norm()), float(runs[0][0][0]), float(loss_shift)))
+    det = KrnEngine(K, deterministic=True).attach(device, "bf16")
+    sx, g_det, _ = _hip_grad(det, conditioned, x, y_shift, device)
+    sx2, g_det2, _ = _hip_grad(det, conditioned, x, y_shift, device)
+    cos_d, ratio_d = _cos(g_det, g_ref), float(g_det.norm() / g_ref.norm())
+    print("exact-accumulation bf16 pass: cosine %.4f, norm ratio %.4f, loss %.5f (a second pass is bit-identical: %s)"
+          % (cos_d, ratio_d, float(sx[0]), bool(torch.equal(g_det, g_det2))))
     gn = float(g_ref.norm())
     per = sorted((_cos(eng.param_view(i, eng.grads).double().cpu().flatten(), sd[i[0]].grad.flatten()),
                   float(eng.param_view(i, eng.grads).double().cpu().norm() / (sd[i[0]].grad.norm() + 1e-30)), i[0]) for i in eng.param_infos
                  if float(sd[i[0]].grad.norm()) > 1e-3 * gn)
-    print("twelve lowest per-tensor cosines among tensors above 1e-3 of |g| (cosine, norm ratio, tensor): "
-          + "; ".join("%.3f %.2f %s" % t for t in per[:12]))
-    # Fixed bars.  Nine conditioned states of round 4 (every run ends somewhere else: float atomics in the f32 training kernels, and the
-    # structured-frame distribution has outlier batches -- loss spikes up to 400 that the float64 oracle reproduces on the same weights,
-    # scratch/spike_check.py): cosine 0.949 .. 0.992, norm ratio 0.936 .. 1.018, independent of the shift from 0.05 up (scratch/parity_ab.py)
-    # (second half of round 4: a race in the new single-launch head kernel -- found through THIS test, which stopped settling -- made the
-    # run-to-run spread of the conditioned states visible: over some forty conditioned states, with the stopping rule on the shifted-target
-    # gradient norm in _condition, cosine 0.919 .. 0.995 and norm ratio 0.92 .. 1.19; the same kernels score 0.99 on one state and 0.93 on
-    # the next, so the bars below are the envelope of settled states, not a property of one lucky run.)
-    # What the eight passes show (round 4, some forty states): within ONE state they agree to the third digit -- the deviation from float64 is
-    # a property of the state, not run-to-run noise: 0.990 .. 0.991 on one state, 0.861 .. 0.901 at norm ratio 1.22 .. 1.31 on another
-    # (suspected: BatchNorm channels whose mean is many standard deviations, where the bf16 rounding of the stored pre-activation is a large
-    # fraction of the deviation the consumer normalises by; scratch/grad_probe.py: identical on the kernels of round 3).  Settled states (shifted-target gradient norm below
-    # G_SETTLED) gave cosine 0.882 .. 0.995, norm ratio 0.97 .. 1.26; unsettled ones down to 0.42.  The bars are for settled states; a run
-    # whose conditioning never got there within its rounds reports that and skips them (its loss / statistics checks above still count).
-    if CONDITIONED_GNORM is None or CONDITIONED_GNORM >= G_SETTLED:
-        pytest.skip("conditioning ended at shifted-target gradient norm %s >= %.1f: gradient bars not applicable to this state"
-                    % (CONDITIONED_GNORM, G_SETTLED))
-    # Two tiers.  EXPECTED (most settled states; reported as a warning when missed): cosine >= 0.93, norm ratio 0.9 .. 1.1.  HARD: a backward
-    # pass that is wrong somewhere (a layer's gradient missing or mis-scaled) points the wrong way or is not finite (see the note at the assertion).
-    if not (cos >= 0.93 and 0.9 <= ratio <= 1.1):
-        import warnings
-        warnings.warn("conditioned state with a state-dependent bf16 bias: gradient cosine %.4f, norm ratio %.4f (expected >= 0.93, 0.9 .. 1.1)"
-                      % (cos, ratio))
-    # (End of round 4: inside the full suite two of three runs drew states at cosine 0.46 / norm ratio 3.1 -- below every one of the ~forty
-    # states of the module run alone.  Until the state dependence is understood the hard tier only rejects a
-    # gradient that points the wrong way or is not finite; the exact backward-pass checks are tests/test_krn_gpu.py (float32 against float64,
-    # bf16 against the oracle's bf16 emulation) and the float32 tier of scratch/grad_probe.py at this size.)
-    assert math.isfinite(cos) and math.isfinite(ratio) and cos > 0.0, (cos, ratio)
+    print("eight lowest per-tensor cosines of the last pass among tensors above 1e-3 of |g| (cosine, norm ratio, tensor): "
+          + "; ".join("%.3f %.2f %s" % t for t in per[:8]))
+    assert torch.equal(g_det, g_det2) and torch.equal(sx, sx2)                 # one state, one batch -> one gradient
+    # measured on this (reproducible) state: mean 0.990 / 1.023, singles 0.985 .. 0.991 / 1.015 .. 1.036, exact accumulation 0.981 / 1.027
+    assert cos >= 0.97 and 0.9 <= ratio <= 1.1, (cos, ratio)
+    assert min(c for c, _ in single) >= 0.95 and all(0.9 <= r_ <= 1.1 for _, r_ in single), single
+    assert cos_d >= 0.95 and 0.9 <= ratio_d <= 1.1, (cos_d, ratio_d)
 
 
 def test_bf16_dann_step_overlapped_streams_vs_oracle(device, conditioned_dann):
     """one DANN step through FusedTrainStep(dann=True) -- source and target passes concurrently on two streams, as
     bench.py --model dann times it -- in bf16 (and f32), against oracle.DannTrainer in float64 from the same state; fixed bars"""
-    import os
     NB = B      # the batch size the backbone was conditioned at: its BatchNorm layers expect 48-image statistics (the README's DANN recipe
                 # uses 16; bench.py times both).  At 16 images the 7x7 layers have 784 samples per channel and the training-mode loss of a
                 # network conditioned at 48 is dominated by that mismatch, in float64 as much as in bf16
-    xs, ys = structured_batch(NB, 21); xt = structured_batch(NB, 22)[0].flip(3) * 0.8
+    xs, ys = structured_batch(NB, 21, noise=CLEAN); xt = structured_batch(NB, 22, noise=CLEAN)[0].flip(3) * 0.8
     ys = (ys + TARGET_SHIFT).clamp(0, 1.2)             # a coherent pose gradient (module docstring)
     alpha = 0.7
     sd = {k: v.clone() for k, v in conditioned_dann.items()}
@@ -328,7 +335,6 @@ def test_bf16_dann_step_overlapped_streams_vs_oracle(device, conditioned_dann):
     lp, ls, lt, gn = _dann_step_f64(tr, xs.double(), ys.double(), xt.double(), alpha)
     d_ref = torch.cat([sd[k].detach().flatten() for k in tr.names]) - p0
     budget = 2 * math.sqrt(lp * 2 * K * 1e-4) + 2 * K * 1e-4
-    outlier = False
     for prec, overlap in (("fp32", "1"), ("bf16", "1"), ("bf16", "0")):
         os.environ["SPB_DANN_OVERLAP"] = overlap
         try:
@@ -351,25 +357,11 @@ def test_bf16_dann_step_overlapped_streams_vs_oracle(device, conditioned_dann):
             assert cos > 0.99 and 0.98 < ratio < 1.02
             continue
         # bf16: the training-mode pose loss within the keypoint budget (+ 5 %), the two domain terms to 2e-2, the clipped SGD update at
-        # fixed bars -- for batches the conditioned state has generalised to.  The float64 pose loss of this (held-out) source batch is
-        # ~0.056 on most states; some states treat it as an OUTLIER (0.23 - 0.30, end of round 4: the float32 HIP path agrees with float64
-        # to 1e-3 there, asserted above, while bf16 lands 30-70 % away -- the keypoint budget below is a statement about inliers).  Such a run
-        # reports it and skips the bf16 bars.
-        if lp > OUTLIER_POSE_LOSS:
-            outlier = True
-            continue
+        # fixed bars.  (The update mixes the pose gradient with the gradients of the two domain terms, reversed at the 7x7 feature and
+        # coming from a domain classifier at its initial state: an incoherent component whose bf16 evaluation is noise-dominated.)
         assert abs(float(s[0]) - lp) <= budget + 0.05 * lp, (float(s[0]), lp, budget)
         assert abs(float(s[3]) - ls) <= 2e-2 and abs(float(s[4]) - lt) <= 2e-2
-        # (the update mixes the pose gradient with the gradients of the two domain terms, reversed at the 7x7 feature and coming from a
-        # domain classifier at its initial state: an incoherent component whose bf16 evaluation is noise-dominated.  Measured on three
-        # conditioned states, both launch modes: 0.851 .. 0.959; the fixed bar is 0.80)
-        if not (cos >= 0.80 and 0.9 <= ratio <= 1.1):
-            import warnings
-            warnings.warn("DANN bf16 update on this conditioned state: cosine %.4f, norm ratio %.4f (expected >= 0.80, 0.9 .. 1.1)" % (cos, ratio))
-        assert math.isfinite(cos) and math.isfinite(ratio) and cos > 0.0, (cos, ratio)     # hard tier: see test_bf16_train_pass... (state-dependent bf16 bias)
-    if outlier:
-        pytest.skip("the conditioned state treats the DANN source batch as an outlier (float64 pose loss %.3f > %.2f): float32 tier checked, "
-                    "bf16 bars not applicable" % (lp, OUTLIER_POSE_LOSS))
+        assert cos >= 0.93 and 0.9 <= ratio <= 1.1, (cos, ratio)          # measured: 0.964 / 1.0000 (both launch modes)
 
 
 def _dann_step_f64(tr, xs, ys, xt, alpha):
