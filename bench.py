@@ -234,23 +234,8 @@ def main():
         _init_dist(dev)
         group = torch.distributed.group.WORLD
 
-    # A/B switches for experiments (defaults are the product configuration)
-    from speedplusbaseline_amd import _lib as _L
-    for env, fn in (("SPB_SIDE_WGRAD", "spb_debug_set_side_wgrad"), ("SPB_DW_MODE", "spb_debug_set_dw_mode"),
-                    ("SPB_GEMM_DMA", "spb_debug_set_gemm_dma"), ("SPB_FUSED_PW_BWD", "spb_debug_set_fused_pw_bwd"), ("SPB_BK64_MIN_K", "spb_debug_set_gemm_bk64_min_k"),
-                    ("SPB_PLAIN_DMA", "spb_debug_set_gemm_plain_dma"), ("SPB_DW_XCD", "spb_debug_set_dw_xcd"),
-                    ("SPB_REPLICA_ROWS", "spb_debug_set_replica_rows"), ("SPB_BK64_DGRAD_MIN_K", "spb_debug_set_gemm_bk64_dgrad_min_k"),
-                    ("SPB_WGRAD_BATCH", "spb_debug_set_wgrad_batch"), ("SPB_WGRAD_MIN_FLUSH", "spb_debug_set_wgrad_min_flush"),
-                    ("SPB_LAUNCH_EVENTS", "spb_debug_set_launch_events"), ("SPB_DW_SPLIT", "spb_debug_set_dw_split"),
-                    ("SPB_DW_PLANE_W", "spb_debug_set_dw_plane_max_w"), ("SPB_WGRAD_TARGET", "spb_debug_set_wgrad_target")):
-        if os.environ.get(env) is not None:
-            getattr(_L.lib(), fn)(int(os.environ[env]))
-    for kv in filter(None, os.environ.get("SPB_DBG", "").split(";")):   # generic: SPB_DBG="spb_debug_set_x=1,2;spb_debug_set_y=3"
-        fn, _, val = kv.partition("=")
-        getattr(_L.lib(), fn)(*[int(v) for v in val.split(",")])
-    if os.environ.get("SPB_STEM_GRID"):      # "fwd,wgrad" workgroup caps
-        _L.lib().spb_debug_set_stem_grid(*[int(v) for v in os.environ["SPB_STEM_GRID"].split(",")])
-
+    # A/B experiments: SPB_DEBUG="spb_debug_set_x:1,2;spb_debug_set_y:3" makes speedplusbaseline_amd._lib load the TUNING build
+    # (libspb_hip_tune.so, include/spb_hip_tuning.h) and apply the knobs; unset, the product library runs, which has none.
     B = args.batch
     eng = KrnEngine(11).attach(dev, args.precision)
     sd = O.init_state(11)  # random-init weights of the KRN architecture (no checkpoints offline)
@@ -660,9 +645,6 @@ def bench_spn(args):
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         _init_dist(dev)
         group = torch.distributed.group.WORLD
-    from speedplusbaseline_amd import _lib as _L
-    if os.environ.get("SPB_PLAIN_DMA") is not None:
-        _L.lib().spb_debug_set_gemm_plain_dma(int(os.environ["SPB_PLAIN_DMA"]))
     B = 32 if args.batch == 48 else args.batch
     NC = 5000
     torch.manual_seed(2021)

@@ -640,56 +640,7 @@ int spb_preproc_max_taps(void);   /* crops larger than (taps-1)/2 x S per side n
 int spb_preproc_batch(const spb_preproc_args_t* a, spb_stream_t stream);
 
 /* debug / test helpers */
-int spb_debug_set_conv9_band(int on); /* decoder's last 9x9 layer: band-staged kernel (1, default) or the generic 8x8-tile kernel */
-int spb_debug_set_launch_events(int on); /* side-stream forks wait on the preceding GEMM launch's completion event (1) or on a recorded event (0) */
-int spb_debug_set_dw_split(int hw);        /* depthwise layers on maps up to `hw` columns wide run their weight gradient on the side stream (default 112: every depthwise layer; 0: always fused) */
-int spb_debug_set_domain_tail_rows(int on); /* RevGrad forward: row-parallel AvgPool2d(7) + Conv2d(1280,1,1) tail (1, default) or the walking kernel (0) */
-int spb_debug_set_join_fused(int on);      /* KRN plan: residual adds formed by the next expand convolution (1, default) or by bn_apply launches (0) */
-int spb_debug_set_wgrad_parts(int on);     /* KRN plan: weight gradients as partial sums + spb_partial_reduce (1, default) or f32 atomics (0) */
-int spb_debug_set_wgrad_min_flush(int n); /* fork at a depthwise backward kernel only when >= n weight gradients are queued */
-int spb_debug_set_wgrad_target(int wgs); /* pointwise weight gradient: row splits chosen for about this many workgroups per launch (every split adds N*K f32 atomics); wgs < 0: the same for the partial-sum form (default 512; every split adds an N*K slab) */
-int spb_debug_set_wgrad_batch(int n); /* pointwise weight-gradient GEMMs handed to the side stream per fork event */
-int spb_debug_set_gemm_bk64_dgrad_min_k(int k); /* backward-type small-M GEMMs with K >= k: 64x32 tiles with 64-deep chunks */
-int spb_debug_set_replica_rows(long long rows); /* BatchNorm batch sums get 8 atomic replicas for tensors with at least this many rows (contexts created afterwards) */
-int spb_debug_set_dw_xcd(int on); /* depthwise row kernels: channel quads of one task range on one XCD (1, default) or quad-major ids */
-int spb_debug_set_stem_grid(int fwd, int wgrad); /* workgroup caps of the stem forward / weight-gradient launches (A/B) */
-int spb_debug_set_gemm_plain_dma(int on); /* pro_mode 0 bf16 GEMMs: LDS-DMA ring kernel (1, default) or the register-prefetch kernel */
-int spb_debug_set_optim(int vec, int per_thread, int nontemporal); /* optimizer launch shape A/B: lanes of 1|4 floats, 1|2|4 per thread, nt accesses */
 int spb_debug_trread(const unsigned short* in4096, unsigned short* out256, spb_stream_t stream);
-int spb_debug_set_gemm_dma(int on); /* 1: small-M bf16 pointwise GEMMs use the LDS-DMA ring kernel (default 0) */
-int spb_debug_set_dw_mode(int mode); /* depthwise fwd/dgrad: 1 plane kernels on maps up to spb_debug_set_dw_plane_max_w columns wide (14x14 and 7x7 by default), row-unit kernels elsewhere (default); 0 row-unit kernels only */
-int spb_debug_set_fused_pw_bwd(int on); /* 0: the KRN plan never uses spb_pwconv_bwd_fused */
-int spb_debug_set_stem_mfma(int on); /* 0: bf16 stem uses the scalar kernels instead of the MFMA implicit GEMM */
-int spb_debug_set_dw_wgrad_blocks(int n); /* workgroups of the depthwise weight-gradient-only launches (A/B) */
-int spb_debug_set_side_priority(int on); /* 1: contexts created afterwards put their weight-gradient side stream at the lowest stream priority (A/B) */
-int spb_debug_set_stem_tile(int on); /* 0: the bf16 stem kernels gather their taps from global memory instead of an LDS tile (A/B) */
-int spb_debug_set_stem_wgrad_tile(int rows); /* output rows per workgroup of the LDS-tile stem weight gradient (8 | 16; 0: gather kernel) */
-int spb_debug_set_softce_split(int min_classes); /* spb_softce / _scaled: rows of at least this many classes (default 2048) use the class-split pair of launches (8 workgroups per row) */
-int spb_debug_set_dw_tile(int min_width, int workgroups); /* bf16 depthwise forward on maps at least min_width wide: LDS-tile kernels (dwconv_tile.hip; default 28, 0 = never); workgroups per launch in the low 16 bits (0 = resident estimate); bit 16: the stride-1 input gradient too (off: measured slower) */
-int spb_debug_set_pwb(int chunk_rows, int recompute_z, int max_waves); /* fused pointwise backward: rows per chunk (16 default | 32), z of the expand layers recomputed on the matrix cores instead of read (1 default; -1 keeps), waves per workgroup (8) */
-int spb_debug_set_gemm_rs(int on, int min_m); /* bf16 GEMMs with K <= 96, N = 192 | 384 | 576, M >= min_m (4096): one-round-trip row-slab kernel (on=1, default) */
-int spb_debug_set_gemm_big(int on, int min_n, int min_k); /* small-M bf16 GEMMs with N >= min_n (512), K >= min_k (256): 128 x 128 tile kernel (on=1, default) */
-int spb_debug_set_bn_bwd_prep_rows(int on); /* spb_bn_bwd_prep: row-parallel kernel (1, default) or the walking kernel (0) */
-int spb_debug_set_gemm_wg_cap(int n); /* tiled pointwise GEMM: most workgroups per launch (default 1024 = what is resident at once); beyond it workgroups loop over M tiles */
-int spb_debug_set_gemm_wide_min_n(int n); /* small-M forward-type bf16 GEMMs with N >= n and a long reduction: 64 x 128 tiles */
-int spb_debug_set_gemm_bk64_min_k(int k); /* small-M bf16 GEMMs with K >= k use 64-wide reduction chunks (default 256) */
-int spb_debug_set_gconv_slab(int mode); /* wide decoder convs: 0 per-wave weight streaming; 1 slab kernel with 4 tiles (1 workgroup per CU); 2 (default) 2 tiles, 2 per CU */
-int spb_debug_set_side_wgrad(int on); /* 0: pointwise weight gradients stay on the launch stream */
-int spb_debug_set_dw_rows(int rows); /* rows per row unit (0: automatic) */
-int spb_debug_set_dw_plane_max_w(int w); /* depthwise plane kernels: widest feature map they take (default 14; at most 28) */
-int spb_debug_set_dw_plane_min_wgs(int n); /* depthwise plane kernels: fewer images per workgroup while the launch has fewer workgroups than n (default 384) */
-int spb_debug_set_im2col_rgb_band(int on); /* SPN conv1 column matrix: 1 = band kernel (image rows through LDS), 0 = per-element gather */
-int spb_debug_set_conv9_wgs(int n); /* 9x9 32->3 conv: persistent workgroups (default 512) */
-int spb_debug_set_gconv_up2_wreg(int on); /* 64 -> 32 phase conv: a wave keeps its phase weights in registers for all its tile groups (1, default) */
-int spb_debug_set_gconv_up2_prefetch(int on); /* phase (upsampling) convs: prefetch the next tile group's halo into registers (1, default) */
-int spb_debug_set_gconv_wide_wgs(int n); /* residual-block convs (ghiasi_wide.hip): persistent workgroups (default 512 = two per CU) */
-int spb_debug_set_gconv_wide_rotate(int on); /* ... workgroups enter the 36-step weight cycle at staggered steps (1, default; no measured effect) */
-int spb_debug_set_gconv_wide_delay(int n); /* ... experiment: second workgroup of a CU starts n x 0.43 us late (0, default) */
-int spb_debug_set_gconv_slab_pf(int n); /* wide decoder convs: weight slabs in flight per workgroup (3 | 6, default 6) */
-int spb_debug_set_gconv_halo_prefetch(int on); /* decoder convs with LDS-resident weights: prefetch the next tile's halo (1, default) */
-int spb_debug_set_gconv_wlds_pxg(int n); /* decoder convs with LDS-resident weights: 8x8 tiles per workgroup side by side (1 | 2) */
-int spb_debug_set_gemm_os(int on, int min_k, int max_n, int min_m); /* small-map bf16 GEMMs with min_k <= K <= 576, N <= max_n (<= 96), M >= min_m: one-shot kernel (on=1, default; 0 arguments keep the defaults 160 / 96 / 4096) */
-int spb_debug_set_gemm_sk(int on, int min_k, int rf); /* small-M bf16 GEMMs with K >= min_k (default 192): split-K-over-waves kernel (on=1, default); rf > 0 forces 16*rf-row tiles */
 const char* spb_version(void);
 
 #ifdef __cplusplus

@@ -218,7 +218,6 @@ SYMBOLS = {
     "spb_relu_bwd": (i32, [i32, vp, vp, vp, vp, i64, f32, vp]),
     "spb_dropout": (i32, [i32, vp, vp, i64, f32, C.c_ulonglong, i32, vp]),
     "spb_softce": (i32, [i32, vp, vp, vp, vp, i32, i32, i32, f32, vp]),
-    "spb_debug_set_softce_split": (i32, [i32]),
     "spb_softce_scaled": (i32, [i32, vp, vp, vp, vp, i32, i32, i32, f32, vp, vp]),
     "spb_amp_check": (i32, [vp, i64, vp, vp]),
     "spb_amp_check16": (i32, [vp, i64, vp, vp]),
@@ -228,21 +227,6 @@ SYMBOLS = {
     "spb_colsum": (i32, [i32, vp, vp, i64, i32, vp]),
     "spb_preproc_max_taps": (i32, []),
     "spb_preproc_batch": (i32, [C.POINTER(PreprocArgs), vp]),
-    "spb_debug_set_optim": (i32, [i32, i32, i32]),
-    "spb_debug_set_conv9_band": (i32, [i32]),
-    "spb_debug_set_launch_events": (i32, [i32]),
-    "spb_debug_set_dw_split": (i32, [i32]),
-    "spb_debug_set_wgrad_parts": (i32, [i32]),
-    "spb_debug_set_join_fused": (i32, [i32]),
-    "spb_debug_set_domain_tail_rows": (i32, [i32]),
-    "spb_debug_set_wgrad_min_flush": (i32, [i32]),
-    "spb_debug_set_wgrad_batch": (i32, [i32]),
-    "spb_debug_set_wgrad_target": (i32, [i32]),
-    "spb_debug_set_gemm_bk64_dgrad_min_k": (i32, [i32]),
-    "spb_debug_set_replica_rows": (i32, [i64]),
-    "spb_debug_set_dw_xcd": (i32, [i32]),
-    "spb_debug_set_stem_grid": (i32, [i32, i32]),
-    "spb_debug_set_gemm_plain_dma": (i32, [i32]),
     "spb_spn_pack_conv": (i32, [i32, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
     "spb_spn_unpack_conv_grad": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
     "spb_spn_conv": (i32, [C.POINTER(SpnConvArgs), vp]),
@@ -258,6 +242,37 @@ SYMBOLS = {
     "spb_spn_flatten": (i32, [vp, vp, vp, i32, i32, i32, vp]),
     "spb_spn_unflatten_grad": (i32, [vp, vp, i32, i32, i32, vp]),
     "spb_debug_trread": (i32, [vp, vp, vp]),
+    "spb_version": (C.c_char_p, []),
+    "spb_krn_num_acts": (i32, [vp]),
+    "spb_krn_ctx_act_info": (i32, [vp, i32, C.POINTER(ActInfo)]),
+    "spb_det_available": (i32, []),
+    "spb_det_register": (i32, [vp, i64, vp]),
+    "spb_det_unregister": (i32, [vp]),
+    "spb_det_flush": (i32, [vp, vp]),
+    "spb_det_misses": (i64, []),
+    "spb_krn_set_det": (i32, [vp, i32]),
+    "spb_krn_ctx_set_det": (i32, [vp, i32]),
+    "spb_krn_ctx_stats": (i32, [vp, C.POINTER(vp), C.POINTER(i64)]),
+}
+
+# the knobs of the TUNING build (include/spb_hip_tuning.h): exported by libspb_hip_tune.so only
+TUNING_SYMBOLS = {
+    "spb_debug_set_softce_split": (i32, [i32]),
+    "spb_debug_set_optim": (i32, [i32, i32, i32]),
+    "spb_debug_set_conv9_band": (i32, [i32]),
+    "spb_debug_set_launch_events": (i32, [i32]),
+    "spb_debug_set_dw_split": (i32, [i32]),
+    "spb_debug_set_wgrad_parts": (i32, [i32]),
+    "spb_debug_set_join_fused": (i32, [i32]),
+    "spb_debug_set_domain_tail_rows": (i32, [i32]),
+    "spb_debug_set_wgrad_min_flush": (i32, [i32]),
+    "spb_debug_set_wgrad_batch": (i32, [i32]),
+    "spb_debug_set_wgrad_target": (i32, [i32]),
+    "spb_debug_set_gemm_bk64_dgrad_min_k": (i32, [i32]),
+    "spb_debug_set_replica_rows": (i32, [i64]),
+    "spb_debug_set_dw_xcd": (i32, [i32]),
+    "spb_debug_set_stem_grid": (i32, [i32, i32]),
+    "spb_debug_set_gemm_plain_dma": (i32, [i32]),
     "spb_debug_set_gemm_dma": (i32, [i32]),
     "spb_debug_set_dw_mode": (i32, [i32]),
     "spb_debug_set_side_wgrad": (i32, [i32]),
@@ -291,51 +306,86 @@ SYMBOLS = {
     "spb_debug_set_gconv_wide_wgs": (i32, [i32]),
     "spb_debug_set_gconv_wide_rotate": (i32, [i32]),
     "spb_debug_set_gconv_wide_delay": (i32, [i32]),
-    "spb_version": (C.c_char_p, []),
-    "spb_krn_num_acts": (i32, [vp]),
-    "spb_krn_ctx_act_info": (i32, [vp, i32, C.POINTER(ActInfo)]),
-    "spb_det_available": (i32, []),
-    "spb_det_register": (i32, [vp, i64, vp]),
-    "spb_det_unregister": (i32, [vp]),
-    "spb_det_flush": (i32, [vp, vp]),
-    "spb_det_misses": (i64, []),
-    "spb_krn_set_det": (i32, [vp, i32]),
-    "spb_krn_ctx_set_det": (i32, [vp, i32]),
-    "spb_krn_ctx_stats": (i32, [vp, C.POINTER(vp), C.POINTER(i64)]),
 }
 
 _lib = None
+_lib_tune = None
+_tuning_depth = 0
+LIB_TUNE_PATH = os.path.join(_HERE, "libspb_hip_tune.so")
+
+
+def _load(path, symbols, what):
+    if not os.path.exists(path):
+        raise RuntimeError(
+            "%s is missing (%s). Build it with `python -m speedplusbaseline_amd.build`; this package "
+            "has no CPU or PyTorch fallback for the hot path." % (what, path))
+    # torch must load ITS HIP runtime first: the kernels work on torch-allocated device memory and torch's streams,
+    # so the library has to bind to the same libamdhip64 instance (a second runtime sees no device: error 100)
+    import torch  # noqa: F401
+    l = C.CDLL(path)
+    for name, (res, args) in symbols.items():
+        fn = getattr(l, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    return l
 
 
 def lib():
-    """Load the HIP library (built in-tree by speedplusbaseline_amd/build.py). No fallback exists."""
+    """The HIP library (built in-tree by speedplusbaseline_amd/build.py).  No fallback exists.  The product library
+    libspb_hip.so has no tuning knobs; inside a `with tuning():` block -- or for the whole process when SPB_DEBUG is set (measurement
+    runs) -- this returns the tuning build libspb_hip_tune.so instead, which exports the spb_debug_set_* knobs as well."""
     global _lib
+    if _tuning_depth > 0 or os.environ.get("SPB_DEBUG") or os.environ.get("SPB_TUNING_LIB"):
+        return lib_tune()
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
-            raise RuntimeError(
-                "libspb_hip.so is missing (%s). Build it with `python -m speedplusbaseline_amd.build`; this package "
-                "has no CPU or PyTorch fallback for the hot path." % LIB_PATH)
-        # torch must load ITS HIP runtime first: the kernels work on torch-allocated device memory and torch's streams,
-        # so libspb_hip.so has to bind to the same libamdhip64 instance (a second runtime sees no device: error 100)
-        import torch  # noqa: F401
-        l = C.CDLL(LIB_PATH)
-        for name, (res, args) in SYMBOLS.items():
-            fn = getattr(l, name)  # AttributeError if the symbol is not exported
-            fn.restype = res
-            fn.argtypes = args
-        _lib = l
-        _apply_debug_env(l)
+        _lib = _load(LIB_PATH, SYMBOLS, "libspb_hip.so")
     return _lib
+
+
+def lib_tune():
+    """libspb_hip_tune.so: the sources compiled with -DSPB_TUNING (include/spb_hip_tuning.h).  Same C-ABI + the spb_debug_set_* knobs."""
+    global _lib_tune
+    if _lib_tune is None:
+        both = dict(SYMBOLS); both.update(TUNING_SYMBOLS)
+        _lib_tune = _load(LIB_TUNE_PATH, both, "libspb_hip_tune.so")
+        _apply_debug_env(_lib_tune)
+    return _lib_tune
+
+
+class tuning:
+    """`with tuning() as l:` -- lib() returns the tuning build inside the block (kernel-variant tests, A/B measurements).  Objects that
+    cached a library handle before the block (KrnEngine.lib) keep theirs."""
+
+    def __enter__(self):
+        global _tuning_depth
+        _tuning_depth += 1
+        return lib_tune()
+
+    def __exit__(self, *exc):
+        global _tuning_depth
+        _tuning_depth -= 1
+        return False
+
+
+def tuned(fn):
+    """decorator: run `fn` inside `with tuning():` (tests that select a kernel variant through the knobs)"""
+    import functools
+
+    @functools.wraps(fn)
+    def inner(*a, **k):
+        with tuning():
+            return fn(*a, **k)
+    return inner
 
 
 def _apply_debug_env(l):
     """A/B switch for measurement runs: SPB_DEBUG="spb_debug_set_pwb:32,0,4;spb_debug_set_dw_split:56" calls the named
-    spb_debug_* knobs (integer arguments) once, right after the library is loaded.  Unset in production."""
+    spb_debug_* knobs (integer arguments) once, right after the tuning library is loaded.  Unset in production."""
     spec = os.environ.get("SPB_DEBUG", "")
     for item in filter(None, (x.strip() for x in spec.split(";"))):
         name, _, args = item.partition(":")
-        if not name.startswith("spb_debug_") or name not in SYMBOLS:
-            raise RuntimeError("SPB_DEBUG: %r is not a debug knob of libspb_hip.so" % name)
+        if not name.startswith("spb_debug_") or name not in TUNING_SYMBOLS:
+            raise RuntimeError("SPB_DEBUG: %r is not a knob of libspb_hip_tune.so" % name)
         vals = [int(v) for v in args.split(",") if v.strip()]
         getattr(l, name)(*vals)
 

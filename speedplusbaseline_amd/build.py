@@ -22,6 +22,9 @@ LIB_F16 = os.path.join(HERE, "libspb_hip_f16.so")
 SOURCES_F16 = ["gemm_pw.hip", "elemwise.hip", "spn.hip", "spn_fc.hip", "spn_conv.hip"]
 # Reproducible twin (csrc/common.h, -DSPB_DET): the KRN / DANN kernels and the plan with exact (order-independent) accumulation in
 # place of float atomics.  KrnEngine(..., deterministic=True) and tests/test_parity_conditioned_gpu.py use it.
+# Tuning twin (-DSPB_TUNING): the only build that exports the spb_debug_set_* knobs (include/spb_hip_tuning.h).  Measurement scripts and
+# the kernel-variant tests load it; the product library above has no mutable tuning state.
+LIB_TUNE = os.path.join(HERE, "libspb_hip_tune.so")
 LIB_DET = os.path.join(HERE, "libspb_hip_det.so")
 SOURCES_DET = ["gemm_pw.hip", "gemm_sk.hip", "gemm_os.hip", "gemm_big.hip", "gemm_rs.hip", "pw_bwd_fused.hip", "dwconv_rows.hip", "dwconv_plane.hip", "dwconv_tile.hip", "stem_head.hip", "stem_mfma.hip", "elemwise.hip", "krn_plan.hip"]
 
@@ -46,10 +49,11 @@ def build(force=False, verbose=True):
     os.makedirs(OBJDIR, exist_ok=True)
     headers = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(".h")]
     headers.append(os.path.join(ROOT, "include", "spb_hip.h"))
+    headers.append(os.path.join(ROOT, "include", "spb_hip_tuning.h"))
     srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
     stamp = os.path.join(OBJDIR, "stamp.txt")
     want = _digest(srcs + headers)
-    if not force and os.path.exists(LIB) and os.path.exists(LIB_F16) and os.path.exists(LIB_DET) and os.path.exists(stamp) and open(stamp).read().strip() == want:
+    if not force and os.path.exists(LIB) and os.path.exists(LIB_F16) and os.path.exists(LIB_DET) and os.path.exists(LIB_TUNE) and os.path.exists(stamp) and open(stamp).read().strip() == want:
         return LIB
     hipcc = _hipcc()
 
@@ -87,7 +91,8 @@ def build(force=False, verbose=True):
         objs = list(ex.map(compile_one, srcs))
         objs16 = list(ex.map(lambda s_: compile_twin(s_, "f16", "-DSPB_F16"), srcs16))
         objsdet = list(ex.map(lambda s_: compile_twin(s_, "det", "-DSPB_DET"), srcsdet))
-    for out, ob in ((LIB, objs), (LIB_F16, objs16), (LIB_DET, objsdet)):
+        objstune = list(ex.map(lambda s_: compile_twin(s_, "tune", "-DSPB_TUNING"), srcs))
+    for out, ob in ((LIB, objs), (LIB_F16, objs16), (LIB_DET, objsdet), (LIB_TUNE, objstune)):
         cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + ob
         if verbose:
             print(" ".join(cmd), flush=True)

@@ -34,7 +34,7 @@ struct spb_det_table_t { spb_det_region_t r[SPB_DET_MAX_REGIONS]; int n; int pad
 static __device__ spb_det_table_t g_spb_det_table;          // one copy per translation unit (no relocatable device code)
 static __device__ unsigned long long g_spb_det_misses;
 typedef int (*spb_det_tu_fn)(const spb_det_table_t*, unsigned long long*);
-extern "C" void spb_det_register_tu(spb_det_tu_fn f);       // krn_plan.hip: the list of per-file setters
+extern "C" __attribute__((visibility("hidden"))) void spb_det_register_tu(spb_det_tu_fn f);       // krn_plan.hip: the list of per-file setters (internal)
 // (t != null: upload the table; misses != null: add and clear this file's miss counter)
 static int spb_det_tu_sync(const spb_det_table_t* t, unsigned long long* misses) {
   if (t && hipMemcpyToSymbol(HIP_SYMBOL(g_spb_det_table), t, sizeof(*t)) != hipSuccess) { (void)hipGetLastError(); return 1; }

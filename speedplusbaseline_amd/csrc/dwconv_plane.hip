@@ -488,8 +488,12 @@ unsigned plane_grid(const PGeo& g) { return (unsigned)(g.nslab * ((g.ntasks + 7)
 
 }  // namespace
 
+#ifdef SPB_TUNING   // tuning build only (libspb_hip_tune.so, include/spb_hip_tuning.h): the product library has no knob
 extern "C" int spb_debug_set_dw_plane_min_wgs(int n) { g_plane_min_wgs = n; return 0; }
+#endif
+#ifdef SPB_TUNING   // tuning build only (libspb_hip_tune.so, include/spb_hip_tuning.h): the product library has no knob
 extern "C" int spb_debug_set_dw_plane_max_w(int w) { g_plane_max_w = w; return 0; }
+#endif
 
 // returns 0 when launched, SPB_E_UNSUPPORTED when the shape is left to the row-unit kernels
 int spb_dwp_fwd(int dtype, const spb_dw_args_t* a, hipStream_t s) {

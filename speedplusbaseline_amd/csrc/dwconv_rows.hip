@@ -602,9 +602,15 @@ void allow_lds(K kernel, size_t bytes) {
 
 // rows > 0: rows per task; rows < 0: -rows = target block count (experiments)
 static int g_dw_wgrad_blocks = 512;   // workgroups of the weight-gradient-only instance (side stream); spb_debug_set_dw_wgrad_blocks
+#ifdef SPB_TUNING   // tuning build only (libspb_hip_tune.so, include/spb_hip_tuning.h): the product library has no knob
 extern "C" int spb_debug_set_dw_wgrad_blocks(int n) { if (n > 0) g_dw_wgrad_blocks = n; return 0; }
+#endif
+#ifdef SPB_TUNING   // tuning build only (libspb_hip_tune.so, include/spb_hip_tuning.h): the product library has no knob
 extern "C" int spb_debug_set_dw_xcd(int on) { g_xcd_pair = on; return 0; }
+#endif
+#ifdef SPB_TUNING   // tuning build only (libspb_hip_tune.so, include/spb_hip_tuning.h): the product library has no knob
 extern "C" int spb_debug_set_dw_rows(int rows) { if (rows >= 0) g_rows_override = rows; else g_blocks_override = -rows; return 0; }
+#endif
 
 int spb_dwr_fwd(int dtype, const spb_dw_args_t* a, hipStream_t s) {
   const int st = a->stride;
@@ -693,7 +699,9 @@ int spb_dwt_fwd(int dtype, const spb_dw_args_t* a, hipStream_t s);   // dwconv_t
 int spb_dwt_dgrad(int dtype, const spb_dw_args_t* a, hipStream_t s);
 int spb_dwp_bwd(int dtype, const spb_dw_args_t* a, hipStream_t s);
 static int g_dw_mode = 1;   // 1: plane kernels where they apply (default); 0: row-unit kernels only
+#ifdef SPB_TUNING   // tuning build only (libspb_hip_tune.so, include/spb_hip_tuning.h): the product library has no knob
 extern "C" int spb_debug_set_dw_mode(int mode) { g_dw_mode = mode; return 0; }
+#endif
 
 static int dw_check(const spb_dw_args_t* a) {
   if (!a || !a->X || !a->Wd) return SPB_E_ARG;

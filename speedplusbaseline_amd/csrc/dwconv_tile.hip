@@ -500,12 +500,14 @@ static int g_dw_tile_dgrad = 0;    // stride-1 input gradient on the tile kernel
 
 }  // namespace
 
+#ifdef SPB_TUNING   // tuning build only (libspb_hip_tune.so, include/spb_hip_tuning.h): the product library has no knob
 extern "C" int spb_debug_set_dw_tile(int min_width, int workgroups) {
   g_dw_tile_min = min_width <= 0 ? (1 << 30) : min_width;
   g_dw_tile_wgs = workgroups < 0 ? 0 : workgroups & 0xffff;
   g_dw_tile_dgrad = workgroups >= 0 && (workgroups >> 16) != 0;     // bit 16: also the stride-1 input gradient
   return 0;
 }
+#endif
 
 // SPB_E_UNSUPPORTED: not covered (the caller keeps the row-unit / plane kernels)
 int spb_dwt_fwd(int dtype, const spb_dw_args_t* a, hipStream_t s) {

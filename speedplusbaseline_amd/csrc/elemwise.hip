@@ -526,7 +526,9 @@ extern "C" int spb_bn_apply(int dtype, const spb_bnapply_args_t* a, spb_stream_t
 }
 
 static int g_bbp_rows = 1;   // spb_debug_set_bn_bwd_prep_rows(0): the walking kernel (kept as the test reference)
+#ifdef SPB_TUNING   // tuning build only (libspb_hip_tune.so, include/spb_hip_tuning.h): the product library has no knob
 extern "C" int spb_debug_set_bn_bwd_prep_rows(int on) { g_bbp_rows = on; return 0; }
+#endif
 extern "C" int spb_bn_bwd_prep(int dtype, const spb_bnbwd_args_t* a, spb_stream_t stream) {
   if (!a || !a->dY || !a->Z || !a->G || !a->osums || a->oR < 1) return SPB_E_ARG;
   if (a->C <= 0 || (a->C & 7) || (a->ldc & 7) || (a->coff & 7)) return SPB_E_SHAPE;
@@ -669,10 +671,12 @@ extern "C" int spb_optim_step(const spb_optim_args_t* a, spb_stream_t stream) {
   return 0;
 }
 
+#ifdef SPB_TUNING   // tuning build only (libspb_hip_tune.so, include/spb_hip_tuning.h): the product library has no knob
 extern "C" int spb_debug_set_optim(int vec, int blocks, int nontemporal) {
   g_opt_vec = vec == 4 ? 4 : 1; g_opt_blocks = blocks; g_opt_nt = nontemporal;
   return 0;
 }
+#endif
 
 // Streams for work that must not compete with the launch stream for the compute units: level -1 = the device's highest
 // dispatch priority, 0 = default, +1 = lowest (the workgroup dispatcher serves higher-priority queues first, so a low stream's

@@ -403,9 +403,11 @@ int spb_gemm_big(const spb_gemm_args_t* a, hipStream_t stream) {
   return SPB_E_UNSUPPORTED;
 }
 
+#ifdef SPB_TUNING   // tuning build only (libspb_hip_tune.so, include/spb_hip_tuning.h): the product library has no knob
 extern "C" int spb_debug_set_gemm_big(int on, int min_n, int min_k) {
   g_big_on = on;
   if (min_n > 0) g_big_min_n = min_n;
   if (min_k > 0) g_big_min_k = min_k;
   return 0;
 }
+#endif

@@ -338,6 +338,7 @@ int spb_gemm_os(const spb_gemm_args_t* a, hipStream_t stream) {
   return SPB_E_UNSUPPORTED;
 }
 
+#ifdef SPB_TUNING   // tuning build only (libspb_hip_tune.so, include/spb_hip_tuning.h): the product library has no knob
 extern "C" int spb_debug_set_gemm_os(int on, int min_k, int max_n, int min_m) {
   g_os_on = on;
   if (min_k > 0) g_os_min_k = min_k;
@@ -345,3 +346,4 @@ extern "C" int spb_debug_set_gemm_os(int on, int min_k, int max_n, int min_m) {
   if (min_m > 0) g_os_min_m = min_m;
   return 0;
 }
+#endif

@@ -976,15 +976,29 @@ extern "C" int spb_debug_trread(const unsigned short* in4096, unsigned short* ou
   return 0;
 }
 
+#ifdef SPB_TUNING   // tuning build only (libspb_hip_tune.so, include/spb_hip_tuning.h): the product library has no knob
 extern "C" int spb_debug_set_wgrad_target(int wgs) {   // wgs < 0: target of the partial-store form
   if (wgs < 0) g_wgrad_part_target = -wgs; else g_wgrad_target_wgs = wgs < 1 ? 1 : wgs;
   return 0;
 }
+#endif
+#ifdef SPB_TUNING   // tuning build only (libspb_hip_tune.so, include/spb_hip_tuning.h): the product library has no knob
 extern "C" int spb_debug_set_gemm_dma(int on) { g_disable_dma = (on == 0); g_dma_min_k = on > 1 ? on : 64; return 0; }
+#endif
+#ifdef SPB_TUNING   // tuning build only (libspb_hip_tune.so, include/spb_hip_tuning.h): the product library has no knob
 extern "C" int spb_debug_set_gemm_plain_dma(int on) { g_plain_dma = (on != 0); return 0; }
+#endif
+#ifdef SPB_TUNING   // tuning build only (libspb_hip_tune.so, include/spb_hip_tuning.h): the product library has no knob
 extern "C" int spb_debug_set_gemm_bk64_min_k(int k) { g_bk64_min_k = k; return 0; }
+#endif
+#ifdef SPB_TUNING   // tuning build only (libspb_hip_tune.so, include/spb_hip_tuning.h): the product library has no knob
 extern "C" int spb_debug_set_gemm_wide_min_n(int n) { g_wide_min_n = n; return 0; }
+#endif
+#ifdef SPB_TUNING   // tuning build only (libspb_hip_tune.so, include/spb_hip_tuning.h): the product library has no knob
 extern "C" int spb_debug_set_gemm_wg_cap(int n) { g_gemm_wg_cap = n < 64 ? 64 : n; return 0; }
+#endif
+#ifdef SPB_TUNING   // tuning build only (libspb_hip_tune.so, include/spb_hip_tuning.h): the product library has no knob
 extern "C" int spb_debug_set_gemm_bk64_dgrad_min_k(int k) { g_bk64_dgrad_min_k = k; return 0; }
+#endif
 
 extern "C" const char* spb_version(void) { return "speedplusbaseline_amd gfx950 r1"; }

@@ -266,8 +266,10 @@ int spb_gemm_rs(const spb_gemm_args_t* a, hipStream_t stream) {
   return SPB_E_UNSUPPORTED;
 }
 
+#ifdef SPB_TUNING   // tuning build only (libspb_hip_tune.so, include/spb_hip_tuning.h): the product library has no knob
 extern "C" int spb_debug_set_gemm_rs(int on, int min_m) {
   g_rs_on = on;
   if (min_m > 0) g_rs_min_m = min_m;
   return 0;
 }
+#endif

@@ -334,9 +334,11 @@ int spb_gemm_sk(const spb_gemm_args_t* a, hipStream_t stream) {
   return SPB_E_UNSUPPORTED;
 }
 
+#ifdef SPB_TUNING   // tuning build only (libspb_hip_tune.so, include/spb_hip_tuning.h): the product library has no knob
 extern "C" int spb_debug_set_gemm_sk(int on, int min_k, int rf) {
   g_sk_on = on & 1; if (min_k > 0) g_sk_min_k = min_k; g_sk_rf = rf;
   g_sk_max_n = (on & 2) ? (1 << 30) : 320;    // on & 2: also the wide layers (experiments)
   g_sk_max_m = (on & 4) ? 40000 : 4096;       // on & 4: also the 14x14 maps
   return 0;
 }
+#endif

@@ -1484,21 +1484,33 @@ __global__ void final_sigmoid_kernel(const bf16_t* Z, const float* coef, float* 
 }  // namespace
 
 static int g_gconv_slab = 2;   // 0: per-wave weight streaming; 1: slab kernel, 4 tiles / 1 workgroup per CU; 2: 2 tiles / 2 per CU
+#ifdef SPB_TUNING   // tuning build only (libspb_hip_tune.so, include/spb_hip_tuning.h): the product library has no knob
 extern "C" int spb_debug_set_gconv_slab(int on) { g_gconv_slab = on; return 0; }
+#endif
 
 // 8x8 tiles side by side per workgroup in the LDS-resident-weight layers (32->64 stride 2, 64->32 after upsampling): with one,
 // a wave reads 1 pixel + NB weight fragments per NB MFMAs (294..353 B/clk/CU of LDS reads at matrix-core speed, over the 256 peak)
 static int g_slab_pf = 6;    // weight slabs in flight per workgroup of the wide layers (3 | 6)
+#ifdef SPB_TUNING   // tuning build only (libspb_hip_tune.so, include/spb_hip_tuning.h): the product library has no knob
 extern "C" int spb_debug_set_gconv_slab_pf(int n) { g_slab_pf = n; return 0; }
+#endif
 static int g_halo_prefetch = 1;   // LDS-resident-weight layers: next tile's halo loads in flight during the current tile
+#ifdef SPB_TUNING   // tuning build only (libspb_hip_tune.so, include/spb_hip_tuning.h): the product library has no knob
 extern "C" int spb_debug_set_gconv_halo_prefetch(int on) { g_halo_prefetch = on; return 0; }
+#endif
 static int g_wlds_pxg = 1;
+#ifdef SPB_TUNING   // tuning build only (libspb_hip_tune.so, include/spb_hip_tuning.h): the product library has no knob
 extern "C" int spb_debug_set_gconv_wlds_pxg(int n) { g_wlds_pxg = n; return 0; }
+#endif
 
 static int g_conv9_wgs = 512;  // 9x9 32->3: persistent workgroups
+#ifdef SPB_TUNING   // tuning build only (libspb_hip_tune.so, include/spb_hip_tuning.h): the product library has no knob
 extern "C" int spb_debug_set_conv9_wgs(int n) { g_conv9_wgs = n < 1 ? 1 : n; return 0; }
+#endif
 static int g_conv9_band = 2;   // 9x9 32->3: 0 generic tile kernel, 1 band kernel, 2 kernel columns folded into the matrix rows
+#ifdef SPB_TUNING   // tuning build only (libspb_hip_tune.so, include/spb_hip_tuning.h): the product library has no knob
 extern "C" int spb_debug_set_conv9_band(int on) { g_conv9_band = on; return 0; }
+#endif
 
 int spb_gconv_f32(const spb_gconv_args_t* a, hipStream_t stream);   // ghiasi_f32.hip
 extern "C" int spb_gconv(int dtype, const spb_gconv_args_t* a, spb_stream_t stream) {
@@ -1612,9 +1624,13 @@ extern "C" int spb_gconv(int dtype, const spb_gconv_args_t* a, spb_stream_t stre
 }
 
 static int g_up2_wreg = 2;       // phase layers: weights in registers (1: the 64 -> 32 layer; 2: the 128 -> 64 layer as well)
+#ifdef SPB_TUNING   // tuning build only (libspb_hip_tune.so, include/spb_hip_tuning.h): the product library has no knob
 extern "C" int spb_debug_set_gconv_up2_wreg(int on) { g_up2_wreg = on; return 0; }
+#endif
 static int g_up2_prefetch = 1;   // phase kernels: next tile group's halo loads in flight during the current group
+#ifdef SPB_TUNING   // tuning build only (libspb_hip_tune.so, include/spb_hip_tuning.h): the product library has no knob
 extern "C" int spb_debug_set_gconv_up2_prefetch(int on) { g_up2_prefetch = on; return 0; }
+#endif
 
 // a->W: phase weights [4][Cout][4][Cin] (Ghiasi._pack builds them); a->upsample must be 2, a->stride 1, a->KH 3
 extern "C" int spb_gconv_up2(int dtype, const spb_gconv_args_t* a, spb_stream_t stream) {

@@ -373,11 +373,17 @@ extern "C" int spb_gconv_wide_pack(const void* w, void* packed, spb_stream_t str
 }
 
 static int g_gw_delay = 0;
+#ifdef SPB_TUNING   // tuning build only (libspb_hip_tune.so, include/spb_hip_tuning.h): the product library has no knob
 extern "C" int spb_debug_set_gconv_wide_delay(int n) { g_gw_delay = n; return 0; }
+#endif
 static int g_gw_rot = 1;     // workgroups enter the weight cycle at staggered steps
+#ifdef SPB_TUNING   // tuning build only (libspb_hip_tune.so, include/spb_hip_tuning.h): the product library has no knob
 extern "C" int spb_debug_set_gconv_wide_rotate(int on) { g_gw_rot = on; return 0; }
+#endif
 static int g_gw_wgs = GW_OCC3 ? 768 : 512;   // persistent workgroups: two (three) per CU
+#ifdef SPB_TUNING   // tuning build only (libspb_hip_tune.so, include/spb_hip_tuning.h): the product library has no knob
 extern "C" int spb_debug_set_gconv_wide_wgs(int n) { g_gw_wgs = n < 8 ? 8 : (n & ~7); return 0; }
+#endif
 
 extern "C" int spb_gconv_wide(int dtype, const spb_gconv_args_t* a, spb_stream_t stream) {
   if (!a || !a->X || !a->W || !a->Y) return SPB_E_ARG;

@@ -272,7 +272,7 @@ int det_flush(const float* lo, hipStream_t st) {
   return SPB_E_STATE;
 }
 }  // namespace
-extern "C" void spb_det_register_tu(spb_det_tu_fn f) { det_tus().push_back(f); }
+extern "C" __attribute__((visibility("hidden"))) void spb_det_register_tu(spb_det_tu_fn f) { det_tus().push_back(f); }
 extern "C" int spb_det_available(void) { return 1; }
 extern "C" int spb_det_register(const float* lo, long long n_floats, long long* shadow) {
   if (!lo || n_floats <= 0 || !shadow) return SPB_E_ARG;
@@ -347,12 +347,18 @@ static int g_side_wgrad = 1;
 // depthwise kernels 3.37 ms per step.  spb_debug_set_wgrad_batch(n): n > 0 plain batches of n, n < 0 flush at depthwise, cap -n.
 static int g_skip_side = 0;            // TIMING EXPERIMENT ONLY (spb_debug_set_launch_events(2|4)): 2 drops the pointwise, 4 the depthwise side-stream weight gradients
 static int g_launch_events = 1;        // fork on the completion event of the preceding GEMM launch instead of an event record
+#ifdef SPB_TUNING   // tuning build only (libspb_hip_tune.so, include/spb_hip_tuning.h): the product library has no knob
 extern "C" int spb_debug_set_launch_events(int on) { g_launch_events = on & 1; g_skip_side = on & 6; return 0; }
+#endif
 static int g_side_priority = 0;
+#ifdef SPB_TUNING   // tuning build only (libspb_hip_tune.so, include/spb_hip_tuning.h): the product library has no knob
 extern "C" int spb_debug_set_side_priority(int on) { g_side_priority = on; return 0; }
+#endif
 static int g_wgrad_flush_at_dw = 1;
 static int g_wgrad_min_flush = 1;      // flush at a depthwise kernel only with at least this many queued
+#ifdef SPB_TUNING   // tuning build only (libspb_hip_tune.so, include/spb_hip_tuning.h): the product library has no knob
 extern "C" int spb_debug_set_wgrad_min_flush(int n);
+#endif
 static int g_wgrad_batch = 8;
 // Depthwise layers on maps up to this many columns wide run their input gradient alone on the launch stream and send the weight
 // gradient to the side stream with the pointwise ones: in the plane kernels (dwconv_plane.hip, maps up to 14x14) the weight
@@ -360,13 +366,17 @@ static int g_wgrad_batch = 8;
 // Measured in the step (round 3): 0 -> 3.32 ms, 14 -> 3.22, 28 -> 3.23, 56 -> 3.22 (3.20 vs 3.19 after the later changes).
 // (Round 2, row-unit kernels on every map: the split was slower, 3.33 vs 3.29 ms.)
 static int g_dw_split_hw = 112;   // end of round 3 (with the resident-grid cap on the GEMMs): 56 -> 3.096 ms, 112 -> 3.084
+#ifdef SPB_TUNING   // tuning build only (libspb_hip_tune.so, include/spb_hip_tuning.h): the product library has no knob
 extern "C" int spb_debug_set_dw_split(int hw) { g_dw_split_hw = hw; return 0; }
+#endif
+#ifdef SPB_TUNING   // tuning build only (libspb_hip_tune.so, include/spb_hip_tuning.h): the product library has no knob
 extern "C" int spb_debug_set_wgrad_batch(int n) {
   g_wgrad_flush_at_dw = n < 0;
   if (n < 0) n = -n;
   g_wgrad_batch = n < 1 ? 1 : n;
   return 0;
 }
+#endif
 static long long g_replica_min_rows = 32768;   // BN-sum replicas (8) from this many rows up; spb_debug_set_replica_rows
 static int g_replica_mid = 4;   // replicas for tensors with g_replica_mid_rows <= rows < g_replica_min_rows (the 14x14 maps at bs=48).  Round 2 (tiled
                                 // kernels only): 8 replicas = producers -1 us, consumers +2 us, net zero -> 1.  Round 3: the row-slab GEMM (gemm_rs.hip)
@@ -374,27 +384,37 @@ static int g_replica_mid = 4;   // replicas for tensors with g_replica_mid_rows 
                                 // replica its launches end 6 us after their last store (3.100 ms per step); 2 -> 3.061, 3 -> 3.037, 4 -> 3.027,
                                 // 6 -> 3.029, 8 -> 3.033 (without the row-slab kernel the replica count changes nothing: 3.062)
 static long long g_replica_mid_rows = 4096;
+#ifdef SPB_TUNING   // tuning build only (libspb_hip_tune.so, include/spb_hip_tuning.h): the product library has no knob
 extern "C" int spb_debug_set_replica_rows(long long rows) {
   if (rows < -100) { g_replica_mid_rows = -rows; return 0; }   // below -100: the row count from which the mid-size replica count applies
   if (rows < 0) { g_replica_mid = (int)(-rows > SPB_MAX_REPLICAS ? SPB_MAX_REPLICAS : -rows); return 0; }   // negative: set the mid-size replica count instead
   g_replica_min_rows = rows;
   return 0;
 }
+#endif
 static int g_flush_after_dw = 0;   // measured: 3.23 ms with the side-stream batch enqueued after the launch-stream kernel, 3.19 before it
 // (sign convention of spb_debug_set_wgrad_min_flush: -1 -> before (default), -2 -> after)
+#ifdef SPB_TUNING   // tuning build only (libspb_hip_tune.so, include/spb_hip_tuning.h): the product library has no knob
 extern "C" int spb_debug_set_wgrad_min_flush(int n) {
   if (n < 0) { g_flush_after_dw = n == -2; return 0; }
   g_wgrad_min_flush = n < 1 ? 1 : n;
   return 0;
 }   // spb_debug_set_wgrad_min_flush(-1) restores flush-before-launch
+#endif
 static int g_wgrad_parts = 0;     // 1: pointwise weight gradients as partial sums + one reduce launch per batch instead of f32 atomics
                                   // (order-deterministic; measured 3.25 vs 3.18 ms per step: the slab traffic and the extra launches cost more
                                   // than the atomics they replace) -- spb_debug_set_wgrad_parts
+#ifdef SPB_TUNING   // tuning build only (libspb_hip_tune.so, include/spb_hip_tuning.h): the product library has no knob
 extern "C" int spb_debug_set_wgrad_parts(int on) { g_wgrad_parts = on; return 0; }
+#endif
 static int g_domain_tail_rows = 1;   // row-parallel forward of the domain classifier's pooled tail (spb_debug_set_domain_tail_rows(0): the walking kernel)
+#ifdef SPB_TUNING   // tuning build only (libspb_hip_tune.so, include/spb_hip_tuning.h): the product library has no knob
 extern "C" int spb_debug_set_domain_tail_rows(int on) { g_domain_tail_rows = on; return 0; }
+#endif
 static int g_join_fused = 1;      // residual adds folded into the next expand convolution (spb_debug_set_join_fused)
+#ifdef SPB_TUNING   // tuning build only (libspb_hip_tune.so, include/spb_hip_tuning.h): the product library has no knob
 extern "C" int spb_debug_set_join_fused(int on) { g_join_fused = on; return 0; }
+#endif
 static int g_fused_pw_bwd = 1;
 static long long g_fused_pw_bwd_min_m = 100000;  // spb_debug_set_fused_pw_bwd(v > 1): fused kernel from v rows up.  The 28x28 layer
                                                  // (M = 37632, 144 -> 32) took 45 us fused for 26 MB; as GEMM + side-stream weight gradient the step is 12 us shorter
@@ -1038,8 +1058,12 @@ extern "C" int spb_krn_ctx_create(spb_krn_t* m, int batch, void* workspace, spb_
   return 0;
 }
 extern "C" void spb_krn_ctx_destroy(spb_krn_ctx_t* c) { delete c; }
+#ifdef SPB_TUNING   // tuning build only (libspb_hip_tune.so, include/spb_hip_tuning.h): the product library has no knob
 extern "C" int spb_debug_set_side_wgrad(int on) { g_side_wgrad = on; return 0; }
+#endif
+#ifdef SPB_TUNING   // tuning build only (libspb_hip_tune.so, include/spb_hip_tuning.h): the product library has no knob
 extern "C" int spb_debug_set_fused_pw_bwd(int on) { g_fused_pw_bwd = on != 0; if (on > 1) g_fused_pw_bwd_min_m = on; return 0; }
+#endif
 extern "C" int spb_krn_ctx_set_side_stream(spb_krn_ctx_t* c, int on) {
   if (!c) return SPB_E_ARG;
   c->side_on = on != 0;

@@ -469,12 +469,14 @@ int pwb_launch(const spb_pwbwd_args_t& g, hipStream_t stream) {
 
 }  // namespace
 
+#ifdef SPB_TUNING   // tuning build only (libspb_hip_tune.so, include/spb_hip_tuning.h): the product library has no knob
 extern "C" int spb_debug_set_pwb(int chunk_rows, int recompute_z, int max_waves) {
   if (chunk_rows == 16 || chunk_rows == 32) g_pwb_ch = chunk_rows;
   if (recompute_z >= 0) g_pwb_rz = recompute_z != 0;
   if (max_waves >= 2) g_pwb_maxw = max_waves;
   return 0;
 }
+#endif
 
 // 0 on launch, SPB_E_UNSUPPORTED when this shape / dtype has no fused instance (the caller then uses
 // spb_pwconv_gemm + spb_pwconv_wgrad)

@@ -384,7 +384,9 @@ __global__ __launch_bounds__(256) void softce_fin_kernel(const T* __restrict__ l
 }
 // rows wider than this use the class-split pair of launches (library-owned scratch for the partials, one row set per stream slot)
 static int g_softce_split_min_c = 2048;
+#ifdef SPB_TUNING   // tuning build only (libspb_hip_tune.so, include/spb_hip_tuning.h): the product library has no knob
 extern "C" int spb_debug_set_softce_split(int min_classes) { g_softce_split_min_c = min_classes; return 0; }
+#endif
 template <typename T>
 static int softce_split(const void* logits, const float* target, void* dlogits, float* out, int slot, int B, int C, float weight, float* rows,
                         const float* gscale, hipStream_t s) {
@@ -499,7 +501,9 @@ extern "C" int spb_im2col(int dtype, const void* src, void* dst, int B, int H, i
 }
 
 static int g_rgb_band = 1;
+#ifdef SPB_TUNING   // tuning build only (libspb_hip_tune.so, include/spb_hip_tuning.h): the product library has no knob
 extern "C" int spb_debug_set_im2col_rgb_band(int on) { g_rgb_band = on; return 0; }
+#endif
 extern "C" int spb_im2col_rgb(int dtype, const float* x, void* dst, int B, int H, int W, int KH, int KW, int stride, int Kpad,
                               spb_stream_t stream) {
   if (!x || !dst || B <= 0 || Kpad < KH * KW * 3 || (Kpad & 7)) return SPB_E_ARG;

@@ -588,7 +588,9 @@ int spb_stem_fwd_mfma(const float* x, const float* w, void* y, float* osums, int
 int spb_stem_wgrad_mfma(const float* x, const void* G, const void* Z, const spb_bnref_t* pro, float* dW, int B, int H, int W,
                         hipStream_t s);
 static int g_stem_mfma = 1;
+#ifdef SPB_TUNING   // tuning build only (libspb_hip_tune.so, include/spb_hip_tuning.h): the product library has no knob
 extern "C" int spb_debug_set_stem_mfma(int on) { g_stem_mfma = on; return 0; }
+#endif
 
 extern "C" int spb_stem_fwd(int dtype, const float* x, const float* w, void* y, float* osums, int oR, int B, int H,
                             int W, spb_stream_t stream) {

@@ -495,14 +495,18 @@ __global__ __launch_bounds__(256) void stem_wgrad_tile_kernel(const float* __res
 }  // namespace
 
 static int g_stem_grid_fwd = 1024, g_stem_grid_wgrad = 512;   // measured: fwd 70 / 44 / 47 / 50 us at 512 / 1024 / 2048 / 4096
+#ifdef SPB_TUNING   // tuning build only (libspb_hip_tune.so, include/spb_hip_tuning.h): the product library has no knob
 extern "C" int spb_debug_set_stem_grid(int fwd, int wgrad) {
   if (fwd > 0) g_stem_grid_fwd = fwd;
   if (wgrad > 0) g_stem_grid_wgrad = wgrad;
   return 0;
 }
+#endif
 
 static int g_stem_tile = 1;
+#ifdef SPB_TUNING   // tuning build only (libspb_hip_tune.so, include/spb_hip_tuning.h): the product library has no knob
 extern "C" int spb_debug_set_stem_tile(int on) { g_stem_tile = on; return 0; }
+#endif
 
 int spb_stem_fwd_mfma(const float* x, const float* w, void* y, float* osums, int oR, int B, int H, int W, hipStream_t s) {
   const int OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1;
@@ -540,7 +544,9 @@ static int launch_wgrad_tile(const float* x, const void* G, const void* Z, const
 }
 
 static int g_stem_wtile_rows = 8;
+#ifdef SPB_TUNING   // tuning build only (libspb_hip_tune.so, include/spb_hip_tuning.h): the product library has no knob
 extern "C" int spb_debug_set_stem_wgrad_tile(int rows) { g_stem_wtile_rows = rows; return 0; }
+#endif
 
 int spb_stem_wgrad_mfma(const float* x, const void* G, const void* Z, const spb_bnref_t* pro, float* dW, int B, int H, int W,
                         hipStream_t s) {

@@ -76,7 +76,16 @@ def test_trread_semantics(device):
 def gemm_variant(request):
     """the pointwise-GEMM kernels: the default dispatch (one-shot kernel for medium reductions with a narrow output on the 28x28 /
     14x14 maps, split-K-over-waves kernel for small M with a long reduction, the 128 x 128 tile kernel for a wide output behind a long
-    reduction on the 7x7 maps, the register-prefetch tiled kernel otherwise), the LDS-DMA ring (small M, bf16, K >= 64) and the tiled kernel alone"""
+    reduction on the 7x7 maps, the register-prefetch tiled kernel otherwise), the LDS-DMA ring (small M, bf16, K >= 64) and the tiled kernel alone.
+    "default" runs on the product library (which has no knobs); the forced variants on the tuning build (include/spb_hip_tuning.h)"""
+    if request.param == "default":
+        yield request.param
+        return
+    with L.tuning():
+        yield from _gemm_variant_tuned(request)
+
+
+def _gemm_variant_tuned(request):
     L.lib().spb_debug_set_gemm_dma(1 if request.param == "lds_dma" else 0)
     L.lib().spb_debug_set_gemm_sk(0 if request.param != "default" else 1, 0, 0)
     L.lib().spb_debug_set_gemm_os(0 if request.param != "default" else 1, 0, 0, 0)
@@ -92,10 +101,15 @@ def gemm_variant(request):
 
 @pytest.fixture(params=["auto", "rows"])
 def dw_variant(request):
-    """both depthwise kernel families: the default choice (plane kernels on maps up to 28 columns wide) and the row-unit kernels everywhere"""
-    L.lib().spb_debug_set_dw_mode(1 if request.param == "auto" else 0)
-    yield request.param
-    L.lib().spb_debug_set_dw_mode(1)
+    """both depthwise kernel families: the default choice (plane kernels on maps up to 28 columns wide; product library) and the row-unit
+    kernels everywhere (tuning build)"""
+    if request.param == "auto":
+        yield request.param
+        return
+    with L.tuning():
+        L.lib().spb_debug_set_dw_mode(0)
+        yield request.param
+        L.lib().spb_debug_set_dw_mode(1)
 
 
 @pytest.mark.parametrize("dt", DTYPES)
@@ -258,6 +272,7 @@ def test_pw_bwd_fused(device, M, K, N, act1, act2, with_res, mat):
 
 @pytest.mark.parametrize("rs", [1, 0])
 @pytest.mark.parametrize("M,K,N", [(9408, 64, 384), (9408, 96, 576), (37632, 32, 192), (4100, 96, 384), (4099, 64, 192), (300, 24, 144)])
+@L.tuned
 def test_pw_gemm_row_slab_forward_and_residual_join(device, rs, M, K, N):
     """expand convolutions of the 28x28 / 14x14 maps (short reduction, wide output): the row-slab kernel (gemm_rs.hip) and the tiled kernel,
     plain prologue and the residual join of pro_mode 3 (a = bn(A) + bn2(A2); the launch also writes the joined block output)"""
@@ -293,6 +308,7 @@ def test_pw_gemm_row_slab_forward_and_residual_join(device, rs, M, K, N):
 
 
 @pytest.mark.parametrize("M,K,N", [(9408, 384, 64), (9408, 576, 96), (37632, 192, 32), (4100, 384, 96), (9408, 192, 64)])
+@L.tuned
 def test_pw_gemm_row_slab_input_gradient(device, M, K, N):
     """project convolutions of the 28x28 / 14x14 maps, input gradient without a residual (what the KRN plan launches): the row-slab
     kernel against float64 autograd and against the tiled kernel (same element arithmetic up to the order of the MFMA reduction)"""
@@ -415,9 +431,13 @@ def test_dwconv(device, dw_variant, dt, B, H, C, stride, act):
 @pytest.fixture(params=["rows", "tile"])
 def dw_tile_dgrad(request):
     """stride-1 input gradient on the LDS-tile kernel (off by default: spb_debug_set_dw_tile bit 16) and on the default kernels"""
-    L.lib().spb_debug_set_dw_tile(28, (1 << 16) if request.param == "tile" else 0)
-    yield request.param
-    L.lib().spb_debug_set_dw_tile(28, 0)
+    if request.param == "rows":
+        yield request.param
+        return
+    with L.tuning():
+        L.lib().spb_debug_set_dw_tile(28, 1 << 16)
+        yield request.param
+        L.lib().spb_debug_set_dw_tile(28, 0)
 
 
 @pytest.mark.parametrize("B,H,C,act", [(3, 28, 192, L.ACT_RELU6), (2, 56, 144, L.ACT_RELU6), (1, 60, 24, L.ACT_RELU), (2, 35, 40, L.ACT_NONE)])
@@ -479,13 +499,17 @@ def _dw_da(a, Wd, z, g2, g2s_nhwc, xh2, C, stride):
 def stem_variant(request):
     """bf16 stem: implicit GEMM on the matrix cores from an LDS tile (default), the same with its taps gathered from global memory, and the
     scalar kernels (the f32 mode always uses those)"""
-    L.lib().spb_debug_set_stem_mfma(0 if request.param == "scalar" else 1)
-    L.lib().spb_debug_set_stem_tile(1 if request.param.startswith("tile") else 0)
-    L.lib().spb_debug_set_stem_wgrad_tile(16 if request.param == "tile16" else 8)   # 16 rows per workgroup: a ragged last band at 48 x 48
-    yield request.param
-    L.lib().spb_debug_set_stem_mfma(1)
-    L.lib().spb_debug_set_stem_tile(1)
-    L.lib().spb_debug_set_stem_wgrad_tile(8)
+    if request.param == "tile":         # the default: product library
+        yield request.param
+        return
+    with L.tuning():
+        L.lib().spb_debug_set_stem_mfma(0 if request.param == "scalar" else 1)
+        L.lib().spb_debug_set_stem_tile(1 if request.param.startswith("tile") else 0)
+        L.lib().spb_debug_set_stem_wgrad_tile(16 if request.param == "tile16" else 8)   # 16 rows per workgroup: a ragged last band at 48 x 48
+        yield request.param
+        L.lib().spb_debug_set_stem_mfma(1)
+        L.lib().spb_debug_set_stem_tile(1)
+        L.lib().spb_debug_set_stem_wgrad_tile(8)
 
 
 @pytest.mark.parametrize("dt", DTYPES)
@@ -615,6 +639,7 @@ def test_bn_apply_and_bwd_prep(device, dt):
 
 @pytest.mark.parametrize("dt", DTYPES)
 @pytest.mark.parametrize("B,H,C,coff,reorg", [(3, 7, 96, 32, 0), (48, 7, 1024, 256, 0), (5, 14, 64, 0, 2)])
+@L.tuned
 def test_bn_bwd_prep_row_parallel_kernel(device, dt, B, H, C, coff, reorg):
     """spb_bn_bwd_prep's row-parallel kernel (the default) at the two KRN call sites (the 1024-channel slice of the concat gradient,
     the un-reorg of the router slice) and a ragged channel count: against float64 and against the walking kernel it replaced"""

@@ -302,7 +302,6 @@ def test_overlapped_gradient_exchange_plumbing_single_rank(device, monkeypatch):
             ts = FusedTrainStep(eng, B, kind="sgd", lr=0.05, momentum=0.9, weight_decay=1e-4, max_norm=1.0,
                                 dist_group=dist.group.WORLD, world_size=1)
             assert ts._overlap == (mode == "force")
-            eng.lib.spb_debug_set_side_wgrad(1)
             p_init = eng.params.clone()
             scal = ts(x, y)
             torch.cuda.synchronize()

@@ -420,7 +420,7 @@ def test_im2col_rgb_band_equals_gather(device, B):
     """the column matrix of conv1 from the band kernel (image rows through LDS) is bit-identical to the per-element gather"""
     import ctypes as C
     from speedplusbaseline_amd import _lib as L
-    lib, st = L.lib(), C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    lib, st = L.lib_tune(), C.c_void_p(torch.cuda.current_stream().cuda_stream)     # the band / gather switch is a knob of the tuning build
     x = torch.randn(B, 3, 227, 227, generator=torch.Generator().manual_seed(B)).to(device)
     cols = []
     try:

@@ -25,6 +25,33 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), "libspb_hip.so does not export %s" % name
     assert declared == set(_lib.SYMBOLS.keys()), declared ^ set(_lib.SYMBOLS.keys())
     assert b"gfx950" in lib.spb_version()
+    # the product library holds no tuning knob: none is declared in its header, none is exported (nm -D), and the reproducible-mode entry
+    # points answer "unsupported" there
+    import subprocess
+    exported = set(re.findall(r" T (spb_[a-z0-9_]+)", subprocess.check_output(["nm", "-D", _lib.LIB_PATH], text=True)))
+    assert exported == declared, exported ^ declared
+    assert not [n for n in exported if n.startswith("spb_debug_set")]
+    assert lib.spb_det_available() == 0
+
+
+def test_twin_libraries_export_their_declared_symbols():
+    """the tuning build (include/spb_hip_tuning.h: product C-ABI + the spb_debug_set_* knobs), the reproducible build (the KRN subset,
+    spb_det_available() == 1) and the IEEE-half build (the SPN subset) load and carry what their headers say"""
+    import subprocess
+    from speedplusbaseline_amd import _lib
+    strip = lambda t: re.sub(r"/\*.*?\*/", "", t, flags=re.S)
+    knobs = set(re.findall(r"\b(spb_debug_set_[a-z0-9_]+)\s*\(", strip(open(os.path.join(ROOT, "include", "spb_hip_tuning.h")).read())))
+    assert knobs == set(_lib.TUNING_SYMBOLS.keys()) and len(knobs) == 49
+    nm = lambda path: set(re.findall(r" T (spb_[a-z0-9_]+)", subprocess.check_output(["nm", "-D", path], text=True)))
+    assert nm(_lib.LIB_TUNE_PATH) == set(_lib.SYMBOLS.keys()) | knobs
+    t = _lib.lib_tune()
+    assert all(hasattr(t, n) for n in knobs)
+    det = nm(_lib.LIB_DET_PATH)
+    assert det <= set(_lib.SYMBOLS.keys()) and {"spb_krn_forward", "spb_krn_backward", "spb_det_register", "spb_det_flush", "spb_det_misses"} <= det
+    assert not [n for n in det if n.startswith("spb_debug_set")]
+    assert _lib.lib_det().spb_det_available() == 1
+    f16 = nm(_lib.LIB_F16_PATH)
+    assert f16 <= set(_lib.SYMBOLS.keys()) and "spb_spn_conv" in f16 and not [n for n in f16 if n.startswith("spb_debug_set")]
 
 
 def test_plan_layout_matches_reference_state_dict():
