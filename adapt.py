@@ -56,6 +56,8 @@ def main():
         lr_scheduler.step()
         if target_test_loader is not None and (epoch + 1) % cfg.test_epoch == 0 and job.is_main:
             valid_krn(epoch, cfg, model, target_test_loader, cameraMatrix, distCoeffs, corners3D, None, device, None)
+        if target_test_loader is not None and (epoch + 1) % cfg.test_epoch == 0:
+            job.barrier()       # the other ranks wait here while rank 0 validates (not inside the collectives below)
         states = {'epoch': epoch + 1, 'model': cfg.model_name, 'state_dict': model.state_dict(),
                   'best_score': epoch + 1, 'optimizer': optimizer.state_dict()}
         if job.world > 1:      # collective: the replicas must still be bit-identical after an epoch of exchanged gradients

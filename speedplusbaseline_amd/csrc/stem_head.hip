@@ -171,6 +171,7 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const spb_head_args_t a, 
   const int NJ = a.Jp / 16;  // <= 2
   unsigned long long* acc64 = reinterpret_cast<unsigned long long*>(a.partial);              // [B][Jp]
   unsigned* ticket = reinterpret_cast<unsigned*>(acc64 + (size_t)a.B * a.Jp);
+  unsigned* poison = ticket + 1;     // count of partial sums the fixed-point accumulator cannot hold (NaN, Inf, |v| >= 2^26): the last arriver then reports NaN
   // every load of a K slice first, on clamped indices (HEAD_U steps of 32)
   uint4 wr[HEAD_U][2], zr[HEAD_U][4];
   auto fetch = [&](int bb, int k0) {
@@ -280,7 +281,8 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const spb_head_args_t a, 
         // one of its additions on the way to memory (different addresses, different channels): about once in a thousand launches the
         // last arriver read an accumulator that lacked a tile -- a wrong prediction, a loss spike of 100-500 and a wrecked update
         // (tests/test_parity_conditioned_gpu.py stopped settling).
-        seen += atomicAdd(acc64 + (size_t)b * a.Jp + col, (unsigned long long)__float2ll_rn(v * HEAD_FIX));
+        if (fabsf(v) < 67108864.f) seen += atomicAdd(acc64 + (size_t)b * a.Jp + col, (unsigned long long)__float2ll_rn(v * HEAD_FIX));
+        else seen += atomicAdd(poison, 1u);      // a diverged network must read NaN / Inf like the reference's, not a saturated finite number
       }
     }
     __syncthreads();
@@ -296,6 +298,7 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const spb_head_args_t a, 
   SPB_TSR(5);
   if (!last_flag) { SPB_TS_FLUSH; return; }
   __threadfence();
+  const bool bad = __hip_atomic_load(poison, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
   float lx = 0.f, ly = 0.f;
   const int nout = a.B * a.J;
   for (int i0 = t; i0 < nout; i0 += 256 * 8) {
@@ -311,7 +314,7 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const spb_head_args_t a, 
       if (idx >= nout) continue;
       const int b = idx / a.J, j = idx % a.J;
       __hip_atomic_store(acc64 + (size_t)b * a.Jp + j, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // left zero for the next call
-      const float s = (float)((double)(long long)fx[u] * (1.0 / (double)HEAD_FIX)) + (a.bias ? a.bias[j] : 0.f);
+      const float s = bad ? __int_as_float(0x7fc00000) : (float)((double)(long long)fx[u] * (1.0 / (double)HEAD_FIX)) + (a.bias ? a.bias[j] : 0.f);
       a.pred[idx] = s;
       if (a.target) {
         const int nK = a.J / 2;
@@ -331,6 +334,7 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const spb_head_args_t a, 
       a.scalars[0] = tx + ty; a.scalars[1] = tx; a.scalars[2] = ty;
     }
     __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(poison, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   SPB_TSR(6);
   SPB_TS_FLUSH;

@@ -549,7 +549,7 @@ class SpacecraftPoseNet(nn.Module):
             mine.copy_(stage[rank * per:(rank + 1) * per])
         if m > 0:
             self._gflat[my_lo:my_hi].copy_(mine[:m])
-        optimizer.update_range_early(my_lo, my_hi, world_size, covers=(lo, hi))
+        optimizer.update_range_early(my_lo, my_hi, world_size, covers=(lo, hi), group=group)
         src = self._shadow if self._shadow is not None else self._flat
         g_in = self._buf("shard_ag_in_%d" % lo, (per,), src.dtype)
         if m > 0:

@@ -192,13 +192,15 @@ def bn_bwd_prep(dY, Z, G, osums, bn, ldc=None, coff=0, reorg=0, oR=1):
     L.check(L.lib().spb_bn_bwd_prep(dtype_code(Z), C.byref(a), _stream()), "spb_bn_bwd_prep")
 
 
-def head_fwd(Z, Wp, bias, pro, J, HW, C_, target=None, S=256):
-    """Z [B, HW*C]; Wp [Jp, HW*C] (compute dtype). Returns pred [B,J], scalars [3], dout [B,J]."""
+def head_fwd(Z, Wp, bias, pro, J, HW, C_, target=None, S=256, partial=None):
+    """Z [B, HW*C]; Wp [Jp, HW*C] (compute dtype). Returns pred [B,J], scalars [3], dout [B,J].  partial: the reduction workspace
+    (S*B*Jp floats, zero before its first use; every call leaves it zero again) -- a fresh one is allocated when None."""
     _need_cuda(Z, Wp, bias, target)
     B = Z.shape[0]
     Jp = Wp.shape[0]
     dev = Z.device
-    partial = torch.zeros(S * B * Jp, dtype=torch.float32, device=dev)   # ends in the reduction's ticket word: zero before the first call
+    if partial is None:
+        partial = torch.zeros(S * B * Jp, dtype=torch.float32, device=dev)   # ends in the reduction's ticket word: zero before the first call
     pred = torch.empty(B, J, dtype=torch.float32, device=dev)
     dout = torch.zeros(B, J, dtype=torch.float32, device=dev)
     scalars = torch.zeros(3, dtype=torch.float32, device=dev)

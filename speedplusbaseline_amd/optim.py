@@ -149,7 +149,7 @@ class SpnOptimizer(torch.optim.Optimizer):
         self._t = 0
         self._m = self._v = self._gmul = None
         self._early = []       # arena ranges already updated for the step in flight (update_range_early)
-        self._shard_buckets = {}   # lo -> (lo, hi, world) of buckets whose moments are rank-sharded right now
+        self._shard_buckets = {}   # lo -> (lo, hi, world, group) of buckets whose moments are rank-sharded right now (group: the one the sharded step ran on)
 
     def _betas(self, kind, momentum):
         if kind == "rmsprop":
@@ -175,8 +175,9 @@ class SpnOptimizer(torch.optim.Optimizer):
         mdl.join_updates()
         if getattr(mdl, "_early_on_comm", False):
             torch.cuda.current_stream().wait_stream(mdl._comm)
-        rank = dist.get_rank(group)
-        for lo, hi, world in buckets.values():
+        for lo, hi, world, bgroup in buckets.values():
+            grp = group if group is not None else bgroup          # the collective runs on the group the sharded steps were issued on
+            rank = dist.get_rank(grp)
             per, my_lo, my_hi = shard_slice(lo, hi, rank, world)
             n, k = hi - lo, my_hi - my_lo
             for arena in (self._m, self._v):
@@ -184,13 +185,13 @@ class SpnOptimizer(torch.optim.Optimizer):
                 if k > 0:
                     g_in[:k].copy_(arena[my_lo:my_hi])
                 g_out = torch.empty(per * world, dtype=torch.float32, device=arena.device)
-                dist.all_gather_into_tensor(g_out, g_in, group=group)
+                dist.all_gather_into_tensor(g_out, g_in, group=grp)
                 arena[lo:hi].copy_(g_out[:n])
 
     def _unshard_if_needed(self, lo, hi):
         """a NON-sharded update of [lo, hi) after sharded steps (e.g. a ragged last batch that takes the generic path) must see
         complete masters and moments there: gather first (collective -- every rank takes the same path, the batch shape decides it)"""
-        if any(a < hi and lo < b for a, b, _ in self._shard_buckets.values()):
+        if any(a < hi and lo < b for a, b, _, _ in self._shard_buckets.values()):
             self.gather_sharded_state()
 
     def _state(self, flat):
@@ -219,7 +220,7 @@ class SpnOptimizer(torch.optim.Optimizer):
                        first_step=(t == 1), shadow=None if mdl._shadow is None else mdl._shadow[lo:hi], max_blocks=max_blocks)
 
     @torch.no_grad()
-    def update_range_early(self, lo, hi, world_size=1, max_blocks=0, covers=None):
+    def update_range_early(self, lo, hi, world_size=1, max_blocks=0, covers=None, group=None):
         """Called by SpacecraftPoseNet.loss_and_grads(..., optimizer=self) from inside the backward pass, on the stream that
         produced (and, data parallel, exchanged) the gradients of arena elements [lo, hi): this step's update of that range,
         issued while the rest of backward still runs.  step() then updates what is left.  Ranges must not overlap.
@@ -231,7 +232,7 @@ class SpnOptimizer(torch.optim.Optimizer):
             self._t += 1
         self._early.append(tuple(covers) if covers is not None else (lo, hi))
         if covers is not None:      # rank-sharded bucket: this rank's moments are current on [lo, hi) only (gather_sharded_state)
-            self._shard_buckets[int(covers[0])] = (int(covers[0]), int(covers[1]), int(world_size))
+            self._shard_buckets[int(covers[0])] = (int(covers[0]), int(covers[1]), int(world_size), group)
         else:
             self._unshard_if_needed(lo, hi)
         if hi > lo:

@@ -111,7 +111,10 @@ def init_job(use_cuda=True):
         torch.cuda.set_device(device)
     backend = os.environ.get("SPB_DIST_BACKEND") or ("gloo" if (one_device or not use_cuda) else "nccl")
     if not dist.is_initialized():
-        dist.init_process_group(backend, rank=rank, world_size=world)
+        # a generous collective timeout: rank 0 alone validates / writes checkpoints between epochs while the others wait in a barrier
+        import datetime
+        dist.init_process_group(backend, rank=rank, world_size=world,
+                                timeout=datetime.timedelta(minutes=int(os.environ.get("SPB_DIST_TIMEOUT_MIN", "120"))))
     return Job(rank, world, device, dist.group.WORLD)
 
 

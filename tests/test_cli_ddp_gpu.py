@@ -71,3 +71,21 @@ def test_adapt_dann_two_ranks(device, tmp_path):
     assert "replicas identical after epoch 1" in out
     ck = _strict_load(_cfg(dann=True), tmp_path / "save" / "checkpoint.pth.tar", 354)
     assert "domain_classifier.0.weight" in ck["state_dict"]
+
+
+def test_scale_command_bench_two_ranks(device):
+    """the driver's multi-GPU line -- `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P
+    bench.py --gpus N --steps K --warmup W` -- with N = 2 on this one-GPU box (both ranks on cuda:0, gloo collectives), so that the first 8-GPU
+    run is not the first run of that path: rank 0 prints ONE JSON line with the contract's fields, n_gpus 2, the global batch of both ranks,
+    weak scaling, a finite value that is consistent with ms_per_step."""
+    import json
+    out = launch2("bench.py", "--gpus", 2, "--steps", 3, "--warmup", 1, "--bare")
+    lines = [l for l in out.splitlines() if l.startswith("{") and '"metric"' in l]
+    assert len(lines) == 1, out[-2000:]
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["steps"] == 3 and r["warmup"] == 1 and r["scaling"] == "weak" and r["higher_is_better"] is True
+    assert r["unit"] == "images/sec" or "images" in r["unit"]
+    assert r["config"]["global_batch"] == 96 and r["dtype"] == "bf16" and r["data"] == "synthetic"
+    assert r["value"] > 0 and abs(r["value"] - 96 / (r["ms_per_step"] * 1e-3)) <= 1e-3 * r["value"]
+    import math
+    assert math.isfinite(r["value"]) and all(math.isfinite(float(v)) for v in r["config"]["loss_last_step"])

@@ -591,6 +591,34 @@ def test_head(device, dt, B):
 
 
 @pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("poison", ["nan", "inf", "huge"])
+def test_head_reports_a_diverged_network_as_nan(device, dt, poison):
+    """the head's split-K sum is 64-bit fixed point (order-independent); a partial sum it cannot hold -- NaN, Inf, |v| >= 2^26 -- must not
+    come out as a saturated FINITE prediction: the reference would show nan / inf there (park2019.py:139-162).  The next call on clean
+    data is clean again (the poison word is reset by the last arriver)."""
+    torch.manual_seed(3)
+    B, J, HW, C = 6, 22, 49, 64
+    Z = torch.randn(B, HW * C, dtype=torch.float32).to(dt).to(device)
+    Wp = torch.zeros(32, HW * C, dtype=dt, device=device)
+    Wp[:J] = (torch.randn(J, HW * C) * 0.05).to(dt).to(device)
+    bias = torch.zeros(J, dtype=torch.float32, device=device)
+    tgt = torch.rand(B, 2, J // 2, dtype=torch.float32, device=device)
+    pro_sums = torch.zeros(1, 2, C, dtype=torch.float32, device=device); pro_sums[0, 1] = 1.0 - EPS    # mean 0, variance 1 - eps
+    pro = ops.bnref(C, sums=pro_sums, gamma=torch.ones(C, device=device), beta=torch.zeros(C, device=device), n=1, act=L.ACT_NONE, moments=1)
+    Zbad = Z.clone()
+    Zbad[2, 777] = {"nan": float("nan"), "inf": float("inf"), "huge": 3.0e38}[poison]
+    ws = torch.zeros(256 * B * 32, dtype=torch.float32, device=device)       # ONE reduction workspace for both calls
+    pred, scal, _ = ops.head_fwd(Zbad, Wp, bias, pro, J, HW, C, target=tgt, partial=ws)
+    torch.cuda.synchronize()
+    assert not torch.isfinite(pred).any() and not torch.isfinite(scal[0])
+    assert not ws.any()                                                       # accumulator, ticket and poison word are zero again
+    pred, scal, _ = ops.head_fwd(Z, Wp, bias, pro, J, HW, C, target=tgt, partial=ws)
+    torch.cuda.synchronize()
+    ref = Z.double().cpu() @ Wp[:J].double().cpu().t()
+    assert torch.isfinite(pred).all() and relerr(pred, ref) < TOL[dt]
+
+
+@pytest.mark.parametrize("dt", DTYPES)
 def test_bn_apply_and_bwd_prep(device, dt):
     torch.manual_seed(11)
     dev = device

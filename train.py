@@ -71,6 +71,10 @@ def main():
         begin_epoch = best_perf = 0
     model = model.to(device)
     sync_replicas(model, job)                   # rank 0's parameters / BatchNorm buffers everywhere
+    if job.world > 1:
+        # after the (identical) model initialisation the stochastic ops -- SPN dropout, GPU augmentation, style sampling -- draw from a
+        # per-rank stream: the same seed on every rank would put correlated noise on the 8 shards of one global batch
+        set_all_seeds(job.seed(cfg.seed), cfg, True)
     lr_scheduler = torch.optim.lr_scheduler.StepLR(optimizer, step_size=cfg.lr_decay_step, gamma=cfg.lr_decay_alpha)
     if cfg.synthetic_batches <= 0:
         if cfg.model_name != 'krn':
@@ -102,6 +106,8 @@ def main():
         if test_loader is not None and (epoch + 1) % cfg.test_epoch == 0 and job.is_main:
             eval('valid_' + cfg.model_name)(epoch + 1, cfg, model, test_loader, cameraMatrix, distCoeffs, corners3D, writer,
                                             device, attClasses)
+        if test_loader is not None and (epoch + 1) % cfg.test_epoch == 0:
+            job.barrier()       # the other ranks wait HERE (not inside the state-dict / replica-check collectives below) while rank 0 validates
         perf = epoch + 1
         is_best = perf > best_perf
         best_perf = max(best_perf, perf)
