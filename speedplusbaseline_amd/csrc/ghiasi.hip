@@ -1116,8 +1116,16 @@ __global__ __launch_bounds__(256) void conv9_kxrows_kernel(const spb_gconv_args_
   const bf16_t* X = reinterpret_cast<const bf16_t*>(g.X);
   const bf16_t* Wg = reinterpret_cast<const bf16_t*>(g.W);       // [Cout][9][9][32]
   bf16_t* Y = reinterpret_cast<bf16_t*>(g.Y);
-  int band = blockIdx.x;
-  if (band >= nbands) return;
+  // XCD-local band ranges (round 5): workgroup k runs on XCD k % 8, and XCD x owns the CONTIGUOUS band range [base, base + cnt) -- whole
+  // images, walked in order by its gridDim.x / 8 workgroups.  A band shares its 8 halo rows with its vertical neighbours; with bands dealt
+  // round-robin over all workgroups those neighbours sat on different XCDs and every L2 fetched the rows again (PMC: 364 MB per launch for
+  // 173 MB of algorithmic traffic).  Now the ~64 bands an XCD has in flight are 16 consecutive band rows of one image: ~1 MB, L2 resident.
+  const int xcd = blockIdx.x & 7, nw8 = (int)gridDim.x >> 3;
+  const int bq = nbands >> 3, br = nbands & 7;
+  const int cnt = bq + (xcd < br ? 1 : 0), base = xcd * bq + (xcd < br ? xcd : br);
+  int lb = blockIdx.x >> 3;
+  if (lb >= cnt) return;
+  int band = base + lb;
   constexpr int total = HR * HW_ * 4;
   constexpr int SUK = (total + 255) / 256;                         // halo vectors per thread (12 for 4-row bands)
   static_assert(SUK <= 16, "band halo must fit the register prefetch");
@@ -1179,8 +1187,8 @@ __global__ __launch_bounds__(256) void conv9_kxrows_kernel(const spb_gconv_args_
     }
     lds_barrier();
     GC_STAMP2(2);
-    const int nband = band + (int)gridDim.x;
-    const bool more = nband < nbands;
+    const bool more = lb + nw8 < cnt;
+    const int nband = base + lb + nw8;
     band_coef(more ? nband : band, (k + 1) & 1);      // next band: coefficients and halo in flight during the taps
     halo_load(more ? nband : band);                   // (clamped, not branched: the last band re-reads its own)
     // wave w: output rows w*C9K_RW ..; per row four 16-column groups of INPUT columns x two row fragments
@@ -1251,7 +1259,7 @@ __global__ __launch_bounds__(256) void conv9_kxrows_kernel(const spb_gconv_args_
       atomicAdd(g.stats + (size_t)b * Cout * 2 + t, red[t] + red[8 + t] + red[16 + t] + red[24 + t]);
     GC_STAMP2(6);
     if (!more) break;
-    band = nband;
+    band = nband; lb += nw8;
   }
 }
 
@@ -1540,7 +1548,7 @@ extern "C" int spb_gconv(int dtype, const spb_gconv_args_t* a, spb_stream_t stre
     static bool oncek = false;
     if (!oncek) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv9_kxrows_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); oncek = true; }
     const int nbands = (Hout / C9K_R) * (Wout / C9K_W) * a->B;
-    const int wgs9 = nbands < g_conv9_wgs ? nbands : g_conv9_wgs;      // persistent: two per CU
+    const int wgs9 = nbands < g_conv9_wgs ? ((nbands + 7) & ~7) : (g_conv9_wgs < 8 ? 8 : (g_conv9_wgs & ~7));      // persistent: two per CU; a multiple of 8 (one share per XCD)
     hipLaunchKernelGGL(conv9_kxrows_kernel, dim3((unsigned)wgs9), dim3(256), ldsk, (hipStream_t)stream, *a, nbands);
     SPB_CHECK_LAUNCH();
     return 0;
