@@ -62,7 +62,8 @@ def _device_index(local_rank):
 
 
 def _init_dist(dev):
-    backend = os.environ.get("SPB_DIST_BACKEND", "nccl")       # "nccl" is RCCL on ROCm
+    # "nccl" is RCCL on ROCm; a one-GPU test rig (SPB_ONE_DEVICE=1: every rank on device 0) cannot host two RCCL ranks and takes gloo
+    backend = os.environ.get("SPB_DIST_BACKEND") or ("gloo" if os.environ.get("SPB_ONE_DEVICE") == "1" else "nccl")
     if backend == "nccl":
         torch.distributed.init_process_group("nccl", device_id=dev)
     else:
@@ -115,6 +116,7 @@ def bench_others(steps=40, warmup=10):
     import subprocess
     runs = (("dann_bs16", ["--model", "dann", "--batch", "16"]), ("dann_bs48", ["--model", "dann", "--batch", "48"]),
             ("spn_bf16", ["--model", "spn", "--precision", "bf16"]), ("spn_fp16", ["--model", "spn", "--precision", "fp16"]),
+            ("krn_fp16", ["--precision", "fp16"]),     # the reference's own AMP recipe for KRN (float16 + GradScaler), beside the bf16 headline
             ("styleaug", ["--styleaug"]), ("decoder", ["--model", "decoder"]))
     out = {}
     t_start = time.perf_counter()
@@ -136,6 +138,8 @@ def bench_others(steps=40, warmup=10):
             roof = _hbm_roof(2 * KRN_BYTES_PER_IMAGE * bsz, ms)          # two passes (source, target) of the KRN traffic
         elif name == "styleaug":
             roof = _hbm_roof(KRN_BYTES_PER_IMAGE * bsz + 0.5 * GHIASI_BYTES_PER_IMAGE * bsz, ms)   # the KRN step + half a restyle (coin p = 0.5)
+        elif name == "krn_fp16":
+            roof = _hbm_roof(KRN_BYTES_PER_IMAGE * bsz, ms)
         out[name] = dict(ms_per_step=ms, value=d["value"], unit=d["unit"], dtype=d["dtype"], steps=d["steps"], roofline=roof,
                          workload=d["config"]["workload"], command="python bench.py " + " ".join(cmd[2:]))
     out["_note"] = ("each entry: its own `python bench.py --bare ...` process started by this one after the headline region (%d steps after %d "
@@ -202,8 +206,8 @@ def main():
 
     if args.bare:
         args.no_cpu_baseline = args.no_others = True
-    if args.precision == "fp16" and args.model != "spn":
-        raise SystemExit("--precision fp16 exists for --model spn only (KRN / RevGrad: bf16 with f32 accumulation, DESIGN.md a13)")
+    if args.precision == "fp16" and args.model not in ("spn", "krn"):
+        raise SystemExit("--precision fp16 exists for --model spn and krn (RevGrad / DANN: bf16 with f32 accumulation, DESIGN.md a13)")
     if args.model == "spn":
         return bench_spn(args)
     if args.model == "dann":
@@ -311,7 +315,7 @@ def main():
     kernels = {}
     roofline = None
     if rank == 0 and not args.bare:
-        es = 2 if args.precision == "bf16" else 4
+        es = 2 if args.precision in ("bf16", "fp16") else 4
         n_prof = 5
         eng.prof_enable(B, 0, True)
         import ctypes as C

@@ -218,6 +218,8 @@ typedef struct spb_head_bwd_args {
   int B, J, Jp, HW, C, oR;
   int roles;           /* 0: everything on `stream`;  1: input gradient + BN sums only;  2: weight + bias gradient only (so the
                           caller can put the latter on a side stream: only the optimizer consumes it) */
+  const float* gscale_dev; /* NULL, or a device scalar multiplied onto gscale: the dynamic loss scale of the float16 recipe
+                              (GradScaler.scale(loss), trainer.py:86-88) without a host read */
 } spb_head_bwd_args_t;
 int spb_head_bwd(int dtype, const spb_head_bwd_args_t* a, spb_stream_t stream);
 
@@ -422,6 +424,10 @@ int spb_krn_update_running(spb_krn_ctx_t* c, spb_stream_t stream);
 int spb_krn_backward(spb_krn_ctx_t* c, float* grads, float gscale, int with_pose, const float* domain_logit_grad,
                      float alpha, spb_stream_t stream);
 /* binary_cross_entropy_with_logits(logits, full(label), reduction='mean') and its gradient * gscale (dann.py:85-92) */
+/* float16 recipe (reference: torch.cuda.amp.autocast + GradScaler around the KRN step, trainer.py:73-94): `scale` is a device scalar
+ * (SPB_AMP_SCALE of an AMP state, spb_amp_*) that every later spb_krn_backward on this context multiplies onto the upstream gradient;
+ * NULL switches it off.  Only the IEEE-half build (libspb_hip_f16.so) needs it: bfloat16 has float32's exponent range. */
+int spb_krn_ctx_set_loss_scale(spb_krn_ctx_t* c, const float* scale);
 int spb_bce_logits(const float* logits, float label, int B, float* loss_out, float* dlogit_out, float gscale,
                    spb_stream_t stream);
 

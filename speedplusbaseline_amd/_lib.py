@@ -87,7 +87,7 @@ class HeadArgs(C.Structure):
 class HeadBwdArgs(C.Structure):
     _fields_ = [("Z", vp), ("Wp", vp), ("dout", vp), ("G", vp), ("osums", vp), ("dW", vp), ("dbias", vp),
                 ("pro", BNRef), ("gscale", f32), ("B", i32), ("J", i32), ("Jp", i32), ("HW", i32), ("C", i32),
-                ("oR", i32), ("roles", i32)]
+                ("oR", i32), ("roles", i32), ("gscale_dev", vp)]
 
 
 class BnUpdEntry(C.Structure):
@@ -180,6 +180,7 @@ SYMBOLS = {
     "spb_krn_ctx_create": (i32, [vp, i32, vp, C.POINTER(vp)]),
     "spb_krn_ctx_destroy": (None, [vp]),
     "spb_krn_ctx_set_side_stream": (i32, [vp, i32]),
+    "spb_krn_ctx_set_loss_scale": (i32, [vp, vp]),
     "spb_krn_prepare_weights": (i32, [vp, vp]),
     "spb_krn_forward": (i32, [vp, vp, vp, i32, vp, vp, vp, vp]),
     "spb_krn_update_running": (i32, [vp, vp]),

@@ -33,19 +33,29 @@ template <int ST> struct TG {
   static constexpr int GPW = (GROUPS + 3) / 4;                 // groups per wave
 };
 
+#ifdef SPB_F16   // the IEEE-half twin (common.h): v_dot2_f32_f16
+__device__ __forceinline__ float dot2(uint32_t a, uint32_t w, float acc) {
+  return __builtin_amdgcn_fdot2(__builtin_bit_cast(spb_h16x2, a), __builtin_bit_cast(spb_h16x2, w), acc, false);
+}
+#define DWT_ONE_LO 0x00003C00u
+#define DWT_ONE_HI 0x3C000000u
+#else
+#define DWT_ONE_LO 0x00003F80u
+#define DWT_ONE_HI 0x3F800000u
 typedef __bf16 bf16x2_hw __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float dot2(uint32_t a, uint32_t w, float acc) {
   return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_hw, a), __builtin_bit_cast(bf16x2_hw, w), acc, false);
 }
+#endif
 
 // 0/1 selector (B operand): column j of the result = reduction index j + 16 h.  Lane (j = lane & 15, q = lane >> 4) holds k = 8q .. 8q+7.
 __device__ __forceinline__ bf16x8_t selector(int lane, int h) {
   const int j = lane & 15, q = lane >> 4, t = j + 16 * h - 8 * q;     // position of the single 1.0 among this lane's 8 elements (if 0 <= t < 8)
   uint4 u;
-  u.x = t == 0 ? 0x00003F80u : (t == 1 ? 0x3F800000u : 0u);
-  u.y = t == 2 ? 0x00003F80u : (t == 3 ? 0x3F800000u : 0u);
-  u.z = t == 4 ? 0x00003F80u : (t == 5 ? 0x3F800000u : 0u);
-  u.w = t == 6 ? 0x00003F80u : (t == 7 ? 0x3F800000u : 0u);
+  u.x = t == 0 ? DWT_ONE_LO : (t == 1 ? DWT_ONE_HI : 0u);
+  u.y = t == 2 ? DWT_ONE_LO : (t == 3 ? DWT_ONE_HI : 0u);
+  u.z = t == 4 ? DWT_ONE_LO : (t == 5 ? DWT_ONE_HI : 0u);
+  u.w = t == 6 ? DWT_ONE_LO : (t == 7 ? DWT_ONE_HI : 0u);
   return __builtin_bit_cast(bf16x8_t, u);
 }
 

@@ -49,14 +49,11 @@ template <int VW> __device__ __forceinline__ RawV<VW> ldv(const bf16_t* p);
 template <> __device__ __forceinline__ RawV<8> ldv<8>(const bf16_t* p) { RawV<8> r; r.u = *reinterpret_cast<const uint4*>(p); return r; }
 template <> __device__ __forceinline__ RawV<4> ldv<4>(const bf16_t* p) { RawV<4> r; r.u = *reinterpret_cast<const uint2*>(p); return r; }
 __device__ __forceinline__ void cvtv(const RawV<8>& r, float* v) {
-  v[0] = __uint_as_float(r.u.x << 16); v[1] = __uint_as_float(r.u.x & 0xffff0000u);
-  v[2] = __uint_as_float(r.u.y << 16); v[3] = __uint_as_float(r.u.y & 0xffff0000u);
-  v[4] = __uint_as_float(r.u.z << 16); v[5] = __uint_as_float(r.u.z & 0xffff0000u);
-  v[6] = __uint_as_float(r.u.w << 16); v[7] = __uint_as_float(r.u.w & 0xffff0000u);
+  spb_unpack2(r.u.x, v[0], v[1]); spb_unpack2(r.u.y, v[2], v[3]);      // (bf16 or, in the -DSPB_F16 twin, IEEE half: common.h)
+  spb_unpack2(r.u.z, v[4], v[5]); spb_unpack2(r.u.w, v[6], v[7]);
 }
 __device__ __forceinline__ void cvtv(const RawV<4>& r, float* v) {
-  v[0] = __uint_as_float(r.u.x << 16); v[1] = __uint_as_float(r.u.x & 0xffff0000u);
-  v[2] = __uint_as_float(r.u.y << 16); v[3] = __uint_as_float(r.u.y & 0xffff0000u);
+  spb_unpack2(r.u.x, v[0], v[1]); spb_unpack2(r.u.y, v[2], v[3]);
 }
 template <int VW> __device__ __forceinline__ void stv(bf16_t* p, const float* v);
 template <> __device__ __forceinline__ void stv<8>(bf16_t* p, const float* v) { st8<bf16_t>(p, v); }

@@ -135,6 +135,7 @@ struct spb_krn_ctx {
   bool bucket_on = false;           // spb_krn_ctx_set_bucket: single-GPU runs skip the mid-backward join
   int n_fork = 0;
   bool det = false;                 // spb_krn_ctx_set_det: this context's batch-sum arena has an exact-accumulation shadow
+  const float* loss_scale = nullptr;   // spb_krn_ctx_set_loss_scale: device scalar multiplied onto the upstream gradient (float16 recipe)
   ~spb_krn_ctx() {
     for (hipEvent_t e : fork_ev) hipEventDestroy(e);
     for (hipEvent_t e : prof_ev) hipEventDestroy(e);
@@ -1064,6 +1065,11 @@ extern "C" int spb_debug_set_side_wgrad(int on) { g_side_wgrad = on; return 0; }
 #ifdef SPB_TUNING   // tuning build only (libspb_hip_tune.so, include/spb_hip_tuning.h): the product library has no knob
 extern "C" int spb_debug_set_fused_pw_bwd(int on) { g_fused_pw_bwd = on != 0; if (on > 1) g_fused_pw_bwd_min_m = on; return 0; }
 #endif
+extern "C" int spb_krn_ctx_set_loss_scale(spb_krn_ctx_t* c, const float* scale) {
+  if (!c) return SPB_E_ARG;
+  c->loss_scale = scale;
+  return 0;
+}
 extern "C" int spb_krn_ctx_set_side_stream(spb_krn_ctx_t* c, int on) {
   if (!c) return SPB_E_ARG;
   c->side_on = on != 0;
@@ -1299,7 +1305,7 @@ extern "C" int spb_krn_backward(spb_krn_ctx_t* c, float* grads, float gscale, in
       spb_head_bwd_args_t h; std::memset(&h, 0, sizeof(h));
       h.Z = r.z(m->aEP[3]); h.Wp = r.wc(m->head_wc_off); h.dout = reinterpret_cast<float*>(c->ws + c->dout_off);
       h.G = r.g(m->aEP[3]); h.osums = r.bsums(m->aEP[3]); h.dW = m->G + m->head_w_off; h.dbias = m->G + m->head_b_off;
-      h.pro = r.ref(m->aEP[3], true); h.gscale = gscale; h.B = c->B; h.J = m->J; h.Jp = m->Jp; h.HW = 49; h.C = 1024;
+      h.pro = r.ref(m->aEP[3], true); h.gscale = gscale; h.gscale_dev = c->loss_scale; h.B = c->B; h.J = m->J; h.Jp = m->Jp; h.HW = 49; h.C = 1024;
       h.oR = c->R[m->aEP[3]];
       r.tic(PC_HEAD_BWD, (3.0 * r.elems(m->aEP[3]) + (double)m->Jp * 49 * 1024) * r.es() + 4.0 * m->J * 49 * 1024,
             4.0 * c->B * m->J * 49 * 1024);

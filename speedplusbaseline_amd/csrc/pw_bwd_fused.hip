@@ -52,8 +52,7 @@ __host__ __device__ inline PwbLay pwb_lay(int CH, int N, int KW, int NPAD, int K
 }
 
 __device__ __forceinline__ void unpack4(uint2 r, float v[4]) {
-  v[0] = __uint_as_float(r.x << 16); v[1] = __uint_as_float(r.x & 0xffff0000u);
-  v[2] = __uint_as_float(r.y << 16); v[3] = __uint_as_float(r.y & 0xffff0000u);
+  spb_unpack2(r.x, v[0], v[1]); spb_unpack2(r.y, v[2], v[3]);      // (bf16 or IEEE half: common.h)
 }
 
 // transpose-load fragment: 32 rows x 16 columns (c0..c0+15) of a row-major bf16 LDS tile with leading dimension LD

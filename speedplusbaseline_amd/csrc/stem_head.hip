@@ -356,6 +356,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const spb_head_bwd_args_t
   float* tab = red + 8 * HBK;                     // [4][HBK] scale, shift, mean, inverse std of the workgroup's entries
   static_assert(HBK == 256, "one table entry per thread");
   const int t = threadIdx.x;
+  const float gs_ = a.gscale * (a.gscale_dev ? *a.gscale_dev : 1.f);     // (the float16 recipe's device-side loss scale)
   SPB_TS_DECL;
   SPB_TSR(0);
   const int KH = a.HW * a.C;
@@ -434,7 +435,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const spb_head_bwd_args_t
       for (int u = 0; u < 8; ++u) {
         const int i = t + 256 * u;
         const int b = b0 + ((i >> 3) & 7) + (i & 7) * NSUB;
-        if (i < a.J * 64) ds[i] = b < a.B ? dl[u] * a.gscale : 0.f;
+        if (i < a.J * 64) ds[i] = b < a.B ? dl[u] * gs_ : 0.f;
       }
     }
     __syncthreads();
@@ -547,7 +548,8 @@ __global__ __launch_bounds__(256) void head_wgrad_kernel(const spb_head_bwd_args
     const Raw8<T> r = ldraw<T>(Z + (size_t)b * KH + (size_t)hw * a.C + c0);
     *reinterpret_cast<Raw8<T>*>(zs + (size_t)i * 8) = r;
   }
-  for (int i = t; i < a.B * 32; i += 256) ds[i] = (i & 31) < a.J ? a.dout[(i >> 5) * a.J + (i & 31)] * a.gscale : 0.f;
+  const float gs_ = a.gscale * (a.gscale_dev ? *a.gscale_dev : 1.f);
+  for (int i = t; i < a.B * 32; i += 256) ds[i] = (i & 31) < a.J ? a.dout[(i >> 5) * a.J + (i & 31)] * gs_ : 0.f;
   const int ci = t & 7;
   float mu, is;
   const float gm = a.pro.gamma[c0 + ci], bt = a.pro.beta[c0 + ci];

@@ -93,8 +93,8 @@ __global__ __launch_bounds__(256) void stem_fwd_mfma_kernel(const float* __restr
       o.x = pack_bf16x2(acc[0], acc[1]); o.y = pack_bf16x2(acc[2], acc[3]);
       if (p < P) {
         *reinterpret_cast<uint2*>(y + (size_t)p * 32 + cb * 16 + lq * 4) = o;
-        const float r0 = __uint_as_float(o.x << 16), r1 = __uint_as_float(o.x & 0xffff0000u);
-        const float r2 = __uint_as_float(o.y << 16), r3 = __uint_as_float(o.y & 0xffff0000u);
+        float r0, r1, r2, r3;
+        spb_unpack2(o.x, r0, r1); spb_unpack2(o.y, r2, r3);
         s1[cb][0] += r0; s1[cb][1] += r1; s1[cb][2] += r2; s1[cb][3] += r3;
         s2[cb][0] += r0 * r0; s2[cb][1] += r1 * r1; s2[cb][2] += r2 * r2; s2[cb][3] += r3 * r3;
       }
@@ -223,7 +223,9 @@ __global__ __launch_bounds__(256) void stem_fwd_tile_kernel(const float* __restr
     const unsigned q[4] = {o.x, o.y, o.z, o.w};
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const float r0 = ok ? __uint_as_float(q[e] << 16) : 0.f, r1 = ok ? __uint_as_float(q[e] & 0xffff0000u) : 0.f;
+      float r0, r1;
+      spb_unpack2(q[e], r0, r1);
+      r0 = ok ? r0 : 0.f; r1 = ok ? r1 : 0.f;
       s1[2 * e] += r0; s1[2 * e + 1] += r1;
       s2[2 * e] += r0 * r0; s2[2 * e + 1] += r1 * r1;
     }

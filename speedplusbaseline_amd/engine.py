@@ -10,7 +10,9 @@ import torch
 
 from . import _lib as L
 
-PRECISIONS = {"fp32": L.F32, "f32": L.F32, "float32": L.F32, "bf16": L.BF16, "bfloat16": L.BF16}
+# "fp16": the IEEE-half build of the library (libspb_hip_f16.so); its 16-bit storage code is the same SPB_BF16 slot of the C-ABI
+PRECISIONS = {"fp32": L.F32, "f32": L.F32, "float32": L.F32, "bf16": L.BF16, "bfloat16": L.BF16, "fp16": L.BF16, "float16": L.BF16}
+HALF = ("fp16", "float16")
 
 
 def _p(t):
@@ -32,10 +34,12 @@ class KrnEngine:
         self.deterministic = bool(deterministic)
         self.lib = L.lib_det() if self.deterministic else L.lib()
         self._det_regions = {}          # float pointer -> shadow tensor (kept alive while registered)
-        self.h = C.c_void_p()
-        L.check(self.lib.spb_krn_create(int(num_keypoints), 1 if dann else 0, C.byref(self.h)), "spb_krn_create")
+        self.half = False               # attach(device, "fp16"): IEEE-half build + device-side dynamic loss scale (self.amp)
+        self.amp = None
         self.num_keypoints = int(num_keypoints)
         self.dann = bool(dann)
+        self.h = C.c_void_p()
+        L.check(self.lib.spb_krn_create(int(num_keypoints), 1 if dann else 0, C.byref(self.h)), "spb_krn_create")
         ti = L.TensorInfo()
         self.param_infos, self.buffer_infos, self.bn_names = [], [], []
         for i in range(self.lib.spb_krn_num_params(self.h)):
@@ -92,6 +96,15 @@ class KrnEngine:
         for h, _ws in self._ctx.values():
             self.lib.spb_krn_ctx_destroy(h)
         self._ctx = {}
+        half = isinstance(precision, str) and precision in HALF
+        if half != self.half:            # the 16-bit format is a compile-time property of the library: rebuild the plan handle on the other build
+            if half and self.deterministic:
+                raise RuntimeError("the reproducible library has no float16 build")
+            self.lib.spb_krn_destroy(self.h)
+            self.lib = L.lib_f16() if half else L.lib()
+            self.h = C.c_void_p()
+            L.check(self.lib.spb_krn_create(self.num_keypoints, 1 if self.dann else 0, C.byref(self.h)), "spb_krn_create")
+            self.half = half
         self.device, self.dtype_code = device, code
         with torch.cuda.device(device):
             self.params = torch.zeros(self.n_params, dtype=torch.float32, device=device)
@@ -106,6 +119,13 @@ class KrnEngine:
             if self.deterministic:
                 self._det_register(self.grads.data_ptr(), self.n_params)
                 L.check(self.lib.spb_krn_set_det(self.h, 1), "spb_krn_set_det")
+            # float16: GradScaler's state on the device (include/spb_hip.h SPB_AMP_*): loss scale 65536 (torch.cuda.amp.GradScaler()'s
+            # default, train.py:101-104), its reciprocal, growth tracker, found_inf, steps taken, lr / bias corrections, skip flag
+            self.amp = None
+            if self.half:
+                self.amp = torch.zeros(L.AMP_STATE, dtype=torch.float32, device=device)
+                self.amp[L.AMP_SCALE] = 65536.0
+                self.amp[L.AMP_INV_SCALE] = 1.0 / 65536.0
         return self
 
     def param_view(self, info, arena=None):
@@ -129,6 +149,8 @@ class KrnEngine:
                     L.check(self.lib.spb_krn_ctx_stats(h, C.byref(sp), C.byref(sn)), "spb_krn_ctx_stats")
                     self._det_register(sp.value, sn.value)
                     L.check(self.lib.spb_krn_ctx_set_det(h, 1), "spb_krn_ctx_set_det")
+                if self.half:           # every backward on this context multiplies the device-side loss scale onto the upstream gradient
+                    L.check(self.lib.spb_krn_ctx_set_loss_scale(h, C.c_void_p(self.amp.data_ptr() + 4 * L.AMP_SCALE)), "spb_krn_ctx_set_loss_scale")
             self._ctx[key] = (h, ws)
         return self._ctx[key][0]
 
@@ -210,7 +232,7 @@ class KrnEngine:
         """{BatchNorm name: raw convolution output z of the last forward as an NCHW VIEW of the context workspace} -- what the parity
         tests hand to the oracle to take its backward pass through this forward state (tests/test_parity_conditioned_gpu.py)"""
         h, ws = self._ctx[(int(batch), int(slot))]
-        dt = torch.bfloat16 if self.dtype_code == L.BF16 else torch.float32
+        dt = (torch.float16 if self.half else torch.bfloat16) if self.dtype_code == L.BF16 else torch.float32
         es = 2 if self.dtype_code == L.BF16 else 4
         out, ai = {}, L.ActInfo()
         for a in range(self.lib.spb_krn_num_acts(self.h)):
@@ -219,6 +241,13 @@ class KrnEngine:
             z = ws[ai.z_off: ai.z_off + n * es].view(dt).view(int(batch), ai.H, ai.W, ai.C).permute(0, 3, 1, 2)
             out[self.bn_names[ai.bn_index][: -len(".num_batches_tracked")]] = z
         return out
+
+    def use_loss_scale(self, batch, slot=0, on=True):
+        """float16: whether backward() on this context multiplies the device-side loss scale onto the upstream gradient (default: yes).
+        Off for the generic loss.backward() path, where the caller's own GradScaler scales the loss."""
+        if self.half:
+            ptr = C.c_void_p(self.amp.data_ptr() + 4 * L.AMP_SCALE) if on else None
+            L.check(self.lib.spb_krn_ctx_set_loss_scale(self.context(batch, slot), ptr), "spb_krn_ctx_set_loss_scale")
 
     def max_train_batch(self):
         """largest per-GPU batch spb_head_bwd accepts (csrc/stem_head.hip: B*32 floats of upstream gradient + a [B,49,8] slab of

@@ -12,25 +12,27 @@ logger = logging.getLogger(__name__)
 def _precision(cfg):
     p = getattr(cfg, "precision", None)
     if p:
-        if p == "fp16" and (cfg.model_name != 'spn' or getattr(cfg, "dann", False)):
-            raise ValueError("--precision fp16 exists for SPN only (IEEE-half kernels + device-side loss scaling); KRN / RevGrad "
-                             "run --precision bf16 (what --use_fp16 selects for them) or fp32")
+        if p == "fp16" and getattr(cfg, "dann", False):
+            raise ValueError("--precision fp16 exists for SPN and KRN (IEEE-half kernels + device-side loss scaling); RevGrad / DANN runs "
+                             "--precision bf16 or fp32 (the reference's adapt.py has no mixed precision at all: adapt.py:99-101)")
         return p
     if getattr(cfg, "fp16", False):
         # reference: torch.cuda.amp autocast (float16) + GradScaler (train.py:101-104, trainer.py:73-94, 146-181).
         #   SPN: real float16 -- IEEE-half activations / weight shadows on v_mfma_f32_16x16x32_f16 (libspb_hip_f16.so), f32
         #        master weights and accumulation, GradScaler's dynamic loss scale kept on the device (spb_amp_*).
-        #   KRN / RevGrad: bfloat16 compute instead (same operand width and matrix-core rate, f32's exponent range: no loss
-        #        scaling); their kernels have no float16 instances.
+        #   KRN (round 5): the same -- the IEEE-half build of the KRN kernels, GradScaler's state on the device (FusedTrainStep._update_fp16).
+        #        --precision bf16 selects bfloat16 compute instead (BASELINE configs[1]: same operand width and matrix-core rate, f32's
+        #        exponent range, no loss scaling; 8x coarser mantissa).
+        #   RevGrad / DANN: bfloat16 (the reference's adapt.py runs without mixed precision, adapt.py:99-101).
         global _warned_fp16
-        if cfg.model_name == 'spn' and not cfg.dann:
+        if not cfg.dann:
             if not _warned_fp16:
-                logger.info("--use_fp16: SPN runs in float16 with device-side dynamic loss scaling (GradScaler defaults: "
-                            "init 65536, x2 after 2000 clean steps, x0.5 and a skipped step on overflow)")
+                logger.info("--use_fp16: %s runs in float16 with device-side dynamic loss scaling (GradScaler defaults: "
+                            "init 65536, x2 after 2000 clean steps, x0.5 and a skipped step on overflow)", cfg.model_name.upper())
                 _warned_fp16 = True
             return "fp16"
         if not _warned_fp16:
-            logger.warning("--use_fp16: for KRN / RevGrad float16 autocast + GradScaler is replaced by bfloat16 compute (no loss "
+            logger.warning("--use_fp16: for RevGrad / DANN float16 autocast + GradScaler is replaced by bfloat16 compute (no loss "
                            "scaling); pass --precision bf16 to select it explicitly")
             _warned_fp16 = True
         return "bf16"

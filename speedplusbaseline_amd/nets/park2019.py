@@ -177,7 +177,11 @@ class _KrnLossFn(torch.autograd.Function):
     def backward(ctx, gloss, glxy, gpred):
         eng = ctx.module.engine()
         arena = torch.zeros_like(eng.params)
-        eng.backward(ctx.B, slot=0, grads=arena, gscale=float(gloss))
+        eng.use_loss_scale(ctx.B, 0, False)       # float16: the upstream gradient (the caller's scaler.scale(loss)) carries the scale here
+        try:
+            eng.backward(ctx.B, slot=0, grads=arena, gscale=float(gloss))
+        finally:
+            eng.use_loss_scale(ctx.B, 0, True)
         return (None, None, None) + tuple(eng.param_view(i, arena) for i in eng.param_infos)
 
 

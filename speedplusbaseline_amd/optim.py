@@ -45,6 +45,9 @@ class FusedOptimizer(torch.optim.Optimizer):
             if self._pending_state is not None:
                 self._load_into(ts, self._pending_state)
                 self._pending_state = None
+            if self._pending_amp is not None and getattr(eng, "amp", None) is not None:     # resumed float16 run: the saved loss scale / step count
+                eng.amp.copy_(self._pending_amp.to(eng.amp.device))
+                self._pending_amp = None
         ts.lr = float(g["lr"])  # StepLR edits param_groups between epochs
         return ts
 
@@ -78,7 +81,7 @@ class FusedOptimizer(torch.optim.Optimizer):
         keep = ts.max_norm
         ts.max_norm = 0.0
         try:
-            ts._update()
+            ts._update(plain=True)     # (float16: loss.backward() through the module leaves UNSCALED gradients -- the caller's GradScaler owns the scale)
         finally:
             ts.max_norm = keep
         return loss
@@ -106,13 +109,24 @@ class FusedOptimizer(torch.optim.Optimizer):
                 state[idx] = st
         pg = {k: v for k, v in g.items() if k != "params"}
         pg["params"] = list(range(len(g["params"])))
-        return {"state": state, "param_groups": [pg]}
+        out = {"state": state, "param_groups": [pg]}
+        # float16: GradScaler's state lives on the device with the engine (loss scale, growth tracker, steps actually taken); torch keeps it
+        # in scaler.state_dict() -- here it travels with the optimizer, like the SPN optimizer's
+        amp = getattr(ts.e, "amp", None) if ts is not None else None
+        if amp is not None:
+            out["spb_amp"] = amp.detach().float().cpu()
+        elif self._pending_amp is not None:
+            out["spb_amp"] = self._pending_amp.clone()
+        return out
+
+    _pending_amp = None
 
     def load_state_dict(self, sd):
         g = self.param_groups[0]
         for k, v in sd["param_groups"][0].items():
             if k != "params":
                 g[k] = v
+        self._pending_amp = sd.get("spb_amp")
         if self._ts is not None:
             self._load_into(self._ts, sd["state"])
         else:
@@ -120,6 +134,9 @@ class FusedOptimizer(torch.optim.Optimizer):
 
     def _load_into(self, ts, state):
         eng = ts.e
+        if self._pending_amp is not None and getattr(eng, "amp", None) is not None:
+            eng.amp.copy_(self._pending_amp.to(eng.amp.device))
+            self._pending_amp = None
         names = {id(p): n for n, p in self._model.named_parameters()}
         infos = {i[0]: i for i in eng.param_infos}
         for idx, p in enumerate(self.param_groups[0]["params"]):

@@ -152,8 +152,36 @@ class FusedTrainStep:
         elif self.world > 1:
             allreduce_sum_(self.e.grads, self.group)  # RCCL sum; the 1/world mean is folded into gmul
 
-    def _update(self):
+    # GradScaler defaults (torch.cuda.amp.GradScaler(): growth 2, backoff 0.5, growth interval 2000; the initial scale lives in engine.amp)
+    amp_growth, amp_backoff, amp_interval = 2.0, 0.5, 2000
+
+    def _update_fp16(self):
+        """float16 (the reference's autocast + GradScaler recipe for KRN, trainer.py:73-98): scaler.unscale_ + inf / nan check, clip_grad_norm_
+        on the unscaled gradient, optimizer.step() or nothing at all, scaler.update() -- on the device, no host read of found_inf."""
+        import ctypes as C
+        from . import _lib as L
         e = self.e
+        b1, b2 = self._betas()
+        lib, st = e.lib, C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        amp = e.amp
+        L.check(lib.spb_amp_check(C.c_void_p(e.grads.data_ptr()), e.grads.numel(), C.c_void_p(amp.data_ptr()), st), "spb_amp_check")
+        L.check(lib.spb_amp_step(C.c_void_p(amp.data_ptr()), float(self.lr), float(b1), float(b2), float(self.amp_growth), float(self.amp_backoff),
+                                 int(self.amp_interval), st), "spb_amp_step")
+        gm = amp[L.AMP_INV_SCALE:L.AMP_INV_SCALE + 1]
+        if self.world > 1:
+            gm = gm * mean_scale(self.world)
+        if self.max_norm > 0:
+            ops.grad_sqnorm_partials(e.grads, self.sqp)
+        ops.optim_step(self.kind, e.params, e.grads, m=self.m, v=self.v, sq_partials=self.sqp if self.max_norm > 0 else None, gmul=gm,
+                       lr=self.lr, beta1=b1, beta2=b2, eps=_KIND_DEFAULT_EPS, weight_decay=self.weight_decay, max_norm=self.max_norm,
+                       clip_value=self.clip_value, step=max(self.t, 1), first_step=False, hyper=amp[L.AMP_LR:L.AMP_LR + 3],
+                       skip=amp[L.AMP_SKIP:L.AMP_SKIP + 1])
+
+    def _update(self, plain=False):
+        """plain=True: the gradients in the arena are already unscaled (the generic loss.backward() path with the caller's own GradScaler)"""
+        e = self.e
+        if getattr(e, "half", False) and not plain:
+            return self._update_fp16()
         b1, b2 = self._betas()
         if self.max_norm > 0:
             ops.grad_sqnorm_partials(e.grads, self.sqp)

