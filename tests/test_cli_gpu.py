@@ -47,6 +47,26 @@ def test_train_spn_with_use_fp16_flag_warns_and_resumes(device, tmp_path):
     assert ck["epoch"] == 2 and ck["optimizer"]["spn_fused"]["t"] == 4
 
 
+def test_train_krn_with_use_fp16_flag_runs_float16_and_resumes_the_scaler(device, tmp_path):
+    """--use_fp16 for KRN = the reference's recipe (train.py:101-104: autocast + GradScaler): IEEE-half kernels, GradScaler's state on the
+    device; the checkpoint carries it (loss scale, steps actually taken) and a resumed run starts from it"""
+    common = ["--model_name", "krn", "--batch_size", 4, "--synthetic_batches", 4, "--optimizer", "adamw", "--lr", "1e-4", "--weight_decay", "0.01",
+              "--savedir", tmp_path / "save", "--logdir", tmp_path / "log", "--use_fp16"]
+    out = run("train.py", *common, "--max_epochs", 1)
+    assert "KRN runs in float16 with device-side dynamic loss scaling" in out and "Training 001" in out
+    ck = torch.load(tmp_path / "save" / "checkpoint.pth.tar", map_location="cpu")
+    amp = ck["optimizer"]["spb_amp"]
+    from speedplusbaseline_amd import _lib as L
+    taken, scale = float(amp[L.AMP_STEPS]), float(amp[L.AMP_SCALE])
+    assert 0 <= taken <= 4 and scale == 65536.0 * 0.5 ** (4 - taken)          # every step was either taken or skipped with the scale halved
+    assert all(torch.isfinite(v.float()).all() for v in ck["state_dict"].values())
+    out = run("train.py", *common, "--max_epochs", 2)
+    assert "Checkpoint loaded" in out and "Training 002" in out
+    amp2 = torch.load(tmp_path / "save" / "checkpoint.pth.tar", map_location="cpu")["optimizer"]["spb_amp"]
+    taken2 = float(amp2[L.AMP_STEPS])
+    assert taken <= taken2 <= taken + 4 and float(amp2[L.AMP_SCALE]) == scale * 0.5 ** (4 - (taken2 - taken))   # continued from the saved state
+
+
 def test_adapt_dann(device, tmp_path):
     out = run("adapt.py", "--perform_dann", "--model_name", "krn", "--batch_size", 4, "--synthetic_batches", 2, "--max_epochs", 1, "--optimizer",
               "adamw", "--savedir", tmp_path / "save", "--logdir", tmp_path / "log", "--precision", "bf16")
