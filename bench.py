@@ -44,7 +44,7 @@ def _host():
     return dict(cpu_model=model, host_cores=os.cpu_count())
 
 
-def _pmc_traffic(family, files=("r4_pmc_traffic.json", "r3_pmc_traffic.json", "r2_pmc_traffic.json", "r1_pmc_traffic.json")):
+def _pmc_traffic(family, files=("r5_pmc_traffic.json", "r4_pmc_traffic.json", "r3_pmc_traffic.json", "r2_pmc_traffic.json", "r1_pmc_traffic.json")):
     """HBM bytes per launch of a kernel family from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE, separate runs,
     corrected as MI355X_MICROARCH.md prescribes; scratch/pmc_summary.py) -- rocprofv3 cannot run inside bench.py"""
     for name in files:
@@ -161,7 +161,7 @@ def bench_decoder(args):
     tf = GHIASI_FLOPS_PER_IMAGE * B / (ms * 1e-3) / 1e12
     traffic = src = None
     if B == 48:
-        for nm in ("r4_ghiasi_pmc_traffic.json", "r3_ghiasi_pmc_traffic.json"):
+        for nm in ("r5_ghiasi_pmc_traffic.json", "r4_ghiasi_pmc_traffic.json", "r3_ghiasi_pmc_traffic.json"):
             try:
                 with open(os.path.join(ROOT, "profiles", nm)) as f:
                     traffic, src = json.load(f)["restyle_hbm_bytes"], nm
@@ -392,7 +392,7 @@ def main():
         dec_traffic, dec_src = (None, None)
         if B == 48:
             try:   # HBM bytes of one restyle (all decoder launches), from the committed FETCH_SIZE / WRITE_SIZE passes of scratch/bench_ghiasi.py
-                for nm in ("r4_ghiasi_pmc_traffic.json", "r3_ghiasi_pmc_traffic.json"):
+                for nm in ("r5_ghiasi_pmc_traffic.json", "r4_ghiasi_pmc_traffic.json", "r3_ghiasi_pmc_traffic.json"):
                     if os.path.exists(os.path.join(ROOT, "profiles", nm)):
                         with open(os.path.join(ROOT, "profiles", nm)) as f:
                             dec_traffic, dec_src = json.load(f)["restyle_hbm_bytes"], nm
@@ -596,7 +596,7 @@ def bench_dann(args):
         eng.prof_enable(B, 0, False); eng.prof_enable(B, 1, False)
         dk, dv = max(agg.items(), key=lambda kv: kv[1]["ms"])
         ach = dv["bytes"] / (dv["ms"] * 1e-3) / 1e9
-        traffic, traffic_src = _pmc_traffic(dk, ("r4_dann_pmc_traffic.json", "r3_dann_pmc_traffic.json")) if B == 48 else (None, None)   # passes taken at bs=48+48
+        traffic, traffic_src = _pmc_traffic(dk, ("r5_dann_pmc_traffic.json", "r4_dann_pmc_traffic.json", "r3_dann_pmc_traffic.json")) if B == 48 else (None, None)   # passes taken at bs=48+48
         roofline = dict(bound="hbm", kernel=dk, achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4),
                         traffic=traffic, traffic_source=traffic_src,
                         launches_per_step=dv["launches"] // n_prof, avg_launch_us=round(dv["ms"] / dv["launches"] * 1e3, 2),
@@ -695,7 +695,7 @@ def bench_spn(args):
         roofline["kernel"] = "whole step (optimizer pass over the arenas + fully connected weight streams + trunk activations)"
         traffic = traffic_src = None
         if B == 32 and NC == 5000:
-            for nm in ("r4_spn_%s_pmc_traffic.json" % args.precision, "r3_spn_pmc_traffic.json"):
+            for nm in ("r5_spn_%s_pmc_traffic.json" % args.precision, "r4_spn_%s_pmc_traffic.json" % args.precision, "r3_spn_pmc_traffic.json"):
                 try:
                     with open(os.path.join(ROOT, "profiles", nm)) as f:
                         j = json.load(f)
