@@ -1199,7 +1199,7 @@ extern "C" int spb_krn_forward(spb_krn_ctx_t* c, const float* x, const float* ta
     g.pro = feat.ref; g.M = c->B * 49; g.K = 320; g.N = 1280; g.pro_mode = 1; g.epi_mode = 0; g.out_act = SPB_ACT_RELU;
     g.oR = 1; g.out_scale = 1.f;
     r.ok(spb_pwconv_gemm(m->dtype, &g, stream));
-    if (g_domain_tail_rows && (49 <= 56)) {
+    if (g_domain_tail_rows && (49 <= 56) && !c->det) {      // (reproducible mode: the walking kernel -- no float atomics into the caller's logits)
       if (hipMemsetAsync(domain_logits, 0, (size_t)c->B * sizeof(float), st) != hipSuccess) r.ok(SPB_E_STATE);
       const dim3 tg((unsigned)c->B, (1280 + 255) / 256);
       if (m->dtype == SPB_BF16)

@@ -46,7 +46,7 @@ def get_model(cfg):
     assert cfg.model_name == 'krn' or cfg.model_name == 'spn', 'Model name must be either krn or spn'
     if not cfg.dann:
         if cfg.model_name == 'krn':
-            model = KeypointRegressionNet(cfg.num_keypoints, precision=_precision(cfg))
+            model = KeypointRegressionNet(cfg.num_keypoints, precision=_precision(cfg), deterministic=getattr(cfg, "deterministic", False))
             logger.info('KRN created')
         else:
             try:
@@ -58,7 +58,7 @@ def get_model(cfg):
                 model = SpacecraftPoseNet(cfg.num_classes, pretrain=False, precision=_precision(cfg))
             logger.info('SPN created')
     else:
-        model = RevGrad(cfg.num_keypoints, precision=_precision(cfg))
+        model = RevGrad(cfg.num_keypoints, precision=_precision(cfg), deterministic=getattr(cfg, "deterministic", False))
         logger.info('RevGrad created with {}'.format(cfg.model_name))
     logger.info('   - Number of total parameters:     {:,}'.format(sum(p.numel() for p in model.parameters())))
     logger.info('   - Number of trainable parameters: {:,}'.format(sum(p.numel() for p in model.parameters() if p.requires_grad)))

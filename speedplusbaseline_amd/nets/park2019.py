@@ -131,7 +131,7 @@ class HipBackedMixin:
     def _spb_attach(self, dev):
         eng = self.__dict__.get("_engine_obj")
         if eng is None:
-            eng = KrnEngine(self.nK, dann=self._spb_dann)
+            eng = KrnEngine(self.nK, dann=self._spb_dann, deterministic=bool(getattr(self, "deterministic", False)))
             self.__dict__["_engine_obj"] = eng
         params, buffers = self._spb_names()
         old = {n: p.detach().clone() for n, p in params.items()}
@@ -186,10 +186,11 @@ class _KrnLossFn(torch.autograd.Function):
 
 
 class KeypointRegressionNet(HipBackedMixin, nn.Module):
-    def __init__(self, num_keypoints, precision=None, backbone_weights=None):
+    def __init__(self, num_keypoints, precision=None, backbone_weights=None, deterministic=False):
         super().__init__()
         self.nK = num_keypoints
         self.precision = precision
+        self.deterministic = bool(deterministic)      # the reproducible library build (KrnEngine(deterministic=True)); fp32 / bf16
         self.base = _mobilenet_v2_features_minus_last(backbone_weights)
         self.extras = nn.ModuleList([ConvDw(320, 1024, stride=1), ConvDw(1024, 1024, stride=1), RouterV2(96, 64),
                                      ConvDw(1024 + 64 * 4, 1024, stride=1)])

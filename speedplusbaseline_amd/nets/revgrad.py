@@ -47,10 +47,11 @@ class _RevGradFn(torch.autograd.Function):
 class RevGrad(HipBackedMixin, nn.Module):
     _spb_dann = True
 
-    def __init__(self, num_keypoints, precision=None):
+    def __init__(self, num_keypoints, precision=None, deterministic=False):
         super().__init__()
         self.nK = num_keypoints
         self.precision = precision
+        self.deterministic = bool(deterministic)
         self.net = KeypointRegressionNet(num_keypoints)
         self.net._spb_owner = False
         self.net.__dict__["_spb_parent"] = self

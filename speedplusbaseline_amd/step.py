@@ -39,6 +39,8 @@ class FusedTrainStep:
         self.use_graph = bool(use_graph)
         self.dann = bool(dann)
         self.dann_overlap = os.environ.get("SPB_DANN_OVERLAP", "1") != "0"   # source / target passes on two streams
+        if getattr(engine, "deterministic", False):
+            self.dann_overlap = False      # reproducible mode: one stream, both passes into the one (exactly accumulated) gradient arena
         self._g2 = self._s2 = None
         self._works = None
         # data-parallel: the arena tail is all-reduced while blocks 13..1 are still in backward (eager mode, plain KRN)

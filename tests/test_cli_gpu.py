@@ -125,3 +125,30 @@ def test_test_py_spn_with_the_default_result_name(device, tmp_path):
     run("test.py", "--model_name", "spn", "--num_classes", 64, "--synthetic_batches", 3, "--logdir", tmp_path / "log")
     txt = open(tmp_path / "log" / "results.txt").read()
     assert "eR" in txt and "speed (raw)" in txt
+
+
+def test_train_krn_deterministic_flag_gives_bit_identical_checkpoints(device, tmp_path):
+    """--deterministic: the reproducible build of the kernels behind the kept command line -- two runs from the same seed write
+    bit-identical parameters, BatchNorm buffers and optimizer moments (the reference cannot: utils.py:297-298); without the flag two runs differ"""
+    def run_once(tag, *extra):
+        d = tmp_path / tag
+        run("train.py", "--model_name", "krn", "--batch_size", 8, "--synthetic_batches", 4, "--max_epochs", 1, "--optimizer", "adamw", "--lr", "1e-3",
+            "--weight_decay", "0.01", "--savedir", d / "save", "--logdir", d / "log", "--precision", "fp32", *extra)
+        ck = torch.load(d / "save" / "checkpoint.pth.tar", map_location="cpu")
+        return ck
+    a, b = run_once("a", "--deterministic"), run_once("b", "--deterministic")
+    assert all(torch.equal(a["state_dict"][k], b["state_dict"][k]) for k in a["state_dict"])
+    sa, sb = a["optimizer"]["state"], b["optimizer"]["state"]
+    assert all(torch.equal(sa[i]["exp_avg"], sb[i]["exp_avg"]) and torch.equal(sa[i]["exp_avg_sq"], sb[i]["exp_avg_sq"]) for i in sa)
+    c, d = run_once("c"), run_once("d")
+    assert any(not torch.equal(c["state_dict"][k], d["state_dict"][k]) for k in c["state_dict"])        # float atomics: run-to-run different
+
+
+def test_adapt_dann_deterministic(device, tmp_path):
+    def run_once(tag):
+        d = tmp_path / tag
+        run("adapt.py", "--perform_dann", "--model_name", "krn", "--batch_size", 4, "--synthetic_batches", 3, "--max_epochs", 1, "--optimizer",
+            "adamw", "--savedir", d / "save", "--logdir", d / "log", "--precision", "bf16", "--deterministic")
+        return torch.load(d / "save" / "checkpoint.pth.tar", map_location="cpu")["state_dict"]
+    a, b = run_once("a"), run_once("b")
+    assert len(a) == 354 and all(torch.equal(a[k], b[k]) for k in a)

@@ -165,3 +165,55 @@ def test_style_augmentation_lookahead_keeps_the_batches(device):
     for i, (x, y) in enumerate(out):
         want = i * 0.5 + 0.25 if coins[i] else float(i)
         assert x.is_cuda and float(x.mean()) == want and float(y.mean()) == float(i)
+
+
+def test_fp16_module_generic_path_with_a_torch_gradscaler(device):
+    """KeypointRegressionNet(precision="fp16") the way the reference's loop uses autocast + GradScaler (trainer.py:73-98): scaler.scale(loss)
+    .backward() through the module (the upstream gradient carries the caller's scale; the engine's device-side scale stays out of it),
+    scaler.unscale_, clip_grad_norm_, scaler.step(optimizer) with a plain torch optimizer.  Gradients finite and close to the fp32 module's."""
+    from src.nets.park2019 import KeypointRegressionNet
+    from torch.nn.utils import clip_grad_norm_
+    x, y = O.synth_batch(4)
+    sd0 = O.init_state(11)
+    grads = {}
+    for prec in ("fp32", "fp16"):
+        model = KeypointRegressionNet(11, precision=prec)
+        model.load_state_dict(sd0, strict=True)
+        model = model.to(device).train()
+        opt = torch.optim.SGD(model.parameters(), lr=0.01)
+        scaler = torch.amp.GradScaler("cuda", init_scale=256.0, enabled=(prec == "fp16"))
+        loss, sm = model(x.to(device), y.to(device))
+        opt.zero_grad(set_to_none=True)
+        scaler.scale(loss).backward()
+        scaler.unscale_(opt)
+        gn = clip_grad_norm_(model.parameters(), 1.0)
+        p_before = model.head[0].bias.detach().clone()
+        scaler.step(opt)
+        scaler.update()
+        assert torch.isfinite(gn) and not torch.equal(model.head[0].bias.detach(), p_before)      # the step was taken
+        grads[prec] = (float(loss), torch.cat([p.grad.detach().flatten().double().cpu() for p in model.parameters()]))
+    l32, g32 = grads["fp32"]; l16, g16 = grads["fp16"]
+    cos = float(torch.dot(g16, g32) / (g16.norm() * g32.norm()))
+    print("loss fp32 %.5f fp16 %.5f; clipped gradient cosine %.4f, norm ratio %.4f" % (l32, l16, cos, float(g16.norm() / g32.norm())))
+    assert abs(l16 - l32) <= 0.03 * l32 and cos > 0.5 and 0.8 < float(g16.norm() / g32.norm()) < 1.25
+
+
+def test_deterministic_module_two_runs_bit_identical(device):
+    """KeypointRegressionNet(deterministic=True) through the fused optimizer path: two runs of three AdamW steps are bit-identical"""
+    from src.nets import get_model, get_optimizer
+    x, y = O.synth_batch(4)
+    outs = []
+    for rep in range(2):
+        cfg = _cfg(optimizer="adamw", lr=1e-3, weight_decay=0.01)
+        cfg.deterministic = True
+        model = get_model(cfg)
+        model.load_state_dict(O.init_state(11), strict=True)
+        opt = get_optimizer(cfg, model)
+        model = model.to(device).train()
+        for _ in range(3):
+            s = opt.train_step(x.to(device), y.to(device))
+        torch.cuda.synchronize()
+        assert model.engine().deterministic and model.engine().det_misses() == 0
+        outs.append((s.cpu().clone(), {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}))
+    assert torch.equal(outs[0][0], outs[1][0])
+    assert all(torch.equal(outs[0][1][k], outs[1][1][k]) for k in outs[0][1])
