@@ -14,7 +14,7 @@ CSRC = os.path.join(HERE, "csrc")
 ROOT = os.path.dirname(HERE)
 LIB = os.path.join(HERE, "libspb_hip.so")
 OBJDIR = os.path.join(HERE, "csrc", "_obj")
-SOURCES = ["gemm_pw.hip", "gemm_sk.hip", "gemm_os.hip", "gemm_big.hip", "gemm_rs.hip", "pw_bwd_fused.hip", "dwconv_rows.hip", "dwconv_plane.hip", "dwconv_tile.hip", "stem_head.hip", "stem_mfma.hip", "elemwise.hip", "ghiasi.hip", "ghiasi_wide.hip", "ghiasi_f32.hip", "spn.hip", "spn_fc.hip", "spn_conv.hip", "preproc.hip", "krn_plan.hip"]
+SOURCES = ["gemm_pw.hip", "gemm_sk.hip", "gemm_os.hip", "gemm_big.hip", "gemm_rs.hip", "gemm_st.hip", "pw_bwd_fused.hip", "dwconv_rows.hip", "dwconv_plane.hip", "dwconv_tile.hip", "stem_head.hip", "stem_mfma.hip", "elemwise.hip", "ghiasi.hip", "ghiasi_wide.hip", "ghiasi_f32.hip", "spn.hip", "spn_fc.hip", "spn_conv.hip", "preproc.hip", "krn_plan.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result", "-Wno-unused-value"]
 # IEEE-half twin for the SPN fp16 recipe (csrc/common.h, -DSPB_F16): the SPN kernels, the pointwise GEMMs they use and the
 # elementwise / optimizer kernels.
@@ -22,7 +22,7 @@ LIB_F16 = os.path.join(HERE, "libspb_hip_f16.so")
 # Round 5: + the KRN / DANN kernels and the plan -- the reference's own AMP recipe for KRN is float16 autocast + GradScaler
 # (train.py:101-104, trainer.py:73-94); bfloat16 stays the benchmarked substitution (BASELINE configs[1]).
 SOURCES_F16 = ["gemm_pw.hip", "elemwise.hip", "spn.hip", "spn_fc.hip", "spn_conv.hip",
-               "gemm_sk.hip", "gemm_os.hip", "gemm_big.hip", "gemm_rs.hip", "pw_bwd_fused.hip", "dwconv_rows.hip", "dwconv_plane.hip", "dwconv_tile.hip",
+               "gemm_sk.hip", "gemm_os.hip", "gemm_big.hip", "gemm_rs.hip", "gemm_st.hip", "pw_bwd_fused.hip", "dwconv_rows.hip", "dwconv_plane.hip", "dwconv_tile.hip",
                "stem_head.hip", "stem_mfma.hip", "krn_plan.hip"]
 # Reproducible twin (csrc/common.h, -DSPB_DET): the KRN / DANN kernels and the plan with exact (order-independent) accumulation in
 # place of float atomics.  KrnEngine(..., deterministic=True) and tests/test_parity_conditioned_gpu.py use it.
@@ -30,7 +30,7 @@ SOURCES_F16 = ["gemm_pw.hip", "elemwise.hip", "spn.hip", "spn_fc.hip", "spn_conv
 # the kernel-variant tests load it; the product library above has no mutable tuning state.
 LIB_TUNE = os.path.join(HERE, "libspb_hip_tune.so")
 LIB_DET = os.path.join(HERE, "libspb_hip_det.so")
-SOURCES_DET = ["gemm_pw.hip", "gemm_sk.hip", "gemm_os.hip", "gemm_big.hip", "gemm_rs.hip", "pw_bwd_fused.hip", "dwconv_rows.hip", "dwconv_plane.hip", "dwconv_tile.hip", "stem_head.hip", "stem_mfma.hip", "elemwise.hip", "krn_plan.hip"]
+SOURCES_DET = ["gemm_pw.hip", "gemm_sk.hip", "gemm_os.hip", "gemm_big.hip", "gemm_rs.hip", "gemm_st.hip", "pw_bwd_fused.hip", "dwconv_rows.hip", "dwconv_plane.hip", "dwconv_tile.hip", "stem_head.hip", "stem_mfma.hip", "elemwise.hip", "krn_plan.hip"]
 
 
 def _hipcc():

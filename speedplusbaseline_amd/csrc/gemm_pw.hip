@@ -22,20 +22,12 @@
 #include "common.h"
 #include <hip/hip_ext.h>
 
-#ifdef SPB_F16   // the IEEE-half twin holds this file's kernels only (build.py SOURCES_F16)
-static int spb_gemm_sk(const spb_gemm_args_t*, hipStream_t) { return SPB_E_UNSUPPORTED; }
-static int spb_gemm_os(const spb_gemm_args_t*, hipStream_t) { return SPB_E_UNSUPPORTED; }
-static int spb_gemm_big(const spb_gemm_args_t*, hipStream_t) { return SPB_E_UNSUPPORTED; }
-#else
 int spb_gemm_sk(const spb_gemm_args_t* a, hipStream_t stream);   // gemm_sk.hip
 int spb_gemm_os(const spb_gemm_args_t* a, hipStream_t stream);   // gemm_os.hip
 int spb_gemm_big(const spb_gemm_args_t* a, hipStream_t stream);  // gemm_big.hip
-#endif
-#ifdef SPB_F16
-static int spb_gemm_rs(const spb_gemm_args_t*, hipStream_t) { return SPB_E_UNSUPPORTED; }
-#else
 int spb_gemm_rs(const spb_gemm_args_t* a, hipStream_t stream);   // gemm_rs.hip
-#endif
+int spb_gemm_st(const spb_gemm_args_t* a, hipStream_t stream);   // gemm_st.hip
+// (round 5: the IEEE-half twin links these files too -- it holds the KRN kernels now, build.py SOURCES_F16)
 
 // phase timestamps for scratch/ubench_gemm.hip (compiled out in the product build)
 #ifndef SPB_TS
@@ -942,6 +934,9 @@ extern "C" int spb_pwconv_gemm(int dtype, const spb_gemm_args_t* a, spb_stream_t
   if (a->epi_mode == 2 && !a->Zout) return SPB_E_ARG;
   if (a->pro_mode == 3 && (!a->A2 || !a->Ymat || a->pro.act != SPB_ACT_NONE || a->pro2.act != SPB_ACT_NONE)) return SPB_E_ARG;
   if (dtype == SPB_BF16) {
+    // 112x112 / 56x56 maps, forward: the streaming kernel (gemm_st.hip)
+    const int es = spb_gemm_st(a, (hipStream_t)stream);
+    if (es != SPB_E_UNSUPPORTED) return es;
     // 28x28 / 14x14 maps, short reduction, wide output (expand forwards, project input gradients): the row-slab kernel (gemm_rs.hip)
     const int er = spb_gemm_rs(a, (hipStream_t)stream);
     if (er != SPB_E_UNSUPPORTED) return er;

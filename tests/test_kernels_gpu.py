@@ -307,6 +307,56 @@ def test_pw_gemm_row_slab_forward_and_residual_join(device, rs, M, K, N):
         L.lib().spb_debug_set_gemm_rs(1, 0)
 
 
+@pytest.mark.parametrize("M,K,N,join", [(4099, 32, 16, False), (4100, 16, 96, False), (5000, 96, 24, False), (4099, 24, 144, False), (4097, 144, 24, False),
+                                         (4100, 144, 32, False), (4099, 24, 144, True), (150528, 24, 144, True), (150528, 24, 144, False), (200704, 16, 96, False), (200704, 32, 16, False)])
+def test_pw_gemm_streaming_forward_large_maps(device, M, K, N, join):
+    """the 1x1 forward convolutions of the 112x112 / 56x56 maps on the streaming kernel (gemm_st.hip, round 5): every (K, N) of MobileNetV2
+    blocks 1-4, plain prologue (BatchNorm + ReLU6 with 8 statistic replicas) and the residual join (a = bn(A) + bn2(A2), written out as Ymat),
+    ragged row counts, against float64 and against the tiled kernel.  Small M runs on the tuning build (the dispatch threshold is a knob);
+    M >= 100000 on the product library as the KRN plan launches it."""
+    dt = torch.bfloat16
+    small = M < 100000
+    def run(st_on):
+        torch.manual_seed(M + N)
+        zin = rt(torch.randn(M, K, dtype=torch.float64) * 1.5 + 0.3, dt)
+        res = rt(torch.randn(M, K, dtype=torch.float64), dt)
+        gamma = torch.rand(K, dtype=torch.float64) + 0.5; beta = torch.randn(K, dtype=torch.float64) * 0.3
+        W = rt(torch.randn(N, K, dtype=torch.float64) / math.sqrt(K), dt)
+        u, _ = bn_train(zin, gamma, beta)
+        act = L.ACT_NONE if join else L.ACT_RELU6
+        a = rt(u + res, dt) if join else act_fn(u, act)
+        y = a @ W.t()
+        if small or not st_on:
+            L.lib().spb_debug_set_gemm_st(3 if st_on else 0, 1000 if small else 100000, 0)      # 3: with the long-reduction instances
+        pro = ops.bnref(K, sums=sums_of(zin, 8, device), gamma=gamma.float().to(device), beta=beta.float().to(device), n=M, R=8, act=act)
+        Y = torch.empty(M, N, dtype=dt, device=device)
+        osums = torch.zeros(8, 2, N, dtype=torch.float32, device=device)
+        Ym = torch.zeros(M, K, dtype=dt, device=device) if join else None
+        if join:
+            ops.pwconv_gemm(zin.to(dt).to(device), W.to(dt).to(device), Y, pro, 3, 1, A2=res.to(dt).to(device), osums=osums, oR=8, Ymat=Ym)
+        else:
+            ops.pwconv_gemm(zin.to(dt).to(device), W.to(dt).to(device), Y, pro, 1, 1, osums=osums, oR=8)
+        torch.cuda.synchronize()
+        return Y, osums.double().cpu().sum(0), Ym, y, u + res
+    if small:
+        with L.tuning():
+            Y, s, Ym, y, joined = run(True)
+            Yt, st_, _, _, _ = run(False)
+            L.lib().spb_debug_set_gemm_st(1, 100000, 0)
+    else:
+        Y, s, Ym, y, joined = run(True)
+        with L.tuning():
+            Yt, st_, _, _, _ = run(False)
+            L.lib().spb_debug_set_gemm_st(1, 100000, 0)
+    assert relerr(Y, y) < TOL[dt], relerr(Y, y)
+    assert relerr(Y, Yt) < 2e-3                                           # vs the tiled kernel: reduction order only
+    ys = Y.double().cpu()
+    assert relerr(s[0], ys.sum(0)) < 1e-4 and relerr(s[1], (ys * ys).sum(0)) < 1e-4
+    assert relerr(s[0], st_[0]) < 1e-3 and relerr(s[1], st_[1]) < 1e-3
+    if join:
+        assert relerr(Ym, joined) < TOL[dt]
+
+
 @pytest.mark.parametrize("M,K,N", [(9408, 384, 64), (9408, 576, 96), (37632, 192, 32), (4100, 384, 96), (9408, 192, 64)])
 @L.tuned
 def test_pw_gemm_row_slab_input_gradient(device, M, K, N):
