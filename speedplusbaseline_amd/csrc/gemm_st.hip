@@ -82,7 +82,7 @@ __global__ __launch_bounds__(256) void pw_st_kernel(const spb_gemm_args_t g, int
     }
   };
   load(c < nchunks ? c : 0, ra0, rb0);
-  load(c + cstep < nchunks ? c + cstep : 0, ra1, rb1);
+  if constexpr (KS < 3) load(c + cstep < nchunks ? c + cstep : 0, ra1, rb1);
   __syncthreads();      // the coefficient table (the only barrier of the launch besides the final reduction)
 
   float s1[NJ][4], s2[NJ][4];
@@ -92,52 +92,42 @@ __global__ __launch_bounds__(256) void pw_st_kernel(const spb_gemm_args_t g, int
     for (int r = 0; r < 4; ++r) { s1[j][r] = 0.f; s2[j][r] = 0.f; }
   const float act_h = act_hi(g.pro.act), act_n = act_ns(g.pro.act, g.pro.slope);
 
-  // one chunk: transform the fragments, 1..KS matrix steps per output fragment, rounded 16-byte stores, sums
-  auto chunk = [&](long long cc, uint4 (&ra)[KS], uint4 (&rb)[PRO == 3 ? KS : 1]) __attribute__((always_inline)) {
-    const long long m = cc * 16 + li;
-    const bool rowok = m < M;
-    bf16x8_t bfr[KS];
+  // the B fragment of reduction step ks of a chunk from the raw 16-byte vector(s): BatchNorm + activation (or the join) in registers
+  auto frag = [&](int ks, long long m, bool rowok, uint4 va, uint4 vb) __attribute__((always_inline)) {
+    const int k = ks * 32 + lq * 8;
+    Raw8<bf16_t> r1; r1.u = va;
+    float a[8], x[8];
+    cvt8(r1, a);
+    float c0[8], c1[8];
+    *reinterpret_cast<float4*>(c0) = *reinterpret_cast<const float4*>(coef + k);
+    *reinterpret_cast<float4*>(c0 + 4) = *reinterpret_cast<const float4*>(coef + k + 4);
+    *reinterpret_cast<float4*>(c1) = *reinterpret_cast<const float4*>(coef + KP + k);
+    *reinterpret_cast<float4*>(c1 + 4) = *reinterpret_cast<const float4*>(coef + KP + k + 4);
+    if constexpr (PRO == 1) {
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      const int k = ks * 32 + lq * 8;
-      Raw8<bf16_t> r1; r1.u = ra[ks];
-      float a[8], x[8];
-      cvt8(r1, a);
-      float c0[8], c1[8];
-      *reinterpret_cast<float4*>(c0) = *reinterpret_cast<const float4*>(coef + k);
-      *reinterpret_cast<float4*>(c0 + 4) = *reinterpret_cast<const float4*>(coef + k + 4);
-      *reinterpret_cast<float4*>(c1) = *reinterpret_cast<const float4*>(coef + KP + k);
-      *reinterpret_cast<float4*>(c1 + 4) = *reinterpret_cast<const float4*>(coef + KP + k + 4);
-      if constexpr (PRO == 1) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const float u = a[j] * c0[j] + c1[j];
-          x[j] = __builtin_amdgcn_fmed3f(u, 0.f, act_h) + act_n * fminf(u, 0.f);
-        }
-      } else {
-        Raw8<bf16_t> r2; r2.u = rb[PRO == 3 ? ks : 0];
-        float a2[8], c2[8];
-        cvt8(r2, a2);
-        *reinterpret_cast<float4*>(c2) = *reinterpret_cast<const float4*>(coef + 2 * KP + k);
-        *reinterpret_cast<float4*>(c2 + 4) = *reinterpret_cast<const float4*>(coef + 2 * KP + k + 4);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) x[j] = a[j] * c0[j] + a2[j] * c1[j] + c2[j];
+      for (int j = 0; j < 8; ++j) {
+        const float u = a[j] * c0[j] + c1[j];
+        x[j] = __builtin_amdgcn_fmed3f(u, 0.f, act_h) + act_n * fminf(u, 0.f);
       }
-      const bool ok = rowok && k < K;
-      uint4 pa;
-      pa.x = pack_bf16x2(x[0], x[1]); pa.y = pack_bf16x2(x[2], x[3]); pa.z = pack_bf16x2(x[4], x[5]); pa.w = pack_bf16x2(x[6], x[7]);
-      if (!ok) pa = make_uint4(0, 0, 0, 0);
-      bfr[ks] = __builtin_bit_cast(bf16x8_t, pa);
-      if constexpr (PRO == 3) { if (ok && split == 0) *reinterpret_cast<uint4*>(Ymat + (size_t)m * K + k) = pa; }
-    }
-    f32x4_t acc[NJ];
+    } else {
+      Raw8<bf16_t> r2; r2.u = vb;
+      float a2[8], c2[8];
+      cvt8(r2, a2);
+      *reinterpret_cast<float4*>(c2) = *reinterpret_cast<const float4*>(coef + 2 * KP + k);
+      *reinterpret_cast<float4*>(c2 + 4) = *reinterpret_cast<const float4*>(coef + 2 * KP + k + 4);
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-      acc[j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks) acc[j] = SPB_MFMA16(__builtin_bit_cast(bf16x8_t, wf[j][ks]), bfr[ks], acc[j]);
+      for (int j = 0; j < 8; ++j) x[j] = a[j] * c0[j] + a2[j] * c1[j] + c2[j];
     }
-    // rows past M and channels past N carry exact zeros (zeroed operands / weight rows): the sums need no mask
+    const bool ok = rowok && k < K;
+    uint4 pa;
+    pa.x = pack_bf16x2(x[0], x[1]); pa.y = pack_bf16x2(x[2], x[3]); pa.z = pack_bf16x2(x[4], x[5]); pa.w = pack_bf16x2(x[6], x[7]);
+    if (!ok) pa = make_uint4(0, 0, 0, 0);
+    if constexpr (PRO == 3) { if (ok && split == 0) *reinterpret_cast<uint4*>(Ymat + (size_t)m * K + k) = pa; }
+    return __builtin_bit_cast(bf16x8_t, pa);
+  };
+  // rounded 16-byte stores and the sums of a chunk's accumulators.  Rows past M and channels past N carry exact zeros (zeroed operands /
+  // weight rows): the sums need no mask
+  auto finish = [&](f32x4_t (&acc)[NJ], long long m, bool rowok) __attribute__((always_inline)) {
     bf16_t* yp = Yg + (size_t)(rowok ? m : M - 1) * N;
     auto fin4 = [&](const f32x4_t& av, float (&t1)[4], float (&t2)[4]) {
       uint2 o;
@@ -161,7 +151,52 @@ __global__ __launch_bounds__(256) void pw_st_kernel(const spb_gemm_args_t g, int
       if (rowok && ch < N) *reinterpret_cast<uint2*>(yp + ch) = o;
     }
   };
+  // one chunk from a register buffer: 1..KS matrix steps per output fragment
+  auto chunk = [&](long long cc, uint4 (&ra)[KS], uint4 (&rb)[PRO == 3 ? KS : 1]) __attribute__((always_inline)) {
+    const long long m = cc * 16 + li;
+    const bool rowok = m < M;
+    bf16x8_t bfr[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) bfr[ks] = frag(ks, m, rowok, ra[ks], rb[PRO == 3 ? ks : 0]);
+    f32x4_t acc[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      acc[j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) acc[j] = SPB_MFMA16(__builtin_bit_cast(bf16x8_t, wf[j][ks]), bfr[ks], acc[j]);
+    }
+    finish(acc, m, rowok);
+  };
 
+  if constexpr (KS >= 3) {
+    // long reduction (the project convolutions 96 -> 24, 144 -> 24 at 56x56): ONE register buffer, refilled in place -- step ks of the next
+    // chunk is requested the moment step ks of this one has been taken out, so KS loads stay in flight with KS registers (two whole
+    // buffers + the copy cost 154 / 222 registers: 2-3 waves per SIMD, slower than the tiled kernel)
+    while (c < nchunks) {
+      // the 16 BatchNorm coefficients a lane needs per step are loop invariant: left alone the compiler keeps all 16 * KS of them in
+      // registers (80 at KS = 5); re-read from LDS per chunk they are 4 ds_read_b128 per step
+      asm volatile("" ::: "memory");
+      const long long cn = c + cstep, cl = cn < nchunks ? cn : c;
+      const long long m = c * 16 + li;
+      const bool rowok = m < M;
+      long long mn = cl * 16 + li;
+      mn = mn < M ? mn : M - 1;
+      f32x4_t acc[NJ];
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) acc[j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const uint4 va = ra0[ks];
+        const int k = ks * 32 + lq * 8;
+        ra0[ks] = *reinterpret_cast<const uint4*>(Ag + (size_t)mn * K + (k < K ? k : K - 8));
+        const bf16x8_t bf = frag(ks, m, rowok, va, va);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[j] = SPB_MFMA16(__builtin_bit_cast(bf16x8_t, wf[j][ks]), bf, acc[j]);
+      }
+      finish(acc, m, rowok);
+      c = cn;
+    }
+  } else {
   // two chunks in flight per wave: the buffer just consumed is refilled with the chunk two steps ahead before the other one is worked on
   while (c < nchunks) {
     {
@@ -183,6 +218,7 @@ __global__ __launch_bounds__(256) void pw_st_kernel(const spb_gemm_args_t g, int
       chunk(c, xa, xb);
     }
     c += cstep;
+  }
   }
 
   // ---- per-channel sums: over the 16 rows of a DPP row -> LDS per wave -> one f32 atomic per channel, sum and workgroup
@@ -207,7 +243,7 @@ __global__ __launch_bounds__(256) void pw_st_kernel(const spb_gemm_args_t g, int
 }
 
 // persistent workgroups: 384 -> 2.627 ms per KRN step, 512 -> 2.625, 640 -> 2.635, 768 -> 2.620, 1024 -> 2.634, 1280 -> 2.636 (without the kernel: 2.665)
-int g_st_on = 1, g_st_min_m = 100000, g_st_wgs = 768, g_st_long_k = 0;
+int g_st_on = 1, g_st_min_m = 100000, g_st_wgs = 768, g_st_long_k = 1;
 
 template <int PRO, int NJ, int KS>
 int launch_st(const spb_gemm_args_t& g, hipStream_t stream) {

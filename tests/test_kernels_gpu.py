@@ -308,7 +308,8 @@ def test_pw_gemm_row_slab_forward_and_residual_join(device, rs, M, K, N):
 
 
 @pytest.mark.parametrize("M,K,N,join", [(4099, 32, 16, False), (4100, 16, 96, False), (5000, 96, 24, False), (4099, 24, 144, False), (4097, 144, 24, False),
-                                         (4100, 144, 32, False), (4099, 24, 144, True), (150528, 24, 144, True), (150528, 24, 144, False), (200704, 16, 96, False), (200704, 32, 16, False)])
+                                         (4100, 144, 32, False), (4099, 24, 144, True), (150528, 24, 144, True), (150528, 24, 144, False), (200704, 16, 96, False), (200704, 32, 16, False), (150528, 96, 24, False),
+                                         (150528, 144, 24, False)])
 def test_pw_gemm_streaming_forward_large_maps(device, M, K, N, join):
     """the 1x1 forward convolutions of the 112x112 / 56x56 maps on the streaming kernel (gemm_st.hip, round 5): every (K, N) of MobileNetV2
     blocks 1-4, plain prologue (BatchNorm + ReLU6 with 8 statistic replicas) and the residual join (a = bn(A) + bn2(A2), written out as Ymat),
