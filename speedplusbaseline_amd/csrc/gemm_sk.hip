@@ -307,13 +307,17 @@ int g_sk_max_m = 4096;     // the 7x7 maps at bs=48 (2352 rows): 19 vs 24 us (in
                           // rows the tiled kernel already has 147+ row tiles and is as fast (13.6 vs 13.2 us) -- measured, round 2
 int g_sk_max_n = 320;      // wider outputs re-read the weights per 16-row tile: the tiled kernel keeps them
 int g_sk_rf = 0;          // > 0: force the row-fragment count (experiments)
+int g_sk_min_wgs = 200;   // dispatch_sk: fewest workgroups a larger row tile may leave
 
 template <int PRO, int EPI>
 int dispatch_sk(const spb_gemm_args_t& g, hipStream_t stream) {
   const int NT = (g.N + 63) / 64;
+  // rows per workgroup: the largest 16 * rf that still gives ~200 workgroups.  Round 5: the old rule (>= 512 workgroups) put every 7x7 layer on
+  // 16-row tiles -- 441 / 735 workgroups that each pull their whole [64 x K] weight slab from L2 (96 MB of weight reads for the 1024 -> 320
+  // input gradient, 48 us under load); 32-row tiles halve that: KRN step 2.62 -> 2.57 ms (rf 1 | 2 | 4 everywhere: 2.622 | 2.573 | 2.602)
   int rf = 1;
   for (int cand = 4; cand >= 2; cand >>= 1)
-    if ((long long)((g.M + 16 * cand - 1) / (16 * cand)) * NT >= 512) { rf = cand; break; }
+    if ((long long)((g.M + 16 * cand - 1) / (16 * cand)) * NT >= g_sk_min_wgs) { rf = cand; break; }
   if (g_sk_rf > 0) rf = g_sk_rf;
   if (rf >= 4) return launch_sk<PRO, EPI, 4, 4, 2>(g, stream);
   if (rf == 2) return launch_sk<PRO, EPI, 2, 4, 2>(g, stream);

@@ -279,8 +279,9 @@ int spb_gemm_st(const spb_gemm_args_t* a, hipStream_t stream) {
     if (N <= 32 && !join) return launch_st<1, 2, 1>(*a, stream);
     return SPB_E_UNSUPPORTED;
   }
-  // project convolutions with a longer reduction (96 -> 24, 144 -> 24 | 32 at 56x56): built (instances <1, 2, 3>, <1, 2, 5>) and measured
-  // 1-4 us SLOWER than the tiled kernel (18.4 / 25.3 against 17.1 / 21.5 us): 154 / 222 registers, 2-3 waves per SIMD -- left to it
+  // project convolutions with a longer reduction (96 -> 24, 144 -> 24 | 32 at 56x56).  The first form (two whole register buffers, 154 / 222
+  // registers) was 1-4 us SLOWER than the tiled kernel; with ONE buffer refilled in place and the coefficients re-read from LDS per chunk
+  // (89 / 119 registers): 17.1 -> 14.2 us and 21.5 -> 18.0 us
   if (g_st_long_k && !join && N <= 32) {
     if (K <= 96) return launch_st<1, 2, 3>(*a, stream);
     if (K <= 160) return launch_st<1, 2, 5>(*a, stream);
