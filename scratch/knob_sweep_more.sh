@@ -1,23 +1,12 @@
 run() { printf "%-60s " "$1"; SPB_DEBUG="$1" python bench.py --bare --steps 100 --warmup 20 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['ms_per_step'])"; }
 run ""
-run "spb_debug_set_gemm_os:0,0,0,0"
-run "spb_debug_set_gemm_os:1,128,96,4096"
-run "spb_debug_set_gemm_os:1,160,96,2000"
-run "spb_debug_set_gemm_big:0,0,0"
-run "spb_debug_set_gemm_big:1,320,256"
-run "spb_debug_set_gemm_rs:0,0"
-run "spb_debug_set_gemm_rs:1,2000"
-run "spb_debug_set_gemm_bk64_min_k:128"
-run "spb_debug_set_gemm_bk64_min_k:512"
-run "spb_debug_set_gemm_wide_min_n:512"
-run "spb_debug_set_dw_plane_min_wgs:256"
-run "spb_debug_set_dw_plane_min_wgs:512"
-run "spb_debug_set_dw_wgrad_blocks:256"
-run "spb_debug_set_dw_wgrad_blocks:768"
-run "spb_debug_set_dw_rows:0"
-run "spb_debug_set_stem_grid:512,512"
-run "spb_debug_set_stem_grid:1024,1024"
-run "spb_debug_set_gemm_bk64_dgrad_min_k:256"
-run "spb_debug_set_dw_tile:56,0"
-run "spb_debug_set_dw_tile:14,0"
+for v in 256 320 448 512; do run "spb_debug_set_wgrad_target:$v"; done
+for v in 6 10; do run "spb_debug_set_wgrad_batch:$v"; done
+for v in 14 28 56; do run "spb_debug_set_dw_split:$v"; done
+run "spb_debug_set_gemm_wg_cap:512"
+run "spb_debug_set_gemm_wg_cap:1024"
+run "spb_debug_set_pwb:16,-1,4"
+run "spb_debug_set_pwb:16,-1,6"
+run "spb_debug_set_dw_plane_max_w:28"
+run "spb_debug_set_gemm_sk:1,0,0;spb_debug_set_gemm_big:1,320,512"
 run ""
