@@ -301,6 +301,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         scal = one_step(args.warmup + i, x, y)
+    t_host = time.perf_counter() - t0          # the host's share: all K steps enqueued (it runs ahead of the GPU until the queues fill)
     sync_all()
     dt = time.perf_counter() - t0
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -444,7 +445,8 @@ def main():
                        "per_gpu_batch": B, "global_batch": B * world, "parallelism": "dp%d" % world,
                        "launch": "hipGraph replay (fwd+bwd | all-reduce | clip+AdamW)" if args.graph else
                                  "eager enqueue, weight-gradient GEMMs on a side stream",
-                       "weights": "random init (no checkpoints offline)", "loss_last_step": loss_last},
+                       "weights": "random init (no checkpoints offline)", "loss_last_step": loss_last,
+                       "host_enqueue_ms_per_step": round(t_host / args.steps * 1e3, 4)},
             "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels, "others": others,
         }
         print(json.dumps(out))

@@ -149,6 +149,12 @@ typedef struct spb_dw_args {
   float* part;             /* dgrad with dW / wgrad: as in spb_wgrad_args_t */
   long long part_cap;
   spb_red_job_t* job_out;
+  /* dgrad, optional: the kernel's first thread stores entry_val to this device word before anything else.  The launch runs behind
+   * its stream's earlier launches, so the store tells a kernel spinning on the word (another stream of the SAME device) that all of
+   * them have completed and their results are released at device scope -- a stream fork without an event on this stream (the KRN
+   * plan hands its weight gradients to a side stream this way).  NULL: nothing is stored. */
+  unsigned* entry_flag;
+  unsigned entry_val;
 } spb_dw_args_t;
 int spb_dwconv_fwd(int dtype, const spb_dw_args_t* args, spb_stream_t stream);
 /* dgrad with args->dW != NULL also accumulates the weight gradient in the same pass (one read of g, z and the input

@@ -65,7 +65,8 @@ class GconvArgs(C.Structure):
 class DwArgs(C.Structure):
     _fields_ = [("X", vp), ("X2", vp), ("Xin", vp), ("Wd", vp), ("Y", vp), ("dW", vp), ("res", vp), ("Zout", vp),
                 ("osums", vp), ("pro", BNRef), ("pro_in", BNRef), ("epi", BNRef), ("B", i32), ("H", i32), ("W", i32),
-                ("C", i32), ("stride", i32), ("epi_mode", i32), ("oR", i32), ("part", vp), ("part_cap", i64), ("job_out", vp)]
+                ("C", i32), ("stride", i32), ("epi_mode", i32), ("oR", i32), ("part", vp), ("part_cap", i64), ("job_out", vp),
+                ("entry_flag", vp), ("entry_val", C.c_uint32)]
 
 
 class BnApplyArgs(C.Structure):

@@ -102,6 +102,14 @@ typedef __attribute__((ext_vector_type(4))) short s16x4_t;
     if (e__ != hipSuccess) return (int)e__;                 \
   } while (0)
 
+// spb_dw_args_t::entry_flag (include/spb_hip.h): the first thread of a launch publishes "everything before me on my stream is complete".
+// Any thread would do -- the dispatch sat behind a barrier bit -- and the store needs no fence of its own: the earlier launches' results
+// were released at device scope when their dispatch packets completed, and whoever spins on the word only gates later dispatches.
+__device__ __forceinline__ void spb_publish_entry(unsigned* flag, unsigned val) {
+  if (flag != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0)
+    __hip_atomic_store(flag, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // ---------------------------------------------------------------------------------------------
 // scalar conversions
 #ifdef SPB_F16

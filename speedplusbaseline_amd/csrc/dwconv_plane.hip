@@ -219,6 +219,7 @@ __global__ __launch_bounds__(256) void dwp_fwd_kernel(const spb_dw_args_t a, con
 // padded dz tile: row 0 = dz row q_first = (ST == 1 ? r0 - 1 : (r0 - 1) >> 1), TR rows per image, column 0 = dz column -1
 template <typename T, int ST, bool WG, bool EPI>
 __global__ __launch_bounds__(256) void dwp_bwd_kernel(const spb_dw_args_t a, const PGeo g) {
+  spb_publish_entry(a.entry_flag, a.entry_val);
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr bool IN = WG || EPI;
   constexpr int NRED = 16 + (WG ? 72 : 0);

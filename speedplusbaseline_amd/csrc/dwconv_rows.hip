@@ -314,6 +314,7 @@ __global__ __launch_bounds__(256, 2) void dwr_fwd_kernel(const spb_dw_args_t a, 
 // stream's critical path while most of the chip idles.
 template <typename T, int ST, bool WG, bool EPI, bool DG = true>
 __global__ __launch_bounds__(256, 2) void dwr_bwd_kernel(const spb_dw_args_t a, const Geo g) {
+  spb_publish_entry(a.entry_flag, a.entry_val);
   static_assert(DG || (WG && !EPI), "the weight-gradient-only instance has no epilogue");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NP = ST == 1 ? 14 : 15;
@@ -749,7 +750,7 @@ extern "C" int spb_dwconv_wgrad(int dtype, const spb_dw_args_t* a, spb_stream_t 
   if (!a->dW || !a->Xin) return SPB_E_ARG;
   if (dtype != SPB_BF16 && dtype != SPB_F32) return SPB_E_ARG;
   spb_dw_args_t k = *a;
-  k.Zout = a->Xin; k.epi = a->pro_in; k.Y = nullptr; k.epi_mode = 0; k.res = nullptr;
+  k.Zout = a->Xin; k.epi = a->pro_in; k.Y = nullptr; k.epi_mode = 0; k.res = nullptr; k.entry_flag = nullptr;
   if (!k.X2) k.X2 = k.X;
   spb_dwr_wgrad(dtype, &k, (hipStream_t)stream);
   SPB_CHECK_LAUNCH();

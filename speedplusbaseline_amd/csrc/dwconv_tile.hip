@@ -292,6 +292,7 @@ __global__ __launch_bounds__(256, ST == 1 ? 4 : 2) void dwt_fwd_kernel(const spb
 // load per lane, requested before the taps.  Not covered (the caller keeps the row-unit kernel): a joining gradient (res), LeakyReLU.
 template <bool EPI>
 __global__ __launch_bounds__(256, 2) void dwt_dgrad1_kernel(const spb_dw_args_t a, const TileGeo tg) {
+  spb_publish_entry(a.entry_flag, a.entry_val);
   typedef TG<1> G;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;

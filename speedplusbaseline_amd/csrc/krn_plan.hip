@@ -134,6 +134,9 @@ struct spb_krn_ctx {
   bool bucket_recorded = false;
   bool bucket_on = false;           // spb_krn_ctx_set_bucket: single-GPU runs skip the mid-backward join
   int n_fork = 0;
+  // forks ordered by a device word instead of an event (see fork_gate_kernel): the word and the serial number of the last fork
+  unsigned* fork_flag = nullptr;
+  unsigned fork_serial = 0;
   bool det = false;                 // spb_krn_ctx_set_det: this context's batch-sum arena has an exact-accumulation shadow
   const float* loss_scale = nullptr;   // spb_krn_ctx_set_loss_scale: device scalar multiplied onto the upstream gradient (float16 recipe)
   ~spb_krn_ctx() {
@@ -143,6 +146,7 @@ struct spb_krn_ctx {
     if (bucket_ev) hipEventDestroy(bucket_ev);
     if (prep_ev) hipEventDestroy(prep_ev);
     if (side) hipStreamDestroy(side);
+    if (fork_flag) hipFree(fork_flag);
   }
 };
 
@@ -349,11 +353,72 @@ static int g_side_wgrad = 1;
 static int g_skip_side = 0;            // TIMING EXPERIMENT ONLY (spb_debug_set_launch_events(2|4)): 2 drops the pointwise, 4 the depthwise side-stream weight gradients
 static int g_launch_events = 1;        // fork on the completion event of the preceding GEMM launch instead of an event record
 #ifdef SPB_TUNING   // tuning build only (libspb_hip_tune.so, include/spb_hip_tuning.h): the product library has no knob
-extern "C" int spb_debug_set_launch_events(int on) { g_launch_events = on & 1; g_skip_side = on & 6; return 0; }
+// bits 3-4: fork mode (0 default = 2, 1 -> events, 2 -> flag stored by a one-wave kernel)
+extern "C" int spb_debug_set_launch_events(int on);
 #endif
+// ---- forks without a packet on the launch queue ------------------------------------------------------------------------------------
+// Handing work to the side stream through an event costs the LAUNCH stream 5-9 us per fork (scratch/ubench_fork.hip: event record
+// 8.7 us, completion event on the producer's dispatch packet 6.6 us, either without the system fence 6.3 / 5.2 us, stream write/wait
+// value 9.0 us; the side work itself is free) -- 22 forks per KRN step.  A fork needs no event: the side stream runs a one-wave GATE
+// kernel that spins on a device word, and the word is stored
+//   * by the first thread of the launch stream's NEXT kernel (the depthwise input gradient the weight gradients run beside): it was
+//     dispatched behind a barrier bit, so its first instruction proves that every earlier launch has completed and been released at
+//     device scope (0.24 us per fork), or
+//   * where no such kernel follows, by a one-wave kernel on the launch stream (1.6 us).
+// The side stream's kernels behind the gate start with their dispatch packet's own device-scope acquire, as behind an event.
+// Serial numbers only grow, so the gate of fork n also passes when the word already holds n + k.  Not used inside a stream capture
+// (a replayed graph would replay the serials): the event path stays for that.
+static int g_fork_mode = 2;            // 0 events, 1 flag stored by a one-wave kernel, 2 flag stored at the entry of the next depthwise kernel
+__global__ void fork_set_kernel(unsigned* flag, unsigned val) {
+  if (threadIdx.x == 0) __hip_atomic_store(flag, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__global__ void fork_gate_kernel(const unsigned* flag, unsigned val) {
+  const unsigned long long t0 = wall_clock64();     // 100 MHz
+  while ((int)(__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - val) < 0) {
+    __builtin_amdgcn_s_sleep(8);
+    // the launch stream never reached the fork (a failed launch in between): fail loudly instead of hanging the device
+    if (wall_clock64() - t0 > 3000000000ull) __builtin_trap();
+  }
+}
+#ifdef SPB_TUNING
+extern "C" int spb_debug_set_launch_events(int on) {
+  g_launch_events = on & 1; g_skip_side = on & 6;
+  const int fm = (on >> 3) & 3;
+  g_fork_mode = fm == 0 ? 2 : fm - 1;
+  return 0;
+}
+#endif
+// Tools that let only ONE kernel of the device run at a time cannot run a spinning gate: the launch stream's kernel it waits for would never
+// start (measured: `rocprofv3 --pmc ...` hangs until the gate's time-out traps).  The side stream is ordered by events instead when
+//   * SPB_EVENT_FORKS=1 is in the environment, or
+//   * ROCPROF_COUNTER_COLLECTION=1 is (what rocprofv3 exports to the application for --pmc / counter-group runs).
+static bool event_forks_forced() {
+  static const bool v = [] {
+    for (const char* name : {"SPB_EVENT_FORKS", "ROCPROF_COUNTER_COLLECTION"}) {
+      const char* e = std::getenv(name);
+      if (e && e[0] && e[0] != '0' && e[0] != 'f' && e[0] != 'F') return true;
+    }
+    return false;
+  }();
+  return v;
+}
 static int g_side_priority = 0;
 #ifdef SPB_TUNING   // tuning build only (libspb_hip_tune.so, include/spb_hip_tuning.h): the product library has no knob
-extern "C" int spb_debug_set_side_priority(int on) { g_side_priority = on; return 0; }
+extern "C" int spb_debug_set_side_priority(int on);
+#endif
+// Flags of the events that order the two streams of ONE device (fork / join / weight-prep).  Without hipEventDisableSystemFence the
+// runtime gives the recording packet -- for a fork that is the input-gradient GEMM the event rides on (hipExtLaunchKernelGGL stop
+// event) -- a SYSTEM-scope release: every XCD's L2 written back and invalidated for the host's benefit, a ~4.8 us bubble on the
+// launch stream in front of each of the step's 22 depthwise backward kernels (profiles/r5_krn_chain.txt, `gap_us`).  Both sides of
+// these events are queues of the same device: a device-scope release is all they need.  (bucket_ev, which a communication stream
+// waits on before RCCL reads the gradients, keeps the system fence.)
+static unsigned g_stream_event_flags = hipEventDisableTiming | hipEventDisableSystemFence;
+#ifdef SPB_TUNING   // tuning build only: bit 0 = lowest stream priority for the side stream, bit 1 = system-fenced events (A/B)
+extern "C" int spb_debug_set_side_priority(int on) {
+  g_side_priority = on & 1;
+  g_stream_event_flags = (on & 2) ? hipEventDisableTiming : (hipEventDisableTiming | hipEventDisableSystemFence);
+  return 0;
+}
 #endif
 static int g_wgrad_flush_at_dw = 1;
 static int g_wgrad_min_flush = 1;      // flush at a depthwise kernel only with at least this many queued
@@ -421,7 +486,13 @@ static long long g_fused_pw_bwd_min_m = 100000;  // spb_debug_set_fused_pw_bwd(v
                                                  // (M = 37632, 144 -> 32) took 45 us fused for 26 MB; as GEMM + side-stream weight gradient the step is 12 us shorter
 struct Runner {
   spb_krn_ctx* c; spb_krn* m; hipStream_t st; int dt; int err = 0;
-  Runner(spb_krn_ctx* c_, hipStream_t s) : c(c_), m(c_->m), st(s), dt(c_->m->dtype) {}
+  bool flag_forks = false;   // forks through the context's device word (fork_gate_kernel) instead of events
+  Runner(spb_krn_ctx* c_, hipStream_t s) : c(c_), m(c_->m), st(s), dt(c_->m->dtype) {
+    if (g_fork_mode != 0 && c->fork_flag && !event_forks_forced()) {
+      hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+      flag_forks = hipStreamIsCapturing(st, &cs) == hipSuccess && cs == hipStreamCaptureStatusNone;
+    }
+  }
   void ok(int e) {
     if (e != 0 && err == 0) err = e;
 #ifdef SPB_DET   // reproducible mode: fold the exact batch-sum shadows into the float slots the next launch reads
@@ -544,7 +615,7 @@ struct Runner {
     }
     // this launch's own completion event: what the queued weight gradients wait for (see flush_wgrads)
     launch_ev = nullptr;
-    if (g_launch_events && before_dw && (!pend.empty() || head_pending || g_dw_split_hw > 0) && side_usable()) {
+    if (g_launch_events && !flag_forks && before_dw && (!pend.empty() || head_pending || g_dw_split_hw > 0) && side_usable()) {
       launch_ev = next_event(); g.stop_event = launch_ev;
     }
     ok(spb_pwconv_gemm(dt, &g, st));
@@ -556,14 +627,24 @@ struct Runner {
   hipEvent_t launch_ev = nullptr;   // completion event attached to the last input-gradient GEMM launch (or null)
   hipEvent_t next_event() {
     if ((size_t)c->n_fork >= c->fork_ev.size()) {
-      hipEvent_t e; hipEventCreateWithFlags(&e, hipEventDisableTiming);
+      hipEvent_t e; hipEventCreateWithFlags(&e, g_stream_event_flags);
       c->fork_ev.push_back(e);
     }
     return c->fork_ev[c->n_fork++];
   }
   bool side_usable() const { return !(c->prof_on || !c->side || !c->side_on || !g_side_wgrad || c->det || m->det); }
+  void gate_side(unsigned serial) {   // the side stream waits until the context's fork word reaches `serial`
+    hipLaunchKernelGGL(fork_gate_kernel, dim3(1), dim3(64), 0, c->side, c->fork_flag, serial);
+    forked = true;
+  }
   hipStream_t side_stream() {
     if (!side_usable()) return st;
+    if (flag_forks) {   // the word is stored by a one-wave kernel behind everything the launch stream holds so far
+      const unsigned serial = ++c->fork_serial;
+      hipLaunchKernelGGL(fork_set_kernel, dim3(1), dim3(64), 0, st, c->fork_flag, serial);
+      gate_side(serial);
+      return c->side;
+    }
     hipEvent_t e = next_event();
     hipEventRecord(e, st);
     hipStreamWaitEvent(c->side, e, 0);
@@ -599,9 +680,10 @@ struct Runner {
   }
   std::vector<spb_dw_args_t> pend_dw;   // depthwise weight gradients of the small maps (see dw_bwd)
   void flush_wgrads() {
-    if (pend.empty() && pend_dw.empty() && !head_pending) return;
+    if (pend.empty() && pend_dw.empty() && !head_pending) { gated = false; return; }
     hipStream_t s;
-    if (launch_ev) {   // everything the queued GEMMs read was final before that launch: wait for it, record nothing
+    if (gated) { gated = false; s = c->side; }   // dw_bwd already put this batch's gate on the side stream
+    else if (launch_ev) {   // everything the queued GEMMs read was final before that launch: wait for it, record nothing
       hipStreamWaitEvent(c->side, launch_ev, 0);
       launch_ev = nullptr; forked = true; s = c->side;
     } else s = side_stream();            // one event record for the whole batch
@@ -626,6 +708,7 @@ struct Runner {
     forked = false;
   }
   bool forked = false;
+  bool gated = false;
   void dw_bwd(const DWDef& L, const Src& in, int Hin, int aout, int atgt, void* plain, const void* res) {
     spb_dw_args_t d; std::memset(&d, 0, sizeof(d));
     d.X = this->g(aout); d.X2 = z(aout); d.Xin = in.ptr; d.Wd = m->P + L.w_off; d.dW = m->G + L.w_off;
@@ -646,10 +729,18 @@ struct Runner {
       d.Y = this->g(atgt); d.osums = bsums(atgt); d.oR = c->R[atgt]; d.res = res; d.epi_mode = 2;
     } else { d.Y = plain; d.epi_mode = 0; d.oR = 1; }
     const double nin = (double)c->B * Hin * Hin * L.C, nout = elems(aout);
-    if (!g_flush_after_dw && g_wgrad_flush_at_dw && (int)(pend.size() + pend_dw.size()) >= g_wgrad_min_flush) flush_wgrads();
+    const bool flush_due = g_wgrad_flush_at_dw && (int)(pend.size() + pend_dw.size()) >= g_wgrad_min_flush &&
+                           (!pend.empty() || !pend_dw.empty() || head_pending);
+    // fork through the device word: this kernel's first thread stores the serial (it runs behind a barrier bit: everything the queued
+    // weight gradients read is complete by then), the gate and the batch follow it onto the side stream -- the kernel that stores the
+    // word is always enqueued BEFORE the gate that waits for it (streams may share a hardware queue)
+    const bool entry_fork = flag_forks && g_fork_mode == 2 && flush_due && side_usable();
+    if (entry_fork) { d.entry_flag = c->fork_flag; d.entry_val = ++c->fork_serial; }
+    if (!entry_fork && !g_flush_after_dw && flush_due) flush_wgrads();
     tic(PC_DW_DGRAD, (2 * nout + 2 * nin + (res ? nin : 0)) * es(), 36.0 * nout);
     ok(spb_dwconv_dgrad(dt, &d, st));
     toc();
+    if (entry_fork) { gate_side(d.entry_val); gated = true; flush_wgrads(); }
     if (split && c->prof_on) {
       tic(PC_DW_WGRAD, (2 * nout + nin) * es() + 36.0 * L.C, 18.0 * nout);
       ok(spb_dwconv_wgrad(dt, &dwg, st));
@@ -658,7 +749,7 @@ struct Runner {
     // the queued weight gradients run beside this memory-bound kernel.  They are handed to the side stream AFTER the launch
     // stream got its kernel: the host is only a bounded number of packets ahead of the GPU, and a burst of ~10 side-stream
     // launches in front of the next launch-stream kernel showed up as 30-50 us holes in the launch queue (round-3 trace)
-    if (g_flush_after_dw && g_wgrad_flush_at_dw && (int)(pend.size() + pend_dw.size()) >= g_wgrad_min_flush) flush_wgrads();
+    if (!entry_fork && g_flush_after_dw && flush_due) flush_wgrads();
     launch_ev = nullptr;   // the event belongs to the launch before the depthwise kernel: nothing queued later may fork on it
   }
 };
@@ -1047,12 +1138,13 @@ extern "C" int spb_krn_ctx_create(spb_krn_t* m, int batch, void* workspace, spb_
       se = hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, least);
     if (se != hipSuccess && hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess) c->side = nullptr;
   }
-  if (hipEventCreateWithFlags(&c->join_ev, hipEventDisableTiming) != hipSuccess) { delete c; return SPB_E_STATE; }
+  if (hipMalloc(&c->fork_flag, 256) != hipSuccess || hipMemset(c->fork_flag, 0, 256) != hipSuccess) { delete c; return SPB_E_STATE; }
+  if (hipEventCreateWithFlags(&c->join_ev, g_stream_event_flags) != hipSuccess) { delete c; return SPB_E_STATE; }
   if (hipEventCreateWithFlags(&c->bucket_ev, hipEventDisableTiming) != hipSuccess) { delete c; return SPB_E_STATE; }
-  if (hipEventCreateWithFlags(&c->prep_ev, hipEventDisableTiming) != hipSuccess) { delete c; return SPB_E_STATE; }
+  if (hipEventCreateWithFlags(&c->prep_ev, g_stream_event_flags) != hipSuccess) { delete c; return SPB_E_STATE; }
   for (int i = 0; i < 64; ++i) {
     hipEvent_t ev;
-    if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) break;
+    if (hipEventCreateWithFlags(&ev, g_stream_event_flags) != hipSuccess) break;
     c->fork_ev.push_back(ev);
   }
   *out = c;
@@ -1099,8 +1191,11 @@ extern "C" int spb_krn_forward(spb_krn_ctx_t* c, const float* x, const float* ta
   bool prep_wait = false;
   if (prep || zero_g) {
     if (r.side_usable() && c->fork_ev.size() > 0) {
-      hipEventRecord(c->fork_ev[0], st);
-      hipStreamWaitEvent(c->side, c->fork_ev[0], 0);
+      if (r.flag_forks) (void)r.side_stream();   // (the previous step's optimizer is the producer: no kernel of this pass can carry the word)
+      else {
+        hipEventRecord(c->fork_ev[0], st);
+        hipStreamWaitEvent(c->side, c->fork_ev[0], 0);
+      }
       if (prep) r.ok(spb_weight_prep(m->dtype, m->prep_d, m->n_prep, m->n_prep_tiles, m->P, m->wc, c->side));
       if (zero_g && hipMemsetAsync(m->G, 0, (size_t)m->n_params * sizeof(float), c->side) != hipSuccess) r.ok(SPB_E_STATE);
       hipEventRecord(c->prep_ev, c->side);

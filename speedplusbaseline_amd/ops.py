@@ -132,9 +132,11 @@ def dwconv_fwd(X, Wd, Y, pro, stride, osums=None, oR=1):
 
 
 def dwconv_dgrad(G, Z, Wd, Y, pro, stride, in_hw, epi=None, Zout=None, res=None, osums=None, oR=1, dW=None, Xin=None,
-                 pro_in=None):
+                 pro_in=None, entry_flag=None, entry_val=0):
     """Input gradient of the depthwise conv.  With `dW` the weight gradient is accumulated in the same pass; `Xin` and
-    `pro_in` (the conv's input tensor and its BN/activation) are then required unless `epi`/`Zout` already name them."""
+    `pro_in` (the conv's input tensor and its BN/activation) are then required unless `epi`/`Zout` already name them.
+    `entry_flag` (a device int32 word): the launch's first thread stores `entry_val` there before anything else
+    (spb_dw_args_t::entry_flag: a stream fork without an event)."""
     B, C_ = G.shape[0], G.shape[3]
     _need_cuda(G, Z, Wd, Y, Zout, res, osums, dW, Xin)
     kw = dict(X2=Z, Y=Y, pro=pro, epi_mode=2 if epi is not None else 0, oR=oR)
@@ -145,6 +147,9 @@ def dwconv_dgrad(G, Z, Wd, Y, pro, stride, in_hw, epi=None, Zout=None, res=None,
         if epi is None:
             kw.update(epi=pro_in, Zout=Xin)
     d = _dwargs(G, Wd, B, in_hw[0], in_hw[1], C_, stride, **kw)
+    if entry_flag is not None:
+        _need_cuda(entry_flag)
+        d.entry_flag = _ptr(entry_flag); d.entry_val = int(entry_val)
     L.check(L.lib().spb_dwconv_dgrad(dtype_code(G), C.byref(d), _stream()), "spb_dwconv_dgrad")
 
 

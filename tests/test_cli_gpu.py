@@ -152,3 +152,20 @@ def test_adapt_dann_deterministic(device, tmp_path):
         return torch.load(d / "save" / "checkpoint.pth.tar", map_location="cpu")["state_dict"]
     a, b = run_once("a"), run_once("b")
     assert len(a) == 354 and all(torch.equal(a[k], b[k]) for k in a)
+
+
+@pytest.mark.parametrize("env", [{"SPB_EVENT_FORKS": "1"}, {"ROCPROF_COUNTER_COLLECTION": "1"}])
+def test_bench_runs_with_event_ordered_side_stream(device, env):
+    """The product library orders its side stream by a spinning gate kernel (csrc/krn_plan.hip); under a tool that serialises the device's
+    kernels (rocprofv3 --pmc exports ROCPROF_COUNTER_COLLECTION=1 to the application) or with SPB_EVENT_FORKS=1 it falls back to events:
+    the same training steps, the same kind of answer."""
+    import json
+    outs = []
+    for extra in ({}, env):
+        p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--bare", "--steps", "3", "--warmup", "0", "--batch", "8"], cwd=ROOT,
+                           capture_output=True, text=True, timeout=600, env=dict(os.environ, PYTHONPATH=ROOT, **extra))
+        assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-3000:])
+        outs.append(json.loads(p.stdout.strip().splitlines()[-1]))
+    a, b = (o["config"]["loss_last_step"] for o in outs)
+    assert all(v == v and abs(v) < 1e6 for v in a + b), (a, b)
+    assert 0.2 * a[0] < b[0] < 5 * a[0], (a, b)       # three AdamW steps from a random init: chaotic already, the same order of magnitude

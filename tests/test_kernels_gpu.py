@@ -479,6 +479,33 @@ def test_dwconv(device, dw_variant, dt, B, H, C, stride, act):
             assert relerr(sf[0], gf.sum(0)) < 1e-3 and relerr(sf[1], (gf * nhwc(xh1).view(-1, C)).sum(0)) < 1e-3
 
 
+@pytest.mark.parametrize("B,H,C,stride", [(4, 14, 96, 1), (2, 28, 64, 2), (2, 56, 48, 1), (1, 112, 32, 2)])   # plane, row-unit and tile kernels
+def test_dwconv_dgrad_publishes_entry_word(device, B, H, C, stride):
+    """spb_dw_args_t::entry_flag (include/spb_hip.h): the input-gradient launch stores entry_val to the device word before anything
+    else -- the KRN plan's stream fork without an event (csrc/krn_plan.hip, fork_gate_kernel) -- and computes what it computes without it."""
+    dt, dev = torch.bfloat16, device
+    torch.manual_seed(H + C)
+    OH = (H + 2 - 3) // stride + 1
+    G = torch.randn(B, OH, OH, C, device=dev).to(dt); Z = torch.randn(B, OH, OH, C, device=dev).to(dt)
+    Wd = (torch.randn(C, 1, 3, 3, device=dev) * 0.3).contiguous()
+    n = B * OH * OH
+    z2 = Z.double().view(-1, C).cpu()
+    g2 = G.double().view(-1, C).cpu()
+    mean = z2.mean(0); var = z2.var(0, unbiased=False); xh = (z2 - mean) / torch.sqrt(var + EPS)
+    bs = torch.stack([g2.sum(0), (g2 * xh).sum(0)]).float().unsqueeze(0).contiguous().to(dev)
+    pro = ops.bnref(C, sums=sums_of(z2, 1, dev), gamma=torch.ones(C, device=dev), beta=torch.zeros(C, device=dev), bsums=bs, n=n,
+                    act=L.ACT_RELU6)
+    outs = []
+    word = torch.zeros(4, dtype=torch.int32, device=dev)
+    for flag in (None, word):
+        P = torch.empty(B, H, H, C, dtype=dt, device=dev)
+        ops.dwconv_dgrad(G, Z, Wd, P, pro, stride, (H, H), entry_flag=flag, entry_val=41 + stride)
+        torch.cuda.synchronize()
+        outs.append(P)
+    assert word.tolist() == [41 + stride, 0, 0, 0]
+    assert torch.equal(outs[0], outs[1])
+
+
 @pytest.fixture(params=["rows", "tile"])
 def dw_tile_dgrad(request):
     """stride-1 input gradient on the LDS-tile kernel (off by default: spb_debug_set_dw_tile bit 16) and on the default kernels"""

@@ -267,6 +267,62 @@ def test_revgrad_forward_and_dann_step(device):
     assert relerr(eng.buffers[off: off + numel], sd[name]) < 1e-4
 
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_side_stream_forks_equal_the_single_stream(device, precision):
+    """The weight gradients run on the context's side stream, ordered behind the launch stream by a device word (csrc/krn_plan.hip,
+    fork_gate_kernel: the depthwise input-gradient launch stores a serial number at its entry, a one-wave gate kernel on the side
+    stream spins on it) -- no event on the launch stream.  A weight gradient that started before its operands were complete would be
+    wrong by ~100 % in its tensor: thirty backward passes with the forks, and ten ordered by events (tuning build), all against the
+    single-stream pass of the same forward state; bar: 3x the largest per-tensor difference between single-stream passes (the order of
+    the float atomics; below 15 % or the test says nothing)."""
+    import speedplusbaseline_amd._lib as L
+    B = 16
+    g = torch.Generator().manual_seed(11)
+    x = torch.rand(B, 3, 224, 224, generator=g).to(device); y = torch.rand(B, 2, 11, generator=g).to(device)
+
+    def passes(eng, side, n):
+        eng.set_side_stream(B, 0, side)
+        out = []
+        for _ in range(n):
+            eng.grads.zero_()
+            eng.forward(x, y, training=True)
+            eng.backward(B)
+            torch.cuda.synchronize()
+            out.append(eng.grads.clone())
+        return out
+
+    def worst(eng, gs, ref):
+        gn = float(ref.norm())
+        w = (0.0, None)
+        for info in eng.param_infos:
+            r = eng.param_view(info, ref)
+            for gi in gs:
+                e = float((eng.param_view(info, gi) - r).norm() / max(float(r.norm()), 1e-3 * gn))
+                if e > w[0]:
+                    w = (e, info[0])
+        return w
+
+    eng = KrnEngine(11).attach(device, precision)
+    load_state(eng, O.init_state(11))
+    single = passes(eng, False, 4)
+    noise = worst(eng, single[1:], single[0])
+    forked = worst(eng, passes(eng, True, 30), single[0])
+    print("%s: single-stream run to run %.3e (%s); device-word forks vs single stream %.3e (%s)" % ((precision,) + noise + forked))
+    bar = max(3 * noise[0], 1e-3)
+    assert bar < 0.45, noise
+    assert forked[0] < bar, (forked, noise)
+    with L.tuning():
+        L.lib().spb_debug_set_launch_events(9)           # bits 3-4 = 1: the event path (what SPB_EVENT_FORKS=1 / a counter-collecting profiler selects)
+        try:
+            eng2 = KrnEngine(11).attach(device, precision)
+            load_state(eng2, O.init_state(11))
+            ev = worst(eng2, passes(eng2, True, 10), single[0])
+        finally:
+            L.lib().spb_debug_set_launch_events(1)
+    print("%s: event forks vs single stream %.3e (%s)" % ((precision,) + ev))
+    assert ev[0] < bar, (ev, noise)
+
+
 def test_overlapped_gradient_exchange_plumbing_single_rank(device, monkeypatch):
     """The data-parallel path that all-reduces the arena tail (blocks 14..17, extras, head) on a communication stream while
     the rest of the backward runs: with ONE rank the all-reduce is the identity, so a step through that path (RCCL
