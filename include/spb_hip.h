@@ -279,6 +279,18 @@ int spb_arena_add(float* dst, const float* src, long long n, spb_stream_t stream
  * the launch stream's kernels first and the update takes what they leave (host side: nets/spn.py loss_and_grads). */
 int spb_stream_create(int level, spb_stream_t* out);
 int spb_stream_destroy(spb_stream_t stream);
+/* Stream fork without an event: everything enqueued on `to` after this call runs behind everything enqueued on `from` before it.
+ * What it replaces: torch.cuda.Stream.wait_stream / hipEventRecord + hipStreamWaitEvent in the host code that spreads one training
+ * step of the reference (trainer.py:72-98,146-185: one stream there) over several streams -- an event record costs the recording
+ * stream 6-9 us on this device, this fork 1.6 us: a one-wave kernel on `from` stores a serial number to a device word owned by the
+ * object, a one-wave gate kernel on `to` spins on it (both streams on ONE device; one object per `from` stream: serials must be
+ * stored in order).  Falls back to an event (created without the system-scope fence) inside a stream capture, when SPB_EVENT_FORKS=1
+ * is set, and under rocprofv3 counter collection (ROCPROF_COUNTER_COLLECTION=1: kernels are serialised there, a gate would spin
+ * forever; it traps after 30 s if the storing launch never runs). */
+typedef struct spb_fork spb_fork_t;
+int spb_fork_create(spb_fork_t** out);
+void spb_fork_destroy(spb_fork_t* f);
+int spb_fork_streams(spb_fork_t* f, spb_stream_t from, spb_stream_t to);
 typedef struct spb_optim_args {
   float* params; float* grads; float* m; float* v; /* flat f32 arenas; m/v may be NULL for sgd w/o momentum */
   const float* sqnorm;  /* optional device scalar: clip coefficient = min(1, max_norm/(sqrt(sqnorm)+1e-6)) */

@@ -162,6 +162,9 @@ SYMBOLS = {
     "spb_arena_add": (i32, [vp, vp, i64, vp]),
     "spb_stream_create": (i32, [i32, C.POINTER(C.c_void_p)]),
     "spb_stream_destroy": (i32, [vp]),
+    "spb_fork_create": (i32, [C.POINTER(C.c_void_p)]),
+    "spb_fork_destroy": (None, [vp]),
+    "spb_fork_streams": (i32, [vp, vp, vp]),
     "spb_optim_step": (i32, [C.POINTER(OptimArgs), vp]),
     "spb_fc_wgrad_update": (i32, [vp, vp, i32, i32, i32, C.POINTER(OptimArgs), vp]),
     "spb_krn_create": (i32, [i32, i32, C.POINTER(vp)]),

@@ -102,6 +102,10 @@ typedef __attribute__((ext_vector_type(4))) short s16x4_t;
     if (e__ != hipSuccess) return (int)e__;                 \
   } while (0)
 
+// stream forks through a device word (elemwise.hip): store `val` behind everything `s` holds / keep `s` waiting until the word reaches `val`
+void spb_fork_store(unsigned* flag, unsigned val, hipStream_t s);
+void spb_fork_gate(const unsigned* flag, unsigned val, hipStream_t s);
+bool spb_fork_by_word(hipStream_t from);   // false: order by events (stream capture, SPB_EVENT_FORKS=1, a counter-collecting profiler)
 // spb_dw_args_t::entry_flag (include/spb_hip.h): the first thread of a launch publishes "everything before me on my stream is complete".
 // Any thread would do -- the dispatch sat behind a barrier bit -- and the store needs no fence of its own: the earlier launches' results
 // were released at device scope when their dispatch packets completed, and whoever spins on the word only gates later dispatches.

@@ -6,6 +6,7 @@
 //   * global-norm clip + optimiser update fused over the flat parameter arena
 //       (reference trainer.py:90,97  clip_grad_norm_; build.py:60-78 sgd/rmsprop/adam/adamw)
 #include <cstring>
+#include <cstdlib>
 #include "common.h"
 #include "optim_math.h"
 
@@ -695,6 +696,89 @@ extern "C" int spb_stream_create(int level, spb_stream_t* out) {
 }
 extern "C" int spb_stream_destroy(spb_stream_t s) {
   return s && hipStreamDestroy((hipStream_t)s) == hipSuccess ? 0 : SPB_E_ARG;
+}
+
+// ---- stream forks without events ("Round 5, second half") -------------------------------------------------------
+// Ordering a second stream behind the launch stream with an event costs the LAUNCH stream 5-9 us per fork, whatever the flavour
+// (scratch/ubench_fork.hip: event record 8.7 us, completion event on the producer's dispatch packet 6.6 us, either without the system
+// fence 6.3 / 5.2 us, stream write/wait value 9.0 us; the forked work itself is free).  A fork needs no event: the second stream runs a
+// one-wave GATE kernel that spins on a device word, and the word is stored
+//   * by a one-wave kernel on the launch stream (1.6 us per fork: spb_fork_streams, the KRN plan's forks that no depthwise kernel follows), or
+//   * by the first thread of the launch stream's NEXT kernel (0.24 us: spb_dw_args_t::entry_flag, spb_publish_entry in common.h).
+// Either store runs behind a barrier bit (every dispatch of this runtime carries barrier=1 and device-scope acquire + release fences:
+// profiles/r5_fork_aql_headers.txt), so it proves every earlier launch of its stream complete and released at device scope; the
+// kernels behind the gate start with their dispatch packet's own device-scope acquire, as behind an event.  Serial numbers only grow: the
+// gate of fork n also passes when the word already holds n + k.  The storing kernel is always enqueued BEFORE the gate that waits for it
+// (HIP streams may share a hardware queue: in host order every gate then depends on earlier entries only -- no cycle).
+__global__ void fork_set_kernel(unsigned* flag, unsigned val) {
+  if (threadIdx.x == 0) __hip_atomic_store(flag, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__global__ void fork_gate_kernel(const unsigned* flag, unsigned val) {
+  const unsigned long long t0 = wall_clock64();     // 100 MHz
+  while ((int)(__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - val) < 0) {
+    __builtin_amdgcn_s_sleep(8);
+    // the storing launch never ran (a failed launch in between, or a tool that serialises the device's kernels): fail loudly
+    // instead of hanging the device
+    if (wall_clock64() - t0 > 3000000000ull) __builtin_trap();
+  }
+}
+void spb_fork_store(unsigned* flag, unsigned val, hipStream_t s) { hipLaunchKernelGGL(fork_set_kernel, dim3(1), dim3(64), 0, s, flag, val); }
+void spb_fork_gate(const unsigned* flag, unsigned val, hipStream_t s) { hipLaunchKernelGGL(fork_gate_kernel, dim3(1), dim3(64), 0, s, flag, val); }
+// Tools that let only ONE kernel of the device run at a time cannot run a spinning gate: the launch it waits for would never start
+// (measured: `rocprofv3 --pmc ...` hangs until the gate's time-out traps).  Streams are ordered by events instead when
+//   * SPB_EVENT_FORKS=1 is in the environment, or
+//   * ROCPROF_COUNTER_COLLECTION=1 is (what rocprofv3 exports to the application for --pmc / counter-group runs),
+// and inside a stream capture (a replayed graph would replay the serial numbers).
+bool spb_event_forks_forced() {
+  static const bool v = [] {
+    for (const char* name : {"SPB_EVENT_FORKS", "ROCPROF_COUNTER_COLLECTION"}) {
+      const char* e = std::getenv(name);
+      if (e && e[0] && e[0] != '0' && e[0] != 'f' && e[0] != 'F') return true;
+    }
+    return false;
+  }();
+  return v;
+}
+bool spb_fork_by_word(hipStream_t from) {
+  if (spb_event_forks_forced()) return false;
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  return hipStreamIsCapturing(from, &cs) == hipSuccess && cs == hipStreamCaptureStatusNone;
+}
+
+struct spb_fork { unsigned* word = nullptr; unsigned serial = 0; hipEvent_t ev = nullptr; };
+extern "C" int spb_fork_create(spb_fork_t** out) {
+  if (!out) return SPB_E_ARG;
+  spb_fork* f = new spb_fork();
+  // the word must BE zero before the first gate can run: hipMemset on device memory returns before the fill has executed, and a gate
+  // on a non-blocking stream does not wait for the null stream -- on recycled memory it would read the last serial of a destroyed fork
+  if (hipMalloc(&f->word, 256) != hipSuccess || hipMemset(f->word, 0, 256) != hipSuccess || hipStreamSynchronize(nullptr) != hipSuccess ||
+      hipEventCreateWithFlags(&f->ev, hipEventDisableTiming | hipEventDisableSystemFence) != hipSuccess) {
+    if (f->word) hipFree(f->word);
+    delete f;
+    return SPB_E_STATE;
+  }
+  *out = f;
+  return 0;
+}
+extern "C" void spb_fork_destroy(spb_fork_t* f) {
+  if (!f) return;
+  if (f->word) hipFree(f->word);
+  if (f->ev) hipEventDestroy(f->ev);
+  delete f;
+}
+extern "C" int spb_fork_streams(spb_fork_t* f, spb_stream_t from, spb_stream_t to) {
+  if (!f) return SPB_E_ARG;
+  hipStream_t a = (hipStream_t)from, b = (hipStream_t)to;
+  if (a == b) return 0;
+  if (spb_fork_by_word(a)) {
+    const unsigned serial = ++f->serial;
+    spb_fork_store(f->word, serial, a);
+    spb_fork_gate(f->word, serial, b);
+  } else {
+    if (hipEventRecord(f->ev, a) != hipSuccess || hipStreamWaitEvent(b, f->ev, 0) != hipSuccess) return SPB_E_STATE;
+  }
+  SPB_CHECK_LAUNCH();
+  return 0;
 }
 
 // ---------------------------------------------------------------------------------------------------------------

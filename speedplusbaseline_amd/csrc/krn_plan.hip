@@ -356,30 +356,9 @@ static int g_launch_events = 1;        // fork on the completion event of the pr
 // bits 3-4: fork mode (0 default = 2, 1 -> events, 2 -> flag stored by a one-wave kernel)
 extern "C" int spb_debug_set_launch_events(int on);
 #endif
-// ---- forks without a packet on the launch queue ------------------------------------------------------------------------------------
-// Handing work to the side stream through an event costs the LAUNCH stream 5-9 us per fork (scratch/ubench_fork.hip: event record
-// 8.7 us, completion event on the producer's dispatch packet 6.6 us, either without the system fence 6.3 / 5.2 us, stream write/wait
-// value 9.0 us; the side work itself is free) -- 22 forks per KRN step.  A fork needs no event: the side stream runs a one-wave GATE
-// kernel that spins on a device word, and the word is stored
-//   * by the first thread of the launch stream's NEXT kernel (the depthwise input gradient the weight gradients run beside): it was
-//     dispatched behind a barrier bit, so its first instruction proves that every earlier launch has completed and been released at
-//     device scope (0.24 us per fork), or
-//   * where no such kernel follows, by a one-wave kernel on the launch stream (1.6 us).
-// The side stream's kernels behind the gate start with their dispatch packet's own device-scope acquire, as behind an event.
-// Serial numbers only grow, so the gate of fork n also passes when the word already holds n + k.  Not used inside a stream capture
-// (a replayed graph would replay the serials): the event path stays for that.
+// ---- forks without a packet on the launch queue: the weight gradients are handed to the side stream through a device word and a
+// one-wave gate kernel instead of an event (the mechanism and its measurements: elemwise.hip, "stream forks without events")
 static int g_fork_mode = 2;            // 0 events, 1 flag stored by a one-wave kernel, 2 flag stored at the entry of the next depthwise kernel
-__global__ void fork_set_kernel(unsigned* flag, unsigned val) {
-  if (threadIdx.x == 0) __hip_atomic_store(flag, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__global__ void fork_gate_kernel(const unsigned* flag, unsigned val) {
-  const unsigned long long t0 = wall_clock64();     // 100 MHz
-  while ((int)(__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - val) < 0) {
-    __builtin_amdgcn_s_sleep(8);
-    // the launch stream never reached the fork (a failed launch in between): fail loudly instead of hanging the device
-    if (wall_clock64() - t0 > 3000000000ull) __builtin_trap();
-  }
-}
 #ifdef SPB_TUNING
 extern "C" int spb_debug_set_launch_events(int on) {
   g_launch_events = on & 1; g_skip_side = on & 6;
@@ -388,20 +367,6 @@ extern "C" int spb_debug_set_launch_events(int on) {
   return 0;
 }
 #endif
-// Tools that let only ONE kernel of the device run at a time cannot run a spinning gate: the launch stream's kernel it waits for would never
-// start (measured: `rocprofv3 --pmc ...` hangs until the gate's time-out traps).  The side stream is ordered by events instead when
-//   * SPB_EVENT_FORKS=1 is in the environment, or
-//   * ROCPROF_COUNTER_COLLECTION=1 is (what rocprofv3 exports to the application for --pmc / counter-group runs).
-static bool event_forks_forced() {
-  static const bool v = [] {
-    for (const char* name : {"SPB_EVENT_FORKS", "ROCPROF_COUNTER_COLLECTION"}) {
-      const char* e = std::getenv(name);
-      if (e && e[0] && e[0] != '0' && e[0] != 'f' && e[0] != 'F') return true;
-    }
-    return false;
-  }();
-  return v;
-}
 static int g_side_priority = 0;
 #ifdef SPB_TUNING   // tuning build only (libspb_hip_tune.so, include/spb_hip_tuning.h): the product library has no knob
 extern "C" int spb_debug_set_side_priority(int on);
@@ -488,10 +453,7 @@ struct Runner {
   spb_krn_ctx* c; spb_krn* m; hipStream_t st; int dt; int err = 0;
   bool flag_forks = false;   // forks through the context's device word (fork_gate_kernel) instead of events
   Runner(spb_krn_ctx* c_, hipStream_t s) : c(c_), m(c_->m), st(s), dt(c_->m->dtype) {
-    if (g_fork_mode != 0 && c->fork_flag && !event_forks_forced()) {
-      hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-      flag_forks = hipStreamIsCapturing(st, &cs) == hipSuccess && cs == hipStreamCaptureStatusNone;
-    }
+    flag_forks = g_fork_mode != 0 && c->fork_flag && spb_fork_by_word(st);
   }
   void ok(int e) {
     if (e != 0 && err == 0) err = e;
@@ -634,14 +596,14 @@ struct Runner {
   }
   bool side_usable() const { return !(c->prof_on || !c->side || !c->side_on || !g_side_wgrad || c->det || m->det); }
   void gate_side(unsigned serial) {   // the side stream waits until the context's fork word reaches `serial`
-    hipLaunchKernelGGL(fork_gate_kernel, dim3(1), dim3(64), 0, c->side, c->fork_flag, serial);
+    spb_fork_gate(c->fork_flag, serial, c->side);
     forked = true;
   }
   hipStream_t side_stream() {
     if (!side_usable()) return st;
     if (flag_forks) {   // the word is stored by a one-wave kernel behind everything the launch stream holds so far
       const unsigned serial = ++c->fork_serial;
-      hipLaunchKernelGGL(fork_set_kernel, dim3(1), dim3(64), 0, st, c->fork_flag, serial);
+      spb_fork_store(c->fork_flag, serial, st);
       gate_side(serial);
       return c->side;
     }
@@ -1138,7 +1100,10 @@ extern "C" int spb_krn_ctx_create(spb_krn_t* m, int batch, void* workspace, spb_
       se = hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, least);
     if (se != hipSuccess && hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess) c->side = nullptr;
   }
-  if (hipMalloc(&c->fork_flag, 256) != hipSuccess || hipMemset(c->fork_flag, 0, 256) != hipSuccess) { delete c; return SPB_E_STATE; }
+  // (the fill has to have executed before the first gate runs on the non-blocking side stream: see spb_fork_create in elemwise.hip)
+  if (hipMalloc(&c->fork_flag, 256) != hipSuccess || hipMemset(c->fork_flag, 0, 256) != hipSuccess || hipStreamSynchronize(nullptr) != hipSuccess) {
+    delete c; return SPB_E_STATE;
+  }
   if (hipEventCreateWithFlags(&c->join_ev, g_stream_event_flags) != hipSuccess) { delete c; return SPB_E_STATE; }
   if (hipEventCreateWithFlags(&c->bucket_ev, hipEventDisableTiming) != hipSuccess) { delete c; return SPB_E_STATE; }
   if (hipEventCreateWithFlags(&c->prep_ev, g_stream_event_flags) != hipSuccess) { delete c; return SPB_E_STATE; }

@@ -474,7 +474,7 @@ class SpacecraftPoseNet(nn.Module):
                 f(_st())
             return
         side = self._side_fc if fc else self._side
-        side.wait_stream(torch.cuda.current_stream())
+        self._fork(side)
         with torch.cuda.stream(side):
             sst = _st()
             for f in fns:
@@ -483,6 +483,13 @@ class SpacecraftPoseNet(nn.Module):
             self._side_fc_used = True
         else:
             self._side_used = True
+
+    def _fork(self, to):
+        """stream `to` continues behind everything the current stream holds: ops.StreamFork (no event record on the current stream)"""
+        f = getattr(self, "_fork_obj", None)
+        if f is None:
+            f = self._fork_obj = ops.StreamFork()
+        f(to)
 
     def _side_streams_in_use(self):
         return ([self._side] if getattr(self, "_side_used", False) else []) + ([self._side_fc] if getattr(self, "_side_fc_used", False) else [])
@@ -501,7 +508,7 @@ class SpacecraftPoseNet(nn.Module):
             return contextlib.nullcontext()
         if getattr(self, "_hs", None) is None:
             self._hs = torch.cuda.Stream(device=self._gflat.device)
-        self._hs.wait_stream(torch.cuda.current_stream())
+        self._fork(self._hs)
         self._heads_forked = True
         return torch.cuda.stream(self._hs)
 
@@ -519,7 +526,7 @@ class SpacecraftPoseNet(nn.Module):
         their own, ordered after everything enqueued so far; the convolution weight gradients keep the side stream"""
         if getattr(self, "_upd", None) is None:
             self._upd = _low_priority_stream(self._gflat.device)
-        self._upd.wait_stream(torch.cuda.current_stream())
+        self._fork(self._upd)
         with torch.cuda.stream(self._upd):
             for name, gT, xT in jobs:
                 optimizer.fused_fc_update(name, gT, xT, B)
@@ -645,7 +652,7 @@ class SpacecraftPoseNet(nn.Module):
         forward waits for it before fc6 (join_updates), state_dict() / flat_parameters() / invalidate() too"""
         if getattr(self, "_upd", None) is None:
             self._upd = _low_priority_stream(self._gflat.device)
-        self._upd.wait_stream(torch.cuda.current_stream())
+        self._fork(self._upd)
         with torch.cuda.stream(self._upd):
             fn()
         self._early_on_upd = True
@@ -810,7 +817,7 @@ class SpacecraftPoseNet(nn.Module):
                 # weights from HBM like the update does.
                 if getattr(self, "_upd", None) is None:
                     self._upd = _low_priority_stream(self._gflat.device)
-                self._upd.wait_stream(torch.cuda.current_stream())
+                self._fork(self._upd)
                 for sd in self._side_streams_in_use():
                     self._upd.wait_stream(sd)
                 with torch.cuda.stream(self._upd):

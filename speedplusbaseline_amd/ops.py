@@ -294,3 +294,39 @@ def fc_wgrad_update(gT, xT, M, kind, params, grads=None, m=None, v=None, gmul=No
 def debug_trread(inp, out):
     _need_cuda(inp, out)
     L.check(L.lib().spb_debug_trread(_ptr(inp), _ptr(out), _stream()), "spb_debug_trread")
+
+
+class StreamFork:
+    """`fork(to)`: everything enqueued on stream `to` afterwards runs behind everything the current stream holds now -- what
+    `to.wait_stream(torch.cuda.current_stream())` does, without the event record that costs the CURRENT stream 6-9 us on this device
+    (spb_fork_streams in include/spb_hip.h: a one-wave store kernel here, a one-wave gate kernel there; events inside a stream capture, with
+    SPB_EVENT_FORKS=1 and under rocprofv3 counter collection).  One native object per source stream (serial numbers must be stored in
+    order); joins -- the current stream waiting for `to` -- stay `wait_stream`: the waiting stream has to stall there anyway."""
+
+    def __init__(self):
+        self._h = {}
+
+    def __call__(self, to, src=None):
+        src = torch.cuda.current_stream(to.device) if src is None else src
+        if src.cuda_stream == to.cuda_stream:
+            return
+        h = self._h.get(src.cuda_stream)
+        if h is None:
+            h = C.c_void_p()
+            with torch.cuda.device(to.device):
+                L.check(L.lib().spb_fork_create(C.byref(h)), "spb_fork_create")
+            self._h[src.cuda_stream] = h
+        L.check(L.lib().spb_fork_streams(h, C.c_void_p(src.cuda_stream), C.c_void_p(to.cuda_stream)), "spb_fork_streams")
+
+    def __del__(self):
+        try:
+            for h in self._h.values():
+                L.lib().spb_fork_destroy(h)
+        except Exception:
+            pass
+
+    def __deepcopy__(self, memo):     # native handles are not copied: a copied module forks through objects of its own
+        return StreamFork()
+
+    def __reduce__(self):
+        return (StreamFork, ())

@@ -41,7 +41,7 @@ class FusedTrainStep:
         self.dann_overlap = os.environ.get("SPB_DANN_OVERLAP", "1") != "0"   # source / target passes on two streams
         if getattr(engine, "deterministic", False):
             self.dann_overlap = False      # reproducible mode: one stream, both passes into the one (exactly accumulated) gradient arena
-        self._g2 = self._s2 = None
+        self._g2 = self._s2 = self._fork = None
         self._works = None
         # data-parallel: the arena tail is all-reduced while blocks 13..1 are still in backward (eager mode, plain KRN)
         mode = os.environ.get("SPB_DDP_OVERLAP", "1")      # "0": one all-reduce after backward; "force": also with one rank (tests)
@@ -130,7 +130,9 @@ class FusedTrainStep:
             self._s2 = torch.cuda.Stream(device=e.device)
         e.prepare_weights()
         ops.arena_zero(e.grads); ops.arena_zero(self._g2)
-        self._s2.wait_stream(main)
+        if self._fork is None:
+            self._fork = ops.StreamFork()
+        self._fork(self._s2, main)          # the target pass continues behind the launch stream: no event record there (ops.StreamFork)
         with torch.cuda.stream(self._s2):
             _, _, dom_t = e.forward(xt, None, training=True, slot=1, domain=True, prepare=False, update_running=False)
             loss_t, dl_t = e.bce_logits(dom_t, 0.0)

@@ -267,14 +267,16 @@ def test_revgrad_forward_and_dann_step(device):
     assert relerr(eng.buffers[off: off + numel], sd[name]) < 1e-4
 
 
-@pytest.mark.parametrize("precision", ["fp32", "bf16"])
-def test_side_stream_forks_equal_the_single_stream(device, precision):
+def test_side_stream_forks_equal_the_single_stream(device, precision="fp32"):
     """The weight gradients run on the context's side stream, ordered behind the launch stream by a device word (csrc/krn_plan.hip,
     fork_gate_kernel: the depthwise input-gradient launch stores a serial number at its entry, a one-wave gate kernel on the side
     stream spins on it) -- no event on the launch stream.  A weight gradient that started before its operands were complete would be
     wrong by ~100 % in its tensor: thirty backward passes with the forks, and ten ordered by events (tuning build), all against the
     single-stream pass of the same forward state; bar: 3x the largest per-tensor difference between single-stream passes (the order of
-    the float atomics; below 15 % or the test says nothing)."""
+    the float atomics; below 15 % or the test says nothing).  float32: every pointwise layer queues its weight gradient there (bf16 fuses
+    the large ones into the input-gradient kernel), and single-stream passes repeat to ~2 % per tensor -- in bf16 at this random-init
+    point they do not (the rounding amplifies the atomics' order to > 100 % on the BatchNorm scales that feed another BatchNorm), so a
+    bf16 instance of this test could not tell a race from the noise."""
     import speedplusbaseline_amd._lib as L
     B = 16
     g = torch.Generator().manual_seed(11)
