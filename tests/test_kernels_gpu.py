@@ -814,3 +814,30 @@ def test_optim_step_matches_torch(device, kind):
                        weight_decay=wd, max_norm=1.0, step=i + 1, first_step=(i == 0))
     torch.cuda.synchronize()
     assert relerr(p, p_ref.detach()) < 1e-5
+
+
+def test_stream_fork_orders_the_second_stream(device):
+    """ops.StreamFork / spb_fork_streams (include/spb_hip.h): what `b.wait_stream(a)` does, without an event record on `a` -- a one-wave
+    kernel on `a` stores a serial number, a one-wave gate kernel on `b` spins on it.  Stream `b` must see everything `a` held at the fork,
+    complete: forty rounds of four 64 MB read-modify-write passes on `a`, a copy on `b` right behind the fork."""
+    fork = ops.StreamFork()
+    a, b = torch.cuda.Stream(device=device), torch.cuda.Stream(device=device)
+    x = torch.zeros(16 << 20, dtype=torch.float32, device=device)
+    torch.cuda.synchronize()
+    seen = []
+    for i in range(40):
+        with torch.cuda.stream(a):
+            for _ in range(4):
+                x.add_(1.0)
+            fork(b)                     # source: the current stream (a)
+        with torch.cuda.stream(b):
+            y = x.clone()
+            seen.append(torch.stack([y.min(), y.max()]))
+        a.wait_stream(b)                # the next round's writes wait for this round's read
+    torch.cuda.synchronize()
+    got = torch.stack(seen).cpu()
+    want = torch.arange(1, 41, dtype=torch.float32).mul(4).unsqueeze(1).expand(40, 2)
+    assert torch.equal(got, want), got[:6]
+    fork(a, a)                          # same stream on both sides: nothing to order
+    import copy
+    assert isinstance(copy.deepcopy(fork), ops.StreamFork)
