@@ -679,6 +679,7 @@ def bench_spn(args):
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = one()
+    t_host = time.perf_counter() - t0           # the host's share: all K steps enqueued
     sync_all()
     dt = time.perf_counter() - t0
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -764,7 +765,8 @@ def bench_spn(args):
                                    "clip_grad_value 1.0, dropout 0.5" % B, "per_gpu_batch": B, "global_batch": B * world,
                        "parallelism": "dp%d" % world + (" (fc gradients reduce-scattered, optimizer state of the fully connected layers "
                                                           "sharded by rank, bf16 shadows all-gathered)" if world > 1 and os.environ.get("SPB_SPN_SHARDED", "1") != "0" else ""),
-                       "weights": "random init", "loss_last_step": [float(v) for v in out.cpu()]},
+                       "weights": "random init", "loss_last_step": [float(v) for v in out.cpu()],
+                       "host_enqueue_ms_per_step": round(t_host / args.steps * 1e3, 4)},
             "roofline": roofline, "cpu_baseline": cpu}))
     if world > 1:
         torch.distributed.destroy_process_group()

@@ -286,7 +286,7 @@ int spb_stream_destroy(spb_stream_t stream);
  * object, a one-wave gate kernel on `to` spins on it (both streams on ONE device; one object per `from` stream: serials must be
  * stored in order).  Falls back to an event (created without the system-scope fence) inside a stream capture, when SPB_EVENT_FORKS=1
  * is set, and under rocprofv3 counter collection (ROCPROF_COUNTER_COLLECTION=1: kernels are serialised there, a gate would spin
- * forever; it traps after 30 s if the storing launch never runs). */
+ * forever; it traps after SPB_FORK_TIMEOUT_S seconds -- default 600, 0 = never -- if the storing launch never runs). */
 typedef struct spb_fork spb_fork_t;
 int spb_fork_create(spb_fork_t** out);
 void spb_fork_destroy(spb_fork_t* f);

@@ -713,17 +713,30 @@ extern "C" int spb_stream_destroy(spb_stream_t s) {
 __global__ void fork_set_kernel(unsigned* flag, unsigned val) {
   if (threadIdx.x == 0) __hip_atomic_store(flag, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__global__ void fork_gate_kernel(const unsigned* flag, unsigned val) {
+__global__ void fork_gate_kernel(const unsigned* flag, unsigned val, unsigned long long timeout_ticks) {
   const unsigned long long t0 = wall_clock64();     // 100 MHz
   while ((int)(__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - val) < 0) {
     __builtin_amdgcn_s_sleep(8);
     // the storing launch never ran (a failed launch in between, or a tool that serialises the device's kernels): fail loudly
     // instead of hanging the device
-    if (wall_clock64() - t0 > 3000000000ull) __builtin_trap();
+    if (timeout_ticks != 0 && wall_clock64() - t0 > timeout_ticks) __builtin_trap();
   }
 }
+// How long a gate waits before it gives up: the storing launch is already enqueued when the gate is, so the wait is the launch stream's own
+// backlog -- which may hold a collective that waits for a late peer rank.  Default 600 s (the default watchdog of torch's process groups);
+// SPB_FORK_TIMEOUT_S overrides it, 0 = wait forever (what an event does).
+static unsigned long long fork_timeout_ticks() {
+  static const unsigned long long v = [] {
+    const char* e = std::getenv("SPB_FORK_TIMEOUT_S");
+    const double sec = (e && e[0]) ? std::atof(e) : 600.0;
+    return sec <= 0.0 ? 0ull : (unsigned long long)(sec * 1e8);
+  }();
+  return v;
+}
 void spb_fork_store(unsigned* flag, unsigned val, hipStream_t s) { hipLaunchKernelGGL(fork_set_kernel, dim3(1), dim3(64), 0, s, flag, val); }
-void spb_fork_gate(const unsigned* flag, unsigned val, hipStream_t s) { hipLaunchKernelGGL(fork_gate_kernel, dim3(1), dim3(64), 0, s, flag, val); }
+void spb_fork_gate(const unsigned* flag, unsigned val, hipStream_t s) {
+  hipLaunchKernelGGL(fork_gate_kernel, dim3(1), dim3(64), 0, s, flag, val, fork_timeout_ticks());
+}
 // Tools that let only ONE kernel of the device run at a time cannot run a spinning gate: the launch it waits for would never start
 // (measured: `rocprofv3 --pmc ...` hangs until the gate's time-out traps).  Streams are ordered by events instead when
 //   * SPB_EVENT_FORKS=1 is in the environment, or
