@@ -299,6 +299,9 @@ __global__ __launch_bounds__(256, 2) void dwr_fwd_kernel(const spb_dw_args_t a, 
   }
 }
 
+#ifndef SPB_DW_HOIST
+#define SPB_DW_HOIST 1
+#endif
 // ------------------------------------------------------------------------------------------------------ backward
 // dz[q] = g[q]*p0 + z[q]*p1 + p2 (BN backward of the conv output, rebuilt on the fly; 0 outside the image)
 // dA[p] = sum_k dz[(p + 1 - k) / ST] * w[k]   (terms with non-integer index absent)
@@ -359,6 +362,23 @@ __global__ __launch_bounds__(256, 2) void dwr_bwd_kernel(const spb_dw_args_t a, 
   const T* Rg = reinterpret_cast<const T*>(a.res);
   T* Y = reinterpret_cast<T*>(a.Y);
   const int eact = a.epi.act; const float eslope = a.epi.slope;
+  // HOIST (input-gradient-only instances): the loop-invariant coefficient vectors of the lane's 8 channels -- 9 tap weights, the three
+  // BN-backward coefficients of dz, scale / shift of the input-side BN -- live in registers for the whole kernel instead of being read
+  // back from LDS for every element (30 ds_read_b128 per element behind the ring's memory clobbers; the instance runs two waves per
+  // SIMD, 256 registers each: 112 more fit)
+  // (the weight-gradient-only instance of the side stream reads no tap weights: it keeps the 40 coefficient values; the fused instance,
+  // at 236-256 registers already, keeps nothing)
+  constexpr bool HOIST = SPB_DW_HOIST && DG && !WG;         // tap weights
+  constexpr bool HOISTP = SPB_DW_HOIST && !(DG && WG);      // BN-backward coefficients of dz, scale / shift of the input side
+  float wr[HOIST ? 72 : 1], pr[HOISTP ? 24 : 1], er[HOISTP ? 16 : 1];
+  if constexpr (HOIST) {
+#pragma unroll
+    for (int k = 0; k < 9; ++k) ld_lds8(cf + k * 8, wr + k * 8);
+  }
+  if constexpr (HOISTP) {
+    ld_lds8(cf + 72, pr); ld_lds8(cf + 80, pr + 8); ld_lds8(cf + 88, pr + 16);
+    ld_lds8(cf + 96, er); ld_lds8(cf + 104, er + 8);
+  }
   char* ring = rings + wave * RD * SLOT;
   const unsigned ring_lds = lds_addr(ring);
   const int wq = bq * 4 + wave, nwq = g.nb * 4;
@@ -399,14 +419,21 @@ __global__ __launch_bounds__(256, 2) void dwr_bwd_kernel(const spb_dw_args_t a, 
   };
   auto dzf = [&](const Raw8<T>& gr, const Raw8<T>& zr, bool ok, float o[8]) {
     float gf[8], zf[8], p0[8], p1[8], p2[8];
-    cvt8(gr, gf); cvt8(zr, zf); ld_lds8(cf + 72, p0); ld_lds8(cf + 80, p1); ld_lds8(cf + 88, p2);
+    cvt8(gr, gf); cvt8(zr, zf);
+    if constexpr (HOISTP) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { p0[j] = pr[j]; p1[j] = pr[HOISTP ? 8 + j : 0]; p2[j] = pr[HOISTP ? 16 + j : 0]; }
+    } else { ld_lds8(cf + 72, p0); ld_lds8(cf + 80, p1); ld_lds8(cf + 88, p2); }
 #pragma unroll
     for (int j = 0; j < 8; ++j) o[j] = ok ? gf[j] * p0[j] + zf[j] * p1[j] + p2[j] : 0.f;
   };
   // a[p] of the conv input from its raw z (WG), 0 for lanes/pixels that do not exist
   auto apf = [&](const float zf[8], bool ok, float o[8]) {
     float sc[8], sh[8];
-    ld_lds8(cf + 96, sc); ld_lds8(cf + 104, sh);
+    if constexpr (HOISTP) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { sc[j] = er[j]; sh[j] = er[HOISTP ? 8 + j : 0]; }
+    } else { ld_lds8(cf + 96, sc); ld_lds8(cf + 104, sh); }
 #pragma unroll
     for (int j = 0; j < 8; ++j) o[j] = ok ? act_fwd(zf[j] * sc[j] + sh[j], eact, eslope) : 0.f;
   };
@@ -416,7 +443,10 @@ __global__ __launch_bounds__(256, 2) void dwr_bwd_kernel(const spb_dw_args_t a, 
   auto fin = [&](float acc[8], const float zf[8], bool ok, size_t off) {
     if (EPI) {
       float sc[8], sh[8];
-      ld_lds8(cf + 96, sc); ld_lds8(cf + 104, sh);
+      if constexpr (HOISTP) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { sc[j] = er[j]; sh[j] = er[HOISTP ? 8 + j : 0]; }
+      } else { ld_lds8(cf + 96, sc); ld_lds8(cf + 104, sh); }
       if (Rg) {
         float rf[8];
         cvt8(ldraw<T>(Rg + off), rf);
@@ -466,8 +496,15 @@ __global__ __launch_bounds__(256, 2) void dwr_bwd_kernel(const spb_dw_args_t a, 
         {                                                                                  \
           if (WG) asm volatile("" ::: "memory"); /* one weight row in flight at a time */  \
           float w0[8], w1[8], w2[8];                                                       \
-          ld_lds8(cf + ((ky) * 3 + 0) * 8, w0); ld_lds8(cf + ((ky) * 3 + 1) * 8, w1);      \
-          ld_lds8(cf + ((ky) * 3 + 2) * 8, w2);                                            \
+          if constexpr (HOIST) {                                                           \
+            _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                \
+              w0[j] = wr[HOIST ? ((ky) * 3 + 0) * 8 + j : 0]; w1[j] = wr[HOIST ? ((ky) * 3 + 1) * 8 + j : 0]; \
+              w2[j] = wr[HOIST ? ((ky) * 3 + 2) * 8 + j : 0];                              \
+            }                                                                              \
+          } else {                                                                         \
+            ld_lds8(cf + ((ky) * 3 + 0) * 8, w0); ld_lds8(cf + ((ky) * 3 + 1) * 8, w1);    \
+            ld_lds8(cf + ((ky) * 3 + 2) * 8, w2);                                          \
+          }                                                                                \
           _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                  \
             const float vr = from_right(DR[j]), vl = from_left(DR[j]);                     \
             if (DG) acc[j] += vr * w0[j] + DR[j] * w1[j] + vl * w2[j];                     \
@@ -513,7 +550,9 @@ __global__ __launch_bounds__(256, 2) void dwr_bwd_kernel(const spb_dw_args_t a, 
 #define DWR_TAP(k, V)                                                                      \
         {                                                                                  \
           float w[8];                                                                      \
-          ld_lds8(cf + (k) * 8, w);                                                        \
+          if constexpr (HOIST) {                                                           \
+            _Pragma("unroll") for (int j = 0; j < 8; ++j) w[j] = wr[HOIST ? (k) * 8 + j : 0]; \
+          } else ld_lds8(cf + (k) * 8, w);                                                 \
           _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                  \
             const float v = (V);                                                           \
             if (DG) acc[j] += v * w[j];                                                    \
