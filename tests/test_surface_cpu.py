@@ -234,3 +234,39 @@ def test_shard_slices_tile_the_bucket():
                 assert a == pos and a <= b <= hi and (b - a) <= per
                 pos = b
             assert pos == hi and len(pers) == 1
+
+
+def test_ctypes_mirrors_have_the_layout_of_the_header(tmp_path):
+    """speedplusbaseline_amd/_lib.py restates every argument struct of include/spb_hip.h as a ctypes.Structure (the Python surface calls the
+    C-ABI through them).  A field added on one side only would shift everything behind it silently: compile the header with gcc and compare
+    sizeof and the offset of EVERY field, by name."""
+    import ctypes as C
+    import subprocess
+    from speedplusbaseline_amd import _lib as L
+    pairs = {"BNRef": "spb_bnref_t", "GemmArgs": "spb_gemm_args_t", "RedJob": "spb_red_job_t", "WgradArgs": "spb_wgrad_args_t",
+             "PwBwdArgs": "spb_pwbwd_args_t", "AmpSegs": "spb_amp_segs_t", "GconvArgs": "spb_gconv_args_t", "DwArgs": "spb_dw_args_t",
+             "BnApplyArgs": "spb_bnapply_args_t", "BnBwdArgs": "spb_bnbwd_args_t", "HeadArgs": "spb_head_args_t",
+             "HeadBwdArgs": "spb_head_bwd_args_t", "BnUpdEntry": "spb_bnupd_entry_t", "PrepEntry": "spb_prep_entry_t",
+             "OptimArgs": "spb_optim_args_t", "SpnConvArgs": "spb_spn_conv_args_t", "SpnPackJob": "spb_spn_pack_job_t",
+             "PreprocArgs": "spb_preproc_args_t", "FcEpiArgs": "spb_fc_epi_args_t", "ActInfo": "spb_act_info_t",
+             "TensorInfo": "spb_tensor_info_t"}
+    mirrored = {n for n in dir(L) if isinstance(getattr(L, n), type) and issubclass(getattr(L, n), C.Structure) and getattr(L, n) is not C.Structure}
+    assert mirrored == set(pairs), mirrored ^ set(pairs)          # a new mirror must be added to this test
+    src = ['#include <stdio.h>', '#include <stddef.h>', '#include "spb_hip.h"', 'int main(void) {']
+    for py, c in pairs.items():
+        src.append('printf("%s sizeof %%zu\\n", sizeof(%s));' % (py, c))
+        for field in getattr(L, py)._fields_:
+            src.append('printf("%s %s %%zu\\n", offsetof(%s, %s));' % (py, field[0], c, field[0]))
+    src.append('return 0; }')
+    (tmp_path / "abi.c").write_text("\n".join(src))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run(["gcc", "-I", os.path.join(root, "include"), str(tmp_path / "abi.c"), "-o", str(tmp_path / "abi")],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[:2000]                      # also: the header is plain C, and every mirrored field exists in it by name
+    out = subprocess.run([str(tmp_path / "abi")], capture_output=True, text=True, check=True).stdout.splitlines()
+    assert len(out) > 300
+    for line in out:
+        py, name, val = line.split()
+        cls = getattr(L, py)
+        want = C.sizeof(cls) if name == "sizeof" else getattr(cls, name).offset
+        assert int(val) == want, (py, name, int(val), want)
