@@ -77,6 +77,10 @@ typedef struct spb_gemm_args {
   void* Ymat;
 } spb_gemm_args_t;
 int spb_pwconv_gemm(int dtype, const spb_gemm_args_t* args, spb_stream_t stream);
+/* Y == NULL with epi_mode 1 (16-bit storage, K <= 32, N in {48, 96, 144, 192}): STATISTICS ONLY -- the per-channel sums of the f32 product
+ * are accumulated into osums and the product is not stored.  What is left of an expand convolution whose output the depthwise kernels
+ * recompute (spb_dw_args_t::Xe).  Ymat (optional with pro_mode 1, required with pro_mode 3) receives the convolution's operand
+ * round16(act(bn(A))) [M,K] (pro_mode 3: the residual join): the tensor those kernels take as Xe with an identity `xe`. */
 
 /* dW[N,K] += sum_m dz[m,n] * a[m,k];  dz = bn_backward(G, Zn) (pro_dz), a = act(bn(X)) (pro_a).  dW is f32. */
 /* Weight-gradient partials.  A kernel that splits its reduction (the rows of the batch) over workgroups either adds every
@@ -110,7 +114,8 @@ int spb_pwconv_wgrad(int dtype, const spb_wgrad_args_t* args, spb_stream_t strea
  * InvertedResidual (call site park2019.py:107-108). */
 typedef struct {
   const void* G;      /* [M,N] g of the conv output (dL/d(bn out) * act') */
-  const void* Zn;     /* [M,N] raw conv output z */
+  const void* Zn;     /* [M,N] raw conv output z; may be NULL when K <= 32 (it is then recomputed from X, never read: the expand
+                         convolutions whose output does not exist in memory, spb_dw_args_t::Xe) */
   const void* Wt;     /* [K,N] transposed weights in the compute dtype */
   const void* X;      /* [M,K] conv input as stored: raw z of its producer, or a materialised tensor */
   const void* Zout;   /* [M,K] raw z of the input-side BN'd tensor (== X when the input is not materialised) */
@@ -155,6 +160,18 @@ typedef struct spb_dw_args {
    * plan hands its weight gradients to a side stream this way).  NULL: nothing is stored. */
   unsigned* entry_flag;
   unsigned entry_val;
+  /* Expand recompute (round 6).  Xe != NULL: the depthwise layer's INPUT tensor does not exist in memory.  It is the raw output of the
+   * 1x1 expand convolution in front of this layer (torchvision InvertedResidual conv[0] -> conv[1], park2019.py:107-108) and every
+   * kernel rebuilds the values it needs on the matrix cores from that convolution's own input:
+   *     z_in[p][c] = sum_k We[c][k] * xe[p][k]   (f32 accumulation, never rounded),   xe = round16(act(bn_xe(Xe)))
+   * so the 6x-expanded 96 / 144-channel tensors of the 112x112 / 56x56 maps are neither written nor read.  Which BatchNorm / activation
+   * then sits ON z_in is named exactly as without Xe: `pro` (forward), `epi` (input gradient: mask and sum g*xhat), `pro_in` (weight
+   * gradient); X (forward), Zout (input gradient) and Xin (weight gradient) are ignored.  Its batch sums come from
+   * spb_pwconv_gemm(Y = NULL) on the same operands.  16-bit storage, H and W >= 28, Ce in {8, 16, 24, 32}; SPB_E_UNSUPPORTED otherwise. */
+  const void* Xe;     /* [B,H,W,Ce] input of the expand convolution: raw z of its producer or a materialised tensor */
+  const void* We;     /* [C][Ce] expand weights in the compute dtype, Ce contiguous */
+  spb_bnref_t xe;     /* BatchNorm (+ activation) turning Xe into the expand convolution's operand; gamma == NULL: identity */
+  int Ce;
 } spb_dw_args_t;
 int spb_dwconv_fwd(int dtype, const spb_dw_args_t* args, spb_stream_t stream);
 /* dgrad with args->dW != NULL also accumulates the weight gradient in the same pass (one read of g, z and the input
@@ -410,6 +427,12 @@ int spb_krn_ctx_stats(spb_krn_ctx_t* c, float** ptr, long long* n_floats);
 typedef struct { long long z_off, g_off; int H, W, C, bn_index; } spb_act_info_t;
 int spb_krn_num_acts(const spb_krn_t* m);
 int spb_krn_ctx_act_info(const spb_krn_ctx_t* c, int a, spb_act_info_t* out);
+/* Round 6: the expanded tensors of inverted-residual blocks 2-4 (16 -> 96 at 112x112, 24 -> 144 at 56x56) are VIRTUAL in 16-bit mode:
+ * only their batch sums exist, every consumer recomputes the values (spb_dw_args_t::Xe).  spb_krn_ctx_virtual(c, a) = 1 for such a
+ * tensor; spb_krn_ctx_materialize writes z of all of them into their workspace slots (z_off above) from the last forward pass's
+ * state, rounded to the storage type, for tests that want to look at them.  Their g (g_off) is a real tensor. */
+int spb_krn_ctx_virtual(const spb_krn_ctx_t* c, int a);
+int spb_krn_ctx_materialize(spb_krn_ctx_t* c, spb_stream_t stream);
 
 /* refresh compute-dtype weight copies (W, W^T, permuted head) from the f32 parameters */
 int spb_krn_prepare_weights(spb_krn_t* m, spb_stream_t stream);

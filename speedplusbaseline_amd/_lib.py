@@ -66,7 +66,7 @@ class DwArgs(C.Structure):
     _fields_ = [("X", vp), ("X2", vp), ("Xin", vp), ("Wd", vp), ("Y", vp), ("dW", vp), ("res", vp), ("Zout", vp),
                 ("osums", vp), ("pro", BNRef), ("pro_in", BNRef), ("epi", BNRef), ("B", i32), ("H", i32), ("W", i32),
                 ("C", i32), ("stride", i32), ("epi_mode", i32), ("oR", i32), ("part", vp), ("part_cap", i64), ("job_out", vp),
-                ("entry_flag", vp), ("entry_val", C.c_uint32)]
+                ("entry_flag", vp), ("entry_val", C.c_uint32), ("Xe", vp), ("We", vp), ("xe", BNRef), ("Ce", i32)]
 
 
 class BnApplyArgs(C.Structure):
@@ -250,6 +250,8 @@ SYMBOLS = {
     "spb_version": (C.c_char_p, []),
     "spb_krn_num_acts": (i32, [vp]),
     "spb_krn_ctx_act_info": (i32, [vp, i32, C.POINTER(ActInfo)]),
+    "spb_krn_ctx_virtual": (i32, [vp, i32]),
+    "spb_krn_ctx_materialize": (i32, [vp, vp]),
     "spb_det_available": (i32, []),
     "spb_det_register": (i32, [vp, i64, vp]),
     "spb_det_unregister": (i32, [vp]),
@@ -289,6 +291,7 @@ TUNING_SYMBOLS = {
     "spb_debug_set_dw_tile": (i32, [i32, i32]),
     "spb_debug_set_gemm_rs": (i32, [i32, i32]),
     "spb_debug_set_gemm_st": (i32, [i32, i32, i32]),
+    "spb_debug_set_fuse_expand": (i32, [i32]),
     "spb_debug_set_gemm_wg_cap": (i32, [i32]),
     "spb_debug_set_bn_bwd_prep_rows": (i32, [i32]),
     "spb_debug_set_stem_mfma": (i32, [i32]),

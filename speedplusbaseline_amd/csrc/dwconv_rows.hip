@@ -315,10 +315,17 @@ __global__ __launch_bounds__(256, 2) void dwr_fwd_kernel(const spb_dw_args_t a, 
 // DG = false: weight gradient only (no input-gradient taps, nothing stored): the instance the KRN plan runs on its side stream
 // for the 14x14 / 7x7 maps, where the fused kernel is bound by VALU issue (18 FMAs per element instead of 9) on the launch
 // stream's critical path while most of the chip idles.
-template <typename T, int ST, bool WG, bool EPI, bool DG = true>
+// XP (round 6, spb_dw_args_t::Xe; 16-bit storage): the conv-input tensor z_in is the output of a 1x1 expand convolution that is not in
+// memory.  A wave's four DPP rows are the four channel octets of the SAME 16 pixels -- exactly the C layout of a 16x16x32 MFMA whose B
+// operand is "pixel l16, input channels 8 row .. 8 row + 7" and whose A rows are the quad's 32 expand-weight rows, permuted as in the fused
+// pointwise backward (pw_bwd_fused.hip, RZ): two MFMAs hand every lane the 8 consecutive channels of its pixel as exact f32.  So the ring
+// carries the 16 / 24-channel expand input instead of z_in (one 16-byte vector per lane, as before -- a sixth of the HBM bytes, shared by
+// all quads), and the activation mask / sum g*xhat (EPI) and the weight gradient's a = act(bn(z_in)) (WG) work on the recomputed value.
+template <typename T, int ST, bool WG, bool EPI, bool DG = true, bool XP = false>
 __global__ __launch_bounds__(256, 2) void dwr_bwd_kernel(const spb_dw_args_t a, const Geo g) {
   spb_publish_entry(a.entry_flag, a.entry_val);
   static_assert(DG || (WG && !EPI), "the weight-gradient-only instance has no epilogue");
+  static_assert(!XP || ((WG || EPI) && sizeof(T) == 2), "expand recompute: 16-bit storage, and only where the conv input is needed");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NP = ST == 1 ? 14 : 15;
   constexpr int LH = ST == 1 ? 1 : 0;                    // stride 2 only needs the right neighbour
@@ -327,7 +334,8 @@ __global__ __launch_bounds__(256, 2) void dwr_bwd_kernel(const spb_dw_args_t a, 
   constexpr int RD = RingDepth<T, NS>::v;
   constexpr int SLOT = NS * (sizeof(T) == 2 ? 1 : 2) * 1024;
   float* cfs = reinterpret_cast<float*>(smem);
-  char* rings = smem + 4 * CFN * sizeof(float);
+  float* xtab = cfs + 4 * CFN;                           // XP: scale | shift of the Ce <= 32 expand-input channels
+  char* rings = smem + 4 * CFN * sizeof(float) + (XP ? 64 * sizeof(float) : 0);
   const int lane = threadIdx.x & 63, l16 = lane & 15, row = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int C = a.C, H = a.H, W = a.W, ncg = C >> 3;
@@ -355,10 +363,32 @@ __global__ __launch_bounds__(256, 2) void dwr_bwd_kernel(const spb_dw_args_t a, 
     cf[72 + l16] = p0; cf[80 + l16] = p1; cf[88 + l16] = p2;
     cf[96 + l16] = sc; cf[104 + l16] = sh; cf[112 + l16] = mu; cf[120 + l16] = is;
   }
+  const int CX = XP ? a.Ce : C;                          // channels of the tensor behind Zo
+  const bool xbn = XP && a.xe.gamma != nullptr;          // (uniform)
+  const float xhi = act_hi(a.xe.act), xns = act_ns(a.xe.act, a.xe.slope);
+  const bool xact = a.xe.act != SPB_ACT_NONE;
+  uint4 wz0 = make_uint4(0, 0, 0, 0), wz1 = make_uint4(0, 0, 0, 0);
+  const int xk0 = 8 * row < CX ? 8 * row : CX - 8;       // this lane's 8 input channels (clamped: the weight fragment is zero past Ce)
+  if constexpr (XP) {
+    // A operands: fragment t, row l16  <->  expand-weight row (= channel of z_in) quad * 32 + (l16 >> 2) * 8 + t * 4 + (l16 & 3), input channels
+    // 8 row .. 8 row + 7.  The C layout then gives lane (l16, row) channels quad * 32 + 8 row + t * 4 + i: with t = 0, 1 its own octet.
+    const bf16_t* We = reinterpret_cast<const bf16_t*>(a.We);
+    const int n0 = quad * 32 + (l16 >> 2) * 8 + (l16 & 3), n1 = n0 + 4;
+    wz0 = *reinterpret_cast<const uint4*>(We + (size_t)(n0 < C ? n0 : C - 1) * CX + xk0);
+    wz1 = *reinterpret_cast<const uint4*>(We + (size_t)(n1 < C ? n1 : C - 1) * CX + xk0);
+    if (n0 >= C || 8 * row >= CX) wz0 = make_uint4(0, 0, 0, 0);
+    if (n1 >= C || 8 * row >= CX) wz1 = make_uint4(0, 0, 0, 0);
+    if (wave == 1 && lane < 32) {                        // (wave 0 builds the coefficient rows above)
+      float s_ = 1.f, h_ = 0.f;
+      if (xbn) bn_fwd_coef(a.xe, lane < CX ? lane : CX - 1, s_, h_);
+      xtab[lane] = s_; xtab[32 + lane] = h_;
+    }
+  }
   __syncthreads();
   const T* G = reinterpret_cast<const T*>(a.X);
   const T* Z = reinterpret_cast<const T*>(a.X2);
-  const T* Zo = reinterpret_cast<const T*>(a.Zout);
+  const T* Zo = reinterpret_cast<const T*>(XP ? a.Xe : a.Zout);
+  const int zc0 = XP ? xk0 : c0;                         // channel offset of this lane's vector in the tensor behind Zo
   const T* Rg = reinterpret_cast<const T*>(a.res);
   T* Y = reinterpret_cast<T*>(a.Y);
   const int eact = a.epi.act; const float eslope = a.epi.slope;
@@ -402,7 +432,7 @@ __global__ __launch_bounds__(256, 2) void dwr_bwd_kernel(const spb_dw_args_t a, 
       const int y = c.sy * g.R - 1 + c.i;
       const size_t go = ((size_t)(c.b * OH + clampi(y, 0, OH - 1)) * OW + qc) * C + c0;
       dma_vec<T>(G + go, sl, 0); dma_vec<T>(Z + go, sl, 1);
-      if (IN) dma_vec<T>(Zo + ((size_t)(c.b * H + clampi(y - 1, 0, H - 1)) * W + qc) * C + c0, sl, 2);
+      if (IN) dma_vec<T>(Zo + ((size_t)(c.b * H + clampi(y - 1, 0, H - 1)) * W + qc) * CX + zc0, sl, 2);
     } else {
       const int y = c.sy * g.R + c.i, r = y - 1;
       const size_t go = ((size_t)(c.b * OH + clampi(y, 0, OH - 1)) * OW + qc) * C + c0;
@@ -410,10 +440,10 @@ __global__ __launch_bounds__(256, 2) void dwr_bwd_kernel(const spb_dw_args_t a, 
       if (IN) {
         const int ya = clampi(2 * r, 0, H - 1), yb = clampi(2 * r + 1, 0, H - 1);
         const int xa = clampi(2 * q, 0, W - 1), xb = clampi(2 * q + 1, 0, W - 1);
-        dma_vec<T>(Zo + ((size_t)(c.b * H + ya) * W + xa) * C + c0, sl, 2);
-        dma_vec<T>(Zo + ((size_t)(c.b * H + ya) * W + xb) * C + c0, sl, 3);
-        dma_vec<T>(Zo + ((size_t)(c.b * H + yb) * W + xa) * C + c0, sl, 4);
-        dma_vec<T>(Zo + ((size_t)(c.b * H + yb) * W + xb) * C + c0, sl, 5);
+        dma_vec<T>(Zo + ((size_t)(c.b * H + ya) * W + xa) * CX + zc0, sl, 2);
+        dma_vec<T>(Zo + ((size_t)(c.b * H + ya) * W + xb) * CX + zc0, sl, 3);
+        dma_vec<T>(Zo + ((size_t)(c.b * H + yb) * W + xa) * CX + zc0, sl, 4);
+        dma_vec<T>(Zo + ((size_t)(c.b * H + yb) * W + xb) * CX + zc0, sl, 5);
       }
     }
   };
@@ -426,6 +456,31 @@ __global__ __launch_bounds__(256, 2) void dwr_bwd_kernel(const spb_dw_args_t a, 
     } else { ld_lds8(cf + 72, p0); ld_lds8(cf + 80, p1); ld_lds8(cf + 88, p2); }
 #pragma unroll
     for (int j = 0; j < 8; ++j) o[j] = ok ? gf[j] * p0[j] + zf[j] * p1[j] + p2[j] : 0.f;
+  };
+  // z_in of this lane's pixel and channel octet: the ring's vector as it is, or (XP) W x on the matrix cores.  Called from wave-uniform
+  // control flow only (all 64 lanes feed the matrix core).
+  auto zin = [&](const char* slot, int piece, float zf[8]) __attribute__((always_inline)) {
+    if constexpr (XP) {
+      Raw8<bf16_t> xr;
+      xr.u = *reinterpret_cast<const uint4*>(slot + (piece << 10) + lane * 16);
+      if (xbn) {                                         // the expand convolution's operand: round16(act(bn(x)))
+        float xv[8], xs[8], xh[8];
+        cvt8(xr, xv);
+        ld_lds8(xtab + xk0, xs); ld_lds8(xtab + 32 + xk0, xh);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) xv[j] = xv[j] * xs[j] + xh[j];
+        if (xact) {                                        // (uniform; MobileNetV2's block inputs are linear)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) xv[j] = __builtin_amdgcn_fmed3f(xv[j], 0.f, xhi) + xns * fminf(xv[j], 0.f);
+        }
+        xr.u.x = pack_bf16x2(xv[0], xv[1]); xr.u.y = pack_bf16x2(xv[2], xv[3]); xr.u.z = pack_bf16x2(xv[4], xv[5]); xr.u.w = pack_bf16x2(xv[6], xv[7]);
+      }
+      const bf16x8_t xb = __builtin_bit_cast(bf16x8_t, xr.u);
+      const f32x4_t z0 = SPB_MFMA16(__builtin_bit_cast(bf16x8_t, wz0), xb, ((f32x4_t){0.f, 0.f, 0.f, 0.f}));
+      const f32x4_t z1 = SPB_MFMA16(__builtin_bit_cast(bf16x8_t, wz1), xb, ((f32x4_t){0.f, 0.f, 0.f, 0.f}));
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { zf[i] = z0[i]; zf[4 + i] = z1[i]; }
+    } else cvt8(ring_vec<T>(slot, piece, lane), zf);
   };
   // a[p] of the conv input from its raw z (WG), 0 for lanes/pixels that do not exist
   auto apf = [&](const float zf[8], bool ok, float o[8]) {
@@ -487,7 +542,7 @@ __global__ __launch_bounds__(256, 2) void dwr_bwd_kernel(const spb_dw_args_t a, 
         const int r = y - 1;                     // input row produced now
         const bool ok = lane_prod && qok && r < H;
         float zf[8], acc[8], ap[8];
-        if (IN) cvt8(ring_vec<T>(slot, 2, lane), zf);
+        if (IN) zin(slot, 2, zf);
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[j] = 0.f;
         if (WG) apf(zf, ok, ap);
@@ -541,7 +596,7 @@ __global__ __launch_bounds__(256, 2) void dwr_bwd_kernel(const spb_dw_args_t a, 
           if (WG || EPI) asm volatile("" ::: "memory");                                    \
           const bool ok = (OKP);                                                           \
           float zf[8], ap[8], acc[8];                                                      \
-          if (IN) cvt8(ring_vec<T>(slot, 2 + (PI), lane), zf);                             \
+          if (IN) zin(slot, 2 + (PI), zf);                                                 \
           if (WG) apf(zf, ok, ap);                                                         \
           _Pragma("unroll") for (int j = 0; j < 8; ++j) acc[j] = 0.f;                      \
           BODY                                                                             \
@@ -685,17 +740,20 @@ int spb_dwr_wgrad(int dtype, const spb_dw_args_t* a, hipStream_t s) {
   const int es = dtype == SPB_BF16 ? 1 : 2;
   const int ns = 2 + (st == 1 ? 1 : 4);
   const int rd = ring_depth_host(ns, es);
-  size_t lds = 4 * CFN * sizeof(float) + (size_t)4 * rd * ns * es * 1024;
-  const size_t red = (size_t)16 * 72 * sizeof(float) + 4 * CFN * sizeof(float);
+  const bool xp = a->Xe != nullptr;
+  if (xp && dtype != SPB_BF16) return SPB_E_UNSUPPORTED;
+  size_t lds = 4 * CFN * sizeof(float) + (xp ? 256 : 0) + (size_t)4 * rd * ns * es * 1024;
+  const size_t red = (size_t)16 * 72 * sizeof(float) + 4 * CFN * sizeof(float) + (xp ? 256 : 0);
   if (lds < red) lds = red;
-#define W_(T_, ST_)                                                                                        \
-  {                                                                                                        \
-    static bool once = false;                                                                              \
-    if (!once) { allow_lds(dwr_bwd_kernel<T_, ST_, true, false, false>, 160 * 1024); once = true; }        \
-    hipLaunchKernelGGL((dwr_bwd_kernel<T_, ST_, true, false, false>), grid, dim3(256), lds, s, *a, g);     \
+#define W_(T_, ST_, XP_)                                                                                        \
+  {                                                                                                             \
+    static bool once = false;                                                                                   \
+    if (!once) { allow_lds(dwr_bwd_kernel<T_, ST_, true, false, false, XP_>, 160 * 1024); once = true; }        \
+    hipLaunchKernelGGL((dwr_bwd_kernel<T_, ST_, true, false, false, XP_>), grid, dim3(256), lds, s, *a, g);     \
   }
-  if (dtype == SPB_BF16) { if (st == 1) W_(bf16_t, 1) else W_(bf16_t, 2) }
-  else { if (st == 1) W_(float, 1) else W_(float, 2) }
+  if (xp) { if (st == 1) W_(bf16_t, 1, true) else W_(bf16_t, 2, true) }
+  else if (dtype == SPB_BF16) { if (st == 1) W_(bf16_t, 1, false) else W_(bf16_t, 2, false) }
+  else { if (st == 1) W_(float, 1, false) else W_(float, 2, false) }
 #undef W_
   return 0;
 }
@@ -707,12 +765,26 @@ int spb_dwr_bwd(int dtype, const spb_dw_args_t* a, hipStream_t s) {
   const int nquads = ((a->C >> 3) + 3) / 4;
   const dim3 grid((unsigned)(nquads * g.nb));
   const bool wg = a->dW != nullptr, epi = a->epi_mode == 2;
+  const bool xp = a->Xe != nullptr && (wg || epi);      // (a plain input gradient never looks at the conv input)
+  if (xp && dtype != SPB_BF16) return SPB_E_UNSUPPORTED;
   const int es = dtype == SPB_BF16 ? 1 : 2;
   const int ns = 2 + ((wg || epi) ? (st == 1 ? 1 : 4) : 0);
   const int rd = ring_depth_host(ns, es);
-  size_t lds = 4 * CFN * sizeof(float) + (size_t)4 * rd * ns * es * 1024;
-  const size_t red = (size_t)16 * 72 * sizeof(float) + 4 * CFN * sizeof(float);   // reduction scratch reuses the rings
+  size_t lds = 4 * CFN * sizeof(float) + (xp ? 256 : 0) + (size_t)4 * rd * ns * es * 1024;
+  const size_t red = (size_t)16 * 72 * sizeof(float) + 4 * CFN * sizeof(float) + (xp ? 256 : 0);   // reduction scratch reuses the rings
   if (lds < red) lds = red;
+  if (xp) {
+#define X_(ST_, WG_, EPI_)                                                                                          \
+  {                                                                                                                 \
+    static bool once = false;                                                                                       \
+    if (!once) { allow_lds(dwr_bwd_kernel<bf16_t, ST_, WG_, EPI_, true, true>, 160 * 1024); once = true; }          \
+    hipLaunchKernelGGL((dwr_bwd_kernel<bf16_t, ST_, WG_, EPI_, true, true>), grid, dim3(256), lds, s, *a, g);       \
+  }
+    if (st == 1) { if (wg) { if (epi) X_(1, true, true) else X_(1, true, false) } else X_(1, false, true) }
+    else { if (wg) { if (epi) X_(2, true, true) else X_(2, true, false) } else X_(2, false, true) }
+#undef X_
+    return 0;
+  }
 #define L_(T_, ST_, WG_, EPI_)                                                                   \
   {                                                                                              \
     static bool once = false;                                                                    \
@@ -743,18 +815,28 @@ static int g_dw_mode = 1;   // 1: plane kernels where they apply (default); 0: r
 extern "C" int spb_debug_set_dw_mode(int mode) { g_dw_mode = mode; return 0; }
 #endif
 
-static int dw_check(const spb_dw_args_t* a) {
-  if (!a || !a->X || !a->Wd) return SPB_E_ARG;
+static int dw_check(const spb_dw_args_t* a, bool fwd = false) {
+  if (!a || !a->Wd) return SPB_E_ARG;
+  if (!a->X && !(fwd && a->Xe)) return SPB_E_ARG;
   if (a->B <= 0 || a->H <= 0 || a->W <= 0 || a->C <= 0 || (a->C & 7)) return SPB_E_SHAPE;
   if (a->stride != 1 && a->stride != 2) return SPB_E_SHAPE;
+  if (a->Xe) {   // expand recompute (spb_dw_args_t::Xe)
+    if (!a->We) return SPB_E_ARG;
+    if (a->Ce < 8 || a->Ce > 32 || (a->Ce & 7)) return SPB_E_SHAPE;
+  }
   return 0;
 }
 
 extern "C" int spb_dwconv_fwd(int dtype, const spb_dw_args_t* a, spb_stream_t stream) {
-  int e = dw_check(a);
+  int e = dw_check(a, true);
   if (e) return e;
   if (!a->Y || (a->epi_mode == 1 && (!a->osums || a->oR < 1))) return SPB_E_ARG;
   if (dtype != SPB_BF16 && dtype != SPB_F32) return SPB_E_ARG;
+  if (a->Xe) {   // the input tensor does not exist: the tile kernel's expand-recompute instance or nothing
+    if (spb_dwt_fwd(dtype, a, (hipStream_t)stream) == SPB_E_UNSUPPORTED) return SPB_E_UNSUPPORTED;
+    SPB_CHECK_LAUNCH();
+    return 0;
+  }
   if (spb_dwt_fwd(dtype, a, (hipStream_t)stream) == SPB_E_UNSUPPORTED) {
     if (g_dw_mode != 1 || spb_dwp_fwd(dtype, a, (hipStream_t)stream) == SPB_E_UNSUPPORTED)
       spb_dwr_fwd(dtype, a, (hipStream_t)stream);
@@ -769,11 +851,16 @@ extern "C" int spb_dwconv_dgrad(int dtype, const spb_dw_args_t* a, spb_stream_t 
   int e = dw_check(a);
   if (e) return e;
   if (!a->Y) return SPB_E_ARG;
-  if (a->epi_mode == 2 && (!a->osums || a->oR < 1 || !a->Zout)) return SPB_E_ARG;
-  if (a->dW != nullptr && !a->Zout) return SPB_E_ARG;
+  if (a->epi_mode == 2 && (!a->osums || a->oR < 1 || (!a->Zout && !a->Xe))) return SPB_E_ARG;
+  if (a->dW != nullptr && !a->Zout && !a->Xe) return SPB_E_ARG;
   if (dtype != SPB_BF16 && dtype != SPB_F32) return SPB_E_ARG;
   spb_dw_args_t k = *a;
   if (!k.X2) k.X2 = k.X;  // no BN behind the convolution: p1 == 0, the kernel still reads a (finite) second operand
+  if (k.Xe && (k.epi_mode == 2 || k.dW)) {   // the conv input is recomputed: the row-unit kernel's expand-recompute instances
+    if (spb_dwr_bwd(dtype, &k, (hipStream_t)stream) == SPB_E_UNSUPPORTED) return SPB_E_UNSUPPORTED;
+    SPB_CHECK_LAUNCH();
+    return 0;
+  }
   if (spb_dwt_dgrad(dtype, &k, (hipStream_t)stream) == SPB_E_UNSUPPORTED) {
     if (g_dw_mode != 1 || spb_dwp_bwd(dtype, &k, (hipStream_t)stream) == SPB_E_UNSUPPORTED)
       spb_dwr_bwd(dtype, &k, (hipStream_t)stream);
@@ -786,12 +873,12 @@ extern "C" int spb_dwconv_dgrad(int dtype, const spb_dw_args_t* a, spb_stream_t 
 extern "C" int spb_dwconv_wgrad(int dtype, const spb_dw_args_t* a, spb_stream_t stream) {
   int e = dw_check(a);
   if (e) return e;
-  if (!a->dW || !a->Xin) return SPB_E_ARG;
+  if (!a->dW || (!a->Xin && !a->Xe)) return SPB_E_ARG;
   if (dtype != SPB_BF16 && dtype != SPB_F32) return SPB_E_ARG;
   spb_dw_args_t k = *a;
   k.Zout = a->Xin; k.epi = a->pro_in; k.Y = nullptr; k.epi_mode = 0; k.res = nullptr; k.entry_flag = nullptr;
   if (!k.X2) k.X2 = k.X;
-  spb_dwr_wgrad(dtype, &k, (hipStream_t)stream);
+  if (spb_dwr_wgrad(dtype, &k, (hipStream_t)stream) == SPB_E_UNSUPPORTED) return SPB_E_UNSUPPORTED;
   SPB_CHECK_LAUNCH();
   return 0;
 }

@@ -65,7 +65,14 @@ struct TileGeo { int nty, ntx, ntiles, nchunks, nsp; };
 // Everything inside the tile loop is straight-line code: masks are integer ANDs, every wave stages GPW groups (the last ones
 // may repeat a group -- identical values to the same LDS address), loads sit on clamped addresses.  (The first version let the
 // compiler turn `ok ? f(x) : 0` into one basic block per element and sank the last group's load into its conditional block.)
-template <int ST, bool CLAMP>
+//
+// XP (round 6, spb_dw_args_t::Xe): the input tensor is the output of a 1x1 expand convolution that is NOT in memory.  The transposer of
+// phase 1 already IS a matrix product -- raw NHWC vector x selector -- so the expand convolution takes its place: the A operand becomes
+// the (BatchNorm'd, re-rounded) 8 input channels of the pixel, the selector becomes this lane's 16 expand-weight rows, and the matrix core
+// returns the expanded activation z = W x as exact f32 in the same "four consecutive pixels of one channel" layout.  Same instruction
+// count as the transposer; the staged bytes per pixel drop from 2 C to 2 Ce (C = 6 Ce), shared by the C / 32 workgroups of a tile
+// (one XCD: L2 hits), and the 96 / 144-channel tensor of the 112x112 / 56x56 maps is never written or read.
+template <int ST, bool CLAMP, bool XP = false>
 __global__ __launch_bounds__(256, ST == 1 ? 4 : 2) void dwt_fwd_kernel(const spb_dw_args_t a, const TileGeo tg) {
   typedef TG<ST> G;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -77,12 +84,42 @@ __global__ __launch_bounds__(256, ST == 1 ? 4 : 2) void dwt_fwd_kernel(const spb
   const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
   const int chunk = idx % tg.nchunks, sp = (idx / tg.nchunks) * 8 + xcd;
   const int c0 = chunk * CHK;
-  const bf16_t* X = reinterpret_cast<const bf16_t*>(a.X);
+  const bf16_t* X = reinterpret_cast<const bf16_t*>(XP ? a.Xe : a.X);
   bf16_t* Y = reinterpret_cast<bf16_t*>(a.Y);
   const float ahi = act_hi(a.pro.act), ans = act_ns(a.pro.act, a.pro.slope);
+  const int CX = XP ? a.Ce : C;                              // channels of the staged tensor
 
   // ---- per-lane constants
-  const bf16x8_t sel0 = selector(lane, 0), sel1 = selector(lane, 1);
+  // B operand of the staging product.  Plain: the 0/1 selector.  XP: rows c0 + 16 h + r of the expand weights, input channels 8 q .. 8 q + 7
+  // (zero past Ce and past C: whatever the clamped A lanes hold there is multiplied away)
+  const bf16x8_t sel0 = selector(lane, 0), sel1 = selector(lane, 1);   // (XP: still the OUTPUT transposer of phase 3)
+  uint4* wl = reinterpret_cast<uint4*>(smem + CHK * G::CHS + 256);   // XP: [2][64] staging B fragments (the same for all four waves; as 8 more
+                                                                     // registers per lane the 128-register stride-1 instance spilled)
+  // XP: scale | shift of the Ce <= 32 input channels, behind the tile planes (read back per staging group: as 16 registers per lane the
+  // 128-register stride-1 instance spilled)
+  float* xt = reinterpret_cast<float*>(smem + CHK * G::CHS);
+  const bool xbn = XP && a.xe.gamma != nullptr;              // (uniform)
+  const float xhi = act_hi(a.xe.act), xns = act_ns(a.xe.act, a.xe.slope);
+  const bool xact = a.xe.act != SPB_ACT_NONE;
+  if constexpr (XP) {
+    const bf16_t* We = reinterpret_cast<const bf16_t*>(a.We);
+    uint4 w[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int c = c0 + 16 * h + r, k = 8 * q;
+      w[h] = *reinterpret_cast<const uint4*>(We + (size_t)(c < C ? c : C - 1) * CX + (k < CX ? k : CX - 8));
+      if (c >= C || k >= CX) w[h] = make_uint4(0, 0, 0, 0);
+    }
+    if (wave == 0) { wl[lane] = w[0]; wl[64 + lane] = w[1]; }
+    // scale / shift of the input channels: built once per workgroup (one channel per thread: one memory round trip)
+    if (threadIdx.x < 32) {
+      float s_ = 1.f, h_ = 0.f;
+      if (xbn) bn_fwd_coef(a.xe, (int)threadIdx.x < CX ? (int)threadIdx.x : CX - 1, s_, h_);
+      xt[threadIdx.x] = s_; xt[32 + threadIdx.x] = h_;
+    }
+    __syncthreads();
+  }
+  const int xk0 = 8 * q < CX ? 8 * q : CX - 8;
   float sc[2], sh[2];      // staging: this lane's channels c0 + r and c0 + 16 + r
   if (a.pro.gamma != nullptr && !a.pro.moments) {   // (uniform) the sums of both channels requested together: one round trip, not two
     BNLoad bl[2];
@@ -139,15 +176,15 @@ __global__ __launch_bounds__(256, ST == 1 ? 4 : 2) void dwt_fwd_kernel(const spb
     t = t < tg.ntiles ? t : tg.ntiles - 1;                   // (past the end: a valid tile again, never consumed)
     const int tx = t % tg.ntx, ty = (t / tg.ntx) % tg.nty, b = t / (tg.ntx * tg.nty);
     const int yin0 = ST * ty * TH - 1, xin0 = ST * tx * TW - 2;
-    int cl = c0 + 8 * q; cl = cl > C - 8 ? C - 8 : cl;
-    const bf16_t* xb = X + (size_t)b * H * W * C + cl;
+    int cl = (XP ? 0 : c0) + 8 * q; cl = cl > CX - 8 ? CX - 8 : cl;
+    const bf16_t* xb = X + (size_t)b * H * W * CX + cl;
 #pragma unroll
     for (int i = 0; i < G::GPW; ++i) {
       int g = wave + 4 * i; g = g < G::GROUPS ? g : G::GROUPS - 1;
       const int slot = g * 16 + r;
       int y = yin0 + slot / G::ROWP, x = xin0 + slot % G::ROWP;
       y = y < 0 ? 0 : (y > H - 1 ? H - 1 : y); x = x < 0 ? 0 : (x > W - 1 ? W - 1 : x);
-      raw[i] = ldraw<bf16_t>(xb + (size_t)(y * W + x) * C);
+      raw[i] = ldraw<bf16_t>(xb + (size_t)(y * W + x) * CX);
     }
   };
   if (sp < tg.ntiles) request(sp);
@@ -162,7 +199,26 @@ __global__ __launch_bounds__(256, ST == 1 ? 4 : 2) void dwt_fwd_kernel(const spb
     for (int i = 0; i < G::GPW; ++i) {
       int g = wave + 4 * i; g = g < G::GROUPS ? g : G::GROUPS - 1;
       const int slot4 = g * 16 + 4 * q;                      // this lane's 4 result pixels: slots slot4 .. slot4+3, one tile row
-      const bf16x8_t av = __builtin_bit_cast(bf16x8_t, raw[i].u);
+      bf16x8_t av = __builtin_bit_cast(bf16x8_t, raw[i].u);
+      if constexpr (XP) {
+        if (xbn) {                                           // (uniform) the expand convolution's operand: round16(act(bn(x)))
+          float xv[8], xsc[8], xsh[8];
+          cvt8(raw[i], xv);
+          *reinterpret_cast<float4*>(xsc) = *reinterpret_cast<const float4*>(xt + xk0);
+          *reinterpret_cast<float4*>(xsc + 4) = *reinterpret_cast<const float4*>(xt + xk0 + 4);
+          *reinterpret_cast<float4*>(xsh) = *reinterpret_cast<const float4*>(xt + 32 + xk0);
+          *reinterpret_cast<float4*>(xsh + 4) = *reinterpret_cast<const float4*>(xt + 32 + xk0 + 4);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) xv[j] = xv[j] * xsc[j] + xsh[j];
+          if (xact) {                                        // (uniform; MobileNetV2's block inputs are linear)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) xv[j] = __builtin_amdgcn_fmed3f(xv[j], 0.f, xhi) + xns * fminf(xv[j], 0.f);
+          }
+          uint4 pk;
+          pk.x = pack_bf16x2(xv[0], xv[1]); pk.y = pack_bf16x2(xv[2], xv[3]); pk.z = pack_bf16x2(xv[4], xv[5]); pk.w = pack_bf16x2(xv[6], xv[7]);
+          av = __builtin_bit_cast(bf16x8_t, pk);
+        }
+      }
       int msk[4] = {-1, -1, -1, -1};
       if (border) {                                          // (uniform)
         const int y = yin0 + slot4 / G::ROWP, x = xin0 + slot4 % G::ROWP;
@@ -172,7 +228,7 @@ __global__ __launch_bounds__(256, ST == 1 ? 4 : 2) void dwt_fwd_kernel(const spb
       }
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
-        const f32x4_t z = SPB_MFMA16(av, h == 0 ? sel0 : sel1, ((f32x4_t){0.f, 0.f, 0.f, 0.f}));
+        const f32x4_t z = SPB_MFMA16(av, XP ? __builtin_bit_cast(bf16x8_t, wl[64 * h + lane]) : (h == 0 ? sel0 : sel1), ((f32x4_t){0.f, 0.f, 0.f, 0.f}));
         float v[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -522,13 +578,16 @@ extern "C" int spb_debug_set_dw_tile(int min_width, int workgroups) {
 
 // SPB_E_UNSUPPORTED: not covered (the caller keeps the row-unit / plane kernels)
 int spb_dwt_fwd(int dtype, const spb_dw_args_t* a, hipStream_t s) {
-  if (dtype != SPB_BF16 || a->W < g_dw_tile_min || a->H < g_dw_tile_min || (a->C & 7)) return SPB_E_UNSUPPORTED;
+  const bool xp = a->Xe != nullptr;
+  if (xp) {   // expand recompute: this kernel or nothing (the plain kernels would read a tensor that does not exist)
+    if (dtype != SPB_BF16 || a->W < 28 || a->H < 28 || (a->C & 7) || !a->We || a->Ce < 8 || a->Ce > 32 || (a->Ce & 7)) return SPB_E_UNSUPPORTED;
+  } else if (dtype != SPB_BF16 || a->W < g_dw_tile_min || a->H < g_dw_tile_min || (a->C & 7)) return SPB_E_UNSUPPORTED;
   const int st = a->stride;
   const int OH = (a->H - 1) / st + 1, OW = (a->W - 1) / st + 1;
   TileGeo tg;
   tg.nty = (OH + TH - 1) / TH; tg.ntx = (OW + TW - 1) / TW; tg.ntiles = a->B * tg.nty * tg.ntx;
   tg.nchunks = (a->C + CHK - 1) / CHK;
-  const size_t lds = (size_t)CHK * (st == 1 ? TG<1>::CHS : TG<2>::CHS);
+  const size_t lds = (size_t)CHK * (st == 1 ? TG<1>::CHS : TG<2>::CHS) + (xp ? 256 + 2048 : 0);
   const int per_cu = st == 1 ? 4 : 2;                          // resident workgroups per CU (registers: 100 / 172 per lane)
   int target = g_dw_tile_wgs > 0 ? g_dw_tile_wgs : 256 * per_cu;   // persistent: one dispatch round
   int per_xcd = target / 8 / tg.nchunks;                     // spatial walkers per XCD
@@ -538,14 +597,17 @@ int spb_dwt_fwd(int dtype, const spb_dw_args_t* a, hipStream_t s) {
   tg.nsp = per_xcd * 8;
   const dim3 grid((unsigned)(tg.nsp * tg.nchunks));
   const bool clamp = a->pro.act == SPB_ACT_RELU || a->pro.act == SPB_ACT_RELU6;
-#define DWT_(ST_, CL_)                                                                                                         \
+#define DWT_(ST_, CL_, XP_)                                                                                                    \
   {                                                                                                                            \
     static bool once = false;                                                                                                  \
-    if (!once) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dwt_fwd_kernel<ST_, CL_>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); once = true; } \
-    hipLaunchKernelGGL((dwt_fwd_kernel<ST_, CL_>), grid, dim3(256), lds, s, *a, tg);                                           \
+    if (!once) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dwt_fwd_kernel<ST_, CL_, XP_>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); once = true; } \
+    hipLaunchKernelGGL((dwt_fwd_kernel<ST_, CL_, XP_>), grid, dim3(256), lds, s, *a, tg);                                      \
   }
-  if (st == 1) { if (clamp) DWT_(1, true) else DWT_(1, false) }
-  else { if (clamp) DWT_(2, true) else DWT_(2, false) }
+  if (xp) {   // (the expanded tensor of MobileNetV2 carries ReLU6: the clamp form; anything else takes the general activation)
+    if (st == 1) { if (clamp) DWT_(1, true, true) else DWT_(1, false, true) }
+    else { if (clamp) DWT_(2, true, true) else DWT_(2, false, true) }
+  } else if (st == 1) { if (clamp) DWT_(1, true, false) else DWT_(1, false, false) }
+  else { if (clamp) DWT_(2, true, false) else DWT_(2, false, false) }
 #undef DWT_
   return 0;
 }

@@ -928,8 +928,14 @@ __global__ void trread_probe(const unsigned short* in, unsigned short* out) {
 }  // namespace
 
 extern "C" int spb_pwconv_gemm(int dtype, const spb_gemm_args_t* a, spb_stream_t stream) {
-  if (!a || !a->A || !a->Bw || !a->Y) return SPB_E_ARG;
+  if (!a || !a->A || !a->Bw) return SPB_E_ARG;
   if (a->M <= 0 || a->K <= 0 || a->N <= 0 || (a->K & 7) || (a->N & 7)) return SPB_E_SHAPE;
+  if (!a->Y) {   // statistics only (epi_mode 1, 16-bit storage, K <= 32): the batch sums of a product that is never stored (gemm_st.hip, SO)
+    if (a->epi_mode != 1 || !a->osums || a->oR < 1 || dtype != SPB_BF16) return SPB_E_ARG;
+    if (a->pro_mode == 3 && (!a->A2 || !a->Ymat || a->pro.act != SPB_ACT_NONE || a->pro2.act != SPB_ACT_NONE)) return SPB_E_ARG;
+    const int es = spb_gemm_st(a, (hipStream_t)stream);
+    return es == SPB_E_UNSUPPORTED ? SPB_E_SHAPE : es;
+  }
   if (a->epi_mode != 0 && (!a->osums || a->oR < 1)) return SPB_E_ARG;
   if (a->epi_mode == 2 && !a->Zout) return SPB_E_ARG;
   if (a->pro_mode == 3 && (!a->A2 || !a->Ymat || a->pro.act != SPB_ACT_NONE || a->pro2.act != SPB_ACT_NONE)) return SPB_E_ARG;

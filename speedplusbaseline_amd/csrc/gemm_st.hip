@@ -26,7 +26,13 @@
 namespace {
 
 // PRO 1: a = act(bn(A));  3: a = bn(A) + bn2(A2), the first column split writes Ymat.  NJ = 16-channel fragments per wave, KS = 32-deep steps
-template <int PRO, int NJ, int KS>
+// SO (round 6): STATISTICS ONLY -- g.Y == NULL: nothing is stored, the per-channel sums see the f32 accumulators.  This is the pass that
+// is left of an expand convolution whose output is never written (spb_dw_args_t::Xe: the depthwise kernels recompute it per pixel):
+// it reads the 16 / 24-channel block input (once from HBM; the column splits of a row range share an XCD) and costs a sixth of the
+// bytes.  The first column split also writes the convolution's OPERAND round16(act(bn(A))) to Ymat when one is given (PRO 3: the residual
+// join, always): the recomputing kernels then read it as it is instead of redoing the BatchNorm per use (measured: with the affine in
+// their staging loops the depthwise forward kernels were 10 us slower than unfused; each input element is staged 8-10 times there).
+template <int PRO, int NJ, int KS, bool SO = false>
 __global__ __launch_bounds__(256) void pw_st_kernel(const spb_gemm_args_t g, int nsplit, long long nchunks) {
   constexpr int KP = 32 * KS, NW = 16 * NJ, NP = NJ / 2;
   __shared__ float coef[3 * KP];
@@ -123,11 +129,19 @@ __global__ __launch_bounds__(256) void pw_st_kernel(const spb_gemm_args_t g, int
     pa.x = pack_bf16x2(x[0], x[1]); pa.y = pack_bf16x2(x[2], x[3]); pa.z = pack_bf16x2(x[4], x[5]); pa.w = pack_bf16x2(x[6], x[7]);
     if (!ok) pa = make_uint4(0, 0, 0, 0);
     if constexpr (PRO == 3) { if (ok && split == 0) *reinterpret_cast<uint4*>(Ymat + (size_t)m * K + k) = pa; }
+    else if constexpr (SO) { if (ok && split == 0 && Ymat != nullptr) *reinterpret_cast<uint4*>(Ymat + (size_t)m * K + k) = pa; }
     return __builtin_bit_cast(bf16x8_t, pa);
   };
   // rounded 16-byte stores and the sums of a chunk's accumulators.  Rows past M and channels past N carry exact zeros (zeroed operands /
   // weight rows): the sums need no mask
   auto finish = [&](f32x4_t (&acc)[NJ], long long m, bool rowok) __attribute__((always_inline)) {
+    if constexpr (SO) {       // rows past M / channels past N carry exact zeros: no mask
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { s1[j][r] += acc[j][r]; s2[j][r] += acc[j][r] * acc[j][r]; }
+      return;
+    }
     bf16_t* yp = Yg + (size_t)(rowok ? m : M - 1) * N;
     auto fin4 = [&](const f32x4_t& av, float (&t1)[4], float (&t2)[4]) {
       uint2 o;
@@ -245,7 +259,7 @@ __global__ __launch_bounds__(256) void pw_st_kernel(const spb_gemm_args_t g, int
 // persistent workgroups: 384 -> 2.627 ms per KRN step, 512 -> 2.625, 640 -> 2.635, 768 -> 2.620, 1024 -> 2.634, 1280 -> 2.636 (without the kernel: 2.665)
 int g_st_on = 1, g_st_min_m = 100000, g_st_wgs = 768, g_st_long_k = 1;
 
-template <int PRO, int NJ, int KS>
+template <int PRO, int NJ, int KS, bool SO = false>
 int launch_st(const spb_gemm_args_t& g, hipStream_t stream) {
   const int NW = 16 * NJ;
   const int nsplit = (g.N + NW - 1) / NW;
@@ -256,9 +270,9 @@ int launch_st(const spb_gemm_args_t& g, hipStream_t stream) {
   nwg = (nwg + 7) & ~7LL;
   const unsigned grid = (unsigned)(nwg * nsplit);
   if (g.stop_event)
-    hipExtLaunchKernelGGL((pw_st_kernel<PRO, NJ, KS>), dim3(grid), dim3(256), 0, stream, nullptr, (hipEvent_t)g.stop_event, 0, g, nsplit, nchunks);
+    hipExtLaunchKernelGGL((pw_st_kernel<PRO, NJ, KS, SO>), dim3(grid), dim3(256), 0, stream, nullptr, (hipEvent_t)g.stop_event, 0, g, nsplit, nchunks);
   else
-    hipLaunchKernelGGL((pw_st_kernel<PRO, NJ, KS>), dim3(grid), dim3(256), 0, stream, g, nsplit, nchunks);
+    hipLaunchKernelGGL((pw_st_kernel<PRO, NJ, KS, SO>), dim3(grid), dim3(256), 0, stream, g, nsplit, nchunks);
   SPB_CHECK_LAUNCH();
   return 0;
 }
@@ -267,6 +281,12 @@ int launch_st(const spb_gemm_args_t& g, hipStream_t stream) {
 
 // 16-bit storage only; SPB_E_UNSUPPORTED tells spb_pwconv_gemm to use the other kernels
 int spb_gemm_st(const spb_gemm_args_t* a, hipStream_t stream) {
+  if (a->Y == nullptr) {   // statistics only (any M).  Column splits of 48 as the storing form: wider splits need 160-250 registers (one or two
+                           // waves per SIMD: 20-25 us per launch, measured) for rows that are L2 hits anyway
+    if ((a->N % 48) || a->N > 192 || (a->K & 7) || a->K > 32 || a->epi_mode != 1 || (a->pro_mode != 1 && a->pro_mode != 3)) return SPB_E_UNSUPPORTED;
+    if (a->bias != nullptr || a->res != nullptr || (a->lda > 0 && a->lda != a->K)) return SPB_E_UNSUPPORTED;
+    return a->pro_mode == 3 ? launch_st<3, 3, 1, true>(*a, stream) : launch_st<1, 3, 1, true>(*a, stream);
+  }
   if (!g_st_on || a->M < g_st_min_m || (a->N & 7) || (a->K & 7)) return SPB_E_UNSUPPORTED;
   if (a->epi_mode != 1 || (a->pro_mode != 1 && a->pro_mode != 3)) return SPB_E_UNSUPPORTED;
   if (a->bias != nullptr || a->out_act != SPB_ACT_NONE || a->out_scale != 1.f || a->res != nullptr) return SPB_E_UNSUPPORTED;

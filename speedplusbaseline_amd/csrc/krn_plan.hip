@@ -24,7 +24,8 @@ struct PWDef { int K, N; long long w_off, bias_off, wc_off, wct_off; };
 struct DWDef { int C, stride; long long w_off; };
 struct ActDef { int H, W, C, bn, act; float slope; };
 struct MatDef { int H, W, C; };
-struct Block { int t, cin, cout, stride, hid, Hin, Hout; bool res; PWDef E, P; DWDef D; int aE, aD, aP, matY; };
+struct Block { int t, cin, cout, stride, hid, Hin, Hout; bool res; PWDef E, P; DWDef D; int aE, aD, aP, matY;
+               int matXe; };   // >= 0: slot for the expand convolution's operand round16(bn(block input)) when the expanded tensor is virtual
 
 constexpr float kEps = 1e-5f;
 constexpr float kMomentum = 0.1f;
@@ -107,6 +108,7 @@ struct spb_krn_ctx {
   size_t stats_off = 0, stats_floats = 0;
   size_t dcat_off = 0, dtap_off = 0, ddom_off = 0, dom1_off = 0, gdom_off = 0;
   size_t partial_off = 0, dout_off = 0, table_off = 0, dompool_off = 0;
+  size_t junk_off = 0;              // 2 x 1280 floats nobody reads (batch sums of an evaluation-mode statistics pass)
   // weight-gradient partial sums (spb_red_job_t): one scratch slab per layer, keyed by the layer's weight offset in the arena
   struct PartSlab { long long key; size_t off; long long floats; };
   std::vector<PartSlab> parts;
@@ -186,8 +188,13 @@ void build_model(spb_krn* m, int nK, bool dann) {
       b.aD = m->add_act(b.Hout, b.Hout, b.hid, m->add_bn(pre + std::to_string(idx) + ".1", b.hid), SPB_ACT_RELU6);
       b.P = m->add_pw(pre + std::to_string(idx + 1), b.hid, b.cout);
       b.aP = m->add_act(b.Hout, b.Hout, b.cout, m->add_bn(pre + std::to_string(idx + 2), b.cout), SPB_ACT_NONE);
-      b.matY = -1;
+      b.matY = -1; b.matXe = -1;
       if (b.res) { m->mats.push_back(MatDef{b.Hout, b.Hout, b.cout}); b.matY = (int)m->mats.size() - 1; }
+      // candidates for a virtual expanded tensor (Runner::virt) whose input is not a materialised block output: the statistics pass of the
+      // expand convolution writes its operand here once, the recomputing kernels read it as it is (26 MB at bs=48 for blocks 2 and 3)
+      if (b.t != 1 && b.cin <= 32 && H >= 28 && k >= 2 && !m->blk[k - 1].res) {
+        m->mats.push_back(MatDef{H, H, cin}); b.matXe = (int)m->mats.size() - 1;
+      }
       cin = b.cout; H = b.Hout;
     }
   // ---- extras (park2019.py:113-118): ConvDw(320,1024), ConvDw(1024,1024), RouterV2(96,64), ConvDw(1280,1024)
@@ -446,6 +453,17 @@ static int g_join_fused = 1;      // residual adds folded into the next expand c
 #ifdef SPB_TUNING   // tuning build only (libspb_hip_tune.so, include/spb_hip_tuning.h): the product library has no knob
 extern "C" int spb_debug_set_join_fused(int on) { g_join_fused = on; return 0; }
 #endif
+// Round 6: expand -> depthwise fusion with recompute.  For the inverted-residual blocks whose expand convolution has a short reduction on a
+// large map (blocks 2-4: 16 -> 96 at 112x112, 24 -> 144 at 56x56 twice) the 6x-expanded tensor is VIRTUAL: the expand launch only
+// accumulates its batch sums (spb_pwconv_gemm with Y == NULL), the depthwise forward / input-gradient / weight-gradient kernels and the
+// fused pointwise backward rebuild the values they need on the matrix cores from the 16 / 24-channel block input (spb_dw_args_t::Xe,
+// spb_pwbwd_args_t::Zn == NULL).  0.81 GB of the step's HBM traffic (four passes over 202 MB) become four passes over 34 MB, and the
+// expanded activation is no longer rounded to 16 bits on the way (the 112x112 layers are where bf16 storage hurts the gradient most).
+// 16-bit storage only; spb_debug_set_fuse_expand(min_width): 0 = off.
+static int g_fuse_expand_min_hw = 56;
+#ifdef SPB_TUNING
+extern "C" int spb_debug_set_fuse_expand(int min_width) { g_fuse_expand_min_hw = min_width <= 0 ? (1 << 30) : min_width; return 0; }
+#endif
 static int g_fused_pw_bwd = 1;
 static long long g_fused_pw_bwd_min_m = 100000;  // spb_debug_set_fused_pw_bwd(v > 1): fused kernel from v rows up.  The 28x28 layer
                                                  // (M = 37632, 144 -> 32) took 45 us fused for 26 MB; as GEMM + side-stream weight gradient the step is 12 us shorter
@@ -517,6 +535,15 @@ struct Runner {
     const Block& b = m->blk[k];
     return b.res ? src_mat(b.matY) : src_act(b.aP, tr);
   }
+  // the expanded tensor of block k exists only as its batch sums (see g_fuse_expand_min_hw): its consumers recompute it
+  bool virt(int k) const {
+    const Block& b = m->blk[k];
+    return dt == SPB_BF16 && b.t != 1 && b.cin <= 32 && (b.cin & 7) == 0 && b.Hin >= g_fuse_expand_min_hw && b.Hin >= 28 &&
+           g_fused_pw_bwd && (long long)c->B * b.Hin * b.Hin >= g_fused_pw_bwd_min_m;   // (its pointwise backward must be the recomputing fused kernel)
+  }
+  void set_xe(spb_dw_args_t& d, const PWDef& E, const Src& x) const {
+    d.Xe = x.ptr; d.We = wc(E.wc_off); d.xe = x.ref; d.Ce = E.K;
+  }
 
   // ---- forward pieces
   void pw_fwd(const PWDef& L, const Src& in, int aout, bool tr) {
@@ -529,30 +556,52 @@ struct Runner {
     ok(spb_pwconv_gemm(dt, &g, st));
     toc();
   }
-  void dw_fwd(const DWDef& L, const Src& in, int Hin, int aout, bool tr) {
+  // what is left of a virtual block's expand convolution: its batch sums (training) and, if the operand is a residual join, the
+  // materialised block output the join writes
+  void pw_stats(const PWDef& L, const Src& in, int aout, bool tr, void* xmat) {
+    spb_gemm_args_t g; std::memset(&g, 0, sizeof(g));
+    g.A = in.ptr; g.Bw = wc(L.wc_off); g.Y = nullptr; g.pro = in.ref; g.M = M(aout); g.K = L.K; g.N = L.N;
+    g.pro_mode = 1; g.out_scale = 1.f; g.epi_mode = 1; g.Ymat = xmat;     // xmat: the operand round16(bn(in)), for the recomputing kernels
+    if (in.mat) { g.pro_mode = 3; g.A2 = in.ptr2; g.pro2 = in.ref2; g.Ymat = in.mat; }
+    // evaluation: the sums are not wanted (the arena holds the running statistics): a scratch row behind the context's tables takes them
+    g.osums = tr ? sums(aout) : reinterpret_cast<float*>(c->ws + c->junk_off); g.oR = tr ? c->R[aout] : 1;
+    tic(PC_PW_FWD, ((double)g.M * ((in.mat ? 3 : 1) + (xmat ? 1 : 0)) * L.K + (double)L.K * L.N) * es(), 2.0 * g.M * L.K * L.N);
+    ok(spb_pwconv_gemm(dt, &g, st));
+    toc();
+  }
+  // the tensor the recomputing kernels of virtual block k read as the expand convolution's operand (identity BatchNorm on it)
+  Src xe_src(int k) const {
+    const Block& b = m->blk[k];
+    return b.matXe >= 0 ? src_mat(b.matXe) : src_mat(m->blk[k - 1].matY);
+  }
+  // E / x: the expand convolution in front of the layer and ITS input, when the expanded tensor is virtual (`in` then only names the
+  // BatchNorm + activation that sits on it)
+  void dw_fwd(const DWDef& L, const Src& in, int Hin, int aout, bool tr, const PWDef* E = nullptr, const Src* x = nullptr) {
     spb_dw_args_t d; std::memset(&d, 0, sizeof(d));
     d.X = in.ptr; d.Wd = m->P + L.w_off; d.Y = z(aout); d.pro = in.ref; d.B = c->B; d.H = Hin; d.W = Hin; d.C = L.C;
     d.stride = L.stride; d.epi_mode = tr ? 1 : 0; d.osums = sums(aout); d.oR = c->R[aout];
-    tic(PC_DW_FWD, ((double)c->B * Hin * Hin * L.C + elems(aout)) * es(), 18.0 * elems(aout));
+    if (E) { set_xe(d, *E, *x); d.X = nullptr; }
+    tic(PC_DW_FWD, ((double)c->B * Hin * Hin * (E ? E->K : L.C) + elems(aout)) * es(), 18.0 * elems(aout) + (E ? 2.0 * c->B * Hin * Hin * E->K * L.C : 0.0));
     ok(spb_dwconv_fwd(dt, &d, st));
     toc();
   }
   // ---- backward pieces.  `atgt` is the Act whose g / bsums the input gradient lands in (-1: plain output to `plain`)
   // before_dw: the next launch is a depthwise backward kernel, where the queued weight gradients fork off (flush_wgrads)
   void pw_bwd(const PWDef& L, const Src& in, int aout, int atgt, void* plain, const void* res, float plain_scale = 1.f,
-              bool before_dw = false) {
+              bool before_dw = false, bool virt_out = false) {
     // wide, shallow layers (the 112x112 / 56x56 maps): one fused pass over g and z for both gradients
     if (g_fused_pw_bwd && dt == SPB_BF16 && atgt >= 0 && M(aout) >= g_fused_pw_bwd_min_m) {
       spb_pwbwd_args_t f; std::memset(&f, 0, sizeof(f));
-      f.G = this->g(aout); f.Zn = z(aout); f.Wt = wc(L.wct_off); f.X = in.ptr; f.Zout = z(atgt); f.res = res;
+      f.G = this->g(aout); f.Zn = virt_out ? nullptr : z(aout); f.Wt = wc(L.wct_off); f.X = in.ptr; f.Zout = z(atgt); f.res = res;
       f.Y = this->g(atgt); f.dW = m->G + L.w_off; f.osums = bsums(atgt); f.pro_dz = ref(aout, true); f.pro_a = in.ref;
       f.epi = ref(atgt, true); f.M = M(aout); f.K = L.K; f.N = L.N; f.oR = c->R[atgt];
       const double mn = (double)f.M * L.N, mk = (double)f.M * L.K;
-      tic(PC_PW_BWD_FUSED, (2 * mn + (2 + (f.X != f.Zout ? 1 : 0) + (res ? 1 : 0)) * mk + (double)L.K * L.N) * es() + 4.0 * L.K * L.N,
-          4.0 * f.M * L.K * L.N);
+      tic(PC_PW_BWD_FUSED, ((L.K <= 32 ? 1 : 2) * mn + (2 + (f.X != f.Zout ? 1 : 0) + (res ? 1 : 0)) * mk + (double)L.K * L.N) * es() + 4.0 * L.K * L.N,
+          4.0 * f.M * L.K * L.N);     // (K <= 32: z is recomputed, not read)
       const int e = spb_pwconv_bwd_fused(dt, &f, st);
       toc();
       if (e == 0) return;
+      if (virt_out) { ok(e); return; }   // no other kernel can stand in: z does not exist
       if (e != SPB_E_UNSUPPORTED) { ok(e); return; }
       if (c->prof_on) c->prof_n--;   // no fused instance for this shape: drop the empty timing record
     }
@@ -671,11 +720,13 @@ struct Runner {
   }
   bool forked = false;
   bool gated = false;
-  void dw_bwd(const DWDef& L, const Src& in, int Hin, int aout, int atgt, void* plain, const void* res) {
+  void dw_bwd(const DWDef& L, const Src& in, int Hin, int aout, int atgt, void* plain, const void* res, const PWDef* E = nullptr,
+              const Src* x = nullptr) {
     spb_dw_args_t d; std::memset(&d, 0, sizeof(d));
     d.X = this->g(aout); d.X2 = z(aout); d.Xin = in.ptr; d.Wd = m->P + L.w_off; d.dW = m->G + L.w_off;
     d.pro = ref(aout, true); d.pro_in = in.ref; d.B = c->B; d.H = Hin; d.W = Hin; d.C = L.C; d.stride = L.stride;
     d.Zout = in.ptr; d.epi = in.ref;  // the convolution's input and its BN/activation (== ref(atgt) when atgt >= 0)
+    if (E) { set_xe(d, *E, *x); d.Xin = nullptr; d.Zout = nullptr; }   // virtual input: recomputed from the expand convolution's operand
     // On the small maps the weight gradient goes to the side stream with the pointwise ones (everything it reads -- g, z and the
     // batch sums of this layer's output, the forward input -- is final and never rewritten during backward) and the launch
     // stream runs the input gradient alone (spb_debug_set_dw_split).
@@ -691,6 +742,7 @@ struct Runner {
       d.Y = this->g(atgt); d.osums = bsums(atgt); d.oR = c->R[atgt]; d.res = res; d.epi_mode = 2;
     } else { d.Y = plain; d.epi_mode = 0; d.oR = 1; }
     const double nin = (double)c->B * Hin * Hin * L.C, nout = elems(aout);
+    const double nzin = E ? (double)c->B * Hin * Hin * E->K : nin;       // elements read for the conv input (mask / a)
     const bool flush_due = g_wgrad_flush_at_dw && (int)(pend.size() + pend_dw.size()) >= g_wgrad_min_flush &&
                            (!pend.empty() || !pend_dw.empty() || head_pending);
     // fork through the device word: this kernel's first thread stores the serial (it runs behind a barrier bit: everything the queued
@@ -699,12 +751,12 @@ struct Runner {
     const bool entry_fork = flag_forks && g_fork_mode == 2 && flush_due && side_usable();
     if (entry_fork) { d.entry_flag = c->fork_flag; d.entry_val = ++c->fork_serial; }
     if (!entry_fork && !g_flush_after_dw && flush_due) flush_wgrads();
-    tic(PC_DW_DGRAD, (2 * nout + 2 * nin + (res ? nin : 0)) * es(), 36.0 * nout);
+    tic(PC_DW_DGRAD, (2 * nout + nin + nzin + (res ? nin : 0)) * es(), 36.0 * nout);
     ok(spb_dwconv_dgrad(dt, &d, st));
     toc();
     if (entry_fork) { gate_side(d.entry_val); gated = true; flush_wgrads(); }
     if (split && c->prof_on) {
-      tic(PC_DW_WGRAD, (2 * nout + nin) * es() + 36.0 * L.C, 18.0 * nout);
+      tic(PC_DW_WGRAD, (2 * nout + nzin) * es() + 36.0 * L.C, 18.0 * nout);
       ok(spb_dwconv_wgrad(dt, &dwg, st));
       toc();
     }
@@ -1025,6 +1077,7 @@ static void layout_ctx(const spb_krn* m, int B, int dtype, spb_krn_ctx* c, size_
   size_t dom1 = take((size_t)B * 49 * 1280 * es);
   size_t gdom = take((size_t)B * 49 * 1280 * es);
   size_t dompool = take((size_t)B * 1280 * sizeof(float));
+  size_t junk = take((size_t)2 * 1280 * sizeof(float));
   size_t partial = take((size_t)S * B * m->Jp * sizeof(float));
   size_t dout = take((size_t)B * m->J * sizeof(float));
   // scratch slabs of the weight-gradient partial sums: pointwise (row splits, or one part per workgroup of the fused
@@ -1054,6 +1107,7 @@ static void layout_ctx(const spb_krn* m, int B, int dtype, spb_krn_ctx* c, size_
   if (c) {
     c->table_off = table; c->stats_off = stats; c->stats_floats = sf; c->dcat_off = dcat; c->dtap_off = dtap;
     c->ddom_off = ddom; c->dom1_off = dom1; c->gdom_off = gdom; c->dompool_off = dompool; c->partial_off = partial;
+    c->junk_off = junk;
     c->dout_off = dout; c->S = S;
     c->parts = slabs;
   }
@@ -1193,7 +1247,16 @@ extern "C" int spb_krn_forward(spb_krn_ctx_t* c, const float* x, const float* ta
   Src cur = r.src_act(m->aStem, tr);
   for (int k = 1; k <= 17; ++k) {
     const Block& b = m->blk[k];
-    if (b.t != 1) {
+    if (b.t != 1 && r.virt(k)) {
+      // virtual expanded tensor: the expand launch leaves only its batch sums (and the residual join it forms on the way), the depthwise
+      // kernel recomputes the expanded activation from the block input
+      // (a block input that already is a materialised tensor -- the previous block had a skip connection and its join was formed
+      // earlier -- cannot occur for the candidates: the join of block k - 1 is always pending here)
+      r.pw_stats(b.E, cur, b.aE, tr, b.matXe >= 0 ? r.y(b.matXe) : nullptr);
+      if (cur.mat) cur = r.block_out(k - 1, tr);
+      const Src xs = r.xe_src(k);
+      r.dw_fwd(b.D, r.src_act(b.aE, tr), b.Hin, b.aD, tr, &b.E, &xs);
+    } else if (b.t != 1) {
       r.pw_fwd(b.E, cur, b.aE, tr);
       if (cur.mat) cur = r.block_out(k - 1, tr);   // the join is materialised now: later readers take the block's output tensor
       r.dw_fwd(b.D, r.src_act(b.aE, tr), b.Hin, b.aD, tr);
@@ -1297,6 +1360,32 @@ extern "C" int spb_krn_update_running(spb_krn_ctx_t* c, spb_stream_t stream) {
   Runner r(c, (hipStream_t)stream);
   const spb_bnupd_entry_t* tab = reinterpret_cast<const spb_bnupd_entry_t*>(c->ws + c->table_off);
   return spb_bn_running_update(tab, (int)m->bns.size(), r.stats(), m->Bf, m->nbt, kMomentum, stream);
+}
+
+// Introspection (parity tests): write the raw output z of every VIRTUAL expand convolution of the context's last forward pass into its
+// workspace slot (spb_krn_ctx_act_info), rounded to the storage type -- the tensors no kernel of the step reads or writes.  Batch sums
+// and every other tensor are left alone.
+extern "C" int spb_krn_ctx_materialize(spb_krn_ctx_t* c, spb_stream_t stream) {
+  if (!c) return SPB_E_ARG;
+  spb_krn* m = c->m;
+  Runner r(c, (hipStream_t)stream);
+  const bool tr = c->last_training != 0;
+  for (int k = 2; k <= 17; ++k) {
+    if (!r.virt(k)) continue;
+    const Block& b = m->blk[k];
+    const Src in = r.xe_src(k);                  // the operand the forward pass materialised
+    spb_gemm_args_t g; std::memset(&g, 0, sizeof(g));
+    g.A = in.ptr; g.Bw = r.wc(b.E.wc_off); g.Y = r.z(b.aE); g.pro = in.ref; g.M = r.M(b.aE); g.K = b.E.K; g.N = b.E.N;
+    g.pro_mode = 1; g.out_scale = 1.f; g.epi_mode = 0; g.oR = 1;
+    r.ok(spb_pwconv_gemm(m->dtype, &g, stream));
+  }
+  return r.err;
+}
+extern "C" int spb_krn_ctx_virtual(const spb_krn_ctx_t* c, int a) {   // 1: BatchNorm'd tensor `a` is virtual in this context (never stored)
+  if (!c || a < 0 || a >= (int)c->m->acts.size()) return SPB_E_ARG;
+  Runner r(const_cast<spb_krn_ctx_t*>(c), nullptr);
+  for (int k = 2; k <= 17; ++k) if (c->m->blk[k].aE == a) return r.virt(k) ? 1 : 0;
+  return 0;
 }
 
 // ---- backward --------------------------------------------------------------------------------------------------
@@ -1416,7 +1505,11 @@ extern "C" int spb_krn_backward(spb_krn_ctx_t* c, float* grads, float gscale, in
     if (b.res) res = r.g(b.aP);                                  // skip connection: d y_{k-1} += d y_k
     else if (k == 14 && with_pose) res = c->ws + c->dtap_off;    // RouterV2 branch taps block 13's output
     r.pw_bwd(b.P, r.src_act(b.aD, true), b.aP, b.aD, nullptr, nullptr, 1.f, true);
-    if (b.t != 1) {
+    if (b.t != 1 && r.virt(k)) {
+      const Src xs = r.xe_src(k);
+      r.dw_bwd(b.D, r.src_act(b.aE, true), b.Hin, b.aD, b.aE, nullptr, nullptr, &b.E, &xs);
+      r.pw_bwd(b.E, in, b.aE, atgt, nullptr, res, 1.f, false, true);
+    } else if (b.t != 1) {
       r.dw_bwd(b.D, r.src_act(b.aE, true), b.Hin, b.aD, b.aE, nullptr, nullptr);
       r.pw_bwd(b.E, in, b.aE, atgt, nullptr, res);
     } else {

@@ -480,7 +480,8 @@ extern "C" int spb_debug_set_pwb(int chunk_rows, int recompute_z, int max_waves)
 // 0 on launch, SPB_E_UNSUPPORTED when this shape / dtype has no fused instance (the caller then uses
 // spb_pwconv_gemm + spb_pwconv_wgrad)
 extern "C" int spb_pwconv_bwd_fused(int dtype, const spb_pwbwd_args_t* a, spb_stream_t stream) {
-  if (!a || !a->G || !a->Zn || !a->Wt || !a->X || !a->Zout || !a->Y || !a->dW || !a->osums) return SPB_E_ARG;
+  if (!a || !a->G || !a->Wt || !a->X || !a->Zout || !a->Y || !a->dW || !a->osums) return SPB_E_ARG;
+  if (!a->Zn && !(g_pwb_rz && a->K <= 32)) return SPB_E_ARG;   // z may be absent only where it is recomputed (RZ: expand layers, K <= 32)
   if (a->M <= 0 || a->K <= 0 || a->N <= 0 || (a->K & 7) || (a->N & 7) || a->oR < 1) return SPB_E_SHAPE;
   if (dtype != SPB_BF16) return SPB_E_UNSUPPORTED;
   const int NB = (a->N + 15) / 16, KBt = (a->K + 15) / 16;

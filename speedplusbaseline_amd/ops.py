@@ -65,15 +65,18 @@ def bnref(C_, sums=None, gamma=None, beta=None, bsums=None, n=1, R=1, act=L.ACT_
 
 def pwconv_gemm(A, Bw, Y, pro, pro_mode, epi_mode, A2=None, res=None, Zout=None, bias=None, osums=None, epi=None,
                 out_act=L.ACT_NONE, oR=1, out_scale=1.0, pro2=None, Ymat=None):
-    _need_rows(A, Y)
+    if Y is None:               # statistics only (epi_mode 1): the batch sums of a product that is never stored
+        _need_rows(A)
+    else:
+        _need_rows(A, Y)
     _need_cuda(Bw, A2, res, Zout, bias, osums)
     g = L.GemmArgs()
     g.A = _ptr(A); g.A2 = _ptr(A2); g.Bw = _ptr(Bw); g.Y = _ptr(Y); g.res = _ptr(res); g.Zout = _ptr(Zout)
     g.bias = _ptr(bias); g.osums = _ptr(osums); g.pro = pro
-    g.epi = epi if epi is not None else bnref(Y.shape[-1])
+    g.epi = epi if epi is not None else bnref(Bw.shape[0])
     g.M, g.K = A.shape[0], A.shape[1]; g.N = Bw.shape[0]
     g.lda = A.stride(0) if A.stride(0) != A.shape[1] else 0     # column slabs of wider matrices (grouped convolutions)
-    g.ldc = Y.stride(0) if Y.stride(0) != Y.shape[1] else 0
+    g.ldc = 0 if Y is None else (Y.stride(0) if Y.stride(0) != Y.shape[1] else 0)
     g.pro_mode = pro_mode; g.epi_mode = epi_mode; g.out_act = out_act; g.oR = oR; g.out_scale = out_scale
     if pro_mode == 3:       # residual join: a = bn(A) + bn2(A2), written to Ymat by the launch
         _need_cuda(Ymat)
@@ -117,22 +120,38 @@ def _dwargs(X, Wd, B, H, W_, C_, stride, **kw):
             setattr(d, k, v)
     ident = bnref(C_)
     for k in ("pro", "pro_in", "epi"):
-        if k not in kw:
+        if k not in kw or kw[k] is None:
             setattr(d, k, ident)
     if "oR" not in kw:
         d.oR = 1
+    d.xe = bnref(8)
     return d
 
 
-def dwconv_fwd(X, Wd, Y, pro, stride, osums=None, oR=1):
-    B, H, W_, C_ = X.shape
+def _set_expand(d, expand):
+    """spb_dw_args_t::Xe -- the depthwise layer's input is the (never stored) output of a 1x1 expand convolution:
+    expand = (Xe [B,H,W,Ce], We [C,Ce] compute dtype, xe = BN/activation turning Xe into that convolution's operand or None)"""
+    Xe, We, xe = expand
+    _need_cuda(Xe, We)
+    d.Xe = _ptr(Xe); d.We = _ptr(We); d.Ce = Xe.shape[-1]
+    d.xe = xe if xe is not None else bnref(Xe.shape[-1])
+    d._keep_expand = (Xe, We, xe)
+
+
+def dwconv_fwd(X, Wd, Y, pro, stride, osums=None, oR=1, expand=None):
+    """expand: see _set_expand; X is then None and `pro` names the BatchNorm / activation on the recomputed tensor"""
+    src = X if expand is None else expand[0]
+    B, H, W_ = src.shape[:3]
+    C_ = Y.shape[3]
     _need_cuda(X, Wd, Y, osums)
     d = _dwargs(X, Wd, B, H, W_, C_, stride, Y=Y, pro=pro, osums=osums, oR=oR, epi_mode=1 if osums is not None else 0)
-    L.check(L.lib().spb_dwconv_fwd(dtype_code(X), C.byref(d), _stream()), "spb_dwconv_fwd")
+    if expand is not None:
+        _set_expand(d, expand)
+    L.check(L.lib().spb_dwconv_fwd(dtype_code(Y), C.byref(d), _stream()), "spb_dwconv_fwd")
 
 
 def dwconv_dgrad(G, Z, Wd, Y, pro, stride, in_hw, epi=None, Zout=None, res=None, osums=None, oR=1, dW=None, Xin=None,
-                 pro_in=None, entry_flag=None, entry_val=0):
+                 pro_in=None, entry_flag=None, entry_val=0, expand=None):
     """Input gradient of the depthwise conv.  With `dW` the weight gradient is accumulated in the same pass; `Xin` and
     `pro_in` (the conv's input tensor and its BN/activation) are then required unless `epi`/`Zout` already name them.
     `entry_flag` (a device int32 word): the launch's first thread stores `entry_val` there before anything else
@@ -150,13 +169,19 @@ def dwconv_dgrad(G, Z, Wd, Y, pro, stride, in_hw, epi=None, Zout=None, res=None,
     if entry_flag is not None:
         _need_cuda(entry_flag)
         d.entry_flag = _ptr(entry_flag); d.entry_val = int(entry_val)
+    if expand is not None:      # the conv input (Zout / Xin) is recomputed: `epi` / `pro_in` name the BatchNorm on the recomputed tensor
+        _set_expand(d, expand)
     L.check(L.lib().spb_dwconv_dgrad(dtype_code(G), C.byref(d), _stream()), "spb_dwconv_dgrad")
 
 
-def dwconv_wgrad(G, Z, Xin, Wd, dW, pro, pro_in, stride):
-    B, H, W_, C_ = Xin.shape
+def dwconv_wgrad(G, Z, Xin, Wd, dW, pro, pro_in, stride, expand=None):
+    src = Xin if expand is None else expand[0]
+    B, H, W_ = src.shape[:3]
+    C_ = G.shape[3]
     _need_cuda(G, Z, Xin, Wd, dW)
     d = _dwargs(G, Wd, B, H, W_, C_, stride, X2=Z, Xin=Xin, dW=dW, pro=pro, pro_in=pro_in)
+    if expand is not None:
+        _set_expand(d, expand)
     L.check(L.lib().spb_dwconv_wgrad(dtype_code(G), C.byref(d), _stream()), "spb_dwconv_wgrad")
 
 

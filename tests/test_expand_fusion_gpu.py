@@ -1,0 +1,179 @@
+"""Expand -> depthwise fusion with recompute (round 6): the kernels behind spb_dw_args_t::Xe and spb_pwconv_gemm(Y = NULL).
+
+Reference call site: torchvision InvertedResidual conv[0] (1x1 expand + BatchNorm + ReLU6) -> conv[1] (depthwise 3x3 + BatchNorm +
+ReLU6), /root/reference/src/nets/park2019.py:107-108.  The 6x-expanded tensor is never stored; every kernel that needs it rebuilds
+    z_e[p][c] = sum_k We[c][k] * xe[p][k],    xe = round16(bn_x(x))
+on the matrix cores.  Each entry point is held to a float64 PyTorch reference of the same composite
+    x -> bn_x -> round16 -> 1x1 expand -> bn_e -> relu6 -> depthwise 3x3 -> bn_d -> relu6 -> loss
+through torch.autograd (input gradient g_e = dL/d bn_e(z_e), its two BatchNorm-backward sums, the depthwise weight gradient), at small
+and ragged shapes on the CPU and at the three bs=48 layer shapes of KRN (blocks 2-4) with the float64 reference evaluated on the GPU.
+Tolerances: 2e-2 relative for 16-bit tensors (operands rounded to bf16, f32 accumulation), 1e-3 for f32 sums against the kernel's own output.
+"""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from speedplusbaseline_amd import _lib as L  # noqa: E402
+from speedplusbaseline_amd import ops  # noqa: E402
+
+EPS = 1e-5
+DT = torch.bfloat16
+
+
+def relerr(a, b):
+    a = a.detach().double(); b = b.detach().double().to(a.device)
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def rt(x):
+    return x.to(DT).double()
+
+
+def bn4(z, g, b):
+    mean = z.mean((0, 2, 3), keepdim=True); var = z.var((0, 2, 3), unbiased=False, keepdim=True)
+    xh = (z - mean) / torch.sqrt(var + EPS)
+    return xh * g.view(1, -1, 1, 1) + b.view(1, -1, 1, 1), xh
+
+
+def dwconv_ref(a, Wd, stride):
+    """depthwise 3x3, pad 1, as nine shifted products (float64 on any device, differentiable)"""
+    H, W = a.shape[2], a.shape[3]
+    OH, OW = (H - 1) // stride + 1, (W - 1) // stride + 1
+    ap = F.pad(a, (1, 1, 1, 1))
+    out = 0
+    for ky in range(3):
+        for kx in range(3):
+            out = out + Wd[:, 0, ky, kx].view(1, -1, 1, 1) * ap[:, :, ky:ky + stride * (OH - 1) + 1:stride, kx:kx + stride * (OW - 1) + 1:stride]
+    return out
+
+
+def sums_of(z2d, R):
+    C = z2d.shape[1]
+    s = torch.stack([z2d.sum(0), (z2d * z2d).sum(0)])
+    w = torch.rand(R, 1, 1, dtype=torch.float64, device=z2d.device) + 0.1
+    w = w / w.sum()
+    return (w * s.unsqueeze(0)).float().contiguous()
+
+
+def nhwc(t):
+    return t.detach().permute(0, 2, 3, 1).contiguous()
+
+
+def build(B, H, Ce, C, stride, mat, ref_dev, seed):
+    """the float64 composite and every device operand of the three kernels"""
+    torch.manual_seed(seed)
+    dev = "cuda"
+    r = lambda *s: torch.randn(*s, dtype=torch.float64, device=ref_dev)
+    x = rt(r(B, Ce, H, H) * 0.8 + 0.1)                                   # what is stored: raw z of the producer (or the materialised block input)
+    c = {}
+    if mat:
+        xe = x
+        c["xe_ref"] = None
+    else:
+        gx = torch.rand(Ce, dtype=torch.float64, device=ref_dev) + 0.5; bx = r(Ce) * 0.2
+        u, _ = bn4(x, gx, bx)
+        xe = rt(u)                                                      # the expand convolution's operand, rounded as the kernels round it
+        x2d = nhwc(x).view(-1, Ce)
+        c["xe_ref"] = ops.bnref(Ce, sums=sums_of(x2d, 8).to(dev), gamma=gx.float().to(dev), beta=bx.float().to(dev), n=x2d.shape[0], R=8, act=L.ACT_NONE)
+    We = rt(r(C, Ce) * 0.3)
+    ze = torch.einsum("bkhw,ck->bchw", xe, We).detach().requires_grad_(True)          # exact: never rounded
+    ge = torch.rand(C, dtype=torch.float64, device=ref_dev) + 0.5; be = r(C) * 0.2
+    ue, xhe = bn4(ze, ge, be); ue.retain_grad()
+    a = F.relu6(ue)
+    Wd = (r(C, 1, 3, 3) * 0.3).float().double().requires_grad_(True)
+    zd = dwconv_ref(a, Wd, stride)
+    zdq = rt(zd.detach()); zd = zd + (zdq - zd).detach()
+    gd = torch.rand(C, dtype=torch.float64, device=ref_dev) + 0.5; bd = r(C) * 0.2
+    ud, xhd = bn4(zd, gd, bd); ud.retain_grad()
+    (F.relu6(ud) * torch.randn_like(ud)).sum().backward()
+    n_in, n_out = B * H * H, zd.numel() // C
+    ze2d = nhwc(ze).view(-1, C)
+    c.update(B=B, H=H, Ce=Ce, C=C, stride=stride, OH=zd.shape[2], n_in=n_in, n_out=n_out,
+             X=nhwc(x).to(DT).to(dev), We=We.to(DT).to(dev), Wd=Wd.detach().float().to(dev).contiguous(),
+             ze=ze, zd=zd, zdq=zdq, ue=ue, xhe=xhe, ud=ud, xhd=xhd, Wd_ref=Wd,
+             pro_e=ops.bnref(C, sums=sums_of(ze2d, 8).to(dev), gamma=ge.float().to(dev), beta=be.float().to(dev), n=n_in, R=8, act=L.ACT_RELU6),
+             gd=gd, bd=bd)
+    return c
+
+
+def expand_of(c):
+    return (c["X"], c["We"], c["xe_ref"])
+
+
+SHAPES = [  # B, H, Ce, C, stride, materialised input, float64 reference on
+    (2, 56, 24, 144, 1, False, "cpu"), (1, 112, 16, 96, 2, False, "cpu"), (3, 56, 24, 144, 2, True, "cpu"),
+    (2, 60, 8, 40, 1, False, "cpu"), (2, 35, 32, 72, 2, False, "cpu"), (1, 28, 32, 192, 1, True, "cpu"),
+    # KRN blocks 2, 3, 4 at bs=48 (park2019.py:107-108; block 4 reads the materialised residual join)
+    (48, 112, 16, 96, 2, False, "cuda"), (48, 56, 24, 144, 1, False, "cuda"), (48, 56, 24, 144, 2, True, "cuda"),
+]
+
+
+@pytest.mark.parametrize("B,H,Ce,C,stride,mat,ref_dev", SHAPES)
+def test_statistics_only_expand_gemm(device, B, H, Ce, C, stride, mat, ref_dev):
+    """spb_pwconv_gemm(Y = NULL): sum z, sum z^2 of the f32 product, nothing stored"""
+    if C % 48 != 0 or C > 192:
+        pytest.skip("statistics-only instances exist for N = 96, 144, 192")
+    c = build(B, H, Ce, C, stride, mat, ref_dev, seed=B + H + C)
+    osums = torch.zeros(4, 2, C, dtype=torch.float32, device=device)
+    pro = c["xe_ref"] if c["xe_ref"] is not None else ops.bnref(Ce)
+    ops.pwconv_gemm(c["X"].view(-1, Ce), c["We"], None, pro, 1, 1, osums=osums, oR=4)
+    torch.cuda.synchronize()
+    z = nhwc(c["ze"]).view(-1, C)
+    s = osums.double().sum(0)
+    assert relerr(s[0], z.sum(0)) < 2e-4 and relerr(s[1], (z * z).sum(0)) < 2e-4
+
+
+@pytest.mark.parametrize("B,H,Ce,C,stride,mat,ref_dev", SHAPES)
+def test_depthwise_forward_recomputes_the_expanded_activation(device, B, H, Ce, C, stride, mat, ref_dev):
+    c = build(B, H, Ce, C, stride, mat, ref_dev, seed=B * H + C)
+    OH = c["OH"]
+    Y = torch.empty(B, OH, OH, C, dtype=DT, device=device)
+    osums = torch.zeros(3, 2, C, dtype=torch.float32, device=device)
+    ops.dwconv_fwd(None, c["Wd"], Y, c["pro_e"], stride, osums=osums, oR=3, expand=expand_of(c))
+    torch.cuda.synchronize()
+    assert relerr(Y, nhwc(c["zd"])) < 2e-2
+    ys = Y.double().view(-1, C); s = osums.double().sum(0)
+    assert relerr(s[0], ys.sum(0)) < 1e-4 and relerr(s[1], (ys * ys).sum(0)) < 1e-4
+
+
+@pytest.mark.parametrize("B,H,Ce,C,stride,mat,ref_dev", SHAPES)
+def test_depthwise_backward_recomputes_mask_and_activation(device, B, H, Ce, C, stride, mat, ref_dev):
+    """input gradient (mask of bn_e(z_e), sum g, sum g*xhat) and weight gradient (a = relu6(bn_e(z_e))) from the recomputed z_e"""
+    c = build(B, H, Ce, C, stride, mat, ref_dev, seed=B * H + C + 1)
+    dev = device
+    g2s = rt(nhwc(c["ud"].grad))
+    zd2d = nhwc(c["zdq"]).view(-1, C)
+    xhd = nhwc(c["xhd"]).view(-1, C)
+    bs = torch.stack([g2s.view(-1, C).sum(0), (g2s.view(-1, C) * xhd).sum(0)]).float().unsqueeze(0).contiguous().to(dev)
+    pro = ops.bnref(C, sums=sums_of(zd2d, 1).to(dev), gamma=c["gd"].float().to(dev), beta=c["bd"].float().to(dev), bsums=bs, n=c["n_out"], act=L.ACT_RELU6)
+    G = g2s.to(DT).to(dev); Z = nhwc(c["zdq"]).to(DT).to(dev)
+    G1 = torch.empty(B, H, H, C, dtype=DT, device=dev)
+    os2 = torch.zeros(2, 2, C, dtype=torch.float32, device=dev)
+    ops.dwconv_dgrad(G, Z, c["Wd"], G1, pro, stride, (H, H), epi=c["pro_e"], osums=os2, oR=2, expand=expand_of(c))
+    torch.cuda.synchronize()
+    assert relerr(G1, nhwc(c["ue"].grad)) < 6e-2
+    gs = G1.double().view(-1, C); s = os2.double().sum(0)
+    xhe = nhwc(c["xhe"]).view(-1, C).to(gs.device)
+    assert relerr(s[0], gs.sum(0)) < 1e-3 and relerr(s[1], (gs * xhe).sum(0)) < 1e-3
+    dW = torch.zeros(C, 1, 3, 3, dtype=torch.float32, device=dev)
+    ops.dwconv_wgrad(G, Z, None, c["Wd"], dW, pro, c["pro_e"], stride, expand=expand_of(c))
+    torch.cuda.synchronize()
+    assert relerr(dW, c["Wd_ref"].grad) < 6e-2
+    # the plain input gradient (no mask, no sums) never looks at the conv input: the ordinary kernels, with or without `expand`
+    P0 = torch.empty(B, H, H, C, dtype=DT, device=dev); P1 = torch.empty_like(P0)
+    ops.dwconv_dgrad(G, Z, c["Wd"], P0, pro, stride, (H, H))
+    ops.dwconv_dgrad(G, Z, c["Wd"], P1, pro, stride, (H, H), expand=expand_of(c))
+    torch.cuda.synchronize()
+    assert torch.equal(P0, P1)
+
+
+def test_expand_recompute_refuses_what_it_cannot_do(device):
+    c = build(1, 28, 32, 64, 1, True, "cpu", seed=3)
+    Y = torch.empty(1, 28, 28, 64, dtype=torch.float32, device=device)
+    with pytest.raises(L.SpbError):       # f32 storage has no recompute instance: an error, not a read of a tensor that does not exist
+        ops.dwconv_fwd(None, c["Wd"], Y, c["pro_e"], 1, expand=(c["X"].float(), c["We"].float(), None))
+    X40 = torch.zeros(1, 28, 28, 40, dtype=DT, device=device)
+    with pytest.raises(L.SpbError):       # more than 32 input channels
+        ops.dwconv_fwd(None, c["Wd"], Y.to(DT), c["pro_e"], 1, expand=(X40, torch.zeros(64, 40, dtype=DT, device=device), None))
