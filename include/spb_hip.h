@@ -26,7 +26,8 @@ typedef void* spb_stream_t; /* hipStream_t */
 
 enum { SPB_F32 = 0, SPB_BF16 = 1 };
 enum { SPB_ACT_NONE = 0, SPB_ACT_RELU = 1, SPB_ACT_RELU6 = 2, SPB_ACT_LEAKY = 3 };
-enum { SPB_E_ARG = -1, SPB_E_SHAPE = -2, SPB_E_STATE = -3, SPB_E_UNSUPPORTED = -4 };
+enum { SPB_E_ARG = -1, SPB_E_SHAPE = -2, SPB_E_STATE = -3, SPB_E_UNSUPPORTED = -4,
+       SPB_E_TIMEOUT = -5 /* a stream-fork gate gave up waiting (SPB_FORK_TIMEOUT_S): the object is poisoned, every later call fails */ };
 
 /* A BatchNorm2d (training or eval) between a producer convolution and its consumers.  The producer's epilogue
  * accumulates per-channel batch sums; consumers derive the affine from them in their load prologue.
@@ -304,6 +305,14 @@ int spb_stream_destroy(spb_stream_t stream);
  * stored in order).  Falls back to an event (created without the system-scope fence) inside a stream capture, when SPB_EVENT_FORKS=1
  * is set, and under rocprofv3 counter collection (ROCPROF_COUNTER_COLLECTION=1: kernels are serialised there, a gate would spin
  * forever; it traps after SPB_FORK_TIMEOUT_S seconds -- default 600, 0 = never -- if the storing launch never runs). */
+/* Round 6: the property the device-word forks rest on -- a kernel starts only after every earlier kernel of its stream has completed and
+ * released its results at device scope -- is TESTED once per process when the first KRN context / fork object is created (~1 ms: a
+ * slow producer, a dependent one-wave kernel that stores the word, a gate + checker on a second stream; csrc/elemwise.hip).
+ * spb_fork_selftest() runs it if it has not run and returns 1 (passed: device-word forks), 0 (failed: events for the rest of the
+ * process, one line on stderr), -1 (events forced by SPB_EVENT_FORKS / ROCPROF_COUNTER_COLLECTION).  A gate that gives up after
+ * SPB_FORK_TIMEOUT_S seconds no longer traps: it raises a host-visible poison word and the owner's next call returns SPB_E_TIMEOUT. */
+int spb_fork_selftest(void);
+int spb_hip_runtime_version(void);   /* hipRuntimeGetVersion() of the runtime the library is bound to (bench.py records it) */
 typedef struct spb_fork spb_fork_t;
 int spb_fork_create(spb_fork_t** out);
 void spb_fork_destroy(spb_fork_t* f);
@@ -416,6 +425,9 @@ int spb_krn_ctx_set_side_stream(spb_krn_ctx_t* c, int on);
 int spb_det_available(void);
 int spb_det_register(const float* lo, long long n_floats, long long* shadow);
 int spb_det_unregister(const float* lo);
+int spb_det_unregister_if(const float* lo, const long long* shadow);   /* only if that region still accumulates into `shadow`: an owner releasing
+                                                                          ITS registration (the address may have a later owner by then; registering
+                                                                          a range drops every older region it overlaps) */
 int spb_det_flush(const float* lo, spb_stream_t stream);
 long long spb_det_misses(void);
 int spb_krn_set_det(spb_krn_t* m, int on);

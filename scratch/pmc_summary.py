@@ -19,6 +19,9 @@ def family(name):
         return "dw_fwd"
     if "dwt_dgrad" in name:
         return "dw_dgrad"
+    m = re.search(r"pw_st_kernel<(\d+)", name)                        # streaming kernel of the large maps (gemm_st.hip): forward only (PRO 1 / 3),
+    if m:                                                             # incl. the statistics-only instances of the virtual expand convolutions
+        return "pw_gemm_fwd"
     m = re.search(r"pw_rs_kernel<(\d+)", name)                        # row-slab kernel: PRO leads the template list (1 / 3 forward, 2 input gradient)
     if m:
         return "pw_gemm_dgrad" if int(m.group(1)) == 2 else "pw_gemm_fwd"
@@ -32,7 +35,11 @@ def family(name):
               "in_apply", "style_fc", "final_sigmoid"):
         if k in name:
             return k
-    return "other:" + name[:40]
+    for k in ("fork_gate", "fork_set", "det_flush", "arena_zero", "arena_add", "amp_", "softce", "fillBuffer", "copyBuffer"):
+        if k in name:
+            return "misc:" + k
+    bare = re.sub(r"^void\s+", "", name).replace("(anonymous namespace)::", "")
+    return "other:" + re.sub(r"[<(].*", "", bare)[:40]
 
 def counters(path, counter):
     agg = collections.defaultdict(lambda: [0, 0.0])
@@ -53,6 +60,14 @@ def main(stats_csv, fetch_csv, write_csv, out_json, steps_in_pmc):
         n = max(nf, nw, 1)
         out["families"][fam] = {"launches": n, "fetch_KB_raw_per_launch": round(kbf / max(nf, 1), 2), "write_KB_per_launch": round(kbw / max(nw, 1), 2),
                                 "hbm_bytes_per_launch": round((2 * kbf / max(nf, 1) + kbw / max(nw, 1)) * 1024)}
+    # whole-step HBM traffic: every launch of the PMC passes (steps_in_pmc = timed + warm-up steps of the profiled command; the one-off
+    # launches of engine construction -- weight copies, arena fills -- are a few MB and ride along)
+    tot = sum(2 * v[1] for v in fetch.values()) + sum(v[1] for v in write.values())
+    # passes in the profiled command = optimizer launches (bench.py: warm-up + timed + its 5 instrumented steps), whatever the caller assumed
+    if "optim_step" in fetch and fetch["optim_step"][0] > 0:
+        steps_in_pmc = fetch["optim_step"][0]
+    out["step_hbm_bytes"] = round(tot * 1024 / max(steps_in_pmc, 1))
+    out["steps_in_pmc"] = steps_in_pmc
     with open(out_json, "w") as f:
         json.dump(out, f, indent=1)
     print(json.dumps(out["families"], indent=1)[:3000])

@@ -250,11 +250,14 @@ SYMBOLS = {
     "spb_version": (C.c_char_p, []),
     "spb_krn_num_acts": (i32, [vp]),
     "spb_krn_ctx_act_info": (i32, [vp, i32, C.POINTER(ActInfo)]),
+    "spb_fork_selftest": (i32, []),
+    "spb_hip_runtime_version": (i32, []),
     "spb_krn_ctx_virtual": (i32, [vp, i32]),
     "spb_krn_ctx_materialize": (i32, [vp, vp]),
     "spb_det_available": (i32, []),
     "spb_det_register": (i32, [vp, i64, vp]),
     "spb_det_unregister": (i32, [vp]),
+    "spb_det_unregister_if": (i32, [vp, vp]),
     "spb_det_flush": (i32, [vp, vp]),
     "spb_det_misses": (i64, []),
     "spb_krn_set_det": (i32, [vp, i32]),
@@ -454,6 +457,11 @@ class SpbError(RuntimeError):
     pass
 
 
+_CODES = {-1: "SPB_E_ARG", -2: "SPB_E_SHAPE", -3: "SPB_E_STATE", -4: "SPB_E_UNSUPPORTED",
+          -5: "SPB_E_TIMEOUT: a stream-fork gate gave up after SPB_FORK_TIMEOUT_S seconds (the launch it waited for never ran); "
+              "the context is poisoned -- rebuild the engine"}
+
+
 def check(code, what):
     if code != 0:
-        raise SpbError("%s failed with code %d" % (what, code))
+        raise SpbError("%s failed with code %d%s" % (what, code, (" (%s)" % _CODES[code]) if code in _CODES else ""))

@@ -29,7 +29,7 @@ template <typename P, typename V> __device__ __forceinline__ void spb_no_atomic(
 // Cost: 1-2 integer atomics per float atomic + one flush launch per kernel launch: a test / reproducibility mode, not the bench path.
 #ifdef SPB_DET
 struct spb_det_region_t { const float* lo; const float* hi; long long* shadow; };
-#define SPB_DET_MAX_REGIONS 16
+#define SPB_DET_MAX_REGIONS 64    // one per engine (gradient arena) + one per (batch size, slot) context; KrnEngine.drop_context frees a slot
 struct spb_det_table_t { spb_det_region_t r[SPB_DET_MAX_REGIONS]; int n; int pad; };
 static __device__ spb_det_table_t g_spb_det_table;          // one copy per translation unit (no relocatable device code)
 static __device__ unsigned long long g_spb_det_misses;
@@ -104,7 +104,10 @@ typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 
 // stream forks through a device word (elemwise.hip): store `val` behind everything `s` holds / keep `s` waiting until the word reaches `val`
 void spb_fork_store(unsigned* flag, unsigned val, hipStream_t s);
-void spb_fork_gate(const unsigned* flag, unsigned val, hipStream_t s);
+void spb_fork_gate(const unsigned* flag, unsigned val, hipStream_t s, unsigned* poison_dev);   // poison_dev: see spb_fork_poison_* (elemwise.hip)
+unsigned* spb_fork_poison_alloc();                   // host word a gate raises instead of trapping when it gives up (SPB_FORK_TIMEOUT_S)
+void spb_fork_poison_free(unsigned* host);
+unsigned* spb_fork_poison_dev(unsigned* host);
 bool spb_fork_by_word(hipStream_t from);   // false: order by events (stream capture, SPB_EVENT_FORKS=1, a counter-collecting profiler)
 // spb_dw_args_t::entry_flag (include/spb_hip.h): the first thread of a launch publishes "everything before me on my stream is complete".
 // Any thread would do -- the dispatch sat behind a barrier bit -- and the store needs no fence of its own: the earlier launches' results

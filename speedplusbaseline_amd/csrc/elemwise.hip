@@ -7,6 +7,7 @@
 //       (reference trainer.py:90,97  clip_grad_norm_; build.py:60-78 sgd/rmsprop/adam/adamw)
 #include <cstring>
 #include <cstdlib>
+#include <cstdio>
 #include "common.h"
 #include "optim_math.h"
 
@@ -713,13 +714,21 @@ extern "C" int spb_stream_destroy(spb_stream_t s) {
 __global__ void fork_set_kernel(unsigned* flag, unsigned val) {
   if (threadIdx.x == 0) __hip_atomic_store(flag, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__global__ void fork_gate_kernel(const unsigned* flag, unsigned val, unsigned long long timeout_ticks) {
+// A gate that gives up does NOT trap any more (round 6; a trap kills the GPU context of the whole process, a Python exception is what a
+// caller can handle): it raises the POISON word -- host memory mapped into the device, owned by whoever owns the fork word -- and lets its
+// stream go.  The owner reads the word at its next call (a plain host load) and fails that call with SPB_E_TIMEOUT; what the side
+// stream computed in between is garbage by then, which is why the error is sticky.
+__global__ void fork_gate_kernel(const unsigned* flag, unsigned val, unsigned long long timeout_ticks, unsigned* poison) {
   const unsigned long long t0 = wall_clock64();     // 100 MHz
   while ((int)(__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - val) < 0) {
     __builtin_amdgcn_s_sleep(8);
     // the storing launch never ran (a failed launch in between, or a tool that serialises the device's kernels): fail loudly
     // instead of hanging the device
-    if (timeout_ticks != 0 && wall_clock64() - t0 > timeout_ticks) __builtin_trap();
+    if (timeout_ticks != 0 && wall_clock64() - t0 > timeout_ticks) {
+      if (poison) __hip_atomic_store(poison, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      else __builtin_trap();
+      return;
+    }
   }
 }
 // How long a gate waits before it gives up: the storing launch is already enqueued when the gate is, so the wait is the launch stream's own
@@ -734,9 +743,93 @@ static unsigned long long fork_timeout_ticks() {
   return v;
 }
 void spb_fork_store(unsigned* flag, unsigned val, hipStream_t s) { hipLaunchKernelGGL(fork_set_kernel, dim3(1), dim3(64), 0, s, flag, val); }
-void spb_fork_gate(const unsigned* flag, unsigned val, hipStream_t s) {
-  hipLaunchKernelGGL(fork_gate_kernel, dim3(1), dim3(64), 0, s, flag, val, fork_timeout_ticks());
+void spb_fork_gate(const unsigned* flag, unsigned val, hipStream_t s, unsigned* poison) {
+  hipLaunchKernelGGL(fork_gate_kernel, dim3(1), dim3(64), 0, s, flag, val, fork_timeout_ticks(), poison);
 }
+// the poison word of a fork: 64 bytes of pinned host memory the device can write (hipHostMalloc is mapped by default on this runtime)
+unsigned* spb_fork_poison_alloc() {
+  void* h = nullptr;
+  if (hipHostMalloc(&h, 64, hipHostMallocMapped) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+  std::memset(h, 0, 64);
+  return static_cast<unsigned*>(h);
+}
+void spb_fork_poison_free(unsigned* p) { if (p) (void)hipHostFree(p); }
+unsigned* spb_fork_poison_dev(unsigned* host) {
+  void* d = nullptr;
+  if (!host || hipHostGetDevicePointer(&d, host, 0) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+  return static_cast<unsigned*>(d);
+}
+
+// ---- start-up self-test of the property the device-word forks rest on (round 6) ----------------------------------------------------
+// "The first instruction of launch n + 1 proves launches <= n of its stream complete and their results visible device-wide" holds because
+// this runtime gives every kernel dispatch the AQL barrier bit and device-scope acquire / release fences (read once from AMD_LOG_LEVEL=4
+// output: profiles/r5_fork_aql_headers.txt).  Nothing in the HIP API promises it.  A runtime that dispatched without the barrier bit would
+// turn every fork into a silent race in the weight gradients, so the property is TESTED before the first fork is trusted (at context /
+// fork creation, outside any stream capture, ~1 ms once per process and device):
+//   stream A:  producer (512 workgroups; each thread waits ~20 us, then writes the round's serial into its words of a 2 MB buffer)
+//              -> one-wave kernel whose first thread stores the serial to the fork word      (exactly what spb_publish_entry does)
+//   stream B:  gate on the word -> checker: counts the buffer words that do NOT hold the serial
+// over 6 rounds.  Without the barrier bit the one-wave kernel overtakes the producer (it needs one free slot, the producer's threads sit
+// in their wait), the gate opens and the checker finds stale words.  Any mismatch, or any HIP error on the way: forks are ordered by
+// events for the rest of the process and one line says so on stderr.  SPB_FORK_SELFTEST_FAIL=1 forces the failure (test rig).
+namespace {
+__global__ void forktest_produce_kernel(unsigned* buf, int n, unsigned serial) {
+  const unsigned long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < 2000ull) __builtin_amdgcn_s_sleep(16);        // ~20 us at 100 MHz: the dependent launch has every chance to overtake
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) buf[i] = serial;
+}
+__global__ void forktest_check_kernel(const unsigned* buf, int n, unsigned serial, unsigned* bad) {
+  unsigned miss = 0;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) miss += buf[i] != serial;
+  if (miss) atomicAdd(bad, miss);
+}
+int g_fork_selftest = -2;        // -2 not run yet, -1 events forced by the environment, 0 failed (events), 1 passed (device-word forks)
+}  // namespace
+bool spb_event_forks_forced();
+extern "C" int spb_fork_selftest(void) {
+  if (g_fork_selftest != -2) return g_fork_selftest;
+  if (spb_event_forks_forced()) return g_fork_selftest = -1;
+  const char* ff = std::getenv("SPB_FORK_SELFTEST_FAIL");
+  bool ok = !(ff && ff[0] == '1');
+  constexpr int N = 512 * 1024;
+  unsigned *buf = nullptr, *word = nullptr, *bad = nullptr, *poison = spb_fork_poison_alloc();
+  hipStream_t a = nullptr, b = nullptr;
+  unsigned hbad = 1;
+  if (ok) {
+    ok = hipMalloc(&buf, N * sizeof(unsigned)) == hipSuccess && hipMalloc(&word, 256) == hipSuccess && hipMalloc(&bad, 256) == hipSuccess &&
+         hipMemset(buf, 0, N * sizeof(unsigned)) == hipSuccess && hipMemset(word, 0, 256) == hipSuccess && hipMemset(bad, 0, 256) == hipSuccess &&
+         hipStreamSynchronize(nullptr) == hipSuccess && hipStreamCreateWithFlags(&a, hipStreamNonBlocking) == hipSuccess &&
+         hipStreamCreateWithFlags(&b, hipStreamNonBlocking) == hipSuccess && poison != nullptr;
+    if (ok) {
+      for (unsigned r = 1; r <= 6; ++r) {
+        hipLaunchKernelGGL(forktest_produce_kernel, dim3(512), dim3(256), 0, a, buf, N, r);
+        hipLaunchKernelGGL(fork_set_kernel, dim3(1), dim3(64), 0, a, word, r);
+        hipLaunchKernelGGL(fork_gate_kernel, dim3(1), dim3(64), 0, b, (const unsigned*)word, r, 200000000ull /* 2 s */, spb_fork_poison_dev(poison));
+        hipLaunchKernelGGL(forktest_check_kernel, dim3(256), dim3(256), 0, b, (const unsigned*)buf, N, r, bad);
+      }
+      ok = hipStreamSynchronize(a) == hipSuccess && hipStreamSynchronize(b) == hipSuccess &&
+           hipMemcpy(&hbad, bad, sizeof(unsigned), hipMemcpyDeviceToHost) == hipSuccess && hipGetLastError() == hipSuccess;
+      if (ok) ok = hbad == 0 && *reinterpret_cast<volatile unsigned*>(poison) == 0;
+    }
+  }
+  (void)hipGetLastError();
+  if (a) (void)hipStreamDestroy(a);
+  if (b) (void)hipStreamDestroy(b);
+  if (buf) (void)hipFree(buf);
+  if (word) (void)hipFree(word);
+  if (bad) (void)hipFree(bad);
+  spb_fork_poison_free(poison);
+  g_fork_selftest = ok ? 1 : 0;
+  if (!ok) {
+    int rv = 0; (void)hipRuntimeGetVersion(&rv);
+    std::fprintf(stderr, "speedplusbaseline_amd: the stream-fork self-test FAILED on this HIP runtime (version %d; %u stale words): a dependent "
+                 "launch started before its predecessor's results were visible.  Streams are ordered by events for the rest of this process "
+                 "(as with SPB_EVENT_FORKS=1).\n", rv, hbad);
+  }
+  return g_fork_selftest;
+}
+extern "C" int spb_hip_runtime_version(void) { int v = 0; return hipRuntimeGetVersion(&v) == hipSuccess ? v : -1; }
+
 // Tools that let only ONE kernel of the device run at a time cannot run a spinning gate: the launch it waits for would never start
 // (measured: `rocprofv3 --pmc ...` hangs until the gate's time-out traps).  Streams are ordered by events instead when
 //   * SPB_EVENT_FORKS=1 is in the environment, or
@@ -753,12 +846,12 @@ bool spb_event_forks_forced() {
   return v;
 }
 bool spb_fork_by_word(hipStream_t from) {
-  if (spb_event_forks_forced()) return false;
+  if (spb_event_forks_forced() || g_fork_selftest != 1) return false;   // (never tested -- no context / fork object created yet -- counts as not trusted)
   hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
   return hipStreamIsCapturing(from, &cs) == hipSuccess && cs == hipStreamCaptureStatusNone;
 }
 
-struct spb_fork { unsigned* word = nullptr; unsigned serial = 0; hipEvent_t ev = nullptr; };
+struct spb_fork { unsigned* word = nullptr; unsigned serial = 0; hipEvent_t ev = nullptr; unsigned* poison = nullptr; };
 extern "C" int spb_fork_create(spb_fork_t** out) {
   if (!out) return SPB_E_ARG;
   spb_fork* f = new spb_fork();
@@ -770,6 +863,8 @@ extern "C" int spb_fork_create(spb_fork_t** out) {
     delete f;
     return SPB_E_STATE;
   }
+  f->poison = spb_fork_poison_alloc();
+  (void)spb_fork_selftest();
   *out = f;
   return 0;
 }
@@ -777,16 +872,18 @@ extern "C" void spb_fork_destroy(spb_fork_t* f) {
   if (!f) return;
   if (f->word) hipFree(f->word);
   if (f->ev) hipEventDestroy(f->ev);
+  spb_fork_poison_free(f->poison);
   delete f;
 }
 extern "C" int spb_fork_streams(spb_fork_t* f, spb_stream_t from, spb_stream_t to) {
   if (!f) return SPB_E_ARG;
   hipStream_t a = (hipStream_t)from, b = (hipStream_t)to;
   if (a == b) return 0;
+  if (f->poison && *reinterpret_cast<volatile unsigned*>(f->poison)) return SPB_E_TIMEOUT;   // an earlier gate of this fork gave up (sticky)
   if (spb_fork_by_word(a)) {
     const unsigned serial = ++f->serial;
     spb_fork_store(f->word, serial, a);
-    spb_fork_gate(f->word, serial, b);
+    spb_fork_gate(f->word, serial, b, spb_fork_poison_dev(f->poison));
   } else {
     if (hipEventRecord(f->ev, a) != hipSuccess || hipStreamWaitEvent(b, f->ev, 0) != hipSuccess) return SPB_E_STATE;
   }

@@ -32,6 +32,10 @@ namespace {
 // bytes.  The first column split also writes the convolution's OPERAND round16(act(bn(A))) to Ymat when one is given (PRO 3: the residual
 // join, always): the recomputing kernels then read it as it is instead of redoing the BatchNorm per use (measured: with the affine in
 // their staging loops the depthwise forward kernels were 10 us slower than unfused; each input element is staged 8-10 times there).
+// The pass is bound by vector-instruction issue, not by bytes in flight: ~90 wave instructions per 16-row chunk and column split (a wave64
+// instruction holds a SIMD for 4 cycles; with 16 input channels half of the lanes of every operand instruction carry padding).  Measured:
+// a six-chunk register ring instead of two chunks in flight made the 112x112 launch SLOWER (23 -> 30 us: 154 registers, two waves per
+// SIMD); one column split of 96 channels instead of two of 48 halves the operand work of that launch.
 template <int PRO, int NJ, int KS, bool SO = false>
 __global__ __launch_bounds__(256) void pw_st_kernel(const spb_gemm_args_t g, int nsplit, long long nchunks) {
   constexpr int KP = 32 * KS, NW = 16 * NJ, NP = NJ / 2;
@@ -97,6 +101,7 @@ __global__ __launch_bounds__(256) void pw_st_kernel(const spb_gemm_args_t g, int
 #pragma unroll
     for (int r = 0; r < 4; ++r) { s1[j][r] = 0.f; s2[j][r] = 0.f; }
   const float act_h = act_hi(g.pro.act), act_n = act_ns(g.pro.act, g.pro.slope);
+  const bool act_none = g.pro.act == SPB_ACT_NONE;
 
   // the B fragment of reduction step ks of a chunk from the raw 16-byte vector(s): BatchNorm + activation (or the join) in registers
   auto frag = [&](int ks, long long m, bool rowok, uint4 va, uint4 vb) __attribute__((always_inline)) {
@@ -113,7 +118,7 @@ __global__ __launch_bounds__(256) void pw_st_kernel(const spb_gemm_args_t g, int
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const float u = a[j] * c0[j] + c1[j];
-        x[j] = __builtin_amdgcn_fmed3f(u, 0.f, act_h) + act_n * fminf(u, 0.f);
+        x[j] = (SO && act_none) ? u : __builtin_amdgcn_fmed3f(u, 0.f, act_h) + act_n * fminf(u, 0.f);   // (uniform; block inputs are linear)
       }
     } else {
       Raw8<bf16_t> r2; r2.u = vb;
@@ -285,6 +290,7 @@ int spb_gemm_st(const spb_gemm_args_t* a, hipStream_t stream) {
                            // waves per SIMD: 20-25 us per launch, measured) for rows that are L2 hits anyway
     if ((a->N % 48) || a->N > 192 || (a->K & 7) || a->K > 32 || a->epi_mode != 1 || (a->pro_mode != 1 && a->pro_mode != 3)) return SPB_E_UNSUPPORTED;
     if (a->bias != nullptr || a->res != nullptr || (a->lda > 0 && a->lda != a->K)) return SPB_E_UNSUPPORTED;
+    if (a->N == 96 && a->pro_mode == 1) return launch_st<1, 6, 1, true>(*a, stream);     // 16 -> 96 at 112x112: one split
     return a->pro_mode == 3 ? launch_st<3, 3, 1, true>(*a, stream) : launch_st<1, 3, 1, true>(*a, stream);
   }
   if (!g_st_on || a->M < g_st_min_m || (a->N & 7) || (a->K & 7)) return SPB_E_UNSUPPORTED;

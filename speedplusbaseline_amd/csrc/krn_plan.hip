@@ -139,6 +139,7 @@ struct spb_krn_ctx {
   // forks ordered by a device word instead of an event (see fork_gate_kernel): the word and the serial number of the last fork
   unsigned* fork_flag = nullptr;
   unsigned fork_serial = 0;
+  unsigned* fork_poison = nullptr;  // host word (device-mapped) a gate raises when it gives up instead of trapping: checked at every entry
   bool det = false;                 // spb_krn_ctx_set_det: this context's batch-sum arena has an exact-accumulation shadow
   const float* loss_scale = nullptr;   // spb_krn_ctx_set_loss_scale: device scalar multiplied onto the upstream gradient (float16 recipe)
   ~spb_krn_ctx() {
@@ -149,7 +150,9 @@ struct spb_krn_ctx {
     if (prep_ev) hipEventDestroy(prep_ev);
     if (side) hipStreamDestroy(side);
     if (fork_flag) hipFree(fork_flag);
+    spb_fork_poison_free(fork_poison);
   }
+  bool poisoned() const { return fork_poison && *reinterpret_cast<volatile unsigned*>(fork_poison) != 0; }
 };
 
 enum ProfCat { PC_STEM_FWD = 0, PC_PW_FWD, PC_DW_FWD, PC_BN_APPLY, PC_HEAD_FWD, PC_BN_UPDATE, PC_HEAD_BWD, PC_PW_DGRAD,
@@ -289,7 +292,14 @@ extern "C" int spb_det_available(void) { return 1; }
 extern "C" int spb_det_register(const float* lo, long long n_floats, long long* shadow) {
   if (!lo || n_floats <= 0 || !shadow) return SPB_E_ARG;
   spb_det_table_t& t = det_table();
-  for (int i = 0; i < t.n; ++i) if (t.r[i].lo == lo) { t.r[i].hi = lo + n_floats; t.r[i].shadow = shadow; return det_upload(); }
+  // a region that overlaps the new one is STALE: its memory went back to the caller's allocator and came out again (an engine that is
+  // garbage but not collected yet -- its owner unregisters with spb_det_unregister_if, which then finds nothing).  Left in the table it
+  // would catch the new owner's atomics first and accumulate them into a dead shadow: two "reproducible" runs of one process differed
+  // (tests/test_surface_gpu.py::test_deterministic_module_generic_autograd_path, round 6)
+  for (int i = 0; i < t.n;) {
+    if (t.r[i].lo < lo + n_floats && lo < t.r[i].hi) { for (int j = i + 1; j < t.n; ++j) t.r[j - 1] = t.r[j]; t.n--; }
+    else ++i;
+  }
   if (t.n >= SPB_DET_MAX_REGIONS) return SPB_E_STATE;
   t.r[t.n].lo = lo; t.r[t.n].hi = lo + n_floats; t.r[t.n].shadow = shadow; t.n++;
   return det_upload();
@@ -299,6 +309,13 @@ extern "C" int spb_det_unregister(const float* lo) {
   for (int i = 0; i < t.n; ++i)
     if (t.r[i].lo == lo) { for (int j = i + 1; j < t.n; ++j) t.r[j - 1] = t.r[j]; t.n--; return det_upload(); }
   return SPB_E_ARG;
+}
+// the same, but only if the region at `lo` still accumulates into `shadow` (the caller's own registration, not a later owner of the address)
+extern "C" int spb_det_unregister_if(const float* lo, const long long* shadow) {
+  spb_det_table_t& t = det_table();
+  for (int i = 0; i < t.n; ++i)
+    if (t.r[i].lo == lo && t.r[i].shadow == shadow) { for (int j = i + 1; j < t.n; ++j) t.r[j - 1] = t.r[j]; t.n--; return det_upload(); }
+  return 0;
 }
 extern "C" int spb_det_flush(const float* lo, spb_stream_t stream) { return det_flush(lo, (hipStream_t)stream); }
 extern "C" long long spb_det_misses(void) {   // float atomics that found no region since the last call (synchronises the device)
@@ -311,6 +328,7 @@ extern "C" long long spb_det_misses(void) {   // float atomics that found no reg
 extern "C" int spb_det_available(void) { return 0; }
 extern "C" int spb_det_register(const float*, long long, long long*) { return SPB_E_UNSUPPORTED; }
 extern "C" int spb_det_unregister(const float*) { return SPB_E_UNSUPPORTED; }
+extern "C" int spb_det_unregister_if(const float*, const long long*) { return SPB_E_UNSUPPORTED; }
 extern "C" int spb_det_flush(const float*, spb_stream_t) { return SPB_E_UNSUPPORTED; }
 extern "C" long long spb_det_misses(void) { return SPB_E_UNSUPPORTED; }
 #endif
@@ -645,7 +663,7 @@ struct Runner {
   }
   bool side_usable() const { return !(c->prof_on || !c->side || !c->side_on || !g_side_wgrad || c->det || m->det); }
   void gate_side(unsigned serial) {   // the side stream waits until the context's fork word reaches `serial`
-    spb_fork_gate(c->fork_flag, serial, c->side);
+    spb_fork_gate(c->fork_flag, serial, c->side, spb_fork_poison_dev(c->fork_poison));
     forked = true;
   }
   hipStream_t side_stream() {
@@ -752,9 +770,15 @@ struct Runner {
     if (entry_fork) { d.entry_flag = c->fork_flag; d.entry_val = ++c->fork_serial; }
     if (!entry_fork && !g_flush_after_dw && flush_due) flush_wgrads();
     tic(PC_DW_DGRAD, (2 * nout + nin + nzin + (res ? nin : 0)) * es(), 36.0 * nout);
-    ok(spb_dwconv_dgrad(dt, &d, st));
+    const int dwe = spb_dwconv_dgrad(dt, &d, st);
+    ok(dwe);
     toc();
-    if (entry_fork) { gate_side(d.entry_val); gated = true; flush_wgrads(); }
+    if (entry_fork) {
+      // the entry returned an error before (or instead of) launching: nobody will store the serial -- publish it with the one-wave
+      // kernel so that the gate passes and the error comes back as an error, not as a side stream spinning into its time-out
+      if (dwe != 0) spb_fork_store(c->fork_flag, d.entry_val, st);
+      gate_side(d.entry_val); gated = true; flush_wgrads();
+    }
     if (split && c->prof_on) {
       tic(PC_DW_WGRAD, (2 * nout + nzin) * es() + 36.0 * L.C, 18.0 * nout);
       ok(spb_dwconv_wgrad(dt, &dwg, st));
@@ -1158,6 +1182,8 @@ extern "C" int spb_krn_ctx_create(spb_krn_t* m, int batch, void* workspace, spb_
   if (hipMalloc(&c->fork_flag, 256) != hipSuccess || hipMemset(c->fork_flag, 0, 256) != hipSuccess || hipStreamSynchronize(nullptr) != hipSuccess) {
     delete c; return SPB_E_STATE;
   }
+  c->fork_poison = spb_fork_poison_alloc();
+  (void)spb_fork_selftest();   // once per process: is "the next launch's first instruction proves the earlier ones complete" true here? (elemwise.hip)
   if (hipEventCreateWithFlags(&c->join_ev, g_stream_event_flags) != hipSuccess) { delete c; return SPB_E_STATE; }
   if (hipEventCreateWithFlags(&c->bucket_ev, hipEventDisableTiming) != hipSuccess) { delete c; return SPB_E_STATE; }
   if (hipEventCreateWithFlags(&c->prep_ev, g_stream_event_flags) != hipSuccess) { delete c; return SPB_E_STATE; }
@@ -1192,6 +1218,7 @@ extern "C" int spb_krn_forward(spb_krn_ctx_t* c, const float* x, const float* ta
                                float* scalars, float* domain_logits, spb_stream_t stream) {
   if (!c || !x || !pred) return SPB_E_ARG;
   if (target && !scalars) return SPB_E_ARG;
+  if (c->poisoned()) return SPB_E_TIMEOUT;
   spb_krn* m = c->m;
   hipStream_t st = (hipStream_t)stream;
   Runner r(c, st);
@@ -1400,6 +1427,7 @@ extern "C" int spb_bce_logits(const float* logits, float label, int B, float* lo
 extern "C" int spb_krn_backward(spb_krn_ctx_t* c, float* grads, float gscale, int with_pose, const float* dlogit,
                                 float alpha, spb_stream_t stream) {
   if (!c) return SPB_E_ARG;
+  if (c->poisoned()) return SPB_E_TIMEOUT;
   spb_krn* m = c->m;
   float* const bound_G = m->G;
   if (grads) m->G = grads;

@@ -76,8 +76,8 @@ class KrnEngine:
         self._det_regions[ptr] = shadow
 
     def _det_release(self):
-        for ptr in list(getattr(self, "_det_regions", {})):
-            self.lib.spb_det_unregister(C.c_void_p(ptr))
+        for ptr, shadow in list(getattr(self, "_det_regions", {}).items()):
+            self.lib.spb_det_unregister_if(C.c_void_p(ptr), _p(shadow))    # (only OUR registration: the address may have a new owner by now)
         self._det_regions = {}
 
     def det_misses(self):
@@ -97,6 +97,7 @@ class KrnEngine:
             self.lib.spb_krn_ctx_destroy(h)
         self._ctx = {}
         half = isinstance(precision, str) and precision in HALF
+        keep_amp = self.amp.detach().cpu() if (half and self.half and self.amp is not None) else None   # re-attach in the same precision
         if half != self.half:            # the 16-bit format is a compile-time property of the library: rebuild the plan handle on the other build
             if half and self.deterministic:
                 raise RuntimeError("the reproducible library has no float16 build")
@@ -126,6 +127,8 @@ class KrnEngine:
                 self.amp = torch.zeros(L.AMP_STATE, dtype=torch.float32, device=device)
                 self.amp[L.AMP_SCALE] = 65536.0
                 self.amp[L.AMP_INV_SCALE] = 1.0 / 65536.0
+                if keep_amp is not None:      # a second model.to() (or a device move) must not reset the loss scale / step count
+                    self.amp.copy_(keep_amp.to(device))
         return self
 
     def param_view(self, info, arena=None):
@@ -153,6 +156,20 @@ class KrnEngine:
                     L.check(self.lib.spb_krn_ctx_set_loss_scale(h, C.c_void_p(self.amp.data_ptr() + 4 * L.AMP_SCALE)), "spb_krn_ctx_set_loss_scale")
             self._ctx[key] = (h, ws)
         return self._ctx[key][0]
+
+    def drop_context(self, batch, slot=0):
+        """free the workspace of one (batch size, slot) context -- and, in reproducible mode, its region of the library's exact-
+        accumulation table (64 regions per process: runs with many distinct batch sizes would exhaust it otherwise)"""
+        key = (int(batch), int(slot))
+        if key in self._ctx:
+            h, _ws = self._ctx.pop(key)
+            if self.deterministic:
+                sp, sn = C.c_void_p(), C.c_longlong()
+                if self.lib.spb_krn_ctx_stats(h, C.byref(sp), C.byref(sn)) == 0 and sp.value in self._det_regions:
+                    torch.cuda.synchronize(self.device)
+                    self.lib.spb_det_unregister_if(C.c_void_p(sp.value), _p(self._det_regions[sp.value]))
+                    del self._det_regions[sp.value]
+            self.lib.spb_krn_ctx_destroy(h)
 
     # ------------------------------------------------------------------------------------------------ passes
     def _check_input(self, x):
@@ -234,12 +251,26 @@ class KrnEngine:
         h, ws = self._ctx[(int(batch), int(slot))]
         dt = (torch.float16 if self.half else torch.bfloat16) if self.dtype_code == L.BF16 else torch.float32
         es = 2 if self.dtype_code == L.BF16 else 4
+        # 16-bit modes: the expanded tensors of blocks 2-4 are virtual (never stored; csrc/krn_plan.hip, Runner::virt) -- written out here,
+        # rounded to the storage type, from the operands the forward pass kept (virtual_activations() names them)
+        L.check(self.lib.spb_krn_ctx_materialize(h, _stream()), "spb_krn_ctx_materialize")
         out, ai = {}, L.ActInfo()
         for a in range(self.lib.spb_krn_num_acts(self.h)):
             L.check(self.lib.spb_krn_ctx_act_info(h, a, C.byref(ai)), "spb_krn_ctx_act_info")
             n = int(batch) * ai.H * ai.W * ai.C
             z = ws[ai.z_off: ai.z_off + n * es].view(dt).view(int(batch), ai.H, ai.W, ai.C).permute(0, 3, 1, 2)
             out[self.bn_names[ai.bn_index][: -len(".num_batches_tracked")]] = z
+        return out
+
+    def virtual_activations(self, batch, slot=0):
+        """names (as in activations()) of the BatchNorm'd tensors that exist only as batch sums in this context: every kernel that needs
+        their values recomputes them on the matrix cores from the expand convolution's input (spb_dw_args_t::Xe)"""
+        h, _ = self._ctx[(int(batch), int(slot))]
+        ai, out = L.ActInfo(), []
+        for a in range(self.lib.spb_krn_num_acts(self.h)):
+            if self.lib.spb_krn_ctx_virtual(h, a) == 1:
+                L.check(self.lib.spb_krn_ctx_act_info(h, a, C.byref(ai)), "spb_krn_ctx_act_info")
+                out.append(self.bn_names[ai.bn_index][: -len(".num_batches_tracked")])
         return out
 
     def use_loss_scale(self, batch, slot=0, on=True):

@@ -163,6 +163,22 @@ class HipBackedMixin:
         return eng
 
 
+def _backward_arena(eng):
+    """Gradient arena of one generic-path backward pass.  Reproducible engines accumulate exactly only into regions registered with the
+    library (spb_det_register): the bound arena `eng.grads`, so that is where the pass runs there -- an unregistered temporary made
+    every float atomic a counted miss and the plan's flush fail with SPB_E_STATE -- and the result is copied out."""
+    if eng.deterministic:
+        eng.grads.zero_()
+        return eng.grads
+    return torch.zeros_like(eng.params)
+
+
+def _grad_views(eng, arena):
+    if arena is eng.grads:
+        arena = arena.clone()
+    return tuple(eng.param_view(i, arena) for i in eng.param_infos)
+
+
 class _KrnLossFn(torch.autograd.Function):
     """autograd bridge of the generic path (loss.backward() with any torch optimizer): one HIP forward, one HIP backward"""
 
@@ -176,13 +192,13 @@ class _KrnLossFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gloss, glxy, gpred):
         eng = ctx.module.engine()
-        arena = torch.zeros_like(eng.params)
+        arena = _backward_arena(eng)
         eng.use_loss_scale(ctx.B, 0, False)       # float16: the upstream gradient (the caller's scaler.scale(loss)) carries the scale here
         try:
             eng.backward(ctx.B, slot=0, grads=arena, gscale=float(gloss))
         finally:
             eng.use_loss_scale(ctx.B, 0, True)
-        return (None, None, None) + tuple(eng.param_view(i, arena) for i in eng.param_infos)
+        return (None, None, None) + _grad_views(eng, arena)
 
 
 class KeypointRegressionNet(HipBackedMixin, nn.Module):

@@ -8,7 +8,7 @@ input-gradient GEMM (out_scale = -alpha), and the forward hook on net.base[-1] i
 import torch
 import torch.nn as nn
 
-from .park2019 import HipBackedMixin, KeypointRegressionNet
+from .park2019 import HipBackedMixin, KeypointRegressionNet, _backward_arena, _grad_views
 
 
 class GradientReversalFunction(torch.autograd.Function):
@@ -37,11 +37,11 @@ class _RevGradFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gloss, glxy, gpred, gdom):
         eng = ctx.module.engine()
-        arena = torch.zeros_like(eng.params)
+        arena = _backward_arena(eng)              # (reproducible engines: the registered arena, see park2019._backward_arena)
         dl = gdom.contiguous().float() if gdom is not None else torch.zeros(ctx.B, device=arena.device)
         eng.backward(ctx.B, slot=ctx.slot, grads=arena, gscale=float(gloss) if ctx.pose else 0.0, with_pose=ctx.pose,
                      dlogit=dl, alpha=ctx.alpha)
-        return (None, None, None, None, None) + tuple(eng.param_view(i, arena) for i in eng.param_infos)
+        return (None, None, None, None, None) + _grad_views(eng, arena)
 
 
 class RevGrad(HipBackedMixin, nn.Module):

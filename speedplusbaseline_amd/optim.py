@@ -10,6 +10,7 @@ Two ways in:
 """
 import torch
 
+from . import _lib as L
 from .step import FusedTrainStep
 
 
@@ -134,9 +135,11 @@ class FusedOptimizer(torch.optim.Optimizer):
 
     def _load_into(self, ts, state):
         eng = ts.e
+        had_amp = False
         if self._pending_amp is not None and getattr(eng, "amp", None) is not None:
             eng.amp.copy_(self._pending_amp.to(eng.amp.device))
             self._pending_amp = None
+            had_amp = True
         names = {id(p): n for n, p in self._model.named_parameters()}
         infos = {i[0]: i for i in eng.param_infos}
         for idx, p in enumerate(self.param_groups[0]["params"]):
@@ -148,6 +151,11 @@ class FusedOptimizer(torch.optim.Optimizer):
             for key, arena in (("exp_avg", ts.m), ("exp_avg_sq", ts.v), ("square_avg", ts.v), ("momentum_buffer", ts.m)):
                 if key in st and st[key] is not None:
                     eng.param_view(info, arena).copy_(st[key].to(arena.device))
+        # float16 run resumed from a checkpoint WITHOUT GradScaler state (written by a bf16 / fp32 run, or by the reference): the Adam bias
+        # corrections follow the device-side count of steps actually taken (AMP_STEPS) -- seed it from the loaded step, or warm moments
+        # would meet the corrections of step 1 and inflate the first updates
+        if not had_amp and getattr(eng, "amp", None) is not None and ts.t > 0:
+            eng.amp[L.AMP_STEPS] = float(ts.t)
 
 
 class SpnOptimizer(torch.optim.Optimizer):

@@ -113,8 +113,11 @@ def init_job(use_cuda=True):
     if not dist.is_initialized():
         # a generous collective timeout: rank 0 alone validates / writes checkpoints between epochs while the others wait in a barrier
         import datetime
-        dist.init_process_group(backend, rank=rank, world_size=world,
-                                timeout=datetime.timedelta(minutes=int(os.environ.get("SPB_DIST_TIMEOUT_MIN", "120"))))
+        tmin = int(os.environ.get("SPB_DIST_TIMEOUT_MIN", "120"))
+        # the library's stream-fork gates (csrc/elemwise.hip) may sit behind a launch stream that holds a collective waiting for a late
+        # peer: they must not give up before the process group itself would (default 600 s, read once when the first gate is enqueued)
+        os.environ.setdefault("SPB_FORK_TIMEOUT_S", str(60 * tmin + 60))
+        dist.init_process_group(backend, rank=rank, world_size=world, timeout=datetime.timedelta(minutes=tmin))
     return Job(rank, world, device, dist.group.WORLD)
 
 

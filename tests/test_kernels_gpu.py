@@ -841,3 +841,77 @@ def test_stream_fork_orders_the_second_stream(device):
     fork(a, a)                          # same stream on both sides: nothing to order
     import copy
     assert isinstance(copy.deepcopy(fork), ops.StreamFork)
+
+
+_FORK_CHILD = r"""
+import sys, torch
+sys.path.insert(0, %r)
+from speedplusbaseline_amd import _lib as L, ops
+dev = torch.device("cuda:0")
+fork = ops.StreamFork()
+a, b = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+x = torch.zeros(4 << 20, device=dev)
+mode = sys.argv[1]
+if mode == "fallback":
+    for i in range(10):
+        with torch.cuda.stream(a):
+            x.add_(1.0); x.add_(1.0)
+            fork(b)
+        with torch.cuda.stream(b):
+            y = x.clone()
+        a.wait_stream(b)
+    torch.cuda.synchronize()
+    assert float(y.min()) == 20.0 and float(y.max()) == 20.0, (float(y.min()), float(y.max()))
+    print("SELFTEST", L.lib().spb_fork_selftest())
+else:                                   # time-out: the storing kernel sits behind ~0.4 s of work, the gate gives up after 0.1 s
+    big = torch.zeros(256 << 20, device=dev)
+    with torch.cuda.stream(a):
+        fork(b)                         # creates the native fork object (its creation synchronises the device) before the backlog exists
+    torch.cuda.synchronize()
+    with torch.cuda.stream(a):
+        for _ in range(800):
+            big.add_(1.0)
+        fork(b)
+    torch.cuda.synchronize()
+    print("SELFTEST", L.lib().spb_fork_selftest())
+    try:
+        with torch.cuda.stream(a):
+            fork(b)
+        print("NO ERROR")
+    except L.SpbError as e:
+        print("ERROR", e)
+    torch.cuda.synchronize()
+    print("ALIVE", float(x.sum()))      # the device context survived (the old gate trapped: every later call failed)
+"""
+
+
+def _fork_child(mode, env):
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = dict(os.environ); e.update(env)
+    return subprocess.run([sys.executable, "-c", _FORK_CHILD % root, mode], env=e, capture_output=True, text=True, timeout=600)
+
+
+def test_stream_fork_selftest_passes_on_this_runtime(device):
+    """the property the device-word forks rest on (a kernel starts only after its stream's earlier kernels completed and released their
+    results device-wide) is tested at start-up, csrc/elemwise.hip spb_fork_selftest: on this runtime it holds"""
+    ops.StreamFork()(torch.cuda.Stream(device=device))          # creates a fork object -> runs the self-test
+    assert L.lib().spb_fork_selftest() in (1, -1)               # (-1: events forced by SPB_EVENT_FORKS / a counter-collecting profiler)
+    assert L.lib().spb_hip_runtime_version() > 0
+
+
+def test_stream_fork_selftest_failure_falls_back_to_events(device):
+    """SPB_FORK_SELFTEST_FAIL=1 (test rig): the library says so once on stderr, orders streams by events and still orders them"""
+    r = _fork_child("fallback", {"SPB_FORK_SELFTEST_FAIL": "1"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "SELFTEST 0" in r.stdout and "self-test FAILED" in r.stderr and r.stderr.count("self-test FAILED") == 1
+
+
+def test_stream_fork_gate_timeout_poisons_instead_of_trapping(device):
+    """a gate whose storing launch does not run within SPB_FORK_TIMEOUT_S raises the fork's poison word: the next call on that fork
+    fails with SPB_E_TIMEOUT (a Python exception) and the device context stays usable"""
+    r = _fork_child("timeout", {"SPB_FORK_TIMEOUT_S": "0.1"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "SELFTEST 1" in r.stdout
+    assert "ERROR" in r.stdout and "SPB_E_TIMEOUT" in r.stdout and "NO ERROR" not in r.stdout
+    assert "ALIVE 0.0" in r.stdout
