@@ -618,7 +618,11 @@ struct Runner {
           4.0 * f.M * L.K * L.N);     // (K <= 32: z is recomputed, not read)
       const int e = spb_pwconv_bwd_fused(dt, &f, st);
       toc();
-      if (e == 0) return;
+      // (ok(0): in the reproducible build this is also the point where the launch's exact batch sums are folded into the float slots the
+      // NEXT launch reads.  Round 6: the early return skipped it, so the depthwise backward of blocks 1-3 rebuilt dz from backward sums
+      // that were still zero -- the reproducible bf16 pass was a different (wrong) gradient: BatchNorm weights of the first layers 8-17x
+      // too large, end-to-end cosine 0.981 where the float-atomic passes had 0.990.  f32 never takes this branch.)
+      if (e == 0) { ok(0); return; }
       if (virt_out) { ok(e); return; }   // no other kernel can stand in: z does not exist
       if (e != SPB_E_UNSUPPORTED) { ok(e); return; }
       if (c->prof_on) c->prof_n--;   // no fused instance for this shape: drop the empty timing record

@@ -343,10 +343,63 @@ def test_bf16_train_pass_tracks_float64_oracle_at_bs48(device, conditioned):
     print("eight lowest per-tensor cosines of the last pass among tensors above 1e-3 of |g| (cosine, norm ratio, tensor): "
           + "; ".join("%.3f %.2f %s" % t for t in per[:8]))
     assert torch.equal(g_det, g_det2) and torch.equal(sx, sx2)                 # one state, one batch -> one gradient
-    # measured on this (reproducible) state: mean 0.990 / 1.023, singles 0.985 .. 0.991 / 1.015 .. 1.036, exact accumulation 0.981 / 1.027
+    # measured on this (reproducible) state, round 6: mean 0.993 / 1.016, singles 0.991 .. 0.994 / 1.009 .. 1.026, exact accumulation 0.991 / 1.022
+    # (round 5: 0.990 / 1.023, 0.985 .. 0.991, and 0.981 for the exact pass -- which then lacked a flush, see the per-tensor test below)
     assert cos >= 0.97 and 0.9 <= ratio <= 1.1, (cos, ratio)
     assert min(c for c, _ in single) >= 0.95 and all(0.9 <= r_ <= 1.1 for _, r_ in single), single
-    assert cos_d >= 0.95 and 0.9 <= ratio_d <= 1.1, (cos_d, ratio_d)
+    assert cos_d >= 0.97 and 0.9 <= ratio_d <= 1.1, (cos_d, ratio_d)
+
+
+def _per_tensor(g, g_ref, sd, names, floor_share=1e-3):
+    gn, off, per = float(g_ref.norm()), 0, []
+    for k in names:
+        n = sd[k].numel()
+        a, b = g[off: off + n], g_ref[off: off + n]
+        off += n
+        if float(b.norm()) > floor_share * gn:
+            per.append((_cos(a, b), float(a.norm() / b.norm()), k))
+    return sorted(per)
+
+
+# bars of the test below; measured values in its docstring
+PER_TENSOR_FLOOR_CLEAN = 0.50
+E2E_FLOOR_CLUTTERED = 0.05
+
+
+def test_bf16_end_to_end_per_tensor_floor_and_chaotic_state_bar(device, conditioned, conditioned_cluttered):
+    """Round-5 review, "parity soft spots": (1) on the well-conditioned state the end-to-end bf16 gradient was only held as a whole (cosine
+    0.99, carried by the large tensors) while the first BatchNorm affines sat at 0.56-0.63; (2) on the chaotic state nothing was asserted
+    end to end.  Both are asserted here on the EXACT-ACCUMULATION bf16 pass -- one state, one batch, one bit-reproducible gradient per
+    build, so the bars carry no run-to-run noise:
+      * clean state: every tensor above 1e-3 of |g| has cosine >= PER_TENSOR_FLOOR_CLEAN to float64 (measured: lowest 0.653
+        base.2.conv.0.1.weight, then 0.695 / 0.708 / 0.733; whole gradient 0.9912 / ratio 1.022);
+      * chaotic state: the end-to-end cosine is POSITIVE (>= E2E_FLOOR_CLUTTERED).  It cannot be held higher honestly: the same kernels on
+        the same state and batch give 0.474 with float atomics (the forced-forward test above prints it) and 0.200 with exact accumulation
+        -- the two passes differ by the rounding of a few thousand float additions, and this state turns that into a different gradient.
+        What IS held on this state is the backward pass through the stored forward state (cosine >= 0.999, test above) and the float16
+        build end to end (>= 0.93, measured 0.985).  PyTorch's CPU bf16 autocast of the oracle reaches 0.84 on it
+        (profiles/r5_bf16_state_analysis.txt); closing that gap needs less rounding at the 112x112 / 56x56 maps than bf16 storage has
+        (DESIGN.md section 4).
+    Round 6 on the way: (a) the expanded tensors of blocks 2-4 (96 channels at 112x112, 144 at 56x56 twice) are no longer stored or rounded
+    -- the kernels recompute them in f32 (csrc/krn_plan.hip, Runner::virt); (b) THIS test found a bug of the reproducible build: the fused
+    pointwise backward returned without folding its exact batch sums, so the depthwise backward of blocks 1-3 rebuilt dz from zero sums
+    (BatchNorm weight gradients of the first layers 8-17x too large, whole-gradient cosine 0.983 instead of 0.991; f32 unaffected)."""
+    det = KrnEngine(K, deterministic=True).attach(device, "bf16")
+    out = {}
+    for which, state, noise in (("clean", conditioned, CLEAN), ("cluttered", conditioned_cluttered, CLUTTERED)):
+        x, y = structured_batch(B, 8, noise=noise)
+        y = (y + TARGET_SHIFT).clamp(0, 1.2)
+        _, g_ref, sd, names = _oracle_grad(state, x, y)
+        _, g_det, _ = _hip_grad(det, state, x, y, device)
+        # (_hip_grad returns the arena in the plan's parameter order == state-dict order of `names`)
+        assert [i[0] for i in det.param_infos] == list(names)
+        per = _per_tensor(g_det, g_ref, sd, names)
+        out[which] = (_cos(g_det, g_ref), float(g_det.norm() / g_ref.norm()), per)
+        print("%s state, exact-accumulation bf16 pass END TO END vs float64: cosine %.4f, norm ratio %.4f; lowest per-tensor cosines (tensors above "
+              "1e-3 of |g|): %s" % (which, out[which][0], out[which][1], "; ".join("%.3f %.2f %s" % t for t in per[:6])))
+    assert out["clean"][2][0][0] >= PER_TENSOR_FLOOR_CLEAN, out["clean"][2][:4]
+    assert out["clean"][0] >= 0.95
+    assert out["cluttered"][0] >= E2E_FLOOR_CLUTTERED, out["cluttered"][:2]
 
 
 def test_bf16_dann_step_overlapped_streams_vs_oracle(device, conditioned_dann):
