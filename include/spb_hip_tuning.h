@@ -63,6 +63,7 @@ int spb_debug_set_gemm_os(int on, int min_k, int max_n, int min_m); /* small-map
 int spb_debug_set_gemm_sk(int on, int min_k, int rf); /* small-M bf16 GEMMs with K >= min_k (default 192): split-K-over-waves kernel (on=1, default); rf > 0 forces 16*rf-row tiles */
 int spb_debug_set_gemm_st(int on, int min_m, int wgs); /* forward 1x1 GEMMs with M >= min_m (100000: the 112x112 / 56x56 maps), K <= 160, N in {16, 24, 32, 48k}: streaming kernel (gemm_st.hip; on=1, default); wgs: persistent workgroups (1280) */
 int spb_debug_set_fuse_expand(int min_width); /* KRN plan: expand -> depthwise fusion with recompute for inverted-residual blocks whose map is at least min_width wide and whose expand input has <= 32 channels (56, default: blocks 2-4; 28: blocks 2-7 need the pointwise backward's recompute too and are not wired; 0: off) */
+int spb_debug_set_router_side(int on); /* KRN plan: the RouterV2 branch (forward: 1x1 + reorg; backward: un-reorg + input gradient) on the side stream beside the 7x7 chain (1, default) or inside the chain (0) */
 #ifdef __cplusplus
 }
 #endif

@@ -295,6 +295,7 @@ TUNING_SYMBOLS = {
     "spb_debug_set_gemm_rs": (i32, [i32, i32]),
     "spb_debug_set_gemm_st": (i32, [i32, i32, i32]),
     "spb_debug_set_fuse_expand": (i32, [i32]),
+    "spb_debug_set_router_side": (i32, [i32]),
     "spb_debug_set_gemm_wg_cap": (i32, [i32]),
     "spb_debug_set_bn_bwd_prep_rows": (i32, [i32]),
     "spb_debug_set_stem_mfma": (i32, [i32]),

@@ -132,6 +132,7 @@ struct spb_krn_ctx {
   std::vector<hipEvent_t> fork_ev;
   hipEvent_t join_ev = nullptr;
   hipEvent_t prep_ev = nullptr;     // weight copies refreshed on the side stream (spb_krn_forward, training & 4)
+  hipEvent_t router_ev = nullptr;   // the RouterV2 branch (forward: 1x1 + reorg into the concat; backward: its input gradient) finished on the side stream
   hipEvent_t bucket_ev = nullptr;   // recorded when the gradients of [split_off, n_params) are final
   bool bucket_recorded = false;
   bool bucket_on = false;           // spb_krn_ctx_set_bucket: single-GPU runs skip the mid-backward join
@@ -148,6 +149,7 @@ struct spb_krn_ctx {
     if (join_ev) hipEventDestroy(join_ev);
     if (bucket_ev) hipEventDestroy(bucket_ev);
     if (prep_ev) hipEventDestroy(prep_ev);
+    if (router_ev) hipEventDestroy(router_ev);
     if (side) hipStreamDestroy(side);
     if (fork_flag) hipFree(fork_flag);
     spb_fork_poison_free(fork_poison);
@@ -482,6 +484,14 @@ static int g_fuse_expand_min_hw = 56;
 #ifdef SPB_TUNING
 extern "C" int spb_debug_set_fuse_expand(int min_width) { g_fuse_expand_min_hw = min_width <= 0 ? (1 << 30) : min_width; return 0; }
 #endif
+// Round 6: the RouterV2 branch (park2019.py:60-80,116: 1x1 conv 96 -> 64 on block 13's output, reorg into the concat) hangs off the main
+// chain -- forward it is needed only by extras[3], backward its input gradient only by block 14's expand convolution -- so its launches
+// (forward: GEMM + the reorg bn_apply, 17 us; backward: bn_bwd_prep + the input-gradient GEMM, 20 us) run on the side stream beside the 7x7
+// chain instead of inside it; one fork and one event wait each way.  spb_debug_set_router_side(0): in the chain, as before.
+static int g_router_side = 1;
+#ifdef SPB_TUNING
+extern "C" int spb_debug_set_router_side(int on) { g_router_side = on != 0; return 0; }
+#endif
 static int g_fused_pw_bwd = 1;
 static long long g_fused_pw_bwd_min_m = 100000;  // spb_debug_set_fused_pw_bwd(v > 1): fused kernel from v rows up.  The 28x28 layer
                                                  // (M = 37632, 144 -> 32) took 45 us fused for 26 MB; as GEMM + side-stream weight gradient the step is 12 us shorter
@@ -666,6 +676,18 @@ struct Runner {
     return c->fork_ev[c->n_fork++];
   }
   bool side_usable() const { return !(c->prof_on || !c->side || !c->side_on || !g_side_wgrad || c->det || m->det); }
+  // Launches of a branch that hangs off the chain (the RouterV2 branch): `body` runs with `st` switched to the side stream, forked from
+  // the launch stream's current point; c->router_ev marks their end.  Returns false (and runs nothing) where the side stream cannot be
+  // used: the caller then issues the same launches in the chain.
+  template <typename F> bool branch_on_side(F body) {
+    if (!g_router_side || !side_usable()) return false;
+    hipStream_t keep = st;
+    st = side_stream();
+    body();
+    hipEventRecord(c->router_ev, st);
+    st = keep;
+    return true;
+  }
   void gate_side(unsigned serial) {   // the side stream waits until the context's fork word reaches `serial`
     spb_fork_gate(c->fork_flag, serial, c->side, spb_fork_poison_dev(c->fork_poison));
     forked = true;
@@ -1191,6 +1213,7 @@ extern "C" int spb_krn_ctx_create(spb_krn_t* m, int batch, void* workspace, spb_
   if (hipEventCreateWithFlags(&c->join_ev, g_stream_event_flags) != hipSuccess) { delete c; return SPB_E_STATE; }
   if (hipEventCreateWithFlags(&c->bucket_ev, hipEventDisableTiming) != hipSuccess) { delete c; return SPB_E_STATE; }
   if (hipEventCreateWithFlags(&c->prep_ev, g_stream_event_flags) != hipSuccess) { delete c; return SPB_E_STATE; }
+  if (hipEventCreateWithFlags(&c->router_ev, g_stream_event_flags) != hipSuccess) { delete c; return SPB_E_STATE; }
   for (int i = 0; i < 64; ++i) {
     hipEvent_t ev;
     if (hipEventCreateWithFlags(&ev, g_stream_event_flags) != hipSuccess) break;
@@ -1274,6 +1297,16 @@ extern "C" int spb_krn_forward(spb_krn_ctx_t* c, const float* x, const float* ta
   r.ok(spb_stem_fwd(m->dtype, x, m->P + m->stem_w_off, r.z(m->aStem), tr ? r.sums(m->aStem) : nullptr, c->R[m->aStem],
                     c->B, kIn, kIn, stream));
   r.toc();
+  auto router_branch = [&]() {   // RouterV2: 1x1 (96 -> 64) + BN + LeakyReLU on block 13's output, reorg into channels [0, 256) of the concat
+    r.pw_fwd(m->router, r.block_out(13, tr), m->aR, tr);
+    spb_bnapply_args_t a; std::memset(&a, 0, sizeof(a));
+    a.Z = r.z(m->aR); a.Y = r.y(m->matCat); a.bn = r.ref(m->aR, tr); a.bn_res = Runner::ident(64);
+    a.B = c->B; a.H = 14; a.W = 14; a.C = 64; a.ldc = 1280; a.coff = 0; a.reorg = 2;
+    r.tic(PC_BN_APPLY, 2.0 * r.elems(m->aR) * r.es());
+    r.ok(spb_bn_apply(m->dtype, &a, (spb_stream_t)r.st));
+    r.toc();
+  };
+  bool router_on_side = false;
   // inverted residual blocks
   Src cur = r.src_act(m->aStem, tr);
   for (int k = 1; k <= 17; ++k) {
@@ -1295,6 +1328,11 @@ extern "C" int spb_krn_forward(spb_krn_ctx_t* c, const float* x, const float* ta
       r.dw_fwd(b.D, cur, b.Hin, b.aD, tr);
     }
     if (prep_wait) { hipStreamWaitEvent(st, c->prep_ev, 0); prep_wait = false; }
+    if (k == 14) {
+      // block 13's output is final (its residual join was formed by this block's expand convolution): the RouterV2 branch starts
+      // here on the side stream, beside blocks 14..17 and the first two ConvDw extras; joined in front of extras[3]
+      router_on_side = r.branch_on_side(router_branch);
+    }
     r.pw_fwd(b.P, r.src_act(b.aD, tr), b.aP, tr);
     if (b.res && g_join_fused && k < 17) {
       // y_k = bn(z_P) + y_{k-1}: formed by the next block's expand convolution while it loads its operand (pro_mode 3) and
@@ -1320,20 +1358,17 @@ extern "C" int spb_krn_forward(spb_krn_ctx_t* c, const float* x, const float* ta
   r.pw_fwd(m->eP[0], r.src_act(m->aED[0], tr), m->aEP[0], tr);
   r.dw_fwd(m->eD[1], r.src_act(m->aEP[0], tr), 7, m->aED[1], tr);
   r.pw_fwd(m->eP[1], r.src_act(m->aED[1], tr), m->aEP[1], tr);
-  r.pw_fwd(m->router, r.block_out(13, tr), m->aR, tr);
-  {  // cat((reorg(router), x1), dim=1)  (park2019.py:74-80)
+  if (!router_on_side) router_branch();
+  {  // cat((reorg(router), x1), dim=1)  (park2019.py:74-80): x1 = extras[1] output into channels [256, 1280)
     spb_bnapply_args_t a; std::memset(&a, 0, sizeof(a));
-    a.Z = r.z(m->aR); a.Y = r.y(m->matCat); a.bn = r.ref(m->aR, tr); a.bn_res = Runner::ident(64);
-    a.B = c->B; a.H = 14; a.W = 14; a.C = 64; a.ldc = 1280; a.coff = 0; a.reorg = 2;
-    r.tic(PC_BN_APPLY, 2.0 * r.elems(m->aR) * r.es());
-    r.ok(spb_bn_apply(m->dtype, &a, stream));
-    r.toc();
+    a.B = c->B; a.ldc = 1280; a.Y = r.y(m->matCat);
     a.Z = r.z(m->aEP[1]); a.bn = r.ref(m->aEP[1], tr); a.bn_res = Runner::ident(1024);
     a.H = 7; a.W = 7; a.C = 1024; a.coff = 256; a.reorg = 0;
     r.tic(PC_BN_APPLY, 2.0 * r.elems(m->aEP[1]) * r.es());
     r.ok(spb_bn_apply(m->dtype, &a, stream));
     r.toc();
   }
+  if (router_on_side) hipStreamWaitEvent(st, c->router_ev, 0);   // the concat is complete when both halves are
   r.dw_fwd(m->eD[3], r.src_mat(m->matCat), 7, m->aED[3], tr);
   r.pw_fwd(m->eP[3], r.src_act(m->aED[3], tr), m->aEP[3], tr);
   {  // head + loss
@@ -1451,6 +1486,7 @@ extern "C" int spb_krn_backward(spb_krn_ctx_t* c, float* grads, float gscale, in
   const int dt = m->dtype;
   const int aF = m->blk[17].aP;  // feature = bn(z) of block 17's projection (no residual there)
   void* ddom = nullptr;
+  bool router_on_side = false;
   if (dlogit) {  // domain classifier backward, then the gradient-reversal layer (-alpha) into the feature
     r.tic(PC_DOMAIN, ((double)c->B * 49 * (3 * 1280 + 2 * 320) + 2 * 320.0 * 1280) * r.es(), 4.0 * c->B * 49 * 320 * 1280);
     const dim3 tgrid((1280 + 63) / 64, (c->B * 49 + DTB_ROWS - 1) / DTB_ROWS);
@@ -1507,13 +1543,21 @@ extern "C" int spb_krn_backward(spb_krn_ctx_t* c, float* grads, float gscale, in
       r.tic(PC_BN_BWD_PREP, 3.0 * r.elems(m->aEP[1]) * r.es());
       r.ok(spb_bn_bwd_prep(dt, &a, stream));
       r.toc();
-      a.Z = r.z(m->aR); a.G = r.g(m->aR); a.osums = r.bsums(m->aR); a.bn = r.ref(m->aR, true);
-      a.H = 14; a.W = 14; a.C = 64; a.coff = 0; a.reorg = 2; a.oR = c->R[m->aR];
-      r.tic(PC_BN_BWD_PREP, 3.0 * r.elems(m->aR) * r.es());
-      r.ok(spb_bn_bwd_prep(dt, &a, stream));
-      r.toc();
     }
-    r.pw_bwd(m->router, r.block_out(13, true), m->aR, -1, c->ws + c->dtap_off, nullptr);
+    // RouterV2 branch: un-reorg its share of the concat gradient, then the 1x1 convolution's backward.  Its input gradient (dtap) is
+    // needed only when the chain reaches block 14's expand convolution (the skip from block 13's output): on the side stream, behind the
+    // depthwise kernel that wrote the concat gradient (the weight gradient goes to the side stream's queue either way)
+    auto router_branch = [&]() {
+      spb_bnbwd_args_t a; std::memset(&a, 0, sizeof(a));
+      a.dY = c->ws + c->dcat_off; a.Z = r.z(m->aR); a.G = r.g(m->aR); a.osums = r.bsums(m->aR); a.bn = r.ref(m->aR, true);
+      a.B = c->B; a.H = 14; a.W = 14; a.C = 64; a.ldc = 1280; a.coff = 0; a.reorg = 2; a.oR = c->R[m->aR];
+      r.tic(PC_BN_BWD_PREP, 3.0 * r.elems(m->aR) * r.es());
+      r.ok(spb_bn_bwd_prep(dt, &a, (spb_stream_t)r.st));
+      r.toc();
+      r.pw_bwd(m->router, r.block_out(13, true), m->aR, -1, c->ws + c->dtap_off, nullptr);
+    };
+    router_on_side = r.branch_on_side(router_branch);
+    if (!router_on_side) router_branch();
     r.pw_bwd(m->eP[1], r.src_act(m->aED[1], true), m->aEP[1], m->aED[1], nullptr, nullptr, 1.f, true);
     r.dw_bwd(m->eD[1], r.src_act(m->aEP[0], true), 7, m->aED[1], m->aEP[0], nullptr, nullptr);
     r.pw_bwd(m->eP[0], r.src_act(m->aED[0], true), m->aEP[0], m->aED[0], nullptr, nullptr, 1.f, true);
@@ -1535,7 +1579,10 @@ extern "C" int spb_krn_backward(spb_krn_ctx_t* c, float* grads, float gscale, in
     // gradient joining the block input besides this block's own path
     const void* res = nullptr;
     if (b.res) res = r.g(b.aP);                                  // skip connection: d y_{k-1} += d y_k
-    else if (k == 14 && with_pose) res = c->ws + c->dtap_off;    // RouterV2 branch taps block 13's output
+    else if (k == 14 && with_pose) {                             // RouterV2 branch taps block 13's output
+      res = c->ws + c->dtap_off;
+      if (router_on_side) { hipStreamWaitEvent(st, c->router_ev, 0); router_on_side = false; }   // its input gradient came from the side stream
+    }
     r.pw_bwd(b.P, r.src_act(b.aD, true), b.aP, b.aD, nullptr, nullptr, 1.f, true);
     if (b.t != 1 && r.virt(k)) {
       const Src xs = r.xe_src(k);

@@ -81,6 +81,9 @@ def pwconv_gemm(A, Bw, Y, pro, pro_mode, epi_mode, A2=None, res=None, Zout=None,
     if pro_mode == 3:       # residual join: a = bn(A) + bn2(A2), written to Ymat by the launch
         _need_cuda(Ymat)
         g.pro2 = pro2 if pro2 is not None else bnref(A.shape[1]); g.Ymat = _ptr(Ymat)
+    elif Ymat is not None:  # statistics-only pass (Y is None): also write the operand round16(act(bn(A)))
+        _need_cuda(Ymat)
+        g.Ymat = _ptr(Ymat)
     L.check(lib_of(A).spb_pwconv_gemm(dtype_code(A, True), C.byref(g), _stream()), "spb_pwconv_gemm")
 
 
