@@ -187,6 +187,7 @@ def bench_decoder(args):
 
 
 def main():
+    from speedplusbaseline_amd import _lib as L
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
@@ -327,7 +328,6 @@ def main():
         n_prof = 5
         eng.prof_enable(B, 0, True)
         import ctypes as C
-        from speedplusbaseline_amd import _lib as L
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(6)]
         t_prep = t_zero = t_opt = 0.0
         agg = {}

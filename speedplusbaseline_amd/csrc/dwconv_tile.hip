@@ -72,8 +72,14 @@ struct TileGeo { int nty, ntx, ntiles, nchunks, nsp; };
 // returns the expanded activation z = W x as exact f32 in the same "four consecutive pixels of one channel" layout.  Same instruction
 // count as the transposer; the staged bytes per pixel drop from 2 C to 2 Ce (C = 6 Ce), shared by the C / 32 workgroups of a tile
 // (one XCD: L2 hits), and the 96 / 144-channel tensor of the 112x112 / 56x56 maps is never written or read.
+// SPB_DWT_XP_OCC3: the stride-2 expand-recompute instance without the cross-tile register prefetch (its rows are a few KB of L2-resident
+// data; the prefetch array is 44 registers) at three workgroups per CU instead of two (168 registers, 8 bytes of scratch per lane).
+// Measured in the step, two A/B pairs (scratch/build_variant.py occ3 -DSPB_DWT_XP_OCC3=1 against =0): 2.436 -> 2.425 ms.
+#ifndef SPB_DWT_XP_OCC3
+#define SPB_DWT_XP_OCC3 1
+#endif
 template <int ST, bool CLAMP, bool XP = false>
-__global__ __launch_bounds__(256, ST == 1 ? 4 : 2) void dwt_fwd_kernel(const spb_dw_args_t a, const TileGeo tg) {
+__global__ __launch_bounds__(256, ST == 1 ? 4 : ((XP && SPB_DWT_XP_OCC3) ? 3 : 2)) void dwt_fwd_kernel(const spb_dw_args_t a, const TileGeo tg) {
   typedef TG<ST> G;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
@@ -187,8 +193,10 @@ __global__ __launch_bounds__(256, ST == 1 ? 4 : 2) void dwt_fwd_kernel(const spb
       raw[i] = ldraw<bf16_t>(xb + (size_t)(y * W + x) * CX);
     }
   };
-  if (sp < tg.ntiles) request(sp);
+  constexpr bool NOPF = XP && ST == 2 && SPB_DWT_XP_OCC3;
+  if (!NOPF && sp < tg.ntiles) request(sp);
   for (int t = sp; t < tg.ntiles; t += tg.nsp) {
+    if (NOPF) request(t);
     const int tx = t % tg.ntx, ty = (t / tg.ntx) % tg.nty, b = t / (tg.ntx * tg.nty);
     const int oy0 = ty * TH, ox0 = tx * TW;
     const int yin0 = ST * oy0 - 1, xin0 = ST * ox0 - 2;
@@ -241,7 +249,7 @@ __global__ __launch_bounds__(256, ST == 1 ? 4 : 2) void dwt_fwd_kernel(const spb
         *reinterpret_cast<uint2*>(smem + (16 * h + r) * G::CHS + slot4 * 2) = o;
       }
     }
-    request(t + tg.nsp);
+    if (!NOPF) request(t + tg.nsp);
     lds_barrier();
     // ---- phase 2: taps.  Lane (r, q) of wave w: output row oyl = 4 w + q, 8 output columns, channel planes of units 0 and 1
     const int oyl = 4 * wave + q;
@@ -588,7 +596,7 @@ int spb_dwt_fwd(int dtype, const spb_dw_args_t* a, hipStream_t s) {
   tg.nty = (OH + TH - 1) / TH; tg.ntx = (OW + TW - 1) / TW; tg.ntiles = a->B * tg.nty * tg.ntx;
   tg.nchunks = (a->C + CHK - 1) / CHK;
   const size_t lds = (size_t)CHK * (st == 1 ? TG<1>::CHS : TG<2>::CHS) + (xp ? 256 + 2048 : 0);
-  const int per_cu = st == 1 ? 4 : 2;                          // resident workgroups per CU (registers: 100 / 172 per lane)
+  const int per_cu = st == 1 ? 4 : ((xp && SPB_DWT_XP_OCC3) ? 3 : 2);   // resident workgroups per CU (registers: 100 / 172 per lane)
   int target = g_dw_tile_wgs > 0 ? g_dw_tile_wgs : 256 * per_cu;   // persistent: one dispatch round
   int per_xcd = target / 8 / tg.nchunks;                     // spatial walkers per XCD
   const int maxsp = (tg.ntiles + 7) / 8;
