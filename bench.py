@@ -194,7 +194,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=48, help="images per GPU (README recipe: 48)")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32", "fp16"],
-                    help="fp16 (IEEE half + device-side dynamic loss scaling) exists for --model spn only: BASELINE configs[5]")
+                    help="bf16: the headline dtype (BASELINE configs[1]); fp16: the IEEE-half build of the same kernels with GradScaler's dynamic loss "
+                         "scaling on the device (--model krn: the reference's own --use_fp16 recipe; --model spn: BASELINE configs[5]); fp32: parity mode")
     ap.add_argument("--graph", action="store_true", help="replay a captured hipGraph instead of enqueuing the launches "
                     "eagerly (eager + side-stream weight gradients is the faster, default mode)")
     ap.add_argument("--no-graph", action="store_true", help=argparse.SUPPRESS)  # old spelling of the default

@@ -30,7 +30,7 @@ parser.add_argument('--perform_dann', dest='dann', action='store_true', default=
 parser.add_argument('--texture_alpha', type=float, default=0.5)
 parser.add_argument('--texture_ratio', type=float, default=0.5)
 parser.add_argument('--use_fp16', dest='fp16', action='store_true', default=False,
-                    help='reference: fp16 autocast + GradScaler; here: SPN runs float16 with device-side dynamic loss scaling, KRN / RevGrad run bfloat16 (logged)')
+                    help='reference: fp16 autocast + GradScaler; here: KRN and SPN run the IEEE-half build of the kernels with GradScaler\'s dynamic loss scaling kept on the device; RevGrad / DANN (adapt.py has no mixed precision in the reference) runs bfloat16 (logged); --precision bf16 selects bfloat16 for KRN / SPN')
 parser.add_argument('--batch_size', type=int, default=32)
 parser.add_argument('--max_epochs', type=int, default=75)
 parser.add_argument('--num_workers', type=int, default=8)

@@ -20,8 +20,8 @@ def family(name):
     if "dwt_dgrad" in name:
         return "dw_dgrad"
     m = re.search(r"pw_st_kernel<(\d+)", name)                        # streaming kernel of the large maps (gemm_st.hip): forward only (PRO 1 / 3),
-    if m:                                                             # incl. the statistics-only instances of the virtual expand convolutions
-        return "pw_gemm_fwd"
+    if m:                                                             # <PRO, NJ, KS, SO>: SO = true are the statistics-only passes of the virtual
+        return "pw_stats" if re.search(r"pw_st_kernel<\d+, *\d+, *\d+, *true>", name) else "pw_gemm_fwd"   # expand convolutions (plan category pw_stats)
     m = re.search(r"pw_rs_kernel<(\d+)", name)                        # row-slab kernel: PRO leads the template list (1 / 3 forward, 2 input gradient)
     if m:
         return "pw_gemm_dgrad" if int(m.group(1)) == 2 else "pw_gemm_fwd"

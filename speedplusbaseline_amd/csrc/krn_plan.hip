@@ -159,10 +159,10 @@ struct spb_krn_ctx {
 
 enum ProfCat { PC_STEM_FWD = 0, PC_PW_FWD, PC_DW_FWD, PC_BN_APPLY, PC_HEAD_FWD, PC_BN_UPDATE, PC_HEAD_BWD, PC_PW_DGRAD,
                PC_PW_WGRAD, PC_DW_DGRAD, PC_DW_WGRAD, PC_BN_BWD_PREP, PC_STEM_WGRAD, PC_BN_PARAM_GRADS, PC_DOMAIN,
-               PC_WEIGHT_PREP, PC_PW_BWD_FUSED, PC_COUNT };
+               PC_WEIGHT_PREP, PC_PW_BWD_FUSED, PC_PW_STATS, PC_COUNT };
 static const char* kProfNames[PC_COUNT] = {"stem_fwd", "pw_gemm_fwd", "dw_fwd", "bn_apply", "head_fwd", "bn_running_update",
                                            "head_bwd", "pw_gemm_dgrad", "pw_wgrad", "dw_dgrad", "dw_wgrad", "bn_bwd_prep",
-                                           "stem_wgrad", "bn_param_grads", "domain_head", "weight_prep", "pw_bwd_fused"};
+                                           "stem_wgrad", "bn_param_grads", "domain_head", "weight_prep", "pw_bwd_fused", "pw_stats"};
 
 namespace {
 
@@ -593,7 +593,7 @@ struct Runner {
     if (in.mat) { g.pro_mode = 3; g.A2 = in.ptr2; g.pro2 = in.ref2; g.Ymat = in.mat; }
     // evaluation: the sums are not wanted (the arena holds the running statistics): a scratch row behind the context's tables takes them
     g.osums = tr ? sums(aout) : reinterpret_cast<float*>(c->ws + c->junk_off); g.oR = tr ? c->R[aout] : 1;
-    tic(PC_PW_FWD, ((double)g.M * ((in.mat ? 3 : 1) + (xmat ? 1 : 0)) * L.K + (double)L.K * L.N) * es(), 2.0 * g.M * L.K * L.N);
+    tic(PC_PW_STATS, ((double)g.M * ((in.mat ? 3 : 1) + (xmat ? 1 : 0)) * L.K + (double)L.K * L.N) * es(), 2.0 * g.M * L.K * L.N);
     ok(spb_pwconv_gemm(dt, &g, st));
     toc();
   }
