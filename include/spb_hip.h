@@ -306,9 +306,9 @@ int spb_stream_destroy(spb_stream_t stream);
  * is set, and under rocprofv3 counter collection (ROCPROF_COUNTER_COLLECTION=1: kernels are serialised there, a gate would spin
  * forever; it traps after SPB_FORK_TIMEOUT_S seconds -- default 600, 0 = never -- if the storing launch never runs). */
 /* Round 6: the property the device-word forks rest on -- a kernel starts only after every earlier kernel of its stream has completed and
- * released its results at device scope -- is TESTED once per process when the first KRN context / fork object is created (~1 ms: a
- * slow producer, a dependent one-wave kernel that stores the word, a gate + checker on a second stream; csrc/elemwise.hip).
- * spb_fork_selftest() runs it if it has not run and returns 1 (passed: device-word forks), 0 (failed: events for the rest of the
+ * released its results at device scope -- is TESTED once per process, at the first fork, on that fork's own two streams (~1 ms and one
+ * synchronisation of both: a slow producer, a dependent one-wave kernel that stores the word, a gate + checker on the second stream;
+ * csrc/elemwise.hip).  spb_fork_selftest() returns the cached verdict -- if no fork has run yet it runs the test on two streams of its own --: 1 (passed: device-word forks), 0 (failed: events for the rest of the
  * process, one line on stderr), -1 (events forced by SPB_EVENT_FORKS / ROCPROF_COUNTER_COLLECTION).  A gate that gives up after
  * SPB_FORK_TIMEOUT_S seconds no longer traps: it raises a host-visible poison word and the owner's next call returns SPB_E_TIMEOUT. */
 int spb_fork_selftest(void);

@@ -108,7 +108,9 @@ void spb_fork_gate(const unsigned* flag, unsigned val, hipStream_t s, unsigned* 
 unsigned* spb_fork_poison_alloc();                   // host word a gate raises instead of trapping when it gives up (SPB_FORK_TIMEOUT_S)
 void spb_fork_poison_free(unsigned* host);
 unsigned* spb_fork_poison_dev(unsigned* host);
-bool spb_fork_by_word(hipStream_t from);   // false: order by events (stream capture, SPB_EVENT_FORKS=1, a counter-collecting profiler)
+// false: order by events (stream capture, SPB_EVENT_FORKS=1, a counter-collecting profiler, or the start-up self-test failed: it runs once
+// per process, on the first (from, to) pair it is asked about)
+bool spb_fork_by_word(hipStream_t from, hipStream_t to);
 // spb_dw_args_t::entry_flag (include/spb_hip.h): the first thread of a launch publishes "everything before me on my stream is complete".
 // Any thread would do -- the dispatch sat behind a barrier bit -- and the store needs no fence of its own: the earlier launches' results
 // were released at device scope when their dispatch packets completed, and whoever spins on the word only gates later dispatches.

@@ -699,7 +699,7 @@ extern "C" int spb_stream_destroy(spb_stream_t s) {
   return s && hipStreamDestroy((hipStream_t)s) == hipSuccess ? 0 : SPB_E_ARG;
 }
 
-// ---- stream forks without events ("Round 5, second half") -------------------------------------------------------
+// ---- stream forks without events (HISTORY.md section 5, "Round 5, second half") -------------------------------------------------------
 // Ordering a second stream behind the launch stream with an event costs the LAUNCH stream 5-9 us per fork, whatever the flavour
 // (scratch/ubench_fork.hip: event record 8.7 us, completion event on the producer's dispatch packet 6.6 us, either without the system
 // fence 6.3 / 5.2 us, stream write/wait value 9.0 us; the forked work itself is free).  A fork needs no event: the second stream runs a
@@ -786,20 +786,19 @@ __global__ void forktest_check_kernel(const unsigned* buf, int n, unsigned seria
 int g_fork_selftest = -2;        // -2 not run yet, -1 events forced by the environment, 0 failed (events), 1 passed (device-word forks)
 }  // namespace
 bool spb_event_forks_forced();
-extern "C" int spb_fork_selftest(void) {
-  if (g_fork_selftest != -2) return g_fork_selftest;
-  if (spb_event_forks_forced()) return g_fork_selftest = -1;
+// The test itself, on the two streams it is given.  (Round 6, first version: the test created two streams of its own at fork / context
+// creation -- and the SPN step went from 1.67 to 2.9 ms: the HIP runtime deals hardware queues to streams round robin, two more streams
+// shifted the deal and the SPN's update stream ended up sharing a queue.  It now runs lazily on the very streams of the first fork.)
+static int fork_selftest_run(hipStream_t a, hipStream_t b) {
   const char* ff = std::getenv("SPB_FORK_SELFTEST_FAIL");
   bool ok = !(ff && ff[0] == '1');
   constexpr int N = 512 * 1024;
   unsigned *buf = nullptr, *word = nullptr, *bad = nullptr, *poison = spb_fork_poison_alloc();
-  hipStream_t a = nullptr, b = nullptr;
   unsigned hbad = 1;
   if (ok) {
     ok = hipMalloc(&buf, N * sizeof(unsigned)) == hipSuccess && hipMalloc(&word, 256) == hipSuccess && hipMalloc(&bad, 256) == hipSuccess &&
          hipMemset(buf, 0, N * sizeof(unsigned)) == hipSuccess && hipMemset(word, 0, 256) == hipSuccess && hipMemset(bad, 0, 256) == hipSuccess &&
-         hipStreamSynchronize(nullptr) == hipSuccess && hipStreamCreateWithFlags(&a, hipStreamNonBlocking) == hipSuccess &&
-         hipStreamCreateWithFlags(&b, hipStreamNonBlocking) == hipSuccess && poison != nullptr;
+         hipStreamSynchronize(nullptr) == hipSuccess && poison != nullptr;
     if (ok) {
       for (unsigned r = 1; r <= 6; ++r) {
         hipLaunchKernelGGL(forktest_produce_kernel, dim3(512), dim3(256), 0, a, buf, N, r);
@@ -813,8 +812,6 @@ extern "C" int spb_fork_selftest(void) {
     }
   }
   (void)hipGetLastError();
-  if (a) (void)hipStreamDestroy(a);
-  if (b) (void)hipStreamDestroy(b);
   if (buf) (void)hipFree(buf);
   if (word) (void)hipFree(word);
   if (bad) (void)hipFree(bad);
@@ -827,6 +824,20 @@ extern "C" int spb_fork_selftest(void) {
                  "(as with SPB_EVENT_FORKS=1).\n", rv, hbad);
   }
   return g_fork_selftest;
+}
+// public query (include/spb_hip.h): the cached verdict; if no fork has run the test yet, on two streams of its own
+extern "C" int spb_fork_selftest(void) {
+  if (g_fork_selftest != -2) return g_fork_selftest;
+  if (spb_event_forks_forced()) return g_fork_selftest = -1;
+  hipStream_t a = nullptr, b = nullptr;
+  if (hipStreamCreateWithFlags(&a, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&b, hipStreamNonBlocking) != hipSuccess) {
+    (void)hipGetLastError();
+    if (a) (void)hipStreamDestroy(a);
+    return g_fork_selftest = 0;
+  }
+  const int r = fork_selftest_run(a, b);
+  (void)hipStreamDestroy(a); (void)hipStreamDestroy(b);
+  return r;
 }
 extern "C" int spb_hip_runtime_version(void) { int v = 0; return hipRuntimeGetVersion(&v) == hipSuccess ? v : -1; }
 
@@ -845,10 +856,17 @@ bool spb_event_forks_forced() {
   }();
   return v;
 }
-bool spb_fork_by_word(hipStream_t from) {
-  if (spb_event_forks_forced() || g_fork_selftest != 1) return false;   // (never tested -- no context / fork object created yet -- counts as not trusted)
+// `to`: the stream the first fork of the process will gate -- the self-test runs on this very pair (once; synchronises both)
+bool spb_fork_by_word(hipStream_t from, hipStream_t to) {
+  if (spb_event_forks_forced()) return false;
   hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-  return hipStreamIsCapturing(from, &cs) == hipSuccess && cs == hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(from, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return false;
+  if (g_fork_selftest == -2) {
+    if (to == nullptr || to == from) return false;
+    if (hipStreamIsCapturing(to, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return false;
+    (void)fork_selftest_run(from, to);
+  }
+  return g_fork_selftest == 1;
 }
 
 struct spb_fork { unsigned* word = nullptr; unsigned serial = 0; hipEvent_t ev = nullptr; unsigned* poison = nullptr; };
@@ -864,7 +882,6 @@ extern "C" int spb_fork_create(spb_fork_t** out) {
     return SPB_E_STATE;
   }
   f->poison = spb_fork_poison_alloc();
-  (void)spb_fork_selftest();
   *out = f;
   return 0;
 }
@@ -880,7 +897,7 @@ extern "C" int spb_fork_streams(spb_fork_t* f, spb_stream_t from, spb_stream_t t
   hipStream_t a = (hipStream_t)from, b = (hipStream_t)to;
   if (a == b) return 0;
   if (f->poison && *reinterpret_cast<volatile unsigned*>(f->poison)) return SPB_E_TIMEOUT;   // an earlier gate of this fork gave up (sticky)
-  if (spb_fork_by_word(a)) {
+  if (spb_fork_by_word(a, b)) {
     const unsigned serial = ++f->serial;
     spb_fork_store(f->word, serial, a);
     spb_fork_gate(f->word, serial, b, spb_fork_poison_dev(f->poison));

@@ -499,7 +499,7 @@ struct Runner {
   spb_krn_ctx* c; spb_krn* m; hipStream_t st; int dt; int err = 0;
   bool flag_forks = false;   // forks through the context's device word (fork_gate_kernel) instead of events
   Runner(spb_krn_ctx* c_, hipStream_t s) : c(c_), m(c_->m), st(s), dt(c_->m->dtype) {
-    flag_forks = g_fork_mode != 0 && c->fork_flag && spb_fork_by_word(st);
+    flag_forks = g_fork_mode != 0 && c->fork_flag && c->side && spb_fork_by_word(st, c->side);
   }
   void ok(int e) {
     if (e != 0 && err == 0) err = e;
@@ -1208,8 +1208,7 @@ extern "C" int spb_krn_ctx_create(spb_krn_t* m, int batch, void* workspace, spb_
   if (hipMalloc(&c->fork_flag, 256) != hipSuccess || hipMemset(c->fork_flag, 0, 256) != hipSuccess || hipStreamSynchronize(nullptr) != hipSuccess) {
     delete c; return SPB_E_STATE;
   }
-  c->fork_poison = spb_fork_poison_alloc();
-  (void)spb_fork_selftest();   // once per process: is "the next launch's first instruction proves the earlier ones complete" true here? (elemwise.hip)
+  c->fork_poison = spb_fork_poison_alloc();   // (the fork self-test runs at the first pass, on the launch stream and this side stream: elemwise.hip)
   if (hipEventCreateWithFlags(&c->join_ev, g_stream_event_flags) != hipSuccess) { delete c; return SPB_E_STATE; }
   if (hipEventCreateWithFlags(&c->bucket_ev, hipEventDisableTiming) != hipSuccess) { delete c; return SPB_E_STATE; }
   if (hipEventCreateWithFlags(&c->prep_ev, g_stream_event_flags) != hipSuccess) { delete c; return SPB_E_STATE; }
