@@ -1313,8 +1313,9 @@ extern "C" int spb_krn_forward(spb_krn_ctx_t* c, const float* x, const float* ta
     if (b.t != 1 && r.virt(k)) {
       // virtual expanded tensor: the expand launch leaves only its batch sums (and the residual join it forms on the way), the depthwise
       // kernel recomputes the expanded activation from the block input
-      // (a block input that already is a materialised tensor -- the previous block had a skip connection and its join was formed
-      // earlier -- cannot occur for the candidates: the join of block k - 1 is always pending here)
+      // (three forms of block input: a raw tensor + its BatchNorm -> the pass writes the operand to the block's own slot; a pending residual
+      // join -> the pass forms and writes the previous block's output, which is the operand; an already materialised previous output
+      // (spb_debug_set_join_fused(0)) -> read as it is)
       r.pw_stats(b.E, cur, b.aE, tr, b.matXe >= 0 ? r.y(b.matXe) : nullptr);
       if (cur.mat) cur = r.block_out(k - 1, tr);
       const Src xs = r.xe_src(k);
