@@ -108,7 +108,8 @@ struct spb_krn_ctx {
   size_t stats_off = 0, stats_floats = 0;
   size_t dcat_off = 0, dtap_off = 0, ddom_off = 0, dom1_off = 0, gdom_off = 0;
   size_t partial_off = 0, dout_off = 0, table_off = 0, dompool_off = 0;
-  size_t junk_off = 0;              // 2 x 1280 floats nobody reads (batch sums of an evaluation-mode statistics pass)
+  size_t junk_off = 0;              // FLOAT offset in the stats arena of 2 x 1280 floats nobody reads (batch sums of an evaluation-mode statistics
+                                    // pass; inside the arena so that the reproducible build accumulates them exactly too: no counted miss)
   // weight-gradient partial sums (spb_red_job_t): one scratch slab per layer, keyed by the layer's weight offset in the arena
   struct PartSlab { long long key; size_t off; long long floats; };
   std::vector<PartSlab> parts;
@@ -592,7 +593,7 @@ struct Runner {
     g.pro_mode = 1; g.out_scale = 1.f; g.epi_mode = 1; g.Ymat = xmat;     // xmat: the operand round16(bn(in)), for the recomputing kernels
     if (in.mat) { g.pro_mode = 3; g.A2 = in.ptr2; g.pro2 = in.ref2; g.Ymat = in.mat; }
     // evaluation: the sums are not wanted (the arena holds the running statistics): a scratch row behind the context's tables takes them
-    g.osums = tr ? sums(aout) : reinterpret_cast<float*>(c->ws + c->junk_off); g.oR = tr ? c->R[aout] : 1;
+    g.osums = tr ? sums(aout) : stats() + c->junk_off; g.oR = tr ? c->R[aout] : 1;
     tic(PC_PW_STATS, ((double)g.M * ((in.mat ? 3 : 1) + (xmat ? 1 : 0)) * L.K + (double)L.K * L.N) * es(), 2.0 * g.M * L.K * L.N);
     ok(spb_pwconv_gemm(dt, &g, st));
     toc();
@@ -1109,6 +1110,7 @@ static void layout_ctx(const spb_krn* m, int B, int dtype, spb_krn_ctx* c, size_
     so[a] = sf; sf += (size_t)Rv[a] * 2 * d.C;
     bo[a] = sf; sf += (size_t)Rv[a] * 2 * d.C;
   }
+  const size_t junk = sf; sf += 2 * 1280;
   size_t stats = take(sf * sizeof(float));
   for (int a = 0; a < nA; ++a) {
     const ActDef& d = m->acts[a];
@@ -1127,7 +1129,6 @@ static void layout_ctx(const spb_krn* m, int B, int dtype, spb_krn_ctx* c, size_
   size_t dom1 = take((size_t)B * 49 * 1280 * es);
   size_t gdom = take((size_t)B * 49 * 1280 * es);
   size_t dompool = take((size_t)B * 1280 * sizeof(float));
-  size_t junk = take((size_t)2 * 1280 * sizeof(float));
   size_t partial = take((size_t)S * B * m->Jp * sizeof(float));
   size_t dout = take((size_t)B * m->J * sizeof(float));
   // scratch slabs of the weight-gradient partial sums: pointwise (row splits, or one part per workgroup of the fused
