@@ -844,11 +844,14 @@ extern "C" int spb_hip_runtime_version(void) { int v = 0; return hipRuntimeGetVe
 // Tools that let only ONE kernel of the device run at a time cannot run a spinning gate: the launch it waits for would never start
 // (measured: `rocprofv3 --pmc ...` hangs until the gate's time-out traps).  Streams are ordered by events instead when
 //   * SPB_EVENT_FORKS=1 is in the environment, or
-//   * ROCPROF_COUNTER_COLLECTION=1 is (what rocprofv3 exports to the application for --pmc / counter-group runs),
+//   * ROCPROF_COUNTER_COLLECTION=1 is (what rocprofv3 exports to the application for --pmc / counter-group runs), or the runtime's own
+//     serialising debug switches AMD_SERIALIZE_KERNEL / HIP_LAUNCH_BLOCKING are,
 // and inside a stream capture (a replayed graph would replay the serial numbers).
 bool spb_event_forks_forced() {
   static const bool v = [] {
-    for (const char* name : {"SPB_EVENT_FORKS", "ROCPROF_COUNTER_COLLECTION"}) {
+    // (AMD_SERIALIZE_KERNEL / HIP_LAUNCH_BLOCKING: debug settings of the HIP runtime that make every launch wait for the previous one, on
+    // whatever stream -- a gate would then never see the store enqueued behind it)
+    for (const char* name : {"SPB_EVENT_FORKS", "ROCPROF_COUNTER_COLLECTION", "AMD_SERIALIZE_KERNEL", "HIP_LAUNCH_BLOCKING"}) {
       const char* e = std::getenv(name);
       if (e && e[0] && e[0] != '0' && e[0] != 'f' && e[0] != 'F') return true;
     }
