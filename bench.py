@@ -124,7 +124,8 @@ def bench_others(steps=40, warmup=10):
     runs = (("dann_bs16", ["--model", "dann", "--batch", "16"]), ("dann_bs48", ["--model", "dann", "--batch", "48"]),
             ("spn_bf16", ["--model", "spn", "--precision", "bf16"]), ("spn_fp16", ["--model", "spn", "--precision", "fp16"]),
             ("krn_fp16", ["--precision", "fp16"]),     # the reference's own AMP recipe for KRN (float16 + GradScaler), beside the bf16 headline
-            ("styleaug", ["--styleaug"]), ("decoder", ["--model", "decoder"]))
+            ("styleaug", ["--styleaug"]), ("decoder", ["--model", "decoder"]),
+            ("decoder_fp16", ["--model", "decoder", "--precision", "fp16"]))   # the same kernels in IEEE half: 8x closer to the reference's float32 decoder
     out = {}
     t_start = time.perf_counter()
     env = dict(os.environ)
@@ -161,7 +162,8 @@ def bench_decoder(args):
     dev = torch.device("cuda", 0)
     B = args.batch
     torch.manual_seed(2021)
-    aug = StyleAugmentor.synthetic(0.5, dev, Ghiasi().state_dict(), seed=2021)   # random decoder weights (none offline)
+    prec = "fp16" if args.precision == "fp16" else "bf16"   # (--precision fp32 is the default of nothing here: the headline default is bf16)
+    aug = StyleAugmentor.synthetic(0.5, dev, Ghiasi().state_dict(), seed=2021, precision=prec)   # random decoder weights (none offline)
     gen = torch.Generator(device="cpu"); gen.manual_seed(2021)
     x = torch.rand(B, 3, 224, 224, generator=gen).to(dev)
     ms = _timed(lambda: aug(x), args.steps, args.warmup)
@@ -178,7 +180,7 @@ def bench_decoder(args):
     print(json.dumps({
         "metric": "images/sec Ghiasi style decoder 224x224 forward", "value": round(B / (ms * 1e-3), 1), "unit": "images/sec", "n_gpus": 1,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "bf16", "data": "synthetic",
+        "dtype": prec, "data": "synthetic",
         "config": {"workload": "Ghiasi style decoder forward (StyleAugmentor, alpha 0.5), %d images 224x224" % B, "per_gpu_batch": B, "weights": "random init"},
         "roofline": dict(bound="mfma", kernel="all launches of one restyle", achieved=round(tf, 1), peak=MFMA_PEAK_TFLOPS["bf16"], unit="TFLOP/s",
                          frac=round(tf / MFMA_PEAK_TFLOPS["bf16"], 4), traffic=traffic, traffic_source=src,

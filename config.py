@@ -56,9 +56,10 @@ parser.add_argument('--no_cuda', dest='use_cuda', action='store_false', default=
 parser.add_argument('--precision', type=str, default=None, choices=[None, 'fp32', 'bf16', 'fp16'],
                     help='compute type of the HIP kernels; default fp32 (the reference trains in fp32); --use_fp16 selects fp16 (IEEE half + device-side '
                          'GradScaler) for SPN and KRN, bf16 for RevGrad / DANN')
-parser.add_argument('--styleaug_precision', type=str, default='bf16', choices=['bf16', 'fp32'],
-                    help='style decoder (--randomize_texture): bf16 matrix-core kernels (default) or the float32 reference-precision mode '
-                         '(the reference runs this module in fp32, trainer.py:68-69; ~30x slower)')
+parser.add_argument('--styleaug_precision', type=str, default='bf16', choices=['bf16', 'fp16', 'fp32'],
+                    help='style decoder (--randomize_texture): bf16 matrix-core kernels (default), the same kernels in IEEE half (+2 % time, '
+                         '8x closer to the float32 image), or the float32 reference-precision mode (the reference runs this module in fp32, '
+                         'trainer.py:68-69; ~30x slower)')
 parser.add_argument('--deterministic', dest='deterministic', action='store_true', default=False,
                     help='KRN / RevGrad on the reproducible build of the kernels (exact, order-independent accumulation instead of float '
                          'atomics): the same seed gives bit-identical checkpoints in every run.  ~2x slower; the reference has no such mode '

@@ -14,7 +14,8 @@ if os.environ.get("GCONV_SLAB_PF"):
 if os.environ.get("GCONV_SLAB"):
     from speedplusbaseline_amd import _lib as L
     L.lib().spb_debug_set_gconv_slab(int(os.environ["GCONV_SLAB"]))
-net = Ghiasi(); net.load_state_dict(G.init_state()); net.to(dev)
+PREC = sys.argv[2] if len(sys.argv) > 2 else "bf16"      # bf16 | fp16 (the IEEE-half build of the same kernels)
+net = Ghiasi(precision=PREC); net.load_state_dict(G.init_state()); net.to(dev)
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 48
 x = torch.rand(B, 3, 224, 224, device=dev); s = torch.randn(B, 100, device=dev)
 for _ in range(3): net(x, s)
@@ -22,7 +23,7 @@ torch.cuda.synchronize(); t0 = time.perf_counter()
 n = 10
 for _ in range(n): net(x, s)
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / n
-print("Ghiasi forward B=%d: %.3f ms  (%.1f TFLOP/s at 15.43 GFLOP/img)" % (B, dt * 1e3, 15.43e9 * B / dt / 1e12))
+print("Ghiasi forward (%s) B=%d: %.3f ms  (%.1f TFLOP/s at 15.43 GFLOP/img)" % (PREC, B, dt * 1e3, 15.43e9 * B / dt / 1e12))
 
 for _ in range(2):   # the first pass creates the events (one of them stalls ~40 ms in the runtime); the second is reported
     net.profile = []

@@ -23,7 +23,10 @@ LIB_F16 = os.path.join(HERE, "libspb_hip_f16.so")
 # (train.py:101-104, trainer.py:73-94); bfloat16 stays the benchmarked substitution (BASELINE configs[1]).
 SOURCES_F16 = ["gemm_pw.hip", "elemwise.hip", "spn.hip", "spn_fc.hip", "spn_conv.hip",
                "gemm_sk.hip", "gemm_os.hip", "gemm_big.hip", "gemm_rs.hip", "gemm_st.hip", "pw_bwd_fused.hip", "dwconv_rows.hip", "dwconv_plane.hip", "dwconv_tile.hip",
-               "stem_head.hip", "stem_mfma.hip", "krn_plan.hip"]
+               "stem_head.hip", "stem_mfma.hip", "krn_plan.hip",
+               # round 6: the style decoder in IEEE half (Ghiasi(precision="fp16")): the reference runs this module in float32 (trainer.py:68-69);
+               # half has eight times bfloat16's mantissa at the same matrix-core rate
+               "ghiasi.hip", "ghiasi_wide.hip", "ghiasi_f32.hip"]
 # Reproducible twin (csrc/common.h, -DSPB_DET): the KRN / DANN kernels and the plan with exact (order-independent) accumulation in
 # place of float atomics.  KrnEngine(..., deterministic=True) and tests/test_parity_conditioned_gpu.py use it.
 # Tuning twin (-DSPB_TUNING): the only build that exports the spb_debug_set_* knobs (include/spb_hip_tuning.h).  Measurement scripts and
@@ -46,6 +49,7 @@ def _digest(paths):
         with open(p, "rb") as f:
             h.update(f.read())
     h.update(" ".join(FLAGS).encode())
+    h.update(repr((SOURCES, SOURCES_F16, SOURCES_DET)).encode())     # a source added to one of the libraries relinks it
     return h.hexdigest()
 
 

@@ -385,8 +385,8 @@ __global__ __launch_bounds__(256) void gconv_kernel(const spb_gconv_args_t g, in
           v[e] = acc[p][nb][e] + ((g.bias && co < Cout) ? g.bias[co] : 0.f);
         }
         o[nb].x = pack_bf16x2(v[0], v[1]); o[nb].y = pack_bf16x2(v[2], v[3]);
-        const float r[4] = {__uint_as_float(o[nb].x << 16), __uint_as_float(o[nb].x & 0xffff0000u),
-                            __uint_as_float(o[nb].y << 16), __uint_as_float(o[nb].y & 0xffff0000u)};
+        float r[4];
+        spb_unpack2(o[nb].x, r[0], r[1]); spb_unpack2(o[nb].y, r[2], r[3]);   // (16-bit storage format: common.h)
 #pragma unroll
         for (int e = 0; e < 4; ++e) { s1[nb][e] += r[e]; s2[nb][e] += r[e] * r[e]; }
       }
@@ -747,8 +747,8 @@ __global__ __launch_bounds__(256, (WREG && NB == 2) ? 3 : 1) void gconv_up2_kern
           v[e] = acc[p][nb][e] + ((g.bias && co < Cout) ? g.bias[co] : 0.f);
         }
         o[nb].x = pack_bf16x2(v[0], v[1]); o[nb].y = pack_bf16x2(v[2], v[3]);
-        const float r[4] = {__uint_as_float(o[nb].x << 16), __uint_as_float(o[nb].x & 0xffff0000u),
-                            __uint_as_float(o[nb].y << 16), __uint_as_float(o[nb].y & 0xffff0000u)};
+        float r[4];
+        spb_unpack2(o[nb].x, r[0], r[1]); spb_unpack2(o[nb].y, r[2], r[3]);   // (16-bit storage format: common.h)
 #pragma unroll
         for (int e = 0; e < 4; ++e) { s1[nb][e] += r[e]; s2[nb][e] += r[e] * r[e]; }
       }
@@ -949,8 +949,8 @@ __global__ __launch_bounds__(256, PXG >= 4 ? 1 : 2) void gconv_slab_kernel(const
 #pragma unroll
       for (int e = 0; e < 4; ++e) v[e] = acc[p][nb][e] + (g.bias ? g.bias[co0 + nb * 4 + e] : 0.f);
       o[nb].x = pack_bf16x2(v[0], v[1]); o[nb].y = pack_bf16x2(v[2], v[3]);
-      const float r[4] = {__uint_as_float(o[nb].x << 16), __uint_as_float(o[nb].x & 0xffff0000u), __uint_as_float(o[nb].y << 16),
-                          __uint_as_float(o[nb].y & 0xffff0000u)};
+      float r[4];
+        spb_unpack2(o[nb].x, r[0], r[1]); spb_unpack2(o[nb].y, r[2], r[3]);   // (16-bit storage format: common.h)
 #pragma unroll
       for (int e = 0; e < 4; ++e) { s1[nb][e] += r[e]; s2[nb][e] += r[e] * r[e]; }
     }
@@ -1071,8 +1071,8 @@ __global__ __launch_bounds__(256) void conv9_band_kernel(const spb_gconv_args_t 
       uint2 o;
       o.x = pack_bf16x2(v[0], v[1]); o.y = pack_bf16x2(v[2], v[3]);
       *reinterpret_cast<uint2*>(Y + ((size_t)(b * H + oy) * W + ox) * g.ldc) = o;
-      const float r[4] = {__uint_as_float(o.x << 16), __uint_as_float(o.x & 0xffff0000u), __uint_as_float(o.y << 16),
-                          __uint_as_float(o.y & 0xffff0000u)};
+      float r[4];
+        spb_unpack2(o.x, r[0], r[1]); spb_unpack2(o.y, r[2], r[3]);   // (16-bit storage format: common.h)
 #pragma unroll
       for (int e = 0; e < 4; ++e) { s1[e] += r[e]; s2[e] += r[e] * r[e]; }
     }
@@ -1240,8 +1240,8 @@ __global__ __launch_bounds__(256) void conv9_kxrows_kernel(const spb_gconv_args_
         uint2 o;
         o.x = pack_bf16x2(v[0], v[1]); o.y = pack_bf16x2(v[2], v[3]);
         *reinterpret_cast<uint2*>(Y + ((size_t)(b * H + y0 + wave * C9K_RW + rw) * W + x0 + lane) * g.ldc) = o;
-        const float rr[4] = {__uint_as_float(o.x << 16), __uint_as_float(o.x & 0xffff0000u), __uint_as_float(o.y << 16),
-                             __uint_as_float(o.y & 0xffff0000u)};
+        float rr[4];
+        spb_unpack2(o.x, rr[0], rr[1]); spb_unpack2(o.y, rr[2], rr[3]);   // (16-bit storage format: common.h)
 #pragma unroll
         for (int e = 0; e < 4; ++e) { s1[e] += rr[e]; s2[e] += rr[e] * rr[e]; }
       }
@@ -1360,8 +1360,8 @@ __global__ __launch_bounds__(256) void conv9_rgb_kernel(const float* __restrict_
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = acc[cb][e] + (bias ? bias[lq * 8 + cb * 4 + e] : 0.f);
         o[cb].x = pack_bf16x2(v[0], v[1]); o[cb].y = pack_bf16x2(v[2], v[3]);
-        const float r[4] = {__uint_as_float(o[cb].x << 16), __uint_as_float(o[cb].x & 0xffff0000u), __uint_as_float(o[cb].y << 16),
-                            __uint_as_float(o[cb].y & 0xffff0000u)};
+        float r[4];
+        spb_unpack2(o[cb].x, r[0], r[1]); spb_unpack2(o[cb].y, r[2], r[3]);   // (16-bit storage format: common.h)
 #pragma unroll
         for (int e = 0; e < 4; ++e) { s1[cb][e] += r[e]; s2[cb][e] += r[e] * r[e]; }
       }

@@ -318,7 +318,8 @@ __global__ __launch_bounds__(256, GW_OCC3 ? 3 : 2) void gconv_wide_kernel(const 
           const unsigned w4[4] = {o.x, o.y, o.z, o.w};
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
-            const spb_f32x2 x = {__uint_as_float(w4[j] << 16), __uint_as_float(w4[j] & 0xffff0000u)};
+            float xlo, xhi; spb_unpack2(w4[j], xlo, xhi);
+            const spb_f32x2 x = {xlo, xhi};
             s1p[j] += x;
             s2p[j] += x * x;
           }

@@ -46,7 +46,7 @@ def _phase_weights(w):
             for r in rows:
                 taps += list(split(r, 2, px))          # (ty, tx) order, each [Cout, Cin]
             out.append(torch.stack(taps, dim=1))       # [Cout, 4, Cin]
-    return torch.stack(out).to(torch.bfloat16).contiguous()
+    return torch.stack(out).contiguous()           # (float32: the caller rounds to its 16-bit storage format)
 
 
 class _Conv(nn.Module):
@@ -93,12 +93,15 @@ class Ghiasi(nn.Module):
     returns the sigmoid image like ghiasi.py:125-135, computed by the HIP kernels."""
 
     def __init__(self, precision="bf16"):
-        """precision "bf16" (default): the matrix-core kernels; "fp32": the reference-precision mode -- the reference runs the decoder outside
-        autocast in float32 (trainer.py:68-69) -- float32 tensors and arithmetic through csrc/ghiasi_f32.hip, ~30x slower, for parity work"""
+        """precision "bf16" (default): the matrix-core kernels; "fp16" (round 6): the same kernels in IEEE half (libspb_hip_f16.so: half
+        storage, v_mfma_f32_16x16x32_f16, f32 accumulation and statistics) -- same speed, eight times finer rounding, the closest a
+        matrix-core path gets to the reference, which runs the decoder outside autocast in float32 (trainer.py:68-69); "fp32": float32
+        tensors and arithmetic through csrc/ghiasi_f32.hip, ~30x slower, for parity work"""
         super().__init__()
-        if precision not in ("bf16", "fp32"):
-            raise ValueError("precision must be bf16 or fp32, got %r" % (precision,))
+        if precision not in ("bf16", "fp16", "fp32"):
+            raise ValueError("precision must be bf16, fp16 or fp32, got %r" % (precision,))
         self.precision = precision
+        self._dt16 = torch.float16 if precision == "fp16" else torch.bfloat16
         self.layers = nn.ModuleList([
             _ConvInRelu(3, 32, 9), _ConvInRelu(32, 64, 3), _ConvInRelu(64, 128, 3),
             _ResidualBlock(128), _ResidualBlock(128), _ResidualBlock(128), _ResidualBlock(128), _ResidualBlock(128),
@@ -107,6 +110,9 @@ class Ghiasi(nn.Module):
         self._packed = None
         self._ws = {}
         self.profile = None   # set to a list to collect (label, cuda event) marks of one forward (scratch/bench_ghiasi.py)
+
+    def _lib(self):
+        return L.lib_f16() if self.precision == "fp16" else L.lib()
 
     def _mark(self, label):
         if self.profile is not None:
@@ -130,13 +136,13 @@ class Ghiasi(nn.Module):
                     elif i == 0:
                         convs[(i, name)] = (c.weight.detach().float().contiguous(), c.bias.detach().float().contiguous())
                     else:
-                        w = c.weight.detach().permute(0, 2, 3, 1).contiguous().to(torch.bfloat16)
+                        w = c.weight.detach().permute(0, 2, 3, 1).contiguous().to(self._dt16)
                         convs[(i, name)] = (w, c.bias.detach().float().contiguous())
                         if isinstance(layer, _UpsampleConvInRelu) and tuple(c.weight.shape[2:]) == (3, 3):
-                            convs[(i, name, "up2")] = _phase_weights(c.weight.detach().float())
+                            convs[(i, name, "up2")] = _phase_weights(c.weight.detach().float()).to(self._dt16)
                         if isinstance(layer, _ResidualBlock) and tuple(w.shape) == (128, 3, 3, 128):
                             wp = torch.empty_like(w)      # one 8 KB LDS image per reduction step (spb_gconv_wide_pack)
-                            L.check(L.lib().spb_gconv_wide_pack(_p(w), _p(wp), _stream()), "spb_gconv_wide_pack")
+                            L.check(self._lib().spb_gconv_wide_pack(_p(w), _p(wp), _stream()), "spb_gconv_wide_pack")
                             convs[(i, name, "wide")] = wp
             for name in ("fc_beta", "fc_gamma", "fc_beta1", "fc_gamma1", "fc_beta2", "fc_gamma2"):
                 if hasattr(layer, name):
@@ -166,7 +172,7 @@ class Ghiasi(nn.Module):
 
     @torch.no_grad()
     def forward(self, x, styles):
-        lib = L.lib()
+        lib = self._lib()
         if not (x.is_cuda and styles.is_cuda):
             raise RuntimeError("Ghiasi.forward needs cuda tensors (no CPU path)")
         if self._packed is None:
@@ -178,7 +184,7 @@ class Ghiasi(nn.Module):
         dev = x.device
         x = x.contiguous().float()
         styles = styles.contiguous().float()
-        bf = torch.bfloat16
+        bf = self._dt16
         st = _stream()
         fc = self._buf("fc", (B, pk["n"]), torch.float32, dev)
         L.check(lib.spb_style_fc(_p(styles), _p(pk["fcw"]), _p(pk["fcb"]), _p(fc), B, pk["n"], st), "spb_style_fc")

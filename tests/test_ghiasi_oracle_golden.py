@@ -82,7 +82,8 @@ def test_upsample_conv_phase_weights_identity():
     w = torch.randn(6, 8, 3, 3)
     x = torch.randn(2, 8, 5, 7, dtype=torch.float64)
     wp = _phase_weights(w)
-    assert tuple(wp.shape) == (4, 6, 4, 8) and wp.dtype == torch.bfloat16
+    assert tuple(wp.shape) == (4, 6, 4, 8) and wp.dtype == torch.float32     # (the caller rounds to its storage format: bf16 or IEEE half)
+    wp = wp.to(torch.bfloat16)
     ref = F.conv2d(F.pad(F.interpolate(x, scale_factor=2, mode="nearest"), (1, 1, 1, 1), mode="reflect"), w.double())
     xp = F.pad(x, (1, 1, 1, 1), mode="replicate")
     out = torch.zeros_like(ref)
