@@ -217,8 +217,8 @@ def main():
 
     if args.bare:
         args.no_cpu_baseline = args.no_others = True
-    if args.precision == "fp16" and args.model not in ("spn", "krn"):
-        raise SystemExit("--precision fp16 exists for --model spn and krn (RevGrad / DANN: bf16 with f32 accumulation, DESIGN.md a13)")
+    if args.precision == "fp16" and args.model not in ("spn", "krn", "decoder"):
+        raise SystemExit("--precision fp16 exists for --model spn, krn and decoder (RevGrad / DANN: bf16 with f32 accumulation, DESIGN.md a13)")
     if args.model == "spn":
         return bench_spn(args)
     if args.model == "dann":

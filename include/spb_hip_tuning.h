@@ -19,6 +19,7 @@ int spb_debug_set_domain_tail_rows(int on); /* RevGrad forward: row-parallel Avg
 int spb_debug_set_join_fused(int on);      /* KRN plan: residual adds formed by the next expand convolution (1, default) or by bn_apply launches (0) */
 int spb_debug_set_wgrad_parts(int on);     /* KRN plan: weight gradients as partial sums + spb_partial_reduce (1, default) or f32 atomics (0) */
 int spb_debug_set_wgrad_min_flush(int n); /* fork at a depthwise backward kernel only when >= n weight gradients are queued */
+int spb_debug_set_wgrad_tile(int mode, int wide_target); /* pointwise weight gradient tiles: 0 = 64 x 64 only (default), 1 = by the count of operand re-derivations, 2..5 = force 64x64 / 64x128 / 128x64 / 128x128; wide_target > 0: workgroup target of launches with 128-wide tiles (default 384) */
 int spb_debug_set_wgrad_target(int wgs); /* pointwise weight gradient: row splits chosen for about this many workgroups per launch (every split adds N*K f32 atomics); wgs < 0: the same for the partial-sum form (default 512; every split adds an N*K slab) */
 int spb_debug_set_wgrad_batch(int n); /* pointwise weight-gradient GEMMs handed to the side stream per fork event */
 int spb_debug_set_gemm_bk64_dgrad_min_k(int k); /* backward-type small-M GEMMs with K >= k: 64x32 tiles with 64-deep chunks */

@@ -278,6 +278,7 @@ TUNING_SYMBOLS = {
     "spb_debug_set_wgrad_min_flush": (i32, [i32]),
     "spb_debug_set_wgrad_batch": (i32, [i32]),
     "spb_debug_set_wgrad_target": (i32, [i32]),
+    "spb_debug_set_wgrad_tile": (i32, [i32, i32]),
     "spb_debug_set_gemm_bk64_dgrad_min_k": (i32, [i32]),
     "spb_debug_set_replica_rows": (i32, [i64]),
     "spb_debug_set_dw_xcd": (i32, [i32]),

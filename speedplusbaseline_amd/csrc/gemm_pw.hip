@@ -687,30 +687,38 @@ int dispatch_modes(const spb_gemm_args_t& g, hipStream_t stream) {
 // weight gradient: dW[n,k] += sum_m dz[m,n] * a[m,k].  The reduction axis (m) is the slow axis of both operands,
 // so the staged row-major LDS tiles are read with the gfx950 transpose load (ds_read_b64_tr_b16): lane (i,q) of a
 // 16-lane group gets 4 consecutive m for one column, exactly the MFMA operand layout.
-constexpr int WT = 64;   // output tile (n and k)
+constexpr int WT = 64;   // base output tile (n and k): FN = FK = 2 fragments of 16 per wave, 2 x 2 waves
 constexpr int WM = 64;   // m rows per LDS stage
 
 // PART: the tile of this row split is stored (plain stores) into slab `split` of g.part ([S][N*K] f32) for spb_partial_reduce
 // instead of being added into dW with f32 atomics
 // ACTK: activation of the input-side transform -- 0 none, 1 clamp (ReLU / ReLU6), 2 generic (the runtime form costs three vector
 // instructions per element where none or one is needed, in a loop that is bound by its vector instruction count)
-template <typename T, bool PART, int ACTK = 2>
+// FN, FK (round 6): 16-wide fragments per wave along n and k; the workgroup's tile is 32 FN x 32 FK.  Every output tile re-derives its
+// operand columns (the BatchNorm-backward form of dz: two loads and three multiply-adds per element; BatchNorm + activation of the input) for
+// every row of its split, and the loop is bound by exactly that work: with 64 x 64 tiles a 960 x 160 gradient transforms 5760 elements per
+// row where 1120 are distinct.  128-wide tiles along the longer axis halve the repeats of the other operand (and the L2 / HBM re-reads).
+template <typename T, bool PART, int ACTK = 2, int FN = 2, int FK = 2>
 __global__ __launch_bounds__(256) void pw_wgrad_kernel(const spb_wgrad_args_t g, int rows_per_split) {
-  constexpr int LD = WT + 8;
+  constexpr int TN = 32 * FN, TK = 32 * FK;
+  constexpr int LDN = TN + 8, LDK = TK + 8;
+  constexpr int CVN = TN / 8, CVK = TK / 8;          // 8-column vectors per tile row
+  constexpr int RPN = 256 / CVN, RPK = 256 / CVK;    // rows one pass of the 256 threads covers
+  constexpr int PN = WM / RPN, PK = WM / RPK;        // passes per 64-row stage
   // two copies of each operand tile: the transform of stage s+1 writes the other copy while slower waves still read stage s, so ONE
   // barrier per stage is enough (with one copy a second barrier had to close every stage)
-  __shared__ __attribute__((aligned(16))) T Ds2[2][WM * LD];
-  __shared__ __attribute__((aligned(16))) T Xs2[2][WM * LD];
-  __shared__ float cz[3][WT];
-  __shared__ float ca[2][WT];
+  __shared__ __attribute__((aligned(16))) T Ds2[2][WM * LDN];
+  __shared__ __attribute__((aligned(16))) T Xs2[2][WM * LDK];
+  __shared__ float cz[3][TN];
+  __shared__ float ca[2][TK];
 
   const int M = g.M, K = g.K, N = g.N;
-  const int NT = (N + WT - 1) / WT, KT = (K + WT - 1) / WT;
+  const int NT = (N + TN - 1) / TN, KT = (K + TK - 1) / TK;
   // the NT*KT output tiles of one row split read the same rows of G and X: keep them on one XCD (one L2), back to back
   // (rocprofv3 FETCH_SIZE showed 3x the algorithmic bytes with the tiles of a split spread over the 8 XCDs)
   const int lbid = xcd_remap(blockIdx.x, gridDim.x);
   const int tile = lbid % (NT * KT), split = lbid / (NT * KT);
-  const int n0 = (tile / KT) * WT, k0 = (tile % KT) * WT;
+  const int n0 = (tile / KT) * TN, k0 = (tile % KT) * TK;
   const int mbeg = split * rows_per_split;
   const int mend = min(M, mbeg + rows_per_split);
 
@@ -718,12 +726,13 @@ __global__ __launch_bounds__(256) void pw_wgrad_kernel(const spb_wgrad_args_t g,
   const int li = l & 15, lq = l >> 4;
   const int wn = w >> 1, wk = w & 1;
 
-  if (t < WT) {
+  if (t < TN) {
     float p0 = 0.f, p1 = 0.f, p2 = 0.f;
     if (n0 + t < N) bn_bwd_coef(g.pro_dz, n0 + t, p0, p1, p2);
     cz[0][t] = p0; cz[1][t] = p1; cz[2][t] = p2;
-  } else if (t < 2 * WT) {
-    const int c = t - WT;
+  }
+  if (t >= 256 - TK) {                 // (TN + TK may be 256: the two ranges overlap in threads only when both tiles are 128 wide)
+    const int c = t - (256 - TK);
     float sc = 0.f, sh = 0.f;
     if (k0 + c < K) bn_fwd_coef(g.pro_a, k0 + c, sc, sh);
     ca[0][c] = sc; ca[1][c] = sh;
@@ -734,25 +743,30 @@ __global__ __launch_bounds__(256) void pw_wgrad_kernel(const spb_wgrad_args_t g,
   const T* Zg = reinterpret_cast<const T*>(g.Zn);
   const T* Xg = reinterpret_cast<const T*>(g.X);
 
-  f32x4_t acc[2][2];
+  f32x4_t acc[FN][FK];
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+  for (int a = 0; a < FN; ++a)
 #pragma unroll
-    for (int b = 0; b < 2; ++b) acc[a][b] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    for (int b = 0; b < FK; ++b) acc[a][b] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
   const size_t ldg = g.ldg > 0 ? g.ldg : N, ldx = g.ldx > 0 ? g.ldx : K;   // row strides of G (and Zn) / X
-  const int cv = t & 7, rw = t >> 3;  // rows rw, rw+32; columns cv*8..cv*8+7
-  const int nl = n0 + cv * 8, kl = k0 + cv * 8;
+  const int cvn = t % CVN, rwn = t / CVN;   // dz: rows rwn + RPN i, columns cvn*8 .. cvn*8+7
+  const int cvk = t % CVK, rwk = t / CVK;   // input: rows rwk + RPK i, columns cvk*8 .. cvk*8+7
+  const int nl = n0 + cvn * 8, kl = k0 + cvk * 8;
   const int nlc = nl < N ? nl : N - 8, klc = kl < K ? kl : K - 8;
-  Raw8<T> gr[2], zr[2], xr[2];
+  Raw8<T> gr[PN], zr[PN], xr[PK];
   // all global loads of a stage are issued together with clamped addresses; the next stage's loads are in flight
   // while the matrix cores work on the current one
 #define WG_LOAD(mb_)                                                          \
-  _Pragma("unroll") for (int i = 0; i < 2; ++i) {                             \
-    const int m = (mb_) + rw + 32 * i;                                        \
+  _Pragma("unroll") for (int i = 0; i < PN; ++i) {                            \
+    const int m = (mb_) + rwn + RPN * i;                                      \
     const size_t mc_ = (size_t)(m < mend ? m : mend - 1);                     \
     gr[i] = ldraw<T>(Gg + mc_ * ldg + nlc);                                   \
     if (Zg) zr[i] = ldraw<T>(Zg + mc_ * ldg + nlc);                           \
+  }                                                                           \
+  _Pragma("unroll") for (int i = 0; i < PK; ++i) {                            \
+    const int m = (mb_) + rwk + RPK * i;                                      \
+    const size_t mc_ = (size_t)(m < mend ? m : mend - 1);                     \
     xr[i] = ldraw<T>(Xg + mc_ * ldx + klc);                                   \
   }
   if (mbeg < mend) WG_LOAD(mbeg);
@@ -762,25 +776,24 @@ __global__ __launch_bounds__(256) void pw_wgrad_kernel(const spb_wgrad_args_t g,
   float z0[8], z1[8], z2[8], a0[8], a1[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
-    z0[j] = cz[0][cv * 8 + j]; z1[j] = cz[1][cv * 8 + j]; z2[j] = cz[2][cv * 8 + j];
-    a0[j] = ca[0][cv * 8 + j]; a1[j] = ca[1][cv * 8 + j];
+    z0[j] = cz[0][cvn * 8 + j]; z1[j] = cz[1][cvn * 8 + j]; z2[j] = cz[2][cvn * 8 + j];
+    a0[j] = ca[0][cvk * 8 + j]; a1[j] = ca[1][cvk * 8 + j];
   }
   int par = 0;
   for (int mb = mbeg; mb < mend; mb += WM, par ^= 1) {
     T* Ds = Ds2[par];
     T* Xs = Xs2[par];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int r = rw + 32 * i, m = mb + r;
-      float v[8], gg[8], zz[8], xx[8];
+    for (int i = 0; i < PN; ++i) {
+      const int r = rwn + RPN * i, m = mb + r;
+      float v[8], gg[8], zz[8];
       cvt8(gr[i], gg);
       if (Zg) cvt8(zr[i], zz);
       else {
 #pragma unroll
         for (int j = 0; j < 8; ++j) zz[j] = 0.f;
       }
-      cvt8(xr[i], xx);
-      const bool okn = (m < mend) && (nl < N), okk = (m < mend) && (kl < K);
+      const bool okn = (m < mend) && (nl < N);
       // rows past the split / columns past the matrix contribute zeros: masked on the PACKED vector (4 selects instead of 8 per operand)
 #pragma unroll
       for (int j = 0; j < 8; ++j) v[j] = gg[j] * z0[j] + zz[j] * z1[j] + z2[j];
@@ -788,12 +801,19 @@ __global__ __launch_bounds__(256) void pw_wgrad_kernel(const spb_wgrad_args_t g,
         uint4 q;
         q.x = pack_bf16x2(v[0], v[1]); q.y = pack_bf16x2(v[2], v[3]); q.z = pack_bf16x2(v[4], v[5]); q.w = pack_bf16x2(v[6], v[7]);
         if (!okn) q = make_uint4(0, 0, 0, 0);
-        *reinterpret_cast<uint4*>(Ds + r * LD + cv * 8) = q;
+        *reinterpret_cast<uint4*>(Ds + r * LDN + cvn * 8) = q;
       } else {
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = okn ? v[j] : 0.f;
-        st8<T>(Ds + r * LD + cv * 8, v);
+        st8<T>(Ds + r * LDN + cvn * 8, v);
       }
+    }
+#pragma unroll
+    for (int i = 0; i < PK; ++i) {
+      const int r = rwk + RPK * i, m = mb + r;
+      float v[8], xx[8];
+      cvt8(xr[i], xx);
+      const bool okk = (m < mend) && (kl < K);
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const float u = xx[j] * a0[j] + a1[j];
@@ -803,11 +823,11 @@ __global__ __launch_bounds__(256) void pw_wgrad_kernel(const spb_wgrad_args_t g,
         uint4 q;
         q.x = pack_bf16x2(v[0], v[1]); q.y = pack_bf16x2(v[2], v[3]); q.z = pack_bf16x2(v[4], v[5]); q.w = pack_bf16x2(v[6], v[7]);
         if (!okk) q = make_uint4(0, 0, 0, 0);
-        *reinterpret_cast<uint4*>(Xs + r * LD + cv * 8) = q;
+        *reinterpret_cast<uint4*>(Xs + r * LDK + cvk * 8) = q;
       } else {
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = okk ? v[j] : 0.f;
-        st8<T>(Xs + r * LD + cv * 8, v);
+        st8<T>(Xs + r * LDK + cvk * 8, v);
       }
     }
     lds_barrier();
@@ -815,40 +835,43 @@ __global__ __launch_bounds__(256) void pw_wgrad_kernel(const spb_wgrad_args_t g,
     if constexpr (sizeof(T) == 2) {
 #pragma unroll
       for (int mc = 0; mc < WM / 32; ++mc) {
-        bf16x8_t pf[2], qf[2];
+        bf16x8_t pf[FN], qf[FK];
+        typedef s16x4_t __attribute__((address_space(3))) * lds_v4;
+        const int row = mc * 32 + lq * 8 + (li >> 2);
 #pragma unroll
-        for (int f = 0; f < 2; ++f) {
-          const int row = mc * 32 + lq * 8 + (li >> 2);
-          const bf16_t* pa = Ds + row * LD + (wn * 2 + f) * 16 + (li & 3) * 4;
-          const bf16_t* qa = Xs + row * LD + (wk * 2 + f) * 16 + (li & 3) * 4;
-          typedef s16x4_t __attribute__((address_space(3))) * lds_v4;
-          const s16x4_t plo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(pa));
-          const s16x4_t phi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(pa + 4 * LD));
-          const s16x4_t qlo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(qa));
-          const s16x4_t qhi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(qa + 4 * LD));
-          union { struct { s16x4_t lo, hi; } s; bf16x8_t v; } up, uq;
-          up.s.lo = plo; up.s.hi = phi; uq.s.lo = qlo; uq.s.hi = qhi;
-          pf[f] = up.v; qf[f] = uq.v;
+        for (int f = 0; f < FN; ++f) {
+          const bf16_t* pa = Ds + row * LDN + (wn * FN + f) * 16 + (li & 3) * 4;
+          union { struct { s16x4_t lo, hi; } s; bf16x8_t v; } up;
+          up.s.lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(pa));
+          up.s.hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(pa + 4 * LDN));
+          pf[f] = up.v;
         }
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
+        for (int f = 0; f < FK; ++f) {
+          const bf16_t* qa = Xs + row * LDK + (wk * FK + f) * 16 + (li & 3) * 4;
+          union { struct { s16x4_t lo, hi; } s; bf16x8_t v; } uq;
+          uq.s.lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(qa));
+          uq.s.hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(qa + 4 * LDK));
+          qf[f] = uq.v;
+        }
 #pragma unroll
-          for (int b = 0; b < 2; ++b)
+        for (int a = 0; a < FN; ++a)
+#pragma unroll
+          for (int b = 0; b < FK; ++b)
             acc[a][b] = SPB_MFMA16(pf[a], qf[b], acc[a][b]);
       }
     } else {
 #pragma unroll 4
       for (int mm = 0; mm < WM / 4; ++mm) {
-        float pf[2], qf[2];
+        float pf[FN], qf[FK];
 #pragma unroll
-        for (int f = 0; f < 2; ++f) {
-          pf[f] = Ds[(mm * 4 + lq) * LD + (wn * 2 + f) * 16 + li];
-          qf[f] = Xs[(mm * 4 + lq) * LD + (wk * 2 + f) * 16 + li];
-        }
+        for (int f = 0; f < FN; ++f) pf[f] = Ds[(mm * 4 + lq) * LDN + (wn * FN + f) * 16 + li];
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
+        for (int f = 0; f < FK; ++f) qf[f] = Xs[(mm * 4 + lq) * LDK + (wk * FK + f) * 16 + li];
 #pragma unroll
-          for (int b = 0; b < 2; ++b)
+        for (int a = 0; a < FN; ++a)
+#pragma unroll
+          for (int b = 0; b < FK; ++b)
             acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(pf[a], qf[b], acc[a][b], 0, 0, 0);
       }
     }
@@ -856,13 +879,13 @@ __global__ __launch_bounds__(256) void pw_wgrad_kernel(const spb_wgrad_args_t g,
 #undef WG_LOAD
 
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+  for (int a = 0; a < FN; ++a)
 #pragma unroll
-    for (int b = 0; b < 2; ++b)
+    for (int b = 0; b < FK; ++b)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int n = n0 + (wn * 2 + a) * 16 + lq * 4 + r;
-        const int k = k0 + (wk * 2 + b) * 16 + li;
+        const int n = n0 + (wn * FN + a) * 16 + lq * 4 + r;
+        const int k = k0 + (wk * FK + b) * 16 + li;
         if (n < N && k < K) {
           if (PART) g.part[(size_t)split * N * K + (size_t)n * K + k] = acc[a][b][r];
           else SPB_ATOMIC_W(g.dW + (size_t)n * K + k, acc[a][b][r]);
@@ -885,32 +908,72 @@ long long wgrad_part_floats(int M, int K, int N) {
   return S >= 2 ? (long long)S * N * K : 0;
 }
 
+// 128-wide tiles (tuning build only, spb_debug_set_wgrad_tile): they cut the operand re-derivations by 30-60 % -- and make the STEP slower, at every
+// workgroup target (round 6, bs=48 bf16: 64 x 64 2.413-2.422 ms; tiles by cost 2.536 at 384 workgroups, 2.488 at 256, 2.457 at 192, 2.438 at 128, 2.479 at
+// 96, 2.574 at 64; 64 x 128 only 2.435, 128 x 64 only 2.436, 128 x 128 only 2.550).  The weight gradients run on the side stream beside the backward chain:
+// what they cost the step is what they take from the launch stream's kernels, and fewer, fatter workgroups (53-70 KB of LDS, 2-4x the time each) take more.
+int g_wgrad_tile_mode = 0;       // 0: 64 x 64 only; 1: by cost; 2..5: force one tile
+int g_wgrad_wide_target = 384;   // workgroup target of a launch with 128-wide tiles (their row splits issue the atomics of a whole tile each)
+
+template <typename T, int FN, int FK>
+int launch_wgrad_tile(const spb_wgrad_args_t& g, hipStream_t stream, int target) {
+  constexpr int TN = 32 * FN, TK = 32 * FK;
+  const int NT = (g.N + TN - 1) / TN, KT = (g.K + TK - 1) / TK;
+  int S = spb_ceil_div(target, NT * KT);
+  const int maxS = spb_ceil_div(g.M, 2 * WM);
+  if (S > maxS) S = maxS;
+  if (S < 1) S = 1;
+  int rps = spb_ceil_div(spb_ceil_div(g.M, S), WM) * WM;
+  S = spb_ceil_div(g.M, rps);
+  const int act = g.pro_a.act;
+  if (act == SPB_ACT_NONE) hipLaunchKernelGGL((pw_wgrad_kernel<T, false, 0, FN, FK>), dim3(NT * KT * S), dim3(256), 0, stream, g, rps);
+  else if (act == SPB_ACT_RELU || act == SPB_ACT_RELU6) hipLaunchKernelGGL((pw_wgrad_kernel<T, false, 1, FN, FK>), dim3(NT * KT * S), dim3(256), 0, stream, g, rps);
+  else hipLaunchKernelGGL((pw_wgrad_kernel<T, false, 2, FN, FK>), dim3(NT * KT * S), dim3(256), 0, stream, g, rps);
+  SPB_CHECK_LAUNCH();
+  return 0;
+}
+
 template <typename T>
 int launch_wgrad(const spb_wgrad_args_t& g, hipStream_t stream) {
   const int NT = (g.N + WT - 1) / WT, KT = (g.K + WT - 1) / WT;
   const long long NK = (long long)g.N * g.K;
   const bool part = g.part != nullptr && g.part_cap >= 2 * NK && (reinterpret_cast<uintptr_t>(g.part) & 15) == 0;
-  int S = spb_ceil_div(part ? g_wgrad_part_target : g_wgrad_target_wgs, NT * KT);
-  const int maxS = spb_ceil_div(g.M, 2 * WM);
-  if (S > maxS) S = maxS;
-  if (part && S > g.part_cap / NK) S = (int)(g.part_cap / NK);
-  if (S < 1) S = 1;
-  int rps = spb_ceil_div(spb_ceil_div(g.M, S), WM) * WM;
-  S = spb_ceil_div(g.M, rps);
   if (g.job_out) std::memset(g.job_out, 0, sizeof(*g.job_out));
-  if (part && S >= 2) {
-    hipLaunchKernelGGL((pw_wgrad_kernel<T, true>), dim3(NT * KT * S), dim3(256), 0, stream, g, rps);
-    SPB_CHECK_LAUNCH();
-    spb_red_job_t job; job.src = g.part; job.dst = g.dW; job.stride = NK; job.n = (int)NK; job.nparts = S;
-    if (g.job_out) { *g.job_out = job; return 0; }
-    return spb_partial_reduce(&job, 1, stream);
+  if (part) {
+    int S = spb_ceil_div(g_wgrad_part_target, NT * KT);
+    const int maxS = spb_ceil_div(g.M, 2 * WM);
+    if (S > maxS) S = maxS;
+    if (S > g.part_cap / NK) S = (int)(g.part_cap / NK);
+    if (S < 1) S = 1;
+    int rps = spb_ceil_div(spb_ceil_div(g.M, S), WM) * WM;
+    S = spb_ceil_div(g.M, rps);
+    if (S >= 2) {
+      hipLaunchKernelGGL((pw_wgrad_kernel<T, true>), dim3(NT * KT * S), dim3(256), 0, stream, g, rps);
+      SPB_CHECK_LAUNCH();
+      spb_red_job_t job; job.src = g.part; job.dst = g.dW; job.stride = NK; job.n = (int)NK; job.nparts = S;
+      if (g.job_out) { *g.job_out = job; return 0; }
+      return spb_partial_reduce(&job, 1, stream);
+    }
   }
-  const int act = g.pro_a.act;
-  if (act == SPB_ACT_NONE) hipLaunchKernelGGL((pw_wgrad_kernel<T, false, 0>), dim3(NT * KT * S), dim3(256), 0, stream, g, rps);
-  else if (act == SPB_ACT_RELU || act == SPB_ACT_RELU6) hipLaunchKernelGGL((pw_wgrad_kernel<T, false, 1>), dim3(NT * KT * S), dim3(256), 0, stream, g, rps);
-  else hipLaunchKernelGGL((pw_wgrad_kernel<T, false, 2>), dim3(NT * KT * S), dim3(256), 0, stream, g, rps);
-  SPB_CHECK_LAUNCH();
-  return 0;
+#ifdef SPB_TUNING
+  if constexpr (sizeof(T) == 2) {
+    if (g_wgrad_tile_mode) {
+      // elements transformed per row of the reduction: every tile re-derives its TN columns of dz (weight 2: two loads, three multiply-adds)
+      // and its TK columns of the input (weight 1); padded columns are loaded and transformed like real ones
+      auto cost = [&](int tn, int tk) { const int nt = (g.N + tn - 1) / tn, kt = (g.K + tk - 1) / tk; return (long long)nt * kt * (2 * tn + tk); };
+      const long long c[4] = {cost(64, 64), cost(64, 128), cost(128, 64), cost(128, 128)};
+      int pick = 0;
+      for (int i = 1; i < 4; ++i)
+        if (c[i] < c[pick]) pick = i;
+      if (c[pick] * 8 > c[0] * 7) pick = 0;    // a wider tile must save an eighth of the work to be worth its larger atomics footprint per split
+      if (g_wgrad_tile_mode > 1) pick = g_wgrad_tile_mode - 2;     // 2..5: force one tile (A/B)
+      if (pick == 1) return launch_wgrad_tile<T, 2, 4>(g, stream, g_wgrad_wide_target);
+      if (pick == 2) return launch_wgrad_tile<T, 4, 2>(g, stream, g_wgrad_wide_target);
+      if (pick == 3) return launch_wgrad_tile<T, 4, 4>(g, stream, g_wgrad_wide_target);
+    }
+  }
+#endif
+  return launch_wgrad_tile<T, 2, 2>(g, stream, g_wgrad_target_wgs);
 }
 
 // lane l of a wave reads 8 bytes at in + l*4 elements through the transpose load; used by the unit test that pins
@@ -980,6 +1043,11 @@ extern "C" int spb_debug_trread(const unsigned short* in4096, unsigned short* ou
 #ifdef SPB_TUNING   // tuning build only (libspb_hip_tune.so, include/spb_hip_tuning.h): the product library has no knob
 extern "C" int spb_debug_set_wgrad_target(int wgs) {   // wgs < 0: target of the partial-store form
   if (wgs < 0) g_wgrad_part_target = -wgs; else g_wgrad_target_wgs = wgs < 1 ? 1 : wgs;
+  return 0;
+}
+extern "C" int spb_debug_set_wgrad_tile(int mode, int wide_target) {   // mode 0: 64 x 64 tiles only (default), 1: by cost, 2..5: force 64x64 / 64x128 / 128x64 / 128x128
+  g_wgrad_tile_mode = mode;
+  if (wide_target > 0) g_wgrad_wide_target = wide_target;
   return 0;
 }
 #endif

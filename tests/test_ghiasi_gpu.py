@@ -181,7 +181,7 @@ def test_upsample_conv_by_phase_against_torch(device, cin, cout, hw):
     stats = torch.zeros(B, cout, 2, dtype=torch.float32, device=device)
     g = L.GconvArgs()
     xd = x.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).to(device)
-    wd = _phase_weights(w.float()).to(device)
+    wd = _phase_weights(w.float()).to(torch.bfloat16).to(device)
     assert tuple(wd.shape) == (4, cout, 4, cin)
     bd, cd = bias.to(device), coef.to(device)
     p = lambda t: C.c_void_p(t.data_ptr())

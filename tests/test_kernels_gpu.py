@@ -91,7 +91,9 @@ def _gemm_variant_tuned(request):
     L.lib().spb_debug_set_gemm_os(0 if request.param != "default" else 1, 0, 0, 0)
     L.lib().spb_debug_set_gemm_big(0 if request.param != "default" else 1, 0, 0)
     L.lib().spb_debug_set_gemm_rs(0 if request.param != "default" else 1, 0)
+    L.lib().spb_debug_set_wgrad_tile(1 if request.param == "tiled" else 0, 0)   # the weight gradient's 128-wide tiles (measured slower in the step; tuning build only)
     yield request.param
+    L.lib().spb_debug_set_wgrad_tile(0, 0)
     L.lib().spb_debug_set_gemm_dma(0)
     L.lib().spb_debug_set_gemm_sk(1, 0, 0)
     L.lib().spb_debug_set_gemm_os(1, 0, 0, 0)
@@ -175,7 +177,9 @@ def _composite(M, K, N, act1, act2, dt, seed):
                                              (2352, 160, 960, L.ACT_NONE, L.ACT_RELU6), (2352, 320, 1024, L.ACT_NONE, L.ACT_RELU),
                                              (2352, 1024, 1024, L.ACT_RELU, L.ACT_RELU), (2349, 72, 200, L.ACT_RELU6, L.ACT_LEAKY),
                                              # one-shot kernel (gemm_os.hip): 28x28 expand, ragged shapes
-                                             (37632, 32, 192, L.ACT_NONE, L.ACT_RELU6), (4100, 72, 200, L.ACT_RELU6, L.ACT_LEAKY), (4099, 40, 168, L.ACT_NONE, L.ACT_RELU)])
+                                             (37632, 32, 192, L.ACT_NONE, L.ACT_RELU6), (4100, 72, 200, L.ACT_RELU6, L.ACT_LEAKY), (4099, 40, 168, L.ACT_NONE, L.ACT_RELU),
+                                             # project convolutions, one ragged in every axis
+                                             (9408, 384, 64, L.ACT_RELU6, L.ACT_NONE), (2352, 960, 160, L.ACT_RELU6, L.ACT_NONE), (1003, 200, 40, L.ACT_RELU6, L.ACT_NONE)])
 def test_pw_gemm_bwd(device, gemm_variant, dt, M, K, N, act1, act2):
     c = _composite(M, K, N, act1, act2, dt, seed=M * 7 + N)
     dev = device

@@ -41,7 +41,7 @@ def test_twin_libraries_export_their_declared_symbols():
     from speedplusbaseline_amd import _lib
     strip = lambda t: re.sub(r"/\*.*?\*/", "", t, flags=re.S)
     knobs = set(re.findall(r"\b(spb_debug_set_[a-z0-9_]+)\s*\(", strip(open(os.path.join(ROOT, "include", "spb_hip_tuning.h")).read())))
-    assert knobs == set(_lib.TUNING_SYMBOLS.keys()) and len(knobs) == 52
+    assert knobs == set(_lib.TUNING_SYMBOLS.keys()) and len(knobs) == 53
     nm = lambda path: set(re.findall(r" T (spb_[a-z0-9_]+)", subprocess.check_output(["nm", "-D", path], text=True)))
     assert nm(_lib.LIB_TUNE_PATH) == set(_lib.SYMBOLS.keys()) | knobs
     t = _lib.lib_tune()
