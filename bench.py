@@ -591,6 +591,14 @@ def bench_dann(args):
     if world > 1:
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
     dt = float(t.item())
+    # the host's share: one step enqueued into EMPTY queues (nothing throttles the host), best of five
+    t_host = 1e9
+    for _ in range(5):
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        step(xs, ys, xt, alpha)
+        t_host = min(t_host, time.perf_counter() - t1)
+    torch.cuda.synchronize()
     # ---- instrumented pass (both passes back to back on the launch stream, HIP events around every launch): the dominant
     # kernel family of the step and its achieved HBM rate, as for the KRN line
     roofline = None
@@ -644,7 +652,8 @@ def bench_dann(args):
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
             "config": {"workload": "RevGrad (KRN + gradient-reversal domain classifier) step: bs=%d source + bs=%d target images/GPU, "
                                    "AdamW lr 1e-3 wd 0.01 + clip_grad_norm 1.0" % (B, B), "per_gpu_batch": B, "global_batch": B * world,
-                       "parallelism": "dp%d" % world, "weights": "random init", "loss_last_step": [float(v) for v in scal.cpu()]},
+                       "parallelism": "dp%d" % world, "weights": "random init", "loss_last_step": [float(v) for v in scal.cpu()],
+                       "host_enqueue_ms_per_step": round(t_host * 1e3, 4)},
             "roofline": roofline, "cpu_baseline": cpu}))
     if world > 1:
         torch.distributed.destroy_process_group()
