@@ -280,11 +280,15 @@ def test_fp16_gradient_end_to_end_and_through_its_own_forward_state(device, cond
     forced = {k: v.detach().double().cpu() for k, v in eng.activations(B).items()}
     assert next(iter(eng.activations(B).values())).dtype == torch.float16
     loss_f, g_forced, _, _ = _oracle_grad(state, x, y, forced, pred.cpu())
-    loss_0, g_free, _, _ = _oracle_grad(state, x, y)
+    loss_0, g_free, sd, names = _oracle_grad(state, x, y)
     e2e = (_cos(g_hip, g_free), float(g_hip.norm() / g_free.norm()))
     thr = (_cos(g_hip, g_forced), float(g_hip.norm() / g_forced.norm()))
+    per = _per_tensor(g_hip, g_free, sd, names)
     print("%s state, float16: loss %.5f (float64 %.5f); gradient vs float64 END TO END: cosine %.4f, norm ratio %.4f; through its own forward "
-          "state: cosine %.4f, norm ratio %.4f" % (which, float(s[0]), loss_0, e2e[0], e2e[1], thr[0], thr[1]))
+          "state: cosine %.4f, norm ratio %.4f; lowest per-tensor cosines end to end: %s"
+          % (which, float(s[0]), loss_0, e2e[0], e2e[1], thr[0], thr[1], "; ".join("%.3f %.2f %s" % t for t in per[:5])))
+    # per tensor (above 1e-3 of |g|), end to end, BOTH states: where bf16 holds 0.50 on the clean state (lowest 0.635) and nothing on the chaotic one
+    assert per[0][0] >= PER_TENSOR_FLOOR_FP16, per[:4]
     assert thr[0] >= 0.999 and 0.99 <= thr[1] <= 1.01, thr
     assert abs(float(s[0]) - loss_0) <= 0.02 * loss_0 + 1e-5
     # end to end: the well-conditioned state to 0.995; the chaotic state -- where bfloat16 gives 0.12 (test above) -- still above 0.93
@@ -348,6 +352,9 @@ def test_bf16_train_pass_tracks_float64_oracle_at_bs48(device, conditioned):
     assert cos >= 0.97 and 0.9 <= ratio <= 1.1, (cos, ratio)
     assert min(c for c, _ in single) >= 0.95 and all(0.9 <= r_ <= 1.1 for _, r_ in single), single
     assert cos_d >= 0.97 and 0.9 <= ratio_d <= 1.1, (cos_d, ratio_d)
+
+
+PER_TENSOR_FLOOR_FP16 = 0.85   # measured: lowest 0.935 (clean state, base.2.conv.0.1.bias) / 0.970 (chaotic state); float atomics: run-to-run noise in the third digit
 
 
 def _per_tensor(g, g_ref, sd, names, floor_share=1e-3):
