@@ -34,7 +34,7 @@ int spb_debug_set_fused_pw_bwd(int on); /* 0: the KRN plan never uses spb_pwconv
 int spb_debug_set_stem_mfma(int on); /* 0: bf16 stem uses the scalar kernels instead of the MFMA implicit GEMM */
 int spb_debug_set_dw_wgrad_blocks(int n); /* workgroups of the depthwise weight-gradient-only launches (A/B) */
 int spb_debug_set_side_priority(int on); /* 1: contexts created afterwards put their weight-gradient side stream at the lowest stream priority (A/B) */
-int spb_debug_set_stem_tile(int on); /* 0: the bf16 stem kernels gather their taps from global memory instead of an LDS tile (A/B) */
+int spb_debug_set_stem_tile(int on); /* 0: the bf16 stem kernels gather their taps from global memory instead of an LDS tile (A/B); 1 (default): LDS tiles, forward bands of 8 output rows; 2: bands of 4 */
 int spb_debug_set_stem_wgrad_tile(int rows); /* output rows per workgroup of the LDS-tile stem weight gradient (8 | 16; 0: gather kernel) */
 int spb_debug_set_softce_split(int min_classes); /* spb_softce / _scaled: rows of at least this many classes (default 2048) use the class-split pair of launches (8 workgroups per row) */
 int spb_debug_set_dw_tile(int min_width, int workgroups); /* bf16 depthwise forward on maps at least min_width wide: LDS-tile kernels (dwconv_tile.hip; default 28, 0 = never); workgroups per launch in the low 16 bits (0 = resident estimate); bit 16: the stride-1 input gradient too (off: measured slower) */

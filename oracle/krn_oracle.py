@@ -123,8 +123,8 @@ def param_names(sd):
 class _Net:
     momentum = BN_MOM  # class-level knob: tests set 1.0 to make running stats equal the batch statistics
     # class-level knob: emulate the bf16 storage/operand rounding points of the HIP path (straight-through in backward):
-    #   every convolution output is stored as bf16; matrix-core operands (input and weight of the stem, the 1x1 convs,
-    #   the head and the domain conv) are rounded to bf16; depthwise arithmetic stays f32 on the small maps, and on the maps
+    #   every convolution output is stored as bf16; matrix-core operands (input and weight of the 1x1 convs,
+    #   the head and the domain conv; rounds 1-5: the stem's as well) are rounded to bf16; depthwise arithmetic stays f32 on the small maps, and on the maps
     #   at least DW_TILE_MIN wide (round 4: csrc/dwconv_tile.hip, forward) the activated operand is staged as bf16 and the
     #   taps are bf16 (v_dot2c_f32_bf16, f32 accumulation); materialised tensors (skip outputs, concat) bf16.
     quant = False
@@ -147,8 +147,8 @@ class _Net:
     def conv(self, x, name, stride=1, padding=0, groups=1):
         w = self.sd[self.p + name + ".weight"]
         b = self.sd.get(self.p + name + ".bias")
-        if groups == 1:  # matrix-core layers (stem, pointwise, head, domain conv): operands rounded
-            x, w = self.q(x), self.q(w)
+        if groups == 1 and name != "base.0.0":  # matrix-core layers (pointwise, head, domain conv): operands rounded.  NOT the stem since round 6: image and
+            x, w = self.q(x), self.q(w)         # stem weights enter the matrix cores as hi + lo pairs (csrc/stem_mfma.hip), the product is exact to ~1e-5
         elif x.shape[-1] >= self.DW_TILE_MIN:  # depthwise layers of the large maps: bf16 operand tile and bf16 taps
             x, w = self.q(x), self.q(w)
         z = F.conv2d(x, w, None, stride, padding, 1, groups)

@@ -7,7 +7,13 @@
 //                  -> each lane ends up with 4 consecutive channels of one pixel: an 8-byte NHWC store, no transpose
 //   weight grad    dW[co, tap] += dz^T[co, p] * patch[p, tap]           (K = 32 pixels per step)
 //                  dz^T comes from a wave-private LDS tile via the transpose load, the patches are gathered from x
-// x is the fp32 NCHW image; it is rounded to bf16 on the fly (the reference's autocast does the same in fp16).
+// x is the fp32 NCHW image.  FORWARD (round 6): image and weights enter the matrix cores as a PAIR of 16-bit values each, hi = round16(v) and
+// lo = round16(v - hi), and the product is W_hi x_hi + W_hi x_lo + W_lo x_hi (f32 accumulation; the dropped W_lo x_lo is 2^-16 of it): the stem convolution is
+// exact to ~1e-5 instead of carrying the 2^-9 relative rounding of a bf16 image.  Why it matters: the network's INPUT is the one operand whose rounding the whole
+// network amplifies -- on the "chaotic" conditioned state of tests/test_parity_conditioned_gpu.py the float64 CPU restatement of the network with bf16 rounding at all the HIP path's
+// points has gradient cosine 0.49 to float64, and 0.90 with just the stem's operands left unrounded (scratch/bf16_state_analysis_r6.py,
+// profiles/r6_bf16_state_analysis.txt).  The kernel is bound by its bytes; the two extra MFMAs per product cost nothing measurable.  The weight gradient still
+// takes the image rounded (it only feeds the stem's own 864 weight gradients).
 #include "common.h"
 
 namespace {
@@ -19,6 +25,20 @@ __device__ __forceinline__ bf16x8_t pack8(const float v[8]) {
   u.x = pack_bf16x2(v[0], v[1]); u.y = pack_bf16x2(v[2], v[3]);
   u.z = pack_bf16x2(v[4], v[5]); u.w = pack_bf16x2(v[6], v[7]);
   return __builtin_bit_cast(bf16x8_t, u);
+}
+
+// hi / lo pair of 8 floats in the library's 16-bit format: hi = round16(v), lo = round16(v - hi)
+__device__ __forceinline__ void pack8_split(const float v[8], bf16x8_t& hi, bf16x8_t& lo) {
+  unsigned hp[4], lp[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const unsigned q = pack_bf16x2(v[2 * k], v[2 * k + 1]);
+    float a, b;
+    spb_unpack2(q, a, b);
+    hp[k] = q; lp[k] = pack_bf16x2(v[2 * k] - a, v[2 * k + 1] - b);
+  }
+  hi = __builtin_bit_cast(bf16x8_t, make_uint4(hp[0], hp[1], hp[2], hp[3]));
+  lo = __builtin_bit_cast(bf16x8_t, make_uint4(lp[0], lp[1], lp[2], lp[3]));
 }
 
 __device__ __forceinline__ bf16x8_t tr_frag(const bf16_t* tile, int LD, int c0, int li, int lq) {
@@ -39,7 +59,7 @@ __global__ __launch_bounds__(256) void stem_fwd_mfma_kernel(const float* __restr
   const long long P = (long long)B * OH * OW;
   const long long groups = (P + 15) / 16;
   // A operand: W[co = cb*16+li][tap = lq*8+e], taps >= 27 are zero
-  bf16x8_t Wa[2];
+  bf16x8_t Wa[2], Wl[2];
 #pragma unroll
   for (int cb = 0; cb < 2; ++cb) {
     float v[8];
@@ -48,7 +68,7 @@ __global__ __launch_bounds__(256) void stem_fwd_mfma_kernel(const float* __restr
       const int t = lq * 8 + e;
       v[e] = t < 27 ? w[(cb * 16 + li) * 27 + t] : 0.f;
     }
-    Wa[cb] = pack8(v);
+    pack8_split(v, Wa[cb], Wl[cb]);
   }
   // the 8 taps this lane gathers for its pixel: (ci, ky, kx) of tap lq*8+e
   int tci[8], tky[8], tkx[8];
@@ -81,12 +101,15 @@ __global__ __launch_bounds__(256) void stem_fwd_mfma_kernel(const float* __restr
   float nxt[8];
   if (gi < groups) gather(gi, nxt);
   for (; gi < groups; gi += gstride) {
-    const bf16x8_t bf = pack8(nxt);
+    bf16x8_t bf, bl;
+    pack8_split(nxt, bf, bl);
     if (gi + gstride < groups) gather(gi + gstride, nxt);   // next group's loads fly during the MFMAs / stores
     const long long p = gi * 16 + li;
 #pragma unroll
     for (int cb = 0; cb < 2; ++cb) {
       f32x4_t acc = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+      acc = SPB_MFMA16(Wl[cb], bf, acc);       // (small terms first)
+      acc = SPB_MFMA16(Wa[cb], bl, acc);
       acc = SPB_MFMA16(Wa[cb], bf, acc);
       // lane (li, lq): pixel p, channels cb*16 + lq*4 .. +3
       uint2 o;
@@ -126,16 +149,19 @@ __global__ __launch_bounds__(256) void stem_fwd_mfma_kernel(const float* __restr
 // weights), and the 8 values a lane feeds to one MFMA are ONE aligned ds_read_b128 (columns 2*ow, 2*ow+1 or 2*ow+2, 2*ow+3 of row
 // 2*oh + ky).  Four MFMAs per 16 pixels (K = 64) instead of two, no masks, no packing.  The weight rows are permuted so that a lane ends
 // up with 8 consecutive channels of its pixel: one 16-byte NHWC store, 1 KB contiguous per wave.
-constexpr int SR = 8;
+// Round 6: TWO tiles, the hi and the lo halves of the image (header); SR output rows per workgroup is a template parameter (the second tile doubles the LDS
+// of a band: 8 rows = 62 KB, 4 rows = 33 KB as before).
+template <int SR>
 __global__ __launch_bounds__(256) void stem_fwd_tile_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                             bf16_t* __restrict__ y, float* osums, int oR, int B, int H, int W,
                                                             int OH, int OW, int NG, int TW) {
-  extern __shared__ __attribute__((aligned(16))) char tile[];    // [2*SR+1][TW] x 8 bytes
+  extern __shared__ __attribute__((aligned(16))) char tile[];    // 2 x [2*SR+1][TW] x 8 bytes: hi, then lo
   __shared__ float red[4][2][32];
   const int t = threadIdx.x, lane = t & 63, li = lane & 15, lq = lane >> 4, wave = t >> 6;
   const int nbands = (OH + SR - 1) / SR;
   const int b = blockIdx.x / nbands, oh0 = (blockIdx.x % nbands) * SR;
   const int RI = 2 * SR + 1, ih0 = 2 * oh0 - 1;
+  char* tile_lo = tile + (size_t)RI * TW * 8;
   // ---- staging: task = (input row, 4-column group); the three planes' float4 of a task become four 8-byte LDS entries
   const int ncg = W >> 2, ntask = RI * ncg;
   for (int t0 = 0; t0 < ntask; t0 += 256 * 4) {
@@ -158,12 +184,17 @@ __global__ __launch_bounds__(256) void stem_fwd_tile_kernel(const float* __restr
         const float a1[4] = {v[u][1].x, v[u][1].y, v[u][1].z, v[u][1].w};
         const float a2[4] = {v[u][2].x, v[u][2].y, v[u][2].z, v[u][2].w};
         uint2* dst = reinterpret_cast<uint2*>(tile) + (size_t)r * TW + c4 * 4 + 1;
+        uint2* dlo = reinterpret_cast<uint2*>(tile_lo) + (size_t)r * TW + c4 * 4 + 1;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-          uint2 q;
+          uint2 q, ql;
           q.x = rowok ? pack_bf16x2(a0[c], a1[c]) : 0u;
           q.y = rowok ? pack_bf16x2(a2[c], 0.f) : 0u;
-          dst[c] = q;
+          float h0, h1, h2, h3;
+          spb_unpack2(q.x, h0, h1); spb_unpack2(q.y, h2, h3);
+          ql.x = rowok ? pack_bf16x2(a0[c] - h0, a1[c] - h1) : 0u;
+          ql.y = rowok ? pack_bf16x2(a2[c] - h2, 0.f) : 0u;
+          dst[c] = q; dlo[c] = ql;
         }
       }
     }
@@ -171,10 +202,11 @@ __global__ __launch_bounds__(256) void stem_fwd_tile_kernel(const float* __restr
   for (int i = t; i < RI * (TW - W); i += 256) {        // the zero columns: column 0 (iw = -1) and W+1 .. TW-1
     const int r = i / (TW - W), cc = i % (TW - W);
     reinterpret_cast<uint2*>(tile)[(size_t)r * TW + (cc == 0 ? 0 : W + cc)] = make_uint2(0u, 0u);
+    reinterpret_cast<uint2*>(tile_lo)[(size_t)r * TW + (cc == 0 ? 0 : W + cc)] = make_uint2(0u, 0u);
   }
   // ---- A operand: Wa[cb][chunk], row li of block cb = output channel (li / 4) * 8 + cb * 4 + li % 4; k group gi = chunk * 4 + lq holds
   // (ky = gi / 2, columns 2 * (gi % 2) + {0, 1}, channel 0..3); ky == 3, column 3 and channel 3 are zero weights
-  bf16x8_t Wa[2][2];
+  bf16x8_t Wa[2][2], Wl[2][2];
 #pragma unroll
   for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
@@ -188,7 +220,7 @@ __global__ __launch_bounds__(256) void stem_fwd_tile_kernel(const float* __restr
         const bool ok = ky < 3 && kx < 3 && ci < 3;
         v[e] = ok ? w[co * 27 + ci * 9 + ky * 3 + kx] : 0.f;
       }
-      Wa[cb][ch] = pack8(v);
+      pack8_split(v, Wa[cb][ch], Wl[cb][ch]);
     }
   unsigned loff[2];
 #pragma unroll
@@ -203,13 +235,21 @@ __global__ __launch_bounds__(256) void stem_fwd_tile_kernel(const float* __restr
   for (int g = wave; g < SR * NG; g += 4) {
     const int ohl = g / NG, owg = g % NG;
     const unsigned base = (unsigned)((2 * ohl * TW + 32 * owg) * 8);
-    bf16x8_t pf[2];
+    bf16x8_t pf[2], pl[2];
 #pragma unroll
-    for (int ch = 0; ch < 2; ++ch) pf[ch] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(tile + base + loff[ch]));
+    for (int ch = 0; ch < 2; ++ch) {
+      pf[ch] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(tile + base + loff[ch]));
+      pl[ch] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(tile_lo + base + loff[ch]));
+    }
     f32x4_t acc[2];
 #pragma unroll
     for (int cb = 0; cb < 2; ++cb) {
       acc[cb] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ch = 0; ch < 2; ++ch) {           // small terms first
+        acc[cb] = SPB_MFMA16(Wl[cb][ch], pf[ch], acc[cb]);
+        acc[cb] = SPB_MFMA16(Wa[cb][ch], pl[ch], acc[cb]);
+      }
       acc[cb] = SPB_MFMA16(Wa[cb][0], pf[0], acc[cb]);
       acc[cb] = SPB_MFMA16(Wa[cb][1], pf[1], acc[cb]);
     }
@@ -505,19 +545,21 @@ extern "C" int spb_debug_set_stem_grid(int fwd, int wgrad) {
 }
 #endif
 
-static int g_stem_tile = 1;
+static int g_stem_tile = 1;     // 1: LDS-tile kernels, forward with 8 output rows per workgroup (62 KB of LDS); 2: 4 rows; 0: gather kernels
 #ifdef SPB_TUNING   // tuning build only (libspb_hip_tune.so, include/spb_hip_tuning.h): the product library has no knob
 extern "C" int spb_debug_set_stem_tile(int on) { g_stem_tile = on; return 0; }
 #endif
 
 int spb_stem_fwd_mfma(const float* x, const float* w, void* y, float* osums, int oR, int B, int H, int W, hipStream_t s) {
   const int OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1;
-  {   // LDS-tile kernel: 16-byte input loads (W % 4 == 0), the band's tile within the default LDS limit
+  {   // LDS-tile kernel: 16-byte input loads (W % 4 == 0), the band's two tiles within the default LDS limit
     const int NG = (OW + 15) / 16, TW = (32 * NG + 4 > W + 2 ? 32 * NG + 4 : W + 2);
-    const size_t lds = (size_t)(2 * SR + 1) * TW * 8;
-    if (g_stem_tile && (W & 3) == 0 && lds <= 60 * 1024) {
-      const int nbands = (OH + SR - 1) / SR;
-      hipLaunchKernelGGL(stem_fwd_tile_kernel, dim3((unsigned)(B * nbands)), dim3(256), lds, s, x, w, (bf16_t*)y, osums, oR, B, H, W, OH, OW, NG, TW);
+    const int sr = g_stem_tile == 2 ? 4 : 8;      // step, A/B pairs: 8 rows 2.4238 / 2.4236 ms, 4 rows 2.4308 / 2.4243
+    const size_t lds = (size_t)2 * (2 * sr + 1) * TW * 8;
+    if (g_stem_tile && (W & 3) == 0 && lds <= 64 * 1024 - 1024) {     // (+ the kernel's 1 KB of static LDS)
+      const int nbands = (OH + sr - 1) / sr;
+      if (sr == 8) hipLaunchKernelGGL(stem_fwd_tile_kernel<8>, dim3((unsigned)(B * nbands)), dim3(256), lds, s, x, w, (bf16_t*)y, osums, oR, B, H, W, OH, OW, NG, TW);
+      else hipLaunchKernelGGL(stem_fwd_tile_kernel<4>, dim3((unsigned)(B * nbands)), dim3(256), lds, s, x, w, (bf16_t*)y, osums, oR, B, H, W, OH, OW, NG, TW);
       return 0;
     }
   }

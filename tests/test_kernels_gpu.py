@@ -586,7 +586,7 @@ def stem_variant(request):
         return
     with L.tuning():
         L.lib().spb_debug_set_stem_mfma(0 if request.param == "scalar" else 1)
-        L.lib().spb_debug_set_stem_tile(1 if request.param.startswith("tile") else 0)
+        L.lib().spb_debug_set_stem_tile((2 if request.param == "tile16" else 1) if request.param.startswith("tile") else 0)   # 2: 4-row forward bands
         L.lib().spb_debug_set_stem_wgrad_tile(16 if request.param == "tile16" else 8)   # 16 rows per workgroup: a ragged last band at 48 x 48
         yield request.param
         L.lib().spb_debug_set_stem_mfma(1)
@@ -615,6 +615,10 @@ def test_stem(device, stem_variant, dt, B, H):
     torch.cuda.synchronize()
     nhwc = lambda t: t.detach().permute(0, 2, 3, 1).contiguous()
     assert relerr(Y, nhwc(z)) < TOL[dt]
+    if dt == torch.bfloat16 and stem_variant != "scalar":
+        # round 6: image and weights enter the matrix cores as hi + lo pairs -- the stored output is the ROUNDING of the exact convolution, not the
+        # convolution of a rounded image (measured 1e-4: a few values on the other side of a rounding boundary; with rounded operands 3e-3)
+        assert relerr(Y, nhwc(zq)) < 6e-4, relerr(Y, nhwc(zq))
     ys = Y.double().cpu().view(-1, 32)
     assert relerr(osums.double().cpu().sum(0)[0], ys.sum(0)) < 1e-4
     gs = rt(nhwc(u.grad), dt).view(-1, 32)

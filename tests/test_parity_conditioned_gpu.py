@@ -10,12 +10,16 @@ What rounds 2-4 got wrong, and what was found (scratch/bf16_state_analysis.py; H
     bit-identical in every process and on every box (its sha256 is printed; the first steps are run twice here and compared).
   * The frames carried per-pixel clutter of amplitude 0.25 under the blob.  A network trained on them is CHAOTIC: on the float64 CPU
     oracle a 2^-9 relative perturbation at the 112x112 layers grows to 15-22 % in the 7x7 activations, loss spikes of several hundred
-    appear in the (deterministic, f32) training run, and the gradient of ANY bfloat16 evaluation is unrelated to the float64 one --
-    the oracle with bf16 rounding at the storage / operand points: cosine 0.58, norm ratio 0.46; PyTorch's own CPU bf16 autocast of the
-    oracle: 0.84 / 0.68; float16 rounding instead (3 more mantissa bits): 0.98 / 1.00.  The suspected |mean| >> sigma channels do not
-    exist (max |mean| / sigma over all 58 BatchNorm layers: 2.4).  With clutter 0.05 the same recipe gives a well-conditioned network
-    (no loss spike, bf16 cosine 0.99), which is the state the end-to-end bars are put on; the cluttered recipe is kept as a second
-    state for the test that does not depend on conditioning (next point).
+    appear in the (deterministic, f32) training run, and rounds 2-5 found the gradient of their bfloat16 pass unrelated to the float64 one
+    (the oracle with bf16 rounding at the storage / operand points: cosine 0.58, norm ratio 0.46; PyTorch's own CPU bf16 autocast of the
+    oracle: 0.84 / 0.68; float16 rounding instead: 0.98 / 1.00; the HIP pass anywhere between -0.16 and 0.47 depending on the order of its
+    float additions).  ROUND 6 FOUND THE CAUSE: it is the rounding of the network's INPUT.  One rounding family at a time on the oracle
+    (scratch/bf16_state_analysis_r6.py, profiles/r6_bf16_state_analysis.txt): every stored tensor and every other operand costs 0.02-0.05
+    of cosine each; the stem's operands -- the float32 image and the 864 stem weights rounded to bfloat16 -- cost more than all of them
+    together: with ONLY them left unrounded the oracle's bf16 gradient goes from cosine 0.49 to 0.90.  The stem kernels now feed image
+    and weights to the matrix cores as hi + lo pairs (csrc/stem_mfma.hip: exact to ~1e-5, +4 us), and the HIP bf16 pass on the chaotic state
+    measures 0.909 (exact accumulation) / 0.911 (float atomics), norm ratio 0.96 / 0.92 -- end to end, asserted below.  The well-conditioned
+    state (clutter 0.05: no loss spike) went from 0.9918 to 0.9945; it stays the state of the tight end-to-end bars.
   * A backward-kernel defect and forward chaos were indistinguishable in an end-to-end cosine.  They are separated now: the oracle
     takes its backward pass THROUGH THE HIP FORWARD STATE (oracle._Net.forced: the stored bf16 convolution outputs and predictions of
     the HIP pass replace its own), so the comparison holds exactly the backward kernels to float64 -- on the well-conditioned AND on the
@@ -52,6 +56,7 @@ STEPS = 2000
 TARGET_SHIFT = 0.05        # the gradient bars are taken against targets shifted by this constant (module docstring)
 N_RUNS = 8                 # identical float-atomic bf16 passes (mean and every single one are held to the bars)
 CLEAN, CLUTTERED = 0.05, 0.25     # amplitude of the per-pixel clutter under the blob (module docstring)
+CHAOTIC_E2E_COSINE = 0.80         # end-to-end bf16 gradient cosine on the chaotic state (PyTorch's CPU bf16 autocast of the oracle: 0.84; the review's bar: that - 0.05)
 NOISE_AMP = float(os.environ.get("SPB_COND_NOISE", CLEAN))    # scratch/cond_explore.py sweeps it
 
 
@@ -142,7 +147,7 @@ def conditioned(device):
 
 @pytest.fixture(scope="module")
 def conditioned_cluttered(device):
-    """the chaotic state (clutter 0.25; module docstring): only the backward-through-the-HIP-forward-state test uses it"""
+    """the chaotic state (clutter 0.25; module docstring)"""
     return _condition(device, CLUTTERED)
 
 
@@ -231,7 +236,7 @@ def _hip_grad(eng, state, x, y, device):
 def test_bf16_backward_through_its_own_forward_state_vs_float64(device, conditioned, conditioned_cluttered, which):
     """the bf16 backward kernels alone: the float64 oracle takes its backward pass through the forward state the HIP pass stored (raw
     convolution outputs of all 58 BatchNorm'd tensors + the predictions), so forward rounding -- which the chaotic state amplifies
-    beyond any bar -- is common to both sides.  Holds on every state; bars fixed."""
+    -- is common to both sides.  Holds on every state; bars fixed."""
     state, noise = (conditioned, CLEAN) if which == "clean" else (conditioned_cluttered, CLUTTERED)
     x, y = structured_batch(B, 8, noise=noise)
     y = (y + TARGET_SHIFT).clamp(0, 1.2)
@@ -257,10 +262,13 @@ def test_bf16_backward_through_its_own_forward_state_vs_float64(device, conditio
     per.sort()
     print("   eight lowest per-tensor cosines among tensors above 1e-3 of |g| (cosine, norm ratio, tensor): " + "; ".join("%.3f %.2f %s" % t for t in per[:8]))
     assert abs(float(s[0]) - loss_f) <= 1e-3 * loss_f + 1e-6          # same predictions -> same loss
-    # measured (round 5): cosine 1.0000 / ratio 1.0000 on the well-conditioned state, 1.0000 / 0.9992 on the chaotic one, where the end-to-end
-    # cosine of the same pass is 0.15; lowest per-tensor cosine 0.999
+    # measured: cosine 1.0000 / ratio 1.0000 on the well-conditioned state, 0.9998 / 0.9995 on the chaotic one; lowest per-tensor cosine 0.997
     assert cos >= 0.999 and 0.99 <= ratio <= 1.01, (cos, ratio)
     assert per[0][0] >= 0.99, per[0]
+    # the same float-atomic pass END TO END (round 6, since the stem takes image and weights unrounded: module docstring): 0.9947 / 0.998 on the
+    # well-conditioned state, 0.911 / 0.917 on the chaotic one (rounds 2-5: 0.12 ... 0.47 there)
+    e2e = (_cos(g_hip, g_free), float(g_hip.norm() / g_free.norm()))
+    assert e2e[0] >= (0.97 if which == "clean" else CHAOTIC_E2E_COSINE) and 0.8 <= e2e[1] <= 1.25, e2e
 
 
 @pytest.mark.parametrize("which", ["clean", "cluttered"])
@@ -287,12 +295,12 @@ def test_fp16_gradient_end_to_end_and_through_its_own_forward_state(device, cond
     print("%s state, float16: loss %.5f (float64 %.5f); gradient vs float64 END TO END: cosine %.4f, norm ratio %.4f; through its own forward "
           "state: cosine %.4f, norm ratio %.4f; lowest per-tensor cosines end to end: %s"
           % (which, float(s[0]), loss_0, e2e[0], e2e[1], thr[0], thr[1], "; ".join("%.3f %.2f %s" % t for t in per[:5])))
-    # per tensor (above 1e-3 of |g|), end to end, BOTH states: where bf16 holds 0.50 on the clean state (lowest 0.635) and nothing on the chaotic one
+    # per tensor (above 1e-3 of |g|), end to end, both states (bf16: 0.60 / 0.65, test below)
     assert per[0][0] >= PER_TENSOR_FLOOR_FP16, per[:4]
     assert thr[0] >= 0.999 and 0.99 <= thr[1] <= 1.01, thr
     assert abs(float(s[0]) - loss_0) <= 0.02 * loss_0 + 1e-5
-    # end to end: the well-conditioned state to 0.995; the chaotic state -- where bfloat16 gives 0.12 (test above) -- still above 0.93
-    assert e2e[0] >= (0.995 if which == "clean" else 0.93) and 0.9 <= e2e[1] <= 1.1, e2e
+    # end to end: the well-conditioned state to 0.995 (measured 0.9992); the chaotic state above 0.95 (0.9875; bfloat16: 0.91)
+    assert e2e[0] >= (0.995 if which == "clean" else 0.95) and 0.9 <= e2e[1] <= 1.1, e2e
 
 
 def test_bf16_train_pass_tracks_float64_oracle_at_bs48(device, conditioned):
@@ -354,7 +362,7 @@ def test_bf16_train_pass_tracks_float64_oracle_at_bs48(device, conditioned):
     assert cos_d >= 0.97 and 0.9 <= ratio_d <= 1.1, (cos_d, ratio_d)
 
 
-PER_TENSOR_FLOOR_FP16 = 0.85   # measured: lowest 0.935 (clean state, base.2.conv.0.1.bias) / 0.970 (chaotic state); float atomics: run-to-run noise in the third digit
+PER_TENSOR_FLOOR_FP16 = 0.88   # measured: lowest 0.969 (clean state, base.0.0.weight) / 0.974 (chaotic state); before the stem took its operands unrounded: 0.935 / 0.970
 
 
 def _per_tensor(g, g_ref, sd, names, floor_share=1e-3):
@@ -369,7 +377,8 @@ def _per_tensor(g, g_ref, sd, names, floor_share=1e-3):
 
 
 # bars of the test below; measured values in its docstring
-PER_TENSOR_FLOOR_CLEAN = 0.50
+PER_TENSOR_FLOOR_CLEAN = 0.60
+PER_TENSOR_FLOOR_CHAOTIC = 0.65
 
 
 def test_bf16_end_to_end_per_tensor_floor_and_chaotic_state_bar(device, conditioned, conditioned_cluttered):
@@ -377,19 +386,16 @@ def test_bf16_end_to_end_per_tensor_floor_and_chaotic_state_bar(device, conditio
     0.99, carried by the large tensors) while the first BatchNorm affines sat at 0.56-0.63; (2) on the chaotic state nothing was asserted
     end to end.  Both are asserted here on the EXACT-ACCUMULATION bf16 pass -- one state, one batch, one bit-reproducible gradient per
     build, so the bars carry no run-to-run noise:
-      * clean state: every tensor above 1e-3 of |g| has cosine >= PER_TENSOR_FLOOR_CLEAN to float64 (measured: lowest 0.653
-        base.2.conv.0.1.weight, then 0.695 / 0.708 / 0.733; whole gradient 0.9912 / ratio 1.022);
-      * chaotic state: NOTHING can be asserted end to end beyond a finite gradient of a sane norm, and this test is where that is
-        recorded: the same kernels on the same state and batch gave cosine 0.474 with float atomics, 0.200 with exact accumulation, and
-        -0.159 with exact accumulation after a change that only regrouped which workgroup walks which tiles of one forward kernel (the
-        f32 partial sums of the batch statistics associate differently: a 1e-7 relative change of a few BatchNorm means).  The state
-        turns that into a different gradient; PyTorch's CPU bf16 autocast of the oracle happens to land at 0.84 on it
-        (profiles/r5_bf16_state_analysis.txt), IEEE half at 0.985 (asserted in the float16 test above: eight times finer rounding is
-        what it takes).  What IS held on this state: the backward pass through the stored forward state (cosine >= 0.999, test above).
-    Round 6 on the way: (a) the expanded tensors of blocks 2-4 (96 channels at 112x112, 144 at 56x56 twice) are no longer stored or rounded
-    -- the kernels recompute them in f32 (csrc/krn_plan.hip, Runner::virt); (b) THIS test found a bug of the reproducible build: the fused
-    pointwise backward returned without folding its exact batch sums, so the depthwise backward of blocks 1-3 rebuilt dz from zero sums
-    (BatchNorm weight gradients of the first layers 8-17x too large, whole-gradient cosine 0.983 instead of 0.991; f32 unaffected)."""
+      * clean state: whole gradient >= 0.95 (measured 0.9945 / ratio 0.999); every tensor above 1e-3 of |g| >= PER_TENSOR_FLOOR_CLEAN
+        (measured: lowest 0.721 base.0.0.weight, then 0.778 / 0.805 / 0.805; before the stem took its operands unrounded: 0.635);
+      * chaotic state: whole gradient >= CHAOTIC_E2E_COSINE and norm ratio 0.8 .. 1.25 (measured 0.9087 / 0.964; float-atomic pass 0.911 /
+        0.917), every tensor >= PER_TENSOR_FLOOR_CHAOTIC (lowest 0.821 base.2.conv.3.weight).  Rounds 2-5 measured anything between -0.16
+        and 0.58 here and concluded that no bfloat16 evaluation of this state can track float64.  That was wrong: what the state amplifies
+        is the rounding of the INPUT IMAGE (and the 864 stem weights) to bfloat16 -- module docstring -- and the stem no longer rounds them.
+    History of this test: (a) round 6 first removed the rounding of the expanded tensors of blocks 2-4 (recomputed in f32, Runner::virt) --
+    no visible effect on this state; (b) the test found a bug of the reproducible build: the fused pointwise backward returned without
+    folding its exact batch sums, so the depthwise backward of blocks 1-3 rebuilt dz from zero sums (BatchNorm weight gradients of the first
+    layers 8-17x too large, whole-gradient cosine 0.983 instead of 0.991; f32 unaffected)."""
     det = KrnEngine(K, deterministic=True).attach(device, "bf16")
     out = {}
     for which, state, noise in (("clean", conditioned, CLEAN), ("cluttered", conditioned_cluttered, CLUTTERED)):
@@ -405,7 +411,8 @@ def test_bf16_end_to_end_per_tensor_floor_and_chaotic_state_bar(device, conditio
               "1e-3 of |g|): %s" % (which, out[which][0], out[which][1], "; ".join("%.3f %.2f %s" % t for t in per[:6])))
     assert out["clean"][2][0][0] >= PER_TENSOR_FLOOR_CLEAN, out["clean"][2][:4]
     assert out["clean"][0] >= 0.95
-    assert math.isfinite(out["cluttered"][0]) and 0.1 <= out["cluttered"][1] <= 10.0, out["cluttered"][:2]
+    assert out["cluttered"][0] >= CHAOTIC_E2E_COSINE and 0.8 <= out["cluttered"][1] <= 1.25, out["cluttered"][:2]
+    assert out["cluttered"][2][0][0] >= PER_TENSOR_FLOOR_CHAOTIC, out["cluttered"][2][:4]
 
 
 def test_bf16_dann_step_overlapped_streams_vs_oracle(device, conditioned_dann):
