@@ -147,8 +147,9 @@ class _Net:
     def conv(self, x, name, stride=1, padding=0, groups=1):
         w = self.sd[self.p + name + ".weight"]
         b = self.sd.get(self.p + name + ".bias")
-        if groups == 1 and name != "base.0.0":  # matrix-core layers (pointwise, head, domain conv): operands rounded.  NOT the stem since round 6: image and
-            x, w = self.q(x), self.q(w)         # stem weights enter the matrix cores as hi + lo pairs (csrc/stem_mfma.hip), the product is exact to ~1e-5
+        if groups == 1:  # matrix-core layers (pointwise, head, domain conv): operands rounded.  NOT the stem since round 6: image and stem
+            if name != "base.0.0":   # weights enter the matrix cores as hi + lo pairs (csrc/stem_mfma.hip), the product is exact to ~1e-5
+                x, w = self.q(x), self.q(w)
         elif x.shape[-1] >= self.DW_TILE_MIN:  # depthwise layers of the large maps: bf16 operand tile and bf16 taps
             x, w = self.q(x), self.q(w)
         z = F.conv2d(x, w, None, stride, padding, 1, groups)
