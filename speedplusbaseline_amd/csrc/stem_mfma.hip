@@ -149,13 +149,14 @@ __global__ __launch_bounds__(256) void stem_fwd_mfma_kernel(const float* __restr
 // weights), and the 8 values a lane feeds to one MFMA are ONE aligned ds_read_b128 (columns 2*ow, 2*ow+1 or 2*ow+2, 2*ow+3 of row
 // 2*oh + ky).  Four MFMAs per 16 pixels (K = 64) instead of two, no masks, no packing.  The weight rows are permuted so that a lane ends
 // up with 8 consecutive channels of its pixel: one 16-byte NHWC store, 1 KB contiguous per wave.
-// Round 6: TWO tiles, the hi and the lo halves of the image (header); SR output rows per workgroup is a template parameter (the second tile doubles the LDS
-// of a band: 8 rows = 62 KB, 4 rows = 33 KB as before).
+// Round 6: the image enters as hi + lo halves (header).  The hi tile's spare slot carries the low half of channel 0, a second tile of 4 bytes per column the low
+// halves of channels 1 and 2: 12 bytes per column, 46.5 KB for a band of 8 output rows -- three workgroups per CU, so the 672 workgroups of a bs=48 launch are
+// resident at once (with two full 8-byte tiles, 62 KB, the launch ran in two rounds: 41 us in the step instead of 20).
 template <int SR>
 __global__ __launch_bounds__(256) void stem_fwd_tile_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                             bf16_t* __restrict__ y, float* osums, int oR, int B, int H, int W,
                                                             int OH, int OW, int NG, int TW) {
-  extern __shared__ __attribute__((aligned(16))) char tile[];    // 2 x [2*SR+1][TW] x 8 bytes: hi, then lo
+  extern __shared__ __attribute__((aligned(16))) char tile[];    // [2*SR+1][TW] x 8 bytes (c0h, c1h, c2h, c0l), then [2*SR+1][TW] x 4 bytes (c1l, c2l)
   __shared__ float red[4][2][32];
   const int t = threadIdx.x, lane = t & 63, li = lane & 15, lq = lane >> 4, wave = t >> 6;
   const int nbands = (OH + SR - 1) / SR;
@@ -184,17 +185,20 @@ __global__ __launch_bounds__(256) void stem_fwd_tile_kernel(const float* __restr
         const float a1[4] = {v[u][1].x, v[u][1].y, v[u][1].z, v[u][1].w};
         const float a2[4] = {v[u][2].x, v[u][2].y, v[u][2].z, v[u][2].w};
         uint2* dst = reinterpret_cast<uint2*>(tile) + (size_t)r * TW + c4 * 4 + 1;
-        uint2* dlo = reinterpret_cast<uint2*>(tile_lo) + (size_t)r * TW + c4 * 4 + 1;
+        unsigned* dlo = reinterpret_cast<unsigned*>(tile_lo) + (size_t)r * TW + c4 * 4 + 1;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-          uint2 q, ql;
-          q.x = rowok ? pack_bf16x2(a0[c], a1[c]) : 0u;
-          q.y = rowok ? pack_bf16x2(a2[c], 0.f) : 0u;
+          // hi entry: the three channels rounded, and in the slot that used to be zero the LOW half of channel 0 (it rides along in the hi
+          // products: its weight row repeats channel 0's); lo entry: the low halves of channels 1 and 2
+          uint2 q;
+          q.x = pack_bf16x2(a0[c], a1[c]);
           float h0, h1, h2, h3;
-          spb_unpack2(q.x, h0, h1); spb_unpack2(q.y, h2, h3);
-          ql.x = rowok ? pack_bf16x2(a0[c] - h0, a1[c] - h1) : 0u;
-          ql.y = rowok ? pack_bf16x2(a2[c] - h2, 0.f) : 0u;
-          dst[c] = q; dlo[c] = ql;
+          spb_unpack2(q.x, h0, h1);
+          q.y = pack_bf16x2(a2[c], a0[c] - h0);
+          spb_unpack2(q.y, h2, h3);
+          const unsigned ql = pack_bf16x2(a1[c] - h1, a2[c] - h2);
+          dst[c] = rowok ? q : make_uint2(0u, 0u);
+          dlo[c] = rowok ? ql : 0u;
         }
       }
     }
@@ -202,32 +206,49 @@ __global__ __launch_bounds__(256) void stem_fwd_tile_kernel(const float* __restr
   for (int i = t; i < RI * (TW - W); i += 256) {        // the zero columns: column 0 (iw = -1) and W+1 .. TW-1
     const int r = i / (TW - W), cc = i % (TW - W);
     reinterpret_cast<uint2*>(tile)[(size_t)r * TW + (cc == 0 ? 0 : W + cc)] = make_uint2(0u, 0u);
-    reinterpret_cast<uint2*>(tile_lo)[(size_t)r * TW + (cc == 0 ? 0 : W + cc)] = make_uint2(0u, 0u);
+    reinterpret_cast<unsigned*>(tile_lo)[(size_t)r * TW + (cc == 0 ? 0 : W + cc)] = 0u;
   }
   // ---- A operand: Wa[cb][chunk], row li of block cb = output channel (li / 4) * 8 + cb * 4 + li % 4; k group gi = chunk * 4 + lq holds
-  // (ky = gi / 2, columns 2 * (gi % 2) + {0, 1}, channel 0..3); ky == 3, column 3 and channel 3 are zero weights
-  bf16x8_t Wa[2][2], Wl[2][2];
+  // (ky = gi / 2, columns 2 * (gi % 2) + {0, 1}, slots 0..3 = channels 0, 1, 2 and the low half of channel 0); ky == 3 and column 3 are zero weights.
+  // Wa: hi halves of the weights (slot 3 repeats channel 0's); Wl: their lo halves against the hi image (slot 3 zero);
+  // Wr[cb]: the hi weights against the low halves of channels 1, 2 -- ONE 32-deep step: k group lq = kernel row ky (3: zero), e = (kx = e / 2, channel 1 + e % 2)
+  bf16x8_t Wa[2][2], Wl[2][2], Wr[2];
 #pragma unroll
-  for (int cb = 0; cb < 2; ++cb)
+  for (int cb = 0; cb < 2; ++cb) {
+    const int co = (li >> 2) * 8 + cb * 4 + (li & 3);
 #pragma unroll
     for (int ch = 0; ch < 2; ++ch) {
-      const int co = (li >> 2) * 8 + cb * 4 + (li & 3);
       const int gi = ch * 4 + lq, ky = gi >> 1;
-      float v[8];
+      float v[8], vl[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const int kx = 2 * (gi & 1) + (e >> 2), ci = e & 3;
-        const bool ok = ky < 3 && kx < 3 && ci < 3;
-        v[e] = ok ? w[co * 27 + ci * 9 + ky * 3 + kx] : 0.f;
+        const bool ok = ky < 3 && kx < 3;
+        v[e] = ok ? w[co * 27 + (ci == 3 ? 0 : ci) * 9 + ky * 3 + kx] : 0.f;
       }
-      pack8_split(v, Wa[cb][ch], Wl[cb][ch]);
+      bf16x8_t lo_all;
+      pack8_split(v, Wa[cb][ch], lo_all);
+      // the lo weights see only the hi image: slot 3 (the image's low half of channel 0) gets a zero weight there
+#pragma unroll
+      for (int e = 0; e < 8; ++e) vl[e] = (e & 3) == 3 ? 0.f : v[e];
+      bf16x8_t hi_unused;
+      pack8_split(vl, hi_unused, Wl[cb][ch]);
     }
+    float vr[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int kx = e >> 1, ci = 1 + (e & 1);
+      vr[e] = (lq < 3 && kx < 3) ? w[co * 27 + ci * 9 + lq * 3 + kx] : 0.f;
+    }
+    Wr[cb] = pack8(vr);
+  }
   unsigned loff[2];
 #pragma unroll
   for (int ch = 0; ch < 2; ++ch) {
     const int gi = ch * 4 + lq, ky = gi >> 1 < 3 ? gi >> 1 : 2;
     loff[ch] = (unsigned)((ky * TW + 2 * li + 2 * (gi & 1)) * 8);
   }
+  const unsigned roff = (unsigned)(((lq < 3 ? lq : 2) * TW + 2 * li) * 4);      // lo tile: kernel row lq, columns 2 li .. 2 li + 3
   float s1[8], s2[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
@@ -235,21 +256,19 @@ __global__ __launch_bounds__(256) void stem_fwd_tile_kernel(const float* __restr
   for (int g = wave; g < SR * NG; g += 4) {
     const int ohl = g / NG, owg = g % NG;
     const unsigned base = (unsigned)((2 * ohl * TW + 32 * owg) * 8);
-    bf16x8_t pf[2], pl[2];
+    bf16x8_t pf[2];
 #pragma unroll
-    for (int ch = 0; ch < 2; ++ch) {
-      pf[ch] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(tile + base + loff[ch]));
-      pl[ch] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(tile_lo + base + loff[ch]));
-    }
+    for (int ch = 0; ch < 2; ++ch) pf[ch] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(tile + base + loff[ch]));
+    const char* lp = tile_lo + (base >> 1) + roff;
+    const uint2 r0 = *reinterpret_cast<const uint2*>(lp), r1 = *reinterpret_cast<const uint2*>(lp + 8);
+    const bf16x8_t pr = __builtin_bit_cast(bf16x8_t, make_uint4(r0.x, r0.y, r1.x, r1.y));
     f32x4_t acc[2];
 #pragma unroll
     for (int cb = 0; cb < 2; ++cb) {
       acc[cb] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int ch = 0; ch < 2; ++ch) {           // small terms first
-        acc[cb] = SPB_MFMA16(Wl[cb][ch], pf[ch], acc[cb]);
-        acc[cb] = SPB_MFMA16(Wa[cb][ch], pl[ch], acc[cb]);
-      }
+      acc[cb] = SPB_MFMA16(Wr[cb], pr, acc[cb]);            // small terms first
+      acc[cb] = SPB_MFMA16(Wl[cb][0], pf[0], acc[cb]);
+      acc[cb] = SPB_MFMA16(Wl[cb][1], pf[1], acc[cb]);
       acc[cb] = SPB_MFMA16(Wa[cb][0], pf[0], acc[cb]);
       acc[cb] = SPB_MFMA16(Wa[cb][1], pf[1], acc[cb]);
     }
@@ -545,7 +564,7 @@ extern "C" int spb_debug_set_stem_grid(int fwd, int wgrad) {
 }
 #endif
 
-static int g_stem_tile = 1;     // 1: LDS-tile kernels, forward with 8 output rows per workgroup (62 KB of LDS); 2: 4 rows; 0: gather kernels
+static int g_stem_tile = 1;     // 1: LDS-tile kernels, forward with 8 output rows per workgroup (46.5 KB of LDS); 2: 4 rows; 0: gather kernels
 #ifdef SPB_TUNING   // tuning build only (libspb_hip_tune.so, include/spb_hip_tuning.h): the product library has no knob
 extern "C" int spb_debug_set_stem_tile(int on) { g_stem_tile = on; return 0; }
 #endif
@@ -554,12 +573,13 @@ int spb_stem_fwd_mfma(const float* x, const float* w, void* y, float* osums, int
   const int OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1;
   {   // LDS-tile kernel: 16-byte input loads (W % 4 == 0), the band's two tiles within the default LDS limit
     const int NG = (OW + 15) / 16, TW = (32 * NG + 4 > W + 2 ? 32 * NG + 4 : W + 2);
-    const int sr = g_stem_tile == 2 ? 4 : 8;      // step, A/B pairs: 8 rows 2.4238 / 2.4236 ms, 4 rows 2.4308 / 2.4243
-    const size_t lds = (size_t)2 * (2 * sr + 1) * TW * 8;
+    const int sr = g_stem_tile == 2 ? 4 : 8;      // step, A/B pairs: 8 rows 2.421 / 2.415 ms, 7 rows 2.423 / 2.421, 6 rows 2.422 / 2.419, 4 rows 2.427 / 2.425
+    const size_t lds = (size_t)(2 * sr + 1) * TW * 12;          // hi tile 8 bytes per column, lo tile 4
     if (g_stem_tile && (W & 3) == 0 && lds <= 64 * 1024 - 1024) {     // (+ the kernel's 1 KB of static LDS)
       const int nbands = (OH + sr - 1) / sr;
-      if (sr == 8) hipLaunchKernelGGL(stem_fwd_tile_kernel<8>, dim3((unsigned)(B * nbands)), dim3(256), lds, s, x, w, (bf16_t*)y, osums, oR, B, H, W, OH, OW, NG, TW);
-      else hipLaunchKernelGGL(stem_fwd_tile_kernel<4>, dim3((unsigned)(B * nbands)), dim3(256), lds, s, x, w, (bf16_t*)y, osums, oR, B, H, W, OH, OW, NG, TW);
+#define SPB_STEM_FWD(SRV) hipLaunchKernelGGL(stem_fwd_tile_kernel<SRV>, dim3((unsigned)(B * nbands)), dim3(256), lds, s, x, w, (bf16_t*)y, osums, oR, B, H, W, OH, OW, NG, TW)
+      if (sr == 8) SPB_STEM_FWD(8); else SPB_STEM_FWD(4);
+#undef SPB_STEM_FWD
       return 0;
     }
   }
