@@ -181,7 +181,9 @@ int spb_dwconv_fwd(int dtype, const spb_dw_args_t* args, spb_stream_t stream);
 int spb_dwconv_dgrad(int dtype, const spb_dw_args_t* args, spb_stream_t stream);
 int spb_dwconv_wgrad(int dtype, const spb_dw_args_t* args, spb_stream_t stream);
 
-/* ---- stem: Conv2d(3,32,3,stride 2,pad 1,bias=False) on the NCHW f32 image (torchvision features[0]) -------- */
+/* ---- stem: Conv2d(3,32,3,stride 2,pad 1,bias=False) on the NCHW f32 image (torchvision features[0]) --------
+ * 16-bit modes (round 6): the forward does NOT round the image or the weights to 16 bits -- both enter the matrix cores as hi + lo pairs and the product is
+ * exact to ~1e-5; only the stored output is 16-bit.  (The rounding of the network's input was what an ill-conditioned trained state amplifies: DESIGN.md section 4.) */
 int spb_stem_fwd(int dtype, const float* x_nchw, const float* w /*[32][3][3][3]*/, void* y_nhwc, float* osums, int oR,
                  int B, int H, int W, spb_stream_t stream);
 int spb_stem_wgrad(int dtype, const float* x_nchw, const void* G, const void* Z, const spb_bnref_t* pro_dz,
