@@ -574,11 +574,13 @@ int spb_stem_fwd_mfma(const float* x, const float* w, void* y, float* osums, int
   {   // LDS-tile kernel: 16-byte input loads (W % 4 == 0), the band's two tiles within the default LDS limit
     const int NG = (OW + 15) / 16, TW = (32 * NG + 4 > W + 2 ? 32 * NG + 4 : W + 2);
     const int sr = g_stem_tile == 2 ? 4 : 8;      // step, A/B pairs: 8 rows 2.421 / 2.415 ms, 7 rows 2.423 / 2.421, 6 rows 2.422 / 2.419, 4 rows 2.427 / 2.425
-    const size_t lds = (size_t)(2 * sr + 1) * TW * 12;          // hi tile 8 bytes per column, lo tile 4
+    size_t lds = (size_t)(2 * sr + 1) * TW * 12;                // hi tile 8 bytes per column, lo tile 4
+    int srx = sr;
+    if (lds > 64 * 1024 - 1024 && sr == 8) { srx = 4; lds = (size_t)(2 * srx + 1) * TW * 12; }   // wide images (--input_shape): bands of 4 rows still fit
     if (g_stem_tile && (W & 3) == 0 && lds <= 64 * 1024 - 1024) {     // (+ the kernel's 1 KB of static LDS)
-      const int nbands = (OH + sr - 1) / sr;
+      const int nbands = (OH + srx - 1) / srx;
 #define SPB_STEM_FWD(SRV) hipLaunchKernelGGL(stem_fwd_tile_kernel<SRV>, dim3((unsigned)(B * nbands)), dim3(256), lds, s, x, w, (bf16_t*)y, osums, oR, B, H, W, OH, OW, NG, TW)
-      if (sr == 8) SPB_STEM_FWD(8); else SPB_STEM_FWD(4);
+      if (srx == 8) SPB_STEM_FWD(8); else SPB_STEM_FWD(4);
 #undef SPB_STEM_FWD
       return 0;
     }

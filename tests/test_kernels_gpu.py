@@ -595,7 +595,7 @@ def stem_variant(request):
 
 
 @pytest.mark.parametrize("dt", DTYPES)
-@pytest.mark.parametrize("B,H", [(3, 32), (2, 44), (2, 48), (1, 224)])   # 44: ragged 16-pixel groups and a ragged last band of rows
+@pytest.mark.parametrize("B,H", [(3, 32), (2, 44), (2, 48), (1, 224), (1, 448)])   # 44: ragged 16-pixel groups and a ragged last band of rows; 448: the tile of an 8-row band no longer fits, 4-row bands do
 def test_stem(device, stem_variant, dt, B, H):
     torch.manual_seed(5)
     dev = device
